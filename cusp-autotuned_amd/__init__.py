@@ -1,0 +1,29 @@
+"""cusp-autotuned_amd -- MI355X-native SpMV engine behind the CUSP API.
+
+The product is the C-ABI shared library ``lib/libcusp_mi355x.so`` (hand-written gfx950 HIP kernels,
+``include/cusp_mi355x.h``) and the header-only C++ layer ``include/cusp/`` that forwards
+``cusp::multiply`` to it.  This Python package is plumbing for tests and ``bench.py``: a ctypes
+binding of that C-ABI that takes torch tensors as device memory (``data_ptr()``) and torch's current
+HIP stream.  There is NO CPU fallback: if the library is missing or was not built, importing the
+binding raises.
+
+Import name: the directory name contains a hyphen, so the repo root ships a tiny loader module
+``cusp_autotuned_amd.py``; ``import cusp_autotuned_amd`` gives this package.
+"""
+from .binding import (  # noqa: F401
+    CmiError,
+    Config,
+    FORMAT_CSR, FORMAT_ELL, FORMAT_DIA, FORMAT_COO, FORMAT_HYB,
+    F64, F32,
+    KERNEL_AUTO, CSR_SCALAR, CSR_VECTOR, CSR_STREAM, ELL_ROW, DIA_ROW, COO_SEGMENTED,
+    lib, lib_path, build, version, check,
+    spmv_csr, spmv_ell, spmv_dia, spmv_coo, spmv_hyb,
+    tuning_select, tuning_set, tuning_load, tuning_save, tuning_clear,
+    poisson5pt_num_entries, poisson5pt_shard_entries, poisson5pt_csr, poisson5pt_dia,
+    csr_to_ell, csr_row_indices, ell_row_lengths,
+    blas_axpy, blas_axpby, blas_copy, blas_fill, blas_dot, blas_nrm2, blas_workspace,
+)
+from .matrices import (  # noqa: F401
+    CsrMatrix, CooMatrix, EllMatrix, DiaMatrix, HybMatrix, multiply, poisson5pt, convert,
+    csr_bytes, ell_bytes, dia_bytes, coo_bytes,
+)

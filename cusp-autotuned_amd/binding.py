@@ -1,0 +1,358 @@
+"""ctypes binding of include/cusp_mi355x.h.  Plumbing only: every function here forwards to the
+C-ABI symbol of the same name with raw device pointers taken from torch tensors.  No compute
+happens in Python and nothing falls back to the CPU."""
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libcusp_mi355x.so")
+_lib = None
+
+FORMAT_CSR, FORMAT_ELL, FORMAT_DIA, FORMAT_COO, FORMAT_HYB = 0, 1, 2, 3, 4
+F64, F32 = 0, 1
+KERNEL_AUTO = 0
+CSR_SCALAR, CSR_VECTOR, CSR_STREAM = 1, 2, 3
+ELL_ROW, DIA_ROW, COO_SEGMENTED = 10, 20, 30
+
+
+class CmiError(RuntimeError):
+    """A non-zero cmi_status (the C++ layer turns the same codes into cusp exceptions)."""
+
+    def __init__(self, status, message):
+        super().__init__(f"{message}")
+        self.status = status
+
+
+class Config(ctypes.Structure):
+    """struct cmi_config: kernel variant + launch shape (0 = let the tuning table decide)."""
+    _fields_ = [
+        ("kernel", c_int32), ("block_size", c_int32), ("threads_per_row", c_int32),
+        ("rows_per_block", c_int32), ("items_per_thread", c_int32), ("nontemporal", c_int32),
+        ("xcd_swizzle", c_int32), ("reserved", c_int32),
+    ]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+
+    def __repr__(self):
+        return "Config(" + ", ".join(f"{k}={v}" for k, v in self.as_dict().items()) + ")"
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def build(verbose=False):
+    """Compile the HIP library for gfx950 in-tree (make -C csrc).  hipcc cross-compiles without a GPU."""
+    out = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"], capture_output=True, text=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout)
+        print(out.stderr)
+    if out.returncode != 0:
+        raise RuntimeError("building libcusp_mi355x.so failed")
+    return _LIB_PATH
+
+
+_PI32 = POINTER(c_int32)
+
+
+def _declare(L):
+    vp, i64, i32 = c_void_p, c_int64, c_int
+    cfgp = POINTER(Config)
+    L.cmi_status_string.restype = c_char_p
+    L.cmi_status_string.argtypes = [c_int]
+    L.cmi_last_error.restype = c_char_p
+    L.cmi_version.restype = c_int
+    L.cmi_device_count.argtypes = [POINTER(c_int)]
+    L.cmi_set_device.argtypes = [c_int]
+    L.cmi_get_device.argtypes = [POINTER(c_int)]
+    L.cmi_device_info.argtypes = [c_int, c_char_p, c_size_t, POINTER(c_int), POINTER(c_int64)]
+    L.cmi_malloc.argtypes = [POINTER(c_void_p), c_size_t]
+    L.cmi_free.argtypes = [vp]
+    for n in ("cmi_memcpy_h2d", "cmi_memcpy_d2h", "cmi_memcpy_d2d"):
+        getattr(L, n).argtypes = [vp, vp, c_size_t, vp]
+    L.cmi_memset.argtypes = [vp, c_int, c_size_t, vp]
+    L.cmi_stream_create.argtypes = [POINTER(c_void_p)]
+    L.cmi_stream_destroy.argtypes = [vp]
+    L.cmi_stream_synchronize.argtypes = [vp]
+    L.cmi_event_create.argtypes = [POINTER(c_void_p)]
+    L.cmi_event_destroy.argtypes = [vp]
+    L.cmi_event_record.argtypes = [vp, vp]
+    L.cmi_event_elapsed_ms.argtypes = [vp, vp, POINTER(c_float)]
+    L.cmi_tuning_load.argtypes = [c_char_p]
+    L.cmi_tuning_save.argtypes = [c_char_p]
+    L.cmi_tuning_set.argtypes = [c_int, c_int, c_double, cfgp]
+    L.cmi_tuning_select.argtypes = [c_int, c_int, i64, i64, i64, cfgp]
+    for suf in ("f64", "f32"):
+        getattr(L, f"cmi_spmv_csr_{suf}").argtypes = [i64, i64, i64, vp, vp, vp, vp, vp, i32, cfgp, vp]
+        getattr(L, f"cmi_spmv_coo_{suf}").argtypes = [i64, i64, i64, vp, vp, vp, vp, vp, i32, cfgp, vp]
+        getattr(L, f"cmi_spmv_ell_{suf}").argtypes = [i64, i64, i64, i64, vp, vp, vp, vp, vp, i32, cfgp, vp]
+        getattr(L, f"cmi_spmv_dia_{suf}").argtypes = [i64, i64, i64, i64, vp, vp, vp, vp, i32, cfgp, vp]
+        getattr(L, f"cmi_spmv_hyb_{suf}").argtypes = [i64, i64, i64, i64, vp, vp, i64, vp, vp, vp, vp, vp, i32,
+                                                     cfgp, cfgp, vp]
+        getattr(L, f"cmi_poisson5pt_csr_{suf}").argtypes = [i64, i64, i64, i64, vp, vp, vp, vp]
+        getattr(L, f"cmi_poisson5pt_dia_{suf}").argtypes = [i64, i64, i64, vp, vp, vp]
+        getattr(L, f"cmi_csr_to_ell_{suf}").argtypes = [i64, vp, vp, vp, i64, i64, vp, vp, vp]
+    L.cmi_poisson5pt_num_entries.restype = c_int64
+    L.cmi_poisson5pt_num_entries.argtypes = [i64, i64]
+    L.cmi_poisson5pt_shard_entries.restype = c_int64
+    L.cmi_poisson5pt_shard_entries.argtypes = [i64, i64, i64, i64]
+    L.cmi_csr_row_indices.argtypes = [i64, vp, vp, vp]
+    L.cmi_ell_row_lengths.argtypes = [i64, i64, i64, vp, vp, vp]
+    L.cmi_blas_workspace_bytes.restype = c_size_t
+    L.cmi_blas_axpy_f64.argtypes = [i64, c_double, vp, vp, vp]
+    L.cmi_blas_axpby_f64.argtypes = [i64, c_double, vp, c_double, vp, vp, vp]
+    L.cmi_blas_copy_f64.argtypes = [i64, vp, vp, vp]
+    L.cmi_blas_fill_f64.argtypes = [i64, c_double, vp, vp]
+    L.cmi_blas_dot_f64.argtypes = [i64, vp, vp, vp, vp, vp]
+    L.cmi_blas_nrm2_f64.argtypes = [i64, vp, vp, vp, vp]
+
+
+def lib():
+    """The loaded C-ABI library.  Raises (loudly) when it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError(
+                f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C cusp-autotuned_amd/csrc`.  The SpMV engine has no CPU fallback.")
+        L = ctypes.CDLL(_LIB_PATH)
+        _declare(L)
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        L = lib()
+        raise CmiError(status, f"{L.cmi_status_string(status).decode()}: {L.cmi_last_error().decode()}")
+
+
+def version():
+    return lib().cmi_version()
+
+
+# ------------------------------------------------------------------------------------------------
+# tensor plumbing
+# ------------------------------------------------------------------------------------------------
+def _ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _suffix(t):
+    import torch
+    if t.dtype == torch.float64:
+        return "f64"
+    if t.dtype == torch.float32:
+        return "f32"
+    raise TypeError(f"value dtype must be float64 or float32, got {t.dtype}")
+
+
+def _stream(stream):
+    """hipStream_t of `stream` (a torch.cuda.Stream), default: torch's current stream."""
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return c_void_p(stream.cuda_stream)
+
+
+def _need(t, name, dtype=None):
+    import torch
+    if t is None:
+        return
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError(f"{name} must be a CUDA/HIP torch tensor (device memory); got {type(t).__name__}"
+                        f"{'' if not isinstance(t, torch.Tensor) else ' on ' + str(t.device)}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name} must have dtype {dtype}, got {t.dtype}")
+
+
+def _cfg(cfg):
+    return None if cfg is None else ctypes.byref(cfg)
+
+
+def spmv_csr(num_rows, num_cols, Ap, Aj, Ax, x, y, accumulate=False, cfg=None, stream=None):
+    import torch
+    for t, n in ((Ap, "Ap"), (Aj, "Aj")):
+        _need(t, n, torch.int32)
+    for t, n in ((Ax, "Ax"), (x, "x"), (y, "y")):
+        _need(t, n, y.dtype)
+    if Ap.numel() != num_rows + 1 or x.numel() != num_cols or y.numel() != num_rows or Aj.numel() != Ax.numel():
+        raise ValueError("spmv_csr: array lengths do not match the matrix shape")
+    fn = getattr(lib(), "cmi_spmv_csr_" + _suffix(y))
+    check(fn(num_rows, num_cols, Aj.numel(), _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(y), int(bool(accumulate)),
+             _cfg(cfg), _stream(stream)))
+
+
+def spmv_coo(num_rows, num_cols, Ai, Aj, Ax, x, y, accumulate=False, cfg=None, stream=None):
+    import torch
+    for t, n in ((Ai, "Ai"), (Aj, "Aj")):
+        _need(t, n, torch.int32)
+    for t, n in ((Ax, "Ax"), (x, "x"), (y, "y")):
+        _need(t, n, y.dtype)
+    if Ai.numel() != Aj.numel() or Aj.numel() != Ax.numel() or x.numel() != num_cols or y.numel() != num_rows:
+        raise ValueError("spmv_coo: array lengths do not match the matrix shape")
+    fn = getattr(lib(), "cmi_spmv_coo_" + _suffix(y))
+    check(fn(num_rows, num_cols, Ax.numel(), _ptr(Ai), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(y), int(bool(accumulate)),
+             _cfg(cfg), _stream(stream)))
+
+
+def spmv_ell(num_rows, num_cols, width, pitch, Aj, Ax, x, y, row_lengths=None, accumulate=False, cfg=None,
+             stream=None):
+    import torch
+    _need(Aj, "Aj", torch.int32)
+    _need(row_lengths, "row_lengths", torch.int32)
+    for t, n in ((Ax, "Ax"), (x, "x"), (y, "y")):
+        _need(t, n, y.dtype)
+    if Aj.numel() < width * pitch or Ax.numel() < width * pitch or x.numel() != num_cols or y.numel() != num_rows:
+        raise ValueError("spmv_ell: array lengths do not match the matrix shape")
+    fn = getattr(lib(), "cmi_spmv_ell_" + _suffix(y))
+    check(fn(num_rows, num_cols, width, pitch, _ptr(Aj), _ptr(Ax), _ptr(row_lengths), _ptr(x), _ptr(y),
+             int(bool(accumulate)), _cfg(cfg), _stream(stream)))
+
+
+def spmv_dia(num_rows, num_cols, num_diagonals, pitch, offsets, values, x, y, accumulate=False, cfg=None,
+             stream=None):
+    import torch
+    _need(offsets, "offsets", torch.int32)
+    for t, n in ((values, "values"), (x, "x"), (y, "y")):
+        _need(t, n, y.dtype)
+    if offsets.numel() != num_diagonals or values.numel() < num_diagonals * pitch or x.numel() != num_cols \
+            or y.numel() != num_rows:
+        raise ValueError("spmv_dia: array lengths do not match the matrix shape")
+    fn = getattr(lib(), "cmi_spmv_dia_" + _suffix(y))
+    check(fn(num_rows, num_cols, num_diagonals, pitch, _ptr(offsets), _ptr(values), _ptr(x), _ptr(y),
+             int(bool(accumulate)), _cfg(cfg), _stream(stream)))
+
+
+def spmv_hyb(num_rows, num_cols, width, pitch, ell_Aj, ell_Ax, coo_Ai, coo_Aj, coo_Ax, x, y, accumulate=False,
+             cfg_ell=None, cfg_coo=None, stream=None):
+    import torch
+    for t, n in ((ell_Aj, "ell_Aj"), (coo_Ai, "coo_Ai"), (coo_Aj, "coo_Aj")):
+        _need(t, n, torch.int32)
+    for t, n in ((ell_Ax, "ell_Ax"), (coo_Ax, "coo_Ax"), (x, "x"), (y, "y")):
+        _need(t, n, y.dtype)
+    fn = getattr(lib(), "cmi_spmv_hyb_" + _suffix(y))
+    check(fn(num_rows, num_cols, width, pitch, _ptr(ell_Aj), _ptr(ell_Ax), coo_Ax.numel(), _ptr(coo_Ai), _ptr(coo_Aj),
+             _ptr(coo_Ax), _ptr(x), _ptr(y), int(bool(accumulate)), _cfg(cfg_ell), _cfg(cfg_coo), _stream(stream)))
+
+
+# ------------------------------------------------------------------------------------------------
+# tuning table
+# ------------------------------------------------------------------------------------------------
+def tuning_select(fmt, dtype, num_rows, num_cols, num_entries):
+    c = Config()
+    check(lib().cmi_tuning_select(fmt, dtype, num_rows, num_cols, num_entries, ctypes.byref(c)))
+    return c
+
+
+def tuning_set(fmt, dtype, mean_entries_per_row, cfg):
+    check(lib().cmi_tuning_set(fmt, dtype, float(mean_entries_per_row), ctypes.byref(cfg)))
+
+
+def tuning_load(path):
+    check(lib().cmi_tuning_load(path.encode() if path else None))
+
+
+def tuning_save(path):
+    check(lib().cmi_tuning_save(path.encode()))
+
+
+def tuning_clear():
+    check(lib().cmi_tuning_clear())
+
+
+# ------------------------------------------------------------------------------------------------
+# on-device builders
+# ------------------------------------------------------------------------------------------------
+def poisson5pt_num_entries(m, n):
+    return int(lib().cmi_poisson5pt_num_entries(m, n))
+
+
+def poisson5pt_shard_entries(m, n, row_begin, row_end):
+    return int(lib().cmi_poisson5pt_shard_entries(m, n, row_begin, row_end))
+
+
+def poisson5pt_csr(m, n, Ap, Aj, Ax, row_begin=0, row_end=None, stream=None):
+    import torch
+    row_end = m * n if row_end is None else row_end
+    _need(Ap, "Ap", torch.int32)
+    _need(Aj, "Aj", torch.int32)
+    _need(Ax, "Ax")
+    nnz = poisson5pt_shard_entries(m, n, row_begin, row_end)
+    if Ap.numel() != row_end - row_begin + 1 or Aj.numel() < nnz or Ax.numel() < nnz:
+        raise ValueError("poisson5pt_csr: output arrays too small")
+    fn = getattr(lib(), "cmi_poisson5pt_csr_" + _suffix(Ax))
+    check(fn(m, n, row_begin, row_end, _ptr(Ap), _ptr(Aj), _ptr(Ax), _stream(stream)))
+
+
+def poisson5pt_dia(m, n, pitch, offsets, values, stream=None):
+    import torch
+    _need(offsets, "offsets", torch.int32)
+    _need(values, "values")
+    if offsets.numel() != 5 or values.numel() < 5 * pitch:
+        raise ValueError("poisson5pt_dia: output arrays too small")
+    fn = getattr(lib(), "cmi_poisson5pt_dia_" + _suffix(values))
+    check(fn(m, n, pitch, _ptr(offsets), _ptr(values), _stream(stream)))
+
+
+def csr_to_ell(num_rows, Ap, Aj, Ax, width, pitch, ell_Aj, ell_Ax, stream=None):
+    import torch
+    for t, n in ((Ap, "Ap"), (Aj, "Aj"), (ell_Aj, "ell_Aj")):
+        _need(t, n, torch.int32)
+    _need(Ax, "Ax", ell_Ax.dtype)
+    _need(ell_Ax, "ell_Ax")
+    if ell_Aj.numel() < width * pitch or ell_Ax.numel() < width * pitch:
+        raise ValueError("csr_to_ell: output arrays too small")
+    fn = getattr(lib(), "cmi_csr_to_ell_" + _suffix(ell_Ax))
+    check(fn(num_rows, _ptr(Ap), _ptr(Aj), _ptr(Ax), width, pitch, _ptr(ell_Aj), _ptr(ell_Ax), _stream(stream)))
+
+
+def csr_row_indices(num_rows, Ap, Ai, stream=None):
+    import torch
+    _need(Ap, "Ap", torch.int32)
+    _need(Ai, "Ai", torch.int32)
+    check(lib().cmi_csr_row_indices(num_rows, _ptr(Ap), _ptr(Ai), _stream(stream)))
+
+
+def ell_row_lengths(num_rows, width, pitch, ell_Aj, row_lengths, stream=None):
+    import torch
+    _need(ell_Aj, "ell_Aj", torch.int32)
+    _need(row_lengths, "row_lengths", torch.int32)
+    check(lib().cmi_ell_row_lengths(num_rows, width, pitch, _ptr(ell_Aj), _ptr(row_lengths), _stream(stream)))
+
+
+# ------------------------------------------------------------------------------------------------
+# BLAS-1 (f64)
+# ------------------------------------------------------------------------------------------------
+def blas_workspace(device="cuda"):
+    import torch
+    return torch.empty(lib().cmi_blas_workspace_bytes() // 8, dtype=torch.float64, device=device)
+
+
+def blas_axpy(alpha, x, y, stream=None):
+    check(lib().cmi_blas_axpy_f64(x.numel(), float(alpha), _ptr(x), _ptr(y), _stream(stream)))
+
+
+def blas_axpby(alpha, x, beta, y, z, stream=None):
+    check(lib().cmi_blas_axpby_f64(x.numel(), float(alpha), _ptr(x), float(beta), _ptr(y), _ptr(z), _stream(stream)))
+
+
+def blas_copy(x, y, stream=None):
+    check(lib().cmi_blas_copy_f64(x.numel(), _ptr(x), _ptr(y), _stream(stream)))
+
+
+def blas_fill(value, y, stream=None):
+    check(lib().cmi_blas_fill_f64(y.numel(), float(value), _ptr(y), _stream(stream)))
+
+
+def blas_dot(x, y, result, workspace, stream=None):
+    check(lib().cmi_blas_dot_f64(x.numel(), _ptr(x), _ptr(y), _ptr(result), _ptr(workspace), _stream(stream)))
+
+
+def blas_nrm2(x, result, workspace, stream=None):
+    check(lib().cmi_blas_nrm2_f64(x.numel(), _ptr(x), _ptr(result), _ptr(workspace), _stream(stream)))

@@ -1,0 +1,210 @@
+// builders.hip -- on-device construction of the benchmark inputs and the CSR -> {ELL, COO} layout
+// transforms, so 1e7..1e8-row matrices never pass through the host.
+//
+// Behaviour restated from the reference (integer outputs must match the host path bit-for-bit):
+//   cusp::gallery::poisson5pt            cusp/gallery/detail/poisson.inl:29-47
+//   generate_matrix_from_stencil (DIA)   cusp/gallery/detail/stencil.inl:118-134,143-188
+//   DIA -> CSR (drop zeros, row-major)   cusp/system/detail/generic/conversions/dia_to_other.h:109-163
+//   CSR -> ELL                           cusp/system/detail/generic/conversions/csr_to_other.h:155-227
+//   CSR -> COO row indices               csr_to_other.h:56-70 (offsets_to_indices)
+//   ELLR row lengths                     cusp/ktt/detail/ellr_matrix.inl:16-53
+//
+// poisson5pt(m, n): grid point (ix, iy), row r = iy*m + ix, stencil (0,-1),(-1,0),(0,0),(1,0),(0,1)
+// -> diagonal offsets [-m,-1,0,1,m], values -1,-1,4,-1,-1, a neighbour counts only if it lies inside
+// the grid.  The CSR row therefore holds, in ascending column order, {r-m | iy>0}, {r-1 | ix>0}, r,
+// {r+1 | ix<m-1}, {r+m | iy<n-1}; its offset has the closed form used below, so every lane writes
+// its row independently (no scan).
+#include "common.h"
+
+namespace cmi {
+
+// number of entries in rows [0, r) of poisson5pt(m, n)
+__host__ __device__ inline int64_t poisson_prefix(int64_t m, int64_t n, int64_t r)
+{
+    const int64_t iy = r / m, ix = r % m; // r may equal m*n (iy == n, ix == 0)
+    int64_t c = 5 * r;
+    c -= iy + (ix > 0 ? 1 : 0);              // rows before r with ix == 0      (no left neighbour)
+    c -= iy;                                 // rows before r with ix == m-1    (no right neighbour)
+    c -= iy > 0 ? m : ix;                    // rows before r with iy == 0      (no lower neighbour)
+    c -= iy >= n ? m : (iy == n - 1 ? ix : 0); // rows before r with iy == n-1  (no upper neighbour)
+    return c;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+poisson_csr_kernel(int64_t m, int64_t n, int64_t row_begin, int64_t row_end, int *__restrict__ Ap,
+                   int *__restrict__ Aj, T *__restrict__ Ax)
+{
+    const int64_t nrows = row_end - row_begin;
+    const int64_t origin = poisson_prefix(m, n, row_begin);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nrows; i += stride) {
+        const int64_t r = row_begin + i;
+        int64_t p = poisson_prefix(m, n, r) - origin;
+        Ap[i] = (int)p;
+        if (i == nrows) break;
+        const int64_t iy = r / m, ix = r % m;
+        if (iy > 0)     { Aj[p] = (int)(r - m); Ax[p] = T(-1); p++; }
+        if (ix > 0)     { Aj[p] = (int)(r - 1); Ax[p] = T(-1); p++; }
+        Aj[p] = (int)r; Ax[p] = T(4); p++;
+        if (ix < m - 1) { Aj[p] = (int)(r + 1); Ax[p] = T(-1); p++; }
+        if (iy < n - 1) { Aj[p] = (int)(r + m); Ax[p] = T(-1); p++; }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+poisson_dia_kernel(int64_t m, int64_t n, int64_t pitch, int *__restrict__ offsets, T *__restrict__ vals)
+{
+    const int64_t N = m * n;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        offsets[0] = (int)-m; offsets[1] = -1; offsets[2] = 0; offsets[3] = 1; offsets[4] = (int)m;
+    }
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < pitch; r += stride) {
+        const bool in = r < N;
+        const int64_t iy = r / m, ix = r % m;
+        vals[0 * pitch + r] = (in && iy > 0) ? T(-1) : T(0);
+        vals[1 * pitch + r] = (in && ix > 0) ? T(-1) : T(0);
+        vals[2 * pitch + r] = in ? T(4) : T(0);
+        vals[3 * pitch + r] = (in && ix < m - 1) ? T(-1) : T(0);
+        vals[4 * pitch + r] = (in && iy < n - 1) ? T(-1) : T(0);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+csr_to_ell_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ Aj,
+                  const T *__restrict__ Ax, int width, int64_t pitch, int *__restrict__ ell_Aj, T *__restrict__ ell_Ax)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pitch; i += stride) {
+        int s = 0, e = 0;
+        if (i < num_rows) { s = Ap[i]; e = Ap[i + 1]; }
+        for (int k = 0; k < width; k++) {
+            const bool have = s + k < e;
+            ell_Aj[(int64_t)k * pitch + i] = have ? Aj[s + k] : -1;
+            ell_Ax[(int64_t)k * pitch + i] = have ? Ax[s + k] : T(0);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+csr_row_indices_kernel(int64_t num_rows, const int *__restrict__ Ap, int *__restrict__ Ai)
+{
+    // a 64-lane wave per row keeps the writes coalesced for long rows; short rows cost one pass
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / kWave;
+    for (int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave; row < num_rows; row += nwaves) {
+        const int s = Ap[row], e = Ap[row + 1];
+        for (int jj = s + lane; jj < e; jj += kWave) Ai[jj] = (int)row;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+ell_row_lengths_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict__ ell_Aj,
+                       int *__restrict__ row_lengths)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows; i += stride) {
+        int len = 0;
+        while (len < width && ell_Aj[(int64_t)len * pitch + i] >= 0) len++;
+        row_lengths[i] = len;
+    }
+}
+
+static int grid_1d(int64_t n)
+{
+    int64_t b = ceil_div(n, 256);
+    if (b > kCus * 16) b = kCus * 16;
+    return b < 1 ? 1 : (int)b;
+}
+
+template <typename T>
+static int poisson_csr(int64_t m, int64_t n, int64_t rb, int64_t re, int *Ap, int *Aj, T *Ax, void *stream)
+{
+    if (m < 1 || n < 1 || rb < 0 || re < rb || re > m * n) return fail(CMI_ERROR_INVALID_VALUE, "cmi_poisson5pt_csr: bad grid or row range");
+    if (m * n > INT32_MAX || cmi_poisson5pt_shard_entries(m, n, rb, re) > INT32_MAX)
+        return fail(CMI_ERROR_INVALID_VALUE, "cmi_poisson5pt_csr: sizes exceed the int32 index type");
+    if (!Ap || (re > rb && (!Aj || !Ax))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_poisson5pt_csr: null array");
+    hipLaunchKernelGGL((poisson_csr_kernel<T>), dim3(grid_1d(re - rb + 1)), dim3(256), 0, as_stream(stream), m, n, rb, re, Ap, Aj, Ax);
+    CMI_LAUNCH_CHECK("poisson5pt csr");
+    return CMI_SUCCESS;
+}
+
+template <typename T>
+static int poisson_dia(int64_t m, int64_t n, int64_t pitch, int *offsets, T *vals, void *stream)
+{
+    if (m < 1 || n < 1 || pitch < m * n) return fail(CMI_ERROR_INVALID_VALUE, "cmi_poisson5pt_dia: bad grid or pitch");
+    if (m * n > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_poisson5pt_dia: sizes exceed the int32 index type");
+    if (!offsets || !vals) return fail(CMI_ERROR_INVALID_VALUE, "cmi_poisson5pt_dia: null array");
+    hipLaunchKernelGGL((poisson_dia_kernel<T>), dim3(grid_1d(pitch)), dim3(256), 0, as_stream(stream), m, n, pitch, offsets, vals);
+    CMI_LAUNCH_CHECK("poisson5pt dia");
+    return CMI_SUCCESS;
+}
+
+template <typename T>
+static int csr_to_ell(int64_t rows, const int *Ap, const int *Aj, const T *Ax, int64_t width, int64_t pitch,
+                      int *ell_Aj, T *ell_Ax, void *stream)
+{
+    if (rows < 0 || width < 0 || width > INT32_MAX || pitch < rows) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_to_ell: bad size");
+    if (width == 0 || pitch == 0) return CMI_SUCCESS;
+    if (!Ap || !ell_Aj || !ell_Ax) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_to_ell: null array");
+    hipLaunchKernelGGL((csr_to_ell_kernel<T>), dim3(grid_1d(pitch)), dim3(256), 0, as_stream(stream), rows, Ap, Aj, Ax, (int)width, pitch, ell_Aj, ell_Ax);
+    CMI_LAUNCH_CHECK("csr_to_ell");
+    return CMI_SUCCESS;
+}
+
+} // namespace cmi
+
+using namespace cmi;
+
+CMI_API int64_t cmi_poisson5pt_num_entries(int64_t m, int64_t n)
+{
+    if (m < 1 || n < 1) return 0;
+    return poisson_prefix(m, n, m * n);
+}
+
+CMI_API int64_t cmi_poisson5pt_shard_entries(int64_t m, int64_t n, int64_t row_begin, int64_t row_end)
+{
+    if (m < 1 || n < 1 || row_begin < 0 || row_end < row_begin || row_end > m * n) return 0;
+    return poisson_prefix(m, n, row_end) - poisson_prefix(m, n, row_begin);
+}
+
+CMI_API int cmi_poisson5pt_csr_f64(int64_t m, int64_t n, int64_t rb, int64_t re, int32_t *Ap, int32_t *Aj, double *Ax, void *stream)
+{ return poisson_csr<double>(m, n, rb, re, Ap, Aj, Ax, stream); }
+CMI_API int cmi_poisson5pt_csr_f32(int64_t m, int64_t n, int64_t rb, int64_t re, int32_t *Ap, int32_t *Aj, float *Ax, void *stream)
+{ return poisson_csr<float>(m, n, rb, re, Ap, Aj, Ax, stream); }
+CMI_API int cmi_poisson5pt_dia_f64(int64_t m, int64_t n, int64_t pitch, int32_t *offsets, double *values, void *stream)
+{ return poisson_dia<double>(m, n, pitch, offsets, values, stream); }
+CMI_API int cmi_poisson5pt_dia_f32(int64_t m, int64_t n, int64_t pitch, int32_t *offsets, float *values, void *stream)
+{ return poisson_dia<float>(m, n, pitch, offsets, values, stream); }
+
+CMI_API int cmi_csr_to_ell_f64(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, const double *Ax, int64_t width,
+                               int64_t pitch, int32_t *ell_Aj, double *ell_Ax, void *stream)
+{ return csr_to_ell<double>(num_rows, Ap, Aj, Ax, width, pitch, ell_Aj, ell_Ax, stream); }
+CMI_API int cmi_csr_to_ell_f32(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, const float *Ax, int64_t width,
+                               int64_t pitch, int32_t *ell_Aj, float *ell_Ax, void *stream)
+{ return csr_to_ell<float>(num_rows, Ap, Aj, Ax, width, pitch, ell_Aj, ell_Ax, stream); }
+
+CMI_API int cmi_csr_row_indices(int64_t num_rows, const int32_t *Ap, int32_t *Ai, void *stream)
+{
+    if (num_rows < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_row_indices: negative size");
+    if (num_rows == 0) return CMI_SUCCESS;
+    if (!Ap) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_row_indices: null array");
+    hipLaunchKernelGGL(csr_row_indices_kernel, dim3(grid_1d(num_rows * 8)), dim3(256), 0, as_stream(stream), num_rows, Ap, Ai);
+    CMI_LAUNCH_CHECK("csr_row_indices");
+    return CMI_SUCCESS;
+}
+
+CMI_API int cmi_ell_row_lengths(int64_t num_rows, int64_t width, int64_t pitch, const int32_t *ell_Aj,
+                                int32_t *row_lengths, void *stream)
+{
+    if (num_rows < 0 || width < 0 || width > INT32_MAX || (width > 0 && pitch < num_rows))
+        return fail(CMI_ERROR_INVALID_VALUE, "cmi_ell_row_lengths: bad size");
+    if (num_rows == 0) return CMI_SUCCESS;
+    if (!row_lengths || (width > 0 && !ell_Aj)) return fail(CMI_ERROR_INVALID_VALUE, "cmi_ell_row_lengths: null array");
+    hipLaunchKernelGGL(ell_row_lengths_kernel, dim3(grid_1d(num_rows)), dim3(256), 0, as_stream(stream), num_rows, (int)width, pitch, ell_Aj, row_lengths);
+    CMI_LAUNCH_CHECK("ell_row_lengths");
+    return CMI_SUCCESS;
+}

@@ -1,0 +1,77 @@
+// common.h -- shared by the HIP translation units of libcusp_mi355x.so.
+// gfx950 (MI355X, CDNA4) only: wave = 64 lanes, 256 CUs in 8 XCDs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/cusp_mi355x.h"
+
+#define CMI_API extern "C" __attribute__((visibility("default")))
+
+namespace cmi {
+
+constexpr int kWave = 64;   // CDNA wavefront
+constexpr int kXcds = 8;    // MI355X: 8 XCDs, blocks dealt round-robin over them
+constexpr int kCus  = 256;
+
+// thread-local last-error message
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+inline int fail(cmi_status st, const char *what)
+{
+    set_error("%s", what);
+    return st;
+}
+
+inline int hip_fail(hipError_t e, const char *what)
+{
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? CMI_ERROR_ALLOC : CMI_ERROR_HIP;
+}
+
+#define CMI_HIP(call)                                      \
+    do {                                                   \
+        hipError_t e__ = (call);                           \
+        if (e__ != hipSuccess) return ::cmi::hip_fail(e__, #call); \
+    } while (0)
+
+// after a kernel launch: report launch-time errors (the reference never checks)
+#define CMI_LAUNCH_CHECK(name)                             \
+    do {                                                   \
+        hipError_t e__ = hipGetLastError();                \
+        if (e__ != hipSuccess) return ::cmi::hip_fail(e__, "launch " name); \
+    } while (0)
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// tuning table lookup (tuning.hip)
+void select_config(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
+                   const cmi_config *user, cmi_config *out);
+
+// XCD-aware tile index: blocks b and b+8 share an XCD (observed round-robin placement; a
+// different placement changes speed only).  With swizzle each XCD walks a contiguous run of
+// tiles, so the x window its rows gather stays in that XCD's L2.  grid = 8*ceil(tiles/8).
+__device__ __forceinline__ int64_t tile_of_block(int64_t b, int64_t tiles_per_xcd, bool swizzle)
+{
+    return swizzle ? (b % kXcds) * tiles_per_xcd + b / kXcds : b;
+}
+
+template <typename T> struct vec2;
+template <> struct vec2<double> { typedef double __attribute__((ext_vector_type(2))) type; };
+template <> struct vec2<float>  { typedef float  __attribute__((ext_vector_type(2))) type; };
+typedef int __attribute__((ext_vector_type(4))) int4v;
+typedef int __attribute__((ext_vector_type(2))) int2v;
+typedef double __attribute__((ext_vector_type(2))) double2v;
+typedef float __attribute__((ext_vector_type(4))) float4v;
+
+template <bool NT, typename V> __device__ __forceinline__ V ld(const V *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+} // namespace cmi

@@ -1,0 +1,134 @@
+// runtime.hip -- status strings, device queries, memory, streams and events of the C-ABI.
+// This is what cusp::device_memory containers sit on (replaces thrust::device_malloc_allocator,
+// reference cusp/detail/memory.inl:28-35, and the cudaEvent timer of performance/timer.h:23-54).
+#include "common.h"
+#include <cstdarg>
+
+namespace cmi {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+} // namespace cmi
+
+using namespace cmi;
+
+CMI_API const char *cmi_status_string(int status)
+{
+    switch (status) {
+    case CMI_SUCCESS: return "CMI_SUCCESS";
+    case CMI_ERROR_INVALID_VALUE: return "CMI_ERROR_INVALID_VALUE";
+    case CMI_ERROR_HIP: return "CMI_ERROR_HIP";
+    case CMI_ERROR_NOT_SUPPORTED: return "CMI_ERROR_NOT_SUPPORTED";
+    case CMI_ERROR_NO_DEVICE: return "CMI_ERROR_NO_DEVICE";
+    case CMI_ERROR_ALLOC: return "CMI_ERROR_ALLOC";
+    case CMI_ERROR_IO: return "CMI_ERROR_IO";
+    default: return "CMI_ERROR_UNKNOWN";
+    }
+}
+
+CMI_API const char *cmi_last_error(void) { return g_err; }
+CMI_API int cmi_version(void) { return CMI_VERSION; }
+
+CMI_API int cmi_device_count(int *count)
+{
+    if (!count) return fail(CMI_ERROR_INVALID_VALUE, "cmi_device_count: null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return CMI_SUCCESS;
+}
+
+CMI_API int cmi_set_device(int device) { CMI_HIP(hipSetDevice(device)); return CMI_SUCCESS; }
+CMI_API int cmi_get_device(int *device)
+{
+    if (!device) return fail(CMI_ERROR_INVALID_VALUE, "cmi_get_device: null");
+    CMI_HIP(hipGetDevice(device));
+    return CMI_SUCCESS;
+}
+
+CMI_API int cmi_device_info(int device, char *name, size_t name_len, int *cus, int64_t *hbm_bytes)
+{
+    hipDeviceProp_t p;
+    CMI_HIP(hipGetDeviceProperties(&p, device));
+    if (name && name_len) snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+    if (cus) *cus = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+    return CMI_SUCCESS;
+}
+
+CMI_API int cmi_malloc(void **ptr, size_t bytes)
+{
+    if (!ptr) return fail(CMI_ERROR_INVALID_VALUE, "cmi_malloc: null out pointer");
+    *ptr = nullptr;
+    if (bytes == 0) return CMI_SUCCESS;
+    CMI_HIP(hipMalloc(ptr, bytes));
+    return CMI_SUCCESS;
+}
+
+CMI_API int cmi_free(void *ptr)
+{
+    if (ptr) CMI_HIP(hipFree(ptr));
+    return CMI_SUCCESS;
+}
+
+static int copy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, void *stream)
+{
+    if (bytes == 0) return CMI_SUCCESS;
+    if (!dst || !src) return fail(CMI_ERROR_INVALID_VALUE, "cmi_memcpy: null pointer");
+    CMI_HIP(hipMemcpyAsync(dst, src, bytes, kind, as_stream(stream)));
+    // host-side copies are synchronous from the caller's point of view, as Thrust's are
+    if (kind != hipMemcpyDeviceToDevice) CMI_HIP(hipStreamSynchronize(as_stream(stream)));
+    return CMI_SUCCESS;
+}
+
+CMI_API int cmi_memcpy_h2d(void *d, const void *s, size_t b, void *st) { return copy(d, s, b, hipMemcpyHostToDevice, st); }
+CMI_API int cmi_memcpy_d2h(void *d, const void *s, size_t b, void *st) { return copy(d, s, b, hipMemcpyDeviceToHost, st); }
+CMI_API int cmi_memcpy_d2d(void *d, const void *s, size_t b, void *st) { return copy(d, s, b, hipMemcpyDeviceToDevice, st); }
+
+CMI_API int cmi_memset(void *dst, int byte_value, size_t bytes, void *stream)
+{
+    if (bytes == 0) return CMI_SUCCESS;
+    if (!dst) return fail(CMI_ERROR_INVALID_VALUE, "cmi_memset: null pointer");
+    CMI_HIP(hipMemsetAsync(dst, byte_value, bytes, as_stream(stream)));
+    return CMI_SUCCESS;
+}
+
+CMI_API int cmi_stream_create(void **stream)
+{
+    if (!stream) return fail(CMI_ERROR_INVALID_VALUE, "cmi_stream_create: null");
+    hipStream_t s;
+    CMI_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return CMI_SUCCESS;
+}
+CMI_API int cmi_stream_destroy(void *stream) { CMI_HIP(hipStreamDestroy(as_stream(stream))); return CMI_SUCCESS; }
+CMI_API int cmi_stream_synchronize(void *stream) { CMI_HIP(hipStreamSynchronize(as_stream(stream))); return CMI_SUCCESS; }
+CMI_API int cmi_device_synchronize(void) { CMI_HIP(hipDeviceSynchronize()); return CMI_SUCCESS; }
+
+CMI_API int cmi_event_create(void **event)
+{
+    if (!event) return fail(CMI_ERROR_INVALID_VALUE, "cmi_event_create: null");
+    hipEvent_t e;
+    CMI_HIP(hipEventCreate(&e));
+    *event = e;
+    return CMI_SUCCESS;
+}
+CMI_API int cmi_event_destroy(void *event) { CMI_HIP(hipEventDestroy((hipEvent_t)event)); return CMI_SUCCESS; }
+CMI_API int cmi_event_record(void *event, void *stream)
+{
+    CMI_HIP(hipEventRecord((hipEvent_t)event, as_stream(stream)));
+    return CMI_SUCCESS;
+}
+CMI_API int cmi_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+    if (!ms) return fail(CMI_ERROR_INVALID_VALUE, "cmi_event_elapsed_ms: null");
+    CMI_HIP(hipEventSynchronize((hipEvent_t)stop));
+    CMI_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return CMI_SUCCESS;
+}

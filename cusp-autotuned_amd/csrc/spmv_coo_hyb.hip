@@ -1,0 +1,148 @@
+// spmv_coo_hyb.hip -- COO SpMV (and the HYB = ELL + COO composition) for gfx950.
+//
+// Replaces (reference tree): the COO flat trio cusp/system/cuda/detail/multiply/coo_flat_spmv.h:231-463 +
+// coo_serial.h:38-54 (three launches and two temporary device arrays per call), the Thrust
+// reduce_by_key fallback that device COO really runs on Thrust >= 1.9
+// (cusp/system/detail/generic/multiply/spmv.h:185-238) and the KTT coo_spmv composite
+// (cusp/system/cuda/ktt/kernels/coo_kernel.h:25-41,289-392).  HYB: generic/multiply/spmv.h:275-290.
+// Arithmetic contracts: sequential/multiply/coo_spmv.h:42-68 and hyb_spmv.h:42-57.
+//
+// Design (wave64, no scratch allocation, one launch after an optional zero-fill of y):
+//   each wave owns a contiguous interval of entries and walks it 64 entries at a time, fully
+//   coalesced (lane i reads entry base+i of Ai, Aj, Ax).  Products are combined by a segmented
+//   inclusive scan over equal adjacent row indices done with wave shuffles (6 steps for 64 lanes).
+//   The tail lane of every segment adds its sum to y[row] with a hardware float atomic
+//   (global_atomic_add_f64 / _f32), except that a segment still open at lane 63 is carried in
+//   registers into the next 64 entries, so a row costs one atomic per wave interval it touches
+//   (sorted input: ~1 per row).  Entries may come in any order; the result is then still correct
+//   (every maximal run of equal rows is one segment) but needs more atomics.
+//
+//   Summation order inside a row differs from the host loop (tree inside a wave, atomics across
+//   waves), so COO agrees with the oracle to rounding (<= 1e-6 relative is the contract), not bitwise.
+//
+// Algorithmic bytes per call (f64): 16*nnz + 16*num_rows.
+#include "common.h"
+
+namespace cmi {
+
+template <typename T> __device__ __forceinline__ void atomic_add(T *p, T v) { unsafeAtomicAdd(p, v); }
+
+template <typename T, bool NT>
+__global__ void __launch_bounds__(1024)
+coo_segmented_kernel(int64_t num_entries, const int *__restrict__ Ai, const int *__restrict__ Aj,
+                     const T *__restrict__ Ax, const T *__restrict__ x, T *__restrict__ y, int64_t interval)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    int64_t begin = wave * interval;
+    int64_t end = begin + interval < num_entries ? begin + interval : num_entries;
+    if (begin >= end) return; // whole wave exits together (begin/end are wave-uniform)
+
+    int carry_row = -1; // open segment carried from the previous 64 entries (held by every lane)
+    T carry_val = T(0);
+
+    for (int64_t base = begin; base < end; base += kWave) {
+        const int64_t e = base + lane;
+        const bool live = e < end;
+        int row = live ? ld<NT>(Ai + e) : -2; // -2: never equal to a real row or to the empty carry
+        T val = live ? ld<NT>(Ax + e) * x[ld<NT>(Aj + e)] : T(0);
+
+        // fold the carry into lane 0 if it continues the same row, else flush it
+        if (carry_row >= 0) {
+            const int row0 = __shfl(row, 0);
+            if (row0 == carry_row) { if (lane == 0) val = carry_val + val; }
+            else if (lane == 0) atomic_add(y + carry_row, carry_val);
+        }
+
+        // segmented inclusive scan over the wave; a segment = a maximal run of equal ADJACENT rows
+        // (head flags, so unsorted input -- e.g. rows 5,3,5 -- is never merged across a gap)
+        const int prev_row = __shfl_up(row, 1);
+        int head = (lane == 0 || prev_row != row) ? 1 : 0;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const T v = __shfl_up(val, o);
+            const int h = __shfl_up(head, o);
+            if (lane >= o && !head) { val = val + v; head = h; }
+        }
+
+        const int next_row = __shfl_down(row, 1);
+        const bool tail = live && (lane == kWave - 1 || next_row != row);
+        // the segment that reaches the last live lane stays open: carry it
+        const int last_lane = (int)((end - base) < kWave ? (end - base) : kWave) - 1;
+        if (tail && lane != last_lane) atomic_add(y + row, val);
+        carry_row = __shfl(row, last_lane);
+        carry_val = __shfl(val, last_lane);
+    }
+    if (lane == 0 && carry_row >= 0) atomic_add(y + carry_row, carry_val);
+}
+
+template <typename T>
+static int spmv_coo(int dtype, int64_t rows, int64_t cols, int64_t nnz, const int *Ai, const int *Aj, const T *Ax,
+                    const T *x, T *y, int accumulate, const cmi_config *user, void *stream)
+{
+    if (rows < 0 || cols < 0 || nnz < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_coo: negative size");
+    if (rows > INT32_MAX || cols > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_coo: sizes exceed the int32 index type");
+    if (rows == 0) return CMI_SUCCESS;
+    if (!y || (nnz > 0 && (!Ai || !Aj || !Ax || !x))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_coo: null array");
+    cmi_config c;
+    select_config(CMI_FORMAT_COO, dtype, rows, cols, nnz, user, &c);
+    if (c.kernel != CMI_COO_SEGMENTED) return fail(CMI_ERROR_NOT_SUPPORTED, "cmi_spmv_coo: config.kernel is not a COO kernel");
+    hipStream_t s = as_stream(stream);
+    // y = initialize(y): zero bytes are +0.0 (sequential/multiply/coo_spmv.h:56-57)
+    if (!accumulate) CMI_HIP(hipMemsetAsync(y, 0, (size_t)rows * sizeof(T), s));
+    if (nnz == 0) return CMI_SUCCESS;
+    const int block = c.block_size;
+    const int steps = c.items_per_thread < 1 ? 1 : c.items_per_thread; // 64-entry steps per wave interval
+    int64_t interval = (int64_t)steps * kWave;
+    int64_t waves = ceil_div(nnz, interval);
+    const int waves_per_block = block / kWave;
+    int64_t grid64 = ceil_div(waves, waves_per_block);
+    if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_coo: grid too large");
+    if (c.nontemporal)
+        hipLaunchKernelGGL((coo_segmented_kernel<T, true>), dim3((int)grid64), dim3(block), 0, s, nnz, Ai, Aj, Ax, x, y, interval);
+    else
+        hipLaunchKernelGGL((coo_segmented_kernel<T, false>), dim3((int)grid64), dim3(block), 0, s, nnz, Ai, Aj, Ax, x, y, interval);
+    CMI_LAUNCH_CHECK("coo spmv");
+    return CMI_SUCCESS;
+}
+
+} // namespace cmi
+
+CMI_API int cmi_spmv_coo_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ai,
+                             const int32_t *Aj, const double *Ax, const double *x, double *y, int accumulate,
+                             const cmi_config *cfg, void *stream)
+{
+    return cmi::spmv_coo<double>(CMI_F64, num_rows, num_cols, num_entries, Ai, Aj, Ax, x, y, accumulate, cfg, stream);
+}
+CMI_API int cmi_spmv_coo_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ai,
+                             const int32_t *Aj, const float *Ax, const float *x, float *y, int accumulate,
+                             const cmi_config *cfg, void *stream)
+{
+    return cmi::spmv_coo<float>(CMI_F32, num_rows, num_cols, num_entries, Ai, Aj, Ax, x, y, accumulate, cfg, stream);
+}
+
+// HYB = ELL part with the caller's accumulate, then the COO part accumulating on top, same stream.
+CMI_API int cmi_spmv_hyb_f64(int64_t num_rows, int64_t num_cols, int64_t ell_entries_per_row, int64_t ell_pitch,
+                             const int32_t *ell_Aj, const double *ell_Ax, int64_t coo_entries,
+                             const int32_t *coo_Ai, const int32_t *coo_Aj, const double *coo_Ax, const double *x,
+                             double *y, int accumulate, const cmi_config *cfg_ell, const cmi_config *cfg_coo,
+                             void *stream)
+{
+    int st = cmi_spmv_ell_f64(num_rows, num_cols, ell_entries_per_row, ell_pitch, ell_Aj, ell_Ax, nullptr, x, y,
+                              accumulate, cfg_ell, stream);
+    if (st) return st;
+    if (coo_entries == 0) return CMI_SUCCESS;
+    return cmi_spmv_coo_f64(num_rows, num_cols, coo_entries, coo_Ai, coo_Aj, coo_Ax, x, y, 1, cfg_coo, stream);
+}
+CMI_API int cmi_spmv_hyb_f32(int64_t num_rows, int64_t num_cols, int64_t ell_entries_per_row, int64_t ell_pitch,
+                             const int32_t *ell_Aj, const float *ell_Ax, int64_t coo_entries,
+                             const int32_t *coo_Ai, const int32_t *coo_Aj, const float *coo_Ax, const float *x,
+                             float *y, int accumulate, const cmi_config *cfg_ell, const cmi_config *cfg_coo,
+                             void *stream)
+{
+    int st = cmi_spmv_ell_f32(num_rows, num_cols, ell_entries_per_row, ell_pitch, ell_Aj, ell_Ax, nullptr, x, y,
+                              accumulate, cfg_ell, stream);
+    if (st) return st;
+    if (coo_entries == 0) return CMI_SUCCESS;
+    return cmi_spmv_coo_f32(num_rows, num_cols, coo_entries, coo_Ai, coo_Aj, coo_Ax, x, y, 1, cfg_coo, stream);
+}

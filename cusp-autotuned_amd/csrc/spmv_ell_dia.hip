@@ -1,0 +1,227 @@
+// spmv_ell_dia.hip -- ELL (+ELLR) and DIA SpMV for gfx950.
+//
+// Replaces (reference tree): cusp/system/cuda/detail/multiply/ell_spmv.h:55-155,
+// dia_spmv.h:69-188 and the KTT kernels cusp/system/cuda/ktt/kernels/ell_kernel.h:86-213,
+// dia_kernel.h:129-252.  Arithmetic contracts: sequential/multiply/ell_spmv.h:41-76 and
+// dia_spmv.h:43-82 (y = init(y); then slot-major / diagonal-major accumulation: per row that is
+// "start from init, add slot 0, slot 1, ..." -- exactly what one lane per row does here, so with
+// -ffp-contract=off both kernels are bit-identical to the host loops).
+//
+// Both formats are column-major with leading dimension `pitch`: lane i of a wave reads element
+// (row0+i, n), i.e. 64 consecutive addresses -- fully coalesced 256/512-byte wave loads.  RPL = rows
+// per lane (1 or 2): with 2, a lane reads int2 / double2 so each wave instruction moves 512 B / 1 KiB.
+//
+// Algorithmic bytes per call (f64):
+//   ELL: width*pitch*(4+8) + 16*num_rows        DIA: ndiag*pitch*8 + 4*ndiag + 16*num_rows
+#include "common.h"
+
+namespace cmi {
+
+// ---------------------------------------------------------------------------------------------
+// ELL: one lane per row (RPL rows per lane)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int RPL, bool ELLR, bool NT>
+__global__ void __launch_bounds__(1024)
+ell_row_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict__ Aj, const T *__restrict__ Ax,
+               const int *__restrict__ row_lengths, const T *__restrict__ x, T *__restrict__ y, int accumulate)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * RPL;
+    for (int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * RPL; row < num_rows; row += stride) {
+        if constexpr (RPL == 1) {
+            T acc = accumulate ? y[row] : T(0);
+            const int n_end = ELLR ? row_lengths[row] : width;
+#pragma unroll 4
+            for (int n = 0; n < n_end; n++) {
+                const int col = ld<NT>(Aj + n * pitch + row);
+                const T v = ld<NT>(Ax + n * pitch + row);
+                if (ELLR || col != -1) acc = acc + v * x[col];
+            }
+            y[row] = acc;
+        } else {
+            // rows row, row+1 (pitch even and arrays 16-byte aligned: checked by the launcher)
+            typedef typename vec2<T>::type T2;
+            const bool has1 = row + 1 < num_rows;
+            T acc0 = accumulate ? y[row] : T(0);
+            T acc1 = (accumulate && has1) ? y[row + 1] : T(0);
+            int len0 = width, len1 = width;
+            if constexpr (ELLR) { len0 = row_lengths[row]; len1 = has1 ? row_lengths[row + 1] : 0; }
+#pragma unroll 4
+            for (int n = 0; n < width; n++) {
+                const int2v c = ld<NT>(reinterpret_cast<const int2v *>(Aj + n * pitch + row));
+                const T2 v = ld<NT>(reinterpret_cast<const T2 *>(Ax + n * pitch + row));
+                if (ELLR ? (n < len0) : (c.x != -1)) acc0 = acc0 + v.x * x[c.x];
+                if (ELLR ? (n < len1) : (c.y != -1 && has1)) acc1 = acc1 + v.y * x[c.y];
+            }
+            y[row] = acc0;
+            if (has1) y[row + 1] = acc1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// DIA: one lane per row, diagonal offsets staged through LDS in chunks
+// ---------------------------------------------------------------------------------------------
+constexpr int kDiaChunk = 256;
+
+template <typename T, bool NT>
+__global__ void __launch_bounds__(1024)
+dia_row_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t pitch,
+               const int *__restrict__ offsets, const T *__restrict__ vals, const T *__restrict__ x,
+               T *__restrict__ y, int accumulate)
+{
+    __shared__ int soff[kDiaChunk];
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = row < num_rows;
+    T acc = (accumulate && live) ? y[row] : T(0);
+    for (int base = 0; base < num_diagonals; base += kDiaChunk) {
+        const int nchunk = num_diagonals - base < kDiaChunk ? num_diagonals - base : kDiaChunk;
+        if (base > 0) __syncthreads();
+        for (int i = threadIdx.x; i < nchunk; i += blockDim.x) soff[i] = offsets[base + i];
+        __syncthreads();
+        if (live) {
+#pragma unroll 4
+            for (int d = 0; d < nchunk; d++) {
+                const int64_t col = row + soff[d];
+                if (col >= 0 && col < num_cols) acc = acc + ld<NT>(vals + (int64_t)(base + d) * pitch + row) * x[col];
+            }
+        }
+    }
+    if (live) y[row] = acc;
+}
+
+// two rows per lane: values as T2 vectors; x for the second row is the neighbouring element
+template <typename T, bool NT>
+__global__ void __launch_bounds__(1024)
+dia_row2_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t pitch,
+                const int *__restrict__ offsets, const T *__restrict__ vals, const T *__restrict__ x,
+                T *__restrict__ y, int accumulate)
+{
+    typedef typename vec2<T>::type T2;
+    __shared__ int soff[kDiaChunk];
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    const bool live0 = row < num_rows, live1 = row + 1 < num_rows;
+    T acc0 = (accumulate && live0) ? y[row] : T(0);
+    T acc1 = (accumulate && live1) ? y[row + 1] : T(0);
+    for (int base = 0; base < num_diagonals; base += kDiaChunk) {
+        const int nchunk = num_diagonals - base < kDiaChunk ? num_diagonals - base : kDiaChunk;
+        if (base > 0) __syncthreads();
+        for (int i = threadIdx.x; i < nchunk; i += blockDim.x) soff[i] = offsets[base + i];
+        __syncthreads();
+        if (live0) {
+#pragma unroll 4
+            for (int d = 0; d < nchunk; d++) {
+                const int64_t c0 = row + soff[d], c1 = c0 + 1;
+                const T2 v = ld<NT>(reinterpret_cast<const T2 *>(vals + (int64_t)(base + d) * pitch + row));
+                if (c0 >= 0 && c0 < num_cols) acc0 = acc0 + v.x * x[c0];
+                if (live1 && c1 >= 0 && c1 < num_cols) acc1 = acc1 + v.y * x[c1];
+            }
+        }
+    }
+    if (live0) y[row] = acc0;
+    if (live1) y[row + 1] = acc1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int spmv_ell(int dtype, int64_t rows, int64_t cols, int64_t width, int64_t pitch, const int *Aj, const T *Ax,
+                    const int *row_lengths, const T *x, T *y, int accumulate, const cmi_config *user, void *stream)
+{
+    if (rows < 0 || cols < 0 || width < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_ell: negative size");
+    if (rows > INT32_MAX || cols > INT32_MAX || width > INT32_MAX)
+        return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_ell: sizes exceed the int32 index type");
+    // reference: throws when pitch < minor dimension (cusp/detail/array2d.inl:43-44)
+    if (width > 0 && pitch < rows) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_ell: pitch < num_rows");
+    if (rows == 0) return CMI_SUCCESS;
+    if (!y || (width > 0 && (!Aj || !Ax || !x))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_ell: null array");
+    cmi_config c;
+    select_config(CMI_FORMAT_ELL, dtype, rows, cols, rows * width, user, &c);
+    if (c.kernel != CMI_ELL_ROW) return fail(CMI_ERROR_NOT_SUPPORTED, "cmi_spmv_ell: config.kernel is not an ELL kernel");
+    hipStream_t s = as_stream(stream);
+    const int block = c.block_size;
+    const bool nt = c.nontemporal != 0;
+    const bool ellr = row_lengths != nullptr;
+    int rpl = c.items_per_thread >= 2 ? 2 : 1;
+    // two rows per lane needs 8-byte aligned int2 and 2*sizeof(T)-aligned value pairs in every slot
+    if (rpl == 2 && !(pitch % 2 == 0 && reinterpret_cast<uintptr_t>(Aj) % 8 == 0 &&
+                      reinterpret_cast<uintptr_t>(Ax) % (2 * sizeof(T)) == 0))
+        rpl = 1;
+    int64_t blocks = ceil_div(rows, (int64_t)block * rpl);
+    const int64_t cap = (int64_t)kCus * 16 * 256 / block;
+    if (blocks > cap) blocks = cap;
+    const int grid = (int)blocks;
+    const int w = (int)width;
+#define CMI_ELL_LAUNCH(RPL, ELLR, NT)                                                                         \
+    hipLaunchKernelGGL((ell_row_kernel<T, RPL, ELLR, NT>), dim3(grid), dim3(block), 0, s, rows, w, pitch, Aj, Ax, \
+                       row_lengths, x, y, accumulate)
+    if (rpl == 1) {
+        if (ellr) { if (nt) CMI_ELL_LAUNCH(1, true, true); else CMI_ELL_LAUNCH(1, true, false); }
+        else      { if (nt) CMI_ELL_LAUNCH(1, false, true); else CMI_ELL_LAUNCH(1, false, false); }
+    } else {
+        if (ellr) { if (nt) CMI_ELL_LAUNCH(2, true, true); else CMI_ELL_LAUNCH(2, true, false); }
+        else      { if (nt) CMI_ELL_LAUNCH(2, false, true); else CMI_ELL_LAUNCH(2, false, false); }
+    }
+#undef CMI_ELL_LAUNCH
+    CMI_LAUNCH_CHECK("ell spmv");
+    return CMI_SUCCESS;
+}
+
+template <typename T>
+static int spmv_dia(int dtype, int64_t rows, int64_t cols, int64_t ndiag, int64_t pitch, const int *offsets,
+                    const T *vals, const T *x, T *y, int accumulate, const cmi_config *user, void *stream)
+{
+    if (rows < 0 || cols < 0 || ndiag < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_dia: negative size");
+    if (rows > INT32_MAX || cols > INT32_MAX || ndiag > INT32_MAX)
+        return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_dia: sizes exceed the int32 index type");
+    if (ndiag > 0 && pitch < rows) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_dia: pitch < num_rows");
+    if (rows == 0) return CMI_SUCCESS;
+    if (!y || (ndiag > 0 && (!offsets || !vals || !x))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_dia: null array");
+    cmi_config c;
+    select_config(CMI_FORMAT_DIA, dtype, rows, cols, rows * ndiag, user, &c);
+    if (c.kernel != CMI_DIA_ROW) return fail(CMI_ERROR_NOT_SUPPORTED, "cmi_spmv_dia: config.kernel is not a DIA kernel");
+    hipStream_t s = as_stream(stream);
+    const int block = c.block_size;
+    const bool nt = c.nontemporal != 0;
+    int rpl = c.items_per_thread >= 2 ? 2 : 1;
+    if (rpl == 2 && !(pitch % 2 == 0 && reinterpret_cast<uintptr_t>(vals) % (2 * sizeof(T)) == 0)) rpl = 1;
+    const int64_t grid64 = ceil_div(rows, (int64_t)block * rpl);
+    if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_dia: grid too large");
+    const int grid = (int)grid64, nd = (int)ndiag;
+    if (rpl == 1) {
+        if (nt) hipLaunchKernelGGL((dia_row_kernel<T, true>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate);
+        else    hipLaunchKernelGGL((dia_row_kernel<T, false>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate);
+    } else {
+        if (nt) hipLaunchKernelGGL((dia_row2_kernel<T, true>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate);
+        else    hipLaunchKernelGGL((dia_row2_kernel<T, false>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate);
+    }
+    CMI_LAUNCH_CHECK("dia spmv");
+    return CMI_SUCCESS;
+}
+
+} // namespace cmi
+
+CMI_API int cmi_spmv_ell_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries_per_row, int64_t pitch,
+                             const int32_t *Aj, const double *Ax, const int32_t *row_lengths, const double *x,
+                             double *y, int accumulate, const cmi_config *cfg, void *stream)
+{
+    return cmi::spmv_ell<double>(CMI_F64, num_rows, num_cols, num_entries_per_row, pitch, Aj, Ax, row_lengths, x, y, accumulate, cfg, stream);
+}
+CMI_API int cmi_spmv_ell_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries_per_row, int64_t pitch,
+                             const int32_t *Aj, const float *Ax, const int32_t *row_lengths, const float *x,
+                             float *y, int accumulate, const cmi_config *cfg, void *stream)
+{
+    return cmi::spmv_ell<float>(CMI_F32, num_rows, num_cols, num_entries_per_row, pitch, Aj, Ax, row_lengths, x, y, accumulate, cfg, stream);
+}
+CMI_API int cmi_spmv_dia_f64(int64_t num_rows, int64_t num_cols, int64_t num_diagonals, int64_t pitch,
+                             const int32_t *diagonal_offsets, const double *values, const double *x, double *y,
+                             int accumulate, const cmi_config *cfg, void *stream)
+{
+    return cmi::spmv_dia<double>(CMI_F64, num_rows, num_cols, num_diagonals, pitch, diagonal_offsets, values, x, y, accumulate, cfg, stream);
+}
+CMI_API int cmi_spmv_dia_f32(int64_t num_rows, int64_t num_cols, int64_t num_diagonals, int64_t pitch,
+                             const int32_t *diagonal_offsets, const float *values, const float *x, float *y,
+                             int accumulate, const cmi_config *cfg, void *stream)
+{
+    return cmi::spmv_dia<float>(CMI_F32, num_rows, num_cols, num_diagonals, pitch, diagonal_offsets, values, x, y, accumulate, cfg, stream);
+}

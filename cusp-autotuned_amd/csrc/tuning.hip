@@ -1,0 +1,313 @@
+// tuning.hip -- persisted launch-shape / kernel-variant table + built-in heuristics.
+//
+// Replaces the reference's run-time KTT tuner state (cusp/ktt/detail/ktt.inl:29-62: a process-wide
+// singleton that re-tunes on every first call and is never persisted, :130-142 reset_tuning) and the
+// hard-wired selector of the stock CUDA path (cusp/system/cuda/detail/multiply/csr_vector_spmv.h
+// :225-258: threads-per-row from the integer mean row length).  Here the choice is made OFFLINE by
+// tools/autotune (which validates every variant against the CPU oracle before timing it, as
+// testing/ktt.cu:142-202 does with KTT's reference computation), written to a JSON file, and looked
+// up at call time by (format, dtype, bucket of mean entries per row).  Nothing is compiled or
+// allocated on the critical path.
+#include "common.h"
+
+#include <dlfcn.h>
+#include <cmath>
+#include <cstdlib>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace cmi {
+
+constexpr int kBuckets = 8; // mean entries/row in [2^b, 2^(b+1)), last bucket open-ended
+
+struct Table {
+    cmi_config cfg[CMI_FORMAT_COUNT][2][kBuckets];
+    bool valid[CMI_FORMAT_COUNT][2][kBuckets];
+};
+
+static Table g_table;
+static std::mutex g_mu;
+static bool g_default_loaded = false;
+
+static int bucket_of(double mean)
+{
+    if (!(mean > 1.0)) return 0;
+    int b = (int)std::floor(std::log2(mean));
+    return b < 0 ? 0 : (b >= kBuckets ? kBuckets - 1 : b);
+}
+
+static const char *kFormatNames[CMI_FORMAT_COUNT] = {"csr", "ell", "dia", "coo", "hyb"};
+static const char *kDtypeNames[2] = {"f64", "f32"};
+
+static int round_block(int b)
+{
+    if (b <= 0) return 256;
+    b = (b + kWave - 1) / kWave * kWave;
+    return b > 1024 ? 1024 : b;
+}
+
+// Built-in heuristics: what runs before any table has been loaded.
+static void heuristic(int format, int dtype, double mean, cmi_config *c)
+{
+    std::memset(c, 0, sizeof(*c));
+    c->block_size = 256;
+    switch (format) {
+    case CMI_FORMAT_CSR:
+        if (mean <= 16.0) {
+            // short rows: stream the nnz tile through LDS, one lane sums one row in storage order
+            c->kernel = CMI_CSR_STREAM;
+            c->items_per_thread = 1;
+            c->xcd_swizzle = 1;
+        } else {
+            // long rows: a sub-wave per row (the reference's selector, extended to the 64-wide wave)
+            c->kernel = CMI_CSR_VECTOR;
+            c->threads_per_row = mean <= 32.0 ? 32 : 64;
+        }
+        break;
+    case CMI_FORMAT_ELL: c->kernel = CMI_ELL_ROW; c->items_per_thread = 1; break;
+    case CMI_FORMAT_DIA: c->kernel = CMI_DIA_ROW; c->items_per_thread = 1; break;
+    case CMI_FORMAT_COO: c->kernel = CMI_COO_SEGMENTED; c->items_per_thread = 4; break;
+    default: break;
+    }
+    (void)dtype;
+}
+
+// Fill every zero ("default") field of a config so kernels see concrete numbers.
+static void complete(int format, int dtype, int64_t rows, int64_t nnz, cmi_config *c)
+{
+    const double mean = rows > 0 ? (double)nnz / (double)rows : 0.0;
+    if (c->kernel == CMI_KERNEL_AUTO) {
+        cmi_config h;
+        heuristic(format, dtype, mean, &h);
+        c->kernel = h.kernel;
+        if (!c->threads_per_row) c->threads_per_row = h.threads_per_row;
+        if (!c->items_per_thread) c->items_per_thread = h.items_per_thread;
+        if (!c->block_size) c->block_size = h.block_size;
+    }
+    c->block_size = round_block(c->block_size);
+    if (format == CMI_FORMAT_CSR) {
+        if (c->kernel == CMI_CSR_VECTOR) {
+            int t = c->threads_per_row;
+            if (t <= 0) { // reference rule (csr_vector_spmv.h:241-256) on the integer mean, up to 64
+                const int64_t m = rows > 0 ? nnz / rows : 0;
+                t = m <= 2 ? 2 : m <= 4 ? 4 : m <= 8 ? 8 : m <= 16 ? 16 : m <= 32 ? 32 : 64;
+            }
+            int p = 2;
+            while (p < t && p < 64) p <<= 1;
+            c->threads_per_row = p;
+        }
+        if (c->kernel == CMI_CSR_STREAM) {
+            int ipt = c->items_per_thread;
+            c->items_per_thread = ipt <= 1 ? 1 : ipt <= 2 ? 2 : 4;
+            const int64_t tile = (int64_t)c->block_size * c->items_per_thread * 4;
+            if (c->rows_per_block <= 0) {
+                // largest row count whose entries fit one LDS pass (3 slots of alignment slack)
+                double r = mean > 0.0 ? std::floor((double)(tile - 3) / mean) : (double)c->block_size;
+                if (r < 1.0) r = 1.0;
+                c->rows_per_block = (int)r;
+            }
+            const int max_rows = 4 * c->block_size; // a lane sums at most 4 rows
+            if (c->rows_per_block > max_rows) c->rows_per_block = max_rows;
+            if (c->rows_per_block < 1) c->rows_per_block = 1;
+        }
+    } else {
+        if (c->items_per_thread <= 0) c->items_per_thread = format == CMI_FORMAT_COO ? 4 : 1;
+    }
+}
+
+// --- minimal JSON (flat objects inside "entries":[...]) --------------------------------------
+
+static bool find_int(const std::string &obj, const char *key, long *out)
+{
+    std::string k = std::string("\"") + key + "\"";
+    size_t p = obj.find(k);
+    if (p == std::string::npos) return false;
+    p = obj.find(':', p + k.size());
+    if (p == std::string::npos) return false;
+    char *end = nullptr;
+    const char *s = obj.c_str() + p + 1;
+    double v = std::strtod(s, &end);
+    if (end == s) return false;
+    *out = (long)v;
+    return true;
+}
+
+static bool find_str(const std::string &obj, const char *key, std::string *out)
+{
+    std::string k = std::string("\"") + key + "\"";
+    size_t p = obj.find(k);
+    if (p == std::string::npos) return false;
+    p = obj.find(':', p + k.size());
+    if (p == std::string::npos) return false;
+    size_t a = obj.find('"', p + 1);
+    if (a == std::string::npos) return false;
+    size_t b = obj.find('"', a + 1);
+    if (b == std::string::npos) return false;
+    *out = obj.substr(a + 1, b - a - 1);
+    return true;
+}
+
+static int load_file(const char *path)
+{
+    FILE *f = std::fopen(path, "rb");
+    if (!f) { set_error("cmi_tuning_load: cannot open %s", path); return CMI_ERROR_IO; }
+    std::string s;
+    char buf[4096];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) s.append(buf, n);
+    std::fclose(f);
+    size_t p = s.find("\"entries\"");
+    if (p == std::string::npos) { set_error("cmi_tuning_load: %s has no \"entries\"", path); return CMI_ERROR_IO; }
+    p = s.find('[', p);
+    int loaded = 0;
+    while (p != std::string::npos) {
+        size_t a = s.find('{', p);
+        size_t close = s.find(']', p);
+        if (a == std::string::npos || (close != std::string::npos && close < a)) break;
+        size_t b = s.find('}', a);
+        if (b == std::string::npos) break;
+        std::string obj = s.substr(a, b - a + 1);
+        std::string fmt, dt;
+        long bucket = -1;
+        if (find_str(obj, "format", &fmt) && find_str(obj, "dtype", &dt) && find_int(obj, "bucket", &bucket)) {
+            int fi = -1, di = -1;
+            for (int i = 0; i < CMI_FORMAT_COUNT; i++) if (fmt == kFormatNames[i]) fi = i;
+            for (int i = 0; i < 2; i++) if (dt == kDtypeNames[i]) di = i;
+            if (fi >= 0 && di >= 0 && bucket >= 0 && bucket < kBuckets) {
+                cmi_config c;
+                std::memset(&c, 0, sizeof(c));
+                long v;
+                if (find_int(obj, "kernel", &v)) c.kernel = (int)v;
+                if (find_int(obj, "block_size", &v)) c.block_size = (int)v;
+                if (find_int(obj, "threads_per_row", &v)) c.threads_per_row = (int)v;
+                if (find_int(obj, "rows_per_block", &v)) c.rows_per_block = (int)v;
+                if (find_int(obj, "items_per_thread", &v)) c.items_per_thread = (int)v;
+                if (find_int(obj, "nontemporal", &v)) c.nontemporal = (int)v;
+                if (find_int(obj, "xcd_swizzle", &v)) c.xcd_swizzle = (int)v;
+                g_table.cfg[fi][di][bucket] = c;
+                g_table.valid[fi][di][bucket] = true;
+                loaded++;
+            }
+        }
+        p = b + 1;
+    }
+    (void)loaded;
+    return CMI_SUCCESS;
+}
+
+// the table shipped next to the library: <libdir>/../tuned/gfx950.json
+static std::string default_table_path()
+{
+    Dl_info info;
+    if (dladdr((void *)&default_table_path, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        size_t s = p.rfind('/');
+        if (s != std::string::npos) return p.substr(0, s) + "/../tuned/gfx950.json";
+    }
+    return "tuned/gfx950.json";
+}
+
+static void ensure_default_loaded()
+{
+    if (g_default_loaded) return;
+    g_default_loaded = true;
+    const char *env = std::getenv("CMI_TUNING_TABLE");
+    if (env && *env) {
+        if (std::strcmp(env, "none") != 0) (void)load_file(env);
+        return;
+    }
+    std::string p = default_table_path();
+    FILE *f = std::fopen(p.c_str(), "rb");
+    if (f) { std::fclose(f); (void)load_file(p.c_str()); }
+}
+
+void select_config(int format, int dtype, int64_t rows, int64_t cols, int64_t nnz, const cmi_config *user,
+                   cmi_config *out)
+{
+    (void)cols;
+    const double mean = rows > 0 ? (double)nnz / (double)rows : 0.0;
+    if (user && user->kernel != CMI_KERNEL_AUTO) {
+        *out = *user;
+    } else {
+        std::lock_guard<std::mutex> lk(g_mu);
+        ensure_default_loaded();
+        const int b = bucket_of(mean);
+        if (format >= 0 && format < CMI_FORMAT_COUNT && g_table.valid[format][dtype][b])
+            *out = g_table.cfg[format][dtype][b];
+        else
+            heuristic(format, dtype, mean, out);
+        if (user) { // AUTO kernel but explicit launch-shape overrides
+            if (user->block_size) out->block_size = user->block_size;
+            if (user->nontemporal) out->nontemporal = user->nontemporal;
+        }
+    }
+    complete(format, dtype, rows, nnz, out);
+}
+
+} // namespace cmi
+
+using namespace cmi;
+
+CMI_API int cmi_tuning_load(const char *path)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_default_loaded = true;
+    if (!path) path = std::getenv("CMI_TUNING_TABLE");
+    if (!path || !*path) return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_load: no path and CMI_TUNING_TABLE unset");
+    return load_file(path);
+}
+
+CMI_API int cmi_tuning_save(const char *path)
+{
+    if (!path) return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_save: null path");
+    std::lock_guard<std::mutex> lk(g_mu);
+    FILE *f = std::fopen(path, "wb");
+    if (!f) { set_error("cmi_tuning_save: cannot open %s", path); return CMI_ERROR_IO; }
+    std::fprintf(f, "{\n  \"arch\": \"gfx950\",\n  \"version\": %d,\n  \"entries\": [\n", CMI_VERSION);
+    bool first = true;
+    for (int fi = 0; fi < CMI_FORMAT_COUNT; fi++)
+        for (int di = 0; di < 2; di++)
+            for (int b = 0; b < kBuckets; b++) {
+                if (!g_table.valid[fi][di][b]) continue;
+                const cmi_config &c = g_table.cfg[fi][di][b];
+                std::fprintf(f,
+                             "%s    {\"format\": \"%s\", \"dtype\": \"%s\", \"bucket\": %d, \"kernel\": %d, "
+                             "\"block_size\": %d, \"threads_per_row\": %d, \"rows_per_block\": %d, "
+                             "\"items_per_thread\": %d, \"nontemporal\": %d, \"xcd_swizzle\": %d}",
+                             first ? "" : ",\n", kFormatNames[fi], kDtypeNames[di], b, c.kernel, c.block_size,
+                             c.threads_per_row, c.rows_per_block, c.items_per_thread, c.nontemporal, c.xcd_swizzle);
+                first = false;
+            }
+    std::fprintf(f, "\n  ]\n}\n");
+    std::fclose(f);
+    return CMI_SUCCESS;
+}
+
+CMI_API int cmi_tuning_clear(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::memset(&g_table, 0, sizeof(g_table));
+    g_default_loaded = true; // stay on the built-in heuristics until the next explicit load
+    return CMI_SUCCESS;
+}
+
+CMI_API int cmi_tuning_set(int format, int dtype, double mean_entries_per_row, const cmi_config *cfg)
+{
+    if (format < 0 || format >= CMI_FORMAT_COUNT || dtype < 0 || dtype > 1 || !cfg)
+        return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_set: bad format/dtype/config");
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int b = bucket_of(mean_entries_per_row);
+    g_table.cfg[format][dtype][b] = *cfg;
+    g_table.valid[format][dtype][b] = true;
+    return CMI_SUCCESS;
+}
+
+CMI_API int cmi_tuning_select(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
+                              cmi_config *out)
+{
+    if (format < 0 || format >= CMI_FORMAT_COUNT || dtype < 0 || dtype > 1 || !out)
+        return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_select: bad format/dtype/out");
+    select_config(format, dtype, num_rows, num_cols, num_entries, nullptr, out);
+    return CMI_SUCCESS;
+}

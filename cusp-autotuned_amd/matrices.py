@@ -1,0 +1,190 @@
+"""Device-memory containers with the public members of the reference's
+cusp::{csr,coo,ell,dia,hyb}_matrix<int, T, cusp::device_memory> and a ``multiply(A, x, y)`` that
+dispatches on the container's format the way cusp::multiply does
+(reference cusp/detail/multiply.inl:27-105 -> cusp/system/detail/generic/multiply.inl:173-191).
+
+Storage is torch tensors on the HIP device (plumbing for device memory only); every multiply goes
+through the C-ABI library -- see binding.py.  The C++ users' equivalent of this file is the
+header-only layer in include/cusp/.
+"""
+from dataclasses import dataclass, field
+
+from . import binding as B
+
+
+def _round_up(n, k):
+    """cusp::detail::round_up (reference cusp/detail/utils.h:24-28)."""
+    return k * ((n + k - 1) // k)
+
+
+@dataclass
+class CsrMatrix:
+    """reference cusp/csr_matrix.h:107-208: row_offsets, column_indices, values."""
+    num_rows: int
+    num_cols: int
+    num_entries: int
+    row_offsets: object
+    column_indices: object
+    values: object
+    format = "csr"
+
+
+@dataclass
+class CooMatrix:
+    """reference cusp/coo_matrix.h:116-224: row_indices, column_indices, values."""
+    num_rows: int
+    num_cols: int
+    num_entries: int
+    row_indices: object
+    column_indices: object
+    values: object
+    format = "coo"
+
+
+@dataclass
+class EllMatrix:
+    """reference cusp/ell_matrix.h:119-228: column-major num_rows x num_entries_per_row arrays with
+    leading dimension pitch = round_up(num_rows, alignment); padding column = invalid_index (-1).
+    row_lengths (optional) is the fork's ELLR extension, cusp/ktt/ellr_matrix.h:17-90."""
+    num_rows: int
+    num_cols: int
+    num_entries: int
+    num_entries_per_row: int
+    pitch: int
+    column_indices: object
+    values: object
+    row_lengths: object = None
+    invalid_index = -1
+    format = "ell"
+
+
+@dataclass
+class DiaMatrix:
+    """reference cusp/dia_matrix.h:120-226: diagonal_offsets + column-major values (pitch)."""
+    num_rows: int
+    num_cols: int
+    num_entries: int
+    pitch: int
+    diagonal_offsets: object
+    values: object
+    format = "dia"
+
+
+@dataclass
+class HybMatrix:
+    """reference cusp/hyb_matrix.h:142-246: ell + coo parts."""
+    num_rows: int
+    num_cols: int
+    num_entries: int
+    ell: EllMatrix
+    coo: CooMatrix
+    format = "hyb"
+
+
+def multiply(A, x, y, accumulate=False, cfg=None, stream=None):
+    """y = A*x (or y += A*x).  Mirrors the 3-argument cusp::multiply (cusp/multiply.h:40)."""
+    if isinstance(A, CsrMatrix):
+        B.spmv_csr(A.num_rows, A.num_cols, A.row_offsets, A.column_indices, A.values, x, y, accumulate, cfg, stream)
+    elif isinstance(A, CooMatrix):
+        B.spmv_coo(A.num_rows, A.num_cols, A.row_indices, A.column_indices, A.values, x, y, accumulate, cfg, stream)
+    elif isinstance(A, EllMatrix):
+        B.spmv_ell(A.num_rows, A.num_cols, A.num_entries_per_row, A.pitch, A.column_indices, A.values, x, y,
+                   A.row_lengths, accumulate, cfg, stream)
+    elif isinstance(A, DiaMatrix):
+        B.spmv_dia(A.num_rows, A.num_cols, A.diagonal_offsets.numel(), A.pitch, A.diagonal_offsets, A.values, x, y,
+                   accumulate, cfg, stream)
+    elif isinstance(A, HybMatrix):
+        e, c = A.ell, A.coo
+        B.spmv_hyb(A.num_rows, A.num_cols, e.num_entries_per_row, e.pitch, e.column_indices, e.values,
+                   c.row_indices, c.column_indices, c.values, x, y, accumulate, cfg, None, stream)
+    else:
+        raise TypeError(f"multiply: unsupported matrix type {type(A).__name__}")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# builders (setup, not the hot path)
+# ------------------------------------------------------------------------------------------------
+def poisson5pt(m, n, fmt="csr", dtype=None, device="cuda", row_begin=0, row_end=None, ell_alignment=32):
+    """cusp::gallery::poisson5pt(A, m, n) built directly in HBM (reference
+    cusp/gallery/detail/poisson.inl:29-47).  fmt in {csr, coo, ell, dia, hyb}.  row_begin/row_end
+    select a row-block shard (CSR/COO/ELL only) with GLOBAL column indices."""
+    import torch
+    dtype = dtype or torch.float64
+    N = m * n
+    row_end = N if row_end is None else row_end
+    if fmt == "dia":
+        if row_begin != 0 or row_end != N:
+            raise ValueError("dia shards are not supported")
+        pitch = N  # the gallery builds DIA with pitch = num_rows (stencil.inl:174)
+        off = torch.empty(5, dtype=torch.int32, device=device)
+        vals = torch.empty(5 * pitch, dtype=dtype, device=device)
+        B.poisson5pt_dia(m, n, pitch, off, vals)
+        return DiaMatrix(N, N, B.poisson5pt_num_entries(m, n), pitch, off, vals)
+    rows = row_end - row_begin
+    nnz = B.poisson5pt_shard_entries(m, n, row_begin, row_end)
+    Ap = torch.empty(rows + 1, dtype=torch.int32, device=device)
+    Aj = torch.empty(nnz, dtype=torch.int32, device=device)
+    Ax = torch.empty(nnz, dtype=dtype, device=device)
+    B.poisson5pt_csr(m, n, Ap, Aj, Ax, row_begin, row_end)
+    csr = CsrMatrix(rows, N, nnz, Ap, Aj, Ax)
+    return csr if fmt == "csr" else convert(csr, fmt, ell_alignment=ell_alignment)
+
+
+def convert(csr, fmt, num_entries_per_row=None, ell_alignment=32):
+    """CSR -> {coo, ell, hyb} on the device (reference conversions/csr_to_other.h:56-70,155-306).
+    For ELL the width defaults to the longest row; for HYB pass num_entries_per_row (the reference's
+    compute_optimal_entries_per_row heuristic lives in the C++ layer / oracle)."""
+    import torch
+    if not isinstance(csr, CsrMatrix):
+        raise TypeError("convert: source must be a CsrMatrix")
+    dev = csr.values.device
+    if fmt == "csr":
+        return csr
+    if fmt == "coo":
+        Ai = torch.empty(csr.num_entries, dtype=torch.int32, device=dev)
+        B.csr_row_indices(csr.num_rows, csr.row_offsets, Ai)
+        return CooMatrix(csr.num_rows, csr.num_cols, csr.num_entries, Ai, csr.column_indices, csr.values)
+    if fmt in ("ell", "hyb"):
+        lens = (csr.row_offsets[1:] - csr.row_offsets[:-1])
+        max_len = int(lens.max().item()) if csr.num_rows else 0
+        width = max_len if num_entries_per_row is None else int(num_entries_per_row)
+        pitch = _round_up(csr.num_rows, ell_alignment)
+        eAj = torch.empty(width * pitch, dtype=torch.int32, device=dev)
+        eAx = torch.empty(width * pitch, dtype=csr.values.dtype, device=dev)
+        B.csr_to_ell(csr.num_rows, csr.row_offsets, csr.column_indices, csr.values, width, pitch, eAj, eAx)
+        n_coo = int(torch.clamp(lens - width, min=0).sum().item())
+        ell = EllMatrix(csr.num_rows, csr.num_cols, csr.num_entries - n_coo, width, pitch, eAj, eAx)
+        if fmt == "ell":
+            if n_coo:
+                raise ValueError("convert: num_entries_per_row is smaller than the longest row (use hyb)")
+            return ell
+        # entries with within-row index >= width, in CSR order (setup-time compaction)
+        Ai = torch.empty(csr.num_entries, dtype=torch.int32, device=dev)
+        B.csr_row_indices(csr.num_rows, csr.row_offsets, Ai)
+        k = torch.arange(csr.num_entries, dtype=torch.int32, device=dev) - csr.row_offsets[Ai.long()]
+        keep = k >= width
+        coo = CooMatrix(csr.num_rows, csr.num_cols, n_coo, Ai[keep].contiguous(),
+                        csr.column_indices[keep].contiguous(), csr.values[keep].contiguous())
+        return HybMatrix(csr.num_rows, csr.num_cols, csr.num_entries, ell, coo)
+    raise ValueError(f"convert: unknown format {fmt!r}")
+
+
+# ------------------------------------------------------------------------------------------------
+# algorithmic (compulsory) HBM bytes per SpMV -- SURVEY.md section 8(d)
+# ------------------------------------------------------------------------------------------------
+def csr_bytes(num_rows, num_entries, value_bytes=8):
+    """Ap once + Aj once + Ax once + x once + y once (square matrix): 12*nnz + 20*N + 4 for f64."""
+    return 4 * (num_rows + 1) + (4 + value_bytes) * num_entries + 2 * value_bytes * num_rows
+
+
+def ell_bytes(num_rows, width, pitch, value_bytes=8):
+    return width * pitch * (4 + value_bytes) + 2 * value_bytes * num_rows
+
+
+def dia_bytes(num_rows, num_diagonals, pitch, value_bytes=8):
+    return num_diagonals * pitch * value_bytes + 4 * num_diagonals + 2 * value_bytes * num_rows
+
+
+def coo_bytes(num_rows, num_entries, value_bytes=8):
+    return num_entries * (8 + value_bytes) + 2 * value_bytes * num_rows

@@ -1,0 +1,254 @@
+/*
+ * cusp_mi355x.h -- C-ABI of the MI355X-native SpMV engine that sits behind
+ * cusp::multiply() for cusp::{csr,coo,ell,dia,hyb}_matrix<int, T, device_memory>.
+ *
+ * Plain pointers and sizes only: no torch, Thrust or C++ types cross this
+ * boundary.  All pointers named Ap/Aj/Ax/x/y/... are DEVICE pointers (HBM);
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).  Every
+ * entry point returns a cmi_status (0 = success); launches are asynchronous on
+ * `stream` like the reference's, but -- unlike the reference, which never checks
+ * a launch (cusp/system/cuda/detail/multiply/csr_vector_spmv.h:204-208) -- launch
+ * errors are reported.  Nothing here takes ownership of caller memory and no
+ * SpMV entry point allocates.
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to
+ * the reference tree).  The header-only C++ layer in
+ * cusp-autotuned_amd/include/cusp/ forwards cusp::multiply to these symbols; a
+ * maintainer of the reference would bind them as shown in INTEGRATION.md.
+ *
+ * Index type is int32 (the reference's `int`), value types are f64 and f32.
+ */
+#ifndef CUSP_MI355X_H
+#define CUSP_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMI_VERSION 100 /* 0.1.0 */
+
+typedef enum cmi_status {
+    CMI_SUCCESS = 0,
+    CMI_ERROR_INVALID_VALUE = 1, /* bad size / null pointer / bad config: cusp::invalid_input_exception */
+    CMI_ERROR_HIP = 2,           /* a HIP runtime call or kernel launch failed: cusp::runtime_exception */
+    CMI_ERROR_NOT_SUPPORTED = 3, /* config names a kernel variant that does not exist */
+    CMI_ERROR_NO_DEVICE = 4,     /* no gfx950 device visible */
+    CMI_ERROR_ALLOC = 5,         /* hipMalloc failed: std::bad_alloc */
+    CMI_ERROR_IO = 6             /* tuning table could not be read / written */
+} cmi_status;
+
+/* Human-readable name of a status, and the message of the last failure on this thread. */
+const char *cmi_status_string(int status);
+const char *cmi_last_error(void);
+int cmi_version(void);
+
+/* ------------------------------------------------------------------------- */
+/* Device + memory: what cusp::device_memory containers sit on.                */
+/* Replaces thrust::device_malloc_allocator (cusp/detail/memory.inl:28-35) and  */
+/* the H<->D copies done by cusp::array1d converting construction               */
+/* (cusp/array1d.h:98-242).                                                     */
+/* ------------------------------------------------------------------------- */
+int cmi_device_count(int *count);
+int cmi_set_device(int device);
+int cmi_get_device(int *device);
+/* name: caller buffer of name_len bytes; cus: compute units; hbm_bytes: total memory */
+int cmi_device_info(int device, char *name, size_t name_len, int *cus, int64_t *hbm_bytes);
+
+int cmi_malloc(void **ptr, size_t bytes);
+int cmi_free(void *ptr);
+int cmi_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int cmi_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int cmi_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
+int cmi_memset(void *dst, int byte_value, size_t bytes, void *stream);
+int cmi_stream_create(void **stream);
+int cmi_stream_destroy(void *stream);
+int cmi_stream_synchronize(void *stream);
+int cmi_device_synchronize(void);
+
+/* hipEvent-based timing on a stream (replaces performance/timer.h:23-54). */
+int cmi_event_create(void **event);
+int cmi_event_destroy(void *event);
+int cmi_event_record(void *event, void *stream);
+int cmi_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
+
+/* ------------------------------------------------------------------------- */
+/* Launch-shape / kernel-variant selection (replaces the KTT tuning           */
+/* parameters of cusp/system/cuda/ktt/{csr,ell,dia,coo}_multiply.h and the      */
+/* fixed selector of cusp/system/cuda/detail/multiply/csr_vector_spmv.h        */
+/* :225-258).  A NULL config means: look the shape up in the persisted tuning   */
+/* table (below), falling back to built-in heuristics.                          */
+/* ------------------------------------------------------------------------- */
+typedef enum cmi_format {
+    CMI_FORMAT_CSR = 0,
+    CMI_FORMAT_ELL = 1,
+    CMI_FORMAT_DIA = 2,
+    CMI_FORMAT_COO = 3,
+    CMI_FORMAT_HYB = 4,
+    CMI_FORMAT_COUNT = 5
+} cmi_format;
+
+typedef enum cmi_dtype { CMI_F64 = 0, CMI_F32 = 1 } cmi_dtype;
+
+typedef enum cmi_kernel {
+    CMI_KERNEL_AUTO = 0,
+    /* CSR */
+    CMI_CSR_SCALAR = 1, /* one lane per row          (ref: csr_scalar.h:51-73)                   */
+    CMI_CSR_VECTOR = 2, /* threads_per_row lanes/row (ref: csr_vector_spmv.h:71-161, THREADS_PER_ROW) */
+    CMI_CSR_STREAM = 3, /* LDS-staged nnz tile, sequential per-row sum (bit-exact vs host order) */
+    /* ELL */
+    CMI_ELL_ROW = 10, /* one lane per row            (ref: ell_spmv.h:55-93)                     */
+    /* DIA */
+    CMI_DIA_ROW = 20, /* one lane per row, offsets in LDS (ref: dia_spmv.h:69-126)               */
+    /* COO */
+    CMI_COO_SEGMENTED = 30, /* wave segmented reduction + f64/f32 atomics at segment tails
+                               (ref: ktt kernels/coo_kernel.h:289-369, coo_flat_spmv.h:231-311)  */
+} cmi_kernel;
+
+typedef struct cmi_config {
+    int32_t kernel;           /* cmi_kernel; CMI_KERNEL_AUTO = pick by heuristics                  */
+    int32_t block_size;       /* threads per workgroup: 64..1024, multiple of 64; 0 = default      */
+    int32_t threads_per_row;  /* CSR vector: 2,4,8,16,32,64; 0 = from mean row length              */
+    int32_t rows_per_block;   /* CSR stream: rows per workgroup tile; 0 = from mean row length     */
+    int32_t items_per_thread; /* CSR stream: 16-byte index vectors per lane per pass (1,2,4);
+                                 ELL/DIA: rows per lane (1,2); COO: entries per lane; 0 = default   */
+    int32_t nontemporal;      /* 1 = load the once-read matrix streams with the nt hint            */
+    int32_t xcd_swizzle;      /* 1 = give each XCD a contiguous run of tiles (L2 reuse of x)       */
+    int32_t reserved;
+} cmi_config;
+
+/* Persisted tuning table (replaces the in-process KTT tuner state,              */
+/* cusp/ktt/detail/ktt.inl:29-62,130-142, which the reference never persists).  */
+/* Keyed by (format, dtype, bucket of mean entries per row).                     */
+int cmi_tuning_load(const char *path);  /* JSON written by tools/autotune; NULL = $CMI_TUNING_TABLE */
+int cmi_tuning_save(const char *path);
+int cmi_tuning_clear(void);             /* back to built-in heuristics (cusp::ktt::reset_tuning)   */
+int cmi_tuning_set(int format, int dtype, double mean_entries_per_row, const cmi_config *cfg);
+/* The config a NULL-config call with this shape would run. */
+int cmi_tuning_select(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
+                      cmi_config *out);
+
+/* ------------------------------------------------------------------------- */
+/* SpMV: y = A*x (accumulate == 0; the reference's 3-argument cusp::multiply,  */
+/* cusp/multiply.h:40,101 -> generic/multiply.inl:98-111) or y = y + A*x        */
+/* (accumulate != 0; initialize = identity, as hyb's COO half uses,             */
+/* generic/multiply/spmv.h:275-290).  x has num_cols elements, y num_rows.      */
+/* ------------------------------------------------------------------------- */
+
+/* Replaces cuda::detail::multiply(csr) (csr_vector_spmv.h:225-258), spmv_csr_scalar
+ * (csr_scalar.h:82-109) and the KTT csr_spmv kernel (ktt/kernels/csr_kernel.h:378-410).
+ * Host-order oracle: sequential/multiply/csr_spmv.h:42-74. */
+int cmi_spmv_csr_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ap,
+                     const int32_t *Aj, const double *Ax, const double *x, double *y, int accumulate,
+                     const cmi_config *cfg, void *stream);
+int cmi_spmv_csr_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ap,
+                     const int32_t *Aj, const float *Ax, const float *x, float *y, int accumulate,
+                     const cmi_config *cfg, void *stream);
+
+/* Replaces cuda::detail::multiply(ell) (ell_spmv.h:103-155) and ktt_ell_kernel / ktt_ellr_kernel
+ * (ktt/kernels/ell_kernel.h:181-213).  Column-major num_rows x num_entries_per_row arrays with
+ * leading dimension `pitch` (element (i,n) at n*pitch+i); padding slots have column -1.
+ * row_lengths may be NULL; when given (the fork's ELLR, cusp/ktt/ellr_matrix.h:17-90) row i has
+ * exactly row_lengths[i] leading valid slots.  Oracle: sequential/multiply/ell_spmv.h:41-76. */
+int cmi_spmv_ell_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries_per_row, int64_t pitch,
+                     const int32_t *Aj, const double *Ax, const int32_t *row_lengths, const double *x,
+                     double *y, int accumulate, const cmi_config *cfg, void *stream);
+int cmi_spmv_ell_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries_per_row, int64_t pitch,
+                     const int32_t *Aj, const float *Ax, const int32_t *row_lengths, const float *x,
+                     float *y, int accumulate, const cmi_config *cfg, void *stream);
+
+/* Replaces cuda::detail::multiply(dia) (dia_spmv.h:136-188) and ktt_dia_vector_kernel
+ * (ktt/kernels/dia_kernel.h:236-252).  values column-major num_rows x num_diagonals, leading
+ * dimension `pitch`.  Oracle: sequential/multiply/dia_spmv.h:43-82. */
+int cmi_spmv_dia_f64(int64_t num_rows, int64_t num_cols, int64_t num_diagonals, int64_t pitch,
+                     const int32_t *diagonal_offsets, const double *values, const double *x, double *y,
+                     int accumulate, const cmi_config *cfg, void *stream);
+int cmi_spmv_dia_f32(int64_t num_rows, int64_t num_cols, int64_t num_diagonals, int64_t pitch,
+                     const int32_t *diagonal_offsets, const float *values, const float *x, float *y,
+                     int accumulate, const cmi_config *cfg, void *stream);
+
+/* Replaces the COO flat trio (coo_flat_spmv.h:387-463, coo_serial.h:38-54), the Thrust
+ * reduce_by_key fallback that device COO actually runs on modern Thrust
+ * (generic/multiply/spmv.h:185-238) and the KTT coo_spmv composite (ktt/kernels/coo_kernel.h:372-392).
+ * Entries may be in any order (sorted by row is fastest).  No scratch allocation.
+ * Oracle: sequential/multiply/coo_spmv.h:42-68. */
+int cmi_spmv_coo_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ai,
+                     const int32_t *Aj, const double *Ax, const double *x, double *y, int accumulate,
+                     const cmi_config *cfg, void *stream);
+int cmi_spmv_coo_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ai,
+                     const int32_t *Aj, const float *Ax, const float *x, float *y, int accumulate,
+                     const cmi_config *cfg, void *stream);
+
+/* HYB = ELL part (caller's accumulate) then COO part accumulating on top
+ * (generic/multiply/spmv.h:275-290; oracle sequential/multiply/hyb_spmv.h:42-57).
+ * cfg_ell / cfg_coo may be NULL. */
+int cmi_spmv_hyb_f64(int64_t num_rows, int64_t num_cols, int64_t ell_entries_per_row, int64_t ell_pitch,
+                     const int32_t *ell_Aj, const double *ell_Ax, int64_t coo_entries,
+                     const int32_t *coo_Ai, const int32_t *coo_Aj, const double *coo_Ax, const double *x,
+                     double *y, int accumulate, const cmi_config *cfg_ell, const cmi_config *cfg_coo,
+                     void *stream);
+int cmi_spmv_hyb_f32(int64_t num_rows, int64_t num_cols, int64_t ell_entries_per_row, int64_t ell_pitch,
+                     const int32_t *ell_Aj, const float *ell_Ax, int64_t coo_entries,
+                     const int32_t *coo_Ai, const int32_t *coo_Aj, const float *coo_Ax, const float *x,
+                     float *y, int accumulate, const cmi_config *cfg_ell, const cmi_config *cfg_coo,
+                     void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* On-device builders of the benchmark inputs.      */
+/* cusp::gallery::poisson5pt (cusp/gallery/detail/poisson.inl:29-47,            */
+/* stencil.inl:143-206) followed by the conversion to the target format         */
+/* (conversions/dia_to_other.h:109-163, csr_to_other.h:56-70,155-227), done     */
+/* directly in HBM so 1e7..1e8-row inputs do not go through the host.            */
+/* Sizes: N = m*n rows, nnz = 5mn - 2m - 2n.                                     */
+/* ------------------------------------------------------------------------- */
+int64_t cmi_poisson5pt_num_entries(int64_t m, int64_t n);
+/* Rows [row_begin, row_end) of the global matrix with GLOBAL column indices (row-block shard,
+ * SURVEY.md section 8(e)); Ap has (row_end-row_begin)+1 entries starting at 0.
+ * Pass 0, m*n for the whole matrix.  Aj/Ax must hold cmi_poisson5pt_shard_entries(). */
+int64_t cmi_poisson5pt_shard_entries(int64_t m, int64_t n, int64_t row_begin, int64_t row_end);
+int cmi_poisson5pt_csr_f64(int64_t m, int64_t n, int64_t row_begin, int64_t row_end, int32_t *Ap,
+                           int32_t *Aj, double *Ax, void *stream);
+int cmi_poisson5pt_csr_f32(int64_t m, int64_t n, int64_t row_begin, int64_t row_end, int32_t *Ap,
+                           int32_t *Aj, float *Ax, void *stream);
+/* DIA: offsets[5] = {-m,-1,0,1,m}; values 5 columns of leading dimension pitch (>= m*n). */
+int cmi_poisson5pt_dia_f64(int64_t m, int64_t n, int64_t pitch, int32_t *offsets, double *values,
+                           void *stream);
+int cmi_poisson5pt_dia_f32(int64_t m, int64_t n, int64_t pitch, int32_t *offsets, float *values,
+                           void *stream);
+
+/* CSR -> ELL (width slots, leading dimension pitch, padding -1 / 0) keeping within-row order;
+ * entries at within-row index >= width are dropped (they belong to HYB's COO part, below).
+ * (csr_to_other.h:155-227) */
+int cmi_csr_to_ell_f64(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, const double *Ax,
+                       int64_t width, int64_t pitch, int32_t *ell_Aj, double *ell_Ax, void *stream);
+int cmi_csr_to_ell_f32(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, const float *Ax,
+                       int64_t width, int64_t pitch, int32_t *ell_Aj, float *ell_Ax, void *stream);
+/* CSR -> COO row indices (offsets_to_indices, csr_to_other.h:56-70). */
+int cmi_csr_row_indices(int64_t num_rows, const int32_t *Ap, int32_t *Ai, void *stream);
+/* ELL -> per-row length of the leading valid run (cusp/ktt/detail/ellr_matrix.inl:16-53). */
+int cmi_ell_row_lengths(int64_t num_rows, int64_t width, int64_t pitch, const int32_t *ell_Aj,
+                        int32_t *row_lengths, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* BLAS-1 on device vectors: the five routines cusp::krylov::cg calls          */
+/* (cusp/krylov/detail/cg.inl:63-105; generic/blas.h:175-220,283-340).          */
+/* dot / nrm2 write their scalar to a DEVICE double (*result_dev) without a     */
+/* host sync; the caller copies it back when it needs the value.                */
+/* `workspace` is a device buffer of cmi_blas_workspace_bytes() bytes.          */
+/* ------------------------------------------------------------------------- */
+size_t cmi_blas_workspace_bytes(void);
+int cmi_blas_axpy_f64(int64_t n, double alpha, const double *x, double *y, void *stream);  /* y += a x */
+int cmi_blas_axpby_f64(int64_t n, double alpha, const double *x, double beta, const double *y,
+                       double *z, void *stream);                                             /* z = a x + b y */
+int cmi_blas_copy_f64(int64_t n, const double *x, double *y, void *stream);
+int cmi_blas_fill_f64(int64_t n, double value, double *y, void *stream);
+int cmi_blas_dot_f64(int64_t n, const double *x, const double *y, double *result_dev, void *workspace,
+                     void *stream);
+int cmi_blas_nrm2_f64(int64_t n, const double *x, double *result_dev, void *workspace, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUSP_MI355X_H */
