@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py -- SpMV GFLOP/s + achieved HBM GB/s (fp64) on 5-point Poisson, the metric of BASELINE.json.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic input = one y = A*x through the
+C-ABI (cmi_spmv_csr_f64) with A, x, y resident in HBM.
+
+N = 1: BASELINE.json configs[1], poisson5pt 3162x3162 (9 998 244 rows, 49 978 572 entries), CSR,
+       int32/f64, kernel + launch shape from the persisted tuning table.
+N > 1: weak scaling -- every rank owns a 3162x3162-point row block of the global
+       poisson5pt(3162, 3162*N) (N=8: 8.0e7 rows; BASELINE.json configs[4] shape), global column
+       indices; a step = exchange of x over RCCL/xGMI (halo or all-gather, see
+       cusp-autotuned_amd/distributed.py) + the local SpMV.  value = 2*global_nnz / max-over-ranks time.
+
+Timing protocol (reference performance/spmv/benchmark.h:84-120): W untimed warm-up steps, then
+exactly K steps between a barrier + device synchronise on both sides; MAX over ranks.
+The dominant kernel's average launch duration is measured live with HIP events on the stream the
+kernel is launched on (cmi_event_*), for the roofline object.
+
+The `cpu_baseline` leg (rank 0, N = 1 only) times the REFERENCE's own sequential host kernel
+(oracle/_ref, kind "reference") -- or the C restatement (kind "port") when that library is absent --
+on the same matrix for ~10-20 s, and also checks the GPU result against it.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M = 3162  # grid side: 3162^2 = 9 998 244 rows per GPU
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--exchange", default="auto", choices=["auto", "halo", "allgather"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--format", default="csr", choices=["csr", "ell", "dia", "coo", "hyb"],
+                    help="N=1 only: bench another format of the same matrix (BASELINE.json configs[2])")
+    return ap.parse_args()
+
+
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary
+    (profiles/*_pmc.json, produced by tools/pmc_summary.py from separate --pmc passes), or None."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    if os.path.isdir(pdir):
+        for f in sorted(os.listdir(pdir)):
+            if f.endswith("_pmc.json"):
+                try:
+                    doc = json.load(open(os.path.join(pdir, f)))
+                    for k in doc.get("kernels", []):
+                        if kernel_substr in k.get("kernel", "") and k.get("hbm_bytes_per_launch"):
+                            best = float(k["hbm_bytes_per_launch"])
+                except Exception:
+                    pass
+    return best
+
+
+def cpu_baseline(cmi, A, x_host, y_gpu_host, seconds):
+    """Times the reference's sequential host SpMV on the same matrix; checks the GPU result."""
+    import numpy as np
+    import oracle
+    Ap, Aj, Ax = (t.cpu().numpy() for t in (A.row_offsets, A.column_indices, A.values))
+    nnz = A.num_entries
+    orc = oracle.Oracle()
+    kind = "reference" if oracle.have_reference() else "port"
+    if kind == "reference":
+        refl = oracle.Reference()
+        run = lambda: refl.spmv_csr(A.num_cols, Ap, Aj, Ax, x_host)  # noqa: E731
+    else:
+        run = lambda: orc.spmv_csr(Ap, Aj, Ax, x_host)  # noqa: E731
+    y = run()  # warm-up (first touch)
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 3 or (time.perf_counter() - t0 < seconds and reps < 500):
+        y = run()
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    exact = bool(np.array_equal(y, y_gpu_host))
+    max_rel = float(np.max(np.abs(y - y_gpu_host)) / max(float(np.max(np.abs(y))), 1e-300))
+    out = {"value": round(2.0 * nnz / dt / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": kind,
+           "sample": f"{reps} full SpMVs of the same poisson5pt {M}x{M} CSR fp64 matrix ({dt * 1e3:.1f} ms each), "
+                     "single thread, -O2 -ffp-contract=off",
+           "ms_per_spmv": round(dt * 1e3, 3), "gpu_result_bit_exact": exact, "gpu_max_rel_err": max_rel}
+    # the OpenMP row-parallel port (reference omp/detail/multiply/csr_spmv.h semantics), all host cores
+    orc.spmv_csr(Ap, Aj, Ax, x_host, omp=True)
+    t0 = time.perf_counter()
+    r2 = 0
+    while r2 < 3 or (time.perf_counter() - t0 < seconds / 3 and r2 < 500):
+        orc.spmv_csr(Ap, Aj, Ax, x_host, omp=True)
+        r2 += 1
+    dt2 = (time.perf_counter() - t0) / r2
+    omp = {"value": round(2.0 * nnz / dt2 / 1e9, 4), "unit": "GFLOP/s", "cores": orc.num_threads(), "kind": "port",
+           "sample": f"{r2} full SpMVs, OpenMP static row split", "ms_per_spmv": round(dt2 * 1e3, 3)}
+    if not (exact or max_rel <= 1e-6):
+        raise SystemExit(f"parity gate failed: GPU y differs from the CPU reference (max rel {max_rel})")
+    return out, omp
+
+
+def main():
+    args = parse()
+    import torch
+    import cusp_autotuned_amd as cmi
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
+                             f"python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    lib = cmi.lib()
+    stream = torch.cuda.current_stream()
+    sptr = ctypes.c_void_p(stream.cuda_stream)
+
+    # ---- workload --------------------------------------------------------------------------
+    m, n = M, M * world
+    rows_per_rank = M * M
+    lo, hi = rank * rows_per_rank, (rank + 1) * rows_per_rank
+    A = cmi.poisson5pt(m, n, "csr", dtype=torch.float64, device=dev, row_begin=lo, row_end=hi)
+    N_global = m * n
+    nnz_global = cmi.poisson5pt_num_entries(m, n)
+    fmt = args.format if world == 1 else "csr"
+    Afmt = A if fmt == "csr" else (cmi.poisson5pt(m, n, "dia", device=dev) if fmt == "dia" else
+                                   cmi.convert(A, fmt, num_entries_per_row=5 if fmt == "hyb" else None))
+    x_host = cmi.fill_x(N_global).numpy()  # deterministic, RNG-free input
+    y = torch.full((rows_per_rank,), 10.0, dtype=torch.float64, device=dev)
+
+    if world == 1:
+        x = torch.from_numpy(x_host).to(dev)
+        step = lambda: cmi.multiply(Afmt, x, y)  # noqa: E731
+        exchange_info = None
+    else:
+        sh = cmi.distributed.ShardedCsr(A, N_global, rank, world, mode=args.exchange,
+                                        col_span=(max(lo - m, 0), min(hi + m, N_global) - 1))
+        sh.x_local.copy_(torch.from_numpy(x_host[lo:hi]).to(dev))
+        step = lambda: sh.multiply(y)  # noqa: E731
+        p = sh.vec.plan
+        exchange_info = {"mode": p.mode, "values_received_per_rank": p.recv_values if p.mode == "halo" else p.allgather_values,
+                         "allgather_values": p.allgather_values}
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up, then exactly K timed steps -------------------------------------------------
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- dominant kernel: average launch duration with HIP events on ITS stream --------------
+    ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()
+    cmi.check(lib.cmi_event_create(ctypes.byref(ev0)))
+    cmi.check(lib.cmi_event_create(ctypes.byref(ev1)))
+    kern_steps = max(args.steps, 20)
+    x_kernel = x if world == 1 else sh.x_view
+    kernel_only = (lambda: cmi.multiply(Afmt, x_kernel, y))
+    kernel_only()
+    torch.cuda.synchronize()
+    cmi.check(lib.cmi_event_record(ev0, sptr))
+    for _ in range(kern_steps):
+        kernel_only()
+    cmi.check(lib.cmi_event_record(ev1, sptr))
+    ms = ctypes.c_float()
+    cmi.check(lib.cmi_event_elapsed_ms(ev0, ev1, ctypes.byref(ms)))
+    kernel_ms = ms.value / kern_steps
+    if dist is not None:
+        t = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kernel_ms = float(t.item())
+
+    # ---- numbers -------------------------------------------------------------------------------
+    ms_per_step = elapsed / args.steps * 1e3
+    gflops = 2.0 * nnz_global / (elapsed / args.steps) / 1e9
+    local_nnz, local_rows = A.num_entries, A.num_rows
+    if fmt == "csr":
+        alg_bytes = cmi.csr_bytes(local_rows, local_nnz)
+        kname = "csr"
+    elif fmt == "ell":
+        alg_bytes, kname = cmi.ell_bytes(local_rows, Afmt.num_entries_per_row, Afmt.pitch), "ell"
+    elif fmt == "dia":
+        alg_bytes, kname = cmi.dia_bytes(local_rows, 5, Afmt.pitch), "dia"
+    elif fmt == "coo":
+        alg_bytes, kname = cmi.coo_bytes(local_rows, local_nnz), "coo"
+    else:
+        alg_bytes, kname = cmi.ell_bytes(local_rows, 5, Afmt.ell.pitch), "ell"
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    cfg = cmi.tuning_select({"csr": 0, "ell": 1, "dia": 2, "coo": 3, "hyb": 1}[fmt], cmi.F64, local_rows, N_global,
+                            local_nnz if fmt in ("csr", "coo") else local_rows * 5)
+
+    if rank == 0:
+        line = {
+            "metric": "spmv_gflops_fp64_poisson5pt",
+            "value": round(gflops, 3),
+            "unit": "GFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "hbm_gbps": round(alg_bytes * world / (elapsed / args.steps) / 1e9, 2),
+            "config": {"workload": f"poisson5pt {m}x{n} {fmt.upper()} int32/f64, y = A*x "
+                                   f"({N_global} rows, {nnz_global} entries; {M}x{M} grid points per GPU)",
+                       "format": fmt, "rows_per_gpu": local_rows, "entries_per_gpu": local_nnz,
+                       "kernel_config": cfg.as_dict(), "parallelism": f"row-block x{world}",
+                       "x_exchange": exchange_info},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(kname),
+                         "kernel_avg_ms": round(kernel_ms, 6), "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel_gflops": round(2.0 * local_nnz / (kernel_ms * 1e-3) / 1e9, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline and fmt == "csr":
+            base, omp = cpu_baseline(cmi, A, x_host, y.cpu().numpy(), args.cpu_seconds)
+            line["cpu_baseline"] = base
+            line["cpu_baseline_omp"] = omp
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

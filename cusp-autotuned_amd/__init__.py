@@ -25,5 +25,6 @@ from .binding import (  # noqa: F401
 )
 from .matrices import (  # noqa: F401
     CsrMatrix, CooMatrix, EllMatrix, DiaMatrix, HybMatrix, multiply, poisson5pt, convert,
-    csr_bytes, ell_bytes, dia_bytes, coo_bytes,
+    csr_bytes, ell_bytes, dia_bytes, coo_bytes, fill_x,
 )
+from . import distributed  # noqa: F401,E402

@@ -102,14 +102,14 @@ static void complete(int format, int dtype, int64_t rows, int64_t nnz, cmi_confi
             c->items_per_thread = ipt <= 1 ? 1 : ipt <= 2 ? 2 : 4;
             const int64_t tile = (int64_t)c->block_size * c->items_per_thread * 4;
             if (c->rows_per_block <= 0) {
-                // largest row count whose entries fit one LDS pass (3 slots of alignment slack)
+                // largest row count whose entries fit one LDS pass (3 slots of alignment slack);
+                // an explicit rows_per_block is left alone and validated by the launcher
                 double r = mean > 0.0 ? std::floor((double)(tile - 3) / mean) : (double)c->block_size;
+                const double max_rows = 4.0 * c->block_size; // a lane sums at most 4 rows
+                if (r > max_rows) r = max_rows;
                 if (r < 1.0) r = 1.0;
                 c->rows_per_block = (int)r;
             }
-            const int max_rows = 4 * c->block_size; // a lane sums at most 4 rows
-            if (c->rows_per_block > max_rows) c->rows_per_block = max_rows;
-            if (c->rows_per_block < 1) c->rows_per_block = 1;
         }
     } else {
         if (c->items_per_thread <= 0) c->items_per_thread = format == CMI_FORMAT_COO ? 4 : 1;

@@ -170,6 +170,18 @@ def convert(csr, fmt, num_entries_per_row=None, ell_alignment=32):
     raise ValueError(f"convert: unknown format {fmt!r}")
 
 
+def fill_x(n, dtype=None, device="cpu", start=0):
+    """The deterministic, RNG-free input vector of SURVEY.md section 8(d):
+    x[i] = ((uint32)(i * 2654435761u) % 1000) / 997.0 - 0.5   for i in [start, start+n).
+    Computed with exact integer ops and one IEEE division on the host, then moved to `device`."""
+    import torch
+    dtype = dtype or torch.float64
+    i = torch.arange(start, start + n, dtype=torch.int64)
+    h = (i * 2654435761) & 0xFFFFFFFF
+    x = (h % 1000).to(torch.float64) / 997.0 - 0.5
+    return x.to(dtype).to(device)
+
+
 # ------------------------------------------------------------------------------------------------
 # algorithmic (compulsory) HBM bytes per SpMV -- SURVEY.md section 8(d)
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,122 @@
+"""CPU tests (-m "not gpu"): the C-ABI library loads, exports every symbol include/*.h declares, and
+its host-only entry points (status strings, argument validation, tuning table) behave.  No compute
+calls: those need a GPU and live in test_spmv_gpu.py."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    names = set()
+    inc = os.path.join(ROOT, "include")
+    for f in os.listdir(inc):
+        if f.endswith(".h"):
+            text = open(os.path.join(inc, f)).read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            names |= set(re.findall(r"\b(cmi_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol(cmi):
+    L = cmi.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 50
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, missing
+
+
+def test_version_and_status_strings(cmi):
+    L = cmi.lib()
+    assert cmi.version() == 100
+    assert L.cmi_status_string(0) == b"CMI_SUCCESS"
+    assert L.cmi_status_string(1) == b"CMI_ERROR_INVALID_VALUE"
+    assert L.cmi_status_string(99) == b"CMI_ERROR_UNKNOWN"
+
+
+def test_argument_validation_fails_before_touching_the_gpu(cmi):
+    L = cmi.lib()
+    # negative size, index overflow, pitch < rows: reported as CMI_ERROR_INVALID_VALUE with a message
+    assert L.cmi_spmv_csr_f64(-1, 4, 0, None, None, None, None, None, 0, None, None) == 1
+    assert b"negative" in L.cmi_last_error()
+    assert L.cmi_spmv_csr_f64(2**31, 4, 0, None, None, None, None, None, 0, None, None) == 1
+    assert L.cmi_spmv_csr_f64(3, 3, 2, None, None, None, None, None, 0, None, None) == 1  # null arrays
+    assert L.cmi_spmv_ell_f64(10, 10, 2, 8, None, None, None, None, None, 0, None, None) == 1  # pitch < rows
+    assert b"pitch" in L.cmi_last_error()
+    assert L.cmi_spmv_dia_f32(10, 10, 2, 8, None, None, None, None, 0, None, None) == 1
+    assert L.cmi_spmv_coo_f64(3, 3, -2, None, None, None, None, None, 0, None, None) == 1
+    # empty matrix: nothing to do, success without a device
+    assert L.cmi_spmv_csr_f64(0, 0, 0, None, None, None, None, None, 0, None, None) == 0
+    with pytest.raises(cmi.CmiError) as e:
+        cmi.check(L.cmi_blas_axpy_f64(-5, 1.0, None, None, None))
+    assert e.value.status == 1
+
+
+def test_python_plumbing_refuses_host_tensors(cmi):
+    import torch
+    t = torch.zeros(4, dtype=torch.float64)
+    i = torch.zeros(5, dtype=torch.int32)
+    with pytest.raises(TypeError, match="device memory"):
+        cmi.spmv_csr(4, 4, i, i[:0], t[:0], t, t)
+
+
+def test_poisson_entry_counts(cmi):
+    assert cmi.poisson5pt_num_entries(100, 100) == 49600
+    assert cmi.poisson5pt_num_entries(3162, 3162) == 49978572
+    assert cmi.poisson5pt_num_entries(10000, 10000) == 499960000
+    assert cmi.poisson5pt_num_entries(2, 3) == 20
+    assert cmi.poisson5pt_num_entries(1, 1) == 1
+    assert cmi.poisson5pt_num_entries(1, 7) == 7 * 3 - 2
+    # shards tile the matrix
+    m, n = 37, 11
+    cuts = [0, 1, 36, 37, 38, 200, 406, 407]
+    assert sum(cmi.poisson5pt_shard_entries(m, n, a, b) for a, b in zip(cuts, cuts[1:])) == \
+        cmi.poisson5pt_num_entries(m, n)
+
+
+def test_tuning_heuristics_and_table_roundtrip(cmi, tmp_path):
+    cmi.tuning_clear()
+    # 5-pt Poisson CSR: short rows -> the LDS-staged stream kernel, one pass fits 204 rows of 5
+    c = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 9998244, 9998244, 49978572)
+    assert c.kernel == cmi.CSR_STREAM and c.block_size == 256 and c.items_per_thread == 1
+    assert c.rows_per_block == 204
+    # long rows -> a sub-wave per row, wave64-wide at the top
+    c = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 100000)
+    assert c.kernel == cmi.CSR_VECTOR and c.threads_per_row == 64
+    c = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F32, 1000, 1000, 20000)
+    assert c.kernel == cmi.CSR_VECTOR and c.threads_per_row == 32
+    assert cmi.tuning_select(cmi.FORMAT_ELL, cmi.F64, 100, 100, 500).kernel == cmi.ELL_ROW
+    assert cmi.tuning_select(cmi.FORMAT_DIA, cmi.F64, 100, 100, 500).kernel == cmi.DIA_ROW
+    assert cmi.tuning_select(cmi.FORMAT_COO, cmi.F64, 100, 100, 500).kernel == cmi.COO_SEGMENTED
+
+    # persist an override, clear, reload: the selection follows the table
+    cfg = cmi.Config(kernel=cmi.CSR_VECTOR, block_size=128, threads_per_row=4, nontemporal=1)
+    cmi.tuning_set(cmi.FORMAT_CSR, cmi.F64, 4.99, cfg)
+    path = str(tmp_path / "table.json")
+    cmi.tuning_save(path)
+    doc = json.load(open(path))
+    assert doc["arch"] == "gfx950" and len(doc["entries"]) == 1
+    assert doc["entries"][0]["format"] == "csr" and doc["entries"][0]["bucket"] == 2
+    cmi.tuning_clear()
+    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 100, 100, 499).kernel == cmi.CSR_STREAM
+    cmi.tuning_load(path)
+    c = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 100, 100, 499)
+    assert (c.kernel, c.block_size, c.threads_per_row, c.nontemporal) == (cmi.CSR_VECTOR, 128, 4, 1)
+    # another bucket is untouched
+    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 100, 100, 900).kernel == cmi.CSR_STREAM
+    cmi.tuning_clear()
+    with pytest.raises(cmi.CmiError):
+        cmi.tuning_load(str(tmp_path / "missing.json"))
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    """No CPU fallback: without the HIP library the binding raises at first use."""
+    import cusp_autotuned_amd.binding as b
+    monkeypatch.setattr(b, "_lib", None)
+    monkeypatch.setattr(b, "_LIB_PATH", "/nonexistent/libcusp_mi355x.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        b.lib()

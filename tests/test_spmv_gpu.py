@@ -1,0 +1,515 @@
+"""GPU parity tests (-m gpu): every SpMV entry point of the C-ABI, every kernel variant, against
+(1) the golden vectors produced by the reference's own kernels, (2) the known answers of the
+reference's tests and (3) the CPU oracle on seeded inputs -- plus size-independent properties at
+BASELINE.json's full size (poisson5pt 3162x3162).
+
+Bars (written here, as the task demands):
+  * integer outputs (row offsets, column indices, row lengths, ...): bit-exact;
+  * one-lane-per-row kernels (csr_scalar, csr_stream, ell, dia): BIT-EXACT vs the reference host
+    loop -- same summation order, library built with -ffp-contract=off;
+  * kernels that re-associate the row sum (csr_vector, coo, hyb's coo half):
+    |y_gpu - y_ref| <= TOL * sum_j |a_ij x_j| with TOL = 1e-6 for f64 (north_star) and 1e-5 for f32.
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.dtype(np.float64): 1e-6, np.dtype(np.float32): 1e-5}
+DT = {"f64": np.float64, "f32": np.float32}
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    return torch
+
+
+def dev(a, torch):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def row_abs(orc, Ap, Aj, Ax, x):
+    return orc.spmv_csr(Ap, Aj, np.abs(Ax), np.abs(x))
+
+
+def assert_close(y, want, bound, dtype, what=""):
+    err = np.abs(y.astype(np.float64) - want.astype(np.float64))
+    lim = TOL[np.dtype(dtype)] * np.maximum(bound.astype(np.float64), np.finfo(dtype).tiny)
+    bad = np.nonzero(err > lim)[0]
+    assert bad.size == 0, f"{what}: {bad.size} rows out of tolerance, first {bad[:5]}, err {err[bad[:5]]}"
+
+
+def csr_variants(cmi, small=False):
+    """Every CSR kernel variant worth distinguishing (launch shape x load policy)."""
+    out = []
+    for blk, nt in itertools.product((64, 256, 1024), (0, 1)):
+        out.append(("scalar", True, cmi.Config(kernel=cmi.CSR_SCALAR, block_size=blk, nontemporal=nt)))
+    for tpr in (2, 4, 8, 16, 32, 64):
+        for blk in ((256,) if small else (128, 256, 512)):
+            out.append((f"vector{tpr}", False, cmi.Config(kernel=cmi.CSR_VECTOR, block_size=blk, threads_per_row=tpr)))
+    out.append(("vector8nt", False, cmi.Config(kernel=cmi.CSR_VECTOR, block_size=256, threads_per_row=8, nontemporal=1)))
+    for blk, ipt, rpb, nt, swz in ((256, 1, 0, 0, 1), (256, 1, 0, 1, 0), (256, 2, 0, 0, 1), (256, 4, 0, 0, 0),
+                                   (128, 1, 0, 0, 1), (512, 1, 0, 0, 1), (64, 1, 7, 0, 1), (256, 1, 1, 0, 0),
+                                   (256, 1, 1024, 0, 1), (128, 2, 512, 1, 1), (1024, 1, 300, 0, 1)):
+        out.append((f"stream b{blk} i{ipt} r{rpb} nt{nt} x{swz}", True,
+                    cmi.Config(kernel=cmi.CSR_STREAM, block_size=blk, items_per_thread=ipt, rows_per_block=rpb,
+                               nontemporal=nt, xcd_swizzle=swz)))
+    return out
+
+
+def run_all_formats(cmi, torch, orc, rows, cols, Ap, Aj, Ax, x, want, want_acc, y0, hyb_width, label):
+    """CSR (all variants), COO, ELL (+ELLR, 1/2 rows per lane), HYB against `want` / `want_acc`."""
+    dtype = Ax.dtype
+    bound = row_abs(orc, Ap, Aj, Ax, x) + (np.abs(y0) if y0 is not None else 0)
+    dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+
+    def fresh(acc):
+        return dev(y0, torch).clone() if acc else torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
+
+    for acc, w in ((False, want["csr"]), (True, want_acc["csr"])):
+        for name, exact, cfg in csr_variants(cmi, small=True):
+            y = fresh(acc)
+            cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, accumulate=acc, cfg=cfg)
+            got = host(y)
+            if exact:
+                assert np.array_equal(got, w), f"{label} csr {name} acc={acc}: not bit-exact"
+            else:
+                assert_close(got, w, bound, dtype, f"{label} csr {name} acc={acc}")
+        y = fresh(acc)  # NULL config: tuning table / heuristics
+        cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, accumulate=acc)
+        assert_close(host(y), w, bound, dtype, f"{label} csr auto acc={acc}")
+
+    # COO (sorted, as csr_to_coo produces)
+    Ai = orc.csr_row_indices(Ap)
+    dAi = dev(Ai, torch)
+    for acc, w in ((False, want["coo"]), (True, want_acc["coo"])):
+        for ipt, blk in ((1, 64), (4, 256), (16, 256), (3, 128)):
+            y = fresh(acc)
+            cmi.spmv_coo(rows, cols, dAi, dAj, dAx, dx, y, accumulate=acc,
+                         cfg=cmi.Config(kernel=cmi.COO_SEGMENTED, block_size=blk, items_per_thread=ipt))
+            assert_close(host(y), w, bound, dtype, f"{label} coo ipt{ipt} acc={acc}")
+
+    # ELL / ELLR
+    width = int(np.diff(Ap).max()) if rows else 0
+    pitch, eAj, eAx = orc.csr_to_ell(Ap, Aj, Ax, width)
+    deAj, deAx = dev(eAj, torch), dev(eAx, torch)
+    rl = torch.empty(rows, dtype=torch.int32, device="cuda")
+    cmi.ell_row_lengths(rows, width, pitch, deAj, rl)
+    assert np.array_equal(host(rl), np.diff(Ap).astype(np.int32)), f"{label}: ELLR row lengths"
+    for acc, w in ((False, want["ell"]), (True, want_acc["ell"])):
+        for rpl, nt, ellr, blk in itertools.product((1, 2), (0, 1), (False, True), (256,)):
+            y = fresh(acc)
+            cmi.spmv_ell(rows, cols, width, pitch, deAj, deAx, dx, y, row_lengths=rl if ellr else None, accumulate=acc,
+                         cfg=cmi.Config(kernel=cmi.ELL_ROW, block_size=blk, items_per_thread=rpl, nontemporal=nt))
+            assert np.array_equal(host(y), w), f"{label} ell rpl{rpl} nt{nt} ellr{ellr} acc={acc}: not bit-exact"
+
+    # HYB at the fixture's split
+    p, hAj, hAx, cAi, cAj, cAx = orc.csr_to_hyb(Ap, Aj, Ax, hyb_width)
+    args = [dev(a, torch) for a in (hAj, hAx, cAi, cAj, cAx)]
+    for acc, w in ((False, want["hyb"]), (True, want_acc["hyb"])):
+        y = fresh(acc)
+        cmi.spmv_hyb(rows, cols, hyb_width, p, *args, dx, y, accumulate=acc)
+        assert_close(host(y), w, bound, dtype, f"{label} hyb acc={acc}")
+
+
+# ------------------------------------------------------------------------------------------------
+# golden vectors from the reference's own kernels
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_poisson_100x100_golden_all_formats(cmi, torch_cuda, orc, golden_poisson, tag):
+    torch, g, dtype = torch_cuda, golden_poisson, DT[tag]
+    m, n = int(g["m"]), int(g["n"])
+    N = m * n
+    off, vals, nnz = orc.poisson5pt_dia(m, n, dtype)
+    Ap, Aj, Ax = orc.dia_to_csr(N, N, off, vals, nnz)
+    x, y0 = g[f"{tag}_x"], g[f"{tag}_y0"]
+    want = {k: g[f"{tag}_y_{k}"] for k in ("csr", "coo", "ell", "hyb", "dia")}
+    want_acc = {k: g[f"{tag}_yacc_{k}"] for k in ("csr", "coo", "ell", "hyb", "dia")}
+    run_all_formats(cmi, torch, orc, N, N, Ap, Aj, Ax, x, want, want_acc, y0, int(g[f"{tag}_hyb_width"]), "poisson100")
+    # DIA: gallery layout (pitch = N), 1 and 2 rows per lane, both load policies -- bit-exact
+    doff, dvals, dx = dev(off, torch), dev(vals, torch), dev(x, torch)
+    for acc, w in ((False, want["dia"]), (True, want_acc["dia"])):
+        for rpl, nt, blk in itertools.product((1, 2), (0, 1), (64, 256)):
+            y = dev(y0, torch).clone() if acc else torch.full((N,), 10.0, dtype=dx.dtype, device="cuda")
+            cmi.spmv_dia(N, N, 5, N, doff, dvals, dx, y, accumulate=acc,
+                         cfg=cmi.Config(kernel=cmi.DIA_ROW, block_size=blk, items_per_thread=rpl, nontemporal=nt))
+            assert np.array_equal(host(y), w), f"dia rpl{rpl} nt{nt} acc={acc}: not bit-exact"
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_irregular_golden_all_formats(cmi, torch_cuda, orc, golden_irregular, tag):
+    torch, g = torch_cuda, golden_irregular
+    rows, cols = int(g["rows"]), int(g["cols"])
+    Ap, Aj, Ax, x, y0 = (g[f"{tag}_{k}"] for k in ("Ap", "Aj", "Ax", "x", "y0"))
+    want = {k: g[f"{tag}_y_{k}"] for k in ("csr", "coo", "ell", "hyb")}
+    want_acc = {k: g[f"{tag}_yacc_{k}"] for k in ("csr", "coo", "ell", "hyb")}
+    run_all_formats(cmi, torch, orc, rows, cols, Ap, Aj, Ax, x, want, want_acc, y0, int(g[f"{tag}_hyb_width"]), "irregular")
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_banded_dia_golden(cmi, torch_cuda, golden_banded, tag):
+    torch, g = torch_cuda, golden_banded
+    rows, cols, pitch = int(g["rows"]), int(g["cols"]), int(g["pitch"])
+    off, vals, x, y0 = g["offsets"], g[f"{tag}_vals"], g[f"{tag}_x"], g[f"{tag}_y0"]
+    doff, dvals, dx = dev(off, torch), dev(vals, torch), dev(x, torch)
+    for acc, w in ((False, g[f"{tag}_y"]), (True, g[f"{tag}_yacc"])):
+        for rpl, nt in itertools.product((1, 2), (0, 1)):
+            y = dev(y0, torch).clone() if acc else torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
+            cmi.spmv_dia(rows, cols, len(off), pitch, doff, dvals, dx, y, accumulate=acc,
+                         cfg=cmi.Config(kernel=cmi.DIA_ROW, items_per_thread=rpl, nontemporal=nt))
+            assert np.array_equal(host(y), w), f"banded dia rpl{rpl} nt{nt} acc={acc}"
+
+
+def test_dia_more_than_256_diagonals(cmi, torch_cuda, orc):
+    """The LDS offset chunk is 256 wide (as the reference's, dia_spmv.h:84-97): cross it.
+    Mirrors the 1024-diagonal matrices of testing/ktt.cu:274-281 at a smaller size."""
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    rows, cols, nd = 1000, 777, 600
+    off = np.sort(rng.choice(np.arange(-rows + 1, cols), size=nd, replace=False)).astype(np.int32)
+    pitch = 1024
+    vals = rng.standard_normal(nd * pitch)
+    x = rng.standard_normal(cols)
+    want = orc.spmv_dia(rows, cols, pitch, off, vals, x)
+    for rpl in (1, 2):
+        y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
+        cmi.spmv_dia(rows, cols, nd, pitch, dev(off, torch), dev(vals, torch), dev(x, torch), y,
+                     cfg=cmi.Config(kernel=cmi.DIA_ROW, items_per_thread=rpl))
+        assert np.array_equal(host(y), want)
+
+
+# ------------------------------------------------------------------------------------------------
+# known answers of the reference's tests (testing/multiply.cu:383-512, generalized_spmv.cu:20-70)
+# ------------------------------------------------------------------------------------------------
+def test_reference_known_answer_matrices(cmi, torch_cuda, orc, known):
+    from conftest import dense_to_csr
+    torch = torch_cuda
+    for case in known["spmv"]:
+        D = np.array(case["dense"])
+        rows, cols = D.shape
+        for dtype in (np.float64, np.float32):
+            Ap, Aj, Ax = dense_to_csr(D, dtype)
+            x = np.array(case["x"], dtype)
+            want = np.array(case["y"], dtype)
+            want_acc = np.array(case["y_accumulate_from_10"], dtype)
+            dx = dev(x, torch)
+            dAp, dAj, dAx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch)
+            for _, _, cfg in csr_variants(cmi, small=True) + [("auto", True, None)]:
+                y = torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
+                cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, cfg=cfg)
+                assert np.array_equal(host(y), want), (case["name"], cfg)  # small integers: exact in any order
+                y = torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
+                cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, accumulate=True, cfg=cfg)
+                assert np.array_equal(host(y), want_acc), (case["name"], cfg)
+            Ai = orc.csr_row_indices(Ap)
+            y = torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
+            cmi.spmv_coo(rows, cols, dev(Ai, torch), dAj, dAx, dx, y)
+            assert np.array_equal(host(y), want), case["name"]
+            width = int(np.diff(Ap).max())
+            pitch, eAj, eAx = orc.csr_to_ell(Ap, Aj, Ax, width)
+            y = torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
+            cmi.spmv_ell(rows, cols, width, pitch, dev(eAj, torch), dev(eAx, torch), dx, y)
+            assert np.array_equal(host(y), want), case["name"]
+            if len(Ax):
+                pd, off, vals = orc.csr_to_dia(rows, cols, Ap, Aj, Ax)
+                y = torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
+                cmi.spmv_dia(rows, cols, len(off), pd, dev(off, torch), dev(vals, torch), dx, y)
+                assert np.array_equal(host(y), want), case["name"]
+            for w in range(width + 1):
+                p, hAj, hAx, cAi, cAj, cAx = orc.csr_to_hyb(Ap, Aj, Ax, w)
+                y = torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
+                cmi.spmv_hyb(rows, cols, w, p, *[dev(a, torch) for a in (hAj, hAx, cAi, cAj, cAx)], dx, y)
+                assert np.array_equal(host(y), want), (case["name"], w)
+    g = known["generalized_spmv"]
+    D = np.array([c for c in known["spmv"] if c["name"] == "A"][0]["dense"])
+    Ap, Aj, Ax = dense_to_csr(D)
+    y = dev(np.array(g["y"], np.float64), torch)
+    cmi.spmv_csr(5, 4, dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(np.array(g["x"], np.float64), torch), y,
+                 accumulate=True)
+    assert host(y).tolist() == [183.0, 74.0, 325.0, 510.0, 131.0]
+
+
+# ------------------------------------------------------------------------------------------------
+# edge cases
+# ------------------------------------------------------------------------------------------------
+def test_empty_and_degenerate_shapes(cmi, torch_cuda):
+    torch = torch_cuda
+    i32, f64 = torch.int32, torch.float64
+    # rows but no entries: y = 0 (or untouched when accumulating)
+    Ap = torch.zeros(6, dtype=i32, device="cuda")
+    e_i, e_v = torch.empty(0, dtype=i32, device="cuda"), torch.empty(0, dtype=f64, device="cuda")
+    x = torch.ones(3, dtype=f64, device="cuda")
+    for cfg in (None, cmi.Config(kernel=cmi.CSR_SCALAR), cmi.Config(kernel=cmi.CSR_VECTOR, threads_per_row=4),
+                cmi.Config(kernel=cmi.CSR_STREAM)):
+        y = torch.full((5,), 10.0, dtype=f64, device="cuda")
+        cmi.spmv_csr(5, 3, Ap, e_i, e_v, x, y, cfg=cfg)
+        assert host(y).tolist() == [0] * 5
+        y = torch.full((5,), 10.0, dtype=f64, device="cuda")
+        cmi.spmv_csr(5, 3, Ap, e_i, e_v, x, y, accumulate=True, cfg=cfg)
+        assert host(y).tolist() == [10] * 5
+    y = torch.full((5,), 10.0, dtype=f64, device="cuda")
+    cmi.spmv_coo(5, 3, e_i, e_i, e_v, x, y)
+    assert host(y).tolist() == [0] * 5
+    y = torch.full((5,), 10.0, dtype=f64, device="cuda")
+    cmi.spmv_ell(5, 3, 0, 32, e_i, e_v, x, y)  # reference: empty ELL -> y = init (ell_spmv.h:117-121)
+    assert host(y).tolist() == [0] * 5
+    y = torch.full((5,), 10.0, dtype=f64, device="cuda")
+    cmi.spmv_dia(5, 3, 0, 32, e_i, e_v, x, y)
+    assert host(y).tolist() == [0] * 5
+    # zero rows: nothing happens, no error
+    cmi.spmv_csr(0, 3, torch.zeros(1, dtype=i32, device="cuda"), e_i, e_v, x, e_v)
+    # a 1x1 matrix
+    y = torch.zeros(1, dtype=f64, device="cuda")
+    one_i = torch.zeros(1, dtype=i32, device="cuda")
+    cmi.spmv_csr(1, 1, torch.tensor([0, 1], dtype=i32, device="cuda"), one_i,
+                 torch.tensor([2.5], dtype=f64, device="cuda"), torch.tensor([4.0], dtype=f64, device="cuda"), y)
+    assert host(y).tolist() == [10.0]
+
+
+def test_bad_config_is_an_error_not_a_fallback(cmi, torch_cuda):
+    torch = torch_cuda
+    Ap = torch.tensor([0, 1], dtype=torch.int32, device="cuda")
+    Aj = torch.zeros(1, dtype=torch.int32, device="cuda")
+    v = torch.ones(1, dtype=torch.float64, device="cuda")
+    for cfg in (cmi.Config(kernel=cmi.ELL_ROW), cmi.Config(kernel=77), cmi.Config(kernel=cmi.DIA_ROW)):
+        with pytest.raises(cmi.CmiError) as e:
+            cmi.spmv_csr(1, 1, Ap, Aj, v, v, v.clone(), cfg=cfg)
+        assert e.value.status == 3  # CMI_ERROR_NOT_SUPPORTED
+    with pytest.raises(cmi.CmiError):
+        cmi.spmv_csr(1, 1, Ap, Aj, v, v, v.clone(), cfg=cmi.Config(kernel=cmi.CSR_STREAM, block_size=64, rows_per_block=9999))
+
+
+def test_unaligned_views_take_the_scalar_load_paths(cmi, torch_cuda, orc, golden_irregular):
+    """Aj/Ax that are not 16-byte aligned (e.g. slices of larger buffers) must still be exact."""
+    torch, g = torch_cuda, golden_irregular
+    rows, cols = int(g["rows"]), int(g["cols"])
+    Ap, Aj, Ax, x = (g[f"f64_{k}"] for k in ("Ap", "Aj", "Ax", "x"))
+    want = g["f64_y_csr"]
+    for shift_i, shift_v in ((1, 0), (0, 1), (3, 1), (2, 0)):
+        bufj = torch.zeros(len(Aj) + 8, dtype=torch.int32, device="cuda")
+        bufv = torch.zeros(len(Ax) + 8, dtype=torch.float64, device="cuda")
+        dAj = bufj[shift_i:shift_i + len(Aj)]
+        dAx = bufv[shift_v:shift_v + len(Ax)]
+        dAj.copy_(dev(Aj, torch))
+        dAx.copy_(dev(Ax, torch))
+        for ipt in (1, 2, 4):
+            y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
+            cmi.spmv_csr(rows, cols, dev(Ap, torch), dAj, dAx, dev(x, torch), y,
+                         cfg=cmi.Config(kernel=cmi.CSR_STREAM, items_per_thread=ipt))
+            assert np.array_equal(host(y), want), (shift_i, shift_v, ipt)
+    # ELL with an odd pitch: the two-rows-per-lane request silently uses one row per lane (same result)
+    width = int(np.diff(Ap).max())
+    pitch, eAj, eAx = orc.csr_to_ell(Ap, Aj, Ax, width, alignment=1)
+    if pitch % 2 == 0:
+        pitch, eAj, eAx = orc.csr_to_ell(np.r_[Ap, Ap[-1]].astype(np.int32), Aj, Ax, width, alignment=1)
+    y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
+    cmi.spmv_ell(rows, cols, width, pitch, dev(eAj, torch), dev(eAx, torch), dev(x, torch), y,
+                 cfg=cmi.Config(kernel=cmi.ELL_ROW, items_per_thread=2))
+    assert np.array_equal(host(y), g["f64_y_ell"])
+
+
+def test_coo_unsorted_entries(cmi, torch_cuda, orc, golden_irregular):
+    """The host loop accepts any entry order (coo_spmv.h:59-67); so does the kernel."""
+    torch, g = torch_cuda, golden_irregular
+    rows, cols = int(g["rows"]), int(g["cols"])
+    Ap, Aj, Ax, x = (g[f"f64_{k}"] for k in ("Ap", "Aj", "Ax", "x"))
+    Ai = orc.csr_row_indices(Ap)
+    perm = np.random.default_rng(5).permutation(len(Ax))
+    bound = row_abs(orc, Ap, Aj, Ax, x)
+    for ipt in (1, 4):
+        y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
+        cmi.spmv_coo(rows, cols, dev(Ai[perm], torch), dev(Aj[perm], torch), dev(Ax[perm], torch), dev(x, torch), y,
+                     cfg=cmi.Config(kernel=cmi.COO_SEGMENTED, items_per_thread=ipt))
+        assert_close(host(y), g["f64_y_coo"], bound, np.float64, "coo unsorted")
+
+
+def test_non_default_stream(cmi, torch_cuda, golden_poisson, orc):
+    torch, g = torch_cuda, golden_poisson
+    Ap, Aj, Ax = orc.poisson5pt_csr(100, 100)
+    s = torch.cuda.Stream()
+    dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(g["f64_x"], torch)
+    y = torch.full((10000,), 10.0, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        cmi.spmv_csr(10000, 10000, dAp, dAj, dAx, dx, y)
+        cmi.spmv_csr(10000, 10000, dAp, dAj, dAx, dx, y, stream=s)
+    s.synchronize()
+    assert np.array_equal(host(y), g["f64_y_csr"])
+
+
+# ------------------------------------------------------------------------------------------------
+# on-device builders: integer outputs bit-exact vs the oracle's restatement of the reference
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n", [(2, 3), (10, 10), (1, 1), (1, 9), (9, 1), (117, 113), (100, 100)])
+def test_device_poisson_builder_matches_oracle(cmi, torch_cuda, orc, m, n):
+    torch = torch_cuda
+    N = m * n
+    Ap, Aj, Ax = orc.poisson5pt_csr(m, n)
+    A = cmi.poisson5pt(m, n, "csr")
+    assert A.num_entries == len(Ax) == 5 * m * n - 2 * m - 2 * n
+    assert np.array_equal(host(A.row_offsets), Ap) and np.array_equal(host(A.column_indices), Aj)
+    assert np.array_equal(host(A.values), Ax)
+    off, vals, nnz = orc.poisson5pt_dia(m, n)
+    D = cmi.poisson5pt(m, n, "dia")
+    assert D.num_entries == nnz and np.array_equal(host(D.diagonal_offsets), off) and np.array_equal(host(D.values), vals)
+    # row-block shards carry global columns and concatenate to the whole matrix
+    cuts = sorted({0, N // 3, N // 2, N - 1 if N > 1 else N, N})
+    parts = [cmi.poisson5pt(m, n, "csr", row_begin=a, row_end=b) for a, b in zip(cuts, cuts[1:])]
+    assert np.array_equal(np.concatenate([host(p.column_indices) for p in parts]), Aj)
+    assert np.array_equal(np.concatenate([host(p.row_offsets)[1:] + Ap[a] for p, a in zip(parts, cuts)]), Ap[1:])
+    # conversions
+    C = cmi.convert(A, "coo")
+    assert np.array_equal(host(C.row_indices), orc.csr_row_indices(Ap))
+    width = int(np.diff(Ap).max())
+    E = cmi.convert(A, "ell")
+    pitch, eAj, eAx = orc.csr_to_ell(Ap, Aj, Ax, width)
+    assert E.pitch == pitch and np.array_equal(host(E.column_indices), eAj) and np.array_equal(host(E.values), eAx)
+    for w in range(0, width + 1):
+        H = cmi.convert(A, "hyb", num_entries_per_row=w)
+        p, hAj, hAx, cAi, cAj, cAx = orc.csr_to_hyb(Ap, Aj, Ax, w)
+        assert np.array_equal(host(H.ell.column_indices), hAj) and np.array_equal(host(H.ell.values), hAx)
+        assert np.array_equal(host(H.coo.row_indices), cAi) and np.array_equal(host(H.coo.column_indices), cAj)
+        assert np.array_equal(host(H.coo.values), cAx)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json full size: poisson5pt 3162 x 3162 (N = 9 998 244, nnz = 49 978 572), fp64
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big(cmi, torch_cuda, orc):
+    import oracle
+    torch = torch_cuda
+    m = n = 3162
+    A = cmi.poisson5pt(m, n, "csr")
+    N = m * n
+    x = oracle.fill_x(N)
+    Ap, Aj, Ax = host(A.row_offsets), host(A.column_indices), host(A.values)
+    want = orc.spmv_csr(Ap, Aj, Ax, x, omp=True)
+    return dict(m=m, n=n, N=N, A=A, x=x, dx=dev(x, torch), want=want, Ap=Ap, Aj=Aj, Ax=Ax)
+
+
+def test_full_size_structure(cmi, big):
+    assert big["N"] == 9998244 and big["A"].num_entries == 49978572
+    Ap, Aj = big["Ap"], big["Aj"]
+    lens = np.diff(Ap)
+    assert lens.min() == 3 and lens.max() == 5 and Ap[-1] == 49978572
+    # spot-check rows against the closed form: corner, edge, interior
+    m = big["m"]
+    for r, cols in ((0, [0, 1, m]), (1, [0, 1, 2, m + 1]), (m + 5, [5, m + 4, m + 5, m + 6, 2 * m + 5])):
+        assert Aj[Ap[r]:Ap[r + 1]].tolist() == cols
+    assert big["Ax"].sum() == 4.0 * big["N"] - (Ap[-1] - big["N"])
+
+
+def test_full_size_csr_bit_exact_and_formats_agree(cmi, torch_cuda, orc, big):
+    torch = torch_cuda
+    A, dx, N, want = big["A"], big["dx"], big["N"], big["want"]
+    # sampled values + checksum recorded from the oracle run (pins the on-box oracle itself)
+    y = torch.full((N,), 10.0, dtype=torch.float64, device="cuda")
+    cmi.multiply(A, dx, y)  # NULL config -> tuning table
+    assert np.array_equal(host(y), want), "default CSR kernel is not bit-exact at full size"
+    for cfg in (cmi.Config(kernel=cmi.CSR_STREAM, items_per_thread=2, xcd_swizzle=1, nontemporal=1),
+                cmi.Config(kernel=cmi.CSR_STREAM, items_per_thread=4, block_size=512),
+                cmi.Config(kernel=cmi.CSR_SCALAR)):
+        y.fill_(10.0)
+        cmi.multiply(A, dx, y, cfg=cfg)
+        assert np.array_equal(host(y), want)
+    bound = 8.0 * np.abs(big["x"]).max() * np.ones(1)
+    for tpr in (4, 8, 64):
+        y.fill_(10.0)
+        cmi.multiply(A, dx, y, cfg=cmi.Config(kernel=cmi.CSR_VECTOR, threads_per_row=tpr))
+        assert np.max(np.abs(host(y) - want)) <= 1e-6 * bound[0]
+    # the other formats of the same matrix: ELL K=5 pitch 9 998 272, DIA, COO, HYB
+    E = cmi.convert(A, "ell")
+    assert E.pitch == 9998272 and E.num_entries_per_row == 5
+    y.fill_(10.0)
+    cmi.multiply(E, dx, y)
+    assert np.array_equal(host(y), want)
+    y.fill_(10.0)
+    cmi.multiply(E, dx, y, cfg=cmi.Config(kernel=cmi.ELL_ROW, items_per_thread=2, nontemporal=1))
+    assert np.array_equal(host(y), want)
+    del E
+    D = cmi.poisson5pt(big["m"], big["n"], "dia")
+    for rpl in (1, 2):
+        y.fill_(10.0)
+        cmi.multiply(D, dx, y, cfg=cmi.Config(kernel=cmi.DIA_ROW, items_per_thread=rpl))
+        assert np.array_equal(host(y), want)
+    del D
+    C = cmi.convert(A, "coo")
+    y.fill_(10.0)
+    cmi.multiply(C, dx, y)
+    assert np.max(np.abs(host(y) - want)) <= 1e-6 * bound[0]
+    del C
+    for w in (3, 4, 5):
+        H = cmi.convert(A, "hyb", num_entries_per_row=w)
+        assert H.coo.num_entries == int(np.maximum(np.diff(big["Ap"]) - w, 0).sum())
+        y.fill_(10.0)
+        cmi.multiply(H, dx, y)
+        assert np.max(np.abs(host(y) - want)) <= 1e-6 * bound[0]
+        del H
+
+
+def test_full_size_properties(cmi, torch_cuda, big):
+    """Size-independent properties: linearity, checksum through column sums, idempotence."""
+    torch = torch_cuda
+    A, N, dx = big["A"], big["N"], big["dx"]
+    y1 = torch.empty(N, dtype=torch.float64, device="cuda")
+    y2 = torch.empty_like(y1)
+    cmi.multiply(A, dx, y1)
+    cmi.multiply(A, dx, y2)
+    assert torch.equal(y1, y2)  # deterministic / idempotent
+    # A is symmetric with known column sums: sum(y) = sum_j colsum_j x_j, colsum_j = 4 - (#neighbours)
+    colsum = torch.zeros(N, dtype=torch.float64, device="cuda")
+    ones = torch.ones(N, dtype=torch.float64, device="cuda")
+    cmi.multiply(A, ones, colsum)  # row sums == column sums (symmetric)
+    lhs = float(y1.sum())
+    rhs = float((colsum * dx).sum())
+    assert abs(lhs - rhs) <= 1e-9 * float(dx.abs().sum())
+    # linearity: A(2x + 3*1) = 2 A x + 3 A 1, exact up to rounding of the scaled inputs
+    z = 2.0 * dx + 3.0 * ones
+    yz = torch.empty_like(y1)
+    cmi.multiply(A, z, yz)
+    assert float((yz - (2.0 * y1 + 3.0 * colsum)).abs().max()) <= 1e-12 * 32
+    # y += A x twice == 2 A x
+    acc = torch.zeros_like(y1)
+    cmi.multiply(A, dx, acc, accumulate=True)
+    cmi.multiply(A, dx, acc, accumulate=True)
+    assert float((acc - 2.0 * y1).abs().max()) <= 1e-12
+
+
+# ------------------------------------------------------------------------------------------------
+# BLAS-1 used by cg
+# ------------------------------------------------------------------------------------------------
+def test_blas1(cmi, torch_cuda):
+    torch = torch_cuda
+    rng = np.random.default_rng(1)
+    ws = cmi.blas_workspace()
+    res = torch.zeros(1, dtype=torch.float64, device="cuda")
+    for n in (1, 2, 63, 64, 1000, 100003, 4_000_001):
+        x, y = rng.standard_normal(n), rng.standard_normal(n)
+        dx, dy = dev(x, torch), dev(y, torch)
+        cmi.blas_dot(dx, dy, res, ws)
+        assert abs(float(res) - float(np.dot(x, y))) <= 1e-12 * float(np.abs(x * y).sum()) + 1e-300
+        cmi.blas_nrm2(dx, res, ws)
+        assert abs(float(res) - float(np.linalg.norm(x))) <= 1e-12 * float(np.linalg.norm(x))
+        cmi.blas_axpy(0.75, dx, dy)
+        assert np.array_equal(host(dy), 0.75 * x + y)  # one multiply + one add per element, unfused
+        dz = torch.empty_like(dx)
+        cmi.blas_axpby(2.0, dx, -0.5, dy, dz)
+        assert np.array_equal(host(dz), 2.0 * x + (-0.5) * (0.75 * x + y))
+        cmi.blas_copy(dz, dy)
+        assert torch.equal(dy, dz)
+        cmi.blas_fill(3.25, dy)
+        assert host(dy).tolist() == [3.25] * n if n < 100 else float(dy.min()) == 3.25 == float(dy.max())
+    # unaligned views fall back to scalar accesses
+    buf = torch.arange(1001, dtype=torch.float64, device="cuda")
+    v = buf[1:]
+    cmi.blas_dot(v, v, res, ws)
+    assert float(res) == float((np.arange(1, 1001, dtype=np.float64) ** 2).sum())

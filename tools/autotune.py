@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""Offline autotuner: replaces the reference's run-time KTT tuning layer
+(cusp/ktt/ktt.h:35-101 `tune`, cusp/system/cuda/ktt/multiply.h:107-154; parameter spaces in
+cusp/system/cuda/ktt/{csr,ell,dia,coo}_multiply.h) with a sweep that runs ONCE on an MI355X and
+persists its choices to cusp-autotuned_amd/tuned/gfx950.json -- the table the library consults
+when cmi_spmv_* is called with a NULL config.
+
+For every (format, dtype, matrix) it enumerates the kernel-variant x launch-shape space below,
+VALIDATES each configuration before timing it against the result of the simplest kernel of the
+library (csr_scalar, one lane per row, itself pinned bit-for-bit to the reference host loop by the
+test-suite) -- exactly what testing/ktt.cu:142-202 does: reference y from the stock multiply with
+the tuner disabled (:176-178), then every configuration compared with it; a configuration that
+fails validation is reported and never selected, times it with HIP events in interleaved rounds (guide rule 24), and records the fastest.
+
+    python tools/autotune.py [--quick] [--formats csr,ell,dia,coo] [--dtypes f64,f32]
+                             [--out cusp-autotuned_amd/tuned/gfx950.json] [--log gpurun_out/autotune.jsonl]
+
+Matrices: poisson5pt 3162x3162 (the headline workload; mean 5 entries/row) plus seeded synthetic CSR
+matrices with mean row lengths 2..96 so every bucket of the table gets a measured entry
+(the reference's performance/csr_vector/csr_vector.cu:41-62 sweeps D = 1..64 the same way).
+"""
+import argparse
+import ctypes
+import itertools
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def csr_space(cmi, mean, quick):
+    out = []
+    blocks = (256,) if quick else (128, 256, 512)
+    for b in blocks:
+        out.append(cmi.Config(kernel=cmi.CSR_SCALAR, block_size=b))
+    tprs = [t for t in (2, 4, 8, 16, 32, 64) if t <= max(2, 4 * mean) and 4 * t >= mean / 4]
+    for t, b, nt in itertools.product(tprs, blocks, (0, 1)):
+        out.append(cmi.Config(kernel=cmi.CSR_VECTOR, block_size=b, threads_per_row=t, nontemporal=nt))
+    if mean <= 40:
+        for b, ipt, nt, swz in itertools.product(blocks, (1, 2, 4), (0, 1), (0, 1)):
+            tile = b * ipt * 4
+            base = max(1, int((tile - 3) / max(mean, 0.25)))
+            rpbs = {min(base, 4 * b)}
+            if not quick:
+                rpbs |= {min(max(1, base * 3 // 4), 4 * b), min(b, base)}
+            for rpb in sorted(rpbs):
+                out.append(cmi.Config(kernel=cmi.CSR_STREAM, block_size=b, items_per_thread=ipt, rows_per_block=rpb,
+                                      nontemporal=nt, xcd_swizzle=swz))
+    return out
+
+
+def ell_space(cmi, quick):
+    return [cmi.Config(kernel=cmi.ELL_ROW, block_size=b, items_per_thread=r, nontemporal=nt)
+            for b, r, nt in itertools.product((256,) if quick else (128, 256, 512, 1024), (1, 2), (0, 1))]
+
+
+def dia_space(cmi, quick):
+    return [cmi.Config(kernel=cmi.DIA_ROW, block_size=b, items_per_thread=r, nontemporal=nt)
+            for b, r, nt in itertools.product((256,) if quick else (128, 256, 512, 1024), (1, 2), (0, 1))]
+
+
+def coo_space(cmi, quick):
+    return [cmi.Config(kernel=cmi.COO_SEGMENTED, block_size=b, items_per_thread=i, nontemporal=nt)
+            for b, i, nt in itertools.product((256,) if quick else (128, 256, 512), (1, 2, 4, 8, 16, 32), (0, 1))]
+
+
+class Timer:
+    def __init__(self, cmi, torch):
+        self.cmi, self.lib, self.torch = cmi, cmi.lib(), torch
+        self.e0, self.e1 = ctypes.c_void_p(), ctypes.c_void_p()
+        cmi.check(self.lib.cmi_event_create(ctypes.byref(self.e0)))
+        cmi.check(self.lib.cmi_event_create(ctypes.byref(self.e1)))
+
+    def time(self, fn, iters):
+        s = ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+        self.cmi.check(self.lib.cmi_event_record(self.e0, s))
+        for _ in range(iters):
+            fn()
+        self.cmi.check(self.lib.cmi_event_record(self.e1, s))
+        ms = ctypes.c_float()
+        self.cmi.check(self.lib.cmi_event_elapsed_ms(self.e0, self.e1, ctypes.byref(ms)))
+        return ms.value / iters
+
+
+def synthetic_csr(rows, cols, mean, seed, dtype):
+    rng = np.random.default_rng(seed)
+    lens = rng.poisson(mean, size=rows).astype(np.int64)
+    lens = np.minimum(lens, cols)
+    Ap = np.zeros(rows + 1, np.int32)
+    Ap[1:] = np.cumsum(lens)
+    nnz = int(Ap[-1])
+    # columns clustered around the diagonal (FEM-like locality), sorted within the row
+    centre = np.repeat(np.arange(rows, dtype=np.int64) * cols // rows, lens)
+    Aj = np.clip(centre + rng.integers(-2000, 2001, size=nnz), 0, cols - 1).astype(np.int32)
+    row_id = np.repeat(np.arange(rows, dtype=np.int64), lens)
+    order = np.lexsort((Aj, row_id))
+    Aj = Aj[order]
+    Ax = rng.standard_normal(nnz).astype(dtype)
+    return Ap, Aj, Ax
+
+
+def tune_one(cmi, torch, timer, label, space, run, check, iters, rounds, log, alg_bytes):
+    """validate, then interleaved timing rounds; returns (best_cfg, best_ms, results)."""
+    valid = []
+    for cfg in space:
+        try:
+            ok, note = check(cfg)
+        except cmi.CmiError as e:  # e.g. a tile that does not fit LDS: not a candidate
+            ok, note = False, f"rejected: {e}"
+        if ok:
+            valid.append(cfg)
+        else:
+            log({"label": label, "config": cfg.as_dict(), "status": "ValidationFailed", "note": note})
+    times = {id(c): [] for c in valid}
+    for _ in range(rounds):
+        for cfg in valid:
+            times[id(cfg)].append(timer.time(lambda: run(cfg), iters))
+    results = []
+    for cfg in valid:
+        t = times[id(cfg)]
+        rec = {"label": label, "config": cfg.as_dict(), "status": "Ok", "ms_min": min(t), "ms_median": float(np.median(t)),
+               "gbps_algorithmic": alg_bytes / (float(np.median(t)) * 1e-3) / 1e9}
+        log(rec)
+        results.append((float(np.median(t)), cfg, rec))
+    results.sort(key=lambda r: r[0])
+    return (results[0][1], results[0][0], results) if results else (None, None, [])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--formats", default="csr,ell,dia,coo")
+    ap.add_argument("--dtypes", default="f64,f32")
+    ap.add_argument("--out", default=os.path.join(ROOT, "cusp-autotuned_amd", "tuned", "gfx950.json"))
+    ap.add_argument("--log", default=os.path.join(ROOT, "gpurun_out", "autotune.jsonl"))
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--grid", type=int, default=3162)
+    ap.add_argument("--skip-synthetic", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import cusp_autotuned_amd as cmi
+
+    assert torch.cuda.is_available(), "the autotuner needs an MI355X"
+    scalar = cmi.Config(kernel=cmi.CSR_SCALAR)  # the validator: simplest kernel, tuner "disabled"
+    timer = Timer(cmi, torch)
+    os.makedirs(os.path.dirname(args.log), exist_ok=True)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    logf = open(args.log, "a")
+
+    def log(rec):
+        logf.write(json.dumps(rec) + "\n")
+        logf.flush()
+
+    cmi.tuning_clear()
+    formats = args.formats.split(",")
+    t_start = time.time()
+    summary = []
+    for tag in args.dtypes.split(","):
+        tdt = torch.float64 if tag == "f64" else torch.float32
+        ndt = np.float64 if tag == "f64" else np.float32
+        vb = 8 if tag == "f64" else 4
+        dcode = cmi.F64 if tag == "f64" else cmi.F32
+        m = n = args.grid
+        N = m * n
+        A = cmi.poisson5pt(m, n, "csr", dtype=tdt)
+        dx = cmi.fill_x(N, tdt, "cuda")
+        y = torch.empty(N, dtype=tdt, device="cuda")
+        cmi.multiply(A, dx, y, cfg=scalar)
+        want = y.cpu().numpy()
+        scale = float(np.abs(want).max())
+        tol = 1e-6 if tag == "f64" else 1e-5
+
+        def checker(mat, exact_kernels):
+            def check(cfg):
+                y.fill_(10.0)
+                cmi.multiply(mat, dx, y, cfg=cfg)
+                got = y.cpu().numpy()
+                if cfg.kernel in exact_kernels:
+                    return bool(np.array_equal(got, want)), "bit-exact required"
+                return bool(np.max(np.abs(got - want)) <= tol * scale), f"tolerance {tol}"
+            return check
+
+        if "csr" in formats:
+            label = f"csr/{tag}/poisson{m}x{n}"
+            best, ms, res = tune_one(cmi, torch, timer, label, csr_space(cmi, 5.0, args.quick),
+                                     lambda cfg: cmi.multiply(A, dx, y, cfg=cfg),
+                                     checker(A, (cmi.CSR_SCALAR, cmi.CSR_STREAM)), args.iters, args.rounds, log,
+                                     cmi.csr_bytes(N, A.num_entries, vb))
+            cmi.tuning_set(cmi.FORMAT_CSR, dcode, A.num_entries / N, best)
+            summary.append((label, best.as_dict(), ms))
+            print(label, best, f"{ms * 1e3:.1f} us", flush=True)
+        if "ell" in formats:
+            E = cmi.convert(A, "ell")
+            label = f"ell/{tag}/poisson{m}x{n}"
+            best, ms, res = tune_one(cmi, torch, timer, label, ell_space(cmi, args.quick),
+                                     lambda cfg: cmi.multiply(E, dx, y, cfg=cfg), checker(E, (cmi.ELL_ROW,)),
+                                     args.iters, args.rounds, log, cmi.ell_bytes(N, 5, E.pitch, vb))
+            for b in range(0, 8):  # ELL/DIA launch shape does not depend on the width: fill every bucket
+                cmi.tuning_set(cmi.FORMAT_ELL, dcode, 2.0 ** b * 1.2, best)
+            summary.append((label, best.as_dict(), ms))
+            print(label, best, f"{ms * 1e3:.1f} us", flush=True)
+            del E
+        if "dia" in formats:
+            D = cmi.poisson5pt(m, n, "dia", dtype=tdt)
+            label = f"dia/{tag}/poisson{m}x{n}"
+            best, ms, res = tune_one(cmi, torch, timer, label, dia_space(cmi, args.quick),
+                                     lambda cfg: cmi.multiply(D, dx, y, cfg=cfg), checker(D, (cmi.DIA_ROW,)),
+                                     args.iters, args.rounds, log, cmi.dia_bytes(N, 5, D.pitch, vb))
+            for b in range(0, 8):
+                cmi.tuning_set(cmi.FORMAT_DIA, dcode, 2.0 ** b * 1.2, best)
+            summary.append((label, best.as_dict(), ms))
+            print(label, best, f"{ms * 1e3:.1f} us", flush=True)
+            del D
+        if "coo" in formats:
+            C = cmi.convert(A, "coo")
+            label = f"coo/{tag}/poisson{m}x{n}"
+            best, ms, res = tune_one(cmi, torch, timer, label, coo_space(cmi, args.quick),
+                                     lambda cfg: cmi.multiply(C, dx, y, cfg=cfg), checker(C, ()),
+                                     args.iters, args.rounds, log, cmi.coo_bytes(N, A.num_entries, vb))
+            for b in range(0, 8):
+                cmi.tuning_set(cmi.FORMAT_COO, dcode, 2.0 ** b * 1.2, best)
+            summary.append((label, best.as_dict(), ms))
+            print(label, best, f"{ms * 1e3:.1f} us", flush=True)
+            del C
+        del A
+
+        # synthetic CSR matrices for the other mean-row-length buckets
+        if "csr" in formats and not args.skip_synthetic:
+            rows = cols = 2_000_000 if not args.quick else 400_000
+            for mean in (1.5, 3.0, 10.0, 24.0, 48.0, 96.0, 200.0):
+                r = rows if mean < 100 else rows // 4
+                Ap, Aj, Ax = synthetic_csr(r, r, mean, int(mean * 10), ndt)
+                S = cmi.CsrMatrix(r, r, len(Ax), torch.from_numpy(Ap).cuda(), torch.from_numpy(Aj).cuda(),
+                                  torch.from_numpy(Ax).cuda())
+                dxs = cmi.fill_x(r, tdt, "cuda")
+                ys = torch.empty(r, dtype=tdt, device="cuda")
+                cmi.multiply(S, dxs, ys, cfg=scalar)
+                wants = ys.cpu().numpy()
+                Sabs = cmi.CsrMatrix(r, r, len(Ax), S.row_offsets, S.column_indices, S.values.abs())
+                cmi.multiply(Sabs, dxs.abs(), ys, cfg=scalar)
+                bound = ys.cpu().numpy()
+                del Sabs
+
+                def check(cfg):
+                    ys.fill_(10.0)
+                    cmi.multiply(S, dxs, ys, cfg=cfg)
+                    got = ys.cpu().numpy()
+                    if cfg.kernel in (cmi.CSR_SCALAR, cmi.CSR_STREAM):
+                        return bool(np.array_equal(got, wants)), "bit-exact required"
+                    return bool(np.all(np.abs(got - wants) <= tol * np.maximum(bound, 1e-30))), f"tolerance {tol}"
+
+                label = f"csr/{tag}/synthetic_mean{mean}"
+                best, ms, res = tune_one(cmi, torch, timer, label, csr_space(cmi, mean, args.quick),
+                                         lambda cfg: cmi.multiply(S, dxs, ys, cfg=cfg), check, args.iters, args.rounds,
+                                         log, cmi.csr_bytes(r, len(Ax), vb))
+                if best is not None:
+                    cmi.tuning_set(cmi.FORMAT_CSR, dcode, len(Ax) / r, best)
+                    summary.append((label, best.as_dict(), ms))
+                    print(label, best, f"{ms * 1e3:.1f} us", flush=True)
+                del S, dxs, ys
+
+    cmi.tuning_save(args.out)
+    print(f"wrote {args.out} in {time.time() - t_start:.0f} s")
+    log({"summary": [{"label": l, "config": c, "ms": t} for l, c, t in summary]})
+
+
+if __name__ == "__main__":
+    main()
