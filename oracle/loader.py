@@ -77,6 +77,12 @@ class Oracle(_SpmvMixin):
         L.orc_csr_diagonals.argtypes = [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64]
         L.orc_csr_row_indices.argtypes = [c_int64, c_void_p, c_void_p]
         L.orc_num_threads.restype = c_int
+        L.orc_set_num_threads.argtypes = [c_int]
+        # size the OpenMP team to the CPU share of this process (a GPU box gives 16 of its cores)
+        try:
+            L.orc_set_num_threads(min(len(os.sched_getaffinity(0)), 64))
+        except AttributeError:
+            pass
         for s in ("f64", "f32"):
             getattr(L, f"orc_spmv_csr_{s}").argtypes = [c_int64] + [c_void_p] * 5 + [c_int]
             getattr(L, f"orc_spmv_csr_omp_{s}").argtypes = [c_int64] + [c_void_p] * 5 + [c_int]
@@ -100,6 +106,9 @@ class Oracle(_SpmvMixin):
 
     def num_threads(self):
         return int(self._lib.orc_num_threads())
+
+    def set_num_threads(self, n):
+        self._lib.orc_set_num_threads(int(n))
 
     # ---- SpMV ----
     def spmv_csr(self, Ap, Aj, Ax, x, y0=None, omp=False):

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Workload for the rocprofv3 --pmc passes (run under the profiler, one counter set per pass):
+launches the dominant SpMV kernel of bench.py (same matrix, same tuning-table config) N times, and a
+CALIBRATION kernel with an exactly known byte count in a comparable access pattern (axpby: 16-byte
+per-lane streaming reads of 2 vectors, 16-byte streaming writes of 1), so that FETCH_SIZE /
+WRITE_SIZE can be corrected as MI355X_MICROARCH.md (HBM section) prescribes before they are compared
+with algorithmic bytes.  Prints the known byte counts as JSON on the last line.
+
+    rocprofv3 --pmc FETCH_SIZE  --kernel-trace --output-format csv -d <dir> -o fetch -- python3 tools/pmc_probe.py
+    rocprofv3 --pmc WRITE_SIZE  --kernel-trace --output-format csv -d <dir> -o write -- python3 tools/pmc_probe.py
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import cusp_autotuned_amd as cmi  # noqa: E402
+
+fmt = sys.argv[1] if len(sys.argv) > 1 else "csr"
+M = 3162
+N = M * M
+A = cmi.poisson5pt(M, M, "csr")
+Afmt = A if fmt == "csr" else (cmi.poisson5pt(M, M, "dia") if fmt == "dia" else cmi.convert(A, fmt))
+x = cmi.fill_x(N, device="cuda")
+y = torch.empty(N, dtype=torch.float64, device="cuda")
+z = torch.empty(N, dtype=torch.float64, device="cuda")
+torch.cuda.synchronize()
+for _ in range(10):
+    cmi.multiply(Afmt, x, y)
+torch.cuda.synchronize()
+# calibration: z = 2x + 3y over 2^25 doubles (256 MiB per vector: far beyond the 256 MiB Infinity Cache in total)
+n_cal = 1 << 25
+a = torch.ones(n_cal, dtype=torch.float64, device="cuda")
+b = torch.ones(n_cal, dtype=torch.float64, device="cuda")
+c = torch.empty(n_cal, dtype=torch.float64, device="cuda")
+torch.cuda.synchronize()
+for _ in range(10):
+    cmi.blas_axpby(2.0, a, 3.0, b, c)
+torch.cuda.synchronize()
+alg = {"csr": cmi.csr_bytes(N, A.num_entries), "ell": cmi.ell_bytes(N, 5, 9998272), "dia": cmi.dia_bytes(N, 5, N),
+       "coo": cmi.coo_bytes(N, A.num_entries)}[fmt]
+print(json.dumps({"format": fmt, "spmv_algorithmic_bytes": alg, "spmv_read_bytes": alg - 8 * N, "spmv_write_bytes": 8 * N,
+                  "calibration_kernel": "axpby_kernel", "calibration_read_bytes": 16 * n_cal,
+                  "calibration_write_bytes": 8 * n_cal}))
