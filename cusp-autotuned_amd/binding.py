@@ -13,7 +13,7 @@ _lib = None
 FORMAT_CSR, FORMAT_ELL, FORMAT_DIA, FORMAT_COO, FORMAT_HYB = 0, 1, 2, 3, 4
 F64, F32 = 0, 1
 KERNEL_AUTO = 0
-CSR_SCALAR, CSR_VECTOR, CSR_STREAM = 1, 2, 3
+CSR_SCALAR, CSR_VECTOR, CSR_STREAM, CSR_STREAM_PIPE = 1, 2, 3, 4
 ELL_ROW, DIA_ROW, COO_SEGMENTED = 10, 20, 30
 
 
@@ -30,11 +30,11 @@ class Config(ctypes.Structure):
     _fields_ = [
         ("kernel", c_int32), ("block_size", c_int32), ("threads_per_row", c_int32),
         ("rows_per_block", c_int32), ("items_per_thread", c_int32), ("nontemporal", c_int32),
-        ("xcd_swizzle", c_int32), ("reserved", c_int32),
+        ("xcd_swizzle", c_int32), ("blocks_per_cu", c_int32),
     ]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
     def __repr__(self):
         return "Config(" + ", ".join(f"{k}={v}" for k, v in self.as_dict().items()) + ")"

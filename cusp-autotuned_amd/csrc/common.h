@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/cusp_mi355x.h"
 
@@ -68,10 +69,32 @@ typedef int __attribute__((ext_vector_type(2))) int2v;
 typedef double __attribute__((ext_vector_type(2))) double2v;
 typedef float __attribute__((ext_vector_type(4))) float4v;
 
+// cache policy of a kernel = cmi_config.nontemporal: bit 0 -> once-read matrix streams are loaded
+// with the nt hint, bit 1 -> y is stored with the nt hint (measured on MI355X: the y store is the
+// expensive 10 % of CSR SpMV's bytes; nt stores cut it by ~40 %, tools/csr_ablate.hip).
+constexpr int kPolLoadNT = 1, kPolStoreNT = 2;
+
 template <bool NT, typename V> __device__ __forceinline__ V ld(const V *p)
 {
     if constexpr (NT) return __builtin_nontemporal_load(p);
     else return *p;
+}
+
+template <bool NT, typename V> __device__ __forceinline__ void st(V *p, V v)
+{
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+// run `f(std::integral_constant<int, POL>)` for the runtime policy value 0..3
+template <typename F> inline void with_policy(int pol, F f)
+{
+    switch (pol & 3) {
+    case 0: f(std::integral_constant<int, 0>()); break;
+    case 1: f(std::integral_constant<int, 1>()); break;
+    case 2: f(std::integral_constant<int, 2>()); break;
+    default: f(std::integral_constant<int, 3>()); break;
+    }
 }
 
 } // namespace cmi

@@ -98,7 +98,7 @@ static int spmv_coo(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     const int waves_per_block = block / kWave;
     int64_t grid64 = ceil_div(waves, waves_per_block);
     if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_coo: grid too large");
-    if (c.nontemporal)
+    if (c.nontemporal & kPolLoadNT)
         hipLaunchKernelGGL((coo_segmented_kernel<T, true>), dim3((int)grid64), dim3(block), 0, s, nnz, Ai, Aj, Ax, x, y, interval);
     else
         hipLaunchKernelGGL((coo_segmented_kernel<T, false>), dim3((int)grid64), dim3(block), 0, s, nnz, Ai, Aj, Ax, x, y, interval);

@@ -25,7 +25,7 @@ namespace cmi {
 // ---------------------------------------------------------------------------------------------
 // csr_scalar
 // ---------------------------------------------------------------------------------------------
-template <typename T, bool NT>
+template <typename T, int POL>
 __global__ void __launch_bounds__(1024)
 csr_scalar_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ Aj,
                   const T *__restrict__ Ax, const T *__restrict__ x, T *__restrict__ y, int accumulate)
@@ -34,8 +34,9 @@ csr_scalar_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__res
     for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < num_rows; row += stride) {
         const int s = Ap[row], e = Ap[row + 1];
         T acc = accumulate ? y[row] : T(0);
+        constexpr bool NT = (POL & kPolLoadNT) != 0;
         for (int jj = s; jj < e; jj++) acc = acc + ld<NT>(Ax + jj) * x[ld<NT>(Aj + jj)];
-        y[row] = acc;
+        st<(POL & kPolStoreNT) != 0>(y + row, acc);
     }
 }
 
@@ -66,7 +67,7 @@ csr_vector_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__res
 // Tile = blockDim.x * IPT * 4 entries.  LDS: T prod[tile] then int rowptr[rows_per_block + 1].
 // VEC: Aj and Ax are 16-byte aligned, so entry index e with e % 4 == 0 is a 16-byte boundary in Aj
 // and a 32-byte boundary in Ax (f64) / 16-byte (f32): one int4 + two double2 (or one float4) per lane.
-template <typename T, int IPT, bool VEC, bool NT>
+template <typename T, int IPT, bool VEC, int POL>
 __global__ void __launch_bounds__(1024)
 csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ Ap,
                   const int *__restrict__ Aj, const T *__restrict__ Ax, const T *__restrict__ x,
@@ -74,6 +75,7 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
                   int swizzle, int accumulate)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool NT = (POL & kPolLoadNT) != 0;
     const int block = blockDim.x;
     const int tid = threadIdx.x;
     const int tile_entries = block * IPT * 4;
@@ -155,7 +157,162 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int r = tid + q * block;
-        if (r < nr) y[r0 + r] = acc[q];
+        if (r < nr) st<(POL & kPolStoreNT) != 0>(y + r0 + r, acc[q]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// csr_stream_pipe: persistent, software-pipelined csr_stream
+// ---------------------------------------------------------------------------------------------
+// The plain csr_stream workgroup pays three DEPENDENT global round trips per tile (row pointers ->
+// index/value streams -> x gather) and lives for one tile; with 8 workgroups per CU that leaves too
+// few bytes in flight to saturate HBM (measured 5.5 TB/s algorithmic with HBM traffic == compulsory
+// bytes, i.e. latency-bound, not traffic-bound).  Here a workgroup is persistent and walks tiles
+// t, t+G, t+2G, ...; while it multiplies and sums tile i it already has in flight
+//   * the 16-byte index/value vectors of tile i+1 (registers),
+//   * the row pointers of tile i+1 (one per lane, register), and
+//   * the two scalar tile bounds Ap[r0], Ap[r0+nr] of tile i+2 (wave-uniform -> scalar loads),
+// issued in that order AFTER the x gathers of tile i so the in-order vmcnt wait for the gathers
+// leaves them outstanding.  LDS (products + row pointers) is double-buffered: one barrier per tile.
+// Same arithmetic as csr_stream (one lane per row, storage order): bit-identical to the host loop.
+// Requires 16-byte aligned Aj/Ax and rows_per_block < blockDim.x; a tile whose entries do not fit
+// the LDS tile (possible only for irregular matrices) is summed straight from global memory.
+template <typename T> struct tile_regs {
+    int4v c;
+    T v0, v1, v2, v3;
+};
+
+// Unconditional 16-byte vector loads of entries [e, e+4): the caller clamps e to a valid, 4-aligned
+// position, so there is no branch between the loads (see the vmcnt note in the kernel).
+template <typename T, bool NT>
+__device__ __forceinline__ void load_tile_vectors(tile_regs<T> &r, const int *__restrict__ Aj,
+                                                  const T *__restrict__ Ax, int e)
+{
+    r.c = ld<NT>(reinterpret_cast<const int4v *>(Aj + e));
+    if constexpr (sizeof(T) == 8) {
+        const double2v a = ld<NT>(reinterpret_cast<const double2v *>(Ax + e));
+        const double2v b = ld<NT>(reinterpret_cast<const double2v *>(Ax + e + 2));
+        r.v0 = a.x; r.v1 = a.y; r.v2 = b.x; r.v3 = b.y;
+    } else {
+        const float4v a = ld<NT>(reinterpret_cast<const float4v *>(Ax + e));
+        r.v0 = a.x; r.v1 = a.y; r.v2 = a.z; r.v3 = a.w;
+    }
+}
+
+// vmcnt note.  gfx950 retires vector-memory operations in issue order and `s_waitcnt vmcnt(N)` waits
+// for all but the N youngest, so "wait for the x gathers but leave the next tile's loads in flight"
+// is only expressible if the number of loads issued after the gathers is the same on every path.
+// Hence: no branch around any load inside the loop (addresses are clamped instead; the last
+// iteration re-requests its own tile), and the tile bounds are fetched with a VECTOR load (lane 0:
+// Ap[r0], other lanes: Ap[r0+nr]) and broadcast with readlane -- a scalar load would share lgkmcnt
+// with the LDS traffic and force lgkmcnt(0) stalls.
+template <typename T, int POL, bool ACC>
+__global__ void __launch_bounds__(1024)
+csr_stream_pipe_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ Ap,
+                       const int *__restrict__ Aj, const T *__restrict__ Ax, const T *__restrict__ x,
+                       T *__restrict__ y, int rows_per_block, int64_t num_tiles, int chunked)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool NT = (POL & kPolLoadNT) != 0;
+    const int block = blockDim.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int tile_entries = block * 4;
+    T *prod = reinterpret_cast<T *>(smem);                                            // [2][tile_entries]
+    int *rowptr = reinterpret_cast<int *>(smem + 2 * (size_t)tile_entries * sizeof(T)); // [2][block]
+    const int last_vec = (int)((num_entries - 4) & ~(int64_t)3); // host guarantees num_entries >= 4
+
+    // tile schedule: strided (t, t+G, ...) or chunked (a contiguous run per workgroup)
+    int64_t tile, tile_end, tile_step;
+    if (chunked) {
+        const int64_t per = (num_tiles + gridDim.x - 1) / gridDim.x;
+        tile = (int64_t)blockIdx.x * per;
+        tile_end = tile + per < num_tiles ? tile + per : num_tiles;
+        tile_step = 1;
+    } else {
+        tile = blockIdx.x;
+        tile_end = num_tiles;
+        tile_step = gridDim.x;
+    }
+    if (tile >= tile_end) return;
+
+    auto rows_of = [&](int64_t t, int64_t &r0, int &nr) {
+        r0 = t * rows_per_block;
+        nr = (int)((num_rows - r0) < rows_per_block ? (num_rows - r0) : rows_per_block);
+    };
+    auto clamp_vec = [&](int e) { return e < last_vec ? e : last_vec; };
+    auto next_of = [&](int64_t t) { return t + tile_step < tile_end ? t + tile_step : t; };
+    auto load_bounds = [&](int64_t t) { // lane 0 of each wave: Ap[r0]; every other lane: Ap[r0+nr]
+        int64_t r0; int nr;
+        rows_of(t, r0, nr);
+        return Ap[r0 + (lane == 0 ? 0 : nr)];
+    };
+
+    // ---- prologue ----
+    int64_t r0_c; int nr_c;
+    rows_of(tile, r0_c, nr_c);
+    int bnd = load_bounds(tile);
+    int nz0_c = __builtin_amdgcn_readlane(bnd, 0), nz1_c = __builtin_amdgcn_readlane(bnd, 1);
+    tile_regs<T> cur;
+    load_tile_vectors<T, NT>(cur, Aj, Ax, clamp_vec((nz0_c & ~3) + tid * 4));
+    int rp_c = Ap[r0_c + (tid < nr_c ? tid : nr_c)];
+    bnd = load_bounds(next_of(tile)); // bounds of the second tile, consumed in iteration 0
+
+    int buf = 0;
+    for (;;) {
+        const int base = nz0_c & ~3;
+        // the tile fits one LDS pass and its last vector lies inside the arrays (wave-uniform)
+        const bool fits = (nz1_c - base <= tile_entries) && ((int64_t)((nz1_c + 3) & ~3) <= num_entries);
+        // every lane owns a row; lanes past the tile's last row shadow it (same value, same address)
+        const int rr = tid < nr_c ? tid : nr_c - 1;
+        // ---- A: gather x for the current tile (its vectors were requested one tile ago) ----
+        const T x0 = x[cur.c.x], x1 = x[cur.c.y], x2 = x[cur.c.z], x3 = x[cur.c.w];
+        T acc = T(0);
+        if constexpr (ACC) acc = y[r0_c + rr];
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- B: request the bounds of tile i+2, then the streams of tile i+1 ----
+        const int64_t tile_n = next_of(tile);
+        const bool has_next = tile_n != tile; // wave-uniform
+        int64_t r0_n; int nr_n;
+        rows_of(tile_n, r0_n, nr_n);
+        const int nz0_n = __builtin_amdgcn_readlane(bnd, 0), nz1_n = __builtin_amdgcn_readlane(bnd, 1);
+        bnd = load_bounds(next_of(tile_n));
+        tile_regs<T> nxt;
+        load_tile_vectors<T, NT>(nxt, Aj, Ax, clamp_vec((nz0_n & ~3) + tid * 4));
+        const int rp_n = Ap[r0_n + (tid < nr_n ? tid : nr_n)];
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- C: products and row pointers into this tile's LDS buffer (slots past the tile's
+        //         entries are written too -- nobody reads them -- so nothing here is conditional) ----
+        T *pbuf = prod + buf * tile_entries;
+        int *rbuf = rowptr + buf * block;
+        pbuf[tid * 4 + 0] = cur.v0 * x0; pbuf[tid * 4 + 1] = cur.v1 * x1;
+        pbuf[tid * 4 + 2] = cur.v2 * x2; pbuf[tid * 4 + 3] = cur.v3 * x3;
+        rbuf[tid] = rp_c;
+        __syncthreads();
+        // ---- E: one lane per row, storage order ----
+        {
+            const int a = rbuf[rr], b = rbuf[rr + 1];
+            if (fits) {
+                const T *p = pbuf + (a - base);
+                const int len = b - a;
+                T v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = k < len ? p[k] : T(0); // reads issue back to back
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (k < len) acc = acc + v[k];
+                for (int k = 8; k < len; k++) acc = acc + p[k];
+            } else { // oversized / array-tail tile: straight from global memory (correct, not fast)
+                for (int jj = a; jj < b; jj++) acc = acc + Ax[jj] * x[Aj[jj]];
+            }
+            st<(POL & kPolStoreNT) != 0>(y + r0_c + rr, acc);
+        }
+        if (!has_next) break;
+        // ---- rotate the pipeline ----
+        cur = nxt; rp_c = rp_n;
+        nz0_c = nz0_n; nz1_c = nz1_n;
+        r0_c = r0_n; nr_c = nr_n;
+        tile = tile_n;
+        buf ^= 1;
     }
 }
 
@@ -164,9 +321,13 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
 // ---------------------------------------------------------------------------------------------
 static int grid_for(int64_t work_items, int block, int items_per_block_thread = 1)
 {
-    // memory-bound grid-stride kernels: cap at 8 workgroups of 256 threads per CU (guide G11)
+    // One-shot grids: a workgroup per chunk of work, no grid-stride revisits.  Measured on MI355X
+    // (tools/membench.hip): streaming kernels launched with exactly as many workgroups as there is
+    // work reach 6.3-6.9 TB/s, the same kernels on a grid capped at 8 workgroups per CU and
+    // grid-strided 4.5-5.0 TB/s for stores.  The kernels keep their stride loop, so the cap below
+    // (2^22 workgroups) only matters for absurd sizes.
     int64_t blocks = ceil_div(work_items, (int64_t)block * items_per_block_thread);
-    const int64_t cap = (int64_t)kCus * 8 * 256 / block;
+    const int64_t cap = (int64_t)1 << 22;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
@@ -188,26 +349,21 @@ static int launch_vector(int tpr, int grid, int block, hipStream_t s, int64_t ro
     return CMI_SUCCESS;
 }
 
-template <typename T, int IPT, bool VEC, bool NT>
-static void launch_stream_one(int grid, int block, size_t lds, hipStream_t s, int64_t rows, int64_t nnz,
-                              const int *Ap, const int *Aj, const T *Ax, const T *x, T *y, int rpb, int64_t tiles,
-                              int64_t tpx, int swz, int acc)
-{
-    hipLaunchKernelGGL((csr_stream_kernel<T, IPT, VEC, NT>), dim3(grid), dim3(block), lds, s, rows, nnz, Ap, Aj, Ax,
-                       x, y, rpb, tiles, tpx, swz, acc);
-}
-
-template <typename T, bool VEC, bool NT>
+template <typename T, bool VEC, int POL>
 static int launch_stream_ipt(int ipt, int grid, int block, size_t lds, hipStream_t s, int64_t rows, int64_t nnz,
                              const int *Ap, const int *Aj, const T *Ax, const T *x, T *y, int rpb, int64_t tiles,
                              int64_t tpx, int swz, int acc)
 {
+#define CMI_STREAM_LAUNCH(IPT)                                                                                   \
+    hipLaunchKernelGGL((csr_stream_kernel<T, IPT, VEC, POL>), dim3(grid), dim3(block), lds, s, rows, nnz, Ap, Aj, \
+                       Ax, x, y, rpb, tiles, tpx, swz, acc)
     switch (ipt) {
-    case 1: launch_stream_one<T, 1, VEC, NT>(grid, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, acc); break;
-    case 2: launch_stream_one<T, 2, VEC, NT>(grid, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, acc); break;
-    case 4: launch_stream_one<T, 4, VEC, NT>(grid, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, acc); break;
+    case 1: CMI_STREAM_LAUNCH(1); break;
+    case 2: CMI_STREAM_LAUNCH(2); break;
+    case 4: CMI_STREAM_LAUNCH(4); break;
     default: return fail(CMI_ERROR_NOT_SUPPORTED, "csr_stream: items_per_thread must be 1, 2 or 4");
     }
+#undef CMI_STREAM_LAUNCH
     return CMI_SUCCESS;
 }
 
@@ -216,7 +372,7 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
                     const T *x, T *y, int accumulate, const cmi_config *user, void *stream)
 {
     if (rows < 0 || cols < 0 || nnz < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_csr: negative size");
-    if (rows > INT32_MAX || cols > INT32_MAX || nnz > INT32_MAX)
+    if (rows > INT32_MAX || cols > INT32_MAX || nnz > INT32_MAX - 65536)
         return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_csr: sizes exceed the int32 index type");
     if (rows == 0) return CMI_SUCCESS;
     if (!Ap || !y || (nnz > 0 && (!Aj || !Ax || !x)))
@@ -225,20 +381,22 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     select_config(CMI_FORMAT_CSR, dtype, rows, cols, nnz, user, &c);
     hipStream_t s = as_stream(stream);
     const int block = c.block_size;
-    const bool nt = c.nontemporal != 0;
+    const int pol = c.nontemporal & 3;
+    int st = CMI_SUCCESS;
 
     switch (c.kernel) {
     case CMI_CSR_SCALAR: {
         const int grid = grid_for(rows, block);
-        if (nt) hipLaunchKernelGGL((csr_scalar_kernel<T, true>), dim3(grid), dim3(block), 0, s, rows, Ap, Aj, Ax, x, y, accumulate);
-        else    hipLaunchKernelGGL((csr_scalar_kernel<T, false>), dim3(grid), dim3(block), 0, s, rows, Ap, Aj, Ax, x, y, accumulate);
+        with_policy(pol, [&](auto P) {
+            hipLaunchKernelGGL((csr_scalar_kernel<T, decltype(P)::value>), dim3(grid), dim3(block), 0, s, rows, Ap, Aj, Ax, x, y, accumulate);
+        });
         break;
     }
     case CMI_CSR_VECTOR: {
         const int tpr = c.threads_per_row;
         const int grid = grid_for(rows * tpr, block);
-        int st = nt ? launch_vector<T, true>(tpr, grid, block, s, rows, Ap, Aj, Ax, x, y, accumulate)
-                    : launch_vector<T, false>(tpr, grid, block, s, rows, Ap, Aj, Ax, x, y, accumulate);
+        st = (pol & kPolLoadNT) ? launch_vector<T, true>(tpr, grid, block, s, rows, Ap, Aj, Ax, x, y, accumulate)
+                                : launch_vector<T, false>(tpr, grid, block, s, rows, Ap, Aj, Ax, x, y, accumulate);
         if (st) return st;
         break;
     }
@@ -254,12 +412,30 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         const size_t lds = (size_t)block * ipt * 4 * sizeof(T) + (size_t)(rpb + 1) * sizeof(int);
         if (lds > 160 * 1024) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream: tile does not fit 160 KiB of LDS");
         const bool vec = (reinterpret_cast<uintptr_t>(Aj) % 16 == 0) && (reinterpret_cast<uintptr_t>(Ax) % 16 == 0);
-        int st;
-        if (vec) st = nt ? launch_stream_ipt<T, true, true>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate)
-                         : launch_stream_ipt<T, true, false>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate);
-        else     st = nt ? launch_stream_ipt<T, false, true>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate)
-                         : launch_stream_ipt<T, false, false>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate);
+        with_policy(pol, [&](auto P) {
+            constexpr int POL = decltype(P)::value;
+            st = vec ? launch_stream_ipt<T, true, POL>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate)
+                     : launch_stream_ipt<T, false, POL>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate);
+        });
         if (st) return st;
+        break;
+    }
+    case CMI_CSR_STREAM_PIPE: {
+        const int rpb = c.rows_per_block;
+        if (rpb < 1 || rpb >= block) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream_pipe: rows_per_block must be in [1, block_size-1]");
+        const bool vec = (reinterpret_cast<uintptr_t>(Aj) % 16 == 0) && (reinterpret_cast<uintptr_t>(Ax) % 16 == 0);
+        if (!vec || nnz < 4) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream_pipe: needs 16-byte aligned Aj/Ax and >= 4 entries (use CMI_CSR_STREAM)");
+        const int64_t tiles = ceil_div(rows, rpb);
+        const size_t lds = 2 * ((size_t)block * 4 * sizeof(T) + (size_t)block * sizeof(int));
+        const int bpc = c.blocks_per_cu > 0 ? c.blocks_per_cu : 8;
+        int64_t grid64 = (int64_t)kCus * bpc;
+        if (grid64 > tiles) grid64 = tiles;
+        const int chunked = c.xcd_swizzle != 0;
+        with_policy(pol, [&](auto P) {
+            constexpr int POL = decltype(P)::value;
+            if (accumulate) hipLaunchKernelGGL((csr_stream_pipe_kernel<T, POL, true>), dim3((int)grid64), dim3(block), lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, chunked);
+            else            hipLaunchKernelGGL((csr_stream_pipe_kernel<T, POL, false>), dim3((int)grid64), dim3(block), lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, chunked);
+        });
         break;
     }
     default: return fail(CMI_ERROR_NOT_SUPPORTED, "cmi_spmv_csr: config.kernel is not a CSR kernel");

@@ -20,11 +20,12 @@ namespace cmi {
 // ---------------------------------------------------------------------------------------------
 // ELL: one lane per row (RPL rows per lane)
 // ---------------------------------------------------------------------------------------------
-template <typename T, int RPL, bool ELLR, bool NT>
+template <typename T, int RPL, bool ELLR, int POL>
 __global__ void __launch_bounds__(1024)
 ell_row_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict__ Aj, const T *__restrict__ Ax,
                const int *__restrict__ row_lengths, const T *__restrict__ x, T *__restrict__ y, int accumulate)
 {
+    constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * RPL;
     for (int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * RPL; row < num_rows; row += stride) {
         if constexpr (RPL == 1) {
@@ -36,7 +37,7 @@ ell_row_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict
                 const T v = ld<NT>(Ax + n * pitch + row);
                 if (ELLR || col != -1) acc = acc + v * x[col];
             }
-            y[row] = acc;
+            st<NTS>(y + row, acc);
         } else {
             // rows row, row+1 (pitch even and arrays 16-byte aligned: checked by the launcher)
             typedef typename vec2<T>::type T2;
@@ -52,8 +53,13 @@ ell_row_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict
                 if (ELLR ? (n < len0) : (c.x != -1)) acc0 = acc0 + v.x * x[c.x];
                 if (ELLR ? (n < len1) : (c.y != -1 && has1)) acc1 = acc1 + v.y * x[c.y];
             }
-            y[row] = acc0;
-            if (has1) y[row + 1] = acc1;
+            if (has1 && (reinterpret_cast<uintptr_t>(y + row) % (2 * sizeof(T)) == 0)) {
+                T2 o; o.x = acc0; o.y = acc1;
+                st<NTS>(reinterpret_cast<T2 *>(y + row), o); // one 16-byte (f64) store for the row pair
+            } else {
+                st<NTS>(y + row, acc0);
+                if (has1) st<NTS>(y + row + 1, acc1);
+            }
         }
     }
 }
@@ -63,12 +69,13 @@ ell_row_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict
 // ---------------------------------------------------------------------------------------------
 constexpr int kDiaChunk = 256;
 
-template <typename T, bool NT>
+template <typename T, int POL>
 __global__ void __launch_bounds__(1024)
 dia_row_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t pitch,
                const int *__restrict__ offsets, const T *__restrict__ vals, const T *__restrict__ x,
                T *__restrict__ y, int accumulate)
 {
+    constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
     __shared__ int soff[kDiaChunk];
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = row < num_rows;
@@ -86,17 +93,18 @@ dia_row_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t pi
             }
         }
     }
-    if (live) y[row] = acc;
+    if (live) st<NTS>(y + row, acc);
 }
 
 // two rows per lane: values as T2 vectors; x for the second row is the neighbouring element
-template <typename T, bool NT>
+template <typename T, int POL>
 __global__ void __launch_bounds__(1024)
 dia_row2_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t pitch,
                 const int *__restrict__ offsets, const T *__restrict__ vals, const T *__restrict__ x,
                 T *__restrict__ y, int accumulate)
 {
     typedef typename vec2<T>::type T2;
+    constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
     __shared__ int soff[kDiaChunk];
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     const bool live0 = row < num_rows, live1 = row + 1 < num_rows;
@@ -117,8 +125,13 @@ dia_row2_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t p
             }
         }
     }
-    if (live0) y[row] = acc0;
-    if (live1) y[row + 1] = acc1;
+    if (live1 && (reinterpret_cast<uintptr_t>(y + row) % (2 * sizeof(T)) == 0)) {
+        T2 o; o.x = acc0; o.y = acc1;
+        st<NTS>(reinterpret_cast<T2 *>(y + row), o);
+    } else {
+        if (live0) st<NTS>(y + row, acc0);
+        if (live1) st<NTS>(y + row + 1, acc1);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -140,28 +153,25 @@ static int spmv_ell(int dtype, int64_t rows, int64_t cols, int64_t width, int64_
     if (c.kernel != CMI_ELL_ROW) return fail(CMI_ERROR_NOT_SUPPORTED, "cmi_spmv_ell: config.kernel is not an ELL kernel");
     hipStream_t s = as_stream(stream);
     const int block = c.block_size;
-    const bool nt = c.nontemporal != 0;
+    const int pol = c.nontemporal & 3;
     const bool ellr = row_lengths != nullptr;
     int rpl = c.items_per_thread >= 2 ? 2 : 1;
     // two rows per lane needs 8-byte aligned int2 and 2*sizeof(T)-aligned value pairs in every slot
     if (rpl == 2 && !(pitch % 2 == 0 && reinterpret_cast<uintptr_t>(Aj) % 8 == 0 &&
                       reinterpret_cast<uintptr_t>(Ax) % (2 * sizeof(T)) == 0))
         rpl = 1;
-    int64_t blocks = ceil_div(rows, (int64_t)block * rpl);
-    const int64_t cap = (int64_t)kCus * 16 * 256 / block;
+    int64_t blocks = ceil_div(rows, (int64_t)block * rpl); // one-shot grid (see spmv_csr.hip grid_for)
+    const int64_t cap = (int64_t)1 << 22;
     if (blocks > cap) blocks = cap;
     const int grid = (int)blocks;
     const int w = (int)width;
-#define CMI_ELL_LAUNCH(RPL, ELLR, NT)                                                                         \
-    hipLaunchKernelGGL((ell_row_kernel<T, RPL, ELLR, NT>), dim3(grid), dim3(block), 0, s, rows, w, pitch, Aj, Ax, \
-                       row_lengths, x, y, accumulate)
-    if (rpl == 1) {
-        if (ellr) { if (nt) CMI_ELL_LAUNCH(1, true, true); else CMI_ELL_LAUNCH(1, true, false); }
-        else      { if (nt) CMI_ELL_LAUNCH(1, false, true); else CMI_ELL_LAUNCH(1, false, false); }
-    } else {
-        if (ellr) { if (nt) CMI_ELL_LAUNCH(2, true, true); else CMI_ELL_LAUNCH(2, true, false); }
-        else      { if (nt) CMI_ELL_LAUNCH(2, false, true); else CMI_ELL_LAUNCH(2, false, false); }
-    }
+#define CMI_ELL_LAUNCH(RPL, ELLR)                                                                             \
+    with_policy(pol, [&](auto P) {                                                                                \
+        hipLaunchKernelGGL((ell_row_kernel<T, RPL, ELLR, decltype(P)::value>), dim3(grid), dim3(block), 0, s, rows, w, \
+                           pitch, Aj, Ax, row_lengths, x, y, accumulate);                                         \
+    })
+    if (rpl == 1) { if (ellr) CMI_ELL_LAUNCH(1, true); else CMI_ELL_LAUNCH(1, false); }
+    else          { if (ellr) CMI_ELL_LAUNCH(2, true); else CMI_ELL_LAUNCH(2, false); }
 #undef CMI_ELL_LAUNCH
     CMI_LAUNCH_CHECK("ell spmv");
     return CMI_SUCCESS;
@@ -182,19 +192,17 @@ static int spmv_dia(int dtype, int64_t rows, int64_t cols, int64_t ndiag, int64_
     if (c.kernel != CMI_DIA_ROW) return fail(CMI_ERROR_NOT_SUPPORTED, "cmi_spmv_dia: config.kernel is not a DIA kernel");
     hipStream_t s = as_stream(stream);
     const int block = c.block_size;
-    const bool nt = c.nontemporal != 0;
+    const int pol = c.nontemporal & 3;
     int rpl = c.items_per_thread >= 2 ? 2 : 1;
     if (rpl == 2 && !(pitch % 2 == 0 && reinterpret_cast<uintptr_t>(vals) % (2 * sizeof(T)) == 0)) rpl = 1;
     const int64_t grid64 = ceil_div(rows, (int64_t)block * rpl);
     if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_dia: grid too large");
     const int grid = (int)grid64, nd = (int)ndiag;
-    if (rpl == 1) {
-        if (nt) hipLaunchKernelGGL((dia_row_kernel<T, true>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate);
-        else    hipLaunchKernelGGL((dia_row_kernel<T, false>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate);
-    } else {
-        if (nt) hipLaunchKernelGGL((dia_row2_kernel<T, true>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate);
-        else    hipLaunchKernelGGL((dia_row2_kernel<T, false>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate);
-    }
+    with_policy(pol, [&](auto P) {
+        constexpr int POL = decltype(P)::value;
+        if (rpl == 1) hipLaunchKernelGGL((dia_row_kernel<T, POL>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate);
+        else          hipLaunchKernelGGL((dia_row2_kernel<T, POL>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate);
+    });
     CMI_LAUNCH_CHECK("dia spmv");
     return CMI_SUCCESS;
 }

@@ -58,7 +58,7 @@ static void heuristic(int format, int dtype, double mean, cmi_config *c)
             // short rows: stream the nnz tile through LDS, one lane sums one row in storage order
             c->kernel = CMI_CSR_STREAM;
             c->items_per_thread = 1;
-            c->xcd_swizzle = 1;
+            c->nontemporal = kPolStoreNT; // measured: nt y stores, plain loads, no XCD swizzle
         } else {
             // long rows: a sub-wave per row (the reference's selector, extended to the 64-wide wave)
             c->kernel = CMI_CSR_VECTOR;
@@ -97,6 +97,18 @@ static void complete(int format, int dtype, int64_t rows, int64_t nnz, cmi_confi
             while (p < t && p < 64) p <<= 1;
             c->threads_per_row = p;
         }
+        if (c->kernel == CMI_CSR_STREAM_PIPE) {
+            c->items_per_thread = 1;
+            if (c->rows_per_block <= 0) {
+                const int64_t tile = (int64_t)c->block_size * 4;
+                double r = mean > 0.0 ? std::floor((double)(tile - 3) / mean) : (double)(c->block_size - 1);
+                if (r > c->block_size - 1) r = c->block_size - 1; // one row pointer per lane
+                if (r >= 32.0) r = std::floor(r / 16.0) * 16.0;   // whole 128-byte lines of y per tile
+                if (r < 1.0) r = 1.0;
+                c->rows_per_block = (int)r;
+            }
+            if (c->blocks_per_cu <= 0) c->blocks_per_cu = 8;
+        }
         if (c->kernel == CMI_CSR_STREAM) {
             int ipt = c->items_per_thread;
             c->items_per_thread = ipt <= 1 ? 1 : ipt <= 2 ? 2 : 4;
@@ -107,6 +119,7 @@ static void complete(int format, int dtype, int64_t rows, int64_t nnz, cmi_confi
                 double r = mean > 0.0 ? std::floor((double)(tile - 3) / mean) : (double)c->block_size;
                 const double max_rows = 4.0 * c->block_size; // a lane sums at most 4 rows
                 if (r > max_rows) r = max_rows;
+                if (r >= 32.0) r = std::floor(r / 16.0) * 16.0; // whole 128-byte lines of y per tile
                 if (r < 1.0) r = 1.0;
                 c->rows_per_block = (int)r;
             }
@@ -185,6 +198,7 @@ static int load_file(const char *path)
                 if (find_int(obj, "items_per_thread", &v)) c.items_per_thread = (int)v;
                 if (find_int(obj, "nontemporal", &v)) c.nontemporal = (int)v;
                 if (find_int(obj, "xcd_swizzle", &v)) c.xcd_swizzle = (int)v;
+                if (find_int(obj, "blocks_per_cu", &v)) c.blocks_per_cu = (int)v;
                 g_table.cfg[fi][di][bucket] = c;
                 g_table.valid[fi][di][bucket] = true;
                 loaded++;
@@ -274,9 +288,10 @@ CMI_API int cmi_tuning_save(const char *path)
                 std::fprintf(f,
                              "%s    {\"format\": \"%s\", \"dtype\": \"%s\", \"bucket\": %d, \"kernel\": %d, "
                              "\"block_size\": %d, \"threads_per_row\": %d, \"rows_per_block\": %d, "
-                             "\"items_per_thread\": %d, \"nontemporal\": %d, \"xcd_swizzle\": %d}",
+                             "\"items_per_thread\": %d, \"nontemporal\": %d, \"xcd_swizzle\": %d, \"blocks_per_cu\": %d}",
                              first ? "" : ",\n", kFormatNames[fi], kDtypeNames[di], b, c.kernel, c.block_size,
-                             c.threads_per_row, c.rows_per_block, c.items_per_thread, c.nontemporal, c.xcd_swizzle);
+                             c.threads_per_row, c.rows_per_block, c.items_per_thread, c.nontemporal, c.xcd_swizzle,
+                             c.blocks_per_cu);
                 first = false;
             }
     std::fprintf(f, "\n  ]\n}\n");

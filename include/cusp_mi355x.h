@@ -98,6 +98,7 @@ typedef enum cmi_kernel {
     CMI_CSR_SCALAR = 1, /* one lane per row          (ref: csr_scalar.h:51-73)                   */
     CMI_CSR_VECTOR = 2, /* threads_per_row lanes/row (ref: csr_vector_spmv.h:71-161, THREADS_PER_ROW) */
     CMI_CSR_STREAM = 3, /* LDS-staged nnz tile, sequential per-row sum (bit-exact vs host order) */
+    CMI_CSR_STREAM_PIPE = 4, /* persistent, software-pipelined csr_stream (next tile's streams in flight) */
     /* ELL */
     CMI_ELL_ROW = 10, /* one lane per row            (ref: ell_spmv.h:55-93)                     */
     /* DIA */
@@ -114,9 +115,10 @@ typedef struct cmi_config {
     int32_t rows_per_block;   /* CSR stream: rows per workgroup tile; 0 = from mean row length     */
     int32_t items_per_thread; /* CSR stream: 16-byte index vectors per lane per pass (1,2,4);
                                  ELL/DIA: rows per lane (1,2); COO: entries per lane; 0 = default   */
-    int32_t nontemporal;      /* 1 = load the once-read matrix streams with the nt hint            */
+    int32_t nontemporal;      /* cache policy bits: 1 = once-read matrix streams loaded with the nt
+                                 hint, 2 = y stored with the nt hint (3 = both)                     */
     int32_t xcd_swizzle;      /* 1 = give each XCD a contiguous run of tiles (L2 reuse of x)       */
-    int32_t reserved;
+    int32_t blocks_per_cu;    /* persistent kernels: workgroups per CU in the grid; 0 = default (8)  */
 } cmi_config;
 
 /* Persisted tuning table (replaces the in-process KTT tuner state,              */

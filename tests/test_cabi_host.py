@@ -80,10 +80,11 @@ def test_poisson_entry_counts(cmi):
 
 def test_tuning_heuristics_and_table_roundtrip(cmi, tmp_path):
     cmi.tuning_clear()
-    # 5-pt Poisson CSR: short rows -> the LDS-staged stream kernel, one pass fits 204 rows of 5
+    # 5-pt Poisson CSR: short rows -> the LDS-staged stream kernel; one pass fits 204 rows of 5,
+    # rounded down to whole 128-byte lines of y (192 rows); y stored with the nt hint
     c = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 9998244, 9998244, 49978572)
     assert c.kernel == cmi.CSR_STREAM and c.block_size == 256 and c.items_per_thread == 1
-    assert c.rows_per_block == 204
+    assert c.rows_per_block == 192 and c.nontemporal == 2
     # long rows -> a sub-wave per row, wave64-wide at the top
     c = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 100000)
     assert c.kernel == cmi.CSR_VECTOR and c.threads_per_row == 64

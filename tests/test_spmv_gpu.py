@@ -50,18 +50,23 @@ def assert_close(y, want, bound, dtype, what=""):
 def csr_variants(cmi, small=False):
     """Every CSR kernel variant worth distinguishing (launch shape x load policy)."""
     out = []
-    for blk, nt in itertools.product((64, 256, 1024), (0, 1)):
+    for blk, nt in itertools.product((64, 256, 1024), (0, 1, 2, 3)):
         out.append(("scalar", True, cmi.Config(kernel=cmi.CSR_SCALAR, block_size=blk, nontemporal=nt)))
     for tpr in (2, 4, 8, 16, 32, 64):
         for blk in ((256,) if small else (128, 256, 512)):
             out.append((f"vector{tpr}", False, cmi.Config(kernel=cmi.CSR_VECTOR, block_size=blk, threads_per_row=tpr)))
     out.append(("vector8nt", False, cmi.Config(kernel=cmi.CSR_VECTOR, block_size=256, threads_per_row=8, nontemporal=1)))
     for blk, ipt, rpb, nt, swz in ((256, 1, 0, 0, 1), (256, 1, 0, 1, 0), (256, 2, 0, 0, 1), (256, 4, 0, 0, 0),
-                                   (128, 1, 0, 0, 1), (512, 1, 0, 0, 1), (64, 1, 7, 0, 1), (256, 1, 1, 0, 0),
-                                   (256, 1, 1024, 0, 1), (128, 2, 512, 1, 1), (1024, 1, 300, 0, 1)):
+                                   (128, 1, 0, 0, 1), (512, 1, 0, 0, 1), (64, 1, 7, 2, 1), (256, 1, 1, 0, 0),
+                                   (256, 1, 1024, 3, 1), (128, 2, 512, 1, 1), (1024, 1, 300, 0, 1), (256, 1, 192, 2, 0)):
         out.append((f"stream b{blk} i{ipt} r{rpb} nt{nt} x{swz}", True,
                     cmi.Config(kernel=cmi.CSR_STREAM, block_size=blk, items_per_thread=ipt, rows_per_block=rpb,
                                nontemporal=nt, xcd_swizzle=swz)))
+    for blk, rpb, nt, chunked, bpc in ((256, 0, 0, 0, 0), (256, 0, 1, 1, 4), (128, 0, 0, 0, 8), (512, 0, 0, 1, 2),
+                                       (64, 7, 2, 0, 1), (256, 255, 3, 0, 16), (256, 1, 1, 1, 3), (1024, 300, 0, 0, 1), (256, 192, 2, 0, 3)):
+        out.append((f"pipe b{blk} r{rpb} nt{nt} c{chunked} bpc{bpc}", True,
+                    cmi.Config(kernel=cmi.CSR_STREAM_PIPE, block_size=blk, rows_per_block=rpb, nontemporal=nt,
+                               xcd_swizzle=chunked, blocks_per_cu=bpc)))
     return out
 
 
@@ -105,7 +110,7 @@ def run_all_formats(cmi, torch, orc, rows, cols, Ap, Aj, Ax, x, want, want_acc, 
     cmi.ell_row_lengths(rows, width, pitch, deAj, rl)
     assert np.array_equal(host(rl), np.diff(Ap).astype(np.int32)), f"{label}: ELLR row lengths"
     for acc, w in ((False, want["ell"]), (True, want_acc["ell"])):
-        for rpl, nt, ellr, blk in itertools.product((1, 2), (0, 1), (False, True), (256,)):
+        for rpl, nt, ellr, blk in itertools.product((1, 2), (0, 1, 2, 3), (False, True), (256,)):
             y = fresh(acc)
             cmi.spmv_ell(rows, cols, width, pitch, deAj, deAx, dx, y, row_lengths=rl if ellr else None, accumulate=acc,
                          cfg=cmi.Config(kernel=cmi.ELL_ROW, block_size=blk, items_per_thread=rpl, nontemporal=nt))
@@ -137,7 +142,7 @@ def test_poisson_100x100_golden_all_formats(cmi, torch_cuda, orc, golden_poisson
     # DIA: gallery layout (pitch = N), 1 and 2 rows per lane, both load policies -- bit-exact
     doff, dvals, dx = dev(off, torch), dev(vals, torch), dev(x, torch)
     for acc, w in ((False, want["dia"]), (True, want_acc["dia"])):
-        for rpl, nt, blk in itertools.product((1, 2), (0, 1), (64, 256)):
+        for rpl, nt, blk in itertools.product((1, 2), (0, 1, 2, 3), (64, 256)):
             y = dev(y0, torch).clone() if acc else torch.full((N,), 10.0, dtype=dx.dtype, device="cuda")
             cmi.spmv_dia(N, N, 5, N, doff, dvals, dx, y, accumulate=acc,
                          cfg=cmi.Config(kernel=cmi.DIA_ROW, block_size=blk, items_per_thread=rpl, nontemporal=nt))
@@ -161,7 +166,7 @@ def test_banded_dia_golden(cmi, torch_cuda, golden_banded, tag):
     off, vals, x, y0 = g["offsets"], g[f"{tag}_vals"], g[f"{tag}_x"], g[f"{tag}_y0"]
     doff, dvals, dx = dev(off, torch), dev(vals, torch), dev(x, torch)
     for acc, w in ((False, g[f"{tag}_y"]), (True, g[f"{tag}_yacc"])):
-        for rpl, nt in itertools.product((1, 2), (0, 1)):
+        for rpl, nt in itertools.product((1, 2), (0, 2, 3)):
             y = dev(y0, torch).clone() if acc else torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
             cmi.spmv_dia(rows, cols, len(off), pitch, doff, dvals, dx, y, accumulate=acc,
                          cfg=cmi.Config(kernel=cmi.DIA_ROW, items_per_thread=rpl, nontemporal=nt))
@@ -203,6 +208,10 @@ def test_reference_known_answer_matrices(cmi, torch_cuda, orc, known):
             dx = dev(x, torch)
             dAp, dAj, dAx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch)
             for _, _, cfg in csr_variants(cmi, small=True) + [("auto", True, None)]:
+                if cfg is not None and cfg.kernel == cmi.CSR_STREAM_PIPE and len(Ax) < 4:
+                    with pytest.raises(cmi.CmiError):  # documented precondition, reported -- never a silent fallback
+                        cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, torch.zeros(rows, dtype=dx.dtype, device="cuda"), cfg=cfg)
+                    continue
                 y = torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
                 cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, cfg=cfg)
                 assert np.array_equal(host(y), want), (case["name"], cfg)  # small integers: exact in any order
@@ -417,6 +426,8 @@ def test_full_size_csr_bit_exact_and_formats_agree(cmi, torch_cuda, orc, big):
     assert np.array_equal(host(y), want), "default CSR kernel is not bit-exact at full size"
     for cfg in (cmi.Config(kernel=cmi.CSR_STREAM, items_per_thread=2, xcd_swizzle=1, nontemporal=1),
                 cmi.Config(kernel=cmi.CSR_STREAM, items_per_thread=4, block_size=512),
+                cmi.Config(kernel=cmi.CSR_STREAM_PIPE), cmi.Config(kernel=cmi.CSR_STREAM_PIPE, xcd_swizzle=1, blocks_per_cu=4),
+                cmi.Config(kernel=cmi.CSR_STREAM_PIPE, block_size=512, nontemporal=1, blocks_per_cu=3),
                 cmi.Config(kernel=cmi.CSR_SCALAR)):
         y.fill_(10.0)
         cmi.multiply(A, dx, y, cfg=cfg)

@@ -42,26 +42,34 @@ def csr_space(cmi, mean, quick):
     for t, b, nt in itertools.product(tprs, blocks, (0, 1)):
         out.append(cmi.Config(kernel=cmi.CSR_VECTOR, block_size=b, threads_per_row=t, nontemporal=nt))
     if mean <= 40:
-        for b, ipt, nt, swz in itertools.product(blocks, (1, 2, 4), (0, 1), (0, 1)):
+        for b, ipt, nt, swz in itertools.product(blocks, (1, 2, 4), (0, 2) if quick else (0, 1, 2, 3), (0, 1)):
             tile = b * ipt * 4
             base = max(1, int((tile - 3) / max(mean, 0.25)))
-            rpbs = {min(base, 4 * b)}
+            aligned = max(1, base // 16 * 16)
+            rpbs = {min(aligned, 4 * b)}
             if not quick:
-                rpbs |= {min(max(1, base * 3 // 4), 4 * b), min(b, base)}
+                rpbs |= {min(base, 4 * b), min(max(1, aligned - 16), 4 * b), min(b, base)}
             for rpb in sorted(rpbs):
                 out.append(cmi.Config(kernel=cmi.CSR_STREAM, block_size=b, items_per_thread=ipt, rows_per_block=rpb,
                                       nontemporal=nt, xcd_swizzle=swz))
+        for b, nt, chunked, bpc in itertools.product(blocks, (0, 2) if quick else (0, 1, 2, 3), (0, 1),
+                                                     (4, 8) if quick else (2, 3, 4, 6, 8, 12)):
+            base = max(1, min(int((b * 4 - 3) / max(mean, 0.25)), b - 1))
+            aligned = max(1, base // 16 * 16)
+            for rpb in sorted({aligned} if quick else {base, aligned}):
+                out.append(cmi.Config(kernel=cmi.CSR_STREAM_PIPE, block_size=b, rows_per_block=rpb, nontemporal=nt,
+                                      xcd_swizzle=chunked, blocks_per_cu=bpc))
     return out
 
 
 def ell_space(cmi, quick):
     return [cmi.Config(kernel=cmi.ELL_ROW, block_size=b, items_per_thread=r, nontemporal=nt)
-            for b, r, nt in itertools.product((256,) if quick else (128, 256, 512, 1024), (1, 2), (0, 1))]
+            for b, r, nt in itertools.product((256,) if quick else (128, 256, 512, 1024), (1, 2), (0, 1, 2, 3))]
 
 
 def dia_space(cmi, quick):
     return [cmi.Config(kernel=cmi.DIA_ROW, block_size=b, items_per_thread=r, nontemporal=nt)
-            for b, r, nt in itertools.product((256,) if quick else (128, 256, 512, 1024), (1, 2), (0, 1))]
+            for b, r, nt in itertools.product((256,) if quick else (128, 256, 512, 1024), (1, 2), (0, 1, 2, 3))]
 
 
 def coo_space(cmi, quick):
@@ -191,7 +199,7 @@ def main():
             label = f"csr/{tag}/poisson{m}x{n}"
             best, ms, res = tune_one(cmi, torch, timer, label, csr_space(cmi, 5.0, args.quick),
                                      lambda cfg: cmi.multiply(A, dx, y, cfg=cfg),
-                                     checker(A, (cmi.CSR_SCALAR, cmi.CSR_STREAM)), args.iters, args.rounds, log,
+                                     checker(A, (cmi.CSR_SCALAR, cmi.CSR_STREAM, cmi.CSR_STREAM_PIPE)), args.iters, args.rounds, log,
                                      cmi.csr_bytes(N, A.num_entries, vb))
             cmi.tuning_set(cmi.FORMAT_CSR, dcode, A.num_entries / N, best)
             summary.append((label, best.as_dict(), ms))
@@ -252,7 +260,7 @@ def main():
                     ys.fill_(10.0)
                     cmi.multiply(S, dxs, ys, cfg=cfg)
                     got = ys.cpu().numpy()
-                    if cfg.kernel in (cmi.CSR_SCALAR, cmi.CSR_STREAM):
+                    if cfg.kernel in (cmi.CSR_SCALAR, cmi.CSR_STREAM, cmi.CSR_STREAM_PIPE):
                         return bool(np.array_equal(got, wants)), "bit-exact required"
                     return bool(np.all(np.abs(got - wants) <= tol * np.maximum(bound, 1e-30))), f"tolerance {tol}"
 
