@@ -1,0 +1,392 @@
+// cusp/detail/matrices.h -- the five sparse containers and their views, with the public data members
+// of the reference:
+//   csr_matrix  (cusp/csr_matrix.h:107-208)   row_offsets, column_indices, values
+//   coo_matrix  (cusp/coo_matrix.h:116-224)   row_indices, column_indices, values, sort_by_row*, is_sorted_*
+//   ell_matrix  (cusp/ell_matrix.h:119-228)   column_indices, values (column-major array2d), invalid_index = -1
+//   dia_matrix  (cusp/dia_matrix.h:120-226)   diagonal_offsets, values (column-major array2d)
+//   hyb_matrix  (cusp/hyb_matrix.h:142-246)   ell, coo
+//   base        (cusp/detail/matrix_base.h:29-68) num_rows, num_cols, num_entries + the typedefs
+// plus cusp::ktt::ellr_matrix (cusp/ktt/ellr_matrix.h:17-90): ELL + row_lengths.
+// Included through cusp/{csr,coo,ell,dia,hyb}_matrix.h, which also pull in cusp/convert.h so that the
+// converting constructors / operator= (any format, any memory space) are complete.
+#pragma once
+#include <algorithm>
+#include <numeric>
+
+#include "../array1d.h"
+#include "../array2d.h"
+
+namespace cusp {
+
+template <typename Src, typename Dst> void convert(const Src &src, Dst &dst); // cusp/convert.h
+
+namespace detail {
+
+template <typename IndexType, typename ValueType, typename MemorySpace, typename Format> class matrix_base {
+public:
+    typedef IndexType index_type;
+    typedef ValueType value_type;
+    typedef MemorySpace memory_space;
+    typedef Format format;
+
+    size_t num_rows, num_cols, num_entries;
+
+    matrix_base() : num_rows(0), num_cols(0), num_entries(0) {}
+    matrix_base(size_t r, size_t c, size_t n) : num_rows(r), num_cols(c), num_entries(n) {}
+    template <typename M> explicit matrix_base(const M &m) : num_rows(m.num_rows), num_cols(m.num_cols), num_entries(m.num_entries) {}
+    void resize(size_t r, size_t c, size_t n) { num_rows = r; num_cols = c; num_entries = n; }
+    void swap(matrix_base &o) { std::swap(num_rows, o.num_rows); std::swap(num_cols, o.num_cols); std::swap(num_entries, o.num_entries); }
+};
+
+// true for cusp containers / views (anything with a format tag)
+template <typename M, typename = void> struct has_format { static const bool value = false; };
+template <typename M> struct has_format<M, typename std::enable_if<!std::is_void<typename M::format>::value>::type> { static const bool value = true; };
+
+} // namespace detail
+
+// ---------------------------------------------------------------------------------------------
+// CSR
+// ---------------------------------------------------------------------------------------------
+template <typename I, typename V, typename M> class csr_matrix_view;
+
+template <typename IndexType, typename ValueType, typename MemorySpace>
+class csr_matrix : public detail::matrix_base<IndexType, ValueType, MemorySpace, csr_format> {
+    typedef detail::matrix_base<IndexType, ValueType, MemorySpace, csr_format> Parent;
+public:
+    typedef array1d<IndexType, MemorySpace> row_offsets_array_type;
+    typedef array1d<IndexType, MemorySpace> column_indices_array_type;
+    typedef array1d<ValueType, MemorySpace> values_array_type;
+    typedef csr_matrix<IndexType, ValueType, MemorySpace> container;
+    typedef csr_matrix_view<IndexType, ValueType, MemorySpace> view;
+    typedef csr_matrix_view<const IndexType, const ValueType, MemorySpace> const_view;
+    template <typename Space> struct rebind { typedef csr_matrix<IndexType, ValueType, Space> type; };
+
+    row_offsets_array_type row_offsets;
+    column_indices_array_type column_indices;
+    values_array_type values;
+
+    csr_matrix() {}
+    csr_matrix(size_t rows, size_t cols, size_t entries) : Parent(rows, cols, entries), row_offsets(rows + 1), column_indices(entries), values(entries) {}
+    csr_matrix(const csr_matrix &) = default;
+    csr_matrix(csr_matrix &&) = default;
+    csr_matrix &operator=(const csr_matrix &) = default;
+    csr_matrix &operator=(csr_matrix &&) = default;
+    template <typename Matrix, typename = typename std::enable_if<detail::has_format<Matrix>::value>::type>
+    csr_matrix(const Matrix &m) { cusp::convert(m, *this); }
+    template <typename Matrix, typename = typename std::enable_if<detail::has_format<Matrix>::value>::type>
+    csr_matrix &operator=(const Matrix &m) { cusp::convert(m, *this); return *this; }
+
+    void resize(size_t rows, size_t cols, size_t entries)
+    {
+        Parent::resize(rows, cols, entries);
+        row_offsets.resize(rows + 1);
+        column_indices.resize(entries);
+        values.resize(entries);
+    }
+    void swap(csr_matrix &o) { Parent::swap(o); row_offsets.swap(o.row_offsets); column_indices.swap(o.column_indices); values.swap(o.values); }
+};
+
+template <typename I, typename V, typename M>
+class csr_matrix_view : public detail::matrix_base<typename std::remove_const<I>::type, typename std::remove_const<V>::type, M, csr_format> {
+    typedef detail::matrix_base<typename std::remove_const<I>::type, typename std::remove_const<V>::type, M, csr_format> Parent;
+public:
+    typedef csr_matrix<typename Parent::index_type, typename Parent::value_type, M> container;
+    typedef csr_matrix_view view;
+    array1d_view<I, M> row_offsets, column_indices;
+    array1d_view<V, M> values;
+
+    csr_matrix_view() {}
+    csr_matrix_view(size_t rows, size_t cols, size_t entries, array1d_view<I, M> ro, array1d_view<I, M> ci, array1d_view<V, M> v)
+        : Parent(rows, cols, entries), row_offsets(ro), column_indices(ci), values(v) {}
+    csr_matrix_view(container &m) : Parent(m), row_offsets(m.row_offsets), column_indices(m.column_indices), values(m.values) {}
+    csr_matrix_view(const container &m) : Parent(m), row_offsets(m.row_offsets), column_indices(m.column_indices), values(m.values) {}
+};
+
+template <typename I, typename V, typename M>
+csr_matrix_view<I, V, M> make_csr_matrix_view(size_t rows, size_t cols, size_t entries, array1d_view<I, M> ro, array1d_view<I, M> ci, array1d_view<V, M> v)
+{
+    return csr_matrix_view<I, V, M>(rows, cols, entries, ro, ci, v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// COO
+// ---------------------------------------------------------------------------------------------
+template <typename I, typename V, typename M> class coo_matrix_view;
+
+template <typename IndexType, typename ValueType, typename MemorySpace>
+class coo_matrix : public detail::matrix_base<IndexType, ValueType, MemorySpace, coo_format> {
+    typedef detail::matrix_base<IndexType, ValueType, MemorySpace, coo_format> Parent;
+public:
+    typedef array1d<IndexType, MemorySpace> row_indices_array_type;
+    typedef array1d<IndexType, MemorySpace> column_indices_array_type;
+    typedef array1d<ValueType, MemorySpace> values_array_type;
+    typedef coo_matrix container;
+    typedef coo_matrix_view<IndexType, ValueType, MemorySpace> view;
+    typedef coo_matrix_view<const IndexType, const ValueType, MemorySpace> const_view;
+    template <typename Space> struct rebind { typedef coo_matrix<IndexType, ValueType, Space> type; };
+
+    row_indices_array_type row_indices;
+    column_indices_array_type column_indices;
+    values_array_type values;
+
+    coo_matrix() {}
+    coo_matrix(size_t rows, size_t cols, size_t entries) : Parent(rows, cols, entries), row_indices(entries), column_indices(entries), values(entries) {}
+    coo_matrix(const coo_matrix &) = default;
+    coo_matrix(coo_matrix &&) = default;
+    coo_matrix &operator=(const coo_matrix &) = default;
+    coo_matrix &operator=(coo_matrix &&) = default;
+    template <typename Matrix, typename = typename std::enable_if<detail::has_format<Matrix>::value>::type>
+    coo_matrix(const Matrix &m) { cusp::convert(m, *this); }
+    template <typename Matrix, typename = typename std::enable_if<detail::has_format<Matrix>::value>::type>
+    coo_matrix &operator=(const Matrix &m) { cusp::convert(m, *this); return *this; }
+
+    void resize(size_t rows, size_t cols, size_t entries)
+    {
+        Parent::resize(rows, cols, entries);
+        row_indices.resize(entries);
+        column_indices.resize(entries);
+        values.resize(entries);
+    }
+    void swap(coo_matrix &o) { Parent::swap(o); row_indices.swap(o.row_indices); column_indices.swap(o.column_indices); values.swap(o.values); }
+
+    // reference cusp/coo_matrix.h: sort_by_row / sort_by_row_and_column / is_sorted_by_row[_and_column]
+    // (set-up operations; done on the host, stable, like the reference's stable_sort_by_key)
+    void sort_by_row() { sort_impl(false); }
+    void sort_by_row_and_column() { sort_impl(true); }
+    bool is_sorted_by_row() const { return sorted_impl(false); }
+    bool is_sorted_by_row_and_column() const { return sorted_impl(true); }
+
+private:
+    void sort_impl(bool and_column)
+    {
+        array1d<IndexType, host_memory> ri(row_indices), ci(column_indices);
+        array1d<ValueType, host_memory> va(values);
+        std::vector<size_t> perm(ri.size());
+        std::iota(perm.begin(), perm.end(), size_t(0));
+        std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t b) {
+            if (ri[a] != ri[b]) return ri[a] < ri[b];
+            return and_column && ci[a] < ci[b];
+        });
+        array1d<IndexType, host_memory> ri2(ri.size()), ci2(ri.size());
+        array1d<ValueType, host_memory> va2(ri.size());
+        for (size_t k = 0; k < perm.size(); k++) { ri2[k] = ri[perm[k]]; ci2[k] = ci[perm[k]]; va2[k] = va[perm[k]]; }
+        row_indices = ri2; column_indices = ci2; values = va2;
+    }
+    bool sorted_impl(bool and_column) const
+    {
+        array1d<IndexType, host_memory> ri(row_indices), ci(column_indices);
+        for (size_t k = 1; k < ri.size(); k++) {
+            if (ri[k - 1] > ri[k]) return false;
+            if (and_column && ri[k - 1] == ri[k] && ci[k - 1] > ci[k]) return false;
+        }
+        return true;
+    }
+};
+
+template <typename I, typename V, typename M>
+class coo_matrix_view : public detail::matrix_base<typename std::remove_const<I>::type, typename std::remove_const<V>::type, M, coo_format> {
+    typedef detail::matrix_base<typename std::remove_const<I>::type, typename std::remove_const<V>::type, M, coo_format> Parent;
+public:
+    typedef coo_matrix<typename Parent::index_type, typename Parent::value_type, M> container;
+    typedef coo_matrix_view view;
+    array1d_view<I, M> row_indices, column_indices;
+    array1d_view<V, M> values;
+
+    coo_matrix_view() {}
+    coo_matrix_view(size_t rows, size_t cols, size_t entries, array1d_view<I, M> ri, array1d_view<I, M> ci, array1d_view<V, M> v)
+        : Parent(rows, cols, entries), row_indices(ri), column_indices(ci), values(v) {}
+    coo_matrix_view(container &m) : Parent(m), row_indices(m.row_indices), column_indices(m.column_indices), values(m.values) {}
+    coo_matrix_view(const container &m) : Parent(m), row_indices(m.row_indices), column_indices(m.column_indices), values(m.values) {}
+};
+
+// ---------------------------------------------------------------------------------------------
+// ELL
+// ---------------------------------------------------------------------------------------------
+template <typename I, typename V, typename M> class ell_matrix_view;
+
+template <typename IndexType, typename ValueType, typename MemorySpace>
+class ell_matrix : public detail::matrix_base<IndexType, ValueType, MemorySpace, ell_format> {
+    typedef detail::matrix_base<IndexType, ValueType, MemorySpace, ell_format> Parent;
+public:
+    typedef array2d<IndexType, MemorySpace, column_major> column_indices_array_type;
+    typedef array2d<ValueType, MemorySpace, column_major> values_array_type;
+    typedef ell_matrix container;
+    typedef ell_matrix_view<IndexType, ValueType, MemorySpace> view;
+    typedef ell_matrix_view<IndexType, ValueType, MemorySpace> const_view;
+    template <typename Space> struct rebind { typedef ell_matrix<IndexType, ValueType, Space> type; };
+
+    static const IndexType invalid_index = static_cast<IndexType>(-1); // reference cusp/ell_matrix.h:129
+
+    column_indices_array_type column_indices;
+    values_array_type values;
+
+    ell_matrix() {}
+    // reference cusp/detail/ell_matrix.inl:30-37: pitch = round_up(num_rows, alignment), default 32
+    ell_matrix(size_t rows, size_t cols, size_t entries, size_t entries_per_row, size_t alignment = 32) { resize(rows, cols, entries, entries_per_row, alignment); }
+    ell_matrix(const ell_matrix &) = default;
+    ell_matrix(ell_matrix &&) = default;
+    ell_matrix &operator=(const ell_matrix &) = default;
+    ell_matrix &operator=(ell_matrix &&) = default;
+    template <typename Matrix, typename = typename std::enable_if<detail::has_format<Matrix>::value>::type>
+    ell_matrix(const Matrix &m) { cusp::convert(m, *this); }
+    template <typename Matrix, typename = typename std::enable_if<detail::has_format<Matrix>::value>::type>
+    ell_matrix &operator=(const Matrix &m) { cusp::convert(m, *this); return *this; }
+
+    void resize(size_t rows, size_t cols, size_t entries, size_t entries_per_row, size_t alignment = 32)
+    {
+        Parent::resize(rows, cols, entries);
+        const size_t pitch = detail::round_up(rows, alignment);
+        column_indices.resize(rows, entries_per_row, pitch);
+        values.resize(rows, entries_per_row, pitch);
+    }
+    void swap(ell_matrix &o) { Parent::swap(o); column_indices.swap(o.column_indices); values.swap(o.values); }
+};
+template <typename I, typename V, typename M> const I ell_matrix<I, V, M>::invalid_index;
+
+template <typename I, typename V, typename M>
+class ell_matrix_view : public detail::matrix_base<I, V, M, ell_format> {
+    typedef detail::matrix_base<I, V, M, ell_format> Parent;
+public:
+    typedef ell_matrix<I, V, M> container;
+    typedef ell_matrix_view view;
+    static const I invalid_index = static_cast<I>(-1);
+    // 2-D views: pointer + shape + pitch of the container's column-major arrays
+    struct view2d_i { const I *ptr; size_t num_rows, num_cols, pitch; const I *data() const { return ptr; } } column_indices;
+    struct view2d_v { const V *ptr; size_t num_rows, num_cols, pitch; const V *data() const { return ptr; } } values;
+    ell_matrix_view(const container &m)
+        : Parent(m), column_indices{m.column_indices.values.data(), m.column_indices.num_rows, m.column_indices.num_cols, m.column_indices.pitch},
+          values{m.values.values.data(), m.values.num_rows, m.values.num_cols, m.values.pitch} {}
+};
+template <typename I, typename V, typename M> const I ell_matrix_view<I, V, M>::invalid_index;
+
+// ---------------------------------------------------------------------------------------------
+// DIA
+// ---------------------------------------------------------------------------------------------
+template <typename I, typename V, typename M> class dia_matrix_view;
+
+template <typename IndexType, typename ValueType, typename MemorySpace>
+class dia_matrix : public detail::matrix_base<IndexType, ValueType, MemorySpace, dia_format> {
+    typedef detail::matrix_base<IndexType, ValueType, MemorySpace, dia_format> Parent;
+public:
+    typedef array1d<IndexType, MemorySpace> diagonal_offsets_array_type;
+    typedef array2d<ValueType, MemorySpace, column_major> values_array_type;
+    typedef dia_matrix container;
+    typedef dia_matrix_view<IndexType, ValueType, MemorySpace> view;
+    typedef dia_matrix_view<IndexType, ValueType, MemorySpace> const_view;
+    template <typename Space> struct rebind { typedef dia_matrix<IndexType, ValueType, Space> type; };
+
+    diagonal_offsets_array_type diagonal_offsets;
+    values_array_type values;
+
+    dia_matrix() {}
+    dia_matrix(size_t rows, size_t cols, size_t entries, size_t diagonals, size_t alignment = 32) { resize(rows, cols, entries, diagonals, alignment); }
+    dia_matrix(const dia_matrix &) = default;
+    dia_matrix(dia_matrix &&) = default;
+    dia_matrix &operator=(const dia_matrix &) = default;
+    dia_matrix &operator=(dia_matrix &&) = default;
+    template <typename Matrix, typename = typename std::enable_if<detail::has_format<Matrix>::value>::type>
+    dia_matrix(const Matrix &m) { cusp::convert(m, *this); }
+    template <typename Matrix, typename = typename std::enable_if<detail::has_format<Matrix>::value>::type>
+    dia_matrix &operator=(const Matrix &m) { cusp::convert(m, *this); return *this; }
+
+    // reference cusp/detail/dia_matrix.inl:26-35,65-69
+    void resize(size_t rows, size_t cols, size_t entries, size_t diagonals, size_t alignment = 32)
+    {
+        Parent::resize(rows, cols, entries);
+        diagonal_offsets.resize(diagonals);
+        values.resize(rows, diagonals, detail::round_up(rows, alignment));
+    }
+    void swap(dia_matrix &o) { Parent::swap(o); diagonal_offsets.swap(o.diagonal_offsets); values.swap(o.values); }
+};
+
+template <typename I, typename V, typename M>
+class dia_matrix_view : public detail::matrix_base<I, V, M, dia_format> {
+    typedef detail::matrix_base<I, V, M, dia_format> Parent;
+public:
+    typedef dia_matrix<I, V, M> container;
+    typedef dia_matrix_view view;
+    array1d_view<const I, M> diagonal_offsets;
+    struct view2d_v { const V *ptr; size_t num_rows, num_cols, pitch; const V *data() const { return ptr; } } values;
+    dia_matrix_view(const container &m)
+        : Parent(m), diagonal_offsets(m.diagonal_offsets),
+          values{m.values.values.data(), m.values.num_rows, m.values.num_cols, m.values.pitch} {}
+};
+
+// ---------------------------------------------------------------------------------------------
+// HYB
+// ---------------------------------------------------------------------------------------------
+template <typename I, typename V, typename M> class hyb_matrix_view;
+
+template <typename IndexType, typename ValueType, typename MemorySpace>
+class hyb_matrix : public detail::matrix_base<IndexType, ValueType, MemorySpace, hyb_format> {
+    typedef detail::matrix_base<IndexType, ValueType, MemorySpace, hyb_format> Parent;
+public:
+    typedef ell_matrix<IndexType, ValueType, MemorySpace> ell_matrix_type;
+    typedef coo_matrix<IndexType, ValueType, MemorySpace> coo_matrix_type;
+    typedef hyb_matrix container;
+    typedef hyb_matrix_view<IndexType, ValueType, MemorySpace> view;
+    typedef hyb_matrix_view<IndexType, ValueType, MemorySpace> const_view;
+    template <typename Space> struct rebind { typedef hyb_matrix<IndexType, ValueType, Space> type; };
+
+    ell_matrix_type ell;
+    coo_matrix_type coo;
+
+    hyb_matrix() {}
+    hyb_matrix(size_t rows, size_t cols, size_t ell_entries, size_t coo_entries, size_t entries_per_row, size_t alignment = 32)
+    {
+        resize(rows, cols, ell_entries, coo_entries, entries_per_row, alignment);
+    }
+    hyb_matrix(const hyb_matrix &) = default;
+    hyb_matrix(hyb_matrix &&) = default;
+    hyb_matrix &operator=(const hyb_matrix &) = default;
+    hyb_matrix &operator=(hyb_matrix &&) = default;
+    template <typename Matrix, typename = typename std::enable_if<detail::has_format<Matrix>::value>::type>
+    hyb_matrix(const Matrix &m) { cusp::convert(m, *this); }
+    template <typename Matrix, typename = typename std::enable_if<detail::has_format<Matrix>::value>::type>
+    hyb_matrix &operator=(const Matrix &m) { cusp::convert(m, *this); return *this; }
+
+    void resize(size_t rows, size_t cols, size_t ell_entries, size_t coo_entries, size_t entries_per_row, size_t alignment = 32)
+    {
+        Parent::resize(rows, cols, ell_entries + coo_entries);
+        ell.resize(rows, cols, ell_entries, entries_per_row, alignment);
+        coo.resize(rows, cols, coo_entries);
+    }
+    void swap(hyb_matrix &o) { Parent::swap(o); ell.swap(o.ell); coo.swap(o.coo); }
+};
+
+template <typename I, typename V, typename M>
+class hyb_matrix_view : public detail::matrix_base<I, V, M, hyb_format> {
+    typedef detail::matrix_base<I, V, M, hyb_format> Parent;
+public:
+    typedef hyb_matrix<I, V, M> container;
+    typedef hyb_matrix_view view;
+    ell_matrix_view<I, V, M> ell;
+    coo_matrix_view<const I, const V, M> coo;
+    hyb_matrix_view(const container &m) : Parent(m), ell(m.ell), coo(m.coo) {}
+};
+
+// ---------------------------------------------------------------------------------------------
+// ELLR (the fork's cusp::ktt::ellr_matrix, cusp/ktt/ellr_matrix.h:17-90): ELL + per-row lengths
+// ---------------------------------------------------------------------------------------------
+namespace ktt {
+template <typename IndexType, typename ValueType, typename MemorySpace>
+class ellr_matrix : public cusp::ell_matrix<IndexType, ValueType, MemorySpace> {
+    typedef cusp::ell_matrix<IndexType, ValueType, MemorySpace> Parent;
+public:
+    typedef ellr_matrix container;
+    cusp::array1d<IndexType, MemorySpace> row_lengths;
+
+    ellr_matrix() {}
+    ellr_matrix(size_t rows, size_t cols, size_t entries, size_t entries_per_row, size_t alignment = 32)
+        : Parent(rows, cols, entries, entries_per_row, alignment), row_lengths(rows) {}
+    template <typename Matrix, typename = typename std::enable_if<cusp::detail::has_format<Matrix>::value>::type>
+    ellr_matrix(const Matrix &m) : Parent(m) { compute_row_lengths(); }
+    template <typename Matrix, typename = typename std::enable_if<cusp::detail::has_format<Matrix>::value>::type>
+    ellr_matrix &operator=(const Matrix &m) { Parent::operator=(m); compute_row_lengths(); return *this; }
+
+    // reference cusp/ktt/detail/ellr_matrix.inl:16-53: length of the leading run of valid columns
+    void compute_row_lengths();
+};
+} // namespace ktt
+
+} // namespace cusp

@@ -170,6 +170,7 @@ def main():
     formats = args.formats.split(",")
     t_start = time.time()
     summary = []
+    synth_cache = {}
     for tag in args.dtypes.split(","):
         tdt = torch.float64 if tag == "f64" else torch.float32
         ndt = np.float64 if tag == "f64" else np.float32
@@ -241,10 +242,15 @@ def main():
 
         # synthetic CSR matrices for the other mean-row-length buckets
         if "csr" in formats and not args.skip_synthetic:
-            rows = cols = 2_000_000 if not args.quick else 400_000
+            rows = cols = 1_000_000 if not args.quick else 200_000
             for mean in (1.5, 3.0, 10.0, 24.0, 48.0, 96.0, 200.0):
                 r = rows if mean < 100 else rows // 4
-                Ap, Aj, Ax = synthetic_csr(r, r, mean, int(mean * 10), ndt)
+                key = (r, mean)
+                if key not in synth_cache:  # same structure for f64 and f32
+                    synth_cache[key] = synthetic_csr(r, r, mean, int(mean * 10), np.float64)
+                Ap, Aj, Ax = synth_cache[key]
+                Ax = Ax.astype(ndt)
+                print(f"synthetic mean {mean}: {r} rows, {len(Ax)} entries", flush=True)
                 S = cmi.CsrMatrix(r, r, len(Ax), torch.from_numpy(Ap).cuda(), torch.from_numpy(Aj).cuda(),
                                   torch.from_numpy(Ax).cuda())
                 dxs = cmi.fill_x(r, tdt, "cuda")
