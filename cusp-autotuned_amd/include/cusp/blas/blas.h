@@ -1,0 +1,112 @@
+// cusp/blas/blas.h -- the BLAS-1 routines cusp::krylov::cg uses, with the reference's signatures
+// (cusp/blas/blas.h; generic implementations cusp/system/detail/generic/blas.h:175-220,283-340):
+//   axpy(x, y, alpha)            y <- alpha*x + y
+//   axpby(x, y, z, alpha, beta)  z <- alpha*x + beta*y
+//   copy(x, y)   fill(x, v)   dot(x, y)   dotc(x, y)   nrm2(x)
+// host_memory: plain loops.  device_memory: cmi_blas_*_f64 kernels (f64, what CG on the benchmark
+// uses); reductions are deterministic two-stage trees whose scalar is copied back (one 8-byte D2H
+// per call -- the reference's Thrust reductions synchronise the same way).
+#pragma once
+#include <cmath>
+
+#include "../array1d.h"
+
+namespace cusp {
+namespace blas {
+
+namespace detail {
+
+struct device_workspace { // lazily allocated per thread, freed at exit: no allocation per call
+    void *ws;
+    double *result;
+    device_workspace() : ws(nullptr), result(nullptr) {}
+    ~device_workspace() { if (ws) cmi_free(ws); if (result) cmi_free(result); }
+    void ensure()
+    {
+        if (!ws) cusp::detail::check(cmi_malloc(&ws, cmi_blas_workspace_bytes()));
+        if (!result) cusp::detail::check(cmi_malloc(reinterpret_cast<void **>(&result), sizeof(double)));
+    }
+};
+inline device_workspace &workspace()
+{
+    static thread_local device_workspace w;
+    w.ensure();
+    return w;
+}
+
+template <typename X, typename Y> void same_size(const X &x, const Y &y)
+{
+    if (x.size() != y.size()) throw cusp::invalid_input_exception("cusp::blas: array sizes differ");
+}
+
+template <typename V> struct require_f64 {
+    static_assert(std::is_same<V, double>::value, "device_memory cusp::blas routines are implemented for double (the CG value type of the benchmark)");
+};
+
+// ---- host ----
+template <typename X, typename Y, typename S> void axpy(const X &x, Y &y, S a, host_memory)
+{ for (size_t i = 0; i < x.size(); i++) y[i] = a * x[i] + y[i]; }
+template <typename X, typename Y, typename Z, typename S> void axpby(const X &x, const Y &y, Z &z, S a, S b, host_memory)
+{ for (size_t i = 0; i < x.size(); i++) z[i] = a * x[i] + b * y[i]; }
+template <typename X, typename Y> void copy(const X &x, Y &y, host_memory)
+{ for (size_t i = 0; i < x.size(); i++) y[i] = x[i]; }
+template <typename X, typename S> void fill(X &x, S v, host_memory)
+{ for (size_t i = 0; i < x.size(); i++) x[i] = v; }
+template <typename X, typename Y> typename X::value_type dot(const X &x, const Y &y, host_memory)
+{
+    typename X::value_type s = 0;
+    for (size_t i = 0; i < x.size(); i++) s += x[i] * y[i];
+    return s;
+}
+// ---- device (f64) ----
+template <typename X, typename Y, typename S> void axpy(const X &x, Y &y, S a, device_memory)
+{ require_f64<typename Y::value_type>(); cusp::detail::check(cmi_blas_axpy_f64(x.size(), a, x.data(), y.data(), nullptr)); }
+template <typename X, typename Y, typename Z, typename S> void axpby(const X &x, const Y &y, Z &z, S a, S b, device_memory)
+{ require_f64<typename Z::value_type>(); cusp::detail::check(cmi_blas_axpby_f64(x.size(), a, x.data(), b, y.data(), z.data(), nullptr)); }
+template <typename X, typename Y> void copy(const X &x, Y &y, device_memory)
+{ require_f64<typename Y::value_type>(); cusp::detail::check(cmi_blas_copy_f64(x.size(), x.data(), y.data(), nullptr)); }
+template <typename X, typename S> void fill(X &x, S v, device_memory)
+{ require_f64<typename X::value_type>(); cusp::detail::check(cmi_blas_fill_f64(x.size(), v, x.data(), nullptr)); }
+template <typename X, typename Y> double dot(const X &x, const Y &y, device_memory)
+{
+    require_f64<typename X::value_type>();
+    device_workspace &w = workspace();
+    cusp::detail::check(cmi_blas_dot_f64(x.size(), x.data(), y.data(), w.result, w.ws, nullptr));
+    double r;
+    cusp::detail::check(cmi_memcpy_d2h(&r, w.result, sizeof(double), nullptr));
+    return r;
+}
+template <typename X> double nrm2(const X &x, device_memory)
+{
+    require_f64<typename X::value_type>();
+    device_workspace &w = workspace();
+    cusp::detail::check(cmi_blas_nrm2_f64(x.size(), x.data(), w.result, w.ws, nullptr));
+    double r;
+    cusp::detail::check(cmi_memcpy_d2h(&r, w.result, sizeof(double), nullptr));
+    return r;
+}
+template <typename X> typename X::value_type nrm2(const X &x, host_memory)
+{
+    typename X::value_type s = 0;
+    for (size_t i = 0; i < x.size(); i++) s += x[i] * x[i];
+    return std::sqrt(s);
+}
+
+} // namespace detail
+
+template <typename X, typename Y, typename S> void axpy(const X &x, Y &y, S alpha)
+{ detail::same_size(x, y); detail::axpy(x, y, static_cast<typename Y::value_type>(alpha), typename Y::memory_space()); }
+template <typename X, typename Y, typename Z, typename S1, typename S2> void axpby(const X &x, const Y &y, Z &z, S1 alpha, S2 beta)
+{
+    typedef typename Z::value_type V;
+    detail::same_size(x, y); detail::same_size(x, z);
+    detail::axpby(x, y, z, static_cast<V>(alpha), static_cast<V>(beta), typename Z::memory_space());
+}
+template <typename X, typename Y> void copy(const X &x, Y &y) { detail::same_size(x, y); detail::copy(x, y, typename Y::memory_space()); }
+template <typename X, typename S> void fill(X &x, S v) { detail::fill(x, static_cast<typename X::value_type>(v), typename X::memory_space()); }
+template <typename X, typename Y> typename X::value_type dot(const X &x, const Y &y) { detail::same_size(x, y); return detail::dot(x, y, typename X::memory_space()); }
+template <typename X, typename Y> typename X::value_type dotc(const X &x, const Y &y) { return dot(x, y); } // real types: conj is the identity
+template <typename X> typename X::value_type nrm2(const X &x) { return detail::nrm2(x, typename X::memory_space()); }
+
+} // namespace blas
+} // namespace cusp

@@ -2,6 +2,7 @@
 // (include/cusp_mi355x.h).  Every C-ABI status becomes the cusp exception the reference would throw
 // for the same condition (cusp/exception.h); unlike the reference, kernel-launch failures are reported.
 #pragma once
+#include <cstdlib>
 #include <new>
 #include <string>
 

@@ -1,0 +1,128 @@
+// cusp/io/matrix_market.h -- read_matrix_market_file / _stream, write_matrix_market_file
+// (reference cusp/io/matrix_market.h, cusp/io/detail/matrix_market.inl:160-300):
+// "coordinate" storage with real / integer / pattern values (pattern -> 1), general or symmetric
+// (off-diagonals mirrored, in file order), 1-based indices validated then made 0-based, the result
+// sorted by (row, column), then converted to the requested container.  Unlocks the SuiteSparse
+// config of BASELINE.json (nlpkkt120, ldoor, thermal2 are not vendored; read them when supplied).
+#pragma once
+#include <fstream>
+#include <sstream>
+#include <string>
+
+#include "../coo_matrix.h"
+
+namespace cusp {
+namespace io {
+
+namespace detail {
+struct matrix_market_banner { std::string storage, symmetry, type; };
+
+inline void tokenize(std::vector<std::string> &tokens, const std::string &str)
+{
+    std::istringstream is(str);
+    std::string t;
+    while (is >> t) tokens.push_back(t);
+}
+
+template <typename Stream> void read_banner(Stream &input, matrix_market_banner &banner)
+{
+    std::string line;
+    std::vector<std::string> tokens;
+    if (!std::getline(input, line)) throw cusp::io_exception("invalid MatrixMarket banner");
+    tokenize(tokens, line);
+    if (tokens.size() != 5 || tokens[0] != "%%MatrixMarket" || tokens[1] != "matrix") throw cusp::io_exception("invalid MatrixMarket banner");
+    banner.storage = tokens[2];
+    banner.type = tokens[3];
+    banner.symmetry = tokens[4];
+    if (banner.storage != "array" && banner.storage != "coordinate") throw cusp::io_exception("invalid MatrixMarket storage format [" + banner.storage + "]");
+    if (banner.type != "complex" && banner.type != "real" && banner.type != "integer" && banner.type != "pattern")
+        throw cusp::io_exception("invalid MatrixMarket data type [" + banner.type + "]");
+    if (banner.symmetry != "general" && banner.symmetry != "symmetric" && banner.symmetry != "hermitian" && banner.symmetry != "skew-symmetric")
+        throw cusp::io_exception("invalid MatrixMarket symmetry [" + banner.symmetry + "]");
+}
+} // namespace detail
+
+template <typename Matrix, typename Stream> void read_matrix_market_stream(Matrix &mtx, Stream &input)
+{
+    typedef typename Matrix::index_type I;
+    typedef typename Matrix::value_type V;
+    detail::matrix_market_banner banner;
+    detail::read_banner(input, banner);
+    if (banner.storage != "coordinate") throw cusp::not_implemented_exception("MatrixMarket array storage is not read by this layer (sparse inputs only)");
+    if (banner.type == "complex") throw cusp::not_implemented_exception("complex MatrixMarket data (real value types only)");
+
+    std::string line;
+    do { // skip comments
+        if (!std::getline(input, line)) throw cusp::io_exception("unexpected EOF while reading MatrixMarket header");
+    } while (line.empty() || line[0] == '%');
+    std::vector<std::string> tokens;
+    detail::tokenize(tokens, line);
+    if (tokens.size() != 3) throw cusp::io_exception("invalid MatrixMarket coordinate format");
+    size_t num_rows, num_cols, num_entries;
+    std::istringstream(tokens[0]) >> num_rows;
+    std::istringstream(tokens[1]) >> num_cols;
+    std::istringstream(tokens[2]) >> num_entries;
+
+    coo_matrix<I, V, host_memory> coo(num_rows, num_cols, num_entries);
+    size_t read = 0;
+    const bool pattern = banner.type == "pattern";
+    long long r, c;
+    double v = 1.0;
+    while (read < num_entries && (input >> r >> c)) {
+        if (!pattern && !(input >> v)) break;
+        if (r < 1) throw cusp::io_exception("found invalid row index (index < 1)");
+        if (c < 1) throw cusp::io_exception("found invalid column index (index < 1)");
+        if (static_cast<size_t>(r) > num_rows) throw cusp::io_exception("found invalid row index (index > num_rows)");
+        if (static_cast<size_t>(c) > num_cols) throw cusp::io_exception("found invalid column index (index > num_columns)");
+        coo.row_indices[read] = static_cast<I>(r - 1);
+        coo.column_indices[read] = static_cast<I>(c - 1);
+        coo.values[read] = static_cast<V>(v);
+        read++;
+    }
+    if (read != num_entries) throw cusp::io_exception("unexpected EOF while reading MatrixMarket entries");
+
+    if (banner.symmetry != "general") {
+        if (banner.symmetry != "symmetric") throw cusp::not_implemented_exception("MatrixMarket I/O does not currently support " + banner.symmetry + " matrices");
+        size_t off = 0;
+        for (size_t n = 0; n < num_entries; n++) off += coo.row_indices[n] != coo.column_indices[n];
+        coo_matrix<I, V, host_memory> general(num_rows, num_cols, num_entries + off);
+        size_t nnz = 0;
+        for (size_t n = 0; n < num_entries; n++) {
+            general.row_indices[nnz] = coo.row_indices[n]; general.column_indices[nnz] = coo.column_indices[n]; general.values[nnz] = coo.values[n]; nnz++;
+            if (coo.row_indices[n] != coo.column_indices[n]) {
+                general.row_indices[nnz] = coo.column_indices[n]; general.column_indices[nnz] = coo.row_indices[n]; general.values[nnz] = coo.values[n]; nnz++;
+            }
+        }
+        coo.swap(general);
+    }
+    coo.sort_by_row_and_column();
+    cusp::convert(coo, mtx);
+}
+
+template <typename Matrix> void read_matrix_market_file(Matrix &mtx, const std::string &filename)
+{
+    std::ifstream file(filename.c_str());
+    if (!file) throw cusp::io_exception(std::string("unable to open file \"") + filename + std::string("\" for reading"));
+    read_matrix_market_stream(mtx, file);
+}
+
+template <typename Matrix, typename Stream> void write_matrix_market_stream(const Matrix &mtx, Stream &output)
+{
+    typedef typename Matrix::index_type I;
+    typedef typename Matrix::value_type V;
+    coo_matrix<I, V, host_memory> coo(mtx);
+    output << "%%MatrixMarket matrix coordinate real general\n";
+    output << "\t" << coo.num_rows << "\t" << coo.num_cols << "\t" << coo.num_entries << "\n";
+    output.precision(17);
+    for (size_t n = 0; n < coo.num_entries; n++) output << (coo.row_indices[n] + 1) << " " << (coo.column_indices[n] + 1) << " " << coo.values[n] << "\n";
+}
+
+template <typename Matrix> void write_matrix_market_file(const Matrix &mtx, const std::string &filename)
+{
+    std::ofstream file(filename.c_str());
+    if (!file) throw cusp::io_exception(std::string("unable to open file \"") + filename + std::string("\" for writing"));
+    write_matrix_market_stream(mtx, file);
+}
+
+} // namespace io
+} // namespace cusp

@@ -1,0 +1,384 @@
+// Tests of the SpMV path written the way the reference's own tests are (same matrices, same
+// protocol), parametrised on TEST_SPACE so the host build and the device build share them:
+//   testing/multiply.cu:383-512,569-645  TestSparseMatrixVectorMultiply / Scaled...
+//   testing/generalized_spmv.cu:20-70    known answer z = [183,74,325,510,131]
+//   testing/convert.cu:65-215,402-497    the 4x4 conversion example in every format
+//   testing/ell_matrix.cu:5-22           constructor pitch / alignment
+//   testing/poisson.cu:6-25              poisson5pt(2,3) as a dense matrix
+//   testing/cg.cu:46-99                  CG on poisson5pt(10,10) and the zero-residual start
+//   testing/multiply.cu:792-858          user execution policy reaches a user overload
+#pragma once
+#include <cusp/array1d.h>
+#include <cusp/array2d.h>
+#include <cusp/coo_matrix.h>
+#include <cusp/csr_matrix.h>
+#include <cusp/dia_matrix.h>
+#include <cusp/ell_matrix.h>
+#include <cusp/hyb_matrix.h>
+#include <cusp/gallery/poisson.h>
+#include <cusp/io/matrix_market.h>
+#include <cusp/krylov/cg.h>
+#include <cusp/ktt/ktt.h>
+#include <cusp/monitor.h>
+#include <cusp/multiply.h>
+
+#include "unittest.h"
+
+template <typename A, typename B> bool arrays_equal(const A &a, const B &b) { return cusp::equal(a, b); }
+#define ASSERT_ARRAYS_EQUAL(a, b) ASSERT_TRUE(arrays_equal(a, b))
+
+// ------------------------------------------------------------------------------------------------
+// testing/multiply.cu:383-432
+template <typename SparseMatrixType, typename DenseMatrixType> void CompareSparseMatrixVectorMultiply(DenseMatrixType A)
+{
+    typedef typename SparseMatrixType::value_type ValueType;
+    typedef typename SparseMatrixType::memory_space MemorySpace;
+    cusp::array1d<ValueType, cusp::host_memory> x(A.num_cols);
+    cusp::array1d<ValueType, cusp::host_memory> y(A.num_rows, 10);
+    for (size_t i = 0; i < x.size(); i++) x[i] = i % 10;
+    cusp::multiply(A, x, y); // dense host reference
+    { // container
+        SparseMatrixType _A(A);
+        cusp::array1d<ValueType, MemorySpace> _x(x);
+        cusp::array1d<ValueType, MemorySpace> _y(A.num_rows, 10);
+        cusp::multiply(_A, _x, _y);
+        ASSERT_ARRAYS_EQUAL(_y, y);
+    }
+    { // matrix view
+        SparseMatrixType _A(A);
+        cusp::array1d<ValueType, MemorySpace> _x(x);
+        cusp::array1d<ValueType, MemorySpace> _y(A.num_rows, 10);
+        typename SparseMatrixType::view _V(_A);
+        cusp::multiply(_V, _x, _y);
+        ASSERT_ARRAYS_EQUAL(_y, y);
+    }
+    { // array views
+        SparseMatrixType _A(A);
+        cusp::array1d<ValueType, MemorySpace> _x(x);
+        cusp::array1d<ValueType, MemorySpace> _y(A.num_rows, 10);
+        typename cusp::array1d<ValueType, MemorySpace>::view _Vx(_x), _Vy(_y);
+        cusp::multiply(_A, _Vx, _Vy);
+        ASSERT_ARRAYS_EQUAL(_Vy, y);
+    }
+    { // explicit policy on the default stream
+        SparseMatrixType _A(A);
+        cusp::array1d<ValueType, MemorySpace> _x(x);
+        cusp::array1d<ValueType, MemorySpace> _y(A.num_rows, 10);
+        cusp::multiply(cusp::hip::par, _A, _x, _y);
+        ASSERT_ARRAYS_EQUAL(_y, y);
+    }
+}
+
+// testing/multiply.cu:514-567
+template <typename SparseMatrixType, typename DenseMatrixType> void CompareScaledSparseMatrixVectorMultiply(DenseMatrixType A)
+{
+    typedef typename SparseMatrixType::value_type ValueType;
+    typedef typename SparseMatrixType::memory_space MemorySpace;
+    cusp::array1d<ValueType, cusp::host_memory> x(A.num_cols);
+    cusp::array1d<ValueType, cusp::host_memory> y(A.num_rows, 10);
+    for (size_t i = 0; i < x.size(); i++) x[i] = i % 10;
+    cusp::identity_function<ValueType> initialize;
+    cusp::multiplies<ValueType> combine;
+    cusp::plus<ValueType> reduce;
+    cusp::multiply(A, x, y, initialize, combine, reduce);
+    SparseMatrixType _A(A);
+    cusp::array1d<ValueType, MemorySpace> _x(x);
+    cusp::array1d<ValueType, MemorySpace> _y(A.num_rows, 10);
+    cusp::multiply(_A, _x, _y, initialize, combine, reduce);
+    ASSERT_ARRAYS_EQUAL(_y, y);
+}
+
+template <typename ValueType, typename Fn> void for_each_reference_matrix(Fn f)
+{
+    typedef cusp::array2d<ValueType, cusp::host_memory> Dense;
+    Dense A(5, 4);
+    const ValueType a[5][4] = {{13, 80, 0, 0}, {0, 27, 0, 0}, {55, 0, 24, 42}, {0, 69, 0, 83}, {0, 0, 27, 0}};
+    for (int i = 0; i < 5; i++) for (int j = 0; j < 4; j++) A(i, j) = a[i][j];
+    Dense B(2, 4);
+    const ValueType b[2][4] = {{0, 2, 3, 4}, {5, 0, 0, 8}};
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 4; j++) B(i, j) = b[i][j];
+    Dense C(2, 2); C(0, 0) = 0; C(0, 1) = 0; C(1, 0) = 3; C(1, 1) = 5;
+    Dense D(2, 1); D(0, 0) = 2; D(1, 0) = 3;
+    Dense E(2, 2, ValueType(0));
+    Dense F(2, 3); F(0, 0) = 0; F(0, 1) = 1.5; F(0, 2) = 3.0; F(1, 0) = 0.5; F(1, 1) = 0; F(1, 2) = 0;
+    Dense G; cusp::gallery::poisson5pt(G, 4, 6);
+    Dense H; cusp::gallery::poisson5pt(H, 8, 3);
+    f(A); f(B); f(C); f(D); f(E); f(F); f(G); f(H);
+}
+
+template <class TestMatrix> void TestSparseMatrixVectorMultiply()
+{
+    typedef typename TestMatrix::value_type V;
+    for_each_reference_matrix<V>([](const cusp::array2d<V, cusp::host_memory> &M) { CompareSparseMatrixVectorMultiply<TestMatrix>(M); });
+}
+DECLARE_SPARSE_MATRIX_UNITTEST(TestSparseMatrixVectorMultiply);
+
+template <class TestMatrix> void TestScaledSparseMatrixVectorMultiply()
+{
+    typedef typename TestMatrix::value_type V;
+    for_each_reference_matrix<V>([](const cusp::array2d<V, cusp::host_memory> &M) { CompareScaledSparseMatrixVectorMultiply<TestMatrix>(M); });
+}
+DECLARE_SPARSE_MATRIX_UNITTEST(TestScaledSparseMatrixVectorMultiply);
+
+// testing/generalized_spmv.cu:20-70
+template <class TestMatrix> void TestGeneralizedSpMVKnownAnswer()
+{
+    typedef typename TestMatrix::value_type V;
+    typedef typename TestMatrix::memory_space MemorySpace;
+    cusp::array2d<V, cusp::host_memory> A(5, 4);
+    const V a[5][4] = {{13, 80, 0, 0}, {0, 27, 0, 0}, {55, 0, 24, 42}, {0, 69, 0, 83}, {0, 0, 27, 0}};
+    for (int i = 0; i < 5; i++) for (int j = 0; j < 4; j++) A(i, j) = a[i][j];
+    TestMatrix test_matrix = A;
+    cusp::array1d<V, MemorySpace> x(4), y(5), z(5, -1);
+    x[0] = 1; x[1] = 2; x[2] = 3; x[3] = 4;
+    y[0] = 10; y[1] = 20; y[2] = 30; y[3] = 40; y[4] = 50;
+    cusp::generalized_spmv(test_matrix, x, y, z, cusp::multiplies<V>(), cusp::plus<V>());
+    ASSERT_EQUAL(V(z[0]), V(183)); ASSERT_EQUAL(V(z[1]), V(74)); ASSERT_EQUAL(V(z[2]), V(325));
+    ASSERT_EQUAL(V(z[3]), V(510)); ASSERT_EQUAL(V(z[4]), V(131));
+}
+DECLARE_SPARSE_MATRIX_UNITTEST(TestGeneralizedSpMVKnownAnswer);
+
+// testing/generalized_spmv.cu:72-143: multiply vs generalized_spmv on poisson grids incl. odd sizes
+template <class TestMatrix> void TestPoissonSizesAgainstHostCsr()
+{
+    typedef typename TestMatrix::value_type V;
+    typedef typename TestMatrix::memory_space MemorySpace;
+    const size_t sizes[][2] = {{5, 5}, {10, 10}, {117, 113}, {313, 444}};
+    for (auto &s : sizes) {
+        cusp::csr_matrix<int, V, cusp::host_memory> H;
+        cusp::gallery::poisson5pt(H, s[0], s[1]);
+        const size_t N = s[0] * s[1];
+        ASSERT_EQUAL(H.num_entries, 5 * N - 2 * s[0] - 2 * s[1]);
+        cusp::array1d<V, cusp::host_memory> x(N), y(N, 10);
+        for (size_t i = 0; i < N; i++) x[i] = V(int(i % 21) - 10); // performance/spmv/benchmark.h x pattern
+        cusp::multiply(H, x, y);
+        TestMatrix A;
+        cusp::gallery::poisson5pt(A, s[0], s[1]); // device targets: built in HBM
+        cusp::array1d<V, MemorySpace> _x(x), _y(N, 10);
+        cusp::multiply(A, _x, _y);
+        ASSERT_ARRAYS_EQUAL(_y, y); // small integers: exact in every summation order
+    }
+}
+DECLARE_SPARSE_MATRIX_UNITTEST(TestPoissonSizesAgainstHostCsr);
+
+// ------------------------------------------------------------------------------------------------
+// testing/convert.cu:65-215: the canonical 4x4 example
+template <typename M> void initialize_conversion_example(cusp::csr_matrix<int, float, M> &csr)
+{
+    csr.resize(4, 4, 7);
+    const int ro[5] = {0, 2, 3, 6, 7}, ci[7] = {0, 1, 2, 0, 2, 3, 1};
+    const float v[7] = {10.25f, 11.00f, 12.50f, 13.75f, 14.00f, 15.25f, 16.50f};
+    for (int i = 0; i < 5; i++) csr.row_offsets[i] = ro[i];
+    for (int i = 0; i < 7; i++) { csr.column_indices[i] = ci[i]; csr.values[i] = v[i]; }
+}
+
+template <typename Space> void TestConversionExampleAllFormats()
+{
+    cusp::csr_matrix<int, float, Space> csr;
+    initialize_conversion_example(csr);
+    const int X = cusp::ell_matrix<int, float, Space>::invalid_index;
+    ASSERT_EQUAL(X, -1);
+    { // CSR -> COO
+        cusp::coo_matrix<int, float, Space> coo(csr);
+        const int ri[7] = {0, 0, 1, 2, 2, 2, 3};
+        ASSERT_EQUAL(coo.num_entries, size_t(7));
+        for (int i = 0; i < 7; i++) { ASSERT_EQUAL(int(coo.row_indices[i]), ri[i]); ASSERT_EQUAL(int(coo.column_indices[i]), int(csr.column_indices[i])); }
+        ASSERT_TRUE(coo.is_sorted_by_row() && coo.is_sorted_by_row_and_column());
+        cusp::csr_matrix<int, float, Space> back(coo);
+        ASSERT_ARRAYS_EQUAL(back.row_offsets, csr.row_offsets);
+        ASSERT_ARRAYS_EQUAL(back.values, csr.values);
+    }
+    { // CSR -> DIA with alignment 1 (testing/convert.cu:402-438)
+        cusp::dia_matrix<int, float, cusp::host_memory> dia;
+        cusp::csr_matrix<int, float, cusp::host_memory> h(csr);
+        cusp::detail::from_host_csr(h, dia, cusp::dia_format(), 1);
+        ASSERT_EQUAL(dia.num_entries, size_t(7));
+        ASSERT_EQUAL(int(dia.diagonal_offsets[0]), -2); ASSERT_EQUAL(int(dia.diagonal_offsets[1]), 0); ASSERT_EQUAL(int(dia.diagonal_offsets[2]), 1);
+        const float e[12] = {0, 0, 13.75f, 16.50f, 10.25f, 0, 14.00f, 0, 11.00f, 12.50f, 15.25f, 0};
+        for (int i = 0; i < 12; i++) ASSERT_EQUAL(float(dia.values.values[i]), e[i]);
+        cusp::dia_matrix<int, float, Space> d2(dia); // H->D (or copy)
+        cusp::csr_matrix<int, float, Space> back(d2);
+        ASSERT_ARRAYS_EQUAL(back.column_indices, csr.column_indices);
+        ASSERT_ARRAYS_EQUAL(back.values, csr.values);
+    }
+    { // CSR -> ELL with alignment 1 (testing/convert.cu:440-497)
+        cusp::ell_matrix<int, float, cusp::host_memory> ell;
+        cusp::csr_matrix<int, float, cusp::host_memory> h(csr);
+        cusp::detail::from_host_csr(h, ell, cusp::ell_format(), 3, 1);
+        ASSERT_EQUAL(ell.column_indices.num_rows, size_t(4)); ASSERT_EQUAL(ell.column_indices.num_cols, size_t(3));
+        const int ec[12] = {0, 2, 0, 1, 1, X, 2, X, X, X, 3, X};
+        const float ev[12] = {10.25f, 12.50f, 13.75f, 16.50f, 11.00f, 0, 14.00f, 0, 0, 0, 15.25f, 0};
+        for (int i = 0; i < 12; i++) { ASSERT_EQUAL(int(ell.column_indices.values[i]), ec[i]); ASSERT_EQUAL(float(ell.values.values[i]), ev[i]); }
+    }
+    { // default conversions keep the matrix: every format -> CSR gives the example back
+        cusp::ell_matrix<int, float, Space> ell(csr);
+        ASSERT_EQUAL(ell.column_indices.pitch, size_t(32)); // default alignment 32
+        cusp::hyb_matrix<int, float, Space> hyb(csr);
+        cusp::dia_matrix<int, float, Space> dia(csr);
+        cusp::coo_matrix<int, float, Space> coo(csr);
+        cusp::csr_matrix<int, float, Space> a(ell), b(hyb), c(dia), d(coo);
+        for (auto *m : {&a, &b, &c, &d}) {
+            ASSERT_ARRAYS_EQUAL(m->row_offsets, csr.row_offsets);
+            ASSERT_ARRAYS_EQUAL(m->column_indices, csr.column_indices);
+            ASSERT_ARRAYS_EQUAL(m->values, csr.values);
+        }
+        // HYB with ELL width 1: testing/convert.cu:177-200
+        cusp::hyb_matrix<int, float, cusp::host_memory> h1;
+        cusp::csr_matrix<int, float, cusp::host_memory> h(csr);
+        cusp::detail::from_host_csr(h, h1, cusp::hyb_format(), 1, 1);
+        ASSERT_EQUAL(h1.ell.num_entries, size_t(4)); ASSERT_EQUAL(h1.coo.num_entries, size_t(3));
+        const int cr[3] = {0, 2, 2}, cc[3] = {1, 2, 3};
+        for (int i = 0; i < 3; i++) { ASSERT_EQUAL(int(h1.coo.row_indices[i]), cr[i]); ASSERT_EQUAL(int(h1.coo.column_indices[i]), cc[i]); }
+    }
+}
+DECLARE_SPACE_UNITTEST(TestConversionExampleAllFormats);
+
+// testing/ell_matrix.cu:5-22
+template <typename Space> void TestEllMatrixBasicConstructor()
+{
+    cusp::ell_matrix<int, float, Space> matrix(3, 2, 6, 2, 4);
+    ASSERT_EQUAL(matrix.num_rows, size_t(3)); ASSERT_EQUAL(matrix.num_cols, size_t(2)); ASSERT_EQUAL(matrix.num_entries, size_t(6));
+    ASSERT_EQUAL(matrix.column_indices.num_cols, size_t(2)); ASSERT_EQUAL(matrix.column_indices.num_rows, size_t(3));
+    ASSERT_EQUAL(matrix.column_indices.pitch, size_t(4)); ASSERT_EQUAL(matrix.column_indices.num_entries, size_t(6));
+    ASSERT_EQUAL(matrix.values.pitch, size_t(4)); ASSERT_EQUAL(matrix.values.num_entries, size_t(6));
+    cusp::ell_matrix<int, double, Space> big(9998244, 9998244, 0, 0);
+    ASSERT_EQUAL(big.column_indices.pitch, size_t(9998272)); // pitch of the 3162^2 ELL
+    typedef cusp::array2d<float, Space, cusp::column_major> A2;
+    A2 bad;
+    ASSERT_THROWS(bad.resize(10, 2, 8), cusp::invalid_input_exception); // pitch < minor dimension
+}
+DECLARE_SPACE_UNITTEST(TestEllMatrixBasicConstructor);
+
+// testing/poisson.cu:6-25
+template <typename Space> void TestPoisson5pt()
+{
+    cusp::dia_matrix<int, float, Space> matrix;
+    cusp::gallery::poisson5pt(matrix, 2, 3);
+    ASSERT_EQUAL(matrix.num_entries, size_t(20));
+    cusp::array2d<float, cusp::host_memory> R(matrix);
+    const float E[6][6] = {{4, -1, -1, 0, 0, 0}, {-1, 4, 0, -1, 0, 0}, {-1, 0, 4, -1, -1, 0}, {0, -1, -1, 4, 0, -1}, {0, 0, -1, 0, 4, -1}, {0, 0, 0, -1, -1, 4}};
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) ASSERT_EQUAL(R(i, j), E[i][j]);
+    // HYB heuristic on 5-pt Poisson: K = 5, COO part empty
+    cusp::csr_matrix<int, double, cusp::host_memory> big;
+    cusp::gallery::poisson5pt(big, 100, 100);
+    ASSERT_EQUAL(cusp::compute_optimal_entries_per_row(big.row_offsets), size_t(5));
+    cusp::hyb_matrix<int, double, Space> hyb(big);
+    ASSERT_EQUAL(hyb.ell.column_indices.num_cols, size_t(5)); ASSERT_EQUAL(hyb.coo.num_entries, size_t(0));
+}
+DECLARE_SPACE_UNITTEST(TestPoisson5pt);
+
+// ------------------------------------------------------------------------------------------------
+// testing/cg.cu:46-99 + docs/quickstart.md:72-87
+template <typename Space> void TestConjugateGradient()
+{
+    cusp::csr_matrix<int, double, Space> A;
+    cusp::gallery::poisson5pt(A, 10, 10);
+    cusp::array1d<double, Space> x(A.num_rows, 0), b(A.num_rows, 1);
+    cusp::monitor<double> monitor(b, 20, 1e-4);
+    cusp::krylov::cg(A, x, b, monitor);
+    cusp::array1d<double, Space> residual(A.num_rows, 0);
+    cusp::multiply(A, x, residual);
+    cusp::blas::axpby(residual, b, residual, -1.0, 1.0);
+    ASSERT_TRUE(monitor.converged());
+    ASSERT_TRUE(monitor.residual_norm() < 1e-4 * cusp::blas::nrm2(b));
+    ASSERT_TRUE(cusp::blas::nrm2(residual) < 1e-4 * cusp::blas::nrm2(b));
+}
+DECLARE_SPACE_UNITTEST(TestConjugateGradient);
+
+template <typename Space> void TestConjugateGradientQuickstartTrace()
+{
+    // docs/quickstart.md:72-87 (examples/Solvers/cg.cu): poisson5pt(10,10), b = 1, x0 = 0, rel-tol 1e-3:
+    // converged after 12 iterations with this residual history (printed to 7 significant digits)
+    const double trace[13] = {1.0e+01, 1.414214e+01, 1.093707e+01, 8.949319e+00, 6.190055e+00, 3.835189e+00, 1.745481e+00,
+                              5.963546e-01, 2.371134e-01, 1.152524e-01, 3.134467e-02, 1.144415e-02, 1.824176e-03};
+    cusp::csr_matrix<int, double, Space> A;
+    cusp::gallery::poisson5pt(A, 10, 10);
+    cusp::array1d<double, Space> x(A.num_rows, 0), b(A.num_rows, 1);
+    cusp::monitor<double> monitor(b, 100, 1e-3);
+    cusp::krylov::cg(A, x, b, monitor);
+    ASSERT_TRUE(monitor.converged());
+    ASSERT_EQUAL(monitor.iteration_count(), size_t(12));
+    ASSERT_EQUAL(monitor.residuals.size(), size_t(13));
+    for (int i = 0; i < 13; i++) ASSERT_TRUE(std::fabs(monitor.residuals[i] - trace[i]) <= 2e-6 * trace[i]);
+}
+DECLARE_SPACE_UNITTEST(TestConjugateGradientQuickstartTrace);
+
+template <typename Space> void TestConjugateGradientZeroResidual()
+{
+    cusp::csr_matrix<int, double, Space> A;
+    cusp::gallery::poisson5pt(A, 10, 10);
+    cusp::array1d<double, Space> x(A.num_rows, 1), b(A.num_rows);
+    cusp::multiply(A, x, b);
+    cusp::monitor<double> monitor(b, 20, 0);
+    cusp::krylov::cg(A, x, b, monitor);
+    ASSERT_EQUAL(monitor.converged(), true);
+    ASSERT_EQUAL(monitor.iteration_count(), size_t(0));
+}
+DECLARE_SPACE_UNITTEST(TestConjugateGradientZeroResidual);
+
+// ------------------------------------------------------------------------------------------------
+// testing/multiply.cu:792-858 with testing/unittest/special_types.h:108-141
+struct my_system : cusp::execution_policy<my_system> {
+    explicit my_system(int) : correctly_dispatched(false), num_copies(0) {}
+    my_system(const my_system &o) : cusp::execution_policy<my_system>(o), correctly_dispatched(false), num_copies(o.num_copies + 1) {}
+    void validate_dispatch() { correctly_dispatched = (num_copies == 0); }
+    bool is_valid() { return correctly_dispatched; }
+    bool correctly_dispatched;
+    unsigned num_copies;
+};
+template <typename MatrixType, typename ArrayType1, typename ArrayType2>
+void multiply(my_system &system, const MatrixType &, const ArrayType1 &, ArrayType2 &) { system.validate_dispatch(); }
+
+struct plain_system : cusp::execution_policy<plain_system> {}; // no overload of its own: default path
+
+template <typename Space> void TestMultiplyDispatch()
+{
+    cusp::csr_matrix<int, float, Space> A;
+    cusp::gallery::poisson5pt(A, 3, 3);
+    cusp::array1d<float, Space> x(9, 1), y(9, 10);
+    my_system sys(0);
+    cusp::multiply(sys, A, x, y); // must reach ::multiply(my_system&, ...) by ADL, policy not copied
+    ASSERT_EQUAL(true, sys.is_valid());
+    ASSERT_EQUAL(float(y[0]), 10.0f); // the user overload did nothing
+    plain_system plain;
+    cusp::multiply(plain, A, x, y);
+    ASSERT_EQUAL(float(y[0]), 2.0f); ASSERT_EQUAL(float(y[4]), 0.0f);
+}
+DECLARE_SPACE_UNITTEST(TestMultiplyDispatch);
+
+// ------------------------------------------------------------------------------------------------
+// error behaviour of the boundary
+template <typename Space> void TestMultiplyErrors()
+{
+    cusp::csr_matrix<int, double, Space> A;
+    cusp::gallery::poisson5pt(A, 4, 4);
+    cusp::array1d<double, Space> x(15), y(16);
+    ASSERT_THROWS(cusp::multiply(A, x, y), cusp::invalid_input_exception);
+    cusp::array1d<double, Space> x2(16, 1.0);
+    cusp::multiply(A, x2, y);
+    ASSERT_EQUAL(double(y[5]), 0.0);
+    cusp::csr_matrix<int, double, Space> empty(3, 3, 0);
+    cusp::array1d<double, Space> z(3, 7.0), w(3, 1.0);
+    cusp::array1d<int, cusp::host_memory> zeros(4, 0);
+    empty.row_offsets = zeros;
+    cusp::multiply(empty, w, z);
+    ASSERT_EQUAL(double(z[1]), 0.0);
+}
+DECLARE_SPACE_UNITTEST(TestMultiplyErrors);
+
+// ELLR (the fork's container, testing/ktt.cu:26-43 runs its kernels on dia / ell / ellr)
+template <typename Space> void TestEllrMatrix()
+{
+    cusp::csr_matrix<int, double, cusp::host_memory> H;
+    cusp::gallery::poisson5pt(H, 7, 5);
+    cusp::ktt::ellr_matrix<int, double, Space> R(H);
+    cusp::array1d<int, cusp::host_memory> len(R.row_lengths);
+    for (size_t i = 0; i < H.num_rows; i++) ASSERT_EQUAL(len[i], H.row_offsets[i + 1] - H.row_offsets[i]);
+    cusp::array1d<double, cusp::host_memory> x(35), y(35, 10);
+    for (int i = 0; i < 35; i++) x[i] = i % 10;
+    cusp::multiply(H, x, y);
+    cusp::array1d<double, Space> _x(x), _y(35, 10);
+    cusp::ktt::multiply(R, _x, _y);
+    ASSERT_ARRAYS_EQUAL(_y, y);
+}
+DECLARE_SPACE_UNITTEST(TestEllrMatrix);

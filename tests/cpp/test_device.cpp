@@ -1,0 +1,62 @@
+// Device build of the cusp:: layer tests: every test of spmv_tests.h with device_memory containers,
+// i.e. through the C-ABI and the gfx950 kernels (-m gpu).
+#define TEST_SPACE cusp::device_memory
+#define TEST_SPACE_NAME "device_memory"
+#include "spmv_tests.h"
+
+void TestDeviceFunctorsNotImplemented()
+{
+    cusp::csr_matrix<int, double, cusp::device_memory> A;
+    cusp::gallery::poisson5pt(A, 3, 3);
+    cusp::array1d<double, cusp::device_memory> x(9, 1.0), y(9, 0.0);
+    struct maxf { double operator()(double a, double b) const { return a > b ? a : b; } };
+    // no silent host fallback for functors the kernels do not implement
+    ASSERT_THROWS(cusp::multiply(A, x, y, cusp::identity_function<double>(), cusp::plus<double>(), maxf()), cusp::not_implemented_exception);
+}
+DECLARE_UNITTEST(TestDeviceFunctorsNotImplemented);
+
+void TestStreamPolicy()
+{
+    void *stream = nullptr;
+    cusp::detail::check(cmi_stream_create(&stream));
+    cusp::csr_matrix<int, double, cusp::device_memory> A;
+    cusp::gallery::poisson5pt(A, 50, 40);
+    cusp::csr_matrix<int, double, cusp::host_memory> H(A);
+    cusp::array1d<double, cusp::host_memory> x(2000), y(2000, 10);
+    for (int i = 0; i < 2000; i++) x[i] = (i % 21) - 10;
+    cusp::multiply(H, x, y);
+    cusp::array1d<double, cusp::device_memory> _x(x), _y(2000, 10);
+    cusp::multiply(cusp::hip::par.on(stream), A, _x, _y);
+    cusp::detail::check(cmi_stream_synchronize(stream));
+    ASSERT_ARRAYS_EQUAL(_y, y);
+    cusp::detail::check(cmi_stream_destroy(stream));
+}
+DECLARE_UNITTEST(TestStreamPolicy);
+
+void TestLargePoissonAllFormatsAgreeWithHost()
+{
+    // 1000 x 1000 grid, fp64: device formats vs the host CSR loop, bit for bit for the one-lane-per-row
+    // kernels (CSR default, ELL, DIA), to 1e-6 relative for COO / HYB's COO half
+    const size_t m = 1000, n = 1000, N = m * n;
+    cusp::csr_matrix<int, double, cusp::device_memory> A;
+    cusp::gallery::poisson5pt(A, m, n);
+    cusp::csr_matrix<int, double, cusp::host_memory> H(A);
+    cusp::array1d<double, cusp::host_memory> x(N), y(N, 10);
+    for (size_t i = 0; i < N; i++) x[i] = double((unsigned(i) * 2654435761u) % 1000u) / 997.0 - 0.5;
+    cusp::multiply(H, x, y);
+    cusp::array1d<double, cusp::device_memory> _x(x), _y(N, 10);
+    cusp::multiply(A, _x, _y);
+    ASSERT_ARRAYS_EQUAL(_y, y);
+    cusp::ell_matrix<int, double, cusp::device_memory> E(A);
+    cusp::blas::fill(_y, 10.0); cusp::multiply(E, _x, _y); ASSERT_ARRAYS_EQUAL(_y, y);
+    cusp::dia_matrix<int, double, cusp::device_memory> D;
+    cusp::gallery::poisson5pt(D, m, n);
+    cusp::blas::fill(_y, 10.0); cusp::multiply(D, _x, _y); ASSERT_ARRAYS_EQUAL(_y, y);
+    cusp::coo_matrix<int, double, cusp::device_memory> C(A);
+    cusp::blas::fill(_y, 10.0); cusp::multiply(C, _x, _y);
+    cusp::array1d<double, cusp::host_memory> got(_y);
+    for (size_t i = 0; i < N; i++) ASSERT_TRUE(std::fabs(got[i] - y[i]) <= 1e-6 * 8.0);
+}
+DECLARE_UNITTEST(TestLargePoissonAllFormatsAgreeWithHost);
+
+int main(int argc, char **argv) { return unittest::run_all(argc, argv); }
