@@ -146,7 +146,8 @@ def main():
     fmt = args.format if world == 1 else "csr"
     Afmt = A if fmt == "csr" else (cmi.poisson5pt(m, n, "dia", device=dev) if fmt == "dia" else
                                    cmi.convert(A, fmt, num_entries_per_row=5 if fmt == "hyb" else None))
-    x_host = cmi.fill_x(N_global).numpy()  # deterministic, RNG-free input
+    # deterministic, RNG-free input; each rank generates only its own slice
+    x_host = cmi.fill_x(rows_per_rank, start=lo).numpy()
     y = torch.full((rows_per_rank,), 10.0, dtype=torch.float64, device=dev)
 
     if world == 1:
@@ -156,7 +157,7 @@ def main():
     else:
         sh = cmi.distributed.ShardedCsr(A, N_global, rank, world, mode=args.exchange,
                                         col_span=(max(lo - m, 0), min(hi + m, N_global) - 1))
-        sh.x_local.copy_(torch.from_numpy(x_host[lo:hi]).to(dev))
+        sh.x_local.copy_(torch.from_numpy(x_host).to(dev))
         step = lambda: sh.multiply(y)  # noqa: E731
         p = sh.vec.plan
         exchange_info = {"mode": p.mode, "values_received_per_rank": p.recv_values if p.mode == "halo" else p.allgather_values,

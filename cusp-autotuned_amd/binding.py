@@ -118,6 +118,11 @@ def lib():
             raise ImportError(
                 f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C cusp-autotuned_amd/csrc`.  The SpMV engine has no CPU fallback.")
+        # torch bundles its own HIP runtime (torch/lib/libamdhip64.so); it must be the one this
+        # process binds, so import torch BEFORE the library pulls in /opt/rocm's copy.  Loading in the
+        # other order leaves two runtimes fighting over the device ("no ROCm-capable device is
+        # detected" at the first launch) -- seen on MI355X when a test module loaded the library first.
+        import torch  # noqa: F401
         L = ctypes.CDLL(_LIB_PATH)
         _declare(L)
         _lib = L

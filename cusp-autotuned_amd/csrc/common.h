@@ -53,12 +53,17 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 void select_config(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
                    const cmi_config *user, cmi_config *out);
 
-// XCD-aware tile index: blocks b and b+8 share an XCD (observed round-robin placement; a
-// different placement changes speed only).  With swizzle each XCD walks a contiguous run of
-// tiles, so the x window its rows gather stays in that XCD's L2.  grid = 8*ceil(tiles/8).
-__device__ __forceinline__ int64_t tile_of_block(int64_t b, int64_t tiles_per_xcd, bool swizzle)
+// XCD-aware tile index.  Workgroups b and b+8 share an XCD (observed round-robin placement; a
+// different placement changes speed only, never results).  mode 0: tile = b.  mode 1: every XCD walks
+// one contiguous eighth of the tiles.  mode C >= 2: tiles are dealt to the XCDs in chunks of C
+// consecutive tiles, so the x window a chunk gathers (its rows +- the matrix bandwidth) is fetched
+// into ONE L2 while the whole grid still sweeps the arrays front to back.
+__device__ __forceinline__ int64_t tile_of_block(int64_t b, int64_t tiles_per_xcd, int mode)
 {
-    return swizzle ? (b % kXcds) * tiles_per_xcd + b / kXcds : b;
+    if (mode == 0) return b;
+    if (mode == 1) return (b % kXcds) * tiles_per_xcd + b / kXcds;
+    const int64_t q = b / kXcds, r = b % kXcds, C = mode;
+    return ((q / C) * kXcds + r) * C + q % C;
 }
 
 template <typename T> struct vec2;

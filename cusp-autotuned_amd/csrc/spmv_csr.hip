@@ -82,7 +82,7 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
     T *prod = reinterpret_cast<T *>(smem);
     int *rowptr = reinterpret_cast<int *>(smem + (size_t)tile_entries * sizeof(T));
 
-    const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle != 0);
+    const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle);
     if (tile >= num_tiles) return; // whole workgroup leaves together: no barrier is skipped by a part
     const int64_t r0 = tile * rows_per_block;
     const int nr = (int)((num_rows - r0) < rows_per_block ? (num_rows - r0) : rows_per_block);
@@ -406,8 +406,8 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         if (rpb < 1 || rpb > 4 * block) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream: rows_per_block must be in [1, 4*block_size]");
         const int64_t tiles = ceil_div(rows, rpb);
         const int64_t tpx = ceil_div(tiles, kXcds);
-        const int swz = c.xcd_swizzle != 0;
-        const int64_t grid64 = swz ? tpx * kXcds : tiles;
+        const int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
+        const int64_t grid64 = swz == 0 ? tiles : swz == 1 ? tpx * kXcds : ceil_div(tiles, (int64_t)kXcds * swz) * kXcds * swz;
         if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream: grid too large");
         const size_t lds = (size_t)block * ipt * 4 * sizeof(T) + (size_t)(rpb + 1) * sizeof(int);
         if (lds > 160 * 1024) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream: tile does not fit 160 KiB of LDS");

@@ -117,7 +117,9 @@ typedef struct cmi_config {
                                  ELL/DIA: rows per lane (1,2); COO: entries per lane; 0 = default   */
     int32_t nontemporal;      /* cache policy bits: 1 = once-read matrix streams loaded with the nt
                                  hint, 2 = y stored with the nt hint (3 = both)                     */
-    int32_t xcd_swizzle;      /* 1 = give each XCD a contiguous run of tiles (L2 reuse of x)       */
+    int32_t xcd_swizzle;      /* CSR stream: 0 = tiles in launch order, 1 = one contiguous eighth of
+                                 the tiles per XCD, C >= 2 = chunks of C tiles dealt round the XCDs
+                                 (L2 reuse of x); CSR stream_pipe: != 0 = chunked tile schedule     */
     int32_t blocks_per_cu;    /* persistent kernels: workgroups per CU in the grid; 0 = default (8)  */
 } cmi_config;
 

@@ -78,9 +78,10 @@ class Oracle(_SpmvMixin):
         L.orc_csr_row_indices.argtypes = [c_int64, c_void_p, c_void_p]
         L.orc_num_threads.restype = c_int
         L.orc_set_num_threads.argtypes = [c_int]
-        # size the OpenMP team to the CPU share of this process (a GPU box gives 16 of its cores)
+        # size the OpenMP team to the CPU share of this process (a one-GPU box gives 16 cores,
+        # whatever the affinity mask says)
         try:
-            L.orc_set_num_threads(min(len(os.sched_getaffinity(0)), 64))
+            L.orc_set_num_threads(min(len(os.sched_getaffinity(0)), 16))
         except AttributeError:
             pass
         for s in ("f64", "f32"):

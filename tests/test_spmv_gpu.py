@@ -58,7 +58,8 @@ def csr_variants(cmi, small=False):
     out.append(("vector8nt", False, cmi.Config(kernel=cmi.CSR_VECTOR, block_size=256, threads_per_row=8, nontemporal=1)))
     for blk, ipt, rpb, nt, swz in ((256, 1, 0, 0, 1), (256, 1, 0, 1, 0), (256, 2, 0, 0, 1), (256, 4, 0, 0, 0),
                                    (128, 1, 0, 0, 1), (512, 1, 0, 0, 1), (64, 1, 7, 2, 1), (256, 1, 1, 0, 0),
-                                   (256, 1, 1024, 3, 1), (128, 2, 512, 1, 1), (1024, 1, 300, 0, 1), (256, 1, 192, 2, 0)):
+                                   (256, 1, 1024, 3, 1), (128, 2, 512, 1, 1), (1024, 1, 300, 0, 1), (256, 1, 192, 2, 0),
+                                   (256, 1, 192, 2, 16), (128, 1, 5, 0, 3), (256, 2, 0, 2, 64)):
         out.append((f"stream b{blk} i{ipt} r{rpb} nt{nt} x{swz}", True,
                     cmi.Config(kernel=cmi.CSR_STREAM, block_size=blk, items_per_thread=ipt, rows_per_block=rpb,
                                nontemporal=nt, xcd_swizzle=swz)))

@@ -42,7 +42,8 @@ def csr_space(cmi, mean, quick):
     for t, b, nt in itertools.product(tprs, blocks, (0, 1)):
         out.append(cmi.Config(kernel=cmi.CSR_VECTOR, block_size=b, threads_per_row=t, nontemporal=nt))
     if mean <= 40:
-        for b, ipt, nt, swz in itertools.product(blocks, (1, 2, 4), (0, 2) if quick else (0, 1, 2, 3), (0, 1)):
+        for b, ipt, nt, swz in itertools.product(blocks, (1, 2, 4), (0, 2) if quick else (0, 1, 2, 3),
+                                                 (0, 1, 32) if quick else (0, 1, 8, 16, 32, 64, 128, 256)):
             tile = b * ipt * 4
             base = max(1, int((tile - 3) / max(mean, 0.25)))
             aligned = max(1, base // 16 * 16)
