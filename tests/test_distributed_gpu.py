@@ -1,0 +1,65 @@
+"""GPU test (-m gpu) of the N>1 path with the REAL local multiply: two ranks share the one GPU of the
+box (gloo as the transport -- RCCL refuses two ranks on one device), each owns a row block of
+poisson5pt built in HBM with global column indices, exchanges x (halo and all-gather) and runs the
+HIP SpMV on its block.  The concatenated y must equal the oracle's whole-matrix result bit for bit.
+The 8-GPU RCCL run itself is the driver's (bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, m, n, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cusp_autotuned_amd as cmi
+        N = m * n
+        offs = cmi.distributed.partition_rows(N, world)
+        lo, hi = offs[rank], offs[rank + 1]
+        A = cmi.poisson5pt(m, n, "csr", row_begin=lo, row_end=hi)
+        sh = cmi.distributed.ShardedCsr(A, N, rank, world, mode=mode)
+        sh.x_local.copy_(cmi.fill_x(hi - lo, start=lo).cuda())
+        y = torch.full((hi - lo,), 10.0, dtype=torch.float64, device="cuda")
+        sh.multiply(y)
+        sh.x_local.mul_(-2.0)
+        y2 = torch.empty_like(y)
+        sh.multiply(y2)
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), y=y.cpu().numpy(), y2=y2.cpu().numpy(), mode=sh.vec.plan.mode,
+                 recv=sh.vec.plan.recv_values)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["halo", "allgather", "auto"])
+def test_two_ranks_one_gpu_real_kernels(tmp_path, orc, mode):
+    import oracle
+    import torch.multiprocessing as mp
+    m, n, world = 300, 200, 2
+    mp.spawn(_worker, args=(world, _free_port(), mode, m, n, str(tmp_path)), nprocs=world, join=True)
+    Ap, Aj, Ax = orc.poisson5pt_csr(m, n)
+    x = oracle.fill_x(m * n)
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    assert np.array_equal(np.concatenate([p["y"] for p in parts]), orc.spmv_csr(Ap, Aj, Ax, x))
+    assert np.array_equal(np.concatenate([p["y2"] for p in parts]), orc.spmv_csr(Ap, Aj, Ax, -2.0 * x))
+    if mode != "allgather":
+        assert all(str(p["mode"]) == "halo" and int(p["recv"]) == m for p in parts)
