@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(1024)
 csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ Ap,
                   const int *__restrict__ Aj, const T *__restrict__ Ax, const T *__restrict__ x,
                   T *__restrict__ y, int rows_per_block, int64_t num_tiles, int64_t tiles_per_xcd,
-                  int swizzle, int accumulate)
+                  int swizzle, int accumulate, int tpr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool NT = (POL & kPolLoadNT) != 0;
@@ -91,12 +91,17 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
     __syncthreads();
     const int nz0 = rowptr[0], nz1 = rowptr[nr];
 
-    // a lane owns rows tid, tid+block, ... (at most 4: rows_per_block <= 4*block, host-checked)
+    // tpr lanes share a row (tpr = 1: one lane per row, storage order, bit-exact; tpr > 1 for long
+    // rows: lane-strided partial sums + a butterfly inside the tpr-lane group).  A group owns rows
+    // g, g + G, ... with G = block / tpr groups (at most 4: rows_per_block <= 4*G, host-checked);
+    // the group's lane 0 keeps the running sums across LDS passes.
+    const int groups = block / tpr;
+    const int grp = tid / tpr, sub = tid - grp * tpr;
     T acc[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int r = tid + q * block;
-        acc[q] = (accumulate && r < nr) ? y[r0 + r] : T(0);
+        const int r = grp + q * groups;
+        acc[q] = (accumulate && sub == 0 && r < nr) ? y[r0 + r] : T(0);
     }
 
     for (int base = VEC ? (nz0 & ~3) : nz0; base < nz1; base += tile_entries) {
@@ -138,17 +143,33 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
             }
         }
         __syncthreads();
-        // ---- phase 2: one lane per row, products added in storage order ----
+        // ---- phase 2: row sums out of LDS ----
+        if (tpr == 1) { // one lane per row, products added in storage order
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int r = tid + q * block;
-            if (r < nr) {
-                int a = rowptr[r], b = rowptr[r + 1];
-                a = a > base ? a : base;
-                b = b < base + tile_entries ? b : base + tile_entries;
-                T s = acc[q];
-                for (int j = a; j < b; j++) s = s + prod[j - base];
-                acc[q] = s;
+            for (int q = 0; q < 4; q++) {
+                const int r = tid + q * block;
+                if (r < nr) {
+                    int a = rowptr[r], b = rowptr[r + 1];
+                    a = a > base ? a : base;
+                    b = b < base + tile_entries ? b : base + tile_entries;
+                    T s = acc[q];
+                    for (int j = a; j < b; j++) s = s + prod[j - base];
+                    acc[q] = s;
+                }
+            }
+        } else { // tpr lanes per row (wave-uniform branch: tpr is a kernel argument)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int r = grp + q * groups;
+                if (r < nr) { // the same for every lane of a group
+                    int a = rowptr[r], b = rowptr[r + 1];
+                    a = a > base ? a : base;
+                    b = b < base + tile_entries ? b : base + tile_entries;
+                    T s = T(0);
+                    for (int j = a + sub; j < b; j += tpr) s = s + prod[j - base];
+                    for (int o = tpr >> 1; o > 0; o >>= 1) s = s + __shfl_down(s, o, tpr);
+                    if (sub == 0) acc[q] = acc[q] + s;
+                }
             }
         }
         if (base + tile_entries < nz1) __syncthreads(); // another pass reuses prod (uniform condition)
@@ -156,8 +177,8 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
 
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int r = tid + q * block;
-        if (r < nr) st<(POL & kPolStoreNT) != 0>(y + r0 + r, acc[q]);
+        const int r = grp + q * groups;
+        if (sub == 0 && r < nr) st<(POL & kPolStoreNT) != 0>(y + r0 + r, acc[q]);
     }
 }
 
@@ -352,11 +373,11 @@ static int launch_vector(int tpr, int grid, int block, hipStream_t s, int64_t ro
 template <typename T, bool VEC, int POL>
 static int launch_stream_ipt(int ipt, int grid, int block, size_t lds, hipStream_t s, int64_t rows, int64_t nnz,
                              const int *Ap, const int *Aj, const T *Ax, const T *x, T *y, int rpb, int64_t tiles,
-                             int64_t tpx, int swz, int acc)
+                             int64_t tpx, int swz, int acc, int tpr)
 {
 #define CMI_STREAM_LAUNCH(IPT)                                                                                   \
     hipLaunchKernelGGL((csr_stream_kernel<T, IPT, VEC, POL>), dim3(grid), dim3(block), lds, s, rows, nnz, Ap, Aj, \
-                       Ax, x, y, rpb, tiles, tpx, swz, acc)
+                       Ax, x, y, rpb, tiles, tpx, swz, acc, tpr)
     switch (ipt) {
     case 1: CMI_STREAM_LAUNCH(1); break;
     case 2: CMI_STREAM_LAUNCH(2); break;
@@ -403,7 +424,9 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     case CMI_CSR_STREAM: {
         const int rpb = c.rows_per_block;
         const int ipt = c.items_per_thread;
-        if (rpb < 1 || rpb > 4 * block) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream: rows_per_block must be in [1, 4*block_size]");
+        int tpr = c.threads_per_row <= 1 ? 1 : c.threads_per_row;
+        if (tpr > 64 || (tpr & (tpr - 1)) != 0) return fail(CMI_ERROR_NOT_SUPPORTED, "csr_stream: threads_per_row must be 0/1 or a power of two <= 64");
+        if (rpb < 1 || rpb > 4 * (block / tpr)) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream: rows_per_block must be in [1, 4*block_size/threads_per_row]");
         const int64_t tiles = ceil_div(rows, rpb);
         const int64_t tpx = ceil_div(tiles, kXcds);
         const int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
@@ -414,8 +437,8 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         const bool vec = (reinterpret_cast<uintptr_t>(Aj) % 16 == 0) && (reinterpret_cast<uintptr_t>(Ax) % 16 == 0);
         with_policy(pol, [&](auto P) {
             constexpr int POL = decltype(P)::value;
-            st = vec ? launch_stream_ipt<T, true, POL>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate)
-                     : launch_stream_ipt<T, false, POL>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate);
+            st = vec ? launch_stream_ipt<T, true, POL>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate, tpr)
+                     : launch_stream_ipt<T, false, POL>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate, tpr);
         });
         if (st) return st;
         break;

@@ -54,16 +54,16 @@ static void heuristic(int format, int dtype, double mean, cmi_config *c)
     c->block_size = 256;
     switch (format) {
     case CMI_FORMAT_CSR:
-        if (mean <= 16.0) {
-            // short rows: stream the nnz tile through LDS, one lane sums one row in storage order
-            c->kernel = CMI_CSR_STREAM;
-            c->items_per_thread = 1;
-            c->nontemporal = kPolStoreNT; // measured: nt y stores, plain loads, no XCD swizzle
-        } else {
-            // long rows: a sub-wave per row (the reference's selector, extended to the 64-wide wave)
-            c->kernel = CMI_CSR_VECTOR;
-            c->threads_per_row = mean <= 32.0 ? 32 : 64;
-        }
+        // every row length: stream the entry tile through LDS (coalesced 16-byte vector loads);
+        // short rows are summed by one lane each (storage order, bit-exact), longer rows by a
+        // power-of-two group of lanes (lane-strided partial sums + butterfly)
+        c->kernel = CMI_CSR_STREAM;
+        c->nontemporal = kPolStoreNT; // measured: nt y stores, plain loads, no XCD swizzle
+        if (mean <= 12.0) { c->items_per_thread = 1; c->threads_per_row = 0; }
+        else if (mean <= 24.0) { c->items_per_thread = 2; c->threads_per_row = 4; }
+        else if (mean <= 48.0) { c->items_per_thread = 2; c->threads_per_row = 8; }
+        else if (mean <= 96.0) { c->items_per_thread = 4; c->threads_per_row = 16; }
+        else { c->items_per_thread = 4; c->threads_per_row = 32; }
         break;
     case CMI_FORMAT_ELL: c->kernel = CMI_ELL_ROW; c->items_per_thread = 1; break;
     case CMI_FORMAT_DIA: c->kernel = CMI_DIA_ROW; c->items_per_thread = 1; break;
@@ -112,12 +112,16 @@ static void complete(int format, int dtype, int64_t rows, int64_t nnz, cmi_confi
         if (c->kernel == CMI_CSR_STREAM) {
             int ipt = c->items_per_thread;
             c->items_per_thread = ipt <= 1 ? 1 : ipt <= 2 ? 2 : 4;
+            int tpr = c->threads_per_row <= 1 ? 1 : c->threads_per_row; // lanes per row in the LDS row-sum phase
+            int p2 = 1;
+            while (p2 < tpr && p2 < 64) p2 <<= 1;
+            c->threads_per_row = p2 == 1 ? 0 : p2;
             const int64_t tile = (int64_t)c->block_size * c->items_per_thread * 4;
             if (c->rows_per_block <= 0) {
                 // largest row count whose entries fit one LDS pass (3 slots of alignment slack);
                 // an explicit rows_per_block is left alone and validated by the launcher
                 double r = mean > 0.0 ? std::floor((double)(tile - 3) / mean) : (double)c->block_size;
-                const double max_rows = 4.0 * c->block_size; // a lane sums at most 4 rows
+                const double max_rows = 4.0 * (c->block_size / p2); // a lane group sums at most 4 rows
                 if (r > max_rows) r = max_rows;
                 if (r >= 32.0) r = std::floor(r / 16.0) * 16.0; // whole 128-byte lines of y per tile
                 if (r < 1.0) r = 1.0;

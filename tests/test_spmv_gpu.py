@@ -63,6 +63,10 @@ def csr_variants(cmi, small=False):
         out.append((f"stream b{blk} i{ipt} r{rpb} nt{nt} x{swz}", True,
                     cmi.Config(kernel=cmi.CSR_STREAM, block_size=blk, items_per_thread=ipt, rows_per_block=rpb,
                                nontemporal=nt, xcd_swizzle=swz)))
+    for blk, ipt, rpb, tpr in ((256, 1, 0, 2), (256, 2, 0, 4), (256, 4, 64, 16), (128, 1, 8, 64), (512, 4, 0, 32), (64, 1, 3, 8)):
+        out.append((f"stream-tpr b{blk} i{ipt} r{rpb} t{tpr}", False,
+                    cmi.Config(kernel=cmi.CSR_STREAM, block_size=blk, items_per_thread=ipt, rows_per_block=rpb,
+                               threads_per_row=tpr, nontemporal=2)))
     for blk, rpb, nt, chunked, bpc in ((256, 0, 0, 0, 0), (256, 0, 1, 1, 4), (128, 0, 0, 0, 8), (512, 0, 0, 1, 2),
                                        (64, 7, 2, 0, 1), (256, 255, 3, 0, 16), (256, 1, 1, 1, 3), (1024, 300, 0, 0, 1), (256, 192, 2, 0, 3)):
         out.append((f"pipe b{blk} r{rpb} nt{nt} c{chunked} bpc{bpc}", True,
