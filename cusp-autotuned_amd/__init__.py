@@ -27,4 +27,4 @@ from .matrices import (  # noqa: F401
     CsrMatrix, CooMatrix, EllMatrix, DiaMatrix, HybMatrix, multiply, poisson5pt, convert,
     csr_bytes, ell_bytes, dia_bytes, coo_bytes, fill_x,
 )
-from . import distributed  # noqa: F401,E402
+from . import distributed, krylov  # noqa: F401,E402

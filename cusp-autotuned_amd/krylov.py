@@ -1,0 +1,114 @@
+"""Conjugate gradients on device vectors, single GPU or row-block sharded -- the caller of the SpMV
+hot path (reference cusp/krylov/detail/cg.inl:41-107, cusp/detail/monitor.inl).  Same operations in
+the same order as the reference, so the residual history matches (docs/quickstart.md:72-87).
+
+Every vector operation is a C-ABI call (cmi_blas_*_f64, cmi_spmv_*); Python only sequences them.
+Sharded (ShardedCsr): every rank holds its slice of x, b and of the four work vectors; the search
+direction p lives INSIDE the rank's x-exchange buffer, so `y <- A p` is exchange + local SpMV with no
+extra copy; the two dot products and the norm per iteration are 8-byte all-reduces (RCCL), as
+SURVEY.md section 8(e) lays out.
+"""
+import math
+
+
+class Monitor:
+    """cusp::monitor (reference cusp/monitor.h:118-250): stop when ||r|| <= abs + rel*||b|| or at the
+    iteration limit; keeps the residual history."""
+
+    def __init__(self, b_norm, iteration_limit=500, relative_tolerance=1e-5, absolute_tolerance=0.0, verbose=False):
+        self.b_norm = float(b_norm)
+        self.r_norm = float("inf")
+        self.iteration_limit = int(iteration_limit)
+        self.iteration_count = 0
+        self.relative_tolerance = float(relative_tolerance)
+        self.absolute_tolerance = float(absolute_tolerance)
+        self.verbose = verbose
+        self.residuals = []
+
+    def tolerance(self):
+        return self.absolute_tolerance + self.relative_tolerance * self.b_norm
+
+    def converged(self):
+        return self.r_norm <= self.tolerance()
+
+    def finished(self, r_norm):
+        self.r_norm = float(r_norm)
+        self.residuals.append(self.r_norm)
+        if self.verbose:
+            print(f"       {self.iteration_count:10d}       {self.r_norm:10.6e}")
+        return self.converged() or self.iteration_count >= self.iteration_limit
+
+    def increment(self):
+        self.iteration_count += 1
+
+
+class _Ops:
+    """dot / norm with the cross-rank reduction folded in."""
+
+    def __init__(self, device, group, world):
+        import torch
+        from . import binding as B
+        self.B, self.torch = B, torch
+        self.ws = B.blas_workspace(device)
+        self.res = torch.zeros(1, dtype=torch.float64, device=device)
+        self.group, self.world = group, world
+
+    def dot(self, x, y):
+        self.B.blas_dot(x, y, self.res, self.ws)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.res, group=self.group)
+        return float(self.res.item())
+
+    def nrm2(self, x):
+        return math.sqrt(self.dot(x, x))
+
+
+def cg(A, x, b, monitor=None, iteration_limit=500, relative_tolerance=1e-5, absolute_tolerance=0.0, group=None):
+    """Solve A x = b (A symmetric positive definite).  A: a matrices.* container (one GPU) or a
+    distributed.ShardedCsr (x, b = this rank's slices).  x holds the initial guess and the result.
+    Returns the Monitor (residual history in .residuals)."""
+    import torch
+    from . import binding as B
+    from .distributed import ShardedCsr
+    from .matrices import multiply
+
+    sharded = isinstance(A, ShardedCsr)
+    world = A.world if sharded else 1
+    n = x.numel()
+    dev = x.device
+    ops = _Ops(dev, group, world)
+    if monitor is None:
+        monitor = Monitor(ops.nrm2(b), iteration_limit, relative_tolerance, absolute_tolerance)
+
+    y = torch.empty(n, dtype=torch.float64, device=dev)
+    z = torch.empty_like(y)
+    r = torch.empty_like(y)
+    # the search direction lives in the exchange buffer when sharded: A p needs no staging copy
+    p = A.x_local if sharded else torch.empty_like(y)
+
+    def spmv(v, out):  # out <- A v
+        if sharded:
+            if v.data_ptr() != A.x_local.data_ptr():
+                B.blas_copy(v, A.x_local)
+            A.multiply(out)
+        else:
+            multiply(A, v, out)
+
+    spmv(x, y)                                   # y <- A x            (cg.inl:63)
+    B.blas_axpby(1.0, b, -1.0, y, r)             # r <- b - A x        (:66)
+    B.blas_copy(r, z)                            # z <- M r, M = I     (:69, linear_operator.h:204-208)
+    B.blas_copy(z, p)                            # p <- z              (:72)
+    rz = ops.dot(r, z)                           # rz = <r, z>         (:75)
+    while not monitor.finished(ops.nrm2(r)):     # monitor.inl:181-207
+        spmv(p, y)                               # y <- A p            (:80)  THE HOT PATH
+        alpha = rz / ops.dot(y, p)               # (:83)
+        B.blas_axpy(alpha, p, x)                 # x <- x + alpha p    (:86)
+        B.blas_axpy(-alpha, y, r)                # r <- r - alpha y    (:89)
+        B.blas_copy(r, z)                        # z <- M r            (:92)
+        rz_old = rz
+        rz = ops.dot(r, z)                       # (:97)
+        beta = rz / rz_old
+        B.blas_axpby(1.0, z, beta, p, p)         # p <- z + beta p     (:103)
+        monitor.increment()                      # (:105)
+    return monitor
