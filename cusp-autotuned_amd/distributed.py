@@ -82,19 +82,12 @@ class ShardedVectorExchange:
             raise ValueError(f"unknown exchange mode {mode!r}")
         self.plan = ExchangePlan(mode, recv, send, self.count, recv_values, allgather_values)
         self._gather_in = None
+        self._ops = None
         if mode == "allgather" and world > 1:
             self._gather_in = torch.zeros(self.count, dtype=dtype, device=device)
 
-    def exchange(self):
-        """Fill x_full with what this rank's rows need.  x_local must already hold the fresh slice."""
-        if self.world == 1:
-            return
+    def _build_ops(self):
         dist, plan = self.dist, self.plan
-        if plan.mode == "allgather":
-            n = self.hi - self.lo
-            self._gather_in[:n].copy_(self.x_local)
-            dist.all_gather_into_tensor(self.x_full, self._gather_in, group=self.group)
-            return
         ops = []
         for p in range(self.world):
             l, h = plan.send[p]
@@ -104,9 +97,30 @@ class ShardedVectorExchange:
             l, h = plan.recv[p]
             if h > l:
                 ops.append(dist.P2POp(dist.irecv, self.x_full[l:h], p, group=self.group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+        return ops
+
+    def start(self):
+        """Begin filling x_full (asynchronous on the communication stream); returns the work handles.
+        x_local must already hold the fresh slice."""
+        if self.world == 1:
+            return []
+        dist, plan = self.dist, self.plan
+        if plan.mode == "allgather":
+            n = self.hi - self.lo
+            self._gather_in[:n].copy_(self.x_local)
+            return [dist.all_gather_into_tensor(self.x_full, self._gather_in, group=self.group, async_op=True)]
+        if self._ops is None:
+            self._ops = self._build_ops()  # built once: the ranges never change
+        return dist.batch_isend_irecv(self._ops) if self._ops else []
+
+    @staticmethod
+    def finish(works):
+        for w in works:
+            w.wait()  # RCCL: the compute stream waits for the communication stream, the host does not block
+
+    def exchange(self):
+        """Fill x_full with what this rank's rows need."""
+        self.finish(self.start())
 
 
 class ShardedCsr:
@@ -117,7 +131,7 @@ class ShardedCsr:
     exchange logic without a GPU.)"""
 
     def __init__(self, A_local, num_cols, rank, world, mode="auto", group=None, local_multiply=None,
-                 col_span=None):
+                 col_span=None, overlap=True, interior=None):
         import torch
         self.A = A_local
         self.rank, self.world = rank, world
@@ -133,19 +147,77 @@ class ShardedCsr:
             raise ValueError(f"rank {rank}: local block has {A_local.num_rows} rows, partition expects "
                              f"{self.vec.hi - self.vec.lo}")
         self.x_view = self.vec.x_full[:num_cols]
+        self._custom = local_multiply is not None
         if local_multiply is None:
             from .matrices import multiply as _mul
             local_multiply = lambda x_full, y: _mul(self.A, x_full, y)  # noqa: E731
         self._mul = local_multiply
         self.torch = torch
+        # Overlap (halo mode): rows [a, b) reference only this rank's own slice of x, so they are
+        # multiplied WHILE the halo is in flight; the boundary rows [0, a) and [b, n) follow once it
+        # has landed.  A row range of a CSR matrix is itself a CSR matrix (row offsets are absolute
+        # positions in the shared column/value arrays), so the split needs no copy and no new kernel.
+        self.interior = None
+        self._cfg = None
+        if overlap and world > 1 and self.vec.plan.mode == "halo" and not self._custom:
+            self.interior = interior if interior is not None else self._interior_rows()
+            from . import binding as B
+            self._cfg = B.tuning_select(B.FORMAT_CSR, B.F64 if A_local.values.dtype == torch.float64 else B.F32,
+                                        A_local.num_rows, A_local.num_cols, A_local.num_entries)
+
+    def _interior_rows(self):
+        """Largest middle block [a, b) of rows whose columns all lie in [lo, hi) (setup-time)."""
+        torch, A = self.torch, self.A
+        n = A.num_rows
+        if n == 0 or A.num_entries == 0:
+            return None
+        lens = (A.row_offsets[1:] - A.row_offsets[:-1]).long()
+        cols = A.column_indices.double()
+        cmin = torch.segment_reduce(cols, "min", lengths=lens, unsafe=True)
+        cmax = torch.segment_reduce(cols, "max", lengths=lens, unsafe=True)
+        empty = lens == 0
+        local = ((cmin >= self.vec.lo) & (cmax < self.vec.hi)) | empty
+        bad = torch.nonzero(~local).flatten()
+        if bad.numel() == 0:
+            return (0, n)
+        # boundary rows cluster at the two ends of a banded block: take the widest run between them
+        first_bad, last_bad = int(bad[0]), int(bad[-1])
+        mid = n // 2
+        below = bad[bad < mid]
+        above = bad[bad >= mid]
+        a = int(below[-1]) + 1 if below.numel() else 0
+        b = int(above[0]) if above.numel() else n
+        del first_bad, last_bad
+        return (a, b) if b - a > n // 2 else None
 
     @property
     def x_local(self):
         return self.vec.x_local
 
+    def _rows(self, a, b, y_local):
+        """y_local[a:b] = A[a:b, :] * x (a row range of the local block)."""
+        from . import binding as B
+        A = self.A
+        if b <= a:
+            return
+        # launch shape chosen for the WHOLE local block (a row range passes the full column/value
+        # arrays, so its own entry count is not what the tuning table should see)
+        B.spmv_csr(b - a, A.num_cols, A.row_offsets[a:b + 1], A.column_indices, A.values, self.x_view, y_local[a:b],
+                   cfg=self._cfg)
+
     def multiply(self, y_local, exchange=True):
         """y_local = A[lo:hi, :] * x, with x's slices taken from every rank's x_local."""
-        if exchange:
+        if not exchange:
+            self._mul(self.x_view, y_local)
+            return y_local
+        if self.interior is None:
             self.vec.exchange()
-        self._mul(self.x_view, y_local)
+            self._mul(self.x_view, y_local)
+            return y_local
+        a, b = self.interior
+        works = self.vec.start()          # halo in flight ...
+        self._rows(a, b, y_local)         # ... while the interior rows are multiplied
+        self.vec.finish(works)
+        self._rows(0, a, y_local)
+        self._rows(b, self.A.num_rows, y_local)
         return y_local
