@@ -41,37 +41,57 @@ coo_segmented_kernel(int64_t num_entries, const int *__restrict__ Ai, const int 
     int carry_row = -1; // open segment carried from the previous 64 entries (held by every lane)
     T carry_val = T(0);
 
-    for (int64_t base = begin; base < end; base += kWave) {
-        const int64_t e = base + lane;
-        const bool live = e < end;
-        int row = live ? ld<NT>(Ai + e) : -2; // -2: never equal to a real row or to the empty carry
-        T val = live ? ld<NT>(Ax + e) * x[ld<NT>(Aj + e)] : T(0);
-
-        // fold the carry into lane 0 if it continues the same row, else flush it
-        if (carry_row >= 0) {
-            const int row0 = __shfl(row, 0);
-            if (row0 == carry_row) { if (lane == 0) val = carry_val + val; }
-            else if (lane == 0) atomic_add(y + carry_row, carry_val);
-        }
-
-        // segmented inclusive scan over the wave; a segment = a maximal run of equal ADJACENT rows
-        // (head flags, so unsorted input -- e.g. rows 5,3,5 -- is never merged across a gap)
-        const int prev_row = __shfl_up(row, 1);
-        int head = (lane == 0 || prev_row != row) ? 1 : 0;
+    // Four 64-entry steps are LOADED together (row / column / value streams, then the x gathers) so a
+    // wave keeps 16 loads in flight; the segmented scans then run step by step on registers.
+    constexpr int U = 4;
+    for (int64_t base4 = begin; base4 < end; base4 += U * kWave) {
+        int rows_[U], cols_[U];
+        T vals_[U], xs_[U];
 #pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-            const T v = __shfl_up(val, o);
-            const int h = __shfl_up(head, o);
-            if (lane >= o && !head) { val = val + v; head = h; }
+        for (int u = 0; u < U; u++) {
+            const int64_t e = base4 + u * kWave + lane;
+            const int64_t ec = e < end ? e : end - 1; // clamp: dead lanes re-read the last entry
+            rows_[u] = ld<NT>(Ai + ec);
+            cols_[u] = ld<NT>(Aj + ec);
+            vals_[u] = ld<NT>(Ax + ec);
         }
+#pragma unroll
+        for (int u = 0; u < U; u++) xs_[u] = x[cols_[u]];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t base = base4 + u * kWave;
+            if (base >= end) break; // wave-uniform
+            const bool live = base + lane < end;
+            int row = live ? rows_[u] : -2; // -2: never equal to a real row or to the empty carry
+            T val = live ? vals_[u] * xs_[u] : T(0);
 
-        const int next_row = __shfl_down(row, 1);
-        const bool tail = live && (lane == kWave - 1 || next_row != row);
-        // the segment that reaches the last live lane stays open: carry it
-        const int last_lane = (int)((end - base) < kWave ? (end - base) : kWave) - 1;
-        if (tail && lane != last_lane) atomic_add(y + row, val);
-        carry_row = __shfl(row, last_lane);
-        carry_val = __shfl(val, last_lane);
+            // fold the carry into lane 0 if it continues the same row, else flush it
+            if (carry_row >= 0) {
+                const int row0 = __shfl(row, 0);
+                if (row0 == carry_row) { if (lane == 0) val = carry_val + val; }
+                else if (lane == 0) atomic_add(y + carry_row, carry_val);
+            }
+
+            // segmented inclusive scan over the wave; a segment = a maximal run of equal ADJACENT rows
+            // (head flags, so unsorted input -- e.g. rows 5,3,5 -- is never merged across a gap)
+            const int prev_row = __shfl_up(row, 1);
+            int head = (lane == 0 || prev_row != row) ? 1 : 0;
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const T v = __shfl_up(val, o);
+                const int h = __shfl_up(head, o);
+                if (lane >= o && !head) { val = val + v; head = h; }
+            }
+
+            const int next_row = __shfl_down(row, 1);
+            const bool tail = live && (lane == kWave - 1 || next_row != row);
+            // the segment that reaches the last live lane stays open: carry it
+            const int last_lane = (int)((end - base) < kWave ? (end - base) : kWave) - 1;
+            if (tail && lane != last_lane) atomic_add(y + row, val);
+            carry_row = __shfl(row, last_lane);
+            carry_val = __shfl(val, last_lane);
+        }
     }
     if (lane == 0 && carry_row >= 0) atomic_add(y + carry_row, carry_val);
 }

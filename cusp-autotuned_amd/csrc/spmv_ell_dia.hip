@@ -20,6 +20,12 @@ namespace cmi {
 // ---------------------------------------------------------------------------------------------
 // ELL: one lane per row (RPL rows per lane)
 // ---------------------------------------------------------------------------------------------
+// Memory-level parallelism: slots are processed U at a time -- all U column loads, all U value loads
+// and all U x gathers are ISSUED before the first product is added (padding slots gather x[0] and are
+// masked out of the sum), so a lane has up to 3U loads in flight instead of walking a
+// load -> wait -> branch -> gather -> wait chain per slot.  The adds then run in slot order, skipping
+// padding exactly as the host loop does: same bits.
+
 template <typename T, int RPL, bool ELLR, int POL>
 __global__ void __launch_bounds__(1024)
 ell_row_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict__ Aj, const T *__restrict__ Ax,
@@ -30,13 +36,29 @@ ell_row_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict
     for (int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * RPL; row < num_rows; row += stride) {
         if constexpr (RPL == 1) {
             T acc = accumulate ? y[row] : T(0);
-            const int n_end = ELLR ? row_lengths[row] : width;
-#pragma unroll 4
-            for (int n = 0; n < n_end; n++) {
-                const int col = ld<NT>(Aj + n * pitch + row);
-                const T v = ld<NT>(Ax + n * pitch + row);
-                if (ELLR || col != -1) acc = acc + v * x[col];
-            }
+            const int len = ELLR ? row_lengths[row] : width; // ELLR: valid leading slots of THIS row
+            // K slots at a time: all column / value loads, then all gathers, then the adds in slot order
+            auto chunk = [&](auto Kc, int n0) {
+                constexpr int K = decltype(Kc)::value;
+                int col[K];
+                T val[K], xv[K];
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    col[k] = ld<NT>(Aj + (n0 + k) * pitch + row);
+                    val[k] = ld<NT>(Ax + (n0 + k) * pitch + row);
+                }
+#pragma unroll
+                for (int k = 0; k < K; k++) xv[k] = x[col[k] < 0 ? 0 : col[k]];
+                __builtin_amdgcn_sched_barrier(0); // keep every load above issued before the first add
+#pragma unroll
+                for (int k = 0; k < K; k++)
+                    if (ELLR ? (n0 + k < len) : (col[k] != -1)) acc = acc + val[k] * xv[k];
+            };
+            int n0 = 0; // width is wave-uniform: full chunks of 8, then a 4 / 2 / 1 tail -- no wasted loads
+            for (; n0 + 8 <= width; n0 += 8) chunk(std::integral_constant<int, 8>(), n0);
+            if (n0 + 4 <= width) { chunk(std::integral_constant<int, 4>(), n0); n0 += 4; }
+            if (n0 + 2 <= width) { chunk(std::integral_constant<int, 2>(), n0); n0 += 2; }
+            if (n0 + 1 <= width) { chunk(std::integral_constant<int, 1>(), n0); }
             st<NTS>(y + row, acc);
         } else {
             // rows row, row+1 (pitch even and arrays 16-byte aligned: checked by the launcher)
@@ -46,13 +68,32 @@ ell_row_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict
             T acc1 = (accumulate && has1) ? y[row + 1] : T(0);
             int len0 = width, len1 = width;
             if constexpr (ELLR) { len0 = row_lengths[row]; len1 = has1 ? row_lengths[row + 1] : 0; }
-#pragma unroll 4
-            for (int n = 0; n < width; n++) {
-                const int2v c = ld<NT>(reinterpret_cast<const int2v *>(Aj + n * pitch + row));
-                const T2 v = ld<NT>(reinterpret_cast<const T2 *>(Ax + n * pitch + row));
-                if (ELLR ? (n < len0) : (c.x != -1)) acc0 = acc0 + v.x * x[c.x];
-                if (ELLR ? (n < len1) : (c.y != -1 && has1)) acc1 = acc1 + v.y * x[c.y];
-            }
+            auto chunk = [&](auto Kc, int n0) {
+                constexpr int K = decltype(Kc)::value;
+                int2v c[K];
+                T2 v[K];
+                T x0[K], x1[K];
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    c[k] = ld<NT>(reinterpret_cast<const int2v *>(Aj + (n0 + k) * pitch + row));
+                    v[k] = ld<NT>(reinterpret_cast<const T2 *>(Ax + (n0 + k) * pitch + row));
+                }
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    x0[k] = x[c[k].x < 0 ? 0 : c[k].x];
+                    x1[k] = x[c[k].y < 0 ? 0 : c[k].y];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    if (ELLR ? (n0 + k < len0) : (c[k].x != -1)) acc0 = acc0 + v[k].x * x0[k];
+                    if (ELLR ? (n0 + k < len1) : (c[k].y != -1 && has1)) acc1 = acc1 + v[k].y * x1[k];
+                }
+            };
+            int n0 = 0;
+            for (; n0 + 4 <= width; n0 += 4) chunk(std::integral_constant<int, 4>(), n0);
+            if (n0 + 2 <= width) { chunk(std::integral_constant<int, 2>(), n0); n0 += 2; }
+            if (n0 + 1 <= width) { chunk(std::integral_constant<int, 1>(), n0); }
             if (has1 && (reinterpret_cast<uintptr_t>(y + row) % (2 * sizeof(T)) == 0)) {
                 T2 o; o.x = acc0; o.y = acc1;
                 st<NTS>(reinterpret_cast<T2 *>(y + row), o); // one 16-byte (f64) store for the row pair
@@ -67,6 +108,9 @@ ell_row_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict
 // ---------------------------------------------------------------------------------------------
 // DIA: one lane per row, diagonal offsets staged through LDS in chunks
 // ---------------------------------------------------------------------------------------------
+// Same memory-level-parallelism scheme as ELL: U diagonals at a time, all value loads and all x
+// loads issued first (column clamped into range, out-of-range products masked), adds in diagonal
+// order.
 constexpr int kDiaChunk = 256;
 
 template <typename T, int POL>
@@ -79,19 +123,34 @@ dia_row_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t pi
     __shared__ int soff[kDiaChunk];
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = row < num_rows;
+    const int64_t lrow = live ? row : num_rows - 1; // dead lanes shadow the last row (loads stay valid)
     T acc = (accumulate && live) ? y[row] : T(0);
     for (int base = 0; base < num_diagonals; base += kDiaChunk) {
         const int nchunk = num_diagonals - base < kDiaChunk ? num_diagonals - base : kDiaChunk;
         if (base > 0) __syncthreads();
         for (int i = threadIdx.x; i < nchunk; i += blockDim.x) soff[i] = offsets[base + i];
         __syncthreads();
-        if (live) {
-#pragma unroll 4
-            for (int d = 0; d < nchunk; d++) {
-                const int64_t col = row + soff[d];
-                if (col >= 0 && col < num_cols) acc = acc + ld<NT>(vals + (int64_t)(base + d) * pitch + row) * x[col];
+        auto chunk = [&](auto Kc, int d0) {
+            constexpr int K = decltype(Kc)::value;
+            T v[K], xv[K];
+            bool ok[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int64_t col = lrow + soff[d0 + k];
+                ok[k] = col >= 0 && col < num_cols;
+                v[k] = ld<NT>(vals + (int64_t)(base + d0 + k) * pitch + lrow);
+                xv[k] = x[col < 0 ? 0 : (col >= num_cols ? num_cols - 1 : col)];
             }
-        }
+            __builtin_amdgcn_sched_barrier(0); // keep every load above issued before the first add
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if (ok[k]) acc = acc + v[k] * xv[k];
+        };
+        int d0 = 0; // nchunk is wave-uniform: full chunks of 8, then a 4 / 2 / 1 tail
+        for (; d0 + 8 <= nchunk; d0 += 8) chunk(std::integral_constant<int, 8>(), d0);
+        if (d0 + 4 <= nchunk) { chunk(std::integral_constant<int, 4>(), d0); d0 += 4; }
+        if (d0 + 2 <= nchunk) { chunk(std::integral_constant<int, 2>(), d0); d0 += 2; }
+        if (d0 + 1 <= nchunk) { chunk(std::integral_constant<int, 1>(), d0); }
     }
     if (live) st<NTS>(y + row, acc);
 }
@@ -108,6 +167,8 @@ dia_row2_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t p
     __shared__ int soff[kDiaChunk];
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     const bool live0 = row < num_rows, live1 = row + 1 < num_rows;
+    // dead lanes shadow the last even row pair that is fully inside the pitch (loads stay valid)
+    const int64_t lrow = live0 ? row : ((num_rows - 1) & ~(int64_t)1);
     T acc0 = (accumulate && live0) ? y[row] : T(0);
     T acc1 = (accumulate && live1) ? y[row + 1] : T(0);
     for (int base = 0; base < num_diagonals; base += kDiaChunk) {
@@ -115,15 +176,31 @@ dia_row2_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t p
         if (base > 0) __syncthreads();
         for (int i = threadIdx.x; i < nchunk; i += blockDim.x) soff[i] = offsets[base + i];
         __syncthreads();
-        if (live0) {
-#pragma unroll 4
-            for (int d = 0; d < nchunk; d++) {
-                const int64_t c0 = row + soff[d], c1 = c0 + 1;
-                const T2 v = ld<NT>(reinterpret_cast<const T2 *>(vals + (int64_t)(base + d) * pitch + row));
-                if (c0 >= 0 && c0 < num_cols) acc0 = acc0 + v.x * x[c0];
-                if (live1 && c1 >= 0 && c1 < num_cols) acc1 = acc1 + v.y * x[c1];
+        auto chunk = [&](auto Kc, int d0) {
+            constexpr int K = decltype(Kc)::value;
+            T2 v[K];
+            T x0[K], x1[K];
+            bool ok0[K], ok1[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int64_t c0 = lrow + soff[d0 + k], c1 = c0 + 1;
+                ok0[k] = live0 && c0 >= 0 && c0 < num_cols;
+                ok1[k] = live1 && c1 >= 0 && c1 < num_cols;
+                v[k] = ld<NT>(reinterpret_cast<const T2 *>(vals + (int64_t)(base + d0 + k) * pitch + lrow));
+                x0[k] = x[c0 < 0 ? 0 : (c0 >= num_cols ? num_cols - 1 : c0)];
+                x1[k] = x[c1 < 0 ? 0 : (c1 >= num_cols ? num_cols - 1 : c1)];
             }
-        }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                if (ok0[k]) acc0 = acc0 + v[k].x * x0[k];
+                if (ok1[k]) acc1 = acc1 + v[k].y * x1[k];
+            }
+        };
+        int d0 = 0;
+        for (; d0 + 4 <= nchunk; d0 += 4) chunk(std::integral_constant<int, 4>(), d0);
+        if (d0 + 2 <= nchunk) { chunk(std::integral_constant<int, 2>(), d0); d0 += 2; }
+        if (d0 + 1 <= nchunk) { chunk(std::integral_constant<int, 1>(), d0); }
     }
     if (live1 && (reinterpret_cast<uintptr_t>(y + row) % (2 * sizeof(T)) == 0)) {
         T2 o; o.x = acc0; o.y = acc1;
