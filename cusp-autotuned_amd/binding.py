@@ -14,7 +14,7 @@ FORMAT_CSR, FORMAT_ELL, FORMAT_DIA, FORMAT_COO, FORMAT_HYB = 0, 1, 2, 3, 4
 F64, F32 = 0, 1
 KERNEL_AUTO = 0
 CSR_SCALAR, CSR_VECTOR, CSR_STREAM, CSR_STREAM_PIPE = 1, 2, 3, 4
-ELL_ROW, DIA_ROW, COO_SEGMENTED = 10, 20, 30
+ELL_ROW, DIA_ROW, COO_SEGMENTED, COO_LANE4 = 10, 20, 30, 31
 
 
 class CmiError(RuntimeError):

@@ -67,7 +67,7 @@ static void heuristic(int format, int dtype, double mean, cmi_config *c)
         break;
     case CMI_FORMAT_ELL: c->kernel = CMI_ELL_ROW; c->items_per_thread = 1; break;
     case CMI_FORMAT_DIA: c->kernel = CMI_DIA_ROW; c->items_per_thread = 1; break;
-    case CMI_FORMAT_COO: c->kernel = CMI_COO_SEGMENTED; c->items_per_thread = 4; break;
+    case CMI_FORMAT_COO: c->kernel = CMI_COO_LANE4; c->items_per_thread = 4; break;
     default: break;
     }
     (void)dtype;

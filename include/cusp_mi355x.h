@@ -106,6 +106,9 @@ typedef enum cmi_kernel {
     /* COO */
     CMI_COO_SEGMENTED = 30, /* wave segmented reduction + f64/f32 atomics at segment tails
                                (ref: ktt kernels/coo_kernel.h:289-369, coo_flat_spmv.h:231-311)  */
+    CMI_COO_LANE4 = 31,     /* four consecutive entries per lane (16-byte vector loads), runs reduced in
+                               registers, one wave scan per 256 entries (ref: ktt coo_direct_multi,
+                               kernels/coo_kernel.h:64-106, VALUES_PER_THREAD)                     */
 } cmi_kernel;
 
 typedef struct cmi_config {

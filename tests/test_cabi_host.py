@@ -92,7 +92,7 @@ def test_tuning_heuristics_and_table_roundtrip(cmi, tmp_path):
     assert c.kernel == cmi.CSR_STREAM and c.threads_per_row == 4 and c.rows_per_block <= 4 * 256 // 4
     assert cmi.tuning_select(cmi.FORMAT_ELL, cmi.F64, 100, 100, 500).kernel == cmi.ELL_ROW
     assert cmi.tuning_select(cmi.FORMAT_DIA, cmi.F64, 100, 100, 500).kernel == cmi.DIA_ROW
-    assert cmi.tuning_select(cmi.FORMAT_COO, cmi.F64, 100, 100, 500).kernel == cmi.COO_SEGMENTED
+    assert cmi.tuning_select(cmi.FORMAT_COO, cmi.F64, 100, 100, 500).kernel == cmi.COO_LANE4
 
     # persist an override, clear, reload: the selection follows the table
     cfg = cmi.Config(kernel=cmi.CSR_VECTOR, block_size=128, threads_per_row=4, nontemporal=1)

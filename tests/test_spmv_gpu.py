@@ -101,11 +101,16 @@ def run_all_formats(cmi, torch, orc, rows, cols, Ap, Aj, Ax, x, want, want_acc, 
     Ai = orc.csr_row_indices(Ap)
     dAi = dev(Ai, torch)
     for acc, w in ((False, want["coo"]), (True, want_acc["coo"])):
-        for ipt, blk in ((1, 64), (4, 256), (16, 256), (3, 128)):
+        for kern, ipt, blk in ((cmi.COO_SEGMENTED, 1, 64), (cmi.COO_SEGMENTED, 4, 256), (cmi.COO_SEGMENTED, 16, 256),
+                               (cmi.COO_SEGMENTED, 3, 128), (cmi.COO_LANE4, 1, 64), (cmi.COO_LANE4, 4, 256),
+                               (cmi.COO_LANE4, 2, 512), (cmi.COO_LANE4, 7, 128)):
             y = fresh(acc)
             cmi.spmv_coo(rows, cols, dAi, dAj, dAx, dx, y, accumulate=acc,
-                         cfg=cmi.Config(kernel=cmi.COO_SEGMENTED, block_size=blk, items_per_thread=ipt))
-            assert_close(host(y), w, bound, dtype, f"{label} coo ipt{ipt} acc={acc}")
+                         cfg=cmi.Config(kernel=kern, block_size=blk, items_per_thread=ipt))
+            assert_close(host(y), w, bound, dtype, f"{label} coo k{kern} ipt{ipt} acc={acc}")
+        y = fresh(acc)
+        cmi.spmv_coo(rows, cols, dAi, dAj, dAx, dx, y, accumulate=acc)  # NULL config
+        assert_close(host(y), w, bound, dtype, f"{label} coo auto acc={acc}")
 
     # ELL / ELLR
     width = int(np.diff(Ap).max()) if rows else 0
@@ -338,11 +343,18 @@ def test_coo_unsorted_entries(cmi, torch_cuda, orc, golden_irregular):
     Ai = orc.csr_row_indices(Ap)
     perm = np.random.default_rng(5).permutation(len(Ax))
     bound = row_abs(orc, Ap, Aj, Ax, x)
-    for ipt in (1, 4):
+    for kern, ipt in ((cmi.COO_SEGMENTED, 1), (cmi.COO_SEGMENTED, 4), (cmi.COO_LANE4, 1), (cmi.COO_LANE4, 3)):
         y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
         cmi.spmv_coo(rows, cols, dev(Ai[perm], torch), dev(Aj[perm], torch), dev(Ax[perm], torch), dev(x, torch), y,
-                     cfg=cmi.Config(kernel=cmi.COO_SEGMENTED, items_per_thread=ipt))
+                     cfg=cmi.Config(kernel=kern, items_per_thread=ipt))
         assert_close(host(y), g["f64_y_coo"], bound, np.float64, "coo unsorted")
+    # unaligned index / value arrays: the lane4 request runs the segmented kernel
+    buf_i = torch.zeros(len(Ai) + 4, dtype=torch.int32, device="cuda")
+    buf_i[1:1 + len(Ai)].copy_(dev(Ai, torch))
+    y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
+    cmi.spmv_coo(rows, cols, buf_i[1:1 + len(Ai)], dev(Aj, torch), dev(Ax, torch), dev(x, torch), y,
+                 cfg=cmi.Config(kernel=cmi.COO_LANE4))
+    assert_close(host(y), g["f64_y_coo"], bound, np.float64, "coo lane4 unaligned")
 
 
 def test_non_default_stream(cmi, torch_cuda, golden_poisson, orc):

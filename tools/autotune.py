@@ -86,8 +86,9 @@ def dia_space(cmi, quick):
 
 
 def coo_space(cmi, quick):
-    return [cmi.Config(kernel=cmi.COO_SEGMENTED, block_size=b, items_per_thread=i, nontemporal=nt)
-            for b, i, nt in itertools.product((256,) if quick else (128, 256, 512), (1, 2, 4, 8, 16, 32), (0, 1))]
+    return [cmi.Config(kernel=k, block_size=b, items_per_thread=i, nontemporal=nt)
+            for k, b, i, nt in itertools.product((cmi.COO_SEGMENTED, cmi.COO_LANE4), (256,) if quick else (128, 256, 512),
+                                                 (1, 2, 4, 8, 16, 32), (0, 1))]
 
 
 class Timer:
