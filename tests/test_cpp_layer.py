@@ -54,3 +54,21 @@ def test_headers_compile_standalone(tmp_path):
 def test_cpp_layer_device_tests_pass(cmi):
     out = _run("test_device")
     assert int(out.strip().splitlines()[-1].split()[0]) >= 50
+
+
+@pytest.mark.gpu
+def test_reference_style_benchmark_driver(cmi, tmp_path):
+    """tools/spmv_bench (the reference's performance/spmv CLI on this engine): every format converts,
+    multiplies on the device and matches the host multiply on the reference's default input."""
+    exe = os.path.join(ROOT, "tools", "bin", "spmv_bench")
+    if not os.path.exists(exe):
+        _build()
+    r = subprocess.run([exe, "--grid=300"], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "MISMATCH" not in r.stdout
+    for fmt in ("coo", "csr", "dia", "ell", "hyb"):
+        assert f"\t{fmt} :" in r.stdout, r.stdout
+    # a MatrixMarket file goes through the reader (the SuiteSparse path of BASELINE.json configs[3])
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "5pt_10x10.mtx")], capture_output=True, text=True,
+                       timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0 and "MISMATCH" not in r.stdout and "460 entries" in r.stdout, r.stdout + r.stderr
