@@ -102,12 +102,13 @@ def _declare(L):
     L.cmi_csr_row_indices.argtypes = [i64, vp, vp, vp]
     L.cmi_ell_row_lengths.argtypes = [i64, i64, i64, vp, vp, vp]
     L.cmi_blas_workspace_bytes.restype = c_size_t
-    L.cmi_blas_axpy_f64.argtypes = [i64, c_double, vp, vp, vp]
-    L.cmi_blas_axpby_f64.argtypes = [i64, c_double, vp, c_double, vp, vp, vp]
-    L.cmi_blas_copy_f64.argtypes = [i64, vp, vp, vp]
-    L.cmi_blas_fill_f64.argtypes = [i64, c_double, vp, vp]
-    L.cmi_blas_dot_f64.argtypes = [i64, vp, vp, vp, vp, vp]
-    L.cmi_blas_nrm2_f64.argtypes = [i64, vp, vp, vp, vp]
+    for suf, sc in (("f64", c_double), ("f32", c_float)):
+        getattr(L, f"cmi_blas_axpy_{suf}").argtypes = [i64, sc, vp, vp, vp]
+        getattr(L, f"cmi_blas_axpby_{suf}").argtypes = [i64, sc, vp, sc, vp, vp, vp]
+        getattr(L, f"cmi_blas_copy_{suf}").argtypes = [i64, vp, vp, vp]
+        getattr(L, f"cmi_blas_fill_{suf}").argtypes = [i64, sc, vp, vp]
+        getattr(L, f"cmi_blas_dot_{suf}").argtypes = [i64, vp, vp, vp, vp, vp]
+        getattr(L, f"cmi_blas_nrm2_{suf}").argtypes = [i64, vp, vp, vp, vp]
 
 
 def lib():
@@ -340,24 +341,27 @@ def blas_workspace(device="cuda"):
 
 
 def blas_axpy(alpha, x, y, stream=None):
-    check(lib().cmi_blas_axpy_f64(x.numel(), float(alpha), _ptr(x), _ptr(y), _stream(stream)))
+    check(getattr(lib(), "cmi_blas_axpy_" + _suffix(y))(x.numel(), float(alpha), _ptr(x), _ptr(y), _stream(stream)))
 
 
 def blas_axpby(alpha, x, beta, y, z, stream=None):
-    check(lib().cmi_blas_axpby_f64(x.numel(), float(alpha), _ptr(x), float(beta), _ptr(y), _ptr(z), _stream(stream)))
+    check(getattr(lib(), "cmi_blas_axpby_" + _suffix(z))(x.numel(), float(alpha), _ptr(x), float(beta), _ptr(y), _ptr(z),
+                                                      _stream(stream)))
 
 
 def blas_copy(x, y, stream=None):
-    check(lib().cmi_blas_copy_f64(x.numel(), _ptr(x), _ptr(y), _stream(stream)))
+    check(getattr(lib(), "cmi_blas_copy_" + _suffix(y))(x.numel(), _ptr(x), _ptr(y), _stream(stream)))
 
 
 def blas_fill(value, y, stream=None):
-    check(lib().cmi_blas_fill_f64(y.numel(), float(value), _ptr(y), _stream(stream)))
+    check(getattr(lib(), "cmi_blas_fill_" + _suffix(y))(y.numel(), float(value), _ptr(y), _stream(stream)))
 
 
 def blas_dot(x, y, result, workspace, stream=None):
-    check(lib().cmi_blas_dot_f64(x.numel(), _ptr(x), _ptr(y), _ptr(result), _ptr(workspace), _stream(stream)))
+    """result: 1-element device tensor of x's dtype."""
+    check(getattr(lib(), "cmi_blas_dot_" + _suffix(x))(x.numel(), _ptr(x), _ptr(y), _ptr(result), _ptr(workspace),
+                                                    _stream(stream)))
 
 
 def blas_nrm2(x, result, workspace, stream=None):
-    check(lib().cmi_blas_nrm2_f64(x.numel(), _ptr(x), _ptr(result), _ptr(workspace), _stream(stream)))
+    check(getattr(lib(), "cmi_blas_nrm2_" + _suffix(x))(x.numel(), _ptr(x), _ptr(result), _ptr(workspace), _stream(stream)))

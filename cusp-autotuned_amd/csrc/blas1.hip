@@ -34,29 +34,38 @@ static int stream_grid(int64_t n, int per_thread)
     return b < 1 ? 1 : (int)b;
 }
 
+// 16 bytes per lane: 2 doubles or 4 floats
+template <typename T> struct vec16;
+template <> struct vec16<double> { typedef double2v type; static constexpr int n = 2; };
+template <> struct vec16<float> { typedef float4v type; static constexpr int n = 4; };
+
+template <typename T>
 __global__ void __launch_bounds__(kBlasBlock)
-axpby_kernel(int64_t n, double a, const double *x, double b, const double *y, double *z, int vec) // z may alias x or y
+axpby_kernel(int64_t n, T a, const T *x, T b, const T *y, T *z, int vec) // z may alias x or y
 {
+    typedef typename vec16<T>::type V;
+    constexpr int W = vec16<T>::n;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (vec) {
-        const int64_t n2 = n / 2;
-        for (int64_t i = t; i < n2; i += stride) {
-            const double2v xv = reinterpret_cast<const double2v *>(x)[i];
-            const double2v yv = reinterpret_cast<const double2v *>(y)[i];
-            double2v zv;
-            zv.x = a * xv.x + b * yv.x;
-            zv.y = a * xv.y + b * yv.y;
-            reinterpret_cast<double2v *>(z)[i] = zv;
+        const int64_t nv = n / W;
+        for (int64_t i = t; i < nv; i += stride) {
+            const V xv = reinterpret_cast<const V *>(x)[i];
+            const V yv = reinterpret_cast<const V *>(y)[i];
+            V zv;
+#pragma unroll
+            for (int k = 0; k < W; k++) zv[k] = a * xv[k] + b * yv[k];
+            reinterpret_cast<V *>(z)[i] = zv;
         }
-        if (t == 0 && (n & 1)) z[n - 1] = a * x[n - 1] + b * y[n - 1];
+        if (t < n - nv * W) { const int64_t i = nv * W + t; z[i] = a * x[i] + b * y[i]; }
     } else {
         for (int64_t i = t; i < n; i += stride) z[i] = a * x[i] + b * y[i];
     }
 }
 
+template <typename T>
 __global__ void __launch_bounds__(kBlasBlock)
-fill_kernel(int64_t n, double v, double *__restrict__ y)
+fill_kernel(int64_t n, T v, T *__restrict__ y)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = v;
@@ -76,38 +85,42 @@ __device__ __forceinline__ double block_sum(double v, double *slots)
     return s; // valid in thread 0
 }
 
+// partial sums are kept in double for both value types (f32 inputs: products widened before the add)
+template <typename T>
 __global__ void __launch_bounds__(kBlasBlock)
-dot_partial_kernel(int64_t n, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ partial,
-                   int vec)
+dot_partial_kernel(int64_t n, const T *__restrict__ x, const T *__restrict__ y, double *__restrict__ partial, int vec)
 {
+    typedef typename vec16<T>::type V;
+    constexpr int W = vec16<T>::n;
     __shared__ double slots[kBlasBlock / kWave];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double acc = 0.0;
     if (vec) {
-        const int64_t n2 = n / 2;
-        for (int64_t i = t; i < n2; i += stride) {
-            const double2v xv = reinterpret_cast<const double2v *>(x)[i];
-            const double2v yv = reinterpret_cast<const double2v *>(y)[i];
-            acc += xv.x * yv.x;
-            acc += xv.y * yv.y;
+        const int64_t nv = n / W;
+        for (int64_t i = t; i < nv; i += stride) {
+            const V xv = reinterpret_cast<const V *>(x)[i];
+            const V yv = reinterpret_cast<const V *>(y)[i];
+#pragma unroll
+            for (int k = 0; k < W; k++) acc += (double)xv[k] * (double)yv[k];
         }
-        if (t == 0 && (n & 1)) acc += x[n - 1] * y[n - 1];
+        if (t < n - nv * W) { const int64_t i = nv * W + t; acc += (double)x[i] * (double)y[i]; }
     } else {
-        for (int64_t i = t; i < n; i += stride) acc += x[i] * y[i];
+        for (int64_t i = t; i < n; i += stride) acc += (double)x[i] * (double)y[i];
     }
     const double s = block_sum(acc, slots);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
+template <typename T>
 __global__ void __launch_bounds__(kBlasBlock)
-dot_final_kernel(int npartial, const double *__restrict__ partial, double *__restrict__ result, int take_sqrt)
+dot_final_kernel(int npartial, const double *__restrict__ partial, T *__restrict__ result, int take_sqrt)
 {
     __shared__ double slots[kBlasBlock / kWave];
     double acc = 0.0;
     for (int i = threadIdx.x; i < npartial; i += blockDim.x) acc += partial[i];
     const double s = block_sum(acc, slots);
-    if (threadIdx.x == 0) *result = take_sqrt ? sqrt(s) : s;
+    if (threadIdx.x == 0) *result = (T)(take_sqrt ? sqrt(s) : s);
 }
 
 static bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
@@ -118,61 +131,63 @@ using namespace cmi;
 
 CMI_API size_t cmi_blas_workspace_bytes(void) { return (size_t)kBlasMaxGrid * sizeof(double); }
 
-CMI_API int cmi_blas_axpby_f64(int64_t n, double alpha, const double *x, double beta, const double *y, double *z, void *stream)
+namespace {
+
+template <typename T> int axpby_impl(int64_t n, T alpha, const T *x, T beta, const T *y, T *z, void *stream)
 {
     if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_axpby: negative n");
     if (n == 0) return CMI_SUCCESS;
     if (!x || !y || !z) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_axpby: null array");
     const int vec = aligned16(x) && aligned16(y) && aligned16(z);
-    hipLaunchKernelGGL(axpby_kernel, dim3(stream_grid(n, 2)), dim3(kBlasBlock), 0, as_stream(stream), n, alpha, x, beta, y, z, vec);
+    hipLaunchKernelGGL((axpby_kernel<T>), dim3(stream_grid(n, vec16<T>::n)), dim3(kBlasBlock), 0, as_stream(stream), n, alpha, x, beta, y, z, vec);
     CMI_LAUNCH_CHECK("axpby");
     return CMI_SUCCESS;
 }
 
-// y <- alpha*x + y   (cusp::blas::axpy, cusp/blas/blas.h)
-CMI_API int cmi_blas_axpy_f64(int64_t n, double alpha, const double *x, double *y, void *stream)
-{
-    return cmi_blas_axpby_f64(n, alpha, x, 1.0, y, y, stream);
-}
-
-CMI_API int cmi_blas_copy_f64(int64_t n, const double *x, double *y, void *stream)
+template <typename T> int copy_impl(int64_t n, const T *x, T *y, void *stream)
 {
     if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_copy: negative n");
     if (n == 0) return CMI_SUCCESS;
     if (!x || !y) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_copy: null array");
-    CMI_HIP(hipMemcpyAsync(y, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, as_stream(stream)));
+    CMI_HIP(hipMemcpyAsync(y, x, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, as_stream(stream)));
     return CMI_SUCCESS;
 }
 
-CMI_API int cmi_blas_fill_f64(int64_t n, double value, double *y, void *stream)
+template <typename T> int fill_impl(int64_t n, T value, T *y, void *stream)
 {
     if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_fill: negative n");
     if (n == 0) return CMI_SUCCESS;
     if (!y) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_fill: null array");
-    hipLaunchKernelGGL(fill_kernel, dim3(stream_grid(n, 1)), dim3(kBlasBlock), 0, as_stream(stream), n, value, y);
+    hipLaunchKernelGGL((fill_kernel<T>), dim3(stream_grid(n, 1)), dim3(kBlasBlock), 0, as_stream(stream), n, value, y);
     CMI_LAUNCH_CHECK("fill");
     return CMI_SUCCESS;
 }
 
-static int dot_impl(int64_t n, const double *x, const double *y, double *result_dev, void *workspace, void *stream, int take_sqrt)
+template <typename T> int dot_impl(int64_t n, const T *x, const T *y, T *result_dev, void *workspace, void *stream, int take_sqrt)
 {
     if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_dot: negative n");
     if (!result_dev || !workspace) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_dot: null result or workspace");
     if (n > 0 && (!x || !y)) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_dot: null array");
-    const int grid = blas_grid(n, 2);
+    const int grid = blas_grid(n, vec16<T>::n);
     const int vec = aligned16(x) && aligned16(y);
-    hipLaunchKernelGGL(dot_partial_kernel, dim3(grid), dim3(kBlasBlock), 0, as_stream(stream), n, x, y, (double *)workspace, vec);
-    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(kBlasBlock), 0, as_stream(stream), grid, (const double *)workspace, result_dev, take_sqrt);
+    hipLaunchKernelGGL((dot_partial_kernel<T>), dim3(grid), dim3(kBlasBlock), 0, as_stream(stream), n, x, y, (double *)workspace, vec);
+    hipLaunchKernelGGL((dot_final_kernel<T>), dim3(1), dim3(kBlasBlock), 0, as_stream(stream), grid, (const double *)workspace, result_dev, take_sqrt);
     CMI_LAUNCH_CHECK("dot");
     return CMI_SUCCESS;
 }
 
-CMI_API int cmi_blas_dot_f64(int64_t n, const double *x, const double *y, double *result_dev, void *workspace, void *stream)
-{
-    return dot_impl(n, x, y, result_dev, workspace, stream, 0);
-}
+} // namespace
 
-CMI_API int cmi_blas_nrm2_f64(int64_t n, const double *x, double *result_dev, void *workspace, void *stream)
-{
-    return dot_impl(n, x, x, result_dev, workspace, stream, 1);
-}
+// y <- alpha*x + y (cusp::blas::axpy), z <- alpha*x + beta*y (axpby), copy, fill, dot, nrm2
+CMI_API int cmi_blas_axpby_f64(int64_t n, double alpha, const double *x, double beta, const double *y, double *z, void *stream) { return axpby_impl<double>(n, alpha, x, beta, y, z, stream); }
+CMI_API int cmi_blas_axpby_f32(int64_t n, float alpha, const float *x, float beta, const float *y, float *z, void *stream) { return axpby_impl<float>(n, alpha, x, beta, y, z, stream); }
+CMI_API int cmi_blas_axpy_f64(int64_t n, double alpha, const double *x, double *y, void *stream) { return axpby_impl<double>(n, alpha, x, 1.0, y, y, stream); }
+CMI_API int cmi_blas_axpy_f32(int64_t n, float alpha, const float *x, float *y, void *stream) { return axpby_impl<float>(n, alpha, x, 1.0f, y, y, stream); }
+CMI_API int cmi_blas_copy_f64(int64_t n, const double *x, double *y, void *stream) { return copy_impl<double>(n, x, y, stream); }
+CMI_API int cmi_blas_copy_f32(int64_t n, const float *x, float *y, void *stream) { return copy_impl<float>(n, x, y, stream); }
+CMI_API int cmi_blas_fill_f64(int64_t n, double value, double *y, void *stream) { return fill_impl<double>(n, value, y, stream); }
+CMI_API int cmi_blas_fill_f32(int64_t n, float value, float *y, void *stream) { return fill_impl<float>(n, value, y, stream); }
+CMI_API int cmi_blas_dot_f64(int64_t n, const double *x, const double *y, double *r, void *ws, void *stream) { return dot_impl<double>(n, x, y, r, ws, stream, 0); }
+CMI_API int cmi_blas_dot_f32(int64_t n, const float *x, const float *y, float *r, void *ws, void *stream) { return dot_impl<float>(n, x, y, r, ws, stream, 0); }
+CMI_API int cmi_blas_nrm2_f64(int64_t n, const double *x, double *r, void *ws, void *stream) { return dot_impl<double>(n, x, x, r, ws, stream, 1); }
+CMI_API int cmi_blas_nrm2_f32(int64_t n, const float *x, float *r, void *ws, void *stream) { return dot_impl<float>(n, x, x, r, ws, stream, 1); }

@@ -3,8 +3,7 @@
 //   axpy(x, y, alpha)            y <- alpha*x + y
 //   axpby(x, y, z, alpha, beta)  z <- alpha*x + beta*y
 //   copy(x, y)   fill(x, v)   dot(x, y)   dotc(x, y)   nrm2(x)
-// host_memory: plain loops.  device_memory: cmi_blas_*_f64 kernels (f64, what CG on the benchmark
-// uses); reductions are deterministic two-stage trees whose scalar is copied back (one 8-byte D2H
+// host_memory: plain loops.  device_memory: cmi_blas_*_{f64,f32} kernels; reductions are deterministic two-stage trees whose scalar is copied back (one 8-byte D2H
 // per call -- the reference's Thrust reductions synchronise the same way).
 #pragma once
 #include <cmath>
@@ -18,13 +17,13 @@ namespace detail {
 
 struct device_workspace { // lazily allocated per thread, freed at exit: no allocation per call
     void *ws;
-    double *result;
+    void *result; // 8 bytes: holds a double or a float scalar
     device_workspace() : ws(nullptr), result(nullptr) {}
     ~device_workspace() { if (ws) cmi_free(ws); if (result) cmi_free(result); }
     void ensure()
     {
         if (!ws) cusp::detail::check(cmi_malloc(&ws, cmi_blas_workspace_bytes()));
-        if (!result) cusp::detail::check(cmi_malloc(reinterpret_cast<void **>(&result), sizeof(double)));
+        if (!result) cusp::detail::check(cmi_malloc(&result, sizeof(double)));
     }
 };
 inline device_workspace &workspace()
@@ -39,8 +38,22 @@ template <typename X, typename Y> void same_size(const X &x, const Y &y)
     if (x.size() != y.size()) throw cusp::invalid_input_exception("cusp::blas: array sizes differ");
 }
 
-template <typename V> struct require_f64 {
-    static_assert(std::is_same<V, double>::value, "device_memory cusp::blas routines are implemented for double (the CG value type of the benchmark)");
+// C-ABI overload sets (double / float)
+inline int c_axpy(int64_t n, double a, const double *x, double *y) { return cmi_blas_axpy_f64(n, a, x, y, nullptr); }
+inline int c_axpy(int64_t n, float a, const float *x, float *y) { return cmi_blas_axpy_f32(n, a, x, y, nullptr); }
+inline int c_axpby(int64_t n, double a, const double *x, double b, const double *y, double *z) { return cmi_blas_axpby_f64(n, a, x, b, y, z, nullptr); }
+inline int c_axpby(int64_t n, float a, const float *x, float b, const float *y, float *z) { return cmi_blas_axpby_f32(n, a, x, b, y, z, nullptr); }
+inline int c_copy(int64_t n, const double *x, double *y) { return cmi_blas_copy_f64(n, x, y, nullptr); }
+inline int c_copy(int64_t n, const float *x, float *y) { return cmi_blas_copy_f32(n, x, y, nullptr); }
+inline int c_fill(int64_t n, double v, double *y) { return cmi_blas_fill_f64(n, v, y, nullptr); }
+inline int c_fill(int64_t n, float v, float *y) { return cmi_blas_fill_f32(n, v, y, nullptr); }
+inline int c_dot(int64_t n, const double *x, const double *y, double *r, void *ws) { return cmi_blas_dot_f64(n, x, y, r, ws, nullptr); }
+inline int c_dot(int64_t n, const float *x, const float *y, float *r, void *ws) { return cmi_blas_dot_f32(n, x, y, r, ws, nullptr); }
+inline int c_nrm2(int64_t n, const double *x, double *r, void *ws) { return cmi_blas_nrm2_f64(n, x, r, ws, nullptr); }
+inline int c_nrm2(int64_t n, const float *x, float *r, void *ws) { return cmi_blas_nrm2_f32(n, x, r, ws, nullptr); }
+
+template <typename V> struct require_real {
+    static_assert(std::is_same<V, double>::value || std::is_same<V, float>::value, "device_memory cusp::blas routines are implemented for float and double");
 };
 
 // ---- host ----
@@ -58,31 +71,33 @@ template <typename X, typename Y> typename X::value_type dot(const X &x, const Y
     for (size_t i = 0; i < x.size(); i++) s += x[i] * y[i];
     return s;
 }
-// ---- device (f64) ----
+// ---- device ----
 template <typename X, typename Y, typename S> void axpy(const X &x, Y &y, S a, device_memory)
-{ require_f64<typename Y::value_type>(); cusp::detail::check(cmi_blas_axpy_f64(x.size(), a, x.data(), y.data(), nullptr)); }
+{ require_real<typename Y::value_type>(); cusp::detail::check(c_axpy(x.size(), a, x.data(), y.data())); }
 template <typename X, typename Y, typename Z, typename S> void axpby(const X &x, const Y &y, Z &z, S a, S b, device_memory)
-{ require_f64<typename Z::value_type>(); cusp::detail::check(cmi_blas_axpby_f64(x.size(), a, x.data(), b, y.data(), z.data(), nullptr)); }
+{ require_real<typename Z::value_type>(); cusp::detail::check(c_axpby(x.size(), a, x.data(), b, y.data(), z.data())); }
 template <typename X, typename Y> void copy(const X &x, Y &y, device_memory)
-{ require_f64<typename Y::value_type>(); cusp::detail::check(cmi_blas_copy_f64(x.size(), x.data(), y.data(), nullptr)); }
+{ require_real<typename Y::value_type>(); cusp::detail::check(c_copy(x.size(), x.data(), y.data())); }
 template <typename X, typename S> void fill(X &x, S v, device_memory)
-{ require_f64<typename X::value_type>(); cusp::detail::check(cmi_blas_fill_f64(x.size(), v, x.data(), nullptr)); }
-template <typename X, typename Y> double dot(const X &x, const Y &y, device_memory)
+{ require_real<typename X::value_type>(); cusp::detail::check(c_fill(x.size(), v, x.data())); }
+template <typename X, typename Y> typename X::value_type dot(const X &x, const Y &y, device_memory)
 {
-    require_f64<typename X::value_type>();
+    typedef typename X::value_type V;
+    require_real<V>();
     device_workspace &w = workspace();
-    cusp::detail::check(cmi_blas_dot_f64(x.size(), x.data(), y.data(), w.result, w.ws, nullptr));
-    double r;
-    cusp::detail::check(cmi_memcpy_d2h(&r, w.result, sizeof(double), nullptr));
+    cusp::detail::check(c_dot(x.size(), x.data(), y.data(), static_cast<V *>(w.result), w.ws));
+    V r;
+    cusp::detail::check(cmi_memcpy_d2h(&r, w.result, sizeof(V), nullptr));
     return r;
 }
-template <typename X> double nrm2(const X &x, device_memory)
+template <typename X> typename X::value_type nrm2(const X &x, device_memory)
 {
-    require_f64<typename X::value_type>();
+    typedef typename X::value_type V;
+    require_real<V>();
     device_workspace &w = workspace();
-    cusp::detail::check(cmi_blas_nrm2_f64(x.size(), x.data(), w.result, w.ws, nullptr));
-    double r;
-    cusp::detail::check(cmi_memcpy_d2h(&r, w.result, sizeof(double), nullptr));
+    cusp::detail::check(c_nrm2(x.size(), x.data(), static_cast<V *>(w.result), w.ws));
+    V r;
+    cusp::detail::check(cmi_memcpy_d2h(&r, w.result, sizeof(V), nullptr));
     return r;
 }
 template <typename X> typename X::value_type nrm2(const X &x, host_memory)

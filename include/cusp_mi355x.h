@@ -239,7 +239,7 @@ int cmi_ell_row_lengths(int64_t num_rows, int64_t width, int64_t pitch, const in
                         int32_t *row_lengths, void *stream);
 
 /* ------------------------------------------------------------------------- */
-/* BLAS-1 on device vectors: the five routines cusp::krylov::cg calls          */
+/* BLAS-1 on device vectors (f64 and f32): the routines cusp::krylov::cg calls */
 /* (cusp/krylov/detail/cg.inl:63-105; generic/blas.h:175-220,283-340).          */
 /* dot / nrm2 write their scalar to a DEVICE double (*result_dev) without a     */
 /* host sync; the caller copies it back when it needs the value.                */
@@ -247,13 +247,22 @@ int cmi_ell_row_lengths(int64_t num_rows, int64_t width, int64_t pitch, const in
 /* ------------------------------------------------------------------------- */
 size_t cmi_blas_workspace_bytes(void);
 int cmi_blas_axpy_f64(int64_t n, double alpha, const double *x, double *y, void *stream);  /* y += a x */
+int cmi_blas_axpy_f32(int64_t n, float alpha, const float *x, float *y, void *stream);
 int cmi_blas_axpby_f64(int64_t n, double alpha, const double *x, double beta, const double *y,
                        double *z, void *stream);                                             /* z = a x + b y */
+int cmi_blas_axpby_f32(int64_t n, float alpha, const float *x, float beta, const float *y, float *z,
+                       void *stream);
 int cmi_blas_copy_f64(int64_t n, const double *x, double *y, void *stream);
+int cmi_blas_copy_f32(int64_t n, const float *x, float *y, void *stream);
 int cmi_blas_fill_f64(int64_t n, double value, double *y, void *stream);
+int cmi_blas_fill_f32(int64_t n, float value, float *y, void *stream);
+/* f32: products and partial sums are accumulated in double, the result is rounded to float once */
 int cmi_blas_dot_f64(int64_t n, const double *x, const double *y, double *result_dev, void *workspace,
                      void *stream);
+int cmi_blas_dot_f32(int64_t n, const float *x, const float *y, float *result_dev, void *workspace,
+                     void *stream);
 int cmi_blas_nrm2_f64(int64_t n, const double *x, double *result_dev, void *workspace, void *stream);
+int cmi_blas_nrm2_f32(int64_t n, const float *x, float *result_dev, void *workspace, void *stream);
 
 #ifdef __cplusplus
 }

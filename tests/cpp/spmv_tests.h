@@ -285,6 +285,23 @@ template <typename Space> void TestConjugateGradient()
 }
 DECLARE_SPACE_UNITTEST(TestConjugateGradient);
 
+// testing/cg.cu:46-67 verbatim protocol: float, monitor(b, 20, 1e-4)
+template <typename Space> void TestConjugateGradientFloat()
+{
+    cusp::csr_matrix<int, float, Space> A;
+    cusp::gallery::poisson5pt(A, 10, 10);
+    cusp::array1d<float, Space> x(A.num_rows, 0.0f), b(A.num_rows, 1.0f);
+    cusp::monitor<float> monitor(b, 20, 1e-4);
+    cusp::krylov::cg(A, x, b, monitor);
+    cusp::array1d<float, Space> residual(A.num_rows, 0.0f);
+    cusp::multiply(A, x, residual);
+    cusp::blas::axpby(residual, b, residual, -1.0f, 1.0f);
+    ASSERT_EQUAL(monitor.converged(), true);
+    ASSERT_TRUE(monitor.residual_norm() < 1e-4 * cusp::blas::nrm2(b));
+    ASSERT_TRUE(cusp::blas::nrm2(residual) < 1e-4 * cusp::blas::nrm2(b));
+}
+DECLARE_SPACE_UNITTEST(TestConjugateGradientFloat);
+
 template <typename Space> void TestConjugateGradientQuickstartTrace()
 {
     // docs/quickstart.md:72-87 (examples/Solvers/cg.cu): poisson5pt(10,10), b = 1, x0 = 0, rel-tol 1e-3:

@@ -536,6 +536,23 @@ def test_blas1(cmi, torch_cuda):
         assert torch.equal(dy, dz)
         cmi.blas_fill(3.25, dy)
         assert host(dy).tolist() == [3.25] * n if n < 100 else float(dy.min()) == 3.25 == float(dy.max())
+    # f32: same entry points, products and partial sums of the reductions kept in double
+    res32 = torch.zeros(1, dtype=torch.float32, device="cuda")
+    for n in (3, 64, 100003):
+        x, y = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+        dx, dy = dev(x, torch), dev(y, torch)
+        cmi.blas_dot(dx, dy, res32, ws)
+        assert float(res32) == float(np.float32(np.dot(x.astype(np.float64), y.astype(np.float64)))) or \
+            abs(float(res32) - float(np.dot(x.astype(np.float64), y.astype(np.float64)))) <= 1e-6 * float(np.abs(x * y).sum())
+        cmi.blas_nrm2(dx, res32, ws)
+        assert abs(float(res32) - float(np.linalg.norm(x.astype(np.float64)))) <= 1e-6 * float(np.linalg.norm(x))
+        cmi.blas_axpy(0.75, dx, dy)
+        assert np.array_equal(host(dy), np.float32(0.75) * x + y)
+        dz = torch.empty_like(dx)
+        cmi.blas_axpby(2.0, dx, -0.5, dy, dz)
+        assert np.array_equal(host(dz), np.float32(2.0) * x + np.float32(-0.5) * (np.float32(0.75) * x + y))
+        cmi.blas_fill(1.5, dz)
+        assert float(dz.min()) == 1.5 == float(dz.max())
     # unaligned views fall back to scalar accesses
     buf = torch.arange(1001, dtype=torch.float64, device="cuda")
     v = buf[1:]
