@@ -109,6 +109,8 @@ def _declare(L):
         getattr(L, f"cmi_blas_fill_{suf}").argtypes = [i64, sc, vp, vp]
         getattr(L, f"cmi_blas_dot_{suf}").argtypes = [i64, vp, vp, vp, vp, vp]
         getattr(L, f"cmi_blas_nrm2_{suf}").argtypes = [i64, vp, vp, vp, vp]
+    L.cmi_cg_update_f64.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.cmi_cg_direction_f64.argtypes = [i64, vp, vp, vp, vp, vp]
 
 
 def lib():
@@ -365,3 +367,14 @@ def blas_dot(x, y, result, workspace, stream=None):
 
 def blas_nrm2(x, result, workspace, stream=None):
     check(getattr(lib(), "cmi_blas_nrm2_" + _suffix(x))(x.numel(), _ptr(x), _ptr(result), _ptr(workspace), _stream(stream)))
+
+
+def cg_update(rz, yp, p, y, x, r, rr_out, workspace, stream=None):
+    """alpha = rz/yp (device scalars); x += alpha p; r -= alpha y; rr_out = <r, r> -- one pass."""
+    check(lib().cmi_cg_update_f64(x.numel(), _ptr(rz), _ptr(yp), _ptr(p), _ptr(y), _ptr(x), _ptr(r), _ptr(rr_out),
+                                  _ptr(workspace), _stream(stream)))
+
+
+def cg_direction(rr_new, rr_old, r, p, stream=None):
+    """beta = rr_new/rr_old (device scalars); p = r + beta p."""
+    check(lib().cmi_cg_direction_f64(p.numel(), _ptr(rr_new), _ptr(rr_old), _ptr(r), _ptr(p), _stream(stream)))

@@ -14,7 +14,8 @@
 namespace cmi {
 
 constexpr int kBlasBlock = 256;
-constexpr int kBlasMaxGrid = kCus * 8; // 2048 partials
+constexpr int kBlasMaxGrid = kCus * 8;   // reductions: 2048 partials
+constexpr int kFusedMaxGrid = 1 << 16;   // fused update+reduce kernels store too: near one-shot grids (65536 partials)
 
 // reductions: a fixed, capped grid (one partial per workgroup, deterministic tree)
 static int blas_grid(int64_t n, int per_thread)
@@ -123,13 +124,82 @@ dot_final_kernel(int npartial, const double *__restrict__ partial, T *__restrict
     if (threadIdx.x == 0) *result = (T)(take_sqrt ? sqrt(s) : s);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused CG vector updates (unpreconditioned CG: z == r), scalars read from DEVICE memory so the
+// host never has to produce alpha / beta (reference cusp/krylov/detail/cg.inl:83-103 does
+// dot -> host -> axpy -> axpy -> copy -> dot -> host -> axpby: seven passes and three host syncs;
+// here: update (x, r, <r,r>) in ONE pass over p, y, x, r and the direction in one pass over r, p).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlasBlock)
+cg_update_kernel(int64_t n, const double *__restrict__ rz, const double *__restrict__ yp, const double *__restrict__ p,
+                 const double *__restrict__ y, double *__restrict__ x, double *__restrict__ r, double *__restrict__ partial, int vec)
+{
+    __shared__ double slots[kBlasBlock / kWave];
+    const double alpha = *rz / *yp; // alpha <- <r,z>/<y,p>   (cg.inl:83)
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double acc = 0.0;
+    if (vec) {
+        const int64_t nv = n / 2;
+        for (int64_t i = t; i < nv; i += stride) {
+            const double2v pv = reinterpret_cast<const double2v *>(p)[i], yv = reinterpret_cast<const double2v *>(y)[i];
+            double2v xv = reinterpret_cast<double2v *>(x)[i], rv = reinterpret_cast<double2v *>(r)[i];
+            xv.x = alpha * pv.x + xv.x; xv.y = alpha * pv.y + xv.y;         // x <- x + alpha p   (:86)
+            rv.x = (-alpha) * yv.x + rv.x; rv.y = (-alpha) * yv.y + rv.y;   // r <- r - alpha y   (:89)
+            reinterpret_cast<double2v *>(x)[i] = xv;
+            reinterpret_cast<double2v *>(r)[i] = rv;
+            acc += rv.x * rv.x;
+            acc += rv.y * rv.y;                                             // <r, r>             (:97, z == r)
+        }
+        if (t == 0 && (n & 1)) {
+            const int64_t i = n - 1;
+            x[i] = alpha * p[i] + x[i];
+            const double ri = (-alpha) * y[i] + r[i];
+            r[i] = ri;
+            acc += ri * ri;
+        }
+    } else {
+        for (int64_t i = t; i < n; i += stride) {
+            x[i] = alpha * p[i] + x[i];
+            const double ri = (-alpha) * y[i] + r[i];
+            r[i] = ri;
+            acc += ri * ri;
+        }
+    }
+    const double s = block_sum(acc, slots);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// p <- r + beta p with beta = rr_new / rr_old read from device memory (cg.inl:100-103, z == r)
+__global__ void __launch_bounds__(kBlasBlock)
+cg_direction_kernel(int64_t n, const double *__restrict__ rr_new, const double *__restrict__ rr_old,
+                    const double *__restrict__ r, double *__restrict__ p, int vec)
+{
+    const double beta = *rr_new / *rr_old;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        const int64_t nv = n / 2;
+        for (int64_t i = t; i < nv; i += stride) {
+            const double2v rv = reinterpret_cast<const double2v *>(r)[i];
+            double2v pv = reinterpret_cast<double2v *>(p)[i];
+            pv.x = 1.0 * rv.x + beta * pv.x;
+            pv.y = 1.0 * rv.y + beta * pv.y;
+            reinterpret_cast<double2v *>(p)[i] = pv;
+        }
+        if (t == 0 && (n & 1)) p[n - 1] = 1.0 * r[n - 1] + beta * p[n - 1];
+    } else {
+        for (int64_t i = t; i < n; i += stride) p[i] = 1.0 * r[i] + beta * p[i];
+    }
+}
+
 static bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 
 } // namespace cmi
 
 using namespace cmi;
 
-CMI_API size_t cmi_blas_workspace_bytes(void) { return (size_t)kBlasMaxGrid * sizeof(double); }
+CMI_API size_t cmi_blas_workspace_bytes(void) { return (size_t)kFusedMaxGrid * sizeof(double); }
 
 namespace {
 
@@ -191,3 +261,38 @@ CMI_API int cmi_blas_dot_f64(int64_t n, const double *x, const double *y, double
 CMI_API int cmi_blas_dot_f32(int64_t n, const float *x, const float *y, float *r, void *ws, void *stream) { return dot_impl<float>(n, x, y, r, ws, stream, 0); }
 CMI_API int cmi_blas_nrm2_f64(int64_t n, const double *x, double *r, void *ws, void *stream) { return dot_impl<double>(n, x, x, r, ws, stream, 1); }
 CMI_API int cmi_blas_nrm2_f32(int64_t n, const float *x, float *r, void *ws, void *stream) { return dot_impl<float>(n, x, x, r, ws, stream, 1); }
+
+// ---- fused CG steps (f64) ----
+static int fused_grid(int64_t n)
+{
+    int64_t b = ceil_div(n, (int64_t)kBlasBlock * 2);
+    if (b > kFusedMaxGrid) b = kFusedMaxGrid;
+    return b < 1 ? 1 : (int)b;
+}
+
+CMI_API int cmi_cg_update_f64(int64_t n, const double *rz_dev, const double *yp_dev, const double *p, const double *y,
+                              double *x, double *r, double *rr_dev, void *workspace, void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_update: negative n");
+    if (!rz_dev || !yp_dev || !rr_dev || !workspace) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_update: null scalar or workspace");
+    if (n > 0 && (!p || !y || !x || !r)) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_update: null array");
+    const int grid = fused_grid(n);
+    const int vec = aligned16(p) && aligned16(y) && aligned16(x) && aligned16(r);
+    hipLaunchKernelGGL(cg_update_kernel, dim3(grid), dim3(kBlasBlock), 0, as_stream(stream), n, rz_dev, yp_dev, p, y, x, r, (double *)workspace, vec);
+    hipLaunchKernelGGL((dot_final_kernel<double>), dim3(1), dim3(kBlasBlock), 0, as_stream(stream), grid, (const double *)workspace, rr_dev, 0);
+    CMI_LAUNCH_CHECK("cg_update");
+    return CMI_SUCCESS;
+}
+
+CMI_API int cmi_cg_direction_f64(int64_t n, const double *rr_new_dev, const double *rr_old_dev, const double *r, double *p,
+                                 void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_direction: negative n");
+    if (!rr_new_dev || !rr_old_dev) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_direction: null scalar");
+    if (n == 0) return CMI_SUCCESS;
+    if (!r || !p) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_direction: null array");
+    const int vec = aligned16(r) && aligned16(p);
+    hipLaunchKernelGGL(cg_direction_kernel, dim3(stream_grid(n, 2)), dim3(kBlasBlock), 0, as_stream(stream), n, rr_new_dev, rr_old_dev, r, p, vec);
+    CMI_LAUNCH_CHECK("cg_direction");
+    return CMI_SUCCESS;
+}

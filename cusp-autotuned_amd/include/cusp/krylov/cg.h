@@ -4,6 +4,8 @@
 // One cusp::multiply per iteration -> cmi_spmv_* on device_memory; vector updates -> cusp::blas.
 #pragma once
 #include <cassert>
+#include <cmath>
+#include <type_traits>
 
 #include "../array1d.h"
 #include "../blas/blas.h"
@@ -20,12 +22,78 @@ template <typename M, typename X, typename Y> auto apply(const M &m, const X &x,
 template <typename M, typename X, typename Y> void apply(const M &m, const X &x, Y &y, long) { cusp::multiply(m, x, y); }
 } // namespace detail
 
+namespace detail {
+
+// Fused unpreconditioned CG on the device (f64): z == r is folded away, alpha and beta stay in device
+// memory, and the vector work of an iteration is cmi_blas_dot + cmi_cg_update + cmi_cg_direction:
+// 4 vector passes and ONE host read (the convergence check) instead of cg.inl's 7 passes and 3 host
+// syncs.  Per-element arithmetic unchanged; the residual history agrees with the plain path to rounding.
+template <typename Monitor> auto has_finished_norm(Monitor *m) -> decltype(m->finished_norm(typename Monitor::Real()), std::true_type());
+std::false_type has_finished_norm(...);
+
+template <typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor>
+void cg_fused_device(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &monitor)
+{
+    const size_t N = A.num_rows;
+    cusp::array1d<double, cusp::device_memory> y(N), r(N), p(N), scalars(3); // scalars: rr[0], rr[1], <y,p>
+    cusp::blas::detail::device_workspace &w = cusp::blas::detail::workspace();
+    double *rr[2] = {scalars.data(), scalars.data() + 1};
+    double *yp = scalars.data() + 2;
+    cusp::multiply(A, x, y);
+    cusp::blas::axpby(b, y, r, 1.0, -1.0);
+    cusp::blas::copy(r, p);
+    cusp::detail::check(cmi_blas_dot_f64(N, r.data(), r.data(), rr[0], w.ws, nullptr));
+    int cur = 0;
+    for (;;) {
+        double rr_host;
+        cusp::detail::check(cmi_memcpy_d2h(&rr_host, rr[cur], sizeof(double), nullptr)); // the one host read
+        if (monitor.finished_norm(std::sqrt(rr_host))) break;
+        cusp::multiply(A, p, y);                                                          // the hot path
+        cusp::detail::check(cmi_blas_dot_f64(N, y.data(), p.data(), yp, w.ws, nullptr));
+        cusp::detail::check(cmi_cg_update_f64(N, rr[cur], yp, p.data(), y.data(), x.data(), r.data(), rr[cur ^ 1], w.ws, nullptr));
+        cusp::detail::check(cmi_cg_direction_f64(N, rr[cur ^ 1], rr[cur], r.data(), p.data(), nullptr));
+        cur ^= 1;
+        ++monitor;
+    }
+}
+
+template <typename A, typename X, typename M, typename Mon> struct use_fused {
+    static const bool value = std::is_same<typename A::memory_space, cusp::device_memory>::value &&
+                              std::is_same<typename A::value_type, double>::value && std::is_same<typename X::value_type, double>::value &&
+                              std::is_same<M, cusp::identity_operator<double, cusp::device_memory>>::value &&
+                              decltype(has_finished_norm(static_cast<Mon *>(nullptr)))::value;
+};
+
+template <typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor, typename Preconditioner>
+void cg_plain(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &monitor, Preconditioner &M);
+
+template <typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor, typename Preconditioner>
+void cg_select(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &monitor, Preconditioner &, std::true_type)
+{
+    cg_fused_device(A, x, b, monitor);
+}
+template <typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor, typename Preconditioner>
+void cg_select(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &monitor, Preconditioner &M, std::false_type)
+{
+    cg_plain(A, x, b, monitor, M);
+}
+
+} // namespace detail
+
 template <typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor, typename Preconditioner>
 void cg(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &monitor, Preconditioner &M)
 {
+    if (A.num_rows != A.num_cols) throw cusp::invalid_input_exception("cg: matrix must be square");
+    detail::cg_select(A, x, b, monitor, M,
+                      std::integral_constant<bool, detail::use_fused<LinearOperator, VectorType1, Preconditioner, Monitor>::value>());
+}
+
+// reference cusp/krylov/detail/cg.inl:41-107, operation by operation (any memory space, any M)
+template <typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor, typename Preconditioner>
+void detail::cg_plain(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &monitor, Preconditioner &M)
+{
     typedef typename LinearOperator::value_type ValueType;
     typedef typename LinearOperator::memory_space MemorySpace;
-    if (A.num_rows != A.num_cols) throw cusp::invalid_input_exception("cg: matrix must be square");
     const size_t N = A.num_rows;
 
     // workspace (reference: four temporary_array's, cg.inl:55-58)

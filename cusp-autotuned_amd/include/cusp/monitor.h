@@ -47,9 +47,12 @@ public:
     }
 
     // reference monitor.inl:181-207
-    template <typename Vector> bool finished(const Vector &r)
+    template <typename Vector> bool finished(const Vector &r) { return finished_norm(cusp::blas::nrm2(r)); }
+
+    // same bookkeeping for a solver that already holds ||r|| (the fused device CG gets it for free)
+    bool finished_norm(Real norm)
     {
-        r_norm = cusp::blas::nrm2(r);
+        r_norm = norm;
         residuals.push_back(r_norm);
         if (verbose) std::cout << "       " << std::setw(10) << iteration_count() << "       " << std::setw(10) << std::scientific << residual_norm() << std::endl;
         if (converged()) {

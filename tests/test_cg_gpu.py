@@ -43,12 +43,13 @@ def numpy_cg(orc, Ap, Aj, Ax, b, iteration_limit, rel_tol):
     return x, hist
 
 
-def test_cg_single_gpu_quickstart_trace_and_oracle(cmi, orc):
+@pytest.mark.parametrize("fused", [True, False])
+def test_cg_single_gpu_quickstart_trace_and_oracle(cmi, orc, fused):
     import torch
     A = cmi.poisson5pt(10, 10, "csr")
     x = torch.zeros(100, dtype=torch.float64, device="cuda")
     b = torch.ones(100, dtype=torch.float64, device="cuda")
-    mon = cmi.krylov.cg(A, x, b, iteration_limit=100, relative_tolerance=1e-3)
+    mon = cmi.krylov.cg(A, x, b, iteration_limit=100, relative_tolerance=1e-3, fused=fused)
     assert mon.converged() and mon.iteration_count == 12 and len(mon.residuals) == 13
     for got, want in zip(mon.residuals, QUICKSTART_TRACE):
         assert abs(got - want) <= 2e-6 * want
@@ -57,6 +58,21 @@ def test_cg_single_gpu_quickstart_trace_and_oracle(cmi, orc):
     assert len(hist) == len(mon.residuals)
     assert np.allclose(mon.residuals, hist, rtol=1e-12, atol=0)
     assert np.allclose(x.cpu().numpy(), xs, rtol=1e-12, atol=1e-14)
+
+
+def test_cg_fused_equals_plain_large(cmi):
+    """Fused (device scalars, 4 passes) and plain (cg.inl replay) drivers: same history to rounding."""
+    import torch
+    m, n = 700, 500
+    A = cmi.poisson5pt(m, n, "csr")
+    b = cmi.fill_x(m * n, device="cuda")
+    hist = {}
+    for fused in (True, False):
+        x = torch.zeros(m * n, dtype=torch.float64, device="cuda")
+        hist[fused] = (cmi.krylov.cg(A, x, b, iteration_limit=60, relative_tolerance=1e-14, fused=fused).residuals, x)
+    assert len(hist[True][0]) == len(hist[False][0]) == 61
+    assert np.allclose(hist[True][0], hist[False][0], rtol=1e-9)
+    assert float((hist[True][1] - hist[False][1]).abs().max()) <= 1e-9 * float(hist[False][1].abs().max())
 
 
 @pytest.mark.parametrize("fmt", ["csr", "ell", "dia", "coo", "hyb"])
