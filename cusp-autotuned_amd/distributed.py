@@ -111,7 +111,18 @@ class ShardedVectorExchange:
             return [dist.all_gather_into_tensor(self.x_full, self._gather_in, group=self.group, async_op=True)]
         if self._ops is None:
             self._ops = self._build_ops()  # built once: the ranges never change
-        return dist.batch_isend_irecv(self._ops) if self._ops else []
+        if not self._ops:
+            return []
+        try:
+            return dist.batch_isend_irecv(self._ops)
+        except RuntimeError as e:  # a transport without point-to-point support: use the collective
+            import sys
+            print(f"[cusp-autotuned_amd] rank {self.rank}: point-to-point halo exchange failed ({e}); "
+                  "falling back to all-gather", file=sys.stderr)
+            self.plan.mode = "allgather"
+            if self._gather_in is None:
+                self._gather_in = self.torch.zeros(self.count, dtype=self.x_full.dtype, device=self.x_full.device)
+            return self.start()
 
     @staticmethod
     def finish(works):
