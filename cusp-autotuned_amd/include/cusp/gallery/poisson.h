@@ -6,6 +6,8 @@
 // device_memory CSR / DIA targets are built directly in HBM by the C-ABI (cmi_poisson5pt_*), ELL / COO
 // through the on-device CSR conversions; results are identical to the host path.
 #pragma once
+#include <vector>
+
 #include "../convert.h"
 #include "../detail/matrices.h"
 
@@ -73,6 +75,58 @@ template <typename Matrix> void poisson5pt_impl(Matrix &A, size_t m, size_t n, d
 template <typename MatrixType> void poisson5pt(MatrixType &matrix, size_t m, size_t n)
 {
     detail::poisson5pt_impl(matrix, m, n, typename MatrixType::memory_space());
+}
+
+// ---- generic stencils (reference cusp/gallery/stencil.h, detail/stencil.inl:143-206) ----------------
+// A stencil point = (offset in each grid dimension, value).  Built as a host DIA matrix (one diagonal per
+// stencil point, in stencil order, pitch = num_rows) and converted to the requested type -- exactly the
+// reference's route.  Used here for the FEM-like surrogates of the SuiteSparse set (27-point: ~27
+// entries/row like nlpkkt120; 7- and 9-point: thermal2-like row lengths).
+struct stencil_point { long long dx, dy, dz; double value; };
+
+template <typename MatrixType>
+void generate_matrix_from_stencil(MatrixType &matrix, const std::vector<stencil_point> &stencil, size_t nx, size_t ny, size_t nz = 1)
+{
+    typedef typename MatrixType::index_type I;
+    typedef typename MatrixType::value_type V;
+    const size_t N = nx * ny * nz;
+    dia_matrix<I, V, host_memory> dia;
+    dia.resize(N, N, 0, stencil.size(), 1);
+    size_t nnz = 0;
+    for (size_t d = 0; d < stencil.size(); d++) {
+        const stencil_point &sp = stencil[d];
+        dia.diagonal_offsets[d] = static_cast<I>(sp.dx + sp.dy * (long long)nx + sp.dz * (long long)(nx * ny));
+        for (size_t r = 0; r < N; r++) {
+            const long long ix = (long long)(r % nx) + sp.dx, iy = (long long)((r / nx) % ny) + sp.dy, iz = (long long)(r / (nx * ny)) + sp.dz;
+            const bool inside = ix >= 0 && ix < (long long)nx && iy >= 0 && iy < (long long)ny && iz >= 0 && iz < (long long)nz;
+            dia.values(r, d) = inside ? static_cast<V>(sp.value) : V(0);
+            nnz += inside && sp.value != 0.0;
+        }
+    }
+    dia.num_entries = nnz;
+    cusp::convert(dia, matrix);
+}
+
+// reference cusp/gallery/detail/poisson.inl:49-120
+template <typename MatrixType> void poisson9pt(MatrixType &matrix, size_t m, size_t n)
+{
+    std::vector<stencil_point> st;
+    for (long long j = -1; j <= 1; j++)
+        for (long long i = -1; i <= 1; i++) st.push_back({i, j, 0, (i == 0 && j == 0) ? 8.0 : -1.0});
+    generate_matrix_from_stencil(matrix, st, m, n);
+}
+template <typename MatrixType> void poisson7pt(MatrixType &matrix, size_t m, size_t n, size_t k)
+{
+    const std::vector<stencil_point> st = {{0, 0, -1, -1.0}, {0, -1, 0, -1.0}, {-1, 0, 0, -1.0}, {0, 0, 0, 6.0}, {1, 0, 0, -1.0}, {0, 1, 0, -1.0}, {0, 0, 1, -1.0}};
+    generate_matrix_from_stencil(matrix, st, m, n, k);
+}
+template <typename MatrixType> void poisson27pt(MatrixType &matrix, size_t m, size_t n, size_t l)
+{
+    std::vector<stencil_point> st;
+    for (long long k = -1; k <= 1; k++)
+        for (long long j = -1; j <= 1; j++)
+            for (long long i = -1; i <= 1; i++) st.push_back({i, j, k, (i == 0 && j == 0 && k == 0) ? 26.0 : -1.0});
+    generate_matrix_from_stencil(matrix, st, m, n, l);
 }
 
 } // namespace gallery

@@ -64,6 +64,36 @@ void TestGenericFunctorsOnHost()
 }
 DECLARE_UNITTEST(TestGenericFunctorsOnHost);
 
+// reference testing/poisson.cu:27-92: exact dense expectations for the 9-, 7- and 27-point stencils
+void TestPoissonOtherStencils()
+{
+    {
+        cusp::dia_matrix<int, float, cusp::host_memory> matrix;
+        cusp::gallery::poisson9pt(matrix, 2, 3);
+        cusp::array2d<float, cusp::host_memory> R(matrix);
+        const float E[6][6] = {{8, -1, -1, -1, 0, 0}, {-1, 8, -1, -1, 0, 0}, {-1, -1, 8, -1, -1, -1}, {-1, -1, -1, 8, -1, -1}, {0, 0, -1, -1, 8, -1}, {0, 0, -1, -1, -1, 8}};
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) ASSERT_EQUAL(R(i, j), E[i][j]);
+    }
+    {
+        cusp::csr_matrix<int, float, cusp::host_memory> matrix;
+        cusp::gallery::poisson7pt(matrix, 2, 2, 2);
+        cusp::array2d<float, cusp::host_memory> R(matrix);
+        const float E[8][8] = {{6, -1, -1, 0, -1, 0, 0, 0}, {-1, 6, 0, -1, 0, -1, 0, 0}, {-1, 0, 6, -1, 0, 0, -1, 0}, {0, -1, -1, 6, 0, 0, 0, -1},
+                               {-1, 0, 0, 0, 6, -1, -1, 0}, {0, -1, 0, 0, -1, 6, 0, -1}, {0, 0, -1, 0, -1, 0, 6, -1}, {0, 0, 0, -1, 0, -1, -1, 6}};
+        for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) ASSERT_EQUAL(R(i, j), E[i][j]);
+    }
+    {
+        cusp::coo_matrix<int, double, cusp::host_memory> matrix;
+        cusp::gallery::poisson27pt(matrix, 2, 2, 2);
+        cusp::array2d<double, cusp::host_memory> R(matrix);
+        for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) ASSERT_EQUAL(R(i, j), i == j ? 26.0 : -1.0);
+        cusp::csr_matrix<int, double, cusp::host_memory> big;
+        cusp::gallery::poisson27pt(big, 12, 11, 10); // interior rows hold 27 entries
+        ASSERT_EQUAL(cusp::compute_max_entries_per_row(big.row_offsets), size_t(27));
+    }
+}
+DECLARE_UNITTEST(TestPoissonOtherStencils);
+
 int main(int argc, char **argv)
 {
     g_golden_dir = GOLDEN_DIR;

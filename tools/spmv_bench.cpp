@@ -4,6 +4,7 @@
 //
 //   spmv_bench                        poisson5pt(512,512), the reference's default input
 //   spmv_bench --grid=3162            poisson5pt(3162,3162), the headline matrix
+//   spmv_bench --stencil=27 --grid=150   27-point stencil on 150^3 (3.4M rows, ~27 entries/row: an nlpkkt120-like surrogate)
 //   spmv_bench my_matrix.mtx          a MatrixMarket file (SuiteSparse: nlpkkt120, ldoor, thermal2 ...)
 //   options: --value_type={float,double}  (default double)
 //
@@ -134,8 +135,12 @@ template <typename I, typename V> int test_all_formats(const std::string &filena
     cusp::csr_matrix<I, V, cusp::host_memory> host_matrix;
     if (filename.empty()) {
         const size_t g = args.count("grid") ? std::stoul(args["grid"]) : 512;
-        std::printf("Generated matrix (poisson5pt %zux%zu) ", g, g);
-        cusp::gallery::poisson5pt(host_matrix, g, g);
+        const int stencil = args.count("stencil") ? std::stoi(args["stencil"]) : 5;
+        if (stencil == 5) { std::printf("Generated matrix (poisson5pt %zux%zu) ", g, g); cusp::gallery::poisson5pt(host_matrix, g, g); }
+        else if (stencil == 9) { std::printf("Generated matrix (poisson9pt %zux%zu) ", g, g); cusp::gallery::poisson9pt(host_matrix, g, g); }
+        else if (stencil == 7) { std::printf("Generated matrix (poisson7pt %zu^3) ", g); cusp::gallery::poisson7pt(host_matrix, g, g, g); }
+        else if (stencil == 27) { std::printf("Generated matrix (poisson27pt %zu^3) ", g); cusp::gallery::poisson27pt(host_matrix, g, g, g); }
+        else { std::fprintf(stderr, "ERROR: --stencil must be 5, 7, 9 or 27\n"); return 1; }
     } else {
         cusp::io::read_matrix_market_file(host_matrix, filename);
         std::printf("Read matrix (%s) ", filename.c_str());
