@@ -126,6 +126,59 @@ def synthetic_csr(rows, cols, mean, seed, dtype):
     return Ap, Aj, Ax
 
 
+def stencil_csr(nx, ny, nz, points, dtype):
+    """CSR of a constant-coefficient stencil on an nx x ny x nz grid, rows in grid order, entries in
+    stencil order (the layout cusp::gallery::generate_matrix_from_stencil + DIA->CSR produces)."""
+    N = nx * ny * nz
+    r = np.arange(N, dtype=np.int64)
+    ix, iy, iz = r % nx, (r // nx) % ny, r // (nx * ny)
+    cols = np.empty((N, len(points)), np.int64)
+    vals = np.empty((N, len(points)), dtype)
+    mask = np.empty((N, len(points)), bool)
+    for k, (dx, dy, dz, v) in enumerate(points):
+        jx, jy, jz = ix + dx, iy + dy, iz + dz
+        mask[:, k] = (jx >= 0) & (jx < nx) & (jy >= 0) & (jy < ny) & (jz >= 0) & (jz < nz)
+        cols[:, k] = r + dx + dy * nx + dz * nx * ny
+        vals[:, k] = v
+    Ap = np.zeros(N + 1, np.int32)
+    Ap[1:] = np.cumsum(mask.sum(axis=1))
+    return Ap, cols[mask].astype(np.int32), vals[mask]
+
+
+def block_expand(Ap, Aj, Ax, dof, dtype):
+    """d degrees of freedom per grid point: every scalar entry becomes a dense d x d block (the row
+    structure of 3-D elasticity / ldoor-like FEM matrices: 27-point x 3 dof = 81 entries per row)."""
+    N = len(Ap) - 1
+    lens = np.diff(Ap).astype(np.int64)
+    Ap2 = np.zeros(N * dof + 1, np.int64)
+    Ap2[1:] = np.cumsum(np.repeat(lens * dof, dof))
+    # row r*dof + a holds, for every scalar entry (r, c), the columns c*dof + 0..dof-1
+    cols_block = (Aj.astype(np.int64)[:, None] * dof + np.arange(dof)[None, :]).reshape(-1)  # per scalar entry: dof cols
+    # rows of one grid point are identical in structure: tile each scalar row's expanded columns dof times
+    starts = Ap[:-1].astype(np.int64) * dof
+    out_cols = np.empty(int(Ap2[-1]), np.int32)
+    out_vals = np.empty(int(Ap2[-1]), dtype)
+    rng = np.random.default_rng(99)
+    for a in range(dof):
+        idx_rows = np.arange(N) * dof + a
+        # destination ranges of rows idx_rows are contiguous runs of length lens*dof
+        dst = np.repeat(Ap2[idx_rows], lens * dof) + (np.arange(int((lens * dof).sum())) - np.repeat(np.cumsum(lens * dof) - lens * dof, lens * dof))
+        out_cols[dst] = cols_block
+        out_vals[dst] = rng.standard_normal(len(cols_block)).astype(dtype)
+    del starts
+    return Ap2.astype(np.int32), out_cols, out_vals
+
+
+def stencil_points(kind):
+    if kind == 27:
+        return [(i, j, k, 26.0 if (i, j, k) == (0, 0, 0) else -1.0) for k in (-1, 0, 1) for j in (-1, 0, 1) for i in (-1, 0, 1)]
+    if kind == 9:
+        return [(i, j, 0, 8.0 if (i, j) == (0, 0) else -1.0) for j in (-1, 0, 1) for i in (-1, 0, 1)]
+    if kind == 7:
+        return [(0, 0, -1, -1.0), (0, -1, 0, -1.0), (-1, 0, 0, -1.0), (0, 0, 0, 6.0), (1, 0, 0, -1.0), (0, 1, 0, -1.0), (0, 0, 1, -1.0)]
+    raise ValueError(kind)
+
+
 def tune_one(cmi, torch, timer, label, space, run, check, iters, rounds, log, alg_bytes):
     """validate, then interleaved timing rounds; returns (best_cfg, best_ms, results)."""
     valid = []
@@ -257,14 +310,35 @@ def main():
         # synthetic CSR matrices for the other mean-row-length buckets
         if "csr" in formats and not args.skip_synthetic:
             rows = cols = 1_000_000 if not args.quick else 200_000
-            for mean in (1.5, 3.0, 10.0, 24.0, 48.0, 96.0, 200.0):
-                r = rows if mean < 100 else rows // 4
-                key = (r, mean)
-                if key not in synth_cache:  # same structure for f64 and f32
-                    synth_cache[key] = synthetic_csr(r, r, mean, int(mean * 10), np.float64)
+            # FEM-like stencils where a realistic shape exists for the bucket (9-point 2-D: 9/row,
+            # 27-point 3-D: ~27/row, an nlpkkt120-like shape), seeded synthetic matrices elsewhere
+            cases = [("synthetic", 1.5), ("synthetic", 3.0), ("stencil9", 2000 if not args.quick else 600),
+                     ("stencil27", 150 if not args.quick else 60), ("block27x2", 90 if not args.quick else 40),
+                     ("block27x3", 70 if not args.quick else 30), ("block27x8", 36 if not args.quick else 20)]
+            for kind, param in cases:
+                if kind == "synthetic":
+                    mean = param
+                    r = rows if mean < 100 else rows // 4
+                    key = (r, mean)
+                    if key not in synth_cache:  # same structure for f64 and f32
+                        synth_cache[key] = synthetic_csr(r, r, mean, int(mean * 10), np.float64)
+                    name = f"synthetic_mean{mean}"
+                else:
+                    g = param
+                    key = (kind, g)
+                    if key not in synth_cache:
+                        if kind == "stencil9":
+                            synth_cache[key] = stencil_csr(g, g, 1, stencil_points(9), np.float64)
+                        else:
+                            base = stencil_csr(g, g, g, stencil_points(27), np.float64)
+                            dof = {"stencil27": 1, "block27x2": 2, "block27x3": 3, "block27x8": 8}[kind]
+                            synth_cache[key] = base if dof == 1 else block_expand(*base, dof, np.float64)
+                    name = f"{kind}_{g}"
                 Ap, Aj, Ax = synth_cache[key]
+                r = len(Ap) - 1
+                mean = len(Ax) / r
                 Ax = Ax.astype(ndt)
-                print(f"synthetic mean {mean}: {r} rows, {len(Ax)} entries", flush=True)
+                print(f"{name}: {r} rows, {len(Ax)} entries ({mean:.2f}/row)", flush=True)
                 S = cmi.CsrMatrix(r, r, len(Ax), torch.from_numpy(Ap).cuda(), torch.from_numpy(Aj).cuda(),
                                   torch.from_numpy(Ax).cuda())
                 dxs = cmi.fill_x(r, tdt, "cuda")
@@ -284,7 +358,7 @@ def main():
                         return bool(np.array_equal(got, wants)), "bit-exact required"
                     return bool(np.all(np.abs(got - wants) <= tol * np.maximum(bound, 1e-30))), f"tolerance {tol}"
 
-                label = f"csr/{tag}/synthetic_mean{mean}"
+                label = f"csr/{tag}/{name}"
                 best, ms, res = tune_one(cmi, torch, timer, label, csr_space(cmi, mean, args.quick),
                                          lambda cfg: cmi.multiply(S, dxs, ys, cfg=cfg), check, args.iters, args.rounds,
                                          log, cmi.csr_bytes(r, len(Ax), vb))
