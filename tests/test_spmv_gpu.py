@@ -257,6 +257,44 @@ def test_reference_known_answer_matrices(cmi, torch_cuda, orc, known):
 
 
 # ------------------------------------------------------------------------------------------------
+# FEM-like long rows (SuiteSparse surrogates of BASELINE.json configs[3]): 27-point stencil (~27/row,
+# nlpkkt120-like) and 27-point x 3 dof (~79/row, ldoor-like), through the tuning table and explicit
+# lane-group configurations
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dof", [1, 3])
+def test_fem_like_long_rows(cmi, torch_cuda, orc, dof):
+    import sys
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1] / "tools"))
+    import autotune
+    torch = torch_cuda
+    g = 24
+    Ap, Aj, Ax = autotune.stencil_csr(g, g, g, autotune.stencil_points(27), np.float64)
+    if dof > 1:
+        Ap, Aj, Ax = autotune.block_expand(Ap, Aj, Ax, dof, np.float64)
+    rows = len(Ap) - 1
+    x = np.random.default_rng(4).standard_normal(rows)
+    want = orc.spmv_csr(Ap, Aj, Ax, x)
+    bound = row_abs(orc, Ap, Aj, Ax, x)
+    dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+    sel = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, rows, rows, len(Ax))
+    assert sel.kernel == cmi.CSR_STREAM
+    cfgs = [None, cmi.Config(kernel=cmi.CSR_STREAM, items_per_thread=2), cmi.Config(kernel=cmi.CSR_STREAM, items_per_thread=4, block_size=512),
+            cmi.Config(kernel=cmi.CSR_STREAM, items_per_thread=2, threads_per_row=4, block_size=256),
+            cmi.Config(kernel=cmi.CSR_STREAM, items_per_thread=2, threads_per_row=8, block_size=512),
+            cmi.Config(kernel=cmi.CSR_STREAM, items_per_thread=2, threads_per_row=32, block_size=512, rows_per_block=16),
+            cmi.Config(kernel=cmi.CSR_VECTOR, threads_per_row=16), cmi.Config(kernel=cmi.CSR_SCALAR)]
+    for cfg in cfgs:
+        y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
+        cmi.spmv_csr(rows, rows, dAp, dAj, dAx, dx, y, cfg=cfg)
+        got = host(y)
+        exact = cfg is not None and cfg.kernel in (cmi.CSR_STREAM, cmi.CSR_SCALAR) and cfg.threads_per_row <= 1
+        if exact or (cfg is None and sel.threads_per_row <= 1):
+            assert np.array_equal(got, want), f"dof{dof} {cfg}"
+        else:
+            assert_close(got, want, bound, np.float64, f"dof{dof} {cfg}")
+
+
+# ------------------------------------------------------------------------------------------------
 # edge cases
 # ------------------------------------------------------------------------------------------------
 def test_empty_and_degenerate_shapes(cmi, torch_cuda):
