@@ -95,6 +95,7 @@ def _declare(L):
         getattr(L, f"cmi_poisson5pt_csr_{suf}").argtypes = [i64, i64, i64, i64, vp, vp, vp, vp]
         getattr(L, f"cmi_poisson5pt_dia_{suf}").argtypes = [i64, i64, i64, vp, vp, vp]
         getattr(L, f"cmi_csr_to_ell_{suf}").argtypes = [i64, vp, vp, vp, i64, i64, vp, vp, vp]
+        getattr(L, f"cmi_csr_to_hyb_coo_{suf}").argtypes = [i64, vp, vp, vp, i64, vp, vp, vp, vp, vp]
     L.cmi_poisson5pt_num_entries.restype = c_int64
     L.cmi_poisson5pt_num_entries.argtypes = [i64, i64]
     L.cmi_poisson5pt_shard_entries.restype = c_int64
@@ -318,6 +319,17 @@ def csr_to_ell(num_rows, Ap, Aj, Ax, width, pitch, ell_Aj, ell_Ax, stream=None):
         raise ValueError("csr_to_ell: output arrays too small")
     fn = getattr(lib(), "cmi_csr_to_ell_" + _suffix(ell_Ax))
     check(fn(num_rows, _ptr(Ap), _ptr(Aj), _ptr(Ax), width, pitch, _ptr(ell_Aj), _ptr(ell_Ax), _stream(stream)))
+
+
+def csr_to_hyb_coo(num_rows, Ap, Aj, Ax, width, coo_offsets, coo_Ai, coo_Aj, coo_Ax, stream=None):
+    import torch
+    for t, n in ((Ap, "Ap"), (Aj, "Aj"), (coo_offsets, "coo_offsets"), (coo_Ai, "coo_Ai"), (coo_Aj, "coo_Aj")):
+        _need(t, n, torch.int32)
+    _need(Ax, "Ax", coo_Ax.dtype)
+    _need(coo_Ax, "coo_Ax")
+    fn = getattr(lib(), "cmi_csr_to_hyb_coo_" + _suffix(coo_Ax))
+    check(fn(num_rows, _ptr(Ap), _ptr(Aj), _ptr(Ax), width, _ptr(coo_offsets), _ptr(coo_Ai), _ptr(coo_Aj), _ptr(coo_Ax),
+             _stream(stream)))
 
 
 def csr_row_indices(num_rows, Ap, Ai, stream=None):

@@ -89,6 +89,29 @@ csr_to_ell_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__res
     }
 }
 
+// CSR -> HYB, COO part: the entries at within-row index >= width, in CSR order.  coo_offsets[i] =
+// number of such entries in rows [0, i) (an exclusive scan of max(0, len_i - width), supplied by the
+// caller: it is a function of the row offsets alone).  A 64-lane wave per row keeps the copies coalesced.
+template <typename T>
+__global__ void __launch_bounds__(256)
+csr_to_hyb_coo_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ Aj, const T *__restrict__ Ax,
+                      int width, const int *__restrict__ coo_offsets, int *__restrict__ coo_Ai, int *__restrict__ coo_Aj,
+                      T *__restrict__ coo_Ax)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / kWave;
+    for (int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave; row < num_rows; row += nwaves) {
+        const int s = Ap[row] + width, e = Ap[row + 1];
+        const int dst = coo_offsets[row];
+        for (int jj = s + lane; jj < e; jj += kWave) {
+            const int o = dst + (jj - s);
+            coo_Ai[o] = (int)row;
+            coo_Aj[o] = Aj[jj];
+            coo_Ax[o] = Ax[jj];
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 csr_row_indices_kernel(int64_t num_rows, const int *__restrict__ Ap, int *__restrict__ Ai)
 {
@@ -144,6 +167,19 @@ static int poisson_dia(int64_t m, int64_t n, int64_t pitch, int *offsets, T *val
 }
 
 template <typename T>
+static int csr_to_hyb_coo(int64_t rows, const int *Ap, const int *Aj, const T *Ax, int64_t width, const int *coo_offsets,
+                          int *coo_Ai, int *coo_Aj, T *coo_Ax, void *stream)
+{
+    if (rows < 0 || width < 0 || width > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_to_hyb_coo: bad size");
+    if (rows == 0) return CMI_SUCCESS;
+    if (!Ap || !coo_offsets) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_to_hyb_coo: null array");
+    hipLaunchKernelGGL((csr_to_hyb_coo_kernel<T>), dim3(grid_1d(rows * 8)), dim3(256), 0, as_stream(stream), rows, Ap, Aj, Ax, (int)width,
+                       coo_offsets, coo_Ai, coo_Aj, coo_Ax);
+    CMI_LAUNCH_CHECK("csr_to_hyb_coo");
+    return CMI_SUCCESS;
+}
+
+template <typename T>
 static int csr_to_ell(int64_t rows, const int *Ap, const int *Aj, const T *Ax, int64_t width, int64_t pitch,
                       int *ell_Aj, T *ell_Ax, void *stream)
 {
@@ -186,6 +222,13 @@ CMI_API int cmi_csr_to_ell_f64(int64_t num_rows, const int32_t *Ap, const int32_
 CMI_API int cmi_csr_to_ell_f32(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, const float *Ax, int64_t width,
                                int64_t pitch, int32_t *ell_Aj, float *ell_Ax, void *stream)
 { return csr_to_ell<float>(num_rows, Ap, Aj, Ax, width, pitch, ell_Aj, ell_Ax, stream); }
+
+CMI_API int cmi_csr_to_hyb_coo_f64(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, const double *Ax, int64_t width,
+                                   const int32_t *coo_offsets, int32_t *coo_Ai, int32_t *coo_Aj, double *coo_Ax, void *stream)
+{ return csr_to_hyb_coo<double>(num_rows, Ap, Aj, Ax, width, coo_offsets, coo_Ai, coo_Aj, coo_Ax, stream); }
+CMI_API int cmi_csr_to_hyb_coo_f32(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, const float *Ax, int64_t width,
+                                   const int32_t *coo_offsets, int32_t *coo_Ai, int32_t *coo_Aj, float *coo_Ax, void *stream)
+{ return csr_to_hyb_coo<float>(num_rows, Ap, Aj, Ax, width, coo_offsets, coo_Ai, coo_Aj, coo_Ax, stream); }
 
 CMI_API int cmi_csr_row_indices(int64_t num_rows, const int32_t *Ap, int32_t *Ai, void *stream)
 {

@@ -387,6 +387,41 @@ struct device_fast_path<csr_matrix<int, V, device_memory>, coo_matrix<int, V, de
     }
 };
 
+inline int csr_to_hyb_coo_device(int64_t rows, const int *Ap, const int *Aj, const double *Ax, int64_t w, const int *off, int *cAi, int *cAj, double *cAx)
+{ return cmi_csr_to_hyb_coo_f64(rows, Ap, Aj, Ax, w, off, cAi, cAj, cAx, nullptr); }
+inline int csr_to_hyb_coo_device(int64_t rows, const int *Ap, const int *Aj, const float *Ax, int64_t w, const int *off, int *cAi, int *cAj, float *cAx)
+{ return cmi_csr_to_hyb_coo_f32(rows, Ap, Aj, Ax, w, off, cAi, cAj, cAx, nullptr); }
+
+// device CSR -> device HYB: only the row offsets visit the host (width heuristic + overflow offsets)
+template <typename V>
+struct device_fast_path<csr_matrix<int, V, device_memory>, hyb_matrix<int, V, device_memory>, csr_format, hyb_format> {
+    static bool run(const csr_matrix<int, V, device_memory> &s, hyb_matrix<int, V, device_memory> &d)
+    {
+        if (s.num_entries == 0) return false;
+        array1d<int, host_memory> off(s.row_offsets);
+        const size_t width = compute_optimal_entries_per_row(off, 3.0f, 4096);
+        array1d<int, host_memory> coo_off(s.num_rows);
+        size_t n_coo = 0;
+        for (size_t i = 0; i < s.num_rows; i++) {
+            coo_off[i] = static_cast<int>(n_coo);
+            const size_t len = off[i + 1] - off[i];
+            if (len > width) n_coo += len - width;
+        }
+        d.resize(s.num_rows, s.num_cols, s.num_entries - n_coo, n_coo, width);
+        if (width > 0)
+            check(csr_to_ell_device(s.num_rows, s.row_offsets.data(), s.column_indices.data(), s.values.data(), width,
+                                    d.ell.column_indices.pitch, d.ell.column_indices.values.data(), d.ell.values.values.data()));
+        if (n_coo) {
+            array1d<int, device_memory> dev_off(coo_off);
+            check(csr_to_hyb_coo_device(s.num_rows, s.row_offsets.data(), s.column_indices.data(), s.values.data(), width, dev_off.data(),
+                                        d.coo.row_indices.data(), d.coo.column_indices.data(), d.coo.values.data()));
+            check(cmi_stream_synchronize(nullptr));
+        }
+        check(cmi_stream_synchronize(nullptr));
+        return true;
+    }
+};
+
 template <typename Src, typename Dst> void convert_impl(const Src &src, Dst &dst, std::true_type /*same format*/)
 {
     copy_same(src, dst, typename Dst::format());

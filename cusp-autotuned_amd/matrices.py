@@ -159,13 +159,16 @@ def convert(csr, fmt, num_entries_per_row=None, ell_alignment=32):
             if n_coo:
                 raise ValueError("convert: num_entries_per_row is smaller than the longest row (use hyb)")
             return ell
-        # entries with within-row index >= width, in CSR order (setup-time compaction)
-        Ai = torch.empty(csr.num_entries, dtype=torch.int32, device=dev)
-        B.csr_row_indices(csr.num_rows, csr.row_offsets, Ai)
-        k = torch.arange(csr.num_entries, dtype=torch.int32, device=dev) - csr.row_offsets[Ai.long()]
-        keep = k >= width
-        coo = CooMatrix(csr.num_rows, csr.num_cols, n_coo, Ai[keep].contiguous(),
-                        csr.column_indices[keep].contiguous(), csr.values[keep].contiguous())
+        # COO part: entries at within-row index >= width, in CSR order.  Their destinations are an
+        # exclusive scan of the per-row overflow counts (a function of the row offsets alone).
+        over = torch.clamp(lens - width, min=0)
+        offs = (torch.cumsum(over, 0) - over).to(torch.int32).contiguous()
+        cAi = torch.empty(n_coo, dtype=torch.int32, device=dev)
+        cAj = torch.empty(n_coo, dtype=torch.int32, device=dev)
+        cAx = torch.empty(n_coo, dtype=csr.values.dtype, device=dev)
+        if n_coo:
+            B.csr_to_hyb_coo(csr.num_rows, csr.row_offsets, csr.column_indices, csr.values, width, offs, cAi, cAj, cAx)
+        coo = CooMatrix(csr.num_rows, csr.num_cols, n_coo, cAi, cAj, cAx)
         return HybMatrix(csr.num_rows, csr.num_cols, csr.num_entries, ell, coo)
     raise ValueError(f"convert: unknown format {fmt!r}")
 

@@ -232,6 +232,16 @@ int cmi_csr_to_ell_f64(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, c
                        int64_t width, int64_t pitch, int32_t *ell_Aj, double *ell_Ax, void *stream);
 int cmi_csr_to_ell_f32(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, const float *Ax,
                        int64_t width, int64_t pitch, int32_t *ell_Aj, float *ell_Ax, void *stream);
+/* CSR -> HYB, COO part (csr_to_other.h:229-306): the entries at within-row index >= width, in CSR order.
+ * coo_offsets[i] = number of such entries in rows [0, i) -- an exclusive scan of max(0, len_i - width),
+ * a function of the row offsets alone, supplied by the caller (num_rows entries).  The ELL part is
+ * cmi_csr_to_ell with the same width. */
+int cmi_csr_to_hyb_coo_f64(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, const double *Ax, int64_t width,
+                           const int32_t *coo_offsets, int32_t *coo_Ai, int32_t *coo_Aj, double *coo_Ax,
+                           void *stream);
+int cmi_csr_to_hyb_coo_f32(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, const float *Ax, int64_t width,
+                           const int32_t *coo_offsets, int32_t *coo_Ai, int32_t *coo_Aj, float *coo_Ax,
+                           void *stream);
 /* CSR -> COO row indices (offsets_to_indices, csr_to_other.h:56-70). */
 int cmi_csr_row_indices(int64_t num_rows, const int32_t *Ap, int32_t *Ai, void *stream);
 /* ELL -> per-row length of the leading valid run (cusp/ktt/detail/ellr_matrix.inl:16-53). */
