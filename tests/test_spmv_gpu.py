@@ -331,6 +331,51 @@ def test_empty_and_degenerate_shapes(cmi, torch_cuda):
     assert host(y).tolist() == [10.0]
 
 
+@pytest.mark.parametrize("shape", ["one_dense_row", "dense_last_row", "mostly_empty", "unsorted_duplicates"])
+def test_pathological_row_length_distributions(cmi, torch_cuda, orc, shape):
+    """Extreme skew: every CSR kernel (multi-pass tiles, lane groups, persistent variant) and the
+    COO kernels must still match the host order / tolerance."""
+    torch = torch_cuda
+    rng = np.random.default_rng(17)
+    rows, cols = 20000, 30000
+    lens = np.zeros(rows, np.int64)
+    if shape == "one_dense_row":
+        lens[:] = rng.integers(0, 4, size=rows)
+        lens[1234] = 250_000
+    elif shape == "dense_last_row":
+        lens[-1] = 70_001
+        lens[0] = 3
+    elif shape == "mostly_empty":
+        lens[rng.integers(0, rows, size=300)] = rng.integers(1, 50, size=300)
+    else:
+        lens[:] = rng.integers(0, 9, size=rows)
+    Ap = np.r_[0, np.cumsum(lens)].astype(np.int32)
+    nnz = int(Ap[-1])
+    Aj = rng.integers(0, cols, size=nnz).astype(np.int32)  # unsorted, duplicates allowed
+    if shape != "unsorted_duplicates":
+        for i in np.nonzero(lens > 1)[0][:50]:
+            Aj[Ap[i]:Ap[i + 1]] = np.sort(Aj[Ap[i]:Ap[i + 1]])
+    Ax = rng.standard_normal(nnz)
+    if shape == "unsorted_duplicates":
+        Ax[rng.integers(0, nnz, size=nnz // 10)] = 0.0  # explicit zeros stay entries
+    x = rng.standard_normal(cols)
+    want = orc.spmv_csr(Ap, Aj, Ax, x)
+    bound = row_abs(orc, Ap, Aj, Ax, x)
+    dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+    for name, exact, cfg in csr_variants(cmi, small=True) + [("auto", False, None)]:
+        y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
+        cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, cfg=cfg)
+        if exact:
+            assert np.array_equal(host(y), want), f"{shape} {name}"
+        else:
+            assert_close(host(y), want, bound, np.float64, f"{shape} {name}")
+    Ai = orc.csr_row_indices(Ap)
+    for kern in (cmi.COO_SEGMENTED, cmi.COO_LANE4):
+        y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
+        cmi.spmv_coo(rows, cols, dev(Ai, torch), dAj, dAx, dx, y, cfg=cmi.Config(kernel=kern, items_per_thread=2))
+        assert_close(host(y), want, bound, np.float64, f"{shape} coo{kern}")
+
+
 def test_bad_config_is_an_error_not_a_fallback(cmi, torch_cuda):
     torch = torch_cuda
     Ap = torch.tensor([0, 1], dtype=torch.int32, device="cuda")
