@@ -128,22 +128,25 @@ template <typename V> struct device_functors<V, identity_function<V>, multiplies
     static int accumulate(const identity_function<V> &) { return 1; }
 };
 
+// explicit launch configuration for cusp::ktt::tune (thread-local; nullptr = tuning table)
+inline const cmi_config *&forced_config() { static thread_local const cmi_config *c = nullptr; return c; }
+
 inline int spmv_csr(int64_t r, int64_t c, int64_t n, const int *Ap, const int *Aj, const double *Ax, const double *x, double *y, int acc, void *s)
-{ return cmi_spmv_csr_f64(r, c, n, Ap, Aj, Ax, x, y, acc, nullptr, s); }
+{ return cmi_spmv_csr_f64(r, c, n, Ap, Aj, Ax, x, y, acc, forced_config(), s); }
 inline int spmv_csr(int64_t r, int64_t c, int64_t n, const int *Ap, const int *Aj, const float *Ax, const float *x, float *y, int acc, void *s)
-{ return cmi_spmv_csr_f32(r, c, n, Ap, Aj, Ax, x, y, acc, nullptr, s); }
+{ return cmi_spmv_csr_f32(r, c, n, Ap, Aj, Ax, x, y, acc, forced_config(), s); }
 inline int spmv_coo(int64_t r, int64_t c, int64_t n, const int *Ai, const int *Aj, const double *Ax, const double *x, double *y, int acc, void *s)
-{ return cmi_spmv_coo_f64(r, c, n, Ai, Aj, Ax, x, y, acc, nullptr, s); }
+{ return cmi_spmv_coo_f64(r, c, n, Ai, Aj, Ax, x, y, acc, forced_config(), s); }
 inline int spmv_coo(int64_t r, int64_t c, int64_t n, const int *Ai, const int *Aj, const float *Ax, const float *x, float *y, int acc, void *s)
-{ return cmi_spmv_coo_f32(r, c, n, Ai, Aj, Ax, x, y, acc, nullptr, s); }
+{ return cmi_spmv_coo_f32(r, c, n, Ai, Aj, Ax, x, y, acc, forced_config(), s); }
 inline int spmv_ell(int64_t r, int64_t c, int64_t w, int64_t p, const int *Aj, const double *Ax, const int *rl, const double *x, double *y, int acc, void *s)
-{ return cmi_spmv_ell_f64(r, c, w, p, Aj, Ax, rl, x, y, acc, nullptr, s); }
+{ return cmi_spmv_ell_f64(r, c, w, p, Aj, Ax, rl, x, y, acc, forced_config(), s); }
 inline int spmv_ell(int64_t r, int64_t c, int64_t w, int64_t p, const int *Aj, const float *Ax, const int *rl, const float *x, float *y, int acc, void *s)
-{ return cmi_spmv_ell_f32(r, c, w, p, Aj, Ax, rl, x, y, acc, nullptr, s); }
+{ return cmi_spmv_ell_f32(r, c, w, p, Aj, Ax, rl, x, y, acc, forced_config(), s); }
 inline int spmv_dia(int64_t r, int64_t c, int64_t d, int64_t p, const int *off, const double *v, const double *x, double *y, int acc, void *s)
-{ return cmi_spmv_dia_f64(r, c, d, p, off, v, x, y, acc, nullptr, s); }
+{ return cmi_spmv_dia_f64(r, c, d, p, off, v, x, y, acc, forced_config(), s); }
 inline int spmv_dia(int64_t r, int64_t c, int64_t d, int64_t p, const int *off, const float *v, const float *x, float *y, int acc, void *s)
-{ return cmi_spmv_dia_f32(r, c, d, p, off, v, x, y, acc, nullptr, s); }
+{ return cmi_spmv_dia_f32(r, c, d, p, off, v, x, y, acc, forced_config(), s); }
 inline int spmv_hyb(int64_t r, int64_t c, int64_t w, int64_t p, const int *eAj, const double *eAx, int64_t n, const int *cAi, const int *cAj,
                     const double *cAx, const double *x, double *y, int acc, void *s)
 { return cmi_spmv_hyb_f64(r, c, w, p, eAj, eAx, n, cAi, cAj, cAx, x, y, acc, nullptr, nullptr, s); }

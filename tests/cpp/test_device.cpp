@@ -59,4 +59,38 @@ void TestLargePoissonAllFormatsAgreeWithHost()
 }
 DECLARE_UNITTEST(TestLargePoissonAllFormatsAgreeWithHost);
 
+// cusp::ktt::tune (the fork's entry point, testing/ktt.cu:142-202): every configuration validated, the best
+// installed, later multiplies still exact
+template <typename Matrix> void tune_one_format(const char *name)
+{
+    cusp::csr_matrix<int, double, cusp::host_memory> H;
+    cusp::gallery::poisson5pt(H, 300, 200);
+    Matrix A(H);
+    const size_t N = H.num_rows;
+    cusp::array1d<double, cusp::host_memory> x(N), y(N, 10);
+    for (size_t i = 0; i < N; i++) x[i] = double(i % 21) - 10;
+    cusp::multiply(H, x, y);
+    cusp::array1d<double, cusp::device_memory> _x(x), _y(N, 10);
+    std::vector<cusp::ktt::tuning_result> res = cusp::ktt::tune(A, _x, _y, 5);
+    ASSERT_TRUE(res.size() >= 10);
+    size_t valid = 0;
+    for (auto &r : res) valid += r.valid;
+    ASSERT_TRUE(valid >= res.size() - 2); // every configuration of the space computes the right answer
+    ASSERT_TRUE(res[0].valid && res[0].milliseconds > 0 && res[0].milliseconds <= res[valid - 1].milliseconds);
+    cusp::blas::fill(_y, 10.0);
+    cusp::multiply(A, _x, _y); // now runs the configuration tune() installed
+    ASSERT_ARRAYS_EQUAL(_y, y);
+    std::printf("        tune(%s): %zu configurations, best %.4f ms (kernel %d, block %d), worst valid %.4f ms\n", name, res.size(),
+                res[0].milliseconds, res[0].config.kernel, res[0].config.block_size, res[valid - 1].milliseconds);
+}
+void TestKttTune()
+{
+    tune_one_format<cusp::csr_matrix<int, double, cusp::device_memory>>("csr");
+    tune_one_format<cusp::ell_matrix<int, double, cusp::device_memory>>("ell");
+    tune_one_format<cusp::dia_matrix<int, double, cusp::device_memory>>("dia");
+    tune_one_format<cusp::coo_matrix<int, double, cusp::device_memory>>("coo");
+    cusp::ktt::reset_tuning(); // back to the built-in heuristics (ktt.inl:130-142)
+}
+DECLARE_UNITTEST(TestKttTune);
+
 int main(int argc, char **argv) { return unittest::run_all(argc, argv); }
