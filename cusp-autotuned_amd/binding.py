@@ -81,6 +81,11 @@ def _declare(L):
     L.cmi_event_destroy.argtypes = [vp]
     L.cmi_event_record.argtypes = [vp, vp]
     L.cmi_event_elapsed_ms.argtypes = [vp, vp, POINTER(c_float)]
+    L.cmi_event_synchronize.argtypes = [vp]
+    L.cmi_malloc_host.argtypes = [POINTER(c_void_p), c_size_t]
+    L.cmi_free_host.argtypes = [vp]
+    L.cmi_memcpy_d2h_async.argtypes = [vp, vp, c_size_t, vp]
+    L.cmi_spmv_csr_dot_f64.argtypes = [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, cfgp, vp]
     L.cmi_tuning_load.argtypes = [c_char_p]
     L.cmi_tuning_save.argtypes = [c_char_p]
     L.cmi_tuning_set.argtypes = [c_int, c_int, c_double, cfgp]
@@ -195,6 +200,20 @@ def spmv_csr(num_rows, num_cols, Ap, Aj, Ax, x, y, accumulate=False, cfg=None, s
     fn = getattr(lib(), "cmi_spmv_csr_" + _suffix(y))
     check(fn(num_rows, num_cols, Aj.numel(), _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(y), int(bool(accumulate)),
              _cfg(cfg), _stream(stream)))
+
+
+def spmv_csr_dot(num_rows, num_cols, Ap, Aj, Ax, x, y, w, result, workspace, cfg=None, stream=None):
+    """y <- A x and result[0] <- <y, w> in one pass (f64; cmi_spmv_csr_dot_f64)."""
+    import torch
+    for t, n in ((Ap, "Ap"), (Aj, "Aj")):
+        _need(t, n, torch.int32)
+    for t, n in ((Ax, "Ax"), (x, "x"), (y, "y"), (w, "w"), (result, "result")):
+        _need(t, n, torch.float64)
+    if (Ap.numel() != num_rows + 1 or x.numel() != num_cols or y.numel() != num_rows or w.numel() != num_rows
+            or Aj.numel() != Ax.numel() or result.numel() < 1):
+        raise ValueError("spmv_csr_dot: array lengths do not match the matrix shape")
+    check(lib().cmi_spmv_csr_dot_f64(num_rows, num_cols, Aj.numel(), _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(y), _ptr(w),
+                                     _ptr(result), _ptr(workspace), _cfg(cfg), _stream(stream)))
 
 
 def spmv_coo(num_rows, num_cols, Ai, Aj, Ax, x, y, accumulate=False, cfg=None, stream=None):

@@ -15,7 +15,7 @@ namespace cmi {
 
 constexpr int kBlasBlock = 256;
 constexpr int kBlasMaxGrid = kCus * 8;   // reductions: 2048 partials
-constexpr int kFusedMaxGrid = 1 << 16;   // fused update+reduce kernels store too: near one-shot grids (65536 partials)
+constexpr int kFusedMaxGrid = kPartialCapacity;  // fused update+reduce kernels store too: near one-shot grids (65536 partials)
 
 // reductions: a fixed, capped grid (one partial per workgroup, deterministic tree)
 static int blas_grid(int64_t n, int per_thread)
@@ -124,6 +124,44 @@ dot_final_kernel(int npartial, const double *__restrict__ partial, T *__restrict
     if (threadIdx.x == 0) *result = (T)(take_sqrt ? sqrt(s) : s);
 }
 
+// middle stage for long partial lists (one-shot fused kernels leave up to 65536 of them): workgroup g
+// folds partial[g*kFoldChunk, (g+1)*kFoldChunk) into folded[g]; still a fixed tree
+constexpr int kFoldChunk = 1024;
+constexpr int kFoldDirect = 2048; // up to here one workgroup folds the list directly
+__global__ void __launch_bounds__(kBlasBlock)
+dot_fold_kernel(int npartial, const double *__restrict__ partial, double *__restrict__ folded)
+{
+    __shared__ double slots[kBlasBlock / kWave];
+    const int lo = blockIdx.x * kFoldChunk;
+    const int hi = lo + kFoldChunk < npartial ? lo + kFoldChunk : npartial;
+    double acc = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += partial[i];
+    const double s = block_sum(acc, slots);
+    if (threadIdx.x == 0) folded[blockIdx.x] = s;
+}
+
+// workspace layout: [0, kFusedMaxGrid) stage-1 partials, [kFusedMaxGrid, +kFusedMaxGrid/kFoldChunk) folded
+template <typename T>
+static void reduce_partials(int npartial, double *workspace, T *result, int take_sqrt, hipStream_t s)
+{
+    const double *src = workspace;
+    if (npartial > kFoldDirect) {
+        const int groups = (npartial + kFoldChunk - 1) / kFoldChunk;
+        double *folded = workspace + kFusedMaxGrid;
+        hipLaunchKernelGGL(dot_fold_kernel, dim3(groups), dim3(kBlasBlock), 0, s, npartial, src, folded);
+        src = folded;
+        npartial = groups;
+    }
+    hipLaunchKernelGGL((dot_final_kernel<T>), dim3(1), dim3(kBlasBlock), 0, s, npartial, src, result, take_sqrt);
+}
+
+int reduce_partials_f64(int npartial, double *workspace, double *result, hipStream_t s)
+{
+    if (npartial > kFusedMaxGrid) return fail(CMI_ERROR_INVALID_VALUE, "reduce_partials: more partials than the workspace holds");
+    reduce_partials<double>(npartial, workspace, result, 0, s);
+    return CMI_SUCCESS;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused CG vector updates (unpreconditioned CG: z == r), scalars read from DEVICE memory so the
 // host never has to produce alpha / beta (reference cusp/krylov/detail/cg.inl:83-103 does
@@ -199,7 +237,7 @@ static bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 1
 
 using namespace cmi;
 
-CMI_API size_t cmi_blas_workspace_bytes(void) { return (size_t)kFusedMaxGrid * sizeof(double); }
+CMI_API size_t cmi_blas_workspace_bytes(void) { return (size_t)(kFusedMaxGrid + kFusedMaxGrid / kFoldChunk) * sizeof(double); }
 
 namespace {
 
@@ -241,7 +279,7 @@ template <typename T> int dot_impl(int64_t n, const T *x, const T *y, T *result_
     const int grid = blas_grid(n, vec16<T>::n);
     const int vec = aligned16(x) && aligned16(y);
     hipLaunchKernelGGL((dot_partial_kernel<T>), dim3(grid), dim3(kBlasBlock), 0, as_stream(stream), n, x, y, (double *)workspace, vec);
-    hipLaunchKernelGGL((dot_final_kernel<T>), dim3(1), dim3(kBlasBlock), 0, as_stream(stream), grid, (const double *)workspace, result_dev, take_sqrt);
+    reduce_partials<T>(grid, (double *)workspace, result_dev, take_sqrt, as_stream(stream));
     CMI_LAUNCH_CHECK("dot");
     return CMI_SUCCESS;
 }
@@ -279,7 +317,7 @@ CMI_API int cmi_cg_update_f64(int64_t n, const double *rz_dev, const double *yp_
     const int grid = fused_grid(n);
     const int vec = aligned16(p) && aligned16(y) && aligned16(x) && aligned16(r);
     hipLaunchKernelGGL(cg_update_kernel, dim3(grid), dim3(kBlasBlock), 0, as_stream(stream), n, rz_dev, yp_dev, p, y, x, r, (double *)workspace, vec);
-    hipLaunchKernelGGL((dot_final_kernel<double>), dim3(1), dim3(kBlasBlock), 0, as_stream(stream), grid, (const double *)workspace, rr_dev, 0);
+    reduce_partials<double>(grid, (double *)workspace, rr_dev, 0, as_stream(stream));
     CMI_LAUNCH_CHECK("cg_update");
     return CMI_SUCCESS;
 }

@@ -53,6 +53,11 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 void select_config(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
                    const cmi_config *user, cmi_config *out);
 
+// Deterministic fold of `npartial` (<= kPartialCapacity) doubles at the start of a
+// cmi_blas_workspace_bytes() buffer into *result (blas1.hip; fixed tree, no atomics).
+constexpr int kPartialCapacity = 1 << 16;
+int reduce_partials_f64(int npartial, double *workspace, double *result, hipStream_t s);
+
 // XCD-aware tile index.  Workgroups b and b+8 share an XCD (observed round-robin placement; a
 // different placement changes speed only, never results).  mode 0: tile = b.  mode 1: every XCD walks
 // one contiguous eighth of the tiles.  mode C >= 2: tiles are dealt to the XCDs in chunks of C

@@ -77,6 +77,23 @@ CMI_API int cmi_free(void *ptr)
     return CMI_SUCCESS;
 }
 
+// page-locked host memory: the target of cmi_memcpy_d2h_async (a pageable target would make the
+// "async" copy synchronous)
+CMI_API int cmi_malloc_host(void **ptr, size_t bytes)
+{
+    if (!ptr) return fail(CMI_ERROR_INVALID_VALUE, "cmi_malloc_host: null out pointer");
+    *ptr = nullptr;
+    if (bytes == 0) return CMI_SUCCESS;
+    CMI_HIP(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    return CMI_SUCCESS;
+}
+
+CMI_API int cmi_free_host(void *ptr)
+{
+    if (ptr) CMI_HIP(hipHostFree(ptr));
+    return CMI_SUCCESS;
+}
+
 static int copy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, void *stream)
 {
     if (bytes == 0) return CMI_SUCCESS;
@@ -90,6 +107,16 @@ static int copy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, vo
 CMI_API int cmi_memcpy_h2d(void *d, const void *s, size_t b, void *st) { return copy(d, s, b, hipMemcpyHostToDevice, st); }
 CMI_API int cmi_memcpy_d2h(void *d, const void *s, size_t b, void *st) { return copy(d, s, b, hipMemcpyDeviceToHost, st); }
 CMI_API int cmi_memcpy_d2d(void *d, const void *s, size_t b, void *st) { return copy(d, s, b, hipMemcpyDeviceToDevice, st); }
+
+// device -> page-locked host, ordered on `stream`, NOT waited for: pair it with cmi_event_record +
+// cmi_event_synchronize (the CG convergence read: the next SpMV is queued before the host waits)
+CMI_API int cmi_memcpy_d2h_async(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (bytes == 0) return CMI_SUCCESS;
+    if (!dst || !src) return fail(CMI_ERROR_INVALID_VALUE, "cmi_memcpy_d2h_async: null pointer");
+    CMI_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    return CMI_SUCCESS;
+}
 
 CMI_API int cmi_memset(void *dst, int byte_value, size_t bytes, void *stream)
 {
@@ -123,6 +150,11 @@ CMI_API int cmi_event_destroy(void *event) { CMI_HIP(hipEventDestroy((hipEvent_t
 CMI_API int cmi_event_record(void *event, void *stream)
 {
     CMI_HIP(hipEventRecord((hipEvent_t)event, as_stream(stream)));
+    return CMI_SUCCESS;
+}
+CMI_API int cmi_event_synchronize(void *event)
+{
+    CMI_HIP(hipEventSynchronize((hipEvent_t)event));
     return CMI_SUCCESS;
 }
 CMI_API int cmi_event_elapsed_ms(void *start, void *stop, float *ms)

@@ -67,14 +67,33 @@ csr_vector_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__res
 // Tile = blockDim.x * IPT * 4 entries.  LDS: T prod[tile] then int rowptr[rows_per_block + 1].
 // VEC: Aj and Ax are 16-byte aligned, so entry index e with e % 4 == 0 is a 16-byte boundary in Aj
 // and a 32-byte boundary in Ax (f64) / 16-byte (f32): one int4 + two double2 (or one float4) per lane.
-template <typename T, int IPT, bool VEC, int POL>
+// DOT: the workgroup also leaves sum_r y[r] * w[r] over its rows in dot_partial[tile] (double; lanes
+// folded by a fixed wave butterfly, waves in order), so <A x, w> costs no second pass over y -- the
+// CG step <A p, p> (reference cusp/krylov/detail/cg.inl:80-83) with w == x == p.
+__device__ __forceinline__ void tile_dot_store(double d, double *slots, double *out)
+{
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) d += __shfl_down(d, o);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) slots[wave] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < (int)((blockDim.x + kWave - 1) / kWave); w++) s += slots[w];
+        *out = s;
+    }
+}
+
+template <typename T, int IPT, bool VEC, int POL, bool DOT = false>
 __global__ void __launch_bounds__(1024)
 csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ Ap,
                   const int *__restrict__ Aj, const T *__restrict__ Ax, const T *__restrict__ x,
                   T *__restrict__ y, int rows_per_block, int64_t num_tiles, int64_t tiles_per_xcd,
-                  int swizzle, int accumulate, int tpr)
+                  int swizzle, int accumulate, int tpr, const T *__restrict__ w = nullptr,
+                  double *__restrict__ dot_partial = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double dot_slots[DOT ? 1024 / kWave : 1];
     constexpr bool NT = (POL & kPolLoadNT) != 0;
     const int block = blockDim.x;
     const int tid = threadIdx.x;
@@ -112,13 +131,18 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
                 }
             }
             prod[tid * 4 + 0] = p0; prod[tid * 4 + 1] = p1; prod[tid * 4 + 2] = p2; prod[tid * 4 + 3] = p3;
+            T wv = T(0);
+            if constexpr (DOT) { if (tid < nr) wv = w[r0 + tid]; } // requested before the barrier
             __syncthreads();
+            double d = 0.0;
             if (tid < nr) {
                 T s = accumulate ? y[r0 + tid] : T(0);
                 const int a = rowptr[tid], b = rowptr[tid + 1];
                 for (int j = a; j < b; j++) s = s + prod[j - fbase];
                 st<(POL & kPolStoreNT) != 0>(y + r0 + tid, s);
+                if constexpr (DOT) d = (double)s * (double)wv;
             }
+            if constexpr (DOT) tile_dot_store(d, dot_slots, dot_partial + tile);
             return;
         }
     }
@@ -207,11 +231,16 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
         if (base + tile_entries < nz1) __syncthreads(); // another pass reuses prod (uniform condition)
     }
 
+    double d = 0.0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int r = grp + q * groups;
-        if (sub == 0 && r < nr) st<(POL & kPolStoreNT) != 0>(y + r0 + r, acc[q]);
+        if (sub == 0 && r < nr) {
+            st<(POL & kPolStoreNT) != 0>(y + r0 + r, acc[q]);
+            if constexpr (DOT) d += (double)acc[q] * (double)w[r0 + r];
+        }
     }
+    if constexpr (DOT) tile_dot_store(d, dot_slots, dot_partial + tile);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -402,14 +431,14 @@ static int launch_vector(int tpr, int grid, int block, hipStream_t s, int64_t ro
     return CMI_SUCCESS;
 }
 
-template <typename T, bool VEC, int POL>
+template <typename T, bool VEC, int POL, bool DOT = false>
 static int launch_stream_ipt(int ipt, int grid, int block, size_t lds, hipStream_t s, int64_t rows, int64_t nnz,
                              const int *Ap, const int *Aj, const T *Ax, const T *x, T *y, int rpb, int64_t tiles,
-                             int64_t tpx, int swz, int acc, int tpr)
+                             int64_t tpx, int swz, int acc, int tpr, const T *w = nullptr, double *dot_partial = nullptr)
 {
-#define CMI_STREAM_LAUNCH(IPT)                                                                                   \
-    hipLaunchKernelGGL((csr_stream_kernel<T, IPT, VEC, POL>), dim3(grid), dim3(block), lds, s, rows, nnz, Ap, Aj, \
-                       Ax, x, y, rpb, tiles, tpx, swz, acc, tpr)
+#define CMI_STREAM_LAUNCH(IPT)                                                                                        \
+    hipLaunchKernelGGL((csr_stream_kernel<T, IPT, VEC, POL, DOT>), dim3(grid), dim3(block), lds, s, rows, nnz, Ap, Aj, \
+                       Ax, x, y, rpb, tiles, tpx, swz, acc, tpr, w, dot_partial)
     switch (ipt) {
     case 1: CMI_STREAM_LAUNCH(1); break;
     case 2: CMI_STREAM_LAUNCH(2); break;
@@ -422,8 +451,12 @@ static int launch_stream_ipt(int ipt, int grid, int block, size_t lds, hipStream
 
 template <typename T>
 static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const int *Ap, const int *Aj, const T *Ax,
-                    const T *x, T *y, int accumulate, const cmi_config *user, void *stream)
+                    const T *x, T *y, int accumulate, const cmi_config *user, void *stream, const T *w = nullptr,
+                    double *dot_partial = nullptr, int *dot_partials = nullptr)
 {
+    // w != nullptr: the caller wants <y, w> too.  *dot_partials = number of per-tile partials the kernel
+    // left in dot_partial, or 0 when the selected kernel cannot fuse it (the caller then runs a plain dot).
+    if (dot_partials) *dot_partials = 0;
     if (rows < 0 || cols < 0 || nnz < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_csr: negative size");
     if (rows > INT32_MAX || cols > INT32_MAX || nnz > INT32_MAX - 65536)
         return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_csr: sizes exceed the int32 index type");
@@ -467,12 +500,20 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         const size_t lds = (size_t)block * ipt * 4 * sizeof(T) + (size_t)(rpb + 1) * sizeof(int);
         if (lds > 160 * 1024) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream: tile does not fit 160 KiB of LDS");
         const bool vec = (reinterpret_cast<uintptr_t>(Aj) % 16 == 0) && (reinterpret_cast<uintptr_t>(Ax) % 16 == 0);
+        const bool dot = w && dot_partial && vec && tiles <= kPartialCapacity && std::is_same<T, double>::value;
         with_policy(pol, [&](auto P) {
             constexpr int POL = decltype(P)::value;
+            if constexpr (std::is_same<T, double>::value) {
+                if (dot) {
+                    st = launch_stream_ipt<T, true, POL, true>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate, tpr, w, dot_partial);
+                    return;
+                }
+            }
             st = vec ? launch_stream_ipt<T, true, POL>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate, tpr)
                      : launch_stream_ipt<T, false, POL>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate, tpr);
         });
         if (st) return st;
+        if (dot && dot_partials) *dot_partials = (int)tiles;
         break;
     }
     case CMI_CSR_STREAM_PIPE: {
@@ -506,6 +547,26 @@ CMI_API int cmi_spmv_csr_f64(int64_t num_rows, int64_t num_cols, int64_t num_ent
                              const cmi_config *cfg, void *stream)
 {
     return cmi::spmv_csr<double>(CMI_F64, num_rows, num_cols, num_entries, Ap, Aj, Ax, x, y, accumulate, cfg, stream);
+}
+
+// y <- A x and *dot_dev <- <y, w> in one pass where the selected kernel can (csr_stream, aligned
+// arrays); otherwise the plain SpMV followed by cmi_blas_dot_f64.  Either way deterministic.
+CMI_API int cmi_spmv_csr_dot_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ap,
+                                 const int32_t *Aj, const double *Ax, const double *x, double *y, const double *w,
+                                 double *dot_dev, void *workspace, const cmi_config *cfg, void *stream)
+{
+    if ((!w && num_rows > 0) || !dot_dev || !workspace) return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_csr_dot: null w, result or workspace");
+    int partials = 0;
+    const int st = cmi::spmv_csr<double>(CMI_F64, num_rows, num_cols, num_entries, Ap, Aj, Ax, x, y, 0, cfg, stream, w,
+                                         (double *)workspace, &partials);
+    if (st) return st;
+    if (partials > 0) {
+        const int st2 = cmi::reduce_partials_f64(partials, (double *)workspace, dot_dev, cmi::as_stream(stream));
+        if (st2) return st2;
+        CMI_LAUNCH_CHECK("csr spmv dot");
+        return CMI_SUCCESS;
+    }
+    return cmi_blas_dot_f64(num_rows, y, w, dot_dev, workspace, stream);
 }
 
 CMI_API int cmi_spmv_csr_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ap,

@@ -83,6 +83,11 @@ class ShardedVectorExchange:
         self.plan = ExchangePlan(mode, recv, send, self.count, recv_values, allgather_values)
         self._gather_in = None
         self._ops = None
+        # RCCL orders its transfers after the work already queued on the compute stream.  A host
+        # transport (gloo in the one-GPU tests) reads the send buffer from the CPU with no such
+        # ordering, so the stream is drained first -- the callers queue kernels ahead of the host
+        # (krylov.cg launches the next SpMV before it reads the residual).
+        self._host_transport = world > 1 and dist.get_backend(group) != "nccl" and self.x_full.is_cuda
         if mode == "allgather" and world > 1:
             self._gather_in = torch.zeros(self.count, dtype=dtype, device=device)
 
@@ -105,6 +110,8 @@ class ShardedVectorExchange:
         if self.world == 1:
             return []
         dist, plan = self.dist, self.plan
+        if self._host_transport:
+            self.torch.cuda.current_stream(self.x_full.device).synchronize()
         if plan.mode == "allgather":
             n = self.hi - self.lo
             self._gather_in[:n].copy_(self.x_local)
@@ -215,6 +222,21 @@ class ShardedCsr:
         # arrays, so its own entry count is not what the tuning table should see)
         B.spmv_csr(b - a, A.num_cols, A.row_offsets[a:b + 1], A.column_indices, A.values, self.x_view, y_local[a:b],
                    cfg=self._cfg)
+
+    def multiply_dot(self, y_local, result, workspace):
+        """y_local = A[lo:hi, :] * x and result[0] = <y_local, x_local> (this rank's part of <A p, p>:
+        the caller all-reduces it).  One fused launch when the block is multiplied whole; the
+        overlapped (interior / boundary) schedule keeps its three launches and adds a dot."""
+        from . import binding as B
+        A = self.A
+        if self.interior is None and not self._custom and A.values.dtype == self.torch.float64:
+            self.vec.exchange()
+            B.spmv_csr_dot(A.num_rows, A.num_cols, A.row_offsets, A.column_indices, A.values, self.x_view, y_local,
+                           self.vec.x_local, result, workspace)
+            return y_local
+        self.multiply(y_local)
+        B.blas_dot(y_local, self.vec.x_local, result, workspace)
+        return y_local
 
     def multiply(self, y_local, exchange=True):
         """y_local = A[lo:hi, :] * x, with x's slices taken from every rank's x_local."""

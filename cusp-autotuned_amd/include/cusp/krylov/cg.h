@@ -25,11 +25,63 @@ template <typename M, typename X, typename Y> void apply(const M &m, const X &x,
 namespace detail {
 
 // Fused unpreconditioned CG on the device (f64): z == r is folded away, alpha and beta stay in device
-// memory, and the vector work of an iteration is cmi_blas_dot + cmi_cg_update + cmi_cg_direction:
-// 4 vector passes and ONE host read (the convergence check) instead of cg.inl's 7 passes and 3 host
-// syncs.  Per-element arithmetic unchanged; the residual history agrees with the plain path to rounding.
+// memory, and an iteration is
+//     cmi_spmv_csr_dot_f64 (y <- A p and <y,p> in one pass; other formats: SpMV + cmi_blas_dot)
+//     cmi_cg_update_f64    (x, r, <r,r> in one pass)
+//     cmi_cg_direction_f64 (p <- r + beta p)
+// i.e. 3 passes and ONE host read (the convergence check) instead of cg.inl's 7 passes and 3 host syncs.
+// The host read is an asynchronous copy into page-locked memory; the host waits for it only AFTER it
+// has queued the next iteration's SpMV (which reads p and writes the scratch y -- no solver state -- so
+// running it speculatively is harmless if the monitor then stops), so the device never idles on the
+// round trip.  Per-element arithmetic unchanged; the residual history agrees with the plain path to
+// rounding.
 template <typename Monitor> auto has_finished_norm(Monitor *m) -> decltype(m->finished_norm(typename Monitor::Real()), std::true_type());
 std::false_type has_finished_norm(...);
+
+struct pinned_scalar { // 8 page-locked bytes + the event that says they have landed
+    double *host;
+    void *event;
+    pinned_scalar() : host(nullptr), event(nullptr)
+    {
+        void *h = nullptr;
+        cusp::detail::check(cmi_malloc_host(&h, sizeof(double)));
+        host = static_cast<double *>(h);
+        const int st = cmi_event_create(&event);
+        if (st != CMI_SUCCESS) { cmi_free_host(host); cusp::detail::check(st); }
+    }
+    ~pinned_scalar() { if (event) cmi_event_destroy(event); if (host) cmi_free_host(host); }
+    pinned_scalar(const pinned_scalar &) = delete;
+    pinned_scalar &operator=(const pinned_scalar &) = delete;
+    void fetch(const double *dev) // queue the copy; returns at once
+    {
+        cusp::detail::check(cmi_memcpy_d2h_async(host, dev, sizeof(double), nullptr));
+        cusp::detail::check(cmi_event_record(event, nullptr));
+    }
+    double wait() { cusp::detail::check(cmi_event_synchronize(event)); return *host; }
+};
+
+// y <- A p and *yp <- <y, p>: one fused launch for CSR, SpMV + dot for the other formats
+template <typename A, typename V> void multiply_dot(const A &a, const V &p, V &y, double *yp, void *ws, cusp::csr_format)
+{
+    cusp::detail::require_int_index<A>();
+    cusp::detail::check(cmi_spmv_csr_dot_f64(a.num_rows, a.num_cols, a.num_entries, a.row_offsets.data(), a.column_indices.data(),
+                                             a.values.data(), p.data(), y.data(), p.data(), yp, ws, cusp::detail::forced_config(), nullptr));
+}
+template <typename A, typename V, typename Format> void multiply_dot(const A &a, const V &p, V &y, double *yp, void *ws, Format)
+{
+    cusp::multiply(a, p, y);
+    cusp::detail::check(cmi_blas_dot_f64(a.num_rows, y.data(), p.data(), yp, ws, nullptr));
+}
+template <typename A, typename V> auto multiply_dot(const A &a, const V &p, V &y, double *yp, void *ws, int) -> decltype(typename A::format(), void())
+{
+    if (p.size() != a.num_cols || y.size() != a.num_rows) throw cusp::invalid_input_exception("cg: vector sizes do not match the matrix");
+    multiply_dot(a, p, y, yp, ws, typename A::format());
+}
+template <typename A, typename V> void multiply_dot(const A &a, const V &p, V &y, double *yp, void *ws, long) // a linear operator without a format
+{
+    cusp::multiply(a, p, y);
+    cusp::detail::check(cmi_blas_dot_f64(y.size(), y.data(), p.data(), yp, ws, nullptr));
+}
 
 template <typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor>
 void cg_fused_device(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &monitor)
@@ -39,22 +91,23 @@ void cg_fused_device(const LinearOperator &A, VectorType1 &x, const VectorType2 
     cusp::blas::detail::device_workspace &w = cusp::blas::detail::workspace();
     double *rr[2] = {scalars.data(), scalars.data() + 1};
     double *yp = scalars.data() + 2;
+    pinned_scalar rr_host;
     cusp::multiply(A, x, y);
     cusp::blas::axpby(b, y, r, 1.0, -1.0);
     cusp::blas::copy(r, p);
     cusp::detail::check(cmi_blas_dot_f64(N, r.data(), r.data(), rr[0], w.ws, nullptr));
+    rr_host.fetch(rr[0]);
     int cur = 0;
     for (;;) {
-        double rr_host;
-        cusp::detail::check(cmi_memcpy_d2h(&rr_host, rr[cur], sizeof(double), nullptr)); // the one host read
-        if (monitor.finished_norm(std::sqrt(rr_host))) break;
-        cusp::multiply(A, p, y);                                                          // the hot path
-        cusp::detail::check(cmi_blas_dot_f64(N, y.data(), p.data(), yp, w.ws, nullptr));
+        multiply_dot(A, p, y, yp, w.ws, 0);                                               // the hot path (speculative, see above)
+        if (monitor.finished_norm(std::sqrt(rr_host.wait()))) break;                      // the one host read
         cusp::detail::check(cmi_cg_update_f64(N, rr[cur], yp, p.data(), y.data(), x.data(), r.data(), rr[cur ^ 1], w.ws, nullptr));
+        rr_host.fetch(rr[cur ^ 1]);
         cusp::detail::check(cmi_cg_direction_f64(N, rr[cur ^ 1], rr[cur], r.data(), p.data(), nullptr));
         cur ^= 1;
         ++monitor;
     }
+    cusp::detail::check(cmi_device_synchronize()); // the discarded SpMV must not outlive y
 }
 
 template <typename A, typename X, typename M, typename Mon> struct use_fused {

@@ -70,10 +70,11 @@ def cg(A, x, b, monitor=None, iteration_limit=500, relative_tolerance=1e-5, abso
     distributed.ShardedCsr (x, b = this rank's slices).  x holds the initial guess and the result.
     Returns the Monitor (residual history in .residuals).
 
-    fused=True (default, f64): the unpreconditioned iteration runs as SpMV + dot + cmi_cg_update +
-    cmi_cg_direction with alpha / beta kept in device memory -- 4 vector passes and ONE host read per
-    iteration (the convergence check) instead of the reference's 7 passes and 3 host syncs; the
-    per-element arithmetic is unchanged.  fused=False replays cg.inl operation by operation."""
+    fused=True (default, f64): the unpreconditioned iteration runs as SpMV(+dot) + cmi_cg_update +
+    cmi_cg_direction with alpha / beta kept in device memory -- 3 vector passes and ONE host read per
+    iteration (the convergence check, hidden behind the next SpMV) instead of the reference's 7 passes
+    and 3 host syncs; the per-element arithmetic is unchanged.  fused=False replays cg.inl operation
+    by operation."""
     import torch
     from . import binding as B
     from .distributed import ShardedCsr
@@ -123,32 +124,83 @@ def cg(A, x, b, monitor=None, iteration_limit=500, relative_tolerance=1e-5, abso
     return monitor
 
 
+class _HostScalar:
+    """8 page-locked bytes + the event that says the device value has landed (the convergence read)."""
+
+    def __init__(self, device):
+        import torch
+        self.torch = torch
+        self.cuda = device.type == "cuda"
+        self.host = torch.zeros(1, dtype=torch.float64)
+        if self.cuda:
+            self.host = self.host.pin_memory()
+            self.event = torch.cuda.Event()
+        self.src = None
+
+    def fetch(self, t):
+        """Queue the copy on the current stream; returns at once."""
+        if self.cuda:
+            self.host.copy_(t, non_blocking=True)
+            self.event.record()
+        else:
+            self.src = t
+
+    def wait(self):
+        if self.cuda:
+            self.event.synchronize()
+            return float(self.host[0])
+        return float(self.src.item())
+
+
 def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
-    """Unpreconditioned CG with z == r folded away and the scalars resident on the device."""
+    """Unpreconditioned CG with z == r folded away and the scalars resident on the device.
+
+    Per iteration: y <- A p together with <y, p> (one launch for CSR: cmi_spmv_csr_dot_f64), then
+    cmi_cg_update (x, r, <r,r>), then cmi_cg_direction.  The single host read (the monitor's residual
+    norm) is an asynchronous copy into page-locked memory that the host waits for only AFTER queueing
+    the next iteration's SpMV: that SpMV reads p and writes the scratch y -- no solver state -- so it
+    is harmless if the monitor then stops, and the device never idles on the host round trip."""
     import torch
     from . import binding as B
+    from .distributed import ShardedCsr
+    from .matrices import CsrMatrix
     dev = x.device
     rr = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(2)]  # <r,r> ping-pong
     yp = torch.zeros(1, dtype=torch.float64, device=dev)
+    rr_host = _HostScalar(dev)
 
     def reduce_(t):
         if world > 1:
             import torch.distributed as dist
             dist.all_reduce(t, group=group)
 
+    def spmv_dot():                              # y <- A p, yp <- <y, p>
+        if isinstance(A, ShardedCsr):
+            A.multiply_dot(y, yp, ops.ws)        # p IS A.x_local
+        elif isinstance(A, CsrMatrix):
+            B.spmv_csr_dot(A.num_rows, A.num_cols, A.row_offsets, A.column_indices, A.values, p, y, p, yp, ops.ws)
+        else:
+            spmv(p, y)
+            B.blas_dot(y, p, yp, ops.ws)
+        reduce_(yp)
+
     spmv(x, y)                                   # y <- A x
     B.blas_axpby(1.0, b, -1.0, y, r)             # r <- b - A x
     B.blas_copy(r, p)                            # p <- z = r
     B.blas_dot(r, r, rr[0], ops.ws)              # rz = <r, r>
     reduce_(rr[0])
+    rr_host.fetch(rr[0])
     cur = 0
-    while not monitor.finished(math.sqrt(float(rr[cur].item()))):   # the one host read per iteration
-        spmv(p, y)                               # y <- A p              THE HOT PATH
-        B.blas_dot(y, p, yp, ops.ws)             # <y, p>  (stays on the device)
-        reduce_(yp)
+    while True:
+        spmv_dot()                               # THE HOT PATH (queued before the host waits)
+        if monitor.finished(math.sqrt(rr_host.wait())):             # the one host read per iteration
+            break
         B.cg_update(rr[cur], yp, p, y, x, r, rr[cur ^ 1], ops.ws)   # x, r, <r,r> in one pass
         reduce_(rr[cur ^ 1])
+        rr_host.fetch(rr[cur ^ 1])
         B.cg_direction(rr[cur ^ 1], rr[cur], r, p)                  # p <- r + beta p
         cur ^= 1
         monitor.increment()
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()                # the discarded SpMV must not outlive y
     return monitor

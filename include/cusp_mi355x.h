@@ -63,6 +63,13 @@ int cmi_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int cmi_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
 int cmi_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
 int cmi_memset(void *dst, int byte_value, size_t bytes, void *stream);
+/* Page-locked host memory and a device->host copy that is ordered on `stream` but NOT waited for  */
+/* (pair with cmi_event_record / cmi_event_synchronize).  Used by cusp::krylov::cg for its one     */
+/* host read per iteration (the monitor's residual norm, reference cusp/detail/monitor.inl:181-207) */
+/* so that the next SpMV is already queued when the host blocks.                                    */
+int cmi_malloc_host(void **ptr, size_t bytes);
+int cmi_free_host(void *ptr);
+int cmi_memcpy_d2h_async(void *dst_pinned, const void *src, size_t bytes, void *stream);
 int cmi_stream_create(void **stream);
 int cmi_stream_destroy(void *stream);
 int cmi_stream_synchronize(void *stream);
@@ -72,6 +79,7 @@ int cmi_device_synchronize(void);
 int cmi_event_create(void **event);
 int cmi_event_destroy(void *event);
 int cmi_event_record(void *event, void *stream);
+int cmi_event_synchronize(void *event);
 int cmi_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
 
 /* ------------------------------------------------------------------------- */
@@ -153,6 +161,14 @@ int cmi_spmv_csr_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries, co
 int cmi_spmv_csr_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ap,
                      const int32_t *Aj, const float *Ax, const float *x, float *y, int accumulate,
                      const cmi_config *cfg, void *stream);
+/* y <- A x AND *dot_dev <- <y, w> (w: num_rows values; w may be x).  The CG step                  */
+/* `y = A p; alpha = rz / dot(y, p)` (reference cusp/krylov/detail/cg.inl:80-83) in ONE pass: the   */
+/* csr_stream workgroups leave per-tile partial sums in `workspace` (cmi_blas_workspace_bytes()),   */
+/* folded by a fixed tree -- deterministic, no atomics.  y is bit-identical to cmi_spmv_csr_f64's.  */
+/* When the selected kernel cannot fuse the dot it runs cmi_spmv_csr_f64 + cmi_blas_dot_f64.        */
+int cmi_spmv_csr_dot_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ap,
+                         const int32_t *Aj, const double *Ax, const double *x, double *y, const double *w,
+                         double *dot_dev, void *workspace, const cmi_config *cfg, void *stream);
 
 /* Replaces cuda::detail::multiply(ell) (ell_spmv.h:103-155) and ktt_ell_kernel / ktt_ellr_kernel
  * (ktt/kernels/ell_kernel.h:181-213).  Column-major num_rows x num_entries_per_row arrays with

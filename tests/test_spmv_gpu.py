@@ -596,6 +596,95 @@ def test_full_size_properties(cmi, torch_cuda, big):
 
 
 # ------------------------------------------------------------------------------------------------
+# fused y = A x, <y, w>  (the CG step cg.inl:80-83 in one pass)
+# ------------------------------------------------------------------------------------------------
+def test_spmv_csr_dot_every_variant(cmi, torch_cuda, golden_irregular):
+    """cmi_spmv_csr_dot_f64: y bit-identical to cmi_spmv_csr_f64 under the same config, the dot within
+    1e-12 * sum|y_i w_i| of numpy's -- for the kernels that fuse it (csr_stream) and the ones that fall
+    back to SpMV + dot alike."""
+    torch = torch_cuda
+    g = golden_irregular
+    rows, cols = int(g["rows"]), int(g["cols"])
+    Ap, Aj, Ax, x = dev(g["f64_Ap"], torch), dev(g["f64_Aj"], torch), dev(g["f64_Ax"], torch), dev(g["f64_x"], torch)
+    w = np.random.default_rng(7).standard_normal(rows)
+    dw = dev(w, torch)
+    ws = cmi.blas_workspace()
+    res = torch.zeros(1, dtype=torch.float64, device="cuda")
+    for name, _, cfg in csr_variants(cmi, small=True) + [("table", True, None)]:
+        y_plain = torch.full((rows,), 3.0, dtype=torch.float64, device="cuda")
+        y_fused = torch.full((rows,), -5.0, dtype=torch.float64, device="cuda")
+        cmi.spmv_csr(rows, cols, Ap, Aj, Ax, x, y_plain, cfg=cfg)
+        res.fill_(float("nan"))
+        cmi.spmv_csr_dot(rows, cols, Ap, Aj, Ax, x, y_fused, dw, res, ws, cfg=cfg)
+        assert torch.equal(y_plain, y_fused), name
+        yh = host(y_fused)
+        assert abs(float(res) - float(np.dot(yh, w))) <= 1e-12 * float(np.abs(yh * w).sum()), name
+    # twice the same call: the same bits (fixed reduction tree, no atomics)
+    cmi.spmv_csr_dot(rows, cols, Ap, Aj, Ax, x, y_fused, dw, res, ws)
+    first = float(res)
+    cmi.spmv_csr_dot(rows, cols, Ap, Aj, Ax, x, y_fused, dw, res, ws)
+    assert float(res) == first
+
+
+@pytest.mark.parametrize("case", ["folded", "over_capacity", "w_is_x"])
+def test_spmv_csr_dot_partial_list_lengths(cmi, torch_cuda, case):
+    """Long per-tile partial lists take the middle fold stage (> 2048 tiles); more tiles than the
+    workspace holds (> 65536) fall back to SpMV + dot; w == x is the CG call."""
+    torch = torch_cuda
+    m = 700
+    A = cmi.poisson5pt(m, m, "csr")
+    n = A.num_rows
+    x = cmi.fill_x(n).cuda()
+    w = x if case == "w_is_x" else torch.from_numpy(np.random.default_rng(3).standard_normal(n)).cuda()
+    cfg = {"folded": cmi.Config(kernel=cmi.CSR_STREAM, block_size=256, rows_per_block=64, nontemporal=2),      # 7657 tiles
+           "over_capacity": cmi.Config(kernel=cmi.CSR_STREAM, block_size=64, rows_per_block=4),                # 122500 tiles
+           "w_is_x": None}[case]
+    ws = cmi.blas_workspace()
+    res = torch.zeros(1, dtype=torch.float64, device="cuda")
+    y0, y1 = torch.empty(n, dtype=torch.float64, device="cuda"), torch.empty(n, dtype=torch.float64, device="cuda")
+    cmi.spmv_csr(n, n, A.row_offsets, A.column_indices, A.values, x, y0, cfg=cfg)
+    cmi.spmv_csr_dot(n, n, A.row_offsets, A.column_indices, A.values, x, y1, w, res, ws, cfg=cfg)
+    assert torch.equal(y0, y1)
+    yh, wh = host(y1), host(w)
+    assert abs(float(res) - float(np.dot(yh, wh))) <= 1e-12 * float(np.abs(yh * wh).sum())
+
+
+def test_spmv_csr_dot_degenerate(cmi, torch_cuda):
+    torch = torch_cuda
+    ws = cmi.blas_workspace()
+    res = torch.full((1,), 9.0, dtype=torch.float64, device="cuda")
+    e_i, e_d = torch.zeros(0, dtype=torch.int32, device="cuda"), torch.zeros(0, dtype=torch.float64, device="cuda")
+    cmi.spmv_csr_dot(0, 0, torch.zeros(1, dtype=torch.int32, device="cuda"), e_i, e_d, e_d, e_d, e_d, res, ws)
+    assert float(res) == 0.0                                     # empty matrix: <y, w> = 0 is still written
+    Ap = torch.zeros(6, dtype=torch.int32, device="cuda")         # 5 empty rows
+    y = torch.full((5,), 2.0, dtype=torch.float64, device="cuda")
+    w = torch.ones(5, dtype=torch.float64, device="cuda")
+    res.fill_(9.0)
+    cmi.spmv_csr_dot(5, 3, Ap, e_i, e_d, torch.ones(3, dtype=torch.float64, device="cuda"), y, w, res, ws)
+    assert float(res) == 0.0 and host(y).tolist() == [0.0] * 5
+    with pytest.raises(Exception):
+        cmi.spmv_csr_dot(5, 3, Ap, e_i, e_d, torch.ones(3, dtype=torch.float64, device="cuda"), y, w[:4], res, ws)
+
+
+def test_cg_update_long_partial_list(cmi, torch_cuda):
+    """cmi_cg_update_f64 on 3M+1 elements leaves > 2048 partials: the folded reduction tree."""
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    n = 3_000_001
+    p, y, x, r = (rng.standard_normal(n) for _ in range(4))
+    dp, dy, dx, dr = (dev(a, torch) for a in (p, y, x, r))
+    rz = torch.tensor([3.0], dtype=torch.float64, device="cuda")
+    yp = torch.tensor([-1.5], dtype=torch.float64, device="cuda")
+    rr = torch.zeros(1, dtype=torch.float64, device="cuda")
+    cmi.cg_update(rz, yp, dp, dy, dx, dr, rr, cmi.blas_workspace())
+    alpha = 3.0 / -1.5
+    r_new = (-alpha) * y + r
+    assert np.array_equal(host(dx), alpha * p + x)
+    assert np.array_equal(host(dr), r_new)
+    assert abs(float(rr) - float(np.dot(r_new, r_new))) <= 1e-12 * float(np.dot(r_new, r_new))
+
+
+# ------------------------------------------------------------------------------------------------
 # BLAS-1 used by cg
 # ------------------------------------------------------------------------------------------------
 def test_blas1(cmi, torch_cuda):
