@@ -4,7 +4,7 @@ happens in Python and nothing falls back to the CPU."""
 import ctypes
 import os
 import subprocess
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "lib", "libcusp_mi355x.so")
@@ -115,7 +115,7 @@ def _declare(L):
         getattr(L, f"cmi_blas_fill_{suf}").argtypes = [i64, sc, vp, vp]
         getattr(L, f"cmi_blas_dot_{suf}").argtypes = [i64, vp, vp, vp, vp, vp]
         getattr(L, f"cmi_blas_nrm2_{suf}").argtypes = [i64, vp, vp, vp, vp]
-    L.cmi_cg_update_f64.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.cmi_cg_update_f64.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.cmi_cg_direction_f64.argtypes = [i64, vp, vp, vp, vp, vp]
 
 
@@ -400,10 +400,56 @@ def blas_nrm2(x, result, workspace, stream=None):
     check(getattr(lib(), "cmi_blas_nrm2_" + _suffix(x))(x.numel(), _ptr(x), _ptr(result), _ptr(workspace), _stream(stream)))
 
 
-def cg_update(rz, yp, p, y, x, r, rr_out, workspace, stream=None):
-    """alpha = rz/yp (device scalars); x += alpha p; r -= alpha y; rr_out = <r, r> -- one pass."""
+def cg_update(rz, yp, p, y, x, r, rr_out, workspace, stream=None, mirror=None):
+    """alpha = rz/yp (device scalars); x += alpha p; r -= alpha y; rr_out = <r, r> -- one pass.
+    mirror: a HostScalar that also receives <r, r> (no copy); its event is recorded behind the call."""
     check(lib().cmi_cg_update_f64(x.numel(), _ptr(rz), _ptr(yp), _ptr(p), _ptr(y), _ptr(x), _ptr(r), _ptr(rr_out),
-                                  _ptr(workspace), _stream(stream)))
+                                  mirror.ptr if mirror is not None else None, _ptr(workspace), _stream(stream)))
+    if mirror is not None:
+        mirror.record(stream)
+
+
+class HostScalar:
+    """8 bytes of page-locked, device-writable host memory (cmi_malloc_host) + the event that says a
+    device value has landed in them: the CG convergence read without a blocking copy."""
+
+    def __init__(self):
+        L = lib()
+        p, e = c_void_p(), c_void_p()
+        check(L.cmi_malloc_host(byref(p), 8))
+        self.ptr = p.value
+        try:
+            check(L.cmi_event_create(byref(e)))
+        except Exception:
+            L.cmi_free_host(self.ptr)
+            self.ptr = None
+            raise
+        self.event = e.value
+
+    def fetch(self, t, stream=None):
+        """Queue device scalar -> host on the stream; returns at once."""
+        check(lib().cmi_memcpy_d2h_async(self.ptr, _ptr(t), 8, _stream(stream)))
+        self.record(stream)
+
+    def record(self, stream=None):
+        check(lib().cmi_event_record(self.event, _stream(stream)))
+
+    def wait(self):
+        check(lib().cmi_event_synchronize(self.event))
+        return ctypes.c_double.from_address(self.ptr).value
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            L = lib()
+            L.cmi_event_destroy(self.event)
+            L.cmi_free_host(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def cg_direction(rr_new, rr_old, r, p, stream=None):

@@ -111,48 +111,77 @@ dot_partial_kernel(int64_t n, const T *__restrict__ x, const T *__restrict__ y, 
     }
     const double s = block_sum(acc, slots);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ticket_of(partial) = 0;
+}
+
+// Long partial lists (one-shot fused kernels leave up to 65536 of them) are folded by several
+// workgroups -- workgroup g folds partial[g*kFoldChunk, (g+1)*kFoldChunk) into folded[g] -- and the
+// LAST workgroup to finish (a ticket counter) folds `folded` in index order and writes the scalar:
+// one launch, and still a fixed summation tree whichever workgroup happens to be last.  The ticket
+// lives in the workspace behind `folded`; the last workgroup leaves it at 0 and every stage-1 kernel
+// zeroes it as well (reset_ticket), so an uninitialised workspace is fine.
+constexpr int kFoldDirect = 2048; // up to here one workgroup folds the list directly
+
+template <typename T>
+__global__ void __launch_bounds__(kBlasBlock)
+dot_fold_final_kernel(int npartial, double *__restrict__ workspace, T *__restrict__ result, double *__restrict__ mirror, int take_sqrt)
+{
+    __shared__ double slots[kBlasBlock / kWave];
+    __shared__ int is_last;
+    const double *partial = workspace;
+    double *folded = workspace + kPartialCapacity;
+    const int lo = blockIdx.x * kFoldChunk;
+    const int hi = lo + kFoldChunk < npartial ? lo + kFoldChunk : npartial;
+    double acc = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += partial[i];
+    double s = block_sum(acc, slots);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(folded + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const unsigned int t = atomicAdd(ticket_of(workspace), 1u);
+        is_last = (t == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    acc = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) acc += __hip_atomic_load(folded + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads(); // slots are reused
+    s = block_sum(acc, slots);
+    if (threadIdx.x == 0) {
+        const double v = take_sqrt ? sqrt(s) : s;
+        *result = (T)v;
+        if (mirror) *mirror = v;
+        *ticket_of(workspace) = 0;
+    }
 }
 
 template <typename T>
 __global__ void __launch_bounds__(kBlasBlock)
-dot_final_kernel(int npartial, const double *__restrict__ partial, T *__restrict__ result, int take_sqrt)
+dot_final_mirror_kernel(int npartial, const double *__restrict__ partial, T *__restrict__ result, double *__restrict__ mirror, int take_sqrt)
 {
     __shared__ double slots[kBlasBlock / kWave];
     double acc = 0.0;
     for (int i = threadIdx.x; i < npartial; i += blockDim.x) acc += partial[i];
     const double s = block_sum(acc, slots);
-    if (threadIdx.x == 0) *result = (T)(take_sqrt ? sqrt(s) : s);
+    if (threadIdx.x == 0) {
+        const double v = take_sqrt ? sqrt(s) : s;
+        *result = (T)v;
+        if (mirror) *mirror = v;
+    }
 }
 
-// middle stage for long partial lists (one-shot fused kernels leave up to 65536 of them): workgroup g
-// folds partial[g*kFoldChunk, (g+1)*kFoldChunk) into folded[g]; still a fixed tree
-constexpr int kFoldChunk = 1024;
-constexpr int kFoldDirect = 2048; // up to here one workgroup folds the list directly
-__global__ void __launch_bounds__(kBlasBlock)
-dot_fold_kernel(int npartial, const double *__restrict__ partial, double *__restrict__ folded)
-{
-    __shared__ double slots[kBlasBlock / kWave];
-    const int lo = blockIdx.x * kFoldChunk;
-    const int hi = lo + kFoldChunk < npartial ? lo + kFoldChunk : npartial;
-    double acc = 0.0;
-    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += partial[i];
-    const double s = block_sum(acc, slots);
-    if (threadIdx.x == 0) folded[blockIdx.x] = s;
-}
-
-// workspace layout: [0, kFusedMaxGrid) stage-1 partials, [kFusedMaxGrid, +kFusedMaxGrid/kFoldChunk) folded
+// workspace layout (doubles): [0, kPartialCapacity) stage-1 partials | kFoldedMax folded | ticket
+// `mirror`: optional second destination (page-locked host memory the device can write)
 template <typename T>
-static void reduce_partials(int npartial, double *workspace, T *result, int take_sqrt, hipStream_t s)
+static void reduce_partials(int npartial, double *workspace, T *result, int take_sqrt, hipStream_t s, double *mirror = nullptr)
 {
-    const double *src = workspace;
     if (npartial > kFoldDirect) {
         const int groups = (npartial + kFoldChunk - 1) / kFoldChunk;
-        double *folded = workspace + kFusedMaxGrid;
-        hipLaunchKernelGGL(dot_fold_kernel, dim3(groups), dim3(kBlasBlock), 0, s, npartial, src, folded);
-        src = folded;
-        npartial = groups;
+        hipLaunchKernelGGL((dot_fold_final_kernel<T>), dim3(groups), dim3(kBlasBlock), 0, s, npartial, workspace, result, mirror, take_sqrt);
+    } else {
+        hipLaunchKernelGGL((dot_final_mirror_kernel<T>), dim3(1), dim3(kBlasBlock), 0, s, npartial, (const double *)workspace, result, mirror, take_sqrt);
     }
-    hipLaunchKernelGGL((dot_final_kernel<T>), dim3(1), dim3(kBlasBlock), 0, s, npartial, src, result, take_sqrt);
 }
 
 int reduce_partials_f64(int npartial, double *workspace, double *result, hipStream_t s)
@@ -206,6 +235,7 @@ cg_update_kernel(int64_t n, const double *__restrict__ rz, const double *__restr
     }
     const double s = block_sum(acc, slots);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ticket_of(partial) = 0;
 }
 
 // p <- r + beta p with beta = rr_new / rr_old read from device memory (cg.inl:100-103, z == r)
@@ -237,7 +267,7 @@ static bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 1
 
 using namespace cmi;
 
-CMI_API size_t cmi_blas_workspace_bytes(void) { return (size_t)(kFusedMaxGrid + kFusedMaxGrid / kFoldChunk) * sizeof(double); }
+CMI_API size_t cmi_blas_workspace_bytes(void) { return (size_t)(kPartialCapacity + kFoldedMax + 1) * sizeof(double); }
 
 namespace {
 
@@ -309,7 +339,7 @@ static int fused_grid(int64_t n)
 }
 
 CMI_API int cmi_cg_update_f64(int64_t n, const double *rz_dev, const double *yp_dev, const double *p, const double *y,
-                              double *x, double *r, double *rr_dev, void *workspace, void *stream)
+                              double *x, double *r, double *rr_dev, double *rr_host_mirror, void *workspace, void *stream)
 {
     if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_update: negative n");
     if (!rz_dev || !yp_dev || !rr_dev || !workspace) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_update: null scalar or workspace");
@@ -317,7 +347,7 @@ CMI_API int cmi_cg_update_f64(int64_t n, const double *rz_dev, const double *yp_
     const int grid = fused_grid(n);
     const int vec = aligned16(p) && aligned16(y) && aligned16(x) && aligned16(r);
     hipLaunchKernelGGL(cg_update_kernel, dim3(grid), dim3(kBlasBlock), 0, as_stream(stream), n, rz_dev, yp_dev, p, y, x, r, (double *)workspace, vec);
-    reduce_partials<double>(grid, (double *)workspace, rr_dev, 0, as_stream(stream));
+    reduce_partials<double>(grid, (double *)workspace, rr_dev, 0, as_stream(stream), rr_host_mirror);
     CMI_LAUNCH_CHECK("cg_update");
     return CMI_SUCCESS;
 }

@@ -56,7 +56,15 @@ void select_config(int format, int dtype, int64_t num_rows, int64_t num_cols, in
 // Deterministic fold of `npartial` (<= kPartialCapacity) doubles at the start of a
 // cmi_blas_workspace_bytes() buffer into *result (blas1.hip; fixed tree, no atomics).
 constexpr int kPartialCapacity = 1 << 16;
+constexpr int kFoldChunk = 1024;
+constexpr int kFoldedMax = kPartialCapacity / kFoldChunk;
 int reduce_partials_f64(int npartial, double *workspace, double *result, hipStream_t s);
+// workspace layout (doubles): [0, kPartialCapacity) partials | kFoldedMax folded | the fold's ticket counter.
+// Every kernel that leaves partials also zeroes the ticket, so the workspace needs no initialisation.
+__device__ __forceinline__ unsigned int *ticket_of(double *workspace)
+{
+    return reinterpret_cast<unsigned int *>(workspace + kPartialCapacity + kFoldedMax);
+}
 
 // XCD-aware tile index.  Workgroups b and b+8 share an XCD (observed round-robin placement; a
 // different placement changes speed only, never results).  mode 0: tile = b.  mode 1: every XCD walks

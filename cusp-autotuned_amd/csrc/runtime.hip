@@ -84,7 +84,7 @@ CMI_API int cmi_malloc_host(void **ptr, size_t bytes)
     if (!ptr) return fail(CMI_ERROR_INVALID_VALUE, "cmi_malloc_host: null out pointer");
     *ptr = nullptr;
     if (bytes == 0) return CMI_SUCCESS;
-    CMI_HIP(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    CMI_HIP(hipHostMalloc(ptr, bytes, hipHostMallocMapped | hipHostMallocCoherent)); // device-writable, fine-grained
     return CMI_SUCCESS;
 }
 

@@ -142,7 +142,10 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
                 st<(POL & kPolStoreNT) != 0>(y + r0 + tid, s);
                 if constexpr (DOT) d = (double)s * (double)wv;
             }
-            if constexpr (DOT) tile_dot_store(d, dot_slots, dot_partial + tile);
+            if constexpr (DOT) {
+                tile_dot_store(d, dot_slots, dot_partial + tile);
+                if (tile == 0 && tid == 0) *ticket_of(dot_partial) = 0;
+            }
             return;
         }
     }
@@ -240,7 +243,10 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
             if constexpr (DOT) d += (double)acc[q] * (double)w[r0 + r];
         }
     }
-    if constexpr (DOT) tile_dot_store(d, dot_slots, dot_partial + tile);
+    if constexpr (DOT) {
+        tile_dot_store(d, dot_slots, dot_partial + tile);
+        if (tile == 0 && tid == 0) *ticket_of(dot_partial) = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

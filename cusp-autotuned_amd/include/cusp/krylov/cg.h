@@ -30,8 +30,8 @@ namespace detail {
 //     cmi_cg_update_f64    (x, r, <r,r> in one pass)
 //     cmi_cg_direction_f64 (p <- r + beta p)
 // i.e. 3 passes and ONE host read (the convergence check) instead of cg.inl's 7 passes and 3 host syncs.
-// The host read is an asynchronous copy into page-locked memory; the host waits for it only AFTER it
-// has queued the next iteration's SpMV (which reads p and writes the scratch y -- no solver state -- so
+// The host read needs no copy: cmi_cg_update's reduction also writes <r,r> into page-locked host
+// memory, and the host waits for the event behind it only AFTER it has queued the next iteration's SpMV (which reads p and writes the scratch y -- no solver state -- so
 // running it speculatively is harmless if the monitor then stops), so the device never idles on the
 // round trip.  Per-element arithmetic unchanged; the residual history agrees with the plain path to
 // rounding.
@@ -55,8 +55,9 @@ struct pinned_scalar { // 8 page-locked bytes + the event that says they have la
     void fetch(const double *dev) // queue the copy; returns at once
     {
         cusp::detail::check(cmi_memcpy_d2h_async(host, dev, sizeof(double), nullptr));
-        cusp::detail::check(cmi_event_record(event, nullptr));
+        record();
     }
+    void record() { cusp::detail::check(cmi_event_record(event, nullptr)); } // behind a kernel that wrote *host itself
     double wait() { cusp::detail::check(cmi_event_synchronize(event)); return *host; }
 };
 
@@ -101,8 +102,8 @@ void cg_fused_device(const LinearOperator &A, VectorType1 &x, const VectorType2 
     for (;;) {
         multiply_dot(A, p, y, yp, w.ws, 0);                                               // the hot path (speculative, see above)
         if (monitor.finished_norm(std::sqrt(rr_host.wait()))) break;                      // the one host read
-        cusp::detail::check(cmi_cg_update_f64(N, rr[cur], yp, p.data(), y.data(), x.data(), r.data(), rr[cur ^ 1], w.ws, nullptr));
-        rr_host.fetch(rr[cur ^ 1]);
+        cusp::detail::check(cmi_cg_update_f64(N, rr[cur], yp, p.data(), y.data(), x.data(), r.data(), rr[cur ^ 1], rr_host.host, w.ws, nullptr));
+        rr_host.record();
         cusp::detail::check(cmi_cg_direction_f64(N, rr[cur ^ 1], rr[cur], r.data(), p.data(), nullptr));
         cur ^= 1;
         ++monitor;

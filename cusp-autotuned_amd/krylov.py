@@ -124,31 +124,13 @@ def cg(A, x, b, monitor=None, iteration_limit=500, relative_tolerance=1e-5, abso
     return monitor
 
 
-class _HostScalar:
-    """8 page-locked bytes + the event that says the device value has landed (the convergence read)."""
-
-    def __init__(self, device):
-        import torch
-        self.torch = torch
-        self.cuda = device.type == "cuda"
-        self.host = torch.zeros(1, dtype=torch.float64)
-        if self.cuda:
-            self.host = self.host.pin_memory()
-            self.event = torch.cuda.Event()
-        self.src = None
+class _SyncScalar:
+    """Host transport stand-in for binding.HostScalar when the vectors are not in HBM (CPU tests)."""
 
     def fetch(self, t):
-        """Queue the copy on the current stream; returns at once."""
-        if self.cuda:
-            self.host.copy_(t, non_blocking=True)
-            self.event.record()
-        else:
-            self.src = t
+        self.src = t
 
     def wait(self):
-        if self.cuda:
-            self.event.synchronize()
-            return float(self.host[0])
         return float(self.src.item())
 
 
@@ -157,8 +139,9 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
 
     Per iteration: y <- A p together with <y, p> (one launch for CSR: cmi_spmv_csr_dot_f64), then
     cmi_cg_update (x, r, <r,r>), then cmi_cg_direction.  The single host read (the monitor's residual
-    norm) is an asynchronous copy into page-locked memory that the host waits for only AFTER queueing
-    the next iteration's SpMV: that SpMV reads p and writes the scratch y -- no solver state -- so it
+    norm) lands in page-locked memory (written by the reduction itself on one GPU, an asynchronous
+    copy behind the all-reduce when sharded) that the host waits for only AFTER queueing the next
+    iteration's SpMV: that SpMV reads p and writes the scratch y -- no solver state -- so it
     is harmless if the monitor then stops, and the device never idles on the host round trip."""
     import torch
     from . import binding as B
@@ -167,7 +150,8 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
     dev = x.device
     rr = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(2)]  # <r,r> ping-pong
     yp = torch.zeros(1, dtype=torch.float64, device=dev)
-    rr_host = _HostScalar(dev)
+    rr_host = B.HostScalar() if dev.type == "cuda" else _SyncScalar()
+    mirror = rr_host if world == 1 and dev.type == "cuda" else None  # sharded: <r,r> is all-reduced first
 
     def reduce_(t):
         if world > 1:
@@ -195,9 +179,10 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
         spmv_dot()                               # THE HOT PATH (queued before the host waits)
         if monitor.finished(math.sqrt(rr_host.wait())):             # the one host read per iteration
             break
-        B.cg_update(rr[cur], yp, p, y, x, r, rr[cur ^ 1], ops.ws)   # x, r, <r,r> in one pass
-        reduce_(rr[cur ^ 1])
-        rr_host.fetch(rr[cur ^ 1])
+        B.cg_update(rr[cur], yp, p, y, x, r, rr[cur ^ 1], ops.ws, mirror=mirror)   # x, r, <r,r> in one pass
+        if mirror is None:
+            reduce_(rr[cur ^ 1])
+            rr_host.fetch(rr[cur ^ 1])
         B.cg_direction(rr[cur ^ 1], rr[cur], r, p)                  # p <- r + beta p
         cur ^= 1
         monitor.increment()

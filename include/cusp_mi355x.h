@@ -295,9 +295,12 @@ int cmi_blas_nrm2_f32(int64_t n, const float *x, float *result_dev, void *worksp
  * cusp/krylov/detail/cg.inl:83-103 (seven vector passes, three host syncs per iteration) by
  *   cmi_cg_update:    alpha = *rz / *yp;  x += alpha p;  r -= alpha y;  *rr = <r, r>   (one pass)
  *   cmi_cg_direction: beta = *rr_new / *rr_old;  p = r + beta p                         (one pass)
- * The element arithmetic is the reference's (one multiply and one add per update, unfused). */
+ * The element arithmetic is the reference's (one multiply and one add per update, unfused).
+ * rr_host_mirror (may be NULL): cmi_malloc_host memory that also receives <r, r> -- written by the
+ * reduction's last workgroup, so the convergence check needs no copy; read it after an event
+ * recorded behind this call has been synchronised. */
 int cmi_cg_update_f64(int64_t n, const double *rz_dev, const double *yp_dev, const double *p, const double *y,
-                      double *x, double *r, double *rr_dev, void *workspace, void *stream);
+                      double *x, double *r, double *rr_dev, double *rr_host_mirror, void *workspace, void *stream);
 int cmi_cg_direction_f64(int64_t n, const double *rr_new_dev, const double *rr_old_dev, const double *r,
                          double *p, void *stream);
 

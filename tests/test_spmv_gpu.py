@@ -676,7 +676,16 @@ def test_cg_update_long_partial_list(cmi, torch_cuda):
     rz = torch.tensor([3.0], dtype=torch.float64, device="cuda")
     yp = torch.tensor([-1.5], dtype=torch.float64, device="cuda")
     rr = torch.zeros(1, dtype=torch.float64, device="cuda")
-    cmi.cg_update(rz, yp, dp, dy, dx, dr, rr, cmi.blas_workspace())
+    ws = cmi.blas_workspace()
+    ws.fill_(float("nan"))  # nothing in the workspace (partials, folded list, ticket) may need initialising
+    mirror = cmi.HostScalar()
+    cmi.cg_update(rz, yp, dp, dy, dx, dr, rr, ws, mirror=mirror)
+    assert mirror.wait() == float(rr)  # the reduction's second destination: page-locked host memory
+    first = float(rr)
+    dx2, dr2 = dev(x, torch), dev(r, torch)
+    cmi.cg_update(rz, yp, dp, dy, dx2, dr2, rr, ws)  # ticket left at 0 by the previous fold; same tree, same bits
+    assert float(rr) == first and mirror.wait() == first
+    mirror.close()
     alpha = 3.0 / -1.5
     r_new = (-alpha) * y + r
     assert np.array_equal(host(dx), alpha * p + x)
