@@ -12,8 +12,11 @@ N = 1: BASELINE.json configs[1], poisson5pt 3162x3162 (9 998 244 rows, 49 978 57
        int32/f64, kernel + launch shape from the persisted tuning table.
 N > 1: weak scaling -- every rank owns a 3162x3162-point row block of the global
        poisson5pt(3162, 3162*N) (N=8: 8.0e7 rows; BASELINE.json configs[4] shape), global column
-       indices; a step = exchange of x over RCCL/xGMI (halo or all-gather, see
-       cusp-autotuned_amd/distributed.py) + the local SpMV.  value = 2*global_nnz / max-over-ranks time.
+       indices; a step = exchange of x over xGMI + the local SpMV.  Default exchange ("auto"): the
+       one-sided halo pull -- each rank copies the 2*3162 boundary values its rows reference straight
+       out of its neighbours' mapped buffers with one small kernel on its own stream ("peer"); if the
+       buffers cannot be mapped, the two-sided RCCL halo exchange ("halo"); "allgather" on request
+       (cusp-autotuned_amd/distributed.py).  value = 2*global_nnz / max-over-ranks time.
 
 Timing protocol (reference performance/spmv/benchmark.h:84-120): W untimed warm-up steps, then
 exactly K steps between a barrier + device synchronise on both sides; MAX over ranks.
@@ -43,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--exchange", default="auto", choices=["auto", "halo", "allgather"])
+    ap.add_argument("--exchange", default="auto", choices=["auto", "peer", "halo", "allgather"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--format", default="csr", choices=["csr", "ell", "dia", "coo", "hyb"],
@@ -160,7 +163,7 @@ def main():
         sh.x_local.copy_(torch.from_numpy(x_host).to(dev))
         step = lambda: sh.multiply(y)  # noqa: E731
         p = sh.vec.plan
-        exchange_info = {"mode": p.mode, "values_received_per_rank": p.recv_values if p.mode == "halo" else p.allgather_values,
+        exchange_info = {"mode": p.mode, "values_received_per_rank": p.allgather_values if p.mode == "allgather" else p.recv_values,
                          "allgather_values": p.allgather_values}
 
     def barrier():
@@ -253,6 +256,7 @@ def main():
             line["cpu_baseline_omp"] = omp
         print(json.dumps(line), flush=True)
     if dist is not None:
+        sh.vec.close()  # barrier + unmap the peers' buffers before anyone frees them
         dist.barrier()
         dist.destroy_process_group()
 

@@ -85,6 +85,10 @@ def _declare(L):
     L.cmi_malloc_host.argtypes = [POINTER(c_void_p), c_size_t]
     L.cmi_free_host.argtypes = [vp]
     L.cmi_memcpy_d2h_async.argtypes = [vp, vp, c_size_t, vp]
+    L.cmi_ipc_get_handle.argtypes = [vp, vp]
+    L.cmi_ipc_open_handle.argtypes = [vp, POINTER(c_void_p)]
+    L.cmi_ipc_close_handle.argtypes = [vp]
+    L.cmi_copy_ranges.argtypes = [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), vp]
     L.cmi_spmv_csr_dot_f64.argtypes = [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, cfgp, vp]
     L.cmi_tuning_load.argtypes = [c_char_p]
     L.cmi_tuning_save.argtypes = [c_char_p]
@@ -450,6 +454,88 @@ class HostScalar:
             self.close()
         except Exception:
             pass
+
+
+IPC_HANDLE_BYTES = 64
+MAX_COPY_RANGES = 16
+
+
+class DeviceBuffer:
+    """An HBM allocation of its own (cmi_malloc, not a slice of torch's caching allocator), so that
+    its IPC handle maps exactly this buffer in a peer process.  `tensor()` views it as a torch tensor."""
+
+    def __init__(self, nbytes, device=None):
+        import torch
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.nbytes = int(nbytes)
+        p = c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().cmi_malloc(byref(p), max(self.nbytes, 8)))
+            self.ptr = p.value
+            check(lib().cmi_memset(self.ptr, 0, max(self.nbytes, 8), _stream(None)))
+
+    def tensor(self, dtype):
+        import torch
+        item = torch.empty(0, dtype=dtype).element_size()
+        typestr = {torch.float64: "<f8", torch.float32: "<f4", torch.int32: "<i4", torch.int64: "<i8", torch.uint8: "|u1"}[dtype]
+        holder = _ArrayInterface(self, (self.nbytes // item,), typestr)
+        t = torch.as_tensor(holder, device=self.device)
+        if t.data_ptr() != self.ptr:
+            raise CmiError(2, "DeviceBuffer.tensor: torch copied the buffer instead of viewing it")
+        t._cmi_buffer = self  # the view keeps the allocation alive
+        return t
+
+    def ipc_handle(self):
+        h = ctypes.create_string_buffer(IPC_HANDLE_BYTES)
+        check(lib().cmi_ipc_get_handle(self.ptr, h))
+        return h.raw
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            lib().cmi_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _ArrayInterface:
+    def __init__(self, owner, shape, typestr):
+        self.owner = owner
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (owner.ptr, False), "version": 2,
+                                         "strides": None}
+
+
+def ipc_open(handle):
+    """Map a peer process's DeviceBuffer; returns the device address valid in THIS process."""
+    p = c_void_p()
+    check(lib().cmi_ipc_open_handle(ctypes.create_string_buffer(handle, IPC_HANDLE_BYTES), byref(p)))
+    return p.value
+
+
+def ipc_close(ptr):
+    check(lib().cmi_ipc_close_handle(ptr))
+
+
+class CopyRanges:
+    """A fixed list of (src address, dst address, bytes) copied by ONE launch (cmi_copy_ranges)."""
+
+    def __init__(self, ranges):
+        ranges = [r for r in ranges if r[2] > 0]
+        if len(ranges) > MAX_COPY_RANGES:
+            raise ValueError(f"at most {MAX_COPY_RANGES} ranges per launch")
+        n = len(ranges)
+        self.n = n
+        self.src = (c_void_p * max(n, 1))(*[r[0] for r in ranges])
+        self.dst = (c_void_p * max(n, 1))(*[r[1] for r in ranges])
+        self.bytes = (c_int64 * max(n, 1))(*[r[2] for r in ranges])
+
+    def launch(self, stream=None):
+        if self.n:
+            check(lib().cmi_copy_ranges(self.n, self.src, self.dst, self.bytes, _stream(stream)))
 
 
 def cg_direction(rr_new, rr_old, r, p, stream=None):

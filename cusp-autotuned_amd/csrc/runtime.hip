@@ -118,6 +118,95 @@ CMI_API int cmi_memcpy_d2h_async(void *dst, const void *src, size_t bytes, void 
     return CMI_SUCCESS;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Peer mapping of an HBM allocation of another process (one process per GPU) + a multi-range copy:
+// what the one-sided halo exchange of the row-block sharded SpMV is made of.  xGMI is a load/store
+// fabric: a rank maps its neighbours' x buffers once and then PULLS the few boundary values it
+// needs with one small kernel on its own stream -- no collective, no second stream, no proxy.
+// ---------------------------------------------------------------------------------------------
+static_assert(sizeof(hipIpcMemHandle_t) <= CMI_IPC_HANDLE_BYTES, "cmi_ipc handle buffer too small");
+
+CMI_API int cmi_ipc_get_handle(void *dev_ptr, void *handle_out)
+{
+    if (!dev_ptr || !handle_out) return fail(CMI_ERROR_INVALID_VALUE, "cmi_ipc_get_handle: null pointer");
+    hipIpcMemHandle_t h;
+    CMI_HIP(hipIpcGetMemHandle(&h, dev_ptr));
+    memset(handle_out, 0, CMI_IPC_HANDLE_BYTES);
+    memcpy(handle_out, &h, sizeof(h));
+    return CMI_SUCCESS;
+}
+
+CMI_API int cmi_ipc_open_handle(const void *handle, void **ptr)
+{
+    if (!handle || !ptr) return fail(CMI_ERROR_INVALID_VALUE, "cmi_ipc_open_handle: null pointer");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    *ptr = nullptr;
+    CMI_HIP(hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return CMI_SUCCESS;
+}
+
+CMI_API int cmi_ipc_close_handle(void *ptr)
+{
+    if (ptr) CMI_HIP(hipIpcCloseMemHandle(ptr));
+    return CMI_SUCCESS;
+}
+
+namespace cmi {
+struct copy_ranges_args {
+    const unsigned char *src[CMI_MAX_COPY_RANGES];
+    unsigned char *dst[CMI_MAX_COPY_RANGES];
+    long long bytes[CMI_MAX_COPY_RANGES];
+};
+
+// blockIdx.y = range; 16-byte accesses when src, dst and the length allow, bytes otherwise
+__global__ void __launch_bounds__(256) copy_ranges_kernel(copy_ranges_args a)
+{
+    const int r = blockIdx.y;
+    const unsigned char *src = a.src[r];
+    unsigned char *dst = a.dst[r];
+    const long long n = a.bytes[r];
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+        const long long nv = n / 16;
+        for (long long i = t; i < nv; i += stride) reinterpret_cast<int4v *>(dst)[i] = reinterpret_cast<const int4v *>(src)[i];
+        for (long long i = nv * 16 + t; i < n; i += stride) dst[i] = src[i];
+    } else if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)n) & 7) == 0) {
+        const long long nv = n / 8;
+        for (long long i = t; i < nv; i += stride) reinterpret_cast<long long *>(dst)[i] = reinterpret_cast<const long long *>(src)[i];
+    } else {
+        for (long long i = t; i < n; i += stride) dst[i] = src[i];
+    }
+}
+} // namespace cmi
+
+CMI_API int cmi_copy_ranges(int count, const void *const *src, void *const *dst, const int64_t *bytes, void *stream)
+{
+    if (count < 0 || count > CMI_MAX_COPY_RANGES) return fail(CMI_ERROR_INVALID_VALUE, "cmi_copy_ranges: count must be in [0, CMI_MAX_COPY_RANGES]");
+    if (count == 0) return CMI_SUCCESS;
+    if (!src || !dst || !bytes) return fail(CMI_ERROR_INVALID_VALUE, "cmi_copy_ranges: null array");
+    copy_ranges_args a;
+    int64_t longest = 0;
+    int used = 0;
+    for (int i = 0; i < count; i++) {
+        if (bytes[i] < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_copy_ranges: negative length");
+        if (bytes[i] == 0) continue;
+        if (!src[i] || !dst[i]) return fail(CMI_ERROR_INVALID_VALUE, "cmi_copy_ranges: null range");
+        a.src[used] = static_cast<const unsigned char *>(src[i]);
+        a.dst[used] = static_cast<unsigned char *>(dst[i]);
+        a.bytes[used] = bytes[i];
+        if (bytes[i] > longest) longest = bytes[i];
+        used++;
+    }
+    if (used == 0) return CMI_SUCCESS;
+    int64_t blocks = ceil_div(longest, (int64_t)256 * 16);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(copy_ranges_kernel, dim3((unsigned)blocks, (unsigned)used), dim3(256), 0, as_stream(stream), a);
+    CMI_LAUNCH_CHECK("copy_ranges");
+    return CMI_SUCCESS;
+}
+
 CMI_API int cmi_memset(void *dst, int byte_value, size_t bytes, void *stream)
 {
     if (bytes == 0) return CMI_SUCCESS;

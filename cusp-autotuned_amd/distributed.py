@@ -13,7 +13,18 @@ reference are brought into that buffer by one of two exchanges:
     send/recv straight into the x buffer.  For a banded matrix (5-pt Poisson: span = own rows +- m)
     that is 2*m values per rank instead of N.  A matrix whose rows reference every column
     degenerates to the all-gather volume.
-  * "auto" (default): halo when it moves less than half of the all-gather volume.
+  * "peer": the halo plan, ONE-SIDED.  xGMI is a load/store fabric, so each rank maps its
+    neighbours' x buffers once (IPC handles of cmi_malloc'ed buffers) and before a multiply PULLS
+    the ranges it needs with one small copy kernel on its own stream (cmi_copy_ranges): no
+    collective launch, no second stream, no proxy thread.  Measured on one MI355X with a 1-rank RCCL
+    communicator standing in for the wire (tools/shard_step_probe.py): the grouped ncclSend/ncclRecv
+    step costs ~65 us of device time around a 134 us SpMV and does not overlap with it; the pull
+    costs ~3 us.  Visibility is at kernel boundaries, so the CALLER orders the peers' producing
+    kernels before the pull: a barrier (bench.py: x is static between its barriers) or the
+    all-reduces of the algorithm (krylov.cg).  `fence()` is that barrier for anyone else.
+  * "auto" (default): halo when it moves less than half of the all-gather volume -- one-sided
+    ("peer") when the buffers are in HBM and every rank could map and verify its neighbours'
+    buffers, two-sided ("halo") otherwise.
 
 The local multiply is the single-GPU C-ABI call (cmi_spmv_*), so N ranks = N independent hot paths
 joined by exactly one exchange step.
@@ -47,11 +58,20 @@ class ShardedVectorExchange:
         self.dist, self.torch = dist, torch
         self.rank, self.world, self.group = rank, world, group
         self.num_cols = num_cols
+        self._span = (col_min, col_max)
         self.offsets = partition_rows(num_cols, world)
         self.count = self.offsets[1] - self.offsets[0] if world > 0 else 0
         self.lo, self.hi = self.offsets[rank], self.offsets[rank + 1]
-        # buffer padded to world*count so the all-gather can write equal-sized pieces
-        self.x_full = torch.zeros(max(world * self.count, 1), dtype=dtype, device=device)
+        # buffer padded to world*count so the all-gather can write equal-sized pieces; in HBM it is an
+        # allocation of its own (not a slice of torch's caching allocator) so that peers can map it
+        numel = max(world * self.count, 1)
+        self._buffer = None
+        if torch.device(device).type == "cuda":
+            from . import binding as B
+            self._buffer = B.DeviceBuffer(numel * torch.empty(0, dtype=dtype).element_size(), device)
+            self.x_full = self._buffer.tensor(dtype)
+        else:
+            self.x_full = torch.zeros(numel, dtype=dtype, device=device)
         self.x_local = self.x_full[self.lo:self.hi]  # this rank's slice lives inside the buffer
 
         # every rank learns every rank's column span (setup-time, tiny)
@@ -72,15 +92,24 @@ class ShardedVectorExchange:
         send = [overlap(spans[p], rank) if p != rank else (0, 0) for p in range(world)]
         recv_values = sum(h - l for l, h in recv)
         allgather_values = (world - 1) * self.count
+        import os
+        try_peer = mode == "peer"
         if mode == "auto":
             # the same decision on every rank: compare the WORST rank's halo volume
             worst = torch.tensor([recv_values], dtype=torch.int64, device=device)
             if world > 1:
                 dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=group)
             mode = "halo" if 2 * int(worst.item()) < allgather_values else "allgather"
-        if mode not in ("halo", "allgather"):
+            try_peer = mode == "halo" and os.environ.get("CMI_EXCHANGE_PEER", "1") != "0"
+        if mode not in ("halo", "allgather", "peer"):
             raise ValueError(f"unknown exchange mode {mode!r}")
-        self.plan = ExchangePlan(mode, recv, send, self.count, recv_values, allgather_values)
+        self.plan = ExchangePlan("halo" if mode == "peer" else mode, recv, send, self.count, recv_values, allgather_values)
+        self._pulls, self._peer_ptrs = [], {}
+        if try_peer and world > 1 and (self._buffer is not None or mode == "peer"):
+            if self._setup_peer():
+                self.plan.mode = "peer"
+            elif mode == "peer":
+                raise RuntimeError("exchange mode 'peer' requested but a rank could not map or verify its neighbours' buffers")
         self._gather_in = None
         self._ops = None
         # RCCL orders its transfers after the work already queued on the compute stream.  A host
@@ -90,6 +119,93 @@ class ShardedVectorExchange:
         self._host_transport = world > 1 and dist.get_backend(group) != "nccl" and self.x_full.is_cuda
         if mode == "allgather" and world > 1:
             self._gather_in = torch.zeros(self.count, dtype=dtype, device=device)
+
+    def _setup_peer(self):
+        """Map the neighbours' buffers and verify one pull end to end; True only if EVERY rank succeeded
+        (collective: all ranks call it).  Any failure leaves the two-sided plan in force."""
+        dist, torch = self.dist, self.torch
+        from . import binding as B
+        ok, why = 1, ""
+        handles = [None] * self.world
+        try:
+            mine = self._buffer.ipc_handle() if self._buffer is not None else None
+        except Exception as e:  # noqa: BLE001
+            mine, ok, why = None, 0, f"ipc_get_handle: {e}"
+        dist.all_gather_object(handles, mine, group=self.group)
+        item = self.x_full.element_size()
+        ranges = []
+        if ok and all(h is not None for h in handles):
+            try:
+                for p, (l, h) in enumerate(self.plan.recv):
+                    if h > l:
+                        if p not in self._peer_ptrs:
+                            self._peer_ptrs[p] = B.ipc_open(handles[p])
+                        # every rank's buffer is indexed by GLOBAL column: the same offset on both sides
+                        ranges.append((self._peer_ptrs[p] + l * item, self._buffer.ptr + l * item, (h - l) * item))
+                self._pulls = [B.CopyRanges(ranges[i:i + B.MAX_COPY_RANGES]) for i in range(0, len(ranges), B.MAX_COPY_RANGES)]
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, f"ipc_open_handle: {e}"
+        else:
+            ok = 0
+            why = why or "a rank has no exportable buffer"
+        # end-to-end check with a per-rank signature (collective steps run on every rank, ok or not)
+        self.x_local.fill_(float(self.rank + 1))
+        self.fence()
+        if ok:
+            try:
+                for c in self._pulls:
+                    c.launch()
+                torch.cuda.current_stream(self.x_full.device).synchronize()
+                for p, (l, h) in enumerate(self.plan.recv):
+                    if h > l and not bool((self.x_full[l:h] == float(p + 1)).all()):
+                        ok, why = 0, f"pull from rank {p} returned wrong data"
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, f"pull: {e}"
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.x_full.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        self.fence()
+        self.x_full.zero_()
+        self.fence()
+        if int(flag.item()) == 1:
+            return True
+        if why:
+            import sys
+            print(f"[cusp-autotuned_amd] rank {self.rank}: one-sided exchange unavailable ({why}); using two-sided halo exchange",
+                  file=sys.stderr)
+        self._release_peers()
+        return False
+
+    def _release_peers(self):
+        self._pulls = []
+        if self._peer_ptrs:
+            from . import binding as B
+            for ptr in self._peer_ptrs.values():
+                try:
+                    B.ipc_close(ptr)
+                except Exception:  # noqa: BLE001
+                    pass
+            self._peer_ptrs = {}
+
+    def fence(self):
+        """Everything queued on this rank's stream has completed AND every rank has reached this point:
+        the ordering the one-sided pull needs between the peers' producers and itself when the caller's
+        algorithm does not already provide it."""
+        if self.x_full.is_cuda:
+            self.torch.cuda.current_stream(self.x_full.device).synchronize()
+        if self.world > 1:
+            self.dist.barrier(group=self.group)
+
+    def close(self):
+        """Unmap the peers' buffers (collective by convention: call it on every rank before the buffers die)."""
+        if self.world > 1 and self._peer_ptrs:
+            self.fence()
+        self._release_peers()
+
+    def __del__(self):
+        try:
+            self._release_peers()
+        except Exception:  # noqa: BLE001
+            pass
 
     def _build_ops(self):
         dist, plan = self.dist, self.plan
@@ -110,6 +226,10 @@ class ShardedVectorExchange:
         if self.world == 1:
             return []
         dist, plan = self.dist, self.plan
+        if plan.mode == "peer":
+            for c in self._pulls:  # one launch (16 ranges each) on the caller's stream; nothing to wait for
+                c.launch()
+            return []
         if self._host_transport:
             self.torch.cuda.current_stream(self.x_full.device).synchronize()
         if plan.mode == "allgather":
@@ -223,18 +343,38 @@ class ShardedCsr:
         B.spmv_csr(b - a, A.num_cols, A.row_offsets[a:b + 1], A.column_indices, A.values, self.x_view, y_local[a:b],
                    cfg=self._cfg)
 
-    def multiply_dot(self, y_local, result, workspace):
+    def new_exchanged_vector(self):
+        """Another full-length vector with this matrix's exchange plan and transport (collective: every
+        rank calls it).  krylov.cg keeps its residual in one so that peers can pull its boundary values."""
+        v = self.vec
+        return ShardedVectorExchange(v.num_cols, v.rank, v.world, v._span[0], v._span[1], v.x_full.dtype, v.x_full.device,
+                                     mode=v.plan.mode, group=v.group)
+
+    def halo_ranges(self):
+        """[lo, hi) of this rank's slice merged with the ranges it receives: the contiguous pieces of the
+        full-length buffers this rank reads (one piece for a banded matrix)."""
+        pieces = sorted([(self.vec.lo, self.vec.hi)] + [(l, h) for l, h in self.vec.plan.recv if h > l])
+        out = [list(pieces[0])]
+        for l, h in pieces[1:]:
+            if l <= out[-1][1]:
+                out[-1][1] = max(out[-1][1], h)
+            else:
+                out.append([l, h])
+        return [tuple(r) for r in out]
+
+    def multiply_dot(self, y_local, result, workspace, exchange=True):
         """y_local = A[lo:hi, :] * x and result[0] = <y_local, x_local> (this rank's part of <A p, p>:
         the caller all-reduces it).  One fused launch when the block is multiplied whole; the
         overlapped (interior / boundary) schedule keeps its three launches and adds a dot."""
         from . import binding as B
         A = self.A
-        if self.interior is None and not self._custom and A.values.dtype == self.torch.float64:
-            self.vec.exchange()
+        if (self.interior is None or not exchange) and not self._custom and A.values.dtype == self.torch.float64:
+            if exchange:
+                self.vec.exchange()
             B.spmv_csr_dot(A.num_rows, A.num_cols, A.row_offsets, A.column_indices, A.values, self.x_view, y_local,
                            self.vec.x_local, result, workspace)
             return y_local
-        self.multiply(y_local)
+        self.multiply(y_local, exchange=exchange)
         B.blas_dot(y_local, self.vec.x_local, result, workspace)
         return y_local
 

@@ -94,11 +94,17 @@ def cg(A, x, b, monitor=None, iteration_limit=500, relative_tolerance=1e-5, abso
     # the search direction lives in the exchange buffer when sharded: A p needs no staging copy
     p = A.x_local if sharded else torch.empty_like(y)
 
+    one_sided = sharded and A.vec.plan.mode == "peer"
+
     def spmv(v, out):  # out <- A v
         if sharded:
+            if one_sided:
+                A.vec.fence()   # the peers have finished pulling the previous contents ...
             if v.data_ptr() != A.x_local.data_ptr():
                 B.blas_copy(v, A.x_local)
-            A.multiply(out)
+            if one_sided:
+                A.vec.fence()   # ... and every slice is complete before anyone pulls (correct, not fast:
+            A.multiply(out)     #     the fused path below needs no fence inside its loop)
         else:
             multiply(A, v, out)
 
@@ -168,24 +174,54 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
             B.blas_dot(y, p, yp, ops.ws)
         reduce_(yp)
 
+    # One-sided sharding ("peer" exchange): p is exchanged ONCE.  Afterwards every rank keeps the p
+    # entries of its halo itself: p_halo <- r_halo + beta p_halo, the same arithmetic with the same
+    # all-reduced beta as the owner, so the same bits -- and r_halo is PULLED from the owner right
+    # after the all-reduce of <r,r>, which completes only when every rank's cg_update (the kernel that
+    # wrote that r) has; the owner overwrites r again only after the next all-reduce of <y,p>, which
+    # needs this rank's contribution, queued behind this pull.  The algorithm's own all-reduces are
+    # all the ordering the one-sided pulls need: no collective is added, no exchange per iteration.
+    one_sided = isinstance(A, ShardedCsr) and A.vec.plan.mode == "peer"
+    if one_sided:
+        r_ex = A.new_exchanged_vector()
+        r = r_ex.x_local
+        pieces = A.halo_ranges()
+        p_full, r_full = A.vec.x_full, r_ex.x_full
+
     spmv(x, y)                                   # y <- A x
     B.blas_axpby(1.0, b, -1.0, y, r)             # r <- b - A x
+    if one_sided:
+        A.vec.fence()                            # (setup) the peers have pulled x out of the buffer p reuses
     B.blas_copy(r, p)                            # p <- z = r
     B.blas_dot(r, r, rr[0], ops.ws)              # rz = <r, r>
     reduce_(rr[0])
+    if one_sided:
+        A.vec.exchange()                         # p halos, ordered behind every rank's copy by the all-reduce
     rr_host.fetch(rr[0])
     cur = 0
     while True:
-        spmv_dot()                               # THE HOT PATH (queued before the host waits)
+        if one_sided:
+            A.multiply_dot(y, yp, ops.ws, exchange=False)           # halos of p are already in place
+            reduce_(yp)
+        else:
+            spmv_dot()                           # THE HOT PATH (queued before the host waits)
         if monitor.finished(math.sqrt(rr_host.wait())):             # the one host read per iteration
             break
         B.cg_update(rr[cur], yp, p, y, x, r, rr[cur ^ 1], ops.ws, mirror=mirror)   # x, r, <r,r> in one pass
         if mirror is None:
             reduce_(rr[cur ^ 1])
             rr_host.fetch(rr[cur ^ 1])
-        B.cg_direction(rr[cur ^ 1], rr[cur], r, p)                  # p <- r + beta p
+        if one_sided:
+            r_ex.exchange()                                         # pull the peers' boundary r
+            for l, h in pieces:                                     # own slice + halo: p <- r + beta p
+                B.cg_direction(rr[cur ^ 1], rr[cur], r_full[l:h], p_full[l:h])
+        else:
+            B.cg_direction(rr[cur ^ 1], rr[cur], r, p)              # p <- r + beta p
         cur ^= 1
         monitor.increment()
+    if one_sided:
+        A.vec.fence()                                               # nobody is still pulling from r_ex
+        r_ex.close()
     if dev.type == "cuda":
         torch.cuda.current_stream(dev).synchronize()                # the discarded SpMV must not outlive y
     return monitor

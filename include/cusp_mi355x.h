@@ -63,6 +63,20 @@ int cmi_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int cmi_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
 int cmi_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
 int cmi_memset(void *dst, int byte_value, size_t bytes, void *stream);
+/* Peer mapping for the row-block sharded SpMV (the reference has no multi-GPU  */
+/* code).  One process per GPU: a rank exports the handle of a cmi_malloc'ed buffer (its slice of x  */
+/* inside the full-length exchange buffer), its neighbours open it once, and before each multiply a  */
+/* rank PULLS the boundary values its rows reference with ONE cmi_copy_ranges launch on its own      */
+/* stream -- loads over xGMI, no collective.  Visibility is at kernel boundaries: the caller orders   */
+/* the producing kernels of the peers before the pull (bench: barrier; CG: its all-reduces).         */
+#define CMI_IPC_HANDLE_BYTES 64
+#define CMI_MAX_COPY_RANGES 16
+int cmi_ipc_get_handle(void *dev_ptr, void *handle_out /* CMI_IPC_HANDLE_BYTES */);
+int cmi_ipc_open_handle(const void *handle, void **peer_ptr);
+int cmi_ipc_close_handle(void *peer_ptr);
+/* dst[i][0, bytes[i]) <- src[i][0, bytes[i]) for i < count <= CMI_MAX_COPY_RANGES, one launch.      */
+/* src / dst / bytes are HOST arrays of device pointers and lengths.                                  */
+int cmi_copy_ranges(int count, const void *const *src, void *const *dst, const int64_t *bytes, void *stream);
 /* Page-locked host memory and a device->host copy that is ordered on `stream` but NOT waited for  */
 /* (pair with cmi_event_record / cmi_event_synchronize).  Used by cusp::krylov::cg for its one     */
 /* host read per iteration (the monitor's residual norm, reference cusp/detail/monitor.inl:181-207) */

@@ -103,7 +103,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, m, n, iters, out_dir):
+def _worker(rank, world, port, m, n, iters, out_dir, mode):
     import sys
     sys.path.insert(0, ROOT)
     import torch
@@ -117,22 +117,27 @@ def _worker(rank, world, port, m, n, iters, out_dir):
         offs = cmi.distributed.partition_rows(N, world)
         lo, hi = offs[rank], offs[rank + 1]
         A = cmi.poisson5pt(m, n, "csr", row_begin=lo, row_end=hi)
-        sh = cmi.distributed.ShardedCsr(A, N, rank, world, mode="auto")
+        sh = cmi.distributed.ShardedCsr(A, N, rank, world, mode=mode)
         b = cmi.fill_x(hi - lo, start=lo).cuda()
         x = torch.zeros(hi - lo, dtype=torch.float64, device="cuda")
         mon = cmi.krylov.cg(sh, x, b, iteration_limit=iters, relative_tolerance=1e-12)
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), x=x.cpu().numpy(), hist=np.array(mon.residuals))
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), x=x.cpu().numpy(), hist=np.array(mon.residuals), mode=sh.vec.plan.mode)
+        sh.vec.close()
     finally:
         dist.destroy_process_group()
 
 
-def test_cg_sharded_two_ranks_matches_single(tmp_path, cmi, orc):
+@pytest.mark.parametrize("mode,world", [("auto", 2), ("halo", 2), ("peer", 3), ("allgather", 2)])
+def test_cg_sharded_matches_single(tmp_path, cmi, orc, mode, world):
+    """auto / peer: the one-sided scheme (p exchanged once, r halos pulled, p halos updated locally,
+    ordered by CG's own all-reduces); halo / allgather: p exchanged two-sidedly every iteration."""
     import torch
     import torch.multiprocessing as mp
     m, n, iters = 120, 90, 30
-    mp.spawn(_worker, args=(2, _free_port(), m, n, iters, str(tmp_path)), nprocs=2, join=True)
-    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(2)]
-    assert np.array_equal(parts[0]["hist"], parts[1]["hist"])  # every rank sees the same scalars
+    mp.spawn(_worker, args=(world, _free_port(), m, n, iters, str(tmp_path), mode), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    assert all(str(p["mode"]) == {"auto": "peer"}.get(mode, mode) for p in parts)
+    assert all(np.array_equal(parts[0]["hist"], p["hist"]) for p in parts)  # every rank sees the same scalars
     Ap, Aj, Ax = orc.poisson5pt_csr(m, n)
     import oracle
     xs, hist = numpy_cg(orc, Ap, Aj, Ax, oracle.fill_x(m * n), iters, 1e-12)

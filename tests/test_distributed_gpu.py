@@ -39,27 +39,38 @@ def _worker(rank, world, port, mode, m, n, out_dir):
         sh = cmi.distributed.ShardedCsr(A, N, rank, world, mode=mode)
         sh.x_local.copy_(cmi.fill_x(hi - lo, start=lo).cuda())
         y = torch.full((hi - lo,), 10.0, dtype=torch.float64, device="cuda")
+        # the one-sided exchange needs the peers' writes of x ordered before the pull and the pull ordered
+        # before their next write: fence() is that epoch boundary (a no-op requirement for the two-sided modes)
+        sh.vec.fence()
         sh.multiply(y)
+        sh.vec.fence()
         sh.x_local.mul_(-2.0)
+        sh.vec.fence()
         y2 = torch.empty_like(y)
         sh.multiply(y2)
         torch.cuda.synchronize()
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), y=y.cpu().numpy(), y2=y2.cpu().numpy(), mode=sh.vec.plan.mode,
-                 recv=sh.vec.plan.recv_values)
+                 recv=sh.vec.plan.recv_values, interior=-1 if sh.interior is None else sh.interior[1] - sh.interior[0])
+        sh.vec.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["halo", "allgather", "auto"])
-def test_two_ranks_one_gpu_real_kernels(tmp_path, orc, mode):
+@pytest.mark.parametrize("mode,world", [("halo", 2), ("allgather", 2), ("peer", 2), ("peer", 3), ("auto", 2)])
+def test_ranks_share_one_gpu_real_kernels(tmp_path, orc, mode, world):
     import oracle
     import torch.multiprocessing as mp
-    m, n, world = 300, 200, 2
+    m, n = 300, 201
     mp.spawn(_worker, args=(world, _free_port(), mode, m, n, str(tmp_path)), nprocs=world, join=True)
     Ap, Aj, Ax = orc.poisson5pt_csr(m, n)
     x = oracle.fill_x(m * n)
     parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
     assert np.array_equal(np.concatenate([p["y"] for p in parts]), orc.spmv_csr(Ap, Aj, Ax, x))
     assert np.array_equal(np.concatenate([p["y2"] for p in parts]), orc.spmv_csr(Ap, Aj, Ax, -2.0 * x))
+    inner = [r for r in range(world) if 0 < r < world - 1]
+    if mode == "halo":
+        assert all(str(p["mode"]) == "halo" for p in parts) and all(int(p["interior"]) > 0 for p in parts)
+    if mode in ("peer", "auto"):  # auto: the buffers are in HBM and the peers' buffers map -> one-sided
+        assert all(str(p["mode"]) == "peer" and int(p["interior"]) == -1 for p in parts)
     if mode != "allgather":
-        assert all(str(p["mode"]) == "halo" and int(p["recv"]) == m for p in parts)
+        assert all(int(parts[r]["recv"]) == (2 * m if r in inner else m) for r in range(world))
