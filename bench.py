@@ -128,12 +128,20 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # CMI_BENCH_REHEARSAL=1 (tests only): all ranks share GPU 0 and talk over gloo, so that the N>1
+    # code path can be exercised end to end on a one-GPU box.  RCCL refuses two ranks on one device.
+    rehearsal = os.environ.get("CMI_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     lib = cmi.lib()
     stream = torch.cuda.current_stream()
@@ -238,7 +246,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share one GPU over gloo; not a measurement)",
             "hbm_gbps": round(alg_bytes * world / (elapsed / args.steps) / 1e9, 2),
             "config": {"workload": f"poisson5pt {m}x{n} {fmt.upper()} int32/f64, y = A*x "
                                    f"({N_global} rows, {nnz_global} entries; {M}x{M} grid points per GPU)",

@@ -74,3 +74,23 @@ def test_ranks_share_one_gpu_real_kernels(tmp_path, orc, mode, world):
         assert all(str(p["mode"]) == "peer" and int(p["interior"]) == -1 for p in parts)
     if mode != "allgather":
         assert all(int(parts[r]["recv"]) == (2 * m if r in inner else m) for r in range(world))
+
+
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """bench.py --gpus 2 end to end on the one GPU of the box (CMI_BENCH_REHEARSAL=1: both ranks on GPU 0,
+    gloo): launch line as the driver's, one JSON line from rank 0, one-sided exchange selected."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, CMI_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["x_exchange"]["mode"] == "peer"
+    assert line["config"]["x_exchange"]["values_received_per_rank"] == 3162
+    assert line["config"]["rows_per_gpu"] == 3162 * 3162 and "cpu_baseline" not in line

@@ -107,15 +107,25 @@ def main():
         halo_hi.copy_(x[n - m:])
         plain()
 
+    pull = B.CopyRanges([(x.data_ptr(), halo_lo.data_ptr(), m * 8), (x.data_ptr() + (n - m) * 8, halo_hi.data_ptr(), m * 8)])
+
+    def one_sided_pull_then_whole():
+        # the device-side work of the "peer" exchange: ONE cmi_copy_ranges launch for both halos on the
+        # compute stream, then the whole-block SpMV (here the sources are local; over xGMI they are the
+        # neighbours' mapped buffers)
+        pull.launch()
+        plain()
+
     for name, f in (("plain", plain), ("sharded (p2p, overlapped)", sharded), ("three launches, no comm", three_launches),
                     ("p2p only", comm_only), ("p2p then whole SpMV", comm_then_whole),
                     ("small all-gather then whole", small_allgather_then_whole),
                     ("copy kernels on side stream, overlapped", copy_kernel_overlap),
-                    ("copy kernels inline then whole", copy_kernel_inline)):
+                    ("copy kernels inline then whole", copy_kernel_inline),
+                    ("one-sided pull (cmi_copy_ranges) then whole", one_sided_pull_then_whole)):
         only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
         if only and not any(o in name for o in only):
             continue
-        print("%-42s: %7.1f us/step (host enqueue %6.1f us)" % ((name,) + timeit(f)), flush=True)
+        print("%-46s: %7.1f us/step (host enqueue %6.1f us)" % ((name,) + timeit(f)), flush=True)
     if "--graph" not in sys.argv:
         dist.destroy_process_group()
         return
