@@ -110,6 +110,9 @@ def _declare(L):
     L.cmi_poisson5pt_shard_entries.restype = c_int64
     L.cmi_poisson5pt_shard_entries.argtypes = [i64, i64, i64, i64]
     L.cmi_csr_row_indices.argtypes = [i64, vp, vp, vp]
+    L.cmi_csr_diagonals.argtypes = [i64, i64, vp, vp, vp, vp, i64, POINTER(c_int64), vp]
+    for suf in ("f64", "f32"):
+        getattr(L, f"cmi_csr_to_dia_{suf}").argtypes = [i64, i64, vp, vp, vp, i64, i64, vp, vp, vp, vp]
     L.cmi_ell_row_lengths.argtypes = [i64, i64, i64, vp, vp, vp]
     L.cmi_blas_workspace_bytes.restype = c_size_t
     for suf, sc in (("f64", c_double), ("f32", c_float)):
@@ -353,6 +356,20 @@ def csr_to_hyb_coo(num_rows, Ap, Aj, Ax, width, coo_offsets, coo_Ai, coo_Aj, coo
     fn = getattr(lib(), "cmi_csr_to_hyb_coo_" + _suffix(coo_Ax))
     check(fn(num_rows, _ptr(Ap), _ptr(Aj), _ptr(Ax), width, _ptr(coo_offsets), _ptr(coo_Ai), _ptr(coo_Aj), _ptr(coo_Ax),
              _stream(stream)))
+
+
+def csr_diagonals(num_rows, num_cols, Ap, Aj, slot_map, diag_list, stream=None):
+    """Flags the occupied diagonals in slot_map, lists their offsets (unordered) in diag_list; returns the
+    count (may exceed diag_list.numel(): list truncated).  Synchronises."""
+    n = c_int64()
+    check(lib().cmi_csr_diagonals(num_rows, num_cols, _ptr(Ap), _ptr(Aj), _ptr(slot_map), _ptr(diag_list), diag_list.numel(),
+                                  byref(n), _stream(stream)))
+    return n.value
+
+
+def csr_to_dia(num_rows, num_cols, Ap, Aj, Ax, offsets, pitch, slot_map, values, stream=None):
+    check(getattr(lib(), "cmi_csr_to_dia_" + _suffix(Ax))(num_rows, num_cols, _ptr(Ap), _ptr(Aj), _ptr(Ax), offsets.numel(), pitch,
+                                                         _ptr(offsets), _ptr(slot_map), _ptr(values), _stream(stream)))
 
 
 def csr_row_indices(num_rows, Ap, Ai, stream=None):

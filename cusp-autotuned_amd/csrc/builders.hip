@@ -136,6 +136,56 @@ ell_row_lengths_kernel(int64_t num_rows, int width, int64_t pitch, const int *__
     }
 }
 
+// ---- CSR -> DIA (reference conversions/csr_to_other.h:73-153: count the occupied diagonals, fill) ----
+// slot_map has one int per possible diagonal, index = (col - row) + num_rows.  Pass 1 flags the occupied
+// ones (plain stores of 1: racing writers agree).  Pass 2 appends each flagged offset to an UNORDERED list
+// through one atomic counter (D atomics in all); the caller sorts the D offsets (ascending, as the
+// reference stores them) and hands them back.  Pass 3 turns the flags into slot numbers, pass 4 scatters.
+__global__ void __launch_bounds__(256)
+dia_flag_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ Aj, int *__restrict__ slot_map)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / kWave;
+    for (int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave; row < num_rows; row += nwaves) {
+        const int s = Ap[row], e = Ap[row + 1];
+        for (int jj = s + lane; jj < e; jj += kWave) slot_map[(int64_t)Aj[jj] - row + num_rows] = 1;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+dia_list_kernel(int64_t num_rows, int64_t map_len, const int *__restrict__ slot_map, int *__restrict__ list, int64_t capacity,
+                unsigned long long *__restrict__ counter)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < map_len; s += stride) {
+        if (slot_map[s]) {
+            const unsigned long long k = atomicAdd(counter, 1ull);
+            if ((int64_t)k < capacity) list[k] = (int)(s - num_rows);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+dia_slot_kernel(int64_t num_rows, int64_t num_diagonals, const int *__restrict__ offsets, int *__restrict__ slot_map)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < num_diagonals) slot_map[(int64_t)offsets[k] + num_rows] = (int)k;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+dia_scatter_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ Aj, const T *__restrict__ Ax,
+                   const int *__restrict__ slot_map, int64_t pitch, T *__restrict__ values)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / kWave;
+    for (int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave; row < num_rows; row += nwaves) {
+        const int s = Ap[row], e = Ap[row + 1];
+        for (int jj = s + lane; jj < e; jj += kWave)
+            values[(int64_t)slot_map[(int64_t)Aj[jj] - row + num_rows] * pitch + row] = Ax[jj];
+    }
+}
+
 static int grid_1d(int64_t n)
 {
     int64_t b = ceil_div(n, 256);
@@ -191,9 +241,66 @@ static int csr_to_ell(int64_t rows, const int *Ap, const int *Aj, const T *Ax, i
     return CMI_SUCCESS;
 }
 
+template <typename T>
+static int csr_to_dia(int64_t rows, int64_t cols, const int *Ap, const int *Aj, const T *Ax, int64_t ndiag, int64_t pitch,
+                      const int *offsets, int *slot_map, T *values, void *stream)
+{
+    if (rows < 0 || cols < 0 || ndiag < 0 || pitch < rows) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_to_dia: bad size");
+    if (rows == 0 || ndiag == 0) return CMI_SUCCESS;
+    if (!Ap || !Aj || !Ax || !offsets || !slot_map || !values) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_to_dia: null array");
+    hipStream_t s = as_stream(stream);
+    CMI_HIP(hipMemsetAsync(values, 0, (size_t)pitch * ndiag * sizeof(T), s));
+    hipLaunchKernelGGL(dia_slot_kernel, dim3((unsigned)ceil_div(ndiag, 256)), dim3(256), 0, s, rows, ndiag, offsets, slot_map);
+    hipLaunchKernelGGL((dia_scatter_kernel<T>), dim3(grid_1d(rows * 8)), dim3(256), 0, s, rows, Ap, Aj, Ax, slot_map, pitch, values);
+    CMI_LAUNCH_CHECK("csr_to_dia");
+    return CMI_SUCCESS;
+}
+
 } // namespace cmi
 
 using namespace cmi;
+
+// Occupied diagonals of a CSR matrix.  slot_map: num_rows + num_cols ints (scratch, kept for
+// cmi_csr_to_dia_*); diag_list: `capacity` ints, receives the offsets (col - row) in NO particular
+// order; *num_diagonals_host: how many there are (may exceed capacity: then the list is truncated and
+// the caller should give up, as the reference does when the fill-in is too large).  Synchronises.
+CMI_API int cmi_csr_diagonals(int64_t num_rows, int64_t num_cols, const int32_t *Ap, const int32_t *Aj, int32_t *slot_map,
+                              int32_t *diag_list, int64_t capacity, int64_t *num_diagonals_host, void *stream)
+{
+    if (num_rows < 0 || num_cols < 0 || capacity < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_diagonals: bad size");
+    if (!num_diagonals_host) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_diagonals: null result");
+    *num_diagonals_host = 0;
+    if (num_rows == 0 || num_cols == 0) return CMI_SUCCESS;
+    if (!Ap || !slot_map || (capacity > 0 && !diag_list)) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_diagonals: null array");
+    hipStream_t s = as_stream(stream);
+    const int64_t map_len = num_rows + num_cols;
+    unsigned long long *counter = nullptr;
+    CMI_HIP(hipMalloc((void **)&counter, sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(counter, 0, sizeof(unsigned long long), s);
+    if (e == hipSuccess) e = hipMemsetAsync(slot_map, 0, (size_t)map_len * sizeof(int), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(dia_flag_kernel, dim3(grid_1d(num_rows * 8)), dim3(256), 0, s, num_rows, Ap, Aj, slot_map);
+        hipLaunchKernelGGL(dia_list_kernel, dim3(grid_1d(map_len)), dim3(256), 0, s, num_rows, map_len, slot_map, diag_list, capacity, counter);
+        e = hipGetLastError();
+    }
+    unsigned long long n = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&n, counter, sizeof(n), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(counter);
+    if (e != hipSuccess) return hip_fail(e, "cmi_csr_diagonals");
+    *num_diagonals_host = (int64_t)n;
+    return CMI_SUCCESS;
+}
+
+// values[k*pitch + i] <- A(i, i + offsets[k]) for the SORTED offsets the caller derived from
+// cmi_csr_diagonals (same slot_map, still flagged); everything else in `values` is zeroed.
+CMI_API int cmi_csr_to_dia_f64(int64_t num_rows, int64_t num_cols, const int32_t *Ap, const int32_t *Aj, const double *Ax,
+                               int64_t num_diagonals, int64_t pitch, const int32_t *offsets, int32_t *slot_map, double *values, void *stream)
+{ return csr_to_dia<double>(num_rows, num_cols, Ap, Aj, Ax, num_diagonals, pitch, offsets, slot_map, values, stream); }
+CMI_API int cmi_csr_to_dia_f32(int64_t num_rows, int64_t num_cols, const int32_t *Ap, const int32_t *Aj, const float *Ax,
+                               int64_t num_diagonals, int64_t pitch, const int32_t *offsets, int32_t *slot_map, float *values, void *stream)
+{ return csr_to_dia<float>(num_rows, num_cols, Ap, Aj, Ax, num_diagonals, pitch, offsets, slot_map, values, stream); }
+
 
 CMI_API int64_t cmi_poisson5pt_num_entries(int64_t m, int64_t n)
 {

@@ -11,9 +11,10 @@
 //   CSR -> DIA : occupied diagonals ascending, same fill-in guard      (csr_to_other.h:73-153)
 //   CSR -> HYB : ELL width from compute_optimal_entries_per_row(3.0, 4096), the rest in COO in CSR
 //                order                              (csr_to_other.h:229-306, format_utils.inl:281-325)
-// Device CSR -> device ELL / COO use the C-ABI's on-device builders (no host round trip), which is
+// Device CSR -> device ELL / COO / HYB / DIA use the C-ABI's on-device builders (no host round trip), which is
 // what makes 1e7-row format sweeps practical.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <limits>
 
@@ -417,6 +418,38 @@ struct device_fast_path<csr_matrix<int, V, device_memory>, hyb_matrix<int, V, de
                                         d.coo.row_indices.data(), d.coo.column_indices.data(), d.coo.values.data()));
             check(cmi_stream_synchronize(nullptr));
         }
+        check(cmi_stream_synchronize(nullptr));
+        return true;
+    }
+};
+
+inline int csr_to_dia_device(int64_t rows, int64_t cols, const int *Ap, const int *Aj, const double *Ax, int64_t nd, int64_t pitch, const int *off, int *map, double *va)
+{ return cmi_csr_to_dia_f64(rows, cols, Ap, Aj, Ax, nd, pitch, off, map, va, nullptr); }
+inline int csr_to_dia_device(int64_t rows, int64_t cols, const int *Ap, const int *Aj, const float *Ax, int64_t nd, int64_t pitch, const int *off, int *map, float *va)
+{ return cmi_csr_to_dia_f32(rows, cols, Ap, Aj, Ax, nd, pitch, off, map, va, nullptr); }
+
+// device CSR -> device DIA: only the (few) diagonal offsets visit the host, to be sorted ascending
+template <typename V>
+struct device_fast_path<csr_matrix<int, V, device_memory>, dia_matrix<int, V, device_memory>, csr_format, dia_format> {
+    static bool run(const csr_matrix<int, V, device_memory> &s, dia_matrix<int, V, device_memory> &d)
+    {
+        if (s.num_entries == 0 || s.num_rows == 0) return false;
+        // no more diagonals than the fill-in guard lets through (csr_to_other.h:97-103)
+        size_t capacity = std::max<size_t>(static_cast<size_t>(3.0 * s.num_entries / s.num_rows) + 1, static_cast<size_t>(1e6) / s.num_rows + 1);
+        capacity = std::min(capacity, s.num_rows + s.num_cols);
+        array1d<int, device_memory> slot_map(s.num_rows + s.num_cols), list(capacity);
+        int64_t nd = 0;
+        check(cmi_csr_diagonals(s.num_rows, s.num_cols, s.row_offsets.data(), s.column_indices.data(), slot_map.data(), list.data(),
+                                static_cast<int64_t>(capacity), &nd, nullptr));
+        check_fill("dia_matrix", static_cast<size_t>(nd) * s.num_rows, s.num_entries);
+        if (static_cast<size_t>(nd) > capacity) throw cusp::format_conversion_exception("dia_matrix fill-in would exceed maximum tolerance");
+        array1d<int, host_memory> off(list);
+        off.resize(static_cast<size_t>(nd));
+        std::sort(off.begin(), off.end());
+        d.resize(s.num_rows, s.num_cols, s.num_entries, static_cast<size_t>(nd));
+        d.diagonal_offsets = off;
+        check(csr_to_dia_device(s.num_rows, s.num_cols, s.row_offsets.data(), s.column_indices.data(), s.values.data(), nd, d.values.pitch,
+                                d.diagonal_offsets.data(), slot_map.data(), d.values.values.data()));
         check(cmi_stream_synchronize(nullptr));
         return true;
     }

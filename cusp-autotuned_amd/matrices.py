@@ -132,7 +132,7 @@ def poisson5pt(m, n, fmt="csr", dtype=None, device="cuda", row_begin=0, row_end=
 
 
 def convert(csr, fmt, num_entries_per_row=None, ell_alignment=32):
-    """CSR -> {coo, ell, hyb} on the device (reference conversions/csr_to_other.h:56-70,155-306).
+    """CSR -> {coo, ell, hyb, dia} on the device (reference conversions/csr_to_other.h:56-306).
     For ELL the width defaults to the longest row; for HYB pass num_entries_per_row (the reference's
     compute_optimal_entries_per_row heuristic lives in the C++ layer / oracle)."""
     import torch
@@ -170,6 +170,24 @@ def convert(csr, fmt, num_entries_per_row=None, ell_alignment=32):
             B.csr_to_hyb_coo(csr.num_rows, csr.row_offsets, csr.column_indices, csr.values, width, offs, cAi, cAj, cAx)
         coo = CooMatrix(csr.num_rows, csr.num_cols, n_coo, cAi, cAj, cAx)
         return HybMatrix(csr.num_rows, csr.num_cols, csr.num_entries, ell, coo)
+    if fmt == "dia":
+        # reference csr_to_other.h:73-153 (max_fill 3.0 once the DIA array exceeds 1e6 slots)
+        if csr.num_entries == 0:
+            return DiaMatrix(csr.num_rows, csr.num_cols, 0, _round_up(csr.num_rows, ell_alignment), torch.empty(0, dtype=torch.int32, device=dev),
+                             torch.empty(0, dtype=csr.values.dtype, device=dev))
+        slot_map = torch.empty(csr.num_rows + csr.num_cols, dtype=torch.int32, device=dev)
+        capacity = max(int(3.0 * csr.num_entries / max(csr.num_rows, 1)) + 1, int(1e6 // max(csr.num_rows, 1)) + 1)
+        capacity = min(capacity, csr.num_rows + csr.num_cols)
+        diag_list = torch.empty(capacity, dtype=torch.int32, device=dev)
+        nd = B.csr_diagonals(csr.num_rows, csr.num_cols, csr.row_offsets, csr.column_indices, slot_map, diag_list)
+        slots = nd * csr.num_rows
+        if nd > capacity or (slots / max(1.0, csr.num_entries) > 3.0 and slots > 1e6):
+            raise ValueError("convert: dia_matrix fill-in would exceed maximum tolerance")
+        offsets = torch.sort(diag_list[:nd]).values.contiguous()
+        pitch = _round_up(csr.num_rows, ell_alignment)
+        values = torch.empty(nd * pitch, dtype=csr.values.dtype, device=dev)
+        B.csr_to_dia(csr.num_rows, csr.num_cols, csr.row_offsets, csr.column_indices, csr.values, offsets, pitch, slot_map, values)
+        return DiaMatrix(csr.num_rows, csr.num_cols, csr.num_entries, pitch, offsets, values)
     raise ValueError(f"convert: unknown format {fmt!r}")
 
 

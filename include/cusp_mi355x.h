@@ -272,6 +272,20 @@ int cmi_csr_to_hyb_coo_f64(int64_t num_rows, const int32_t *Ap, const int32_t *A
 int cmi_csr_to_hyb_coo_f32(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, const float *Ax, int64_t width,
                            const int32_t *coo_offsets, int32_t *coo_Ai, int32_t *coo_Aj, float *coo_Ax,
                            void *stream);
+/* CSR -> DIA on the device (reference conversions/csr_to_other.h:73-153, there with Thrust sorts):   */
+/* cmi_csr_diagonals flags the occupied diagonals in slot_map (num_rows + num_cols ints of scratch)  */
+/* and lists their offsets (col - row) UNORDERED in diag_list (at most `capacity`; the true count    */
+/* comes back in *num_diagonals_host -- larger than capacity means "too much fill-in, give up").     */
+/* The caller sorts the few offsets ascending (the reference's order), uploads them, and             */
+/* cmi_csr_to_dia_* zeroes `values` (pitch x num_diagonals, column-major) and scatters the entries.  */
+int cmi_csr_diagonals(int64_t num_rows, int64_t num_cols, const int32_t *Ap, const int32_t *Aj, int32_t *slot_map,
+                      int32_t *diag_list, int64_t capacity, int64_t *num_diagonals_host, void *stream);
+int cmi_csr_to_dia_f64(int64_t num_rows, int64_t num_cols, const int32_t *Ap, const int32_t *Aj, const double *Ax,
+                       int64_t num_diagonals, int64_t pitch, const int32_t *offsets, int32_t *slot_map,
+                       double *values, void *stream);
+int cmi_csr_to_dia_f32(int64_t num_rows, int64_t num_cols, const int32_t *Ap, const int32_t *Aj, const float *Ax,
+                       int64_t num_diagonals, int64_t pitch, const int32_t *offsets, int32_t *slot_map,
+                       float *values, void *stream);
 /* CSR -> COO row indices (offsets_to_indices, csr_to_other.h:56-70). */
 int cmi_csr_row_indices(int64_t num_rows, const int32_t *Ap, int32_t *Ai, void *stream);
 /* ELL -> per-row length of the leading valid run (cusp/ktt/detail/ellr_matrix.inl:16-53). */

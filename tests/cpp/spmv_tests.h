@@ -233,6 +233,49 @@ template <typename Space> void TestConversionExampleAllFormats()
 }
 DECLARE_SPACE_UNITTEST(TestConversionExampleAllFormats);
 
+// CSR -> DIA in the matrix's own memory space (device: cmi_csr_diagonals + cmi_csr_to_dia, only the sorted
+// offsets visit the host) must produce the arrays of the host conversion (csr_to_other.h:73-153)
+template <typename Space> void TestCsrToDiaMatchesHostConversion()
+{
+    cusp::csr_matrix<int, double, cusp::host_memory> h;
+    cusp::gallery::poisson5pt(h, 37, 23);
+    // a rectangular banded matrix with an empty row and an empty diagonal in between
+    cusp::csr_matrix<int, double, cusp::host_memory> r(50, 70, 0);
+    {
+        std::vector<int> ro(1, 0), ci; std::vector<double> v;
+        for (int i = 0; i < 50; i++) {
+            if (i != 17)
+                for (int o : {-3, 0, 2, 25}) { const int j = i + o; if (j >= 0 && j < 70) { ci.push_back(j); v.push_back(1.0 + i + 0.25 * o); } }
+            ro.push_back(int(ci.size()));
+        }
+        r.resize(50, 70, ci.size());
+        for (size_t k = 0; k < ro.size(); k++) r.row_offsets[k] = ro[k];
+        for (size_t k = 0; k < ci.size(); k++) { r.column_indices[k] = ci[k]; r.values[k] = v[k]; }
+    }
+    for (const auto *src : {&h, &r}) {
+        cusp::dia_matrix<int, double, cusp::host_memory> want(*src);
+        cusp::csr_matrix<int, double, Space> s(*src);
+        cusp::dia_matrix<int, double, Space> got(s);
+        ASSERT_EQUAL(got.num_rows, want.num_rows); ASSERT_EQUAL(got.num_cols, want.num_cols); ASSERT_EQUAL(got.num_entries, want.num_entries);
+        ASSERT_EQUAL(got.values.pitch, want.values.pitch);
+        ASSERT_ARRAYS_EQUAL(got.diagonal_offsets, want.diagonal_offsets);
+        ASSERT_ARRAYS_EQUAL(got.values.values, want.values.values);
+    }
+    // too many diagonals for the fill-in guard: the same exception on either path
+    cusp::csr_matrix<int, double, cusp::host_memory> wide(3000, 3000, 3000 * 2);
+    for (int i = 0; i <= 3000; i++) wide.row_offsets[i] = 2 * i;
+    for (int i = 0; i < 3000; i++) {
+        const int a = (i * 7) % 3000, b = (i * 13 + 5) % 3000;
+        wide.column_indices[2 * i] = std::min(a, b); wide.column_indices[2 * i + 1] = std::max(a, b) + (a == b);
+        if (wide.column_indices[2 * i + 1] >= 3000) wide.column_indices[2 * i + 1] = 2999, wide.column_indices[2 * i] = 2998;
+        wide.values[2 * i] = 1; wide.values[2 * i + 1] = 2;
+    }
+    cusp::csr_matrix<int, double, Space> ws(wide);
+    cusp::dia_matrix<int, double, Space> wd;
+    ASSERT_THROWS(cusp::convert(ws, wd), cusp::format_conversion_exception);
+}
+DECLARE_SPACE_UNITTEST(TestCsrToDiaMatchesHostConversion);
+
 // testing/ell_matrix.cu:5-22
 template <typename Space> void TestEllMatrixBasicConstructor()
 {

@@ -596,6 +596,47 @@ def test_full_size_properties(cmi, torch_cuda, big):
 
 
 # ------------------------------------------------------------------------------------------------
+# CSR -> DIA on the device
+# ------------------------------------------------------------------------------------------------
+def test_device_csr_to_dia_matches_oracle(cmi, torch_cuda, orc, golden_irregular):
+    """cmi_csr_diagonals + cmi_csr_to_dia_* reproduce the arrays of the reference conversion
+    (csr_to_other.h:73-153: occupied diagonals ascending, zero fill) bit for bit; the SpMV on the result
+    equals the CSR SpMV; the fill-in guard rejects a matrix with too many diagonals."""
+    torch = torch_cuda
+    cases = []
+    Ap, Aj, Ax = orc.poisson5pt_csr(61, 47)
+    cases.append((61 * 47, 61 * 47, Ap, Aj, Ax))
+    # rectangular banded matrix with an empty row (built here; float32 and float64)
+    rng = np.random.default_rng(5)
+    rows, cols, offs = 700, 900, (-450, -3, 0, 1, 17, 400, 880)
+    ap, aj, ax = [0], [], []
+    for i in range(rows):
+        if i != 123:
+            for o in offs:
+                if 0 <= i + o < cols:
+                    aj.append(i + o)
+                    ax.append(rng.standard_normal())
+        ap.append(len(aj))
+    for dt in (np.float64, np.float32):
+        cases.append((rows, cols, np.array(ap, np.int32), np.array(aj, np.int32), np.array(ax, dt)))
+    for rows, cols, Ap, Aj, Ax in cases:
+        A = cmi.CsrMatrix(rows, cols, len(Aj), dev(Ap, torch), dev(Aj, torch), dev(Ax, torch))
+        D = cmi.convert(A, "dia")
+        pitch, off, vals = orc.csr_to_dia(rows, cols, Ap, Aj, Ax)
+        assert D.pitch == pitch and np.array_equal(host(D.diagonal_offsets), off)
+        assert np.array_equal(host(D.values), vals)
+        x = np.random.default_rng(1).standard_normal(cols).astype(Ax.dtype)
+        y = torch.empty(rows, dtype=A.values.dtype, device="cuda")
+        cmi.multiply(D, dev(x, torch), y)
+        assert np.array_equal(host(y), orc.spmv_dia(rows, cols, pitch, off, vals, x))
+    # the irregular golden matrix occupies 2365 diagonals: 3.5e6 slots for 15378 entries -> refused
+    g = golden_irregular
+    A = cmi.CsrMatrix(int(g["rows"]), int(g["cols"]), len(g["f64_Aj"]), dev(g["f64_Ap"], torch), dev(g["f64_Aj"], torch), dev(g["f64_Ax"], torch))
+    with pytest.raises(ValueError, match="fill-in"):
+        cmi.convert(A, "dia")
+
+
+# ------------------------------------------------------------------------------------------------
 # fused y = A x, <y, w>  (the CG step cg.inl:80-83 in one pass)
 # ------------------------------------------------------------------------------------------------
 def test_spmv_csr_dot_every_variant(cmi, torch_cuda, golden_irregular):
