@@ -16,7 +16,9 @@ N > 1: weak scaling -- every rank owns a 3162x3162-point row block of the global
        one-sided halo pull -- each rank copies the 2*3162 boundary values its rows reference straight
        out of its neighbours' mapped buffers with one small kernel on its own stream ("peer"); if the
        buffers cannot be mapped, the two-sided RCCL halo exchange ("halo"); "allgather" on request
-       (cusp-autotuned_amd/distributed.py).  value = 2*global_nnz / max-over-ranks time.
+       (cusp-autotuned_amd/distributed.py).  value = 2*global_nnz / max-over-ranks time.  The north-star's
+       literal exchange (RCCL all-gather of the whole x before each multiply) is timed beside it on up
+       to 20 steps and reported as `allgather_exchange` (never as `value`).
 
 Timing protocol (reference performance/spmv/benchmark.h:84-120): W untimed warm-up steps, then
 exactly K steps between a barrier + device synchronise on both sides; MAX over ranks.
@@ -193,6 +195,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- N>1: the north-star's literal exchange (RCCL all-gather of the whole x before each multiply) timed
+    #      beside the default one, same protocol, fewer steps (it moves (N-1)/N of x per rank per step) ------
+    allgather_leg = None
+    if dist is not None and exchange_info["mode"] != "allgather":
+        try:
+            sh_ag = cmi.distributed.ShardedCsr(A, N_global, rank, world, mode="allgather")
+            sh_ag.x_local.copy_(sh.x_local)
+            y_ag = torch.empty_like(y)
+            ag_steps = max(1, min(args.steps, 20))
+            for _ in range(2):
+                sh_ag.multiply(y_ag)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(ag_steps):
+                sh_ag.multiply(y_ag)
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            same = torch.tensor([int(torch.equal(y_ag, y))], dtype=torch.int32, device=dev)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            ag_s = float(t.item()) / ag_steps
+            allgather_leg = {"ms_per_step": round(ag_s * 1e3, 5), "value": round(2.0 * nnz_global / ag_s / 1e9, 3), "unit": "GFLOP/s",
+                             "steps": ag_steps, "values_received_per_rank": sh_ag.vec.plan.allgather_values,
+                             "y_identical_to_default_exchange": bool(int(same.item()))}
+            del sh_ag, y_ag
+        except Exception as e:  # noqa: BLE001 -- the secondary leg must never take the main line down
+            allgather_leg = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     # ---- dominant kernel: average launch duration with HIP events on ITS stream --------------
     ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()
     cmi.check(lib.cmi_event_create(ctypes.byref(ev0)))
@@ -258,6 +288,8 @@ def main():
                          "kernel_avg_ms": round(kernel_ms, 6), "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_gflops": round(2.0 * local_nnz / (kernel_ms * 1e-3) / 1e9, 2)},
         }
+        if allgather_leg is not None:
+            line["allgather_exchange"] = allgather_leg
         if world == 1 and not args.no_cpu_baseline and fmt == "csr":
             base, omp = cpu_baseline(cmi, A, x_host, y.cpu().numpy(), args.cpu_seconds)
             line["cpu_baseline"] = base
