@@ -40,6 +40,31 @@ template <typename Stream> void read_banner(Stream &input, matrix_market_banner 
     if (banner.symmetry != "general" && banner.symmetry != "symmetric" && banner.symmetry != "hermitian" && banner.symmetry != "skew-symmetric")
         throw cusp::io_exception("invalid MatrixMarket symmetry [" + banner.symmetry + "]");
 }
+
+// "array" storage: `rows cols`, then rows*cols values in column-major order; only real / integer general is
+// supported, as in the reference; the dense matrix is then converted to the requested type (zeros dropped)
+template <typename Matrix, typename Stream> void read_array_stream(Matrix &mtx, Stream &input, const matrix_market_banner &banner)
+{
+    typedef typename Matrix::value_type V;
+    if (banner.type == "pattern") throw cusp::not_implemented_exception("pattern array MatrixMarket format is not supported");
+    if (banner.symmetry != "general") throw cusp::not_implemented_exception("only general array symmetric MatrixMarket format is supported");
+    std::string line;
+    do {
+        if (!std::getline(input, line)) throw cusp::io_exception("unexpected EOF while reading MatrixMarket header");
+    } while (line.empty() || line[0] == '%');
+    std::vector<std::string> tokens;
+    tokenize(tokens, line);
+    if (tokens.size() != 2) throw cusp::io_exception("invalid MatrixMarket array format");
+    size_t num_rows, num_cols;
+    std::istringstream(tokens[0]) >> num_rows;
+    std::istringstream(tokens[1]) >> num_cols;
+    array2d<V, host_memory, column_major> dense(num_rows, num_cols);
+    size_t read = 0;
+    double v;
+    while (read < num_rows * num_cols && (input >> v)) dense.values[read++] = static_cast<V>(v);
+    if (read != num_rows * num_cols) throw cusp::io_exception("unexpected EOF while reading MatrixMarket entries");
+    cusp::convert(dense, mtx);
+}
 } // namespace detail
 
 template <typename Matrix, typename Stream> void read_matrix_market_stream(Matrix &mtx, Stream &input)
@@ -48,8 +73,11 @@ template <typename Matrix, typename Stream> void read_matrix_market_stream(Matri
     typedef typename Matrix::value_type V;
     detail::matrix_market_banner banner;
     detail::read_banner(input, banner);
-    if (banner.storage != "coordinate") throw cusp::not_implemented_exception("MatrixMarket array storage is not read by this layer (sparse inputs only)");
     if (banner.type == "complex") throw cusp::not_implemented_exception("complex MatrixMarket data (real value types only)");
+    if (banner.storage == "array") { // dense, column-major (reference matrix_market.inl:344-420, 459-466)
+        detail::read_array_stream(mtx, input, banner);
+        return;
+    }
 
     std::string line;
     do { // skip comments

@@ -61,12 +61,43 @@ def cmi():
 
 
 def read_mtx(path):
-    """Tiny MatrixMarket coordinate reader for the fixture file (general, integer/real)."""
+    """Small MatrixMarket reader for the fixture files (test infrastructure): coordinate real / integer /
+    pattern, general / symmetric, and dense `array` storage.  Returns rows, cols, I, J, V (0-based,
+    symmetric entries mirrored, dense zeros dropped) in file order."""
     with open(path) as f:
-        lines = [l for l in f if not l.startswith("%")]
+        banner = f.readline().split()
+        lines = [l for l in f if l.strip() and not l.startswith("%")]
+    storage, kind, sym = banner[2], banner[3], banner[4]
+    if storage == "array":
+        rows, cols = map(int, lines[0].split())
+        D = np.array([float(l) for l in lines[1:1 + rows * cols]]).reshape(cols, rows).T
+        I, J = np.nonzero(D)
+        return rows, cols, I.astype(np.int64), J.astype(np.int64), D[I, J]
     rows, cols, nnz = map(int, lines[0].split())
+    if nnz == 0:
+        return rows, cols, np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0)
     ent = np.array([l.split() for l in lines[1:1 + nnz]], dtype=np.float64)
-    return rows, cols, ent[:, 0].astype(np.int64) - 1, ent[:, 1].astype(np.int64) - 1, ent[:, 2]
+    I, J = ent[:, 0].astype(np.int64) - 1, ent[:, 1].astype(np.int64) - 1
+    V = ent[:, 2] if kind != "pattern" else np.ones(nnz)
+    if sym == "symmetric":
+        off = I != J
+        I, J, V = np.concatenate([I, J[off]]), np.concatenate([J, I[off]]), np.concatenate([V, V[off]])
+    return rows, cols, I, J, V
+
+
+def coo_to_csr(rows, I, J, V, dtype=np.float64):
+    """Sort by (row, column) and build CSR (test infrastructure)."""
+    order = np.lexsort((J, I))
+    I, J, V = I[order], J[order], V[order]
+    Ap = np.zeros(rows + 1, np.int32)
+    np.add.at(Ap, I + 1, 1)
+    return np.cumsum(Ap).astype(np.int32), J.astype(np.int32), V.astype(dtype)
+
+
+def reference_data_files():
+    """The data files the reference's own tests hold (testing/data/{test,laplacian,random_10x10}/*.mtx)."""
+    import glob
+    return sorted(glob.glob(os.path.join(GOLDEN, "ref_data", "*", "*.mtx")) + [os.path.join(GOLDEN, "5pt_10x10.mtx")])
 
 
 def dense_to_csr(D, dtype=np.float64):

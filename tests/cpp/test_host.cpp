@@ -94,6 +94,96 @@ void TestPoissonOtherStencils()
 }
 DECLARE_UNITTEST(TestPoissonOtherStencils);
 
+// The reference's own data files (testing/data/test/*.mtx) with the dense answers its tests expect
+// (testing/matrix_market.cu:60-100, 146-186, 188-215, 217-260)
+void TestReadMatrixMarketReferenceFiles()
+{
+    const std::string dir = g_golden_dir + "/ref_data/test/";
+    {
+        cusp::coo_matrix<int, float, cusp::host_memory> coo;
+        cusp::io::read_matrix_market_file(coo, dir + "coordinate_real_general.mtx");
+        cusp::array2d<float, cusp::host_memory> D(coo);
+        const float E[5][5] = {{1.0f, 0, 0, 6.0f, 0}, {0, 10.5f, 0, 0, 0}, {0, 0, 0.25f, 0, 0}, {0, 250.5f, 0, -250.0f, 38.75f}, {0, 0, 0, 0, 12.0f}};
+        ASSERT_EQUAL(D.num_rows, size_t(5)); ASSERT_EQUAL(D.num_cols, size_t(5));
+        for (int i = 0; i < 5; i++) for (int j = 0; j < 5; j++) ASSERT_EQUAL(D(i, j), E[i][j]);
+        cusp::csr_matrix<int, float, cusp::host_memory> csr;                      // :217-260, straight into CSR
+        cusp::io::read_matrix_market_file(csr, dir + "coordinate_real_general.mtx");
+        cusp::array2d<float, cusp::host_memory> D2(csr);
+        for (int i = 0; i < 5; i++) for (int j = 0; j < 5; j++) ASSERT_EQUAL(D2(i, j), E[i][j]);
+    }
+    {
+        cusp::coo_matrix<int, float, cusp::host_memory> coo;
+        cusp::io::read_matrix_market_file(coo, dir + "coordinate_pattern_symmetric.mtx");
+        cusp::array2d<float, cusp::host_memory> D(coo);
+        const float E[5][5] = {{1, 0, 0, 0, 0}, {0, 1, 0, 1, 0}, {0, 0, 1, 0, 0}, {0, 1, 0, 1, 1}, {0, 0, 0, 1, 1}};
+        for (int i = 0; i < 5; i++) for (int j = 0; j < 5; j++) ASSERT_EQUAL(D(i, j), E[i][j]);
+    }
+    {
+        cusp::coo_matrix<int, float, cusp::host_memory> coo;
+        cusp::io::read_matrix_market_file(coo, dir + "array_real_general.mtx");
+        cusp::array2d<float, cusp::host_memory> D(coo);
+        ASSERT_EQUAL(D.num_rows, size_t(4)); ASSERT_EQUAL(D.num_cols, size_t(3));
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 3; j++) ASSERT_EQUAL(D(i, j), float(1 + i + 4 * j));
+    }
+}
+DECLARE_UNITTEST(TestReadMatrixMarketReferenceFiles);
+
+// testing/data/laplacian/*.mtx are what cusp::gallery produces: the files pin the generic stencil builder
+void TestGalleryAgainstReferenceLaplacianFiles()
+{
+    const std::string dir = g_golden_dir + "/ref_data/laplacian/";
+    auto same = [](const cusp::csr_matrix<int, double, cusp::host_memory> &F, const cusp::csr_matrix<int, double, cusp::host_memory> &G) {
+        ASSERT_EQUAL(F.num_rows, G.num_rows); ASSERT_EQUAL(F.num_cols, G.num_cols); ASSERT_EQUAL(F.num_entries, G.num_entries);
+        ASSERT_ARRAYS_EQUAL(F.row_offsets, G.row_offsets);
+        ASSERT_ARRAYS_EQUAL(F.column_indices, G.column_indices);
+        ASSERT_ARRAYS_EQUAL(F.values, G.values);
+    };
+    cusp::csr_matrix<int, double, cusp::host_memory> F, G;
+    cusp::io::read_matrix_market_file(F, dir + "9pt_10x10.mtx");
+    cusp::gallery::poisson9pt(G, 10, 10);
+    same(F, G);
+    cusp::io::read_matrix_market_file(F, dir + "7pt_10x10x10.mtx"); // this file's diagonal is 7, not poisson7pt's 6
+    cusp::gallery::generate_matrix_from_stencil(G, {{0, 0, -1, -1.0}, {0, -1, 0, -1.0}, {-1, 0, 0, -1.0}, {0, 0, 0, 7.0}, {1, 0, 0, -1.0}, {0, 1, 0, -1.0}, {0, 0, 1, -1.0}}, 10, 10, 10);
+    same(F, G);
+    cusp::csr_matrix<int, double, cusp::host_memory> P;
+    cusp::gallery::poisson7pt(P, 10, 10, 10);
+    ASSERT_ARRAYS_EQUAL(F.row_offsets, P.row_offsets);       // same pattern as the gallery's 7-point matrix
+    ASSERT_ARRAYS_EQUAL(F.column_indices, P.column_indices);
+    cusp::io::read_matrix_market_file(F, dir + "3pt_100.mtx");
+    cusp::gallery::generate_matrix_from_stencil(G, {{-1, 0, 0, -1.0}, {0, 0, 0, 2.0}, {1, 0, 0, -1.0}}, 100, 1);
+    same(F, G);
+}
+DECLARE_UNITTEST(TestGalleryAgainstReferenceLaplacianFiles);
+
+// testing/data/random_10x10/NNN_nonzeros.mtx (0 ... 100 entries in a 10x10 matrix): every format built from
+// the file multiplies like the dense matrix (integer entries, x in halves: every sum is exact in any order)
+void TestRandom10x10FilesAllFormats()
+{
+    const char *names[] = {"000", "001", "002", "005", "008", "010", "015", "020", "030", "050", "080", "100"};
+    for (const char *nm : names) {
+        cusp::coo_matrix<int, double, cusp::host_memory> coo;
+        cusp::io::read_matrix_market_file(coo, g_golden_dir + "/ref_data/random_10x10/" + nm + "_nonzeros.mtx");
+        ASSERT_EQUAL(coo.num_rows, size_t(10)); ASSERT_EQUAL(coo.num_entries, size_t(std::atoi(nm)));
+        cusp::array2d<double, cusp::host_memory> D(coo);
+        cusp::array1d<double, cusp::host_memory> x(10), want(10, 0.0);
+        for (int j = 0; j < 10; j++) x[j] = 0.5 * j - 2.0;
+        for (int i = 0; i < 10; i++) for (int j = 0; j < 10; j++) want[i] += D(i, j) * x[j];
+        cusp::csr_matrix<int, double, cusp::host_memory> csr(coo);
+        cusp::hyb_matrix<int, double, cusp::host_memory> hyb(coo);
+        cusp::array1d<double, cusp::host_memory> y(10, -1.0);
+        cusp::multiply(coo, x, y); ASSERT_ARRAYS_EQUAL(y, want);
+        cusp::multiply(csr, x, y); ASSERT_ARRAYS_EQUAL(y, want);
+        cusp::multiply(hyb, x, y); ASSERT_ARRAYS_EQUAL(y, want);
+        if (coo.num_entries) {
+            cusp::ell_matrix<int, double, cusp::host_memory> ell(coo);
+            cusp::dia_matrix<int, double, cusp::host_memory> dia(coo);
+            cusp::multiply(ell, x, y); ASSERT_ARRAYS_EQUAL(y, want);
+            cusp::multiply(dia, x, y); ASSERT_ARRAYS_EQUAL(y, want);
+        }
+    }
+}
+DECLARE_UNITTEST(TestRandom10x10FilesAllFormats);
+
 int main(int argc, char **argv)
 {
     g_golden_dir = GOLDEN_DIR;

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import GOLDEN, dense_to_csr, read_mtx
+from conftest import GOLDEN, coo_to_csr, dense_to_csr, read_mtx, reference_data_files
 
 DT = {"f64": np.float64, "f32": np.float32}
 
@@ -222,3 +222,31 @@ def test_empty_shapes(orc):
     assert y.tolist() == [0, 0, 0]
     y = orc.spmv_coo(3, e, e, np.empty(0), np.ones(3), y0=np.array([1., 2., 3.]))
     assert y.tolist() == [1, 2, 3]
+
+
+# ---- every data file the reference's tests hold: oracle SpMV (all formats) == dense product -------------
+@pytest.mark.parametrize("path", reference_data_files(), ids=lambda p: os.path.basename(p))
+def test_oracle_on_reference_data_files(orc, path):
+    rows, cols, I, J, V = read_mtx(path)
+    D = np.zeros((rows, cols))
+    np.add.at(D, (I, J), V)
+    Ap, Aj, Ax = coo_to_csr(rows, I, J, V)
+    assert len(Aj) == len(I) and Ap[-1] == len(I)
+    x = (np.arange(cols) % 7 - 3.0) * 0.5            # halves: with the files' small-integer entries every sum is exact
+    exact = bool(np.all(V == np.round(V * 4) / 4))   # (coordinate_real_general holds 10.5, 250.5, 38.75: still exact)
+    want = D @ x
+    got = {"csr": orc.spmv_csr(Ap, Aj, Ax, x), "coo": orc.spmv_coo(rows, orc.csr_row_indices(Ap), Aj, Ax, x)}
+    width = int(np.diff(Ap).max()) if len(Aj) else 0
+    pitch, eAj, eAx = orc.csr_to_ell(Ap, Aj, Ax, width)
+    got["ell"] = orc.spmv_ell(rows, width, pitch, eAj, eAx, x)
+    if len(Aj):
+        pd, off, vals = orc.csr_to_dia(rows, cols, Ap, Aj, Ax)
+        got["dia"] = orc.spmv_dia(rows, cols, pd, off, vals, x)
+    hw = orc.optimal_entries_per_row(Ap)
+    p, hAj, hAx, cAi, cAj, cAx = orc.csr_to_hyb(Ap, Aj, Ax, hw)
+    got["hyb"] = orc.spmv_hyb(rows, hw, p, hAj, hAx, cAi, cAj, cAx, x)
+    for fmt, y in got.items():
+        if exact:
+            assert np.array_equal(y, want), fmt
+        else:
+            assert np.allclose(y, want, rtol=1e-13, atol=0), fmt

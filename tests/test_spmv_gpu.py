@@ -11,6 +11,7 @@ Bars (written here, as the task demands):
     |y_gpu - y_ref| <= TOL * sum_j |a_ij x_j| with TOL = 1e-6 for f64 (north_star) and 1e-5 for f32.
 """
 import itertools
+import os
 
 import numpy as np
 import pytest
@@ -254,6 +255,50 @@ def test_reference_known_answer_matrices(cmi, torch_cuda, orc, known):
     cmi.spmv_csr(5, 4, dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(np.array(g["x"], np.float64), torch), y,
                  accumulate=True)
     assert host(y).tolist() == [183.0, 74.0, 325.0, 510.0, 131.0]
+
+
+# ------------------------------------------------------------------------------------------------
+# the data files the reference's own tests hold (testing/data/{test,laplacian,random_10x10}/*.mtx)
+# ------------------------------------------------------------------------------------------------
+def test_reference_data_files_all_formats(cmi, torch_cuda, orc):
+    """Every file, every format and kernel variant, f64 and f32, plain and accumulate -- against the oracle's
+    result for the same arrays (000_nonzeros.mtx is the empty matrix, 100_nonzeros.mtx the full one)."""
+    from conftest import coo_to_csr, read_mtx, reference_data_files
+    torch = torch_cuda
+    files = reference_data_files()
+    assert len(files) == 19
+    for path in files:
+        rows, cols, I, J, V = read_mtx(path)
+        for dtype in (np.float64, np.float32):
+            Ap, Aj, Ax = coo_to_csr(rows, I, J, V, dtype)
+            x = ((np.arange(cols) % 7 - 3.0) * 0.5).astype(dtype)
+            y0 = ((np.arange(rows) % 5) * 0.25 + 1.0).astype(dtype)
+            hw = orc.optimal_entries_per_row(Ap)
+            width = int(np.diff(Ap).max()) if len(Aj) else 0
+            pitch, eAj, eAx = orc.csr_to_ell(Ap, Aj, Ax, width)
+            p, hAj, hAx, cAi, cAj, cAx = orc.csr_to_hyb(Ap, Aj, Ax, hw)
+            Ai = orc.csr_row_indices(Ap)
+            want, want_acc = {}, {}
+            for w, yy in ((want, None), (want_acc, y0)):
+                w["csr"] = orc.spmv_csr(Ap, Aj, Ax, x, yy)
+                w["coo"] = orc.spmv_coo(rows, Ai, Aj, Ax, x, yy)
+                w["ell"] = orc.spmv_ell(rows, width, pitch, eAj, eAx, x, yy)
+                w["hyb"] = orc.spmv_hyb(rows, hw, p, hAj, hAx, cAi, cAj, cAx, x, yy)
+            if len(Aj) >= 4:  # csr_stream_pipe's documented precondition
+                run_all_formats(cmi, torch, orc, rows, cols, Ap, Aj, Ax, x, want, want_acc, y0, hw, os.path.basename(path))
+            else:             # 0, 1, 2 entries: the table-selected paths
+                dx = dev(x, torch)
+                y = torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
+                cmi.spmv_csr(rows, cols, dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dx, y)
+                assert np.array_equal(host(y), want["csr"]), path
+                y = torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
+                cmi.spmv_coo(rows, cols, dev(Ai, torch), dev(Aj, torch), dev(Ax, torch), dx, y)
+                assert np.array_equal(host(y), want["coo"]), path
+            if len(Aj):
+                pd, off, vals = orc.csr_to_dia(rows, cols, Ap, Aj, Ax)
+                y = torch.full((rows,), 10.0, dtype=dev(x, torch).dtype, device="cuda")
+                cmi.spmv_dia(rows, cols, len(off), pd, dev(off, torch), dev(vals, torch), dev(x, torch), y)
+                assert np.array_equal(host(y), orc.spmv_dia(rows, cols, pd, off, vals, x)), path
 
 
 # ------------------------------------------------------------------------------------------------
