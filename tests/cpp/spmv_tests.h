@@ -276,6 +276,78 @@ template <typename Space> void TestCsrToDiaMatchesHostConversion()
 }
 DECLARE_SPACE_UNITTEST(TestCsrToDiaMatchesHostConversion);
 
+// testing/monitor.cu:5-68, statement by statement
+template <typename Space> void TestMonitorSimple()
+{
+    cusp::array1d<float, Space> b(2), r(2);
+    b[0] = 10; b[1] = 0; r[0] = 10; r[1] = 0;
+    cusp::monitor<float> monitor(b, 5, 0.5, 1.0);
+    ASSERT_EQUAL(monitor.finished(r), false);
+    ASSERT_EQUAL(monitor.iteration_count(), size_t(0)); ASSERT_EQUAL(monitor.iteration_limit(), size_t(5));
+    ASSERT_EQUAL(monitor.relative_tolerance(), 0.5f); ASSERT_EQUAL(monitor.absolute_tolerance(), 1.0f); ASSERT_EQUAL(monitor.tolerance(), 6.0f);
+    ++monitor;
+    ASSERT_EQUAL(monitor.finished(r), false); ASSERT_EQUAL(monitor.iteration_count(), size_t(1)); ASSERT_EQUAL(monitor.residual_norm(), 10.0f);
+    r[0] = 2;
+    ASSERT_EQUAL(monitor.finished(r), true); ASSERT_EQUAL(monitor.iteration_count(), size_t(1)); ASSERT_EQUAL(monitor.residual_norm(), 2.0f);
+    r[0] = 7;
+    ASSERT_EQUAL(monitor.finished(r), false); ASSERT_EQUAL(monitor.iteration_count(), size_t(1)); ASSERT_EQUAL(monitor.residual_norm(), 7.0f);
+    ++monitor;
+    ASSERT_EQUAL(monitor.finished(r), false); ASSERT_EQUAL(monitor.iteration_count(), size_t(2)); ASSERT_EQUAL(monitor.residual_norm(), 7.0f);
+    ++monitor; ++monitor;
+    ASSERT_EQUAL(monitor.finished(r), false); ASSERT_EQUAL(monitor.iteration_count(), size_t(4)); ASSERT_EQUAL(monitor.residual_norm(), 7.0f);
+    ++monitor;
+    ASSERT_EQUAL(monitor.finished(r), true); ASSERT_EQUAL(monitor.iteration_count(), size_t(5)); ASSERT_EQUAL(monitor.residual_norm(), 7.0f);
+    monitor.reset(r);
+    ASSERT_EQUAL(monitor.finished(r), false); ASSERT_EQUAL(monitor.iteration_count(), size_t(0)); ASSERT_EQUAL(monitor.residual_norm(), 7.0f);
+}
+DECLARE_SPACE_UNITTEST(TestMonitorSimple);
+
+// the BLAS-1 routines cg calls, with the vectors and answers of testing/blas.cu:56-140 (axpy, axpby), 252-276
+// (copy), 278-303 (dot; dotc on real data), 335-357 (fill), 407-425 (nrm2), containers and views, size checks
+template <typename Space> void TestBlasKnownAnswers()
+{
+    typedef cusp::array1d<float, Space> Array;
+    typedef typename Array::view View;
+    const float xs[4] = {7.0f, 5.0f, 4.0f, -3.0f}, ys[4] = {0.0f, -2.0f, 0.0f, 5.0f};
+    Array x(4), y(4), z(4, 0), w(3);
+    for (int i = 0; i < 4; i++) { x[i] = xs[i]; y[i] = ys[i]; }
+    cusp::blas::axpy(x, y, 2.0f);
+    { const float e[4] = {14, 8, 8, -1}; for (int i = 0; i < 4; i++) ASSERT_EQUAL(float(y[i]), e[i]); }
+    { View vx(x), vy(y); cusp::blas::axpy(vx, vy, 2.0f); }
+    { const float e[4] = {28, 18, 16, -7}; for (int i = 0; i < 4; i++) ASSERT_EQUAL(float(y[i]), e[i]); }
+    ASSERT_THROWS(cusp::blas::axpy(x, w, 1.0f), cusp::invalid_input_exception);
+
+    for (int i = 0; i < 4; i++) y[i] = ys[i];
+    cusp::blas::axpby(x, y, z, 2.0f, 1.0f);
+    { const float e[4] = {14, 8, 8, -1}; for (int i = 0; i < 4; i++) ASSERT_EQUAL(float(z[i]), e[i]); }
+    cusp::blas::fill(z, 0.0f);
+    { View vx(x), vy(y), vz(z); cusp::blas::axpby(vx, vy, vz, 2.0f, 1.0f); }
+    { const float e[4] = {14, 8, 8, -1}; for (int i = 0; i < 4; i++) ASSERT_EQUAL(float(z[i]), e[i]); }
+    ASSERT_THROWS(cusp::blas::axpby(x, y, w, 2.0f, 1.0f), cusp::invalid_input_exception);
+
+    { Array c(4, -1); cusp::blas::copy(x, c); ASSERT_ARRAYS_EQUAL(x, c); }
+    { Array c(4, -1); View vx(x), vc(c); cusp::blas::copy(vx, vc); ASSERT_ARRAYS_EQUAL(x, c); }
+    ASSERT_THROWS(cusp::blas::copy(w, x), cusp::invalid_input_exception);
+
+    const float x6[6] = {7, 5, 4, -3, 0, 4}, y6[6] = {0, -2, 0, 5, 6, 1};
+    Array a(6), b(6);
+    for (int i = 0; i < 6; i++) { a[i] = x6[i]; b[i] = y6[i]; }
+    ASSERT_EQUAL(cusp::blas::dot(a, b), -21.0f);
+    ASSERT_EQUAL(cusp::blas::dot(View(a), View(b)), -21.0f);
+    ASSERT_EQUAL(cusp::blas::dotc(a, b), -21.0f);
+    ASSERT_THROWS(cusp::blas::dot(a, w), cusp::invalid_input_exception);
+
+    cusp::blas::fill(x, 2.0f);
+    for (int i = 0; i < 4; i++) ASSERT_EQUAL(float(x[i]), 2.0f);
+    { View vx(x); cusp::blas::fill(vx, 1.0f); }
+    for (int i = 0; i < 4; i++) ASSERT_EQUAL(float(x[i]), 1.0f);
+
+    a[5] = 1.0f; // 7 5 4 -3 0 1
+    ASSERT_EQUAL(cusp::blas::nrm2(a), 10.0f);
+    ASSERT_EQUAL(cusp::blas::nrm2(View(a)), 10.0f);
+}
+DECLARE_SPACE_UNITTEST(TestBlasKnownAnswers);
+
 // testing/ell_matrix.cu:5-22
 template <typename Space> void TestEllMatrixBasicConstructor()
 {
