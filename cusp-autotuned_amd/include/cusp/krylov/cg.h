@@ -9,6 +9,7 @@
 
 #include "../array1d.h"
 #include "../blas/blas.h"
+#include "../execution_policy.h"
 #include "../linear_operator.h"
 #include "../monitor.h"
 #include "../multiply.h"
@@ -17,6 +18,10 @@ namespace cusp {
 namespace krylov {
 
 namespace detail {
+// the overloads without a policy must not swallow cg(policy, A, x, b[, monitor]) calls
+template <typename T> struct is_policy : std::is_base_of<cusp::execution_policy<T>, T> {};
+template <typename T> using not_policy = typename std::enable_if<!is_policy<T>::value>::type;
+
 // z <- M r for a matrix-like preconditioner or a linear operator with operator()
 template <typename M, typename X, typename Y> auto apply(const M &m, const X &x, Y &y, int) -> decltype(m(x, y), void()) { m(x, y); }
 template <typename M, typename X, typename Y> void apply(const M &m, const X &x, Y &y, long) { cusp::multiply(m, x, y); }
@@ -134,7 +139,8 @@ void cg_select(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Mo
 
 } // namespace detail
 
-template <typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor, typename Preconditioner>
+template <typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor, typename Preconditioner,
+          typename = detail::not_policy<LinearOperator>>
 void cg(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &monitor, Preconditioner &M)
 {
     if (A.num_rows != A.num_cols) throw cusp::invalid_input_exception("cg: matrix must be square");
@@ -173,7 +179,7 @@ void detail::cg_plain(const LinearOperator &A, VectorType1 &x, const VectorType2
     }
 }
 
-template <typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor>
+template <typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor, typename = detail::not_policy<LinearOperator>>
 void cg(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &monitor)
 {
     typedef typename LinearOperator::value_type ValueType;
@@ -182,7 +188,7 @@ void cg(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &
     cusp::krylov::cg(A, x, b, monitor, M);
 }
 
-template <typename LinearOperator, typename VectorType1, typename VectorType2>
+template <typename LinearOperator, typename VectorType1, typename VectorType2, typename = detail::not_policy<LinearOperator>>
 void cg(const LinearOperator &A, VectorType1 &x, const VectorType2 &b)
 {
     typedef typename LinearOperator::value_type ValueType;
@@ -190,5 +196,45 @@ void cg(const LinearOperator &A, VectorType1 &x, const VectorType2 &b)
     cusp::krylov::cg(A, x, b, monitor);
 }
 
+} // namespace krylov
+} // namespace cusp
+
+// ---- execution-policy overloads (reference cusp/krylov/cg.h: cg(exec, A, x, b[, monitor[, M]])) ---------
+// A policy derived from cusp::execution_policy<Derived> reaches a user `cg(my_policy&, ...)` overload by ADL
+// (testing/cg.cu:11-44); a policy without one gets the memory-space dispatch above.
+namespace cusp {
+namespace krylov {
+namespace detail {
+namespace policy_default {
+template <typename Derived, typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor, typename Preconditioner,
+          typename = typename std::enable_if<std::is_base_of<cusp::execution_policy<Derived>, Derived>::value>::type>
+void cg(Derived &, const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &monitor, Preconditioner &M)
+{
+    cusp::krylov::cg(A, x, b, monitor, M);
+}
+} // namespace policy_default
+} // namespace detail
+
+template <typename Derived, typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor, typename Preconditioner>
+void cg(const cusp::execution_policy<Derived> &exec, const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &monitor, Preconditioner &M)
+{
+    using cusp::krylov::detail::policy_default::cg;
+    cg(const_cast<Derived &>(exec.derived()), A, x, b, monitor, M);
+}
+template <typename Derived, typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor>
+void cg(const cusp::execution_policy<Derived> &exec, const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &monitor)
+{
+    typedef typename LinearOperator::value_type ValueType;
+    typedef typename LinearOperator::memory_space MemorySpace;
+    cusp::identity_operator<ValueType, MemorySpace> M(A.num_rows, A.num_cols);
+    cusp::krylov::cg(exec, A, x, b, monitor, M);
+}
+template <typename Derived, typename LinearOperator, typename VectorType1, typename VectorType2>
+void cg(const cusp::execution_policy<Derived> &exec, const LinearOperator &A, VectorType1 &x, const VectorType2 &b)
+{
+    typedef typename LinearOperator::value_type ValueType;
+    cusp::monitor<ValueType> monitor(b);
+    cusp::krylov::cg(exec, A, x, b, monitor);
+}
 } // namespace krylov
 } // namespace cusp

@@ -478,6 +478,29 @@ template <typename Space> void TestMultiplyDispatch()
 }
 DECLARE_SPACE_UNITTEST(TestMultiplyDispatch);
 
+// testing/cg.cu:11-44: cg(policy, ...) reaches a user overload by ADL; a policy without one solves
+template <class LinearOperator, class VectorType1, class VectorType2, class Monitor, class Preconditioner>
+void cg(my_system &system, const LinearOperator &, VectorType1 &, const VectorType2 &, Monitor &, Preconditioner &) { system.validate_dispatch(); }
+
+template <typename Space> void TestConjugateGradientDispatch()
+{
+    cusp::csr_matrix<int, float, Space> A;
+    cusp::gallery::poisson5pt(A, 10, 10);
+    cusp::array1d<float, Space> x(A.num_rows, 0.0f);
+    cusp::monitor<float> monitor(x, 20, 1e-4);
+    cusp::identity_operator<float, Space> M(A.num_rows, A.num_cols);
+    my_system sys(0);
+    cusp::krylov::cg(sys, A, x, x, monitor, M);
+    ASSERT_EQUAL(true, sys.is_valid());
+    plain_system plain;
+    cusp::array1d<float, Space> b(A.num_rows, 1.0f);
+    cusp::monitor<float> m2(b, 100, 1e-4);
+    cusp::krylov::cg(plain, A, x, b, m2);
+    ASSERT_EQUAL(m2.converged(), true);
+    cusp::krylov::cg(cusp::hip::par, A, x, b);
+}
+DECLARE_SPACE_UNITTEST(TestConjugateGradientDispatch);
+
 // ------------------------------------------------------------------------------------------------
 // error behaviour of the boundary
 template <typename Space> void TestMultiplyErrors()
