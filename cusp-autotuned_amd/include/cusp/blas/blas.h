@@ -9,6 +9,7 @@
 #include <cmath>
 
 #include "../array1d.h"
+#include "../execution_policy.h"
 
 namespace cusp {
 namespace blas {
@@ -122,6 +123,39 @@ template <typename X, typename S> void fill(X &x, S v) { detail::fill(x, static_
 template <typename X, typename Y> typename X::value_type dot(const X &x, const Y &y) { detail::same_size(x, y); return detail::dot(x, y, typename X::memory_space()); }
 template <typename X, typename Y> typename X::value_type dotc(const X &x, const Y &y) { return dot(x, y); } // real types: conj is the identity
 template <typename X> typename X::value_type nrm2(const X &x) { return detail::nrm2(x, typename X::memory_space()); }
+
+// ---- execution-policy overloads (reference cusp/blas/blas.h: every routine also takes a policy first) ----
+// A policy derived from cusp::execution_policy<Derived> reaches a user overload `axpy(my_policy&, ...)` by
+// ADL (testing/blas.cu:752-1208); a policy without one gets the memory-space dispatch above.
+namespace detail {
+namespace policy_default {
+template <typename D> using if_policy = typename std::enable_if<std::is_base_of<cusp::execution_policy<D>, D>::value>::type;
+template <typename D, typename X, typename Y, typename S, typename = if_policy<D>> void axpy(D &, const X &x, Y &y, S a) { cusp::blas::axpy(x, y, a); }
+template <typename D, typename X, typename Y, typename Z, typename S1, typename S2, typename = if_policy<D>>
+void axpby(D &, const X &x, const Y &y, Z &z, S1 a, S2 b) { cusp::blas::axpby(x, y, z, a, b); }
+template <typename D, typename X, typename Y, typename = if_policy<D>> void copy(D &, const X &x, Y &y) { cusp::blas::copy(x, y); }
+template <typename D, typename X, typename S, typename = if_policy<D>> void fill(D &, X &x, S v) { cusp::blas::fill(x, v); }
+template <typename D, typename X, typename Y, typename = if_policy<D>> typename X::value_type dot(D &, const X &x, const Y &y) { return cusp::blas::dot(x, y); }
+template <typename D, typename X, typename Y, typename = if_policy<D>> typename X::value_type dotc(D &, const X &x, const Y &y) { return cusp::blas::dotc(x, y); }
+template <typename D, typename X, typename = if_policy<D>> typename X::value_type nrm2(D &, const X &x) { return cusp::blas::nrm2(x); }
+} // namespace policy_default
+} // namespace detail
+
+template <typename D, typename X, typename Y, typename S> void axpy(const cusp::execution_policy<D> &exec, const X &x, Y &y, S alpha)
+{ using detail::policy_default::axpy; axpy(const_cast<D &>(exec.derived()), x, y, alpha); }
+template <typename D, typename X, typename Y, typename Z, typename S1, typename S2>
+void axpby(const cusp::execution_policy<D> &exec, const X &x, const Y &y, Z &z, S1 alpha, S2 beta)
+{ using detail::policy_default::axpby; axpby(const_cast<D &>(exec.derived()), x, y, z, alpha, beta); }
+template <typename D, typename X, typename Y> void copy(const cusp::execution_policy<D> &exec, const X &x, Y &y)
+{ using detail::policy_default::copy; copy(const_cast<D &>(exec.derived()), x, y); }
+template <typename D, typename X, typename S> void fill(const cusp::execution_policy<D> &exec, X &x, S v)
+{ using detail::policy_default::fill; fill(const_cast<D &>(exec.derived()), x, v); }
+template <typename D, typename X, typename Y> typename X::value_type dot(const cusp::execution_policy<D> &exec, const X &x, const Y &y)
+{ using detail::policy_default::dot; return dot(const_cast<D &>(exec.derived()), x, y); }
+template <typename D, typename X, typename Y> typename X::value_type dotc(const cusp::execution_policy<D> &exec, const X &x, const Y &y)
+{ using detail::policy_default::dotc; return dotc(const_cast<D &>(exec.derived()), x, y); }
+template <typename D, typename X> typename X::value_type nrm2(const cusp::execution_policy<D> &exec, const X &x)
+{ using detail::policy_default::nrm2; return nrm2(const_cast<D &>(exec.derived()), x); }
 
 } // namespace blas
 } // namespace cusp

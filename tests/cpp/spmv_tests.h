@@ -501,6 +501,34 @@ template <typename Space> void TestConjugateGradientDispatch()
 }
 DECLARE_SPACE_UNITTEST(TestConjugateGradientDispatch);
 
+// testing/blas.cu:752-1208 for the routines cg uses: blas::f(policy, ...) reaches the user's overload by ADL
+template <typename A1, typename A2, typename S> void axpy(my_system &s, const A1 &, A2 &, const S) { s.validate_dispatch(); }
+template <typename A1, typename A2, typename A3, typename S1, typename S2> void axpby(my_system &s, const A1 &, const A2 &, A3 &, S1, S2) { s.validate_dispatch(); }
+template <typename A1, typename A2> void copy(my_system &s, const A1 &, A2 &) { s.validate_dispatch(); }
+template <typename A1, typename S> void fill(my_system &s, A1 &, const S) { s.validate_dispatch(); }
+template <typename A1, typename A2> typename A1::value_type dot(my_system &s, const A1 &, const A2 &) { s.validate_dispatch(); return 0; }
+template <typename A1, typename A2> typename A1::value_type dotc(my_system &s, const A1 &, const A2 &) { s.validate_dispatch(); return 0; }
+template <typename A1> typename A1::value_type nrm2(my_system &s, const A1 &) { s.validate_dispatch(); return 0; }
+
+template <typename Space> void TestBlasDispatch()
+{
+    cusp::array1d<float, Space> x(4, 1.0f), y(4, 2.0f), z(4, 0.0f);
+    { my_system sys(0); cusp::blas::axpy(sys, x, y, 2.0f); ASSERT_EQUAL(true, sys.is_valid()); }
+    { my_system sys(0); cusp::blas::axpby(sys, x, y, z, 2.0f, 1.0f); ASSERT_EQUAL(true, sys.is_valid()); }
+    { my_system sys(0); cusp::blas::copy(sys, x, y); ASSERT_EQUAL(true, sys.is_valid()); }
+    { my_system sys(0); cusp::blas::fill(sys, x, 3.0f); ASSERT_EQUAL(true, sys.is_valid()); }
+    { my_system sys(0); cusp::blas::dot(sys, x, y); ASSERT_EQUAL(true, sys.is_valid()); }
+    { my_system sys(0); cusp::blas::dotc(sys, x, y); ASSERT_EQUAL(true, sys.is_valid()); }
+    { my_system sys(0); cusp::blas::nrm2(sys, x); ASSERT_EQUAL(true, sys.is_valid()); }
+    ASSERT_EQUAL(float(y[0]), 2.0f); // the user overloads did nothing
+    plain_system plain;              // a policy without overloads: the real routines
+    cusp::blas::axpy(plain, x, y, 2.0f);
+    ASSERT_EQUAL(float(y[3]), 4.0f);
+    ASSERT_EQUAL(cusp::blas::dot(cusp::hip::par, x, y), 16.0f);
+    ASSERT_EQUAL(cusp::blas::nrm2(plain, x), 2.0f);
+}
+DECLARE_SPACE_UNITTEST(TestBlasDispatch);
+
 // ------------------------------------------------------------------------------------------------
 // error behaviour of the boundary
 template <typename Space> void TestMultiplyErrors()
