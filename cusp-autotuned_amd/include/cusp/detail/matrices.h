@@ -107,6 +107,10 @@ csr_matrix_view<I, V, M> make_csr_matrix_view(size_t rows, size_t cols, size_t e
 {
     return csr_matrix_view<I, V, M>(rows, cols, entries, ro, ci, v);
 }
+// reference cusp/csr_matrix.h make_csr_matrix_view(matrix | const matrix | view) (testing/csr_matrix_view.cu:95-194)
+template <typename I, typename V, typename M> csr_matrix_view<I, V, M> make_csr_matrix_view(csr_matrix<I, V, M> &m) { return csr_matrix_view<I, V, M>(m); }
+template <typename I, typename V, typename M> csr_matrix_view<const I, const V, M> make_csr_matrix_view(const csr_matrix<I, V, M> &m) { return csr_matrix_view<const I, const V, M>(m); }
+template <typename I, typename V, typename M> csr_matrix_view<I, V, M> make_csr_matrix_view(const csr_matrix_view<I, V, M> &v) { return v; }
 
 // ---------------------------------------------------------------------------------------------
 // COO
@@ -198,6 +202,15 @@ public:
     coo_matrix_view(container &m) : Parent(m), row_indices(m.row_indices), column_indices(m.column_indices), values(m.values) {}
     coo_matrix_view(const container &m) : Parent(m), row_indices(m.row_indices), column_indices(m.column_indices), values(m.values) {}
 };
+
+template <typename I, typename V, typename M>
+coo_matrix_view<I, V, M> make_coo_matrix_view(size_t rows, size_t cols, size_t entries, array1d_view<I, M> ri, array1d_view<I, M> ci, array1d_view<V, M> v)
+{
+    return coo_matrix_view<I, V, M>(rows, cols, entries, ri, ci, v);
+}
+template <typename I, typename V, typename M> coo_matrix_view<I, V, M> make_coo_matrix_view(coo_matrix<I, V, M> &m) { return coo_matrix_view<I, V, M>(m); }
+template <typename I, typename V, typename M> coo_matrix_view<const I, const V, M> make_coo_matrix_view(const coo_matrix<I, V, M> &m) { return coo_matrix_view<const I, const V, M>(m); }
+template <typename I, typename V, typename M> coo_matrix_view<I, V, M> make_coo_matrix_view(const coo_matrix_view<I, V, M> &v) { return v; }
 
 // ---------------------------------------------------------------------------------------------
 // ELL

@@ -276,6 +276,167 @@ template <typename Space> void TestCsrToDiaMatchesHostConversion()
 }
 DECLARE_SPACE_UNITTEST(TestCsrToDiaMatchesHostConversion);
 
+// ------------------------------------------------------------------------------------------------
+// containers: testing/{csr,coo,ell,dia,hyb}_matrix.cu -- BasicConstructor, CopyConstructor, Resize, Swap, Rebind
+template <typename Space> void TestContainerShapes()
+{
+    { // csr_matrix.cu:4-16, 57-70
+        cusp::csr_matrix<int, float, Space> m(3, 2, 6), r;
+        r.resize(3, 2, 6);
+        for (auto *p : {&m, &r}) {
+            ASSERT_EQUAL(p->num_rows, size_t(3)); ASSERT_EQUAL(p->num_cols, size_t(2)); ASSERT_EQUAL(p->num_entries, size_t(6));
+            ASSERT_EQUAL(p->row_offsets.size(), size_t(4)); ASSERT_EQUAL(p->column_indices.size(), size_t(6)); ASSERT_EQUAL(p->values.size(), size_t(6));
+        }
+    }
+    { // coo_matrix.cu:4-16
+        cusp::coo_matrix<int, float, Space> m(3, 2, 6);
+        ASSERT_EQUAL(m.row_indices.size(), size_t(6)); ASSERT_EQUAL(m.column_indices.size(), size_t(6)); ASSERT_EQUAL(m.values.size(), size_t(6));
+    }
+    { // ell_matrix.cu:4-21, 99-117
+        cusp::ell_matrix<int, float, Space> m(3, 2, 6, 2, 4), r;
+        r.resize(3, 2, 6, 2, 4);
+        for (auto *p : {&m, &r}) {
+            ASSERT_EQUAL(p->num_rows, size_t(3)); ASSERT_EQUAL(p->num_cols, size_t(2)); ASSERT_EQUAL(p->num_entries, size_t(6));
+            ASSERT_EQUAL(p->column_indices.num_cols, size_t(2)); ASSERT_EQUAL(p->column_indices.num_rows, size_t(3));
+            ASSERT_EQUAL(p->column_indices.pitch, size_t(4)); ASSERT_EQUAL(p->column_indices.num_entries, size_t(6));
+            ASSERT_EQUAL(p->values.num_cols, size_t(2)); ASSERT_EQUAL(p->values.num_rows, size_t(3)); ASSERT_EQUAL(p->values.pitch, size_t(4));
+        }
+    }
+    { // dia_matrix.cu:4-17, 57-71
+        cusp::dia_matrix<int, float, Space> m(4, 5, 7, 3, 8), r;
+        r.resize(4, 5, 7, 3, 8);
+        for (auto *p : {&m, &r}) {
+            ASSERT_EQUAL(p->num_rows, size_t(4)); ASSERT_EQUAL(p->num_cols, size_t(5)); ASSERT_EQUAL(p->num_entries, size_t(7));
+            ASSERT_EQUAL(p->diagonal_offsets.size(), size_t(3));
+            ASSERT_EQUAL(p->values.num_rows, size_t(4)); ASSERT_EQUAL(p->values.num_cols, size_t(3)); ASSERT_EQUAL(p->values.pitch, size_t(8));
+        }
+    }
+    { // hyb_matrix.cu:4-30, 92-119
+        cusp::hyb_matrix<int, float, Space> m(10, 10, 42, 13, 5, 16), r;
+        r.resize(10, 10, 42, 13, 5, 16);
+        for (auto *p : {&m, &r}) {
+            ASSERT_EQUAL(p->num_rows, size_t(10)); ASSERT_EQUAL(p->num_cols, size_t(10)); ASSERT_EQUAL(p->num_entries, size_t(55));
+            ASSERT_EQUAL(p->ell.num_rows, size_t(10)); ASSERT_EQUAL(p->ell.num_entries, size_t(42));
+            ASSERT_EQUAL(p->ell.column_indices.num_rows, size_t(10)); ASSERT_EQUAL(p->ell.column_indices.num_cols, size_t(5)); ASSERT_EQUAL(p->ell.column_indices.pitch, size_t(16));
+            ASSERT_EQUAL(p->ell.values.num_cols, size_t(5)); ASSERT_EQUAL(p->ell.values.pitch, size_t(16));
+            ASSERT_EQUAL(p->coo.num_rows, size_t(10)); ASSERT_EQUAL(p->coo.num_entries, size_t(13));
+            ASSERT_EQUAL(p->coo.row_indices.size(), size_t(13)); ASSERT_EQUAL(p->coo.column_indices.size(), size_t(13)); ASSERT_EQUAL(p->coo.values.size(), size_t(13));
+        }
+    }
+}
+DECLARE_SPACE_UNITTEST(TestContainerShapes);
+
+template <typename Space> void TestContainerCopySwapRebind()
+{
+    // csr_matrix.cu:18-54, 73-117 (the 3x2 and 1x2 / 3x1 examples)
+    cusp::csr_matrix<int, float, Space> m(3, 2, 6);
+    for (int i = 0; i < 4; i++) m.row_offsets[i] = 2 * i;
+    for (int i = 0; i < 6; i++) { m.column_indices[i] = i % 2; m.values[i] = float(i); }
+    cusp::csr_matrix<int, float, Space> c(m);
+    ASSERT_EQUAL(c.num_rows, size_t(3)); ASSERT_EQUAL(c.num_cols, size_t(2)); ASSERT_EQUAL(c.num_entries, size_t(6));
+    ASSERT_ARRAYS_EQUAL(c.row_offsets, m.row_offsets); ASSERT_ARRAYS_EQUAL(c.column_indices, m.column_indices); ASSERT_ARRAYS_EQUAL(c.values, m.values);
+
+    cusp::csr_matrix<int, float, Space> A(1, 2, 2), B(3, 1, 3);
+    A.row_offsets[0] = 0; A.row_offsets[1] = 2;
+    A.column_indices[0] = 0; A.values[0] = 0; A.column_indices[1] = 1; A.values[1] = 1;
+    for (int i = 0; i < 4; i++) B.row_offsets[i] = i;
+    for (int i = 0; i < 3; i++) { B.column_indices[i] = 0; B.values[i] = float(i); }
+    cusp::csr_matrix<int, float, Space> A_copy(A), B_copy(B);
+    A.swap(B);
+    ASSERT_EQUAL(A.num_rows, size_t(3)); ASSERT_EQUAL(A.num_cols, size_t(1)); ASSERT_EQUAL(A.num_entries, size_t(3));
+    ASSERT_ARRAYS_EQUAL(A.row_offsets, B_copy.row_offsets); ASSERT_ARRAYS_EQUAL(A.column_indices, B_copy.column_indices); ASSERT_ARRAYS_EQUAL(A.values, B_copy.values);
+    ASSERT_EQUAL(B.num_rows, size_t(1)); ASSERT_EQUAL(B.num_cols, size_t(2)); ASSERT_EQUAL(B.num_entries, size_t(2));
+    ASSERT_ARRAYS_EQUAL(B.row_offsets, A_copy.row_offsets); ASSERT_ARRAYS_EQUAL(B.values, A_copy.values);
+
+    // the other formats: copy through the same space, swap, and rebind to the OTHER memory space (…_matrix.cu Rebind)
+    cusp::csr_matrix<int, float, cusp::host_memory> h;
+    cusp::gallery::poisson5pt(h, 4, 3);
+    cusp::coo_matrix<int, float, Space> coo(h), coo2; coo2.swap(coo);
+    ASSERT_EQUAL(coo.num_entries, size_t(0)); ASSERT_EQUAL(coo2.num_entries, h.num_entries);
+    cusp::ell_matrix<int, float, Space> ell(h), ell2(ell);
+    ASSERT_ARRAYS_EQUAL(ell2.column_indices.values, ell.column_indices.values); ASSERT_ARRAYS_EQUAL(ell2.values.values, ell.values.values);
+    cusp::dia_matrix<int, float, Space> dia(h), dia2; dia2.swap(dia);
+    ASSERT_EQUAL(dia2.diagonal_offsets.size(), size_t(5)); ASSERT_EQUAL(dia.diagonal_offsets.size(), size_t(0));
+    cusp::hyb_matrix<int, float, Space> hyb(h), hyb2(hyb);
+    ASSERT_EQUAL(hyb2.num_entries, h.num_entries);
+    typedef typename cusp::csr_matrix<int, float, cusp::host_memory>::template rebind<Space>::type Rebound;
+    Rebound there(h);
+    ASSERT_EQUAL(there.num_entries, h.num_entries);
+    typedef typename cusp::ell_matrix<int, float, Space>::template rebind<cusp::host_memory>::type EllHost;
+    EllHost back(ell2);
+    cusp::csr_matrix<int, float, cusp::host_memory> h2(back);
+    ASSERT_ARRAYS_EQUAL(h2.column_indices, h.column_indices); ASSERT_ARRAYS_EQUAL(h2.values, h.values);
+}
+DECLARE_SPACE_UNITTEST(TestContainerCopySwapRebind);
+
+// testing/csr_matrix_view.cu:6-194 (views here are typed by element + memory space, not by Thrust iterator:
+// `typename Matrix::view`; the tests compare the addresses the views alias)
+template <typename Space> void TestCsrMatrixViews()
+{
+    typedef cusp::csr_matrix<int, float, Space> Matrix;
+    typedef typename Matrix::view View;
+    Matrix M(3, 2, 6);
+    auto same = [&](const View &v) {
+        ASSERT_EQUAL(v.num_rows, size_t(3)); ASSERT_EQUAL(v.num_cols, size_t(2)); ASSERT_EQUAL(v.num_entries, size_t(6));
+        ASSERT_TRUE(v.row_offsets.data() == M.row_offsets.data() && v.row_offsets.size() == M.row_offsets.size());
+        ASSERT_TRUE(v.column_indices.data() == M.column_indices.data() && v.column_indices.size() == M.column_indices.size());
+        ASSERT_TRUE(v.values.data() == M.values.data() && v.values.size() == M.values.size());
+    };
+    View V(3, 2, 6, cusp::make_array1d_view(M.row_offsets), cusp::make_array1d_view(M.column_indices), cusp::make_array1d_view(M.values));
+    same(V);
+    View W(M); same(W);
+    View A = M; same(A);             // :52-92 assignment from matrix, from view
+    View B = A; same(B);
+    same(cusp::make_csr_matrix_view(M));
+    View X = cusp::make_csr_matrix_view(M);
+    View Y = cusp::make_csr_matrix_view(X);
+    Y.row_offsets[0] = 0; Y.column_indices[0] = 1; Y.values[0] = 2; // writes through the view reach the matrix
+    same(Y);
+    ASSERT_EQUAL(int(M.column_indices[0]), 1); ASSERT_EQUAL(float(M.values[0]), 2.0f);
+    const Matrix C(3, 2, 6);
+    ASSERT_EQUAL(cusp::make_csr_matrix_view(C).num_entries, size_t(6));
+    ASSERT_TRUE(cusp::make_csr_matrix_view(C).values.data() == C.values.data());
+    // a view multiplies like its matrix
+    cusp::csr_matrix<int, float, Space> P;
+    cusp::gallery::poisson5pt(P, 4, 4);
+    cusp::array1d<float, Space> x(16, 1.0f), y1(16, 9.0f), y2(16, -9.0f);
+    cusp::multiply(P, x, y1);
+    typename cusp::csr_matrix<int, float, Space>::view PV(P);
+    cusp::multiply(PV, x, y2);
+    ASSERT_ARRAYS_EQUAL(y1, y2);
+    typedef cusp::coo_matrix<int, float, Space> Coo;
+    Coo K(P);
+    typename Coo::view KV = cusp::make_coo_matrix_view(K);
+    cusp::multiply(KV, x, y2);
+    ASSERT_ARRAYS_EQUAL(y1, y2);
+}
+DECLARE_SPACE_UNITTEST(TestCsrMatrixViews);
+
+// coo_matrix.cu:130-267: sort_by_row, sort_by_row_and_column, is_sorted_*
+template <typename Space> void TestCooMatrixSorting()
+{
+    {
+        cusp::coo_matrix<int, float, Space> A(5, 5, 4);
+        const int r[4] = {3, 4, 1, 2}, c[4] = {1, 2, 3, 4};
+        for (int i = 0; i < 4; i++) { A.row_indices[i] = r[i]; A.column_indices[i] = c[i]; A.values[i] = float(i + 1); }
+        ASSERT_EQUAL(A.is_sorted_by_row(), false); ASSERT_EQUAL(A.is_sorted_by_row_and_column(), false);
+        A.sort_by_row();
+        const int er[4] = {1, 2, 3, 4}, ec[4] = {3, 4, 1, 2}; const float ev[4] = {3, 4, 1, 2};
+        for (int i = 0; i < 4; i++) { ASSERT_EQUAL(int(A.row_indices[i]), er[i]); ASSERT_EQUAL(int(A.column_indices[i]), ec[i]); ASSERT_EQUAL(float(A.values[i]), ev[i]); }
+        ASSERT_EQUAL(A.is_sorted_by_row(), true);
+    }
+    {
+        cusp::coo_matrix<int, float, Space> A(5, 5, 7);
+        const int r[7] = {3, 4, 1, 2, 1, 0, 2}, c[7] = {1, 2, 3, 2, 2, 3, 1};
+        for (int i = 0; i < 7; i++) { A.row_indices[i] = r[i]; A.column_indices[i] = c[i]; A.values[i] = float(i + 1); }
+        A.sort_by_row_and_column();
+        const int er[7] = {0, 1, 1, 2, 2, 3, 4}, ec[7] = {3, 2, 3, 1, 2, 1, 2}; const float ev[7] = {6, 5, 3, 7, 4, 1, 2};
+        for (int i = 0; i < 7; i++) { ASSERT_EQUAL(int(A.row_indices[i]), er[i]); ASSERT_EQUAL(int(A.column_indices[i]), ec[i]); ASSERT_EQUAL(float(A.values[i]), ev[i]); }
+        ASSERT_EQUAL(A.is_sorted_by_row_and_column(), true);
+    }
+}
+DECLARE_SPACE_UNITTEST(TestCooMatrixSorting);
+
 // testing/monitor.cu:5-68, statement by statement
 template <typename Space> void TestMonitorSimple()
 {
