@@ -53,7 +53,8 @@ def _worker(rank, world, port, mode, m, n, out_dir):
         y2 = torch.empty_like(y)
         sh.multiply(y2)
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), y=y.numpy(), y2=y2.numpy(), lo=lo, hi=hi,
-                 mode=sh.vec.plan.mode, recv=sh.vec.plan.recv_values, ag=sh.vec.plan.allgather_values)
+                 mode=sh.vec.plan.mode, recv=sh.vec.plan.recv_values, ag=sh.vec.plan.allgather_values,
+                 pieces=np.array(sh.halo_ranges()))
     finally:
         dist.destroy_process_group()
 
@@ -73,7 +74,10 @@ def test_sharded_spmv_gloo(tmp_path, orc, mode, world, m, n):
     assert parts[0]["lo"] == 0 and parts[-1]["hi"] == N
     assert np.array_equal(np.concatenate([p["y"] for p in parts]), want)
     assert np.array_equal(np.concatenate([p["y2"] for p in parts]), want2)
-    for p in parts:
+    for r, p in enumerate(parts):
+        # 5-pt Poisson: own slice + the halo on either side is ONE contiguous piece of the full-length buffer
+        lo, hi = int(p["lo"]), int(p["hi"])
+        assert p["pieces"].tolist() == [[max(lo - m, 0), min(hi + m, N)]], (r, p["pieces"])
         if mode != "auto":
             assert str(p["mode"]) == mode
         if str(p["mode"]) == "halo":
