@@ -13,7 +13,7 @@ _lib = None
 FORMAT_CSR, FORMAT_ELL, FORMAT_DIA, FORMAT_COO, FORMAT_HYB = 0, 1, 2, 3, 4
 F64, F32 = 0, 1
 KERNEL_AUTO = 0
-CSR_SCALAR, CSR_VECTOR, CSR_STREAM, CSR_STREAM_PIPE = 1, 2, 3, 4
+CSR_SCALAR, CSR_VECTOR, CSR_STREAM, CSR_STREAM_PIPE, CSR_BALANCED = 1, 2, 3, 4, 5
 ELL_ROW, DIA_ROW, COO_SEGMENTED, COO_LANE4 = 10, 20, 30, 31
 
 
@@ -110,6 +110,7 @@ def _declare(L):
     L.cmi_poisson5pt_shard_entries.restype = c_int64
     L.cmi_poisson5pt_shard_entries.argtypes = [i64, i64, i64, i64]
     L.cmi_csr_row_indices.argtypes = [i64, vp, vp, vp]
+    L.cmi_csr_max_row_length.argtypes = [i64, vp, POINTER(c_int64), vp]
     L.cmi_csr_diagonals.argtypes = [i64, i64, vp, vp, vp, vp, i64, POINTER(c_int64), vp]
     for suf in ("f64", "f32"):
         getattr(L, f"cmi_csr_to_dia_{suf}").argtypes = [i64, i64, vp, vp, vp, i64, i64, vp, vp, vp, vp]

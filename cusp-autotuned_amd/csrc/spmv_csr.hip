@@ -19,6 +19,8 @@
 // SpMV is HBM-bound (0.125 flop/byte): no MFMA.  Algorithmic bytes per call:
 //   12*nnz + 20*num_rows + 4   (Ap once, Aj once, Ax once, x once, y once; f64).
 #include "common.h"
+#include <cstdlib>
+#include <mutex>
 
 namespace cmi {
 
@@ -405,6 +407,233 @@ csr_stream_pipe_kernel(int64_t num_rows, int64_t num_entries, const int *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// csr_balanced: merge-path split of (row ends + entries) -- for irregular row lengths
+// ---------------------------------------------------------------------------------------------
+// The other kernels give a workgroup ROWS; one row of a million entries then serialises a workgroup
+// (measured: 8 such rows in a 2M-row matrix take 37 ms instead of 50 us).  Here the unit of work is a
+// tile of kBalItems ITEMS of the merged sequence "entry 0, entry 1, ..., row-0-ends, entry k, ..." --
+// consuming an entry costs one product, consuming a row end one store -- so every tile does the same
+// amount of work whatever the row lengths, empty rows included (Merrill & Garland's merge-based SpMV;
+// the reference's KTT `csr_kernel_balanced`, cuda/ktt/kernels/csr_kernel.h:316-375, splits entries only
+// and needs a row_starts array recomputed on the host side).  A workgroup owns a contiguous chunk of
+// tiles: ONE cooperative 256-ary search of the row offsets finds where its chunk starts, after that the
+// end of a tile is the start of the next.  Per tile: the row offsets and the products go to LDS (16-byte
+// vector loads, as csr_stream), then a group of lanes per row (1..64, chosen per tile from the number of
+// rows in it) sums the row's segment.  Rows that lie inside one tile are stored (or added to y when
+// accumulating) without atomics; the first and last row of a tile may continue in a neighbour tile and
+// go through global_atomic_add -- so y is zero-filled first when not accumulating.  Re-associates the
+// row sums: parity class of csr_vector (<= 1e-6 relative), not bit-exact.
+constexpr int kBalBlock = 256;
+constexpr int kBalItems = 1024; // items per tile = 4 per lane
+
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(kBalBlock)
+csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ Ap, const int *__restrict__ Aj,
+                    const T *__restrict__ Ax, const T *__restrict__ x, T *__restrict__ y, int64_t num_tiles, int accumulate)
+{
+    __shared__ __attribute__((aligned(16))) T prod[kBalItems + 8];
+    __shared__ int ro[kBalItems + 2];
+    __shared__ int wave_counts[kBalBlock / kWave];
+    const int tid = threadIdx.x;
+
+    const int64_t per = (num_tiles + gridDim.x - 1) / gridDim.x;
+    const int64_t t_begin = (int64_t)blockIdx.x * per;
+    const int64_t t_end = t_begin + per < num_tiles ? t_begin + per : num_tiles;
+    if (t_begin >= t_end) return; // whole workgroup
+
+    // ---- where does item t_begin * kBalItems fall?  i0 = rows whose end item precedes it.  Row i's end
+    //      is item Ap[i+1] + i of the merged sequence (strictly increasing in i): 256-ary search. ----
+    const int64_t d0 = t_begin * kBalItems;
+    int64_t lo = 0, hi = num_rows;
+    while (lo < hi) {
+        const int64_t step = (hi - lo + kBalBlock - 1) / kBalBlock;
+        const int64_t p = lo + (int64_t)tid * step;
+        const int consumed = p < hi ? ((int64_t)Ap[p + 1] + p < d0) : 0;
+        const int c = __syncthreads_count(consumed); // the true probes are a prefix
+        if (c == 0) { hi = lo; break; }
+        const int64_t last_true = lo + (int64_t)(c - 1) * step;
+        const int64_t first_false = last_true + step;
+        lo = last_true + 1;
+        hi = first_false < hi ? first_false : hi;
+    }
+    int64_t i0 = lo;          // first row not yet finished
+    int64_t j0 = d0 - i0;     // first entry not yet consumed
+
+    for (int64_t t = t_begin; t < t_end; t++) {
+        const int64_t d1 = (t + 1) * kBalItems; // items [t*kBalItems, d1)
+        // ---- row offsets of the rows that could end in this tile ----
+        const int avail = (int)((num_rows - i0) < kBalItems ? (num_rows - i0) : kBalItems);
+        for (int k = tid; k <= avail; k += kBalBlock) ro[k] = Ap[i0 + k];
+        __syncthreads();
+        // rows ending in the tile: end item Ap[i+1] + i < d1 (a prefix of the candidates)
+        int mine = 0;
+        for (int k = tid; k < avail; k += kBalBlock) mine += ((int64_t)ro[k + 1] + i0 + k < d1);
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+        if ((tid & (kWave - 1)) == 0) wave_counts[tid / kWave] = mine;
+        __syncthreads();
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < kBalBlock / kWave; w++) c += wave_counts[w];
+        int64_t j1 = j0 + (kBalItems - c);
+        if (j1 > num_entries) j1 = num_entries;
+        // the row after the last finished one may have its first entries here
+        const bool tail_row = (i0 + c < num_rows) && (j1 > (int64_t)ro[c]);
+        const int nr = c + (tail_row ? 1 : 0);
+
+        // ---- products of entries [j0, j1) into LDS ----
+        const int base = VEC ? (int)(j0 & ~(int64_t)3) : (int)j0;
+        const int span = (int)(j1 - base);
+        if constexpr (VEC) {
+            for (int v = tid * 4; v < span; v += kBalBlock * 4) {
+                const int e = base + v;
+                T p0, p1, p2, p3;
+                if ((int64_t)e + 4 <= num_entries) {
+                    const int4v cidx = *reinterpret_cast<const int4v *>(Aj + e);
+                    if constexpr (sizeof(T) == 8) {
+                        const double2v v01 = *reinterpret_cast<const double2v *>(Ax + e);
+                        const double2v v23 = *reinterpret_cast<const double2v *>(Ax + e + 2);
+                        p0 = v01.x * x[cidx.x]; p1 = v01.y * x[cidx.y]; p2 = v23.x * x[cidx.z]; p3 = v23.y * x[cidx.w];
+                    } else {
+                        const float4v vv = *reinterpret_cast<const float4v *>(Ax + e);
+                        p0 = vv.x * x[cidx.x]; p1 = vv.y * x[cidx.y]; p2 = vv.z * x[cidx.z]; p3 = vv.w * x[cidx.w];
+                    }
+                } else {
+                    p0 = (int64_t)e + 0 < num_entries ? Ax[e + 0] * x[Aj[e + 0]] : T(0);
+                    p1 = (int64_t)e + 1 < num_entries ? Ax[e + 1] * x[Aj[e + 1]] : T(0);
+                    p2 = (int64_t)e + 2 < num_entries ? Ax[e + 2] * x[Aj[e + 2]] : T(0);
+                    p3 = (int64_t)e + 3 < num_entries ? Ax[e + 3] * x[Aj[e + 3]] : T(0);
+                }
+                prod[v + 0] = p0; prod[v + 1] = p1; prod[v + 2] = p2; prod[v + 3] = p3;
+            }
+        } else {
+            for (int v = tid; v < span; v += kBalBlock) prod[v] = Ax[base + v] * x[Aj[base + v]];
+        }
+        __syncthreads();
+
+        // ---- row segments: tpr lanes per row, tpr = largest power of two with 256/tpr >= rows (<= 64) ----
+        int tpr = 1;
+        while (tpr < kWave && (kBalBlock / (tpr * 2)) >= nr) tpr *= 2;
+        const int groups = kBalBlock / tpr;
+        const int grp = tid / tpr, sub = tid - grp * tpr;
+        for (int k = grp; k < nr; k += groups) { // the same k for every lane of a group
+            int64_t a = ro[k], b = (k < c) ? (int64_t)ro[k + 1] : j1;
+            const bool whole = (a >= j0) && (k < c); // starts and ends inside this tile
+            if (a < j0) a = j0;
+            if (b > j1) b = j1;
+            T sum = T(0);
+            for (int64_t j = a + sub; j < b; j += tpr) sum = sum + prod[j - base];
+            for (int o = tpr >> 1; o > 0; o >>= 1) sum = sum + __shfl_down(sum, o, tpr);
+            if (sub == 0) {
+                T *dst = y + i0 + k;
+                if (whole) *dst = accumulate ? *dst + sum : sum;
+                else if (b > a) unsafeAtomicAdd(dst, sum); // continues in a neighbouring tile (y zero-filled / accumulating)
+            }
+        }
+        i0 += c;
+        j0 = j1;
+        __syncthreads(); // ro / prod are rewritten by the next tile
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) zero_fill_kernel(int64_t n, T *__restrict__ y)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = T(0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// row-length profile: which matrices get csr_balanced when the caller leaves the kernel choice open
+// ---------------------------------------------------------------------------------------------
+// The tuning table is keyed by the MEAN row length; skew is invisible to it, and skew is what breaks the
+// row-tile kernels: csr_stream's one-lane-per-row sum (the bit-exact order) spends ~40 ns per entry of a
+// long row, serially (tools/irregular_probe.py --sweep: 64 rows of 65536 entries turn 56 us into 2.6 ms).
+// So the first table-selected multiply of a matrix measures its longest row (one pass over the row
+// offsets + a 4-byte read-back, ~20 us) and the result is remembered, keyed by (row-offset pointer, rows,
+// entries, device).  A stale entry -- offsets edited in place, or the address reused -- can only cost
+// speed: every kernel is correct for every matrix.  CMI_CSR_PROFILE=0 turns the whole thing off.
+__global__ void __launch_bounds__(256) max_row_length_kernel(int64_t num_rows, const int *__restrict__ Ap, int *__restrict__ out)
+{
+    __shared__ int slots[256 / kWave];
+    int m = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows; i += stride) {
+        const int len = Ap[i + 1] - Ap[i];
+        m = len > m ? len : m;
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) { const int v = __shfl_down(m, o); m = v > m ? v : m; }
+    if ((threadIdx.x & (kWave - 1)) == 0) slots[threadIdx.x / kWave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 256 / kWave; w++) m = slots[w] > m ? slots[w] : m;
+        atomicMax(out, m);
+    }
+}
+
+static int measure_max_row_length(int64_t rows, const int *Ap, hipStream_t s, int64_t *out)
+{
+    int *dev = nullptr;
+    CMI_HIP(hipMalloc((void **)&dev, sizeof(int)));
+    int host = 0;
+    hipError_t e = hipMemsetAsync(dev, 0, sizeof(int), s);
+    if (e == hipSuccess) {
+        int64_t blocks = ceil_div(rows, 256 * 4);
+        if (blocks > kCus * 8) blocks = kCus * 8;
+        hipLaunchKernelGGL(max_row_length_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, rows, Ap, dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&host, dev, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return hip_fail(e, "row-length profile");
+    *out = host;
+    return CMI_SUCCESS;
+}
+
+struct profile_entry { const void *ap; int64_t rows, nnz; int device; int64_t max_len; uint64_t stamp; };
+static std::mutex g_profile_mu;
+static profile_entry g_profiles[64];
+static uint64_t g_profile_clock = 0;
+
+static bool profile_enabled()
+{
+    static const bool on = [] { const char *e = std::getenv("CMI_CSR_PROFILE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+// longest row of the matrix, from the cache or measured now; < 0 if it cannot be had (stream is capturing)
+static int64_t cached_max_row_length(int64_t rows, int64_t nnz, const int *Ap, hipStream_t s)
+{
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return -1;
+    {
+        std::lock_guard<std::mutex> lk(g_profile_mu);
+        for (auto &p : g_profiles)
+            if (p.ap == Ap && p.rows == rows && p.nnz == nnz && p.device == device && p.stamp) { p.stamp = ++g_profile_clock; return p.max_len; }
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return -1;
+    int64_t max_len = 0;
+    if (measure_max_row_length(rows, Ap, s, &max_len) != CMI_SUCCESS) return -1;
+    std::lock_guard<std::mutex> lk(g_profile_mu);
+    profile_entry *victim = &g_profiles[0];
+    for (auto &p : g_profiles)
+        if (p.stamp < victim->stamp) victim = &p;
+    *victim = profile_entry{Ap, rows, nnz, device, max_len, ++g_profile_clock};
+    return max_len;
+}
+
+// serial cost of the longest row under the one-lane-per-row sum vs the whole multiply at streaming speed
+static bool prefers_balanced(int64_t rows, int64_t nnz, int64_t max_len, size_t value_bytes)
+{
+    const double stream_us = ((double)nnz * (4 + value_bytes) + (double)rows * (4 + 2 * value_bytes)) / 5.0e6; // 5 TB/s
+    const double floor_us = 20.0; // launch + latency floor of any multiply
+    return (double)max_len * 0.04 > (stream_us > floor_us ? stream_us : floor_us);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
 static int grid_for(int64_t work_items, int block, int items_per_block_thread = 1)
@@ -472,6 +701,10 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     cmi_config c;
     select_config(CMI_FORMAT_CSR, dtype, rows, cols, nnz, user, &c);
     hipStream_t s = as_stream(stream);
+    if ((!user || user->kernel == CMI_KERNEL_AUTO) && nnz > 0 && profile_enabled()) {
+        const int64_t max_len = cached_max_row_length(rows, nnz, Ap, s);
+        if (max_len >= 0 && prefers_balanced(rows, nnz, max_len, sizeof(T))) c.kernel = CMI_CSR_BALANCED;
+    }
     const int block = c.block_size;
     const int pol = c.nontemporal & 3;
     int st = CMI_SUCCESS;
@@ -540,6 +773,19 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         });
         break;
     }
+    case CMI_CSR_BALANCED: {
+        if (rows + nnz > ((int64_t)1 << 40)) return fail(CMI_ERROR_INVALID_VALUE, "csr_balanced: matrix too large");
+        const int64_t tiles = ceil_div(rows + nnz, kBalItems);
+        const int bpc = c.blocks_per_cu > 0 ? c.blocks_per_cu : 8;
+        int64_t grid64 = (int64_t)kCus * bpc;
+        if (grid64 > tiles) grid64 = tiles;
+        if (!accumulate) // rows split across tiles are completed with atomics: they start from zero
+            hipLaunchKernelGGL((zero_fill_kernel<T>), dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, s, rows, y);
+        const bool vec = (reinterpret_cast<uintptr_t>(Aj) % 16 == 0) && (reinterpret_cast<uintptr_t>(Ax) % 16 == 0);
+        if (vec) hipLaunchKernelGGL((csr_balanced_kernel<T, true>), dim3((unsigned)grid64), dim3(kBalBlock), 0, s, rows, nnz, Ap, Aj, Ax, x, y, tiles, accumulate);
+        else     hipLaunchKernelGGL((csr_balanced_kernel<T, false>), dim3((unsigned)grid64), dim3(kBalBlock), 0, s, rows, nnz, Ap, Aj, Ax, x, y, tiles, accumulate);
+        break;
+    }
     default: return fail(CMI_ERROR_NOT_SUPPORTED, "cmi_spmv_csr: config.kernel is not a CSR kernel");
     }
     CMI_LAUNCH_CHECK("csr spmv");
@@ -573,6 +819,17 @@ CMI_API int cmi_spmv_csr_dot_f64(int64_t num_rows, int64_t num_cols, int64_t num
         return CMI_SUCCESS;
     }
     return cmi_blas_dot_f64(num_rows, y, w, dot_dev, workspace, stream);
+}
+
+// Longest row of a CSR matrix (device pass + read-back; synchronises the stream).  cmi_spmv_csr_* with no
+// explicit kernel does this itself, once per matrix; exposed for hosts that keep their own profile.
+CMI_API int cmi_csr_max_row_length(int64_t num_rows, const int32_t *Ap, int64_t *max_length_host, void *stream)
+{
+    if (num_rows < 0 || !max_length_host) return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_max_row_length: bad argument");
+    *max_length_host = 0;
+    if (num_rows == 0) return CMI_SUCCESS;
+    if (!Ap) return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_max_row_length: null row offsets");
+    return cmi::measure_max_row_length(num_rows, Ap, cmi::as_stream(stream), max_length_host);
 }
 
 CMI_API int cmi_spmv_csr_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ap,

@@ -121,6 +121,9 @@ typedef enum cmi_kernel {
     CMI_CSR_VECTOR = 2, /* threads_per_row lanes/row (ref: csr_vector_spmv.h:71-161, THREADS_PER_ROW) */
     CMI_CSR_STREAM = 3, /* LDS-staged nnz tile, sequential per-row sum (bit-exact vs host order) */
     CMI_CSR_STREAM_PIPE = 4, /* persistent, software-pipelined csr_stream (next tile's streams in flight) */
+    CMI_CSR_BALANCED = 5,   /* merge-path split of row ends + entries: equal work per tile whatever the row
+                               lengths (a few huge rows, power-law tails, runs of empty rows); replaces KTT's
+                               csr_kernel_balanced (cuda/ktt/kernels/csr_kernel.h:316-375); block_size 256   */
     /* ELL */
     CMI_ELL_ROW = 10, /* one lane per row            (ref: ell_spmv.h:55-93)                     */
     /* DIA */
@@ -175,6 +178,13 @@ int cmi_spmv_csr_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries, co
 int cmi_spmv_csr_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ap,
                      const int32_t *Aj, const float *Ax, const float *x, float *y, int accumulate,
                      const cmi_config *cfg, void *stream);
+/* Row-length profile.  With cfg == NULL (or kernel AUTO) cmi_spmv_csr_* measures the longest row of a    */
+/* matrix the first time it sees it (key: row-offset pointer, rows, entries, device; ~20 us, one stream    */
+/* synchronisation; skipped while the stream is being captured) and switches from the table's row-tile     */
+/* kernel to CMI_CSR_BALANCED when that row alone would cost more than the whole multiply.  A stale       */
+/* profile can only cost speed.  CMI_CSR_PROFILE=0 disables it.  cmi_csr_max_row_length is the same pass   */
+/* for hosts that want to decide themselves.                                                               */
+int cmi_csr_max_row_length(int64_t num_rows, const int32_t *Ap, int64_t *max_length_host, void *stream);
 /* y <- A x AND *dot_dev <- <y, w> (w: num_rows values; w may be x).  The CG step                  */
 /* `y = A p; alpha = rz / dot(y, p)` (reference cusp/krylov/detail/cg.inl:80-83) in ONE pass: the   */
 /* csr_stream workgroups leave per-tile partial sums in `workspace` (cmi_blas_workspace_bytes()),   */

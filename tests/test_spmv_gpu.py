@@ -73,6 +73,8 @@ def csr_variants(cmi, small=False):
         out.append((f"pipe b{blk} r{rpb} nt{nt} c{chunked} bpc{bpc}", True,
                     cmi.Config(kernel=cmi.CSR_STREAM_PIPE, block_size=blk, rows_per_block=rpb, nontemporal=nt,
                                xcd_swizzle=chunked, blocks_per_cu=bpc)))
+    for bpc in (0, 1, 3):  # merge-path split: re-associates (lane groups + atomics on rows that span tiles)
+        out.append((f"balanced bpc{bpc}", False, cmi.Config(kernel=cmi.CSR_BALANCED, block_size=256, blocks_per_cu=bpc)))
     return out
 
 
@@ -421,6 +423,52 @@ def test_pathological_row_length_distributions(cmi, torch_cuda, orc, shape):
         assert_close(host(y), want, bound, np.float64, f"{shape} coo{kern}")
 
 
+def test_row_length_profile_selects_the_balanced_kernel(cmi, torch_cuda, orc):
+    """With no explicit kernel the library measures the longest row once per matrix and leaves the row-tile
+    kernel for the merge-path one when that row would dominate: results stay within tolerance, and the
+    multiply no longer takes milliseconds per long row."""
+    import time
+    torch = torch_cuda
+    rng = np.random.default_rng(23)
+    rows = cols = 300_000
+    lens = rng.integers(2, 9, size=rows)
+    lens[[5, 77_777, 299_999]] = 400_000
+    Ap = np.r_[0, np.cumsum(lens)].astype(np.int32)
+    nnz = int(Ap[-1])
+    Aj = rng.integers(0, cols, size=nnz).astype(np.int32)
+    Ax = rng.standard_normal(nnz)
+    x = rng.standard_normal(cols)
+    dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+    L = cmi.lib()
+    import ctypes
+    got = ctypes.c_int64()
+    cmi.check(L.cmi_csr_max_row_length(rows, ctypes.c_void_p(dAp.data_ptr()), ctypes.byref(got), None))
+    assert got.value == 400_000
+    want = orc.spmv_csr(Ap, Aj, Ax, x)
+    bound = row_abs(orc, Ap, Aj, Ax, x)
+    y = torch.empty(rows, dtype=torch.float64, device="cuda")
+
+    def timed(cfg):
+        cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, cfg=cfg)  # first call: profile / warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, cfg=cfg)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    t_auto = timed(None)
+    assert_close(host(y), want, bound, np.float64, "auto (profile)")
+    table = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, rows, cols, nnz)   # what the mean row length alone selects
+    t_table = timed(table)
+    assert np.array_equal(host(y), want)                                  # ... bit-exact, but one lane sums each long row
+    assert t_auto * 5 < t_table, (t_auto, t_table)
+    # accumulate mode through the balanced kernel: no zero fill, y += A x
+    y0 = rng.standard_normal(rows)
+    dy = dev(y0, torch)
+    cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, dy, accumulate=True, cfg=cmi.Config(kernel=cmi.CSR_BALANCED))
+    assert_close(host(dy), orc.spmv_csr(Ap, Aj, Ax, x, y0), bound + np.abs(y0), np.float64, "balanced accumulate")
+
+
 def test_bad_config_is_an_error_not_a_fallback(cmi, torch_cuda):
     torch = torch_cuda
     Ap = torch.tensor([0, 1], dtype=torch.int32, device="cuda")
@@ -702,7 +750,11 @@ def test_spmv_csr_dot_every_variant(cmi, torch_cuda, golden_irregular):
         cmi.spmv_csr(rows, cols, Ap, Aj, Ax, x, y_plain, cfg=cfg)
         res.fill_(float("nan"))
         cmi.spmv_csr_dot(rows, cols, Ap, Aj, Ax, x, y_fused, dw, res, ws, cfg=cfg)
-        assert torch.equal(y_plain, y_fused), name
+        if cfg is None or cfg.kernel == cmi.CSR_BALANCED:  # (the 5000-entry row makes the profile pick csr_balanced too)
+            # atomics on rows that span tiles: order-dependent rounding
+            assert torch.allclose(y_plain, y_fused, rtol=1e-12, atol=1e-12), name
+        else:
+            assert torch.equal(y_plain, y_fused), name
         yh = host(y_fused)
         assert abs(float(res) - float(np.dot(yh, w))) <= 1e-12 * float(np.abs(yh * w).sum()), name
     # twice the same call: the same bits (fixed reduction tree, no atomics)
