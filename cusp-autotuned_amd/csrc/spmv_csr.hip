@@ -459,22 +459,35 @@ csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict
     int64_t i0 = lo;          // first row not yet finished
     int64_t j0 = d0 - i0;     // first entry not yet consumed
 
+    // Row offsets of the next tile are requested one tile ahead (register `pref`: Ap[i0 + tid], lane 0 also
+    // Ap[i0 + 256]), so a tile's dependent chain is  entries -> x gather -> sums,  not  offsets -> entries -> ...
+    auto offset_at = [&](int64_t r) { return Ap[r < num_rows ? r : num_rows]; };
+    int pref = offset_at(i0 + tid);
+    int pref_hi = tid == 0 ? offset_at(i0 + kBalBlock) : 0;
+
     for (int64_t t = t_begin; t < t_end; t++) {
         const int64_t d1 = (t + 1) * kBalItems; // items [t*kBalItems, d1)
-        // ---- row offsets of the rows that could end in this tile ----
-        const int avail = (int)((num_rows - i0) < kBalItems ? (num_rows - i0) : kBalItems);
-        for (int k = tid; k <= avail; k += kBalBlock) ro[k] = Ap[i0 + k];
+        const int avail = (int)((num_rows - i0) < kBalItems ? (num_rows - i0) : kBalItems); // rows that could end here
+        ro[tid] = pref;
+        if (tid == 0) ro[kBalBlock] = pref_hi;
         __syncthreads();
-        // rows ending in the tile: end item Ap[i+1] + i < d1 (a prefix of the candidates)
-        int mine = 0;
-        for (int k = tid; k < avail; k += kBalBlock) mine += ((int64_t)ro[k + 1] + i0 + k < d1);
+        // rows ending in the tile: end item Ap[i+1] + i < d1 -- a prefix of the candidates
+        int c = __syncthreads_count(tid < avail && (int64_t)ro[tid + 1] + i0 + tid < d1);
+        if (c == kBalBlock && avail > kBalBlock) { // 256+ rows end here (mean row length < 3): look at all candidates
+            for (int k = kBalBlock + 1 + tid; k <= avail; k += kBalBlock) ro[k] = Ap[i0 + k];
+            __syncthreads();
+            int mine = 0;
+            for (int k = kBalBlock + tid; k < avail; k += kBalBlock) mine += ((int64_t)ro[k + 1] + i0 + k < d1);
 #pragma unroll
-        for (int o = kWave / 2; o > 0; o >>= 1) mine += __shfl_down(mine, o);
-        if ((tid & (kWave - 1)) == 0) wave_counts[tid / kWave] = mine;
-        __syncthreads();
-        int c = 0;
+            for (int o = kWave / 2; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+            if ((tid & (kWave - 1)) == 0) wave_counts[tid / kWave] = mine;
+            __syncthreads();
 #pragma unroll
-        for (int w = 0; w < kBalBlock / kWave; w++) c += wave_counts[w];
+            for (int w = 0; w < kBalBlock / kWave; w++) c += wave_counts[w];
+        }
+        // next tile's offsets: in flight while this tile's entries are processed
+        pref = offset_at(i0 + c + tid);
+        pref_hi = tid == 0 ? offset_at(i0 + c + kBalBlock) : 0;
         int64_t j1 = j0 + (kBalItems - c);
         if (j1 > num_entries) j1 = num_entries;
         // the row after the last finished one may have its first entries here

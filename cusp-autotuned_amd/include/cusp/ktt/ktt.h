@@ -83,6 +83,7 @@ inline std::vector<cmi_config> configuration_space(int format, double mean)
                         if (!tpr) out.push_back(make(CMI_CSR_STREAM, b, 0, 0, ipt, nt, 64, 0));
                     }
         for (int tpr : {4, 16, 64}) out.push_back(make(CMI_CSR_VECTOR, 256, tpr, 0, 0, 0, 0, 0));
+        out.push_back(make(CMI_CSR_BALANCED, 256, 0, 0, 0, 0, 0, 0)); // merge-path split: wins on skewed row lengths
         if (mean <= 40)
             for (int bpc : {3, 8}) out.push_back(make(CMI_CSR_STREAM_PIPE, 256, 0, 0, 0, 2, 0, bpc));
     } else if (format == CMI_FORMAT_ELL || format == CMI_FORMAT_DIA) {
