@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstddef>
 #include <utility>
+#include <iterator>
 #include <vector>
 
 #include "format.h"
@@ -97,6 +98,8 @@ public:
 
     T *data() { return Parent::data(); }
     const T *data() const { return Parent::data(); }
+    view subarray(size_t start, size_t n) { return view(data() + start, n); }
+    const_view subarray(size_t start, size_t n) const { return const_view(data() + start, n); }
 
 private:
     template <typename Other> void assign_from(const Other &o)
@@ -131,6 +134,11 @@ public:
     array1d(const array1d &o) : array1d() { assign_from(o); }
     array1d(array1d &&o) noexcept : ptr_(o.ptr_), size_(o.size_), capacity_(o.capacity_) { o.ptr_ = nullptr; o.size_ = o.capacity_ = 0; }
     array1d(const std::vector<T> &v) : array1d() { resize(v.size()); detail::raw_copy<T, device_memory, host_memory>::run(ptr_, v.data(), v.size()); }
+    // a range of HOST iterators (device iterators are plain pointers here and cannot be told apart: construct from
+    // the array or a view instead)
+    template <typename It, typename = typename std::iterator_traits<It>::iterator_category,
+              typename = typename std::enable_if<!std::is_pointer<It>::value>::type>
+    array1d(It first, It last) : array1d(std::vector<T>(first, last)) {}
     template <typename Other, typename = typename Other::memory_space, typename = typename Other::value_type>
     array1d(const Other &o) : array1d() { assign_from(o); }
     ~array1d() { release(); }
@@ -175,6 +183,21 @@ public:
     }
     void clear() { size_ = 0; }
     void swap(array1d &o) { std::swap(ptr_, o.ptr_); std::swap(size_, o.size_); std::swap(capacity_, o.capacity_); }
+    void reserve(size_t n)
+    {
+        if (n <= capacity_) return;
+        const size_t keep = size_;
+        resize(n);
+        size_ = keep;
+    }
+    void push_back(const T &v) // set-up convenience (reference testing/array1d.cu:7-27): amortised doubling, one 1-element copy
+    {
+        if (size_ == capacity_) reserve(capacity_ ? 2 * capacity_ : 4);
+        detail::raw_copy<T, device_memory, host_memory>::run(ptr_ + size_, &v, 1);
+        size_++;
+    }
+    view subarray(size_t start, size_t n) { return view(ptr_ + start, n); }
+    const_view subarray(size_t start, size_t n) const { return const_view(ptr_ + start, n); }
 
 private:
     template <typename Other> void assign_from(const Other &o)
@@ -243,6 +266,35 @@ private:
 template <typename T, typename M> array1d_view<T, M> make_array1d_view(array1d<T, M> &a) { return array1d_view<T, M>(a); }
 template <typename T, typename M> array1d_view<const T, M> make_array1d_view(const array1d<T, M> &a) { return array1d_view<const T, M>(a); }
 template <typename T, typename M> array1d_view<T, M> make_array1d_view(const array1d_view<T, M> &v) { return v; }
+
+// equality across memory spaces and with std::vector (reference testing/array1d.cu:165-193): element-wise on
+// host copies -- a test / set-up convenience, not a hot path
+namespace detail {
+template <typename A> std::vector<typename std::remove_const<typename A::value_type>::type> host_copy(const A &a)
+{
+    typedef typename std::remove_const<typename A::value_type>::type U;
+    std::vector<U> out(a.size());
+    raw_copy<U, host_memory, typename A::memory_space>::run(out.data(), const_cast<const U *>(a.data()), a.size());
+    return out;
+}
+template <typename T> const std::vector<T> &host_copy(const std::vector<T> &v) { return v; }
+template <typename X, typename = void> struct is_array_like : std::false_type {};
+template <typename X> struct is_array_like<X, typename std::enable_if<std::is_same<typename X::format, array1d_format>::value>::type> : std::true_type {};
+template <typename T, typename A> struct is_array_like<std::vector<T, A>, void> : std::true_type {};
+template <typename A, typename B> bool arrays_equal_any(const A &a, const B &b)
+{
+    if (a.size() != b.size()) return false;
+    const auto ha = host_copy(a);
+    const auto hb = host_copy(b);
+    for (size_t i = 0; i < ha.size(); i++)
+        if (!(ha[i] == hb[i])) return false;
+    return true;
+}
+} // namespace detail
+template <typename T, typename M, typename B, typename = typename std::enable_if<detail::is_array_like<B>::value>::type>
+bool operator==(const array1d<T, M> &a, const B &b) { return detail::arrays_equal_any(a, b); }
+template <typename T, typename M, typename B, typename = typename std::enable_if<detail::is_array_like<B>::value>::type>
+bool operator!=(const array1d<T, M> &a, const B &b) { return !detail::arrays_equal_any(a, b); }
 
 // cusp::copy between any two array-likes (reference cusp/copy.h); sizes must already match or dst resizes
 template <typename Src, typename Dst> void copy_array(const Src &src, Dst &dst)

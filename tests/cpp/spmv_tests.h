@@ -277,6 +277,61 @@ template <typename Space> void TestCsrToDiaMatchesHostConversion()
 DECLARE_SPACE_UNITTEST(TestCsrToDiaMatchesHostConversion);
 
 // ------------------------------------------------------------------------------------------------
+// testing/array1d.cu:7-193 (push_back, cross-space construction and assignment, std::vector interop,
+// iterator-range construction, equality across spaces); Thrust vectors are not part of this layer.  The
+// "other" space is host_memory <-> Space, so the host build (no GPU) stays on the host
+template <typename Space> void TestArray1dBasics()
+{
+    cusp::array1d<int, Space> a(4);
+    ASSERT_EQUAL(a.size(), size_t(4));
+    for (int i = 0; i < 4; i++) a[i] = i;
+    a.push_back(4);
+    ASSERT_EQUAL(a.size(), size_t(5));
+    for (int i = 0; i < 5; i++) ASSERT_EQUAL(int(a[i]), i);
+
+    cusp::array1d<int, Space> b(2);
+    b[0] = 0; b[1] = 1;
+    cusp::array1d<int, cusp::host_memory> h(b);
+    cusp::array1d<int, Space> d(b);
+    ASSERT_EQUAL(h.size(), size_t(2)); ASSERT_EQUAL(int(h[1]), 1);
+    ASSERT_EQUAL(d.size(), size_t(2)); ASSERT_EQUAL(int(d[0]), 0); ASSERT_EQUAL(int(d[1]), 1);
+    const cusp::array1d<int, cusp::host_memory> ch(2, 10);
+    const cusp::array1d<int, Space> cd(ch);
+    ASSERT_EQUAL(cd.size(), size_t(2)); ASSERT_EQUAL(int(cd[0]), 10); ASSERT_EQUAL(int(cd[1]), 10);
+
+    std::vector<int> v(2, 10);
+    cusp::array1d<int, Space> fromv(v), assigned = v, ranged(v.begin(), v.end());
+    for (auto *p : {&fromv, &assigned, &ranged}) { ASSERT_EQUAL(p->size(), size_t(2)); ASSERT_EQUAL(int((*p)[0]), 10); ASSERT_EQUAL(int((*p)[1]), 10); }
+
+    cusp::array1d<int, cusp::host_memory> h2 = b;
+    cusp::array1d<int, Space> d2 = b;
+    ASSERT_EQUAL(int(h2[1]), 1); ASSERT_EQUAL(int(d2[1]), 1);
+    b = ch;
+    ASSERT_EQUAL(int(b[0]), 10); ASSERT_EQUAL(int(b[1]), 10);
+    const cusp::array1d<int, Space> cd20(2, 20);
+    b = cd20;
+    ASSERT_EQUAL(b.size(), size_t(2)); ASSERT_EQUAL(int(b[0]), 20); ASSERT_EQUAL(int(b[1]), 20);
+
+    cusp::array1d<int, Space> A(2);
+    A[0] = 10; A[1] = 20;
+    cusp::array1d<int, cusp::host_memory> eh(A);
+    cusp::array1d<int, Space> ed(A);
+    std::vector<int> ev = {10, 20};
+    ASSERT_TRUE(A == eh); ASSERT_TRUE(A == ed); ASSERT_TRUE(A == ev);
+    eh.push_back(30); ed.push_back(30); ev.push_back(30);
+    ASSERT_TRUE(A != eh); ASSERT_TRUE(A != ed); ASSERT_TRUE(A != ev);
+    // resize keeps the leading elements; views alias the storage
+    A.resize(4, 7);
+    ASSERT_EQUAL(int(A[1]), 20); ASSERT_EQUAL(int(A[3]), 7);
+    typename cusp::array1d<int, Space>::view w(A);
+    w[0] = -1;
+    ASSERT_EQUAL(int(A[0]), -1); ASSERT_EQUAL(w.size(), size_t(4));
+    typename cusp::array1d<int, Space>::view sub = A.subarray(1, 2);
+    ASSERT_EQUAL(sub.size(), size_t(2)); ASSERT_EQUAL(int(sub[0]), 20); ASSERT_EQUAL(int(sub[1]), 7);
+}
+DECLARE_SPACE_UNITTEST(TestArray1dBasics);
+
+// ------------------------------------------------------------------------------------------------
 // containers: testing/{csr,coo,ell,dia,hyb}_matrix.cu -- BasicConstructor, CopyConstructor, Resize, Swap, Rebind
 template <typename Space> void TestContainerShapes()
 {
