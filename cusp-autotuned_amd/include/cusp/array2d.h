@@ -46,6 +46,19 @@ public:
     template <typename U, typename Space2>
     array2d(const array2d<U, Space2, Orientation> &o)
         : num_rows(o.num_rows), num_cols(o.num_cols), num_entries(o.num_entries), pitch(o.pitch), values(o.values) {}
+    // the OTHER orientation (any memory space / element type): transposed element by element through the host
+    // (reference testing/array2d.cu:229-252); set-up convenience
+    template <typename U, typename Space2, typename Orientation2, typename = typename std::enable_if<!std::is_same<Orientation2, Orientation>::value>::type>
+    array2d(const array2d<U, Space2, Orientation2> &o) : array2d() { assign_transposed(o); }
+    template <typename U, typename Space2, typename Orientation2, typename = typename std::enable_if<!std::is_same<Orientation2, Orientation>::value>::type>
+    array2d &operator=(const array2d<U, Space2, Orientation2> &o) { assign_transposed(o); return *this; }
+    template <typename U, typename Space2, typename = typename std::enable_if<!std::is_same<Space2, MemorySpace>::value || !std::is_same<U, T>::value>::type>
+    array2d &operator=(const array2d<U, Space2, Orientation> &o)
+    {
+        num_rows = o.num_rows; num_cols = o.num_cols; num_entries = o.num_entries; pitch = o.pitch;
+        values = o.values;
+        return *this;
+    }
     // from a sparse matrix: see cusp/convert.h (array2d(const Matrix&) is defined there)
     template <typename Matrix, typename = typename Matrix::format, typename = typename std::enable_if<!std::is_same<typename Matrix::format, array2d_format>::value>::type>
     array2d(const Matrix &m);
@@ -75,6 +88,18 @@ public:
     }
 
     size_t index_of(size_t i, size_t j) const { return detail::index_of_impl<Orientation>::at(i, j, pitch); }
+
+private:
+    template <typename Other> void assign_transposed(const Other &o)
+    {
+        array1d<typename Other::value_type, host_memory> src(o.values);
+        resize(o.num_rows, o.num_cols);
+        array1d<T, host_memory> dst(values.size(), T(0));
+        for (size_t i = 0; i < num_rows; i++)
+            for (size_t j = 0; j < num_cols; j++) dst[index_of(i, j)] = static_cast<T>(src[o.index_of(i, j)]);
+        values = dst;
+    }
+public:
 
     // host: direct reference; device: proxy (set-up only)
     template <typename S = MemorySpace>

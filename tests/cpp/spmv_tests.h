@@ -331,6 +331,65 @@ template <typename Space> void TestArray1dBasics()
 }
 DECLARE_SPACE_UNITTEST(TestArray1dBasics);
 
+// testing/array2d.cu:100-296: element layout of both orientations with trivial and padded pitch, mixed-orientation
+// assignment, resize (pitch smaller than the leading dimension is an error), swap
+template <typename Space> void TestArray2dLayouts()
+{
+    const float v[2][3] = {{10, 20, 30}, {40, 50, 60}};
+    {
+        cusp::array2d<float, Space, cusp::row_major> A(2, 3);
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) A(i, j) = v[i][j];
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) ASSERT_EQUAL(float(A(i, j)), v[i][j]);
+        const float e[6] = {10, 20, 30, 40, 50, 60};
+        for (int k = 0; k < 6; k++) ASSERT_EQUAL(float(A.values[k]), e[k]);
+        A.resize(2, 3, 4);
+        cusp::blas::fill(A.values, 0.0f);
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) A(i, j) = v[i][j];
+        const float p[8] = {10, 20, 30, 0, 40, 50, 60, 0};
+        for (int k = 0; k < 8; k++) ASSERT_EQUAL(float(A.values[k]), p[k]);
+    }
+    {
+        cusp::array2d<float, Space, cusp::column_major> A(2, 3);
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) A(i, j) = v[i][j];
+        const float e[6] = {10, 40, 20, 50, 30, 60};
+        for (int k = 0; k < 6; k++) ASSERT_EQUAL(float(A.values[k]), e[k]);
+        A.resize(2, 3, 4);
+        cusp::blas::fill(A.values, 0.0f);
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) A(i, j) = v[i][j];
+        const float p[12] = {10, 40, 0, 0, 20, 50, 0, 0, 30, 60, 0, 0};
+        for (int k = 0; k < 12; k++) ASSERT_EQUAL(float(A.values[k]), p[k]);
+    }
+    {
+        cusp::array2d<float, Space, cusp::row_major> R(2, 3);
+        cusp::array2d<float, Space, cusp::column_major> C(2, 3);
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) R(i, j) = v[i][j];
+        C = R;
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) ASSERT_EQUAL(float(C(i, j)), v[i][j]);
+        cusp::blas::fill(R.values, 0.0f);
+        R = C;
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) ASSERT_EQUAL(float(R(i, j)), v[i][j]);
+    }
+    {
+        cusp::array2d<float, Space> A;
+        A.resize(3, 2);
+        ASSERT_EQUAL(A.num_rows, size_t(3)); ASSERT_EQUAL(A.num_cols, size_t(2)); ASSERT_EQUAL(A.pitch, size_t(2));
+        ASSERT_EQUAL(A.num_entries, size_t(6)); ASSERT_EQUAL(A.values.size(), size_t(6));
+        A.resize(3, 2, 4);
+        ASSERT_EQUAL(A.pitch, size_t(4)); ASSERT_EQUAL(A.num_entries, size_t(6)); ASSERT_EQUAL(A.values.size(), size_t(12));
+        ASSERT_THROWS(A.resize(3, 2, 1), cusp::invalid_input_exception);
+    }
+    {
+        cusp::array2d<float, Space> A(2, 2), B(3, 1);
+        A(0, 0) = 10; A(0, 1) = 20; A(1, 0) = 30; A(1, 1) = 40;
+        B(0, 0) = 50; B(1, 0) = 60; B(2, 0) = 70;
+        cusp::array2d<float, Space> A_copy(A), B_copy(B);
+        A.swap(B);
+        ASSERT_EQUAL(A.num_rows, size_t(3)); ASSERT_EQUAL(A.num_cols, size_t(1)); ASSERT_ARRAYS_EQUAL(A.values, B_copy.values);
+        ASSERT_EQUAL(B.num_rows, size_t(2)); ASSERT_EQUAL(B.num_cols, size_t(2)); ASSERT_ARRAYS_EQUAL(B.values, A_copy.values);
+    }
+}
+DECLARE_SPACE_UNITTEST(TestArray2dLayouts);
+
 // ------------------------------------------------------------------------------------------------
 // containers: testing/{csr,coo,ell,dia,hyb}_matrix.cu -- BasicConstructor, CopyConstructor, Resize, Swap, Rebind
 template <typename Space> void TestContainerShapes()
