@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cg-iterations", type=int, default=50, help="iterations of the secondary CG leg (0 = skip)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "peer", "halo", "allgather"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -216,8 +217,23 @@ def main():
             same = torch.tensor([int(torch.equal(y_ag, y))], dtype=torch.int32, device=dev)
             dist.all_reduce(same, op=dist.ReduceOp.MIN)
             ag_s = float(t.item()) / ag_steps
+
+            def exchange_only(vec):  # the exchange alone, same protocol (make the xGMI bound visible)
+                for _ in range(2):
+                    vec.exchange()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(ag_steps):
+                    vec.exchange()
+                barrier()
+                tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                return round(float(tt.item()) / ag_steps * 1e3, 5)
+
+            exchange_info["exchange_only_ms"] = exchange_only(sh.vec)
             allgather_leg = {"ms_per_step": round(ag_s * 1e3, 5), "value": round(2.0 * nnz_global / ag_s / 1e9, 3), "unit": "GFLOP/s",
                              "steps": ag_steps, "values_received_per_rank": sh_ag.vec.plan.allgather_values,
+                             "exchange_only_ms": exchange_only(sh_ag.vec),
                              "y_identical_to_default_exchange": bool(int(same.item()))}
             del sh_ag, y_ag
         except Exception as e:  # noqa: BLE001 -- the secondary leg must never take the main line down
@@ -243,6 +259,44 @@ def main():
         t = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         kernel_ms = float(t.item())
+
+    # ---- the caller: CG iterations/s on the same matrix (cusp::krylov::cg's loop, cg.inl:80-105; fused device
+    #      path, sharded when N>1), with the recurrence residual checked against b - A x at the end -----------
+    cg_leg = None
+    if fmt == "csr" and args.cg_iterations > 0:
+        try:
+            b_vec = torch.from_numpy(x_host).to(dev)
+            x_sol = torch.zeros(rows_per_rank, dtype=torch.float64, device=dev)
+            op = A if world == 1 else sh
+            cmi.krylov.cg(op, x_sol.clone(), b_vec, iteration_limit=3, relative_tolerance=0.0)  # warm-up
+            barrier()
+            t0 = time.perf_counter()
+            mon = cmi.krylov.cg(op, x_sol, b_vec, iteration_limit=args.cg_iterations, relative_tolerance=0.0)
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            if dist is not None:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            # true residual of the returned x
+            r_true = torch.empty_like(b_vec)
+            if world == 1:
+                cmi.multiply(A, x_sol, r_true)
+            else:
+                sh.vec.fence()
+                sh.x_local.copy_(x_sol)
+                sh.vec.fence()
+                sh.multiply(r_true)
+            rr = ((b_vec - r_true) ** 2).sum().reshape(1)
+            if dist is not None:
+                dist.all_reduce(rr)
+            true_norm = float(rr.item()) ** 0.5
+            cg_s = float(t.item())
+            cg_leg = {"iterations": mon.iteration_count, "iterations_per_s": round(mon.iteration_count / cg_s, 1),
+                      "us_per_iteration": round(cg_s / max(mon.iteration_count, 1) * 1e6, 2),
+                      "final_residual_norm": mon.residuals[-1], "true_residual_norm": true_norm,
+                      "residual_consistent": bool(abs(true_norm - mon.residuals[-1]) <= 1e-6 * mon.residuals[0]),
+                      "exchange": None if world == 1 else sh.vec.plan.mode}
+        except Exception as e:  # noqa: BLE001 -- a secondary leg
+            cg_leg = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # ---- numbers -------------------------------------------------------------------------------
     ms_per_step = elapsed / args.steps * 1e3
@@ -290,6 +344,8 @@ def main():
         }
         if allgather_leg is not None:
             line["allgather_exchange"] = allgather_leg
+        if cg_leg is not None:
+            line["cg"] = cg_leg
         if world == 1 and not args.no_cpu_baseline and fmt == "csr":
             base, omp = cpu_baseline(cmi, A, x_host, y.cpu().numpy(), args.cpu_seconds)
             line["cpu_baseline"] = base
