@@ -304,6 +304,56 @@ def test_reference_data_files_all_formats(cmi, torch_cuda, orc):
 
 
 # ------------------------------------------------------------------------------------------------
+# seeded random matrices: shapes from 1x1 to a few thousand, rectangular both ways, empty rows and
+# columns, row lengths from 0 to dense -- every format and kernel variant against the oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(10))
+def test_random_matrices_all_formats(cmi, torch_cuda, orc, seed):
+    torch = torch_cuda
+    rng = np.random.default_rng(1000 + seed)
+    rows, cols = [(7, 129), (3001, 1000), (257, 64), (2049, 4097), (1000, 1), (64, 2500), (65, 64), (1, 1), (1000, 1000), (2, 4097)][seed]
+    kind = seed % 5
+    if kind == 0:
+        lens = rng.integers(0, min(cols, 9) + 1, size=rows)                 # short rows, some empty
+    elif kind == 1:
+        lens = np.where(rng.random(rows) < 0.7, 0, rng.integers(1, min(cols, 40) + 1, size=rows))  # mostly empty
+    elif kind == 2:
+        lens = np.full(rows, min(cols, 33))                                  # uniform, ELL-friendly
+    elif kind == 3:
+        lens = np.minimum((rng.pareto(1.2, size=rows) * 3).astype(np.int64), cols)  # heavy tail
+    else:
+        lens = rng.integers(0, cols + 1, size=rows) if rows * cols <= 300_000 else rng.integers(0, 60, size=rows)  # up to dense
+    lens = np.minimum(lens, cols).astype(np.int64)
+    Ap = np.r_[0, np.cumsum(lens)].astype(np.int32)
+    Aj = np.concatenate([np.sort(rng.choice(cols, size=int(l), replace=False)) for l in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+    nnz = int(Ap[-1])
+    for dtype in (np.float64, np.float32):
+        Ax = rng.standard_normal(nnz).astype(dtype)
+        x = rng.standard_normal(cols).astype(dtype)
+        y0 = rng.standard_normal(rows).astype(dtype)
+        width = int(lens.max()) if rows else 0
+        hw = orc.optimal_entries_per_row(Ap)
+        pitch, eAj, eAx = orc.csr_to_ell(Ap, Aj, Ax, width)
+        p, hAj, hAx, cAi, cAj, cAx = orc.csr_to_hyb(Ap, Aj, Ax, hw)
+        Ai = orc.csr_row_indices(Ap)
+        want, want_acc = {}, {}
+        for w, yy in ((want, None), (want_acc, y0)):
+            w["csr"] = orc.spmv_csr(Ap, Aj, Ax, x, yy)
+            w["coo"] = orc.spmv_coo(rows, Ai, Aj, Ax, x, yy)
+            w["ell"] = orc.spmv_ell(rows, width, pitch, eAj, eAx, x, yy)
+            w["hyb"] = orc.spmv_hyb(rows, hw, p, hAj, hAx, cAi, cAj, cAx, x, yy)
+        if nnz >= 4:
+            run_all_formats(cmi, torch, orc, rows, cols, Ap, Aj, Ax, x, want, want_acc, y0, hw, f"random seed {seed} {rows}x{cols} kind {kind}")
+        if 0 < nnz and len(np.unique(Aj.astype(np.int64) - np.repeat(np.arange(rows), lens))) * rows <= 3_000_000:
+            pd, off, vals = orc.csr_to_dia(rows, cols, Ap, Aj, Ax)
+            for rpl in (1, 2):
+                y = torch.full((rows,), 10.0, dtype=dev(x, torch).dtype, device="cuda")
+                cmi.spmv_dia(rows, cols, len(off), pd, dev(off, torch), dev(vals, torch), dev(x, torch), y,
+                             cfg=cmi.Config(kernel=cmi.DIA_ROW, items_per_thread=rpl))
+                assert np.array_equal(host(y), orc.spmv_dia(rows, cols, pd, off, vals, x)), (seed, rpl)
+
+
+# ------------------------------------------------------------------------------------------------
 # FEM-like long rows (SuiteSparse surrogates of BASELINE.json configs[3]): 27-point stencil (~27/row,
 # nlpkkt120-like) and 27-point x 3 dof (~79/row, ldoor-like), through the tuning table and explicit
 # lane-group configurations
