@@ -85,6 +85,7 @@ def _declare(L):
     L.cmi_malloc_host.argtypes = [POINTER(c_void_p), c_size_t]
     L.cmi_free_host.argtypes = [vp]
     L.cmi_memcpy_d2h_async.argtypes = [vp, vp, c_size_t, vp]
+    L.cmi_device_can_access_peer.argtypes = [c_int, c_int, POINTER(c_int)]
     L.cmi_ipc_get_handle.argtypes = [vp, vp]
     L.cmi_ipc_open_handle.argtypes = [vp, POINTER(c_void_p)]
     L.cmi_ipc_close_handle.argtypes = [vp]
@@ -525,6 +526,12 @@ class _ArrayInterface:
         self.owner = owner
         self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (owner.ptr, False), "version": 2,
                                          "strides": None}
+
+
+def device_can_access_peer(device, peer_device):
+    flag = c_int()
+    check(lib().cmi_device_can_access_peer(int(device), int(peer_device), byref(flag)))
+    return bool(flag.value)
 
 
 def ipc_open(handle):

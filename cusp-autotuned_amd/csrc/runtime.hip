@@ -146,6 +146,17 @@ CMI_API int cmi_ipc_open_handle(const void *handle, void **ptr)
     return CMI_SUCCESS;
 }
 
+// can kernels on `device` load / store memory that lives on `peer_device`? (the question RCCL asks before it
+// picks its direct peer-to-peer transport); the one-sided exchange is only set up between such pairs
+CMI_API int cmi_device_can_access_peer(int device, int peer_device, int *can_access)
+{
+    if (!can_access) return fail(CMI_ERROR_INVALID_VALUE, "cmi_device_can_access_peer: null result");
+    *can_access = 0;
+    if (device == peer_device) { *can_access = 1; return CMI_SUCCESS; }
+    CMI_HIP(hipDeviceCanAccessPeer(can_access, device, peer_device));
+    return CMI_SUCCESS;
+}
+
 CMI_API int cmi_ipc_close_handle(void *ptr)
 {
     if (ptr) CMI_HIP(hipIpcCloseMemHandle(ptr));

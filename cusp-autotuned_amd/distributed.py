@@ -127,17 +127,24 @@ class ShardedVectorExchange:
         from . import binding as B
         ok, why = 1, ""
         handles = [None] * self.world
+        my_device = self.x_full.device.index if self.x_full.is_cuda else None
         try:
-            mine = self._buffer.ipc_handle() if self._buffer is not None else None
+            mine = (self._buffer.ipc_handle(), my_device) if self._buffer is not None else None
         except Exception as e:  # noqa: BLE001
             mine, ok, why = None, 0, f"ipc_get_handle: {e}"
         dist.all_gather_object(handles, mine, group=self.group)
+        devices = [h[1] if h is not None else None for h in handles]
+        handles = [h[0] if h is not None else None for h in handles]
         item = self.x_full.element_size()
         ranges = []
         if ok and all(h is not None for h in handles):
             try:
                 for p, (l, h) in enumerate(self.plan.recv):
                     if h > l:
+                        # the driver's answer to "may kernels on my GPU touch that GPU's memory?" comes first
+                        # (ranks of one node see the same device numbering)
+                        if not B.device_can_access_peer(my_device, devices[p]):
+                            raise RuntimeError(f"GPU {my_device} has no peer access to GPU {devices[p]} (rank {p})")
                         if p not in self._peer_ptrs:
                             self._peer_ptrs[p] = B.ipc_open(handles[p])
                         # every rank's buffer is indexed by GLOBAL column: the same offset on both sides

@@ -71,6 +71,7 @@ int cmi_memset(void *dst, int byte_value, size_t bytes, void *stream);
 /* the producing kernels of the peers before the pull (bench: barrier; CG: its all-reduces).         */
 #define CMI_IPC_HANDLE_BYTES 64
 #define CMI_MAX_COPY_RANGES 16
+int cmi_device_can_access_peer(int device, int peer_device, int *can_access); /* same device: 1 */
 int cmi_ipc_get_handle(void *dev_ptr, void *handle_out /* CMI_IPC_HANDLE_BYTES */);
 int cmi_ipc_open_handle(const void *handle, void **peer_ptr);
 int cmi_ipc_close_handle(void *peer_ptr);
