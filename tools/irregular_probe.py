@@ -39,7 +39,9 @@ def sweep():
         x = torch.rand(n, device="cuda", dtype=torch.float64)
         y = torch.empty(n, device="cuda", dtype=torch.float64)
         out = []
-        for vn, cfg in (("table", None), ("balanced", cmi.Config(kernel=cmi.CSR_BALANCED, block_size=256))):
+        variants = [("table", None)] + [(f"bal/{per}", cmi.Config(kernel=cmi.CSR_BALANCED, items_per_thread=per)) for per in (1, 2, 4, 8, 16)] + \
+            [("bal/persistent8", cmi.Config(kernel=cmi.CSR_BALANCED, blocks_per_cu=8))]
+        for vn, cfg in variants:
             for _ in range(3):
                 cmi.spmv_csr(n, n, Ap, Aj, Ax, x, y, cfg=cfg)
             torch.cuda.synchronize()
@@ -48,11 +50,11 @@ def sweep():
                 cmi.spmv_csr(n, n, Ap, Aj, Ax, x, y, cfg=cfg)
             torch.cuda.synchronize()
             out.append((time.perf_counter() - t0) / 10 * 1e6)
-        print(f"64 rows of {L:7d}: nnz {nnz:9d}  table {out[0]:9.1f} us   balanced {out[1]:9.1f} us", flush=True)
+        print(f"64 rows of {L:7d}: nnz {nnz:9d}  " + "  ".join(f"{v[0]} {o:7.1f}" for v, o in zip(variants, out)), flush=True)
     A = cmi.poisson5pt(3162, 3162, "csr")
     x = cmi.fill_x(A.num_rows).cuda()
     y = torch.empty(A.num_rows, dtype=torch.float64, device="cuda")
-    for vn, cfg in (("table", None), ("balanced", cmi.Config(kernel=cmi.CSR_BALANCED, block_size=256))):
+    for vn, cfg in variants:
         for _ in range(3):
             cmi.multiply(A, x, y, cfg=cfg)
         torch.cuda.synchronize()
