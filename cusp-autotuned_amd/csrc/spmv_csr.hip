@@ -411,20 +411,20 @@ csr_stream_pipe_kernel(int64_t num_rows, int64_t num_entries, const int *__restr
 // ---------------------------------------------------------------------------------------------
 // The other kernels give a workgroup ROWS; one row of a million entries then serialises a workgroup
 // (measured: 8 such rows in a 2M-row matrix take 37 ms instead of 50 us).  Here the unit of work is a
-// tile of kBalItems ITEMS of the merged sequence "entry 0, entry 1, ..., row-0-ends, entry k, ..." --
+// tile of kBalItems (2048) ITEMS of the merged sequence "entry 0, entry 1, ..., row-0-ends, entry k, ..." --
 // consuming an entry costs one product, consuming a row end one store -- so every tile does the same
 // amount of work whatever the row lengths, empty rows included (Merrill & Garland's merge-based SpMV;
 // the reference's KTT `csr_kernel_balanced`, cuda/ktt/kernels/csr_kernel.h:316-375, splits entries only
 // and needs a row_starts array recomputed on the host side).  A workgroup owns a contiguous chunk of
-// tiles: ONE cooperative 256-ary search of the row offsets finds where its chunk starts, after that the
+// tiles: ONE cooperative 512-ary search of the row offsets finds where its chunk starts, after that the
 // end of a tile is the start of the next.  Per tile: the row offsets and the products go to LDS (16-byte
 // vector loads, as csr_stream), then a group of lanes per row (1..64, chosen per tile from the number of
 // rows in it) sums the row's segment.  Rows that lie inside one tile are stored (or added to y when
 // accumulating) without atomics; the first and last row of a tile may continue in a neighbour tile and
 // go through global_atomic_add -- so y is zero-filled first when not accumulating.  Re-associates the
 // row sums: parity class of csr_vector (<= 1e-6 relative), not bit-exact.
-constexpr int kBalBlock = 256;
-constexpr int kBalItems = 1024; // items per tile = 4 per lane
+constexpr int kBalBlock = 512;
+constexpr int kBalItems = 2048; // items per tile = 4 per lane
 
 template <typename T, bool VEC>
 __global__ void __launch_bounds__(kBalBlock)

@@ -124,7 +124,7 @@ typedef enum cmi_kernel {
     CMI_CSR_STREAM_PIPE = 4, /* persistent, software-pipelined csr_stream (next tile's streams in flight) */
     CMI_CSR_BALANCED = 5,   /* merge-path split of row ends + entries: equal work per tile whatever the row
                                lengths (a few huge rows, power-law tails, runs of empty rows); replaces KTT's
-                               csr_kernel_balanced (cuda/ktt/kernels/csr_kernel.h:316-375); block_size 256;
+                               csr_kernel_balanced (cuda/ktt/kernels/csr_kernel.h:316-375); block_size 512 (fixed);
                                items_per_thread = consecutive tiles per workgroup (0: 4), blocks_per_cu > 0:
                                persistent grid of CUs*blocks_per_cu workgroups instead              */
     /* ELL */
