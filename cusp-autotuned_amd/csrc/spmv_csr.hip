@@ -441,7 +441,7 @@ csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict
     if (t_begin >= t_end) return; // whole workgroup
 
     // ---- where does item t_begin * kBalItems fall?  i0 = rows whose end item precedes it.  Row i's end
-    //      is item Ap[i+1] + i of the merged sequence (strictly increasing in i): 256-ary search. ----
+    //      is item Ap[i+1] + i of the merged sequence (strictly increasing in i): kBalBlock-ary search. ----
     const int64_t d0 = t_begin * kBalItems;
     int64_t lo = 0, hi = num_rows;
     while (lo < hi) {
@@ -459,7 +459,7 @@ csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict
     int64_t j0 = d0 - i0;     // first entry not yet consumed
 
     // Row offsets of the next tile are requested one tile ahead (register `pref`: Ap[i0 + tid], lane 0 also
-    // Ap[i0 + 256]), so a tile's dependent chain is  entries -> x gather -> sums,  not  offsets -> entries -> ...
+    // Ap[i0 + kBalBlock]), so a tile's dependent chain is  entries -> x gather -> sums,  not  offsets -> entries -> ...
     auto offset_at = [&](int64_t r) { return Ap[r < num_rows ? r : num_rows]; };
     int pref = offset_at(i0 + tid);
     int pref_hi = tid == 0 ? offset_at(i0 + kBalBlock) : 0;
@@ -472,7 +472,7 @@ csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict
         __syncthreads();
         // rows ending in the tile: end item Ap[i+1] + i < d1 -- a prefix of the candidates
         int c = __syncthreads_count(tid < avail && (int64_t)ro[tid + 1] + i0 + tid < d1);
-        if (c == kBalBlock && avail > kBalBlock) { // 256+ rows end here (mean row length < 3): look at all candidates
+        if (c == kBalBlock && avail > kBalBlock) { // kBalBlock+ rows end here (mean row length < 3): look at all candidates
             for (int k = kBalBlock + 1 + tid; k <= avail; k += kBalBlock) ro[k] = Ap[i0 + k];
             __syncthreads();
             int mine = 0;
