@@ -56,7 +56,7 @@ def _worker(rank, world, port, mode, m, n, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,world", [("halo", 2), ("allgather", 2), ("peer", 2), ("peer", 3), ("auto", 2)])
+@pytest.mark.parametrize("mode,world", [("halo", 2), ("allgather", 2), ("peer", 2), ("peer", 3), ("peer", 4), ("auto", 2), ("halo", 3)])
 def test_ranks_share_one_gpu_real_kernels(tmp_path, orc, mode, world):
     import oracle
     import torch.multiprocessing as mp
