@@ -519,6 +519,42 @@ def test_row_length_profile_selects_the_balanced_kernel(cmi, torch_cuda, orc):
     assert_close(host(dy), orc.spmv_csr(Ap, Aj, Ax, x, y0), bound + np.abs(y0), np.float64, "balanced accumulate")
 
 
+def test_multiply_inside_hip_graph_capture(cmi, torch_cuda, orc):
+    """cmi_spmv_* is capturable: launches only, nothing synchronises -- in particular the row-length profile of
+    a matrix the library has never seen is skipped while the stream is capturing (it needs a read-back), and
+    the table-selected kernel is recorded instead.  Replays reproduce the eager result in every format."""
+    torch = torch_cuda
+    Ap, Aj, Ax = orc.poisson5pt_csr(83, 61)
+    n = 83 * 61
+    x = np.random.default_rng(5).standard_normal(n)
+    want = orc.spmv_csr(Ap, Aj, Ax, x)
+    A = cmi.CsrMatrix(n, n, len(Aj), dev(Ap, torch), dev(Aj, torch), dev(Ax, torch))  # fresh arrays: no cached profile
+    mats = {"csr": A, "ell": cmi.convert(A, "ell"), "coo": cmi.convert(A, "coo"), "hyb": cmi.convert(A, "hyb", num_entries_per_row=3),
+            "dia": cmi.convert(A, "dia")}
+    dx = dev(x, torch)
+    side = torch.cuda.Stream()
+    for fmt, M in mats.items():
+        y = torch.full((n,), 7.0, dtype=torch.float64, device="cuda")
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            cmi.multiply(M, dx, y)
+        y.fill_(-1.0)
+        g.replay()
+        torch.cuda.synchronize()
+        got = host(y)
+        if fmt in ("csr", "ell", "dia"):
+            assert np.array_equal(got, want), fmt
+        else:
+            assert np.allclose(got, want, rtol=1e-12, atol=1e-12), fmt
+        dx2 = dx * 2.0            # same graph, new input values in the same buffers
+        dx.copy_(dx2)
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.allclose(host(y), 2.0 * want, rtol=1e-12, atol=1e-12), fmt
+        dx.copy_(dev(x, torch))
+
+
 def test_bad_config_is_an_error_not_a_fallback(cmi, torch_cuda):
     torch = torch_cuda
     Ap = torch.tensor([0, 1], dtype=torch.int32, device="cuda")
