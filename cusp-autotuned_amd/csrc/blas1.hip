@@ -119,7 +119,7 @@ dot_partial_kernel(int64_t n, const T *__restrict__ x, const T *__restrict__ y, 
 // LAST workgroup to finish (a ticket counter) folds `folded` in index order and writes the scalar:
 // one launch, and still a fixed summation tree whichever workgroup happens to be last.  The ticket
 // lives in the workspace behind `folded`; the last workgroup leaves it at 0 and every stage-1 kernel
-// zeroes it as well (reset_ticket), so an uninitialised workspace is fine.
+// zeroes it as well, so an uninitialised workspace is fine.
 constexpr int kFoldDirect = 2048; // up to here one workgroup folds the list directly
 
 template <typename T>

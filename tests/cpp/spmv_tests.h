@@ -16,7 +16,9 @@
 #include <cusp/ell_matrix.h>
 #include <cusp/hyb_matrix.h>
 #include <cusp/gallery/poisson.h>
+#include <cusp/copy.h>
 #include <cusp/io/matrix_market.h>
+#include <cusp/print.h>
 #include <cusp/krylov/cg.h>
 #include <cusp/ktt/ktt.h>
 #include <cusp/monitor.h>
@@ -525,6 +527,30 @@ template <typename Space> void TestCsrMatrixViews()
     ASSERT_ARRAYS_EQUAL(y1, y2);
 }
 DECLARE_SPACE_UNITTEST(TestCsrMatrixViews);
+
+// cusp::copy (same format, any memory spaces) and cusp::print (reference cusp/copy.h, cusp/print.h)
+template <typename Space> void TestCopyAndPrint()
+{
+    cusp::csr_matrix<int, float, cusp::host_memory> h;
+    cusp::gallery::poisson5pt(h, 3, 2);
+    cusp::csr_matrix<int, float, Space> d;
+    cusp::copy(h, d);
+    cusp::csr_matrix<int, float, cusp::host_memory> back;
+    cusp::copy(d, back);
+    ASSERT_ARRAYS_EQUAL(back.row_offsets, h.row_offsets); ASSERT_ARRAYS_EQUAL(back.column_indices, h.column_indices); ASSERT_ARRAYS_EQUAL(back.values, h.values);
+    cusp::array1d<float, Space> v(3, 2.5f), w;
+    cusp::copy(v, w);
+    ASSERT_ARRAYS_EQUAL(v, w);
+    std::ostringstream os;
+    cusp::print(d, os);                       // any sparse format prints as its COO triplets
+    const std::string text = os.str();
+    ASSERT_TRUE(text.rfind("sparse matrix <6, 6> with 20 entries\n", 0) == 0);
+    ASSERT_TRUE(text.find("              0              0        (4)\n") != std::string::npos);
+    std::ostringstream oa;
+    cusp::print(v, oa);
+    ASSERT_EQUAL(oa.str(), std::string("array1d <3>\n        (2.5)\n        (2.5)\n        (2.5)\n"));
+}
+DECLARE_SPACE_UNITTEST(TestCopyAndPrint);
 
 // coo_matrix.cu:130-267: sort_by_row, sort_by_row_and_column, is_sorted_*
 template <typename Space> void TestCooMatrixSorting()
