@@ -76,7 +76,7 @@ def test_reference_style_benchmark_driver(cmi, tmp_path):
 
 # ---- the reference's own example programs, compiled unchanged against this layer (oracle/_ref/examples) ----
 EXAMPLES = os.path.join(ROOT, "oracle", "_ref", "examples")
-HOST_EXAMPLES = ["MatrixFormats_coo", "MatrixFormats_csr", "MatrixFormats_dia", "MatrixFormats_ell", "MatrixFormats_hyb"]
+HOST_EXAMPLES = ["Algorithms_multiply", "MatrixFormats_coo", "MatrixFormats_csr", "MatrixFormats_dia", "MatrixFormats_ell", "MatrixFormats_hyb"]
 DEVICE_EXAMPLES = ["Solvers_cg", "Gallery_poisson", "Monitors_monitor", "Monitors_verbose_monitor", "InputOutput_matrix_market"]
 
 
@@ -97,6 +97,9 @@ def test_reference_examples_build_unchanged_and_host_ones_run(cmi):
         r = subprocess.run([os.path.join(EXAMPLES, e)], capture_output=True, text=True, timeout=60)
         assert r.returncode == 0, e + r.stderr[-500:]
         first = r.stdout.splitlines()[0]
+        if e == "Algorithms_multiply":  # dense 2x2 times [10, 20]: y = [50, 140] (examples/Algorithms/multiply.cu)
+            assert r.stdout.split() == ["array1d", "<2>", "(50)", "(140)"], r.stdout
+            continue
         assert first == ("sparse matrix <3, 4> with 8 entries" if e.endswith("hyb") else "sparse matrix <4, 3> with 6 entries"), (e, first)
     coo = subprocess.run([os.path.join(EXAMPLES, "MatrixFormats_coo")], capture_output=True, text=True).stdout.splitlines()
     assert coo[1].split() == ["0", "0", "(10)"] and coo[6].split() == ["3", "2", "(60)"]
