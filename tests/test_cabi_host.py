@@ -56,6 +56,50 @@ def test_argument_validation_fails_before_touching_the_gpu(cmi):
     assert e.value.status == 1
 
 
+def test_argument_validation_of_the_newer_entry_points(cmi):
+    """fused SpMV+dot, CG steps, multi-range copy, IPC, CSR->DIA, row profile: bad arguments are reported as
+    CMI_ERROR_INVALID_VALUE before any HIP call (this runs without a GPU)."""
+    L = cmi.lib()
+    i64 = ctypes.c_int64
+    assert L.cmi_spmv_csr_dot_f64(5, 5, 3, None, None, None, None, None, None, None, None, None, None) == 1
+    assert b"cmi_spmv_csr_dot" in L.cmi_last_error()
+    assert L.cmi_cg_update_f64(-1, None, None, None, None, None, None, None, None, None, None) == 1
+    assert L.cmi_cg_update_f64(4, None, None, None, None, None, None, None, None, None, None) == 1  # null scalars
+    assert L.cmi_cg_direction_f64(4, None, None, None, None, None) == 1
+    assert L.cmi_copy_ranges(17, None, None, None, None) == 1 and b"CMI_MAX_COPY_RANGES" in L.cmi_last_error()
+    assert L.cmi_copy_ranges(-1, None, None, None, None) == 1
+    assert L.cmi_copy_ranges(0, None, None, None, None) == 0                    # nothing to copy
+    assert L.cmi_copy_ranges(2, None, None, None, None) == 1                    # null arrays
+    src = (ctypes.c_void_p * 1)(None)
+    dst = (ctypes.c_void_p * 1)(None)
+    nbytes = (i64 * 1)(-8)
+    assert L.cmi_copy_ranges(1, src, dst, nbytes, None) == 1 and b"negative" in L.cmi_last_error()
+    nbytes[0] = 0
+    assert L.cmi_copy_ranges(1, src, dst, nbytes, None) == 0                    # empty range: skipped
+    nbytes[0] = 8
+    assert L.cmi_copy_ranges(1, src, dst, nbytes, None) == 1                    # null range of 8 bytes
+    assert L.cmi_ipc_get_handle(None, None) == 1 and L.cmi_ipc_open_handle(None, None) == 1
+    assert L.cmi_ipc_close_handle(None) == 0
+    assert L.cmi_device_can_access_peer(0, 1, None) == 1
+    same = ctypes.c_int(0)
+    assert L.cmi_device_can_access_peer(3, 3, ctypes.byref(same)) == 0 and same.value == 1  # a device reaches itself
+    n = i64(-1)
+    assert L.cmi_csr_diagonals(-1, 3, None, None, None, None, 0, ctypes.byref(n), None) == 1
+    assert L.cmi_csr_diagonals(3, 3, None, None, None, None, 0, None, None) == 1
+    assert L.cmi_csr_diagonals(0, 0, None, None, None, None, 0, ctypes.byref(n), None) == 0 and n.value == 0
+    assert L.cmi_csr_to_dia_f64(4, 4, None, None, None, 2, 3, None, None, None, None) == 1  # pitch < rows
+    assert L.cmi_csr_to_dia_f32(0, 0, None, None, None, 0, 0, None, None, None, None) == 0
+    assert L.cmi_csr_max_row_length(-1, None, ctypes.byref(n), None) == 1
+    assert L.cmi_csr_max_row_length(0, None, ctypes.byref(n), None) == 0 and n.value == 0
+    assert L.cmi_csr_max_row_length(5, None, ctypes.byref(n), None) == 1
+    assert L.cmi_malloc_host(None, 8) == 1 and L.cmi_free_host(None) == 0
+    assert L.cmi_memcpy_d2h_async(None, None, 0, None) == 0 and L.cmi_memcpy_d2h_async(None, None, 8, None) == 1
+    # an unknown CSR kernel id is an error, not a fallback
+    cfg = cmi.Config(kernel=9)
+    assert L.cmi_spmv_csr_f64(0, 0, 0, None, None, None, None, None, 0, ctypes.byref(cfg), None) == 0  # empty: nothing launched
+    assert cmi.lib().cmi_blas_workspace_bytes() == (65536 + 64 + 1) * 8
+
+
 def test_python_plumbing_refuses_host_tensors(cmi):
     import torch
     t = torch.zeros(4, dtype=torch.float64)
