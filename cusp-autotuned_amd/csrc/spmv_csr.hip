@@ -431,9 +431,12 @@ __global__ void __launch_bounds__(kBalBlock)
 csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ Ap, const int *__restrict__ Aj,
                     const T *__restrict__ Ax, const T *__restrict__ x, T *__restrict__ y, int64_t num_tiles, int64_t per, int accumulate)
 {
-    __shared__ __attribute__((aligned(16))) T prod[kBalItems + 8];
-    __shared__ int ro[kBalItems + 2];
-    __shared__ int wave_counts[kBalBlock / kWave];
+    // LDS is double-buffered by tile parity: a tile's two barriers (offsets+counts, products) are then all the
+    // synchronisation there is -- whoever writes buffer b for tile t+2 has passed tile t+1's barriers, which
+    // every wave reaches only after its reads of tile t.
+    __shared__ __attribute__((aligned(16))) T prod_buf[2][kBalItems + 8];
+    __shared__ int ro_buf[2][kBalItems + 2];
+    __shared__ int wave_counts_buf[2][kBalBlock / kWave];
     const int tid = threadIdx.x;
 
     const int64_t t_begin = (int64_t)blockIdx.x * per; // `per` consecutive tiles per workgroup, workgroups in launch order
@@ -458,23 +461,31 @@ csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict
     int64_t i0 = lo;          // first row not yet finished
     int64_t j0 = d0 - i0;     // first entry not yet consumed
 
-    // Row offsets of the next tile are requested one tile ahead (register `pref`: Ap[i0 + tid], lane 0 also
-    // Ap[i0 + kBalBlock]), so a tile's dependent chain is  entries -> x gather -> sums,  not  offsets -> entries -> ...
+    // Row offsets of the next tile are requested one tile ahead (registers `pref`, `pref_up`: Ap[i0 + tid] and
+    // Ap[i0 + tid + 1]), so a tile's dependent chain is  entries -> x gather -> sums,  not  offsets -> entries -> ...
     auto offset_at = [&](int64_t r) { return Ap[r < num_rows ? r : num_rows]; };
     int pref = offset_at(i0 + tid);
-    int pref_hi = tid == 0 ? offset_at(i0 + kBalBlock) : 0;
+    int pref_up = offset_at(i0 + tid + 1); // the row's END offset (lane kBalBlock-1 holds Ap[i0 + kBalBlock])
 
     for (int64_t t = t_begin; t < t_end; t++) {
+        T *prod = prod_buf[(t - t_begin) & 1];
+        int *ro = ro_buf[(t - t_begin) & 1];
+        int *wave_counts = wave_counts_buf[(t - t_begin) & 1];
         const int64_t d1 = (t + 1) * kBalItems; // items [t*kBalItems, d1)
         const int avail = (int)((num_rows - i0) < kBalItems ? (num_rows - i0) : kBalItems); // rows that could end here
         ro[tid] = pref;
-        if (tid == 0) ro[kBalBlock] = pref_hi;
+        if (tid == kBalBlock - 1) ro[kBalBlock] = pref_up;
+        // rows ending in the tile: end item Ap[i+1] + i < d1 -- a prefix of the candidates; counted per wave
+        // from registers (ballot), summed after the one barrier that also publishes the offsets
+        const unsigned long long ended = __ballot(tid < avail && (int64_t)pref_up + i0 + tid < d1);
+        if ((tid & (kWave - 1)) == 0) wave_counts[tid / kWave] = __popcll(ended);
         __syncthreads();
-        // rows ending in the tile: end item Ap[i+1] + i < d1 -- a prefix of the candidates
-        int c = __syncthreads_count(tid < avail && (int64_t)ro[tid + 1] + i0 + tid < d1);
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < kBalBlock / kWave; w++) c += wave_counts[w];
         if (c == kBalBlock && avail > kBalBlock) { // kBalBlock+ rows end here (mean row length < 3): look at all candidates
             for (int k = kBalBlock + 1 + tid; k <= avail; k += kBalBlock) ro[k] = Ap[i0 + k];
-            __syncthreads();
+            __syncthreads(); // (also: every wave has read the first-stage counts)
             int mine = 0;
             for (int k = kBalBlock + tid; k < avail; k += kBalBlock) mine += ((int64_t)ro[k + 1] + i0 + k < d1);
 #pragma unroll
@@ -486,7 +497,7 @@ csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict
         }
         // next tile's offsets: in flight while this tile's entries are processed
         pref = offset_at(i0 + c + tid);
-        pref_hi = tid == 0 ? offset_at(i0 + c + kBalBlock) : 0;
+        pref_up = offset_at(i0 + c + tid + 1);
         int64_t j1 = j0 + (kBalItems - c);
         if (j1 > num_entries) j1 = num_entries;
         // the row after the last finished one may have its first entries here
@@ -544,7 +555,6 @@ csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict
         }
         i0 += c;
         j0 = j1;
-        __syncthreads(); // ro / prod are rewritten by the next tile
     }
 }
 
