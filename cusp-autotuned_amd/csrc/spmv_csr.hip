@@ -435,22 +435,28 @@ csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict
     // synchronisation there is -- whoever writes buffer b for tile t+2 has passed tile t+1's barriers, which
     // every wave reaches only after its reads of tile t.
     __shared__ __attribute__((aligned(16))) T prod_buf[2][kBalItems + 8];
-    __shared__ int ro_buf[2][kBalItems + 2];
+    __shared__ int ro_buf[2][kBalBlock + 2];
     __shared__ int wave_counts_buf[2][kBalBlock / kWave];
     const int tid = threadIdx.x;
 
-    const int64_t t_begin = (int64_t)blockIdx.x * per; // `per` consecutive tiles per workgroup, workgroups in launch order
-    const int64_t t_end = t_begin + per < num_tiles ? t_begin + per : num_tiles;
-    if (t_begin >= t_end) return; // whole workgroup
+    // `per` nominal tiles per workgroup, workgroups in launch order: items [d, d_end) of the merged sequence.
+    // Only the chunk's ends sit on multiples of kBalItems (all the independent search below needs); inside the
+    // chunk a tile ends after kBalItems items OR after the kBalBlock-th row end, whichever comes first, so at
+    // most one row per lane ends in a tile (runs of empty or one-entry rows simply make shorter tiles).
+    const int64_t total_items = num_rows + num_entries;
+    int64_t d = (int64_t)blockIdx.x * per * kBalItems;
+    int64_t d_end = d + per * kBalItems;
+    if (d_end > total_items) d_end = total_items;
+    if (d >= d_end) return; // whole workgroup
+    (void)num_tiles;
 
-    // ---- where does item t_begin * kBalItems fall?  i0 = rows whose end item precedes it.  Row i's end
-    //      is item Ap[i+1] + i of the merged sequence (strictly increasing in i): kBalBlock-ary search. ----
-    const int64_t d0 = t_begin * kBalItems;
+    // ---- where does item d fall?  i0 = rows whose end item precedes it.  Row i's end is item
+    //      Ap[i+1] + i of the merged sequence (strictly increasing in i): kBalBlock-ary search. ----
     int64_t lo = 0, hi = num_rows;
     while (lo < hi) {
         const int64_t step = (hi - lo + kBalBlock - 1) / kBalBlock;
         const int64_t p = lo + (int64_t)tid * step;
-        const int consumed = p < hi ? ((int64_t)Ap[p + 1] + p < d0) : 0;
+        const int consumed = p < hi ? ((int64_t)Ap[p + 1] + p < d) : 0;
         const int c = __syncthreads_count(consumed); // the true probes are a prefix
         if (c == 0) { hi = lo; break; }
         const int64_t last_true = lo + (int64_t)(c - 1) * step;
@@ -458,8 +464,8 @@ csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict
         lo = last_true + 1;
         hi = first_false < hi ? first_false : hi;
     }
-    int64_t i0 = lo;          // first row not yet finished
-    int64_t j0 = d0 - i0;     // first entry not yet consumed
+    int64_t i0 = lo;         // first row not yet finished
+    int64_t j0 = d - i0;     // first entry not yet consumed
 
     // Row offsets of the next tile are requested one tile ahead (registers `pref`, `pref_up`: Ap[i0 + tid] and
     // Ap[i0 + tid + 1]), so a tile's dependent chain is  entries -> x gather -> sums,  not  offsets -> entries -> ...
@@ -467,12 +473,12 @@ csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict
     int pref = offset_at(i0 + tid);
     int pref_up = offset_at(i0 + tid + 1); // the row's END offset (lane kBalBlock-1 holds Ap[i0 + kBalBlock])
 
-    for (int64_t t = t_begin; t < t_end; t++) {
-        T *prod = prod_buf[(t - t_begin) & 1];
-        int *ro = ro_buf[(t - t_begin) & 1];
-        int *wave_counts = wave_counts_buf[(t - t_begin) & 1];
-        const int64_t d1 = (t + 1) * kBalItems; // items [t*kBalItems, d1)
-        const int avail = (int)((num_rows - i0) < kBalItems ? (num_rows - i0) : kBalItems); // rows that could end here
+    for (int parity = 0; d < d_end; parity ^= 1) {
+        T *prod = prod_buf[parity];
+        int *ro = ro_buf[parity];
+        int *wave_counts = wave_counts_buf[parity];
+        int64_t d1 = d + kBalItems < d_end ? d + kBalItems : d_end; // items [d, d1)
+        const int avail = (int)((num_rows - i0) < kBalBlock ? (num_rows - i0) : kBalBlock); // candidate rows
         ro[tid] = pref;
         if (tid == kBalBlock - 1) ro[kBalBlock] = pref_up;
         // rows ending in the tile: end item Ap[i+1] + i < d1 -- a prefix of the candidates; counted per wave
@@ -483,35 +489,26 @@ csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict
         int c = 0;
 #pragma unroll
         for (int w = 0; w < kBalBlock / kWave; w++) c += wave_counts[w];
-        if (c == kBalBlock && avail > kBalBlock) { // kBalBlock+ rows end here (mean row length < 3): look at all candidates
-            for (int k = kBalBlock + 1 + tid; k <= avail; k += kBalBlock) ro[k] = Ap[i0 + k];
-            __syncthreads(); // (also: every wave has read the first-stage counts)
-            int mine = 0;
-            for (int k = kBalBlock + tid; k < avail; k += kBalBlock) mine += ((int64_t)ro[k + 1] + i0 + k < d1);
-#pragma unroll
-            for (int o = kWave / 2; o > 0; o >>= 1) mine += __shfl_down(mine, o);
-            if ((tid & (kWave - 1)) == 0) wave_counts[tid / kWave] = mine;
-            __syncthreads();
-#pragma unroll
-            for (int w = 0; w < kBalBlock / kWave; w++) c += wave_counts[w];
+        if (c == kBalBlock) { // every candidate ends before d1: stop right behind the last one's end item
+            const int64_t stop = (int64_t)ro[kBalBlock] + i0 + kBalBlock; // its end item + 1
+            if (stop < d1) d1 = stop;
         }
         // next tile's offsets: in flight while this tile's entries are processed
         pref = offset_at(i0 + c + tid);
         pref_up = offset_at(i0 + c + tid + 1);
-        int64_t j1 = j0 + (kBalItems - c);
-        if (j1 > num_entries) j1 = num_entries;
+        const int64_t j1 = d1 - (i0 + c); // the items below d1 are (i0 + c) row ends and j1 entries
         // the row after the last finished one may have its first entries here
         const bool tail_row = (i0 + c < num_rows) && (j1 > (int64_t)ro[c]);
         const int nr = c + (tail_row ? 1 : 0);
 
         // ---- products of entries [j0, j1) into LDS ----
-        const int base = VEC ? (int)(j0 & ~(int64_t)3) : (int)j0;
+        const int64_t base = VEC ? (j0 & ~(int64_t)3) : j0;
         const int span = (int)(j1 - base);
         if constexpr (VEC) {
             for (int v = tid * 4; v < span; v += kBalBlock * 4) {
-                const int e = base + v;
+                const int64_t e = base + v;
                 T p0, p1, p2, p3;
-                if ((int64_t)e + 4 <= num_entries) {
+                if (e + 4 <= num_entries) {
                     const int4v cidx = *reinterpret_cast<const int4v *>(Aj + e);
                     if constexpr (sizeof(T) == 8) {
                         const double2v v01 = *reinterpret_cast<const double2v *>(Ax + e);
@@ -522,10 +519,10 @@ csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict
                         p0 = vv.x * x[cidx.x]; p1 = vv.y * x[cidx.y]; p2 = vv.z * x[cidx.z]; p3 = vv.w * x[cidx.w];
                     }
                 } else {
-                    p0 = (int64_t)e + 0 < num_entries ? Ax[e + 0] * x[Aj[e + 0]] : T(0);
-                    p1 = (int64_t)e + 1 < num_entries ? Ax[e + 1] * x[Aj[e + 1]] : T(0);
-                    p2 = (int64_t)e + 2 < num_entries ? Ax[e + 2] * x[Aj[e + 2]] : T(0);
-                    p3 = (int64_t)e + 3 < num_entries ? Ax[e + 3] * x[Aj[e + 3]] : T(0);
+                    p0 = e + 0 < num_entries ? Ax[e + 0] * x[Aj[e + 0]] : T(0);
+                    p1 = e + 1 < num_entries ? Ax[e + 1] * x[Aj[e + 1]] : T(0);
+                    p2 = e + 2 < num_entries ? Ax[e + 2] * x[Aj[e + 2]] : T(0);
+                    p3 = e + 3 < num_entries ? Ax[e + 3] * x[Aj[e + 3]] : T(0);
                 }
                 prod[v + 0] = p0; prod[v + 1] = p1; prod[v + 2] = p2; prod[v + 3] = p3;
             }
@@ -534,7 +531,7 @@ csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict
         }
         __syncthreads();
 
-        // ---- row segments: tpr lanes per row, tpr = largest power of two with 256/tpr >= rows (<= 64) ----
+        // ---- row segments: tpr lanes per row, tpr = largest power of two with kBalBlock/tpr >= rows (<= 64) ----
         int tpr = 1;
         while (tpr < kWave && (kBalBlock / (tpr * 2)) >= nr) tpr *= 2;
         const int groups = kBalBlock / tpr;
@@ -555,6 +552,7 @@ csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict
         }
         i0 += c;
         j0 = j1;
+        d = d1;
     }
 }
 
