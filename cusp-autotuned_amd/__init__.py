@@ -17,7 +17,7 @@ from .binding import (  # noqa: F401
     F64, F32,
     KERNEL_AUTO, CSR_SCALAR, CSR_VECTOR, CSR_STREAM, CSR_STREAM_PIPE, CSR_BALANCED, ELL_ROW, DIA_ROW, COO_SEGMENTED, COO_LANE4,
     lib, lib_path, build, version, check,
-    spmv_csr, spmv_csr_dot, spmv_ell, spmv_dia, spmv_coo, spmv_hyb,
+    spmv_csr, spmv_csr_dot, spmv_ell_dot, spmv_dia_dot, spmv_ell, spmv_dia, spmv_coo, spmv_hyb,
     tuning_select, tuning_set, tuning_load, tuning_save, tuning_clear,
     poisson5pt_num_entries, poisson5pt_shard_entries, poisson5pt_csr, poisson5pt_dia,
     csr_to_ell, csr_to_hyb_coo, csr_row_indices, ell_row_lengths,

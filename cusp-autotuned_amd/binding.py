@@ -91,6 +91,8 @@ def _declare(L):
     L.cmi_ipc_close_handle.argtypes = [vp]
     L.cmi_copy_ranges.argtypes = [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), vp]
     L.cmi_spmv_csr_dot_f64.argtypes = [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, cfgp, vp]
+    L.cmi_spmv_ell_dot_f64.argtypes = [i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, cfgp, vp]
+    L.cmi_spmv_dia_dot_f64.argtypes = [i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, cfgp, vp]
     L.cmi_tuning_load.argtypes = [c_char_p]
     L.cmi_tuning_save.argtypes = [c_char_p]
     L.cmi_tuning_set.argtypes = [c_int, c_int, c_double, cfgp]
@@ -222,6 +224,30 @@ def spmv_csr_dot(num_rows, num_cols, Ap, Aj, Ax, x, y, w, result, workspace, cfg
             or Aj.numel() != Ax.numel() or result.numel() < 1):
         raise ValueError("spmv_csr_dot: array lengths do not match the matrix shape")
     check(lib().cmi_spmv_csr_dot_f64(num_rows, num_cols, Aj.numel(), _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(y), _ptr(w),
+                                     _ptr(result), _ptr(workspace), _cfg(cfg), _stream(stream)))
+
+
+def spmv_ell_dot(num_rows, num_cols, width, pitch, Aj, Ax, x, y, w, result, workspace, row_lengths=None, cfg=None, stream=None):
+    """ELL: y <- A x and result[0] <- <y, w> in one pass (f64; cmi_spmv_ell_dot_f64)."""
+    import torch
+    for t, n in ((Ax, "Ax"), (x, "x"), (y, "y"), (w, "w"), (result, "result")):
+        _need(t, n, torch.float64)
+    _need(Aj, "Aj", torch.int32)
+    if x.numel() != num_cols or y.numel() != num_rows or w.numel() != num_rows or Aj.numel() < width * pitch or Ax.numel() < width * pitch:
+        raise ValueError("spmv_ell_dot: array lengths do not match the matrix shape")
+    check(lib().cmi_spmv_ell_dot_f64(num_rows, num_cols, width, pitch, _ptr(Aj), _ptr(Ax), _ptr(row_lengths), _ptr(x), _ptr(y), _ptr(w),
+                                     _ptr(result), _ptr(workspace), _cfg(cfg), _stream(stream)))
+
+
+def spmv_dia_dot(num_rows, num_cols, num_diagonals, pitch, offsets, values, x, y, w, result, workspace, cfg=None, stream=None):
+    """DIA: y <- A x and result[0] <- <y, w> in one pass (f64; cmi_spmv_dia_dot_f64)."""
+    import torch
+    for t, n in ((values, "values"), (x, "x"), (y, "y"), (w, "w"), (result, "result")):
+        _need(t, n, torch.float64)
+    _need(offsets, "offsets", torch.int32)
+    if x.numel() != num_cols or y.numel() != num_rows or w.numel() != num_rows or offsets.numel() != num_diagonals or values.numel() < num_diagonals * pitch:
+        raise ValueError("spmv_dia_dot: array lengths do not match the matrix shape")
+    check(lib().cmi_spmv_dia_dot_f64(num_rows, num_cols, num_diagonals, pitch, _ptr(offsets), _ptr(values), _ptr(x), _ptr(y), _ptr(w),
                                      _ptr(result), _ptr(workspace), _cfg(cfg), _stream(stream)))
 
 

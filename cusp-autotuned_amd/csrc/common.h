@@ -66,6 +66,22 @@ __device__ __forceinline__ unsigned int *ticket_of(double *workspace)
     return reinterpret_cast<unsigned int *>(workspace + kPartialCapacity + kFoldedMax);
 }
 
+// One partial of a fused dot product per workgroup: lanes folded by a fixed wave butterfly, waves in order
+// (`slots`: one double per wave of the workgroup, in LDS).  Every thread of the workgroup must call it.
+__device__ __forceinline__ void tile_dot_store(double d, double *slots, double *out)
+{
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) d += __shfl_down(d, o);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) slots[wave] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < (int)((blockDim.x + kWave - 1) / kWave); w++) s += slots[w];
+        *out = s;
+    }
+}
+
 // XCD-aware tile index.  Workgroups b and b+8 share an XCD (observed round-robin placement; a
 // different placement changes speed only, never results).  mode 0: tile = b.  mode 1: every XCD walks
 // one contiguous eighth of the tiles.  mode C >= 2: tiles are dealt to the XCDs in chunks of C

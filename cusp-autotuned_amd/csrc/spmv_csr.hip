@@ -72,20 +72,6 @@ csr_vector_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__res
 // DOT: the workgroup also leaves sum_r y[r] * w[r] over its rows in dot_partial[tile] (double; lanes
 // folded by a fixed wave butterfly, waves in order), so <A x, w> costs no second pass over y -- the
 // CG step <A p, p> (reference cusp/krylov/detail/cg.inl:80-83) with w == x == p.
-__device__ __forceinline__ void tile_dot_store(double d, double *slots, double *out)
-{
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) d += __shfl_down(d, o);
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    if (lane == 0) slots[wave] = d;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int w = 0; w < (int)((blockDim.x + kWave - 1) / kWave); w++) s += slots[w];
-        *out = s;
-    }
-}
-
 template <typename T, int IPT, bool VEC, int POL, bool DOT = false>
 __global__ void __launch_bounds__(1024)
 csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ Ap,

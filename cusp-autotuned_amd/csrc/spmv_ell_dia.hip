@@ -26,12 +26,17 @@ namespace cmi {
 // load -> wait -> branch -> gather -> wait chain per slot.  The adds then run in slot order, skipping
 // padding exactly as the host loop does: same bits.
 
-template <typename T, int RPL, bool ELLR, int POL>
+// DOT: the workgroup also leaves sum_r y[r] * w[r] over its rows in dot_partial[blockIdx.x] (see
+// spmv_csr.hip csr_stream DOT: the CG step <A p, p> without a second pass over y).
+template <typename T, int RPL, bool ELLR, int POL, bool DOT = false>
 __global__ void __launch_bounds__(1024)
 ell_row_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict__ Aj, const T *__restrict__ Ax,
-               const int *__restrict__ row_lengths, const T *__restrict__ x, T *__restrict__ y, int accumulate)
+               const int *__restrict__ row_lengths, const T *__restrict__ x, T *__restrict__ y, int accumulate,
+               const T *__restrict__ w = nullptr, double *__restrict__ dot_partial = nullptr)
 {
     constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
+    __shared__ double dot_slots[DOT ? 1024 / kWave : 1];
+    double dsum = 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * RPL;
     for (int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * RPL; row < num_rows; row += stride) {
         if constexpr (RPL == 1) {
@@ -60,6 +65,7 @@ ell_row_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict
             if (n0 + 2 <= width) { chunk(std::integral_constant<int, 2>(), n0); n0 += 2; }
             if (n0 + 1 <= width) { chunk(std::integral_constant<int, 1>(), n0); }
             st<NTS>(y + row, acc);
+            if constexpr (DOT) dsum += (double)acc * (double)w[row];
         } else {
             // rows row, row+1 (pitch even and arrays 16-byte aligned: checked by the launcher)
             typedef typename vec2<T>::type T2;
@@ -101,7 +107,15 @@ ell_row_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict
                 st<NTS>(y + row, acc0);
                 if (has1) st<NTS>(y + row + 1, acc1);
             }
+            if constexpr (DOT) {
+                dsum += (double)acc0 * (double)w[row];
+                if (has1) dsum += (double)acc1 * (double)w[row + 1];
+            }
         }
+    }
+    if constexpr (DOT) {
+        tile_dot_store(dsum, dot_slots, dot_partial + blockIdx.x);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *ticket_of(dot_partial) = 0;
     }
 }
 
@@ -113,14 +127,15 @@ ell_row_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict
 // order.
 constexpr int kDiaChunk = 256;
 
-template <typename T, int POL>
+template <typename T, int POL, bool DOT = false>
 __global__ void __launch_bounds__(1024)
 dia_row_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t pitch,
                const int *__restrict__ offsets, const T *__restrict__ vals, const T *__restrict__ x,
-               T *__restrict__ y, int accumulate)
+               T *__restrict__ y, int accumulate, const T *__restrict__ w = nullptr, double *__restrict__ dot_partial = nullptr)
 {
     constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
     __shared__ int soff[kDiaChunk];
+    __shared__ double dot_slots[DOT ? 1024 / kWave : 1];
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = row < num_rows;
     const int64_t lrow = live ? row : num_rows - 1; // dead lanes shadow the last row (loads stay valid)
@@ -153,18 +168,23 @@ dia_row_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t pi
         if (d0 + 1 <= nchunk) { chunk(std::integral_constant<int, 1>(), d0); }
     }
     if (live) st<NTS>(y + row, acc);
+    if constexpr (DOT) {
+        tile_dot_store(live ? (double)acc * (double)w[row] : 0.0, dot_slots, dot_partial + blockIdx.x);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *ticket_of(dot_partial) = 0;
+    }
 }
 
 // two rows per lane: values as T2 vectors; x for the second row is the neighbouring element
-template <typename T, int POL>
+template <typename T, int POL, bool DOT = false>
 __global__ void __launch_bounds__(1024)
 dia_row2_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t pitch,
                 const int *__restrict__ offsets, const T *__restrict__ vals, const T *__restrict__ x,
-                T *__restrict__ y, int accumulate)
+                T *__restrict__ y, int accumulate, const T *__restrict__ w = nullptr, double *__restrict__ dot_partial = nullptr)
 {
     typedef typename vec2<T>::type T2;
     constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
     __shared__ int soff[kDiaChunk];
+    __shared__ double dot_slots[DOT ? 1024 / kWave : 1];
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     const bool live0 = row < num_rows, live1 = row + 1 < num_rows;
     // dead lanes shadow the last even row pair that is fully inside the pitch (loads stay valid)
@@ -209,6 +229,12 @@ dia_row2_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t p
         if (live0) st<NTS>(y + row, acc0);
         if (live1) st<NTS>(y + row + 1, acc1);
     }
+    if constexpr (DOT) {
+        double d = live0 ? (double)acc0 * (double)w[row] : 0.0;
+        if (live1) d += (double)acc1 * (double)w[row + 1];
+        tile_dot_store(d, dot_slots, dot_partial + blockIdx.x);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *ticket_of(dot_partial) = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -216,8 +242,10 @@ dia_row2_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t p
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 static int spmv_ell(int dtype, int64_t rows, int64_t cols, int64_t width, int64_t pitch, const int *Aj, const T *Ax,
-                    const int *row_lengths, const T *x, T *y, int accumulate, const cmi_config *user, void *stream)
+                    const int *row_lengths, const T *x, T *y, int accumulate, const cmi_config *user, void *stream,
+                    const T *wdot = nullptr, double *dot_partial = nullptr, int *dot_partials = nullptr)
 {
+    if (dot_partials) *dot_partials = 0; // > 0: the kernel left that many partials of <y, wdot> in dot_partial
     if (rows < 0 || cols < 0 || width < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_ell: negative size");
     if (rows > INT32_MAX || cols > INT32_MAX || width > INT32_MAX)
         return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_ell: sizes exceed the int32 index type");
@@ -229,7 +257,7 @@ static int spmv_ell(int dtype, int64_t rows, int64_t cols, int64_t width, int64_
     select_config(CMI_FORMAT_ELL, dtype, rows, cols, rows * width, user, &c);
     if (c.kernel != CMI_ELL_ROW) return fail(CMI_ERROR_NOT_SUPPORTED, "cmi_spmv_ell: config.kernel is not an ELL kernel");
     hipStream_t s = as_stream(stream);
-    const int block = c.block_size;
+    int block = c.block_size;
     const int pol = c.nontemporal & 3;
     const bool ellr = row_lengths != nullptr;
     int rpl = c.items_per_thread >= 2 ? 2 : 1;
@@ -237,6 +265,9 @@ static int spmv_ell(int dtype, int64_t rows, int64_t cols, int64_t width, int64_
     if (rpl == 2 && !(pitch % 2 == 0 && reinterpret_cast<uintptr_t>(Aj) % 8 == 0 &&
                       reinterpret_cast<uintptr_t>(Ax) % (2 * sizeof(T)) == 0))
         rpl = 1;
+    // a fused dot leaves one partial per workgroup: widen the workgroups until they fit the workspace
+    if (wdot && dot_partial)
+        while (block < 1024 && ceil_div(rows, (int64_t)block * rpl) > kPartialCapacity) block *= 2;
     int64_t blocks = ceil_div(rows, (int64_t)block * rpl); // one-shot grid (see spmv_csr.hip grid_for)
     const int64_t cap = (int64_t)1 << 22;
     if (blocks > cap) blocks = cap;
@@ -247,8 +278,25 @@ static int spmv_ell(int dtype, int64_t rows, int64_t cols, int64_t width, int64_
         hipLaunchKernelGGL((ell_row_kernel<T, RPL, ELLR, decltype(P)::value>), dim3(grid), dim3(block), 0, s, rows, w, \
                            pitch, Aj, Ax, row_lengths, x, y, accumulate);                                         \
     })
+#define CMI_ELL_LAUNCH_DOT(RPL, ELLR)                                                                         \
+    with_policy(pol, [&](auto P) {                                                                                \
+        hipLaunchKernelGGL((ell_row_kernel<T, RPL, ELLR, decltype(P)::value, true>), dim3(grid), dim3(block), 0, s, rows, w, \
+                           pitch, Aj, Ax, row_lengths, x, y, accumulate, wdot, dot_partial);                      \
+    })
+    const bool dot = wdot && dot_partial && std::is_same<T, double>::value && grid <= kPartialCapacity &&
+                     (int64_t)grid * block * rpl >= rows; // one-shot grid: every workgroup leaves exactly one partial
+    if constexpr (std::is_same<T, double>::value) {
+        if (dot) {
+            if (rpl == 1) { if (ellr) CMI_ELL_LAUNCH_DOT(1, true); else CMI_ELL_LAUNCH_DOT(1, false); }
+            else          { if (ellr) CMI_ELL_LAUNCH_DOT(2, true); else CMI_ELL_LAUNCH_DOT(2, false); }
+            CMI_LAUNCH_CHECK("ell spmv dot");
+            if (dot_partials) *dot_partials = grid;
+            return CMI_SUCCESS;
+        }
+    }
     if (rpl == 1) { if (ellr) CMI_ELL_LAUNCH(1, true); else CMI_ELL_LAUNCH(1, false); }
     else          { if (ellr) CMI_ELL_LAUNCH(2, true); else CMI_ELL_LAUNCH(2, false); }
+#undef CMI_ELL_LAUNCH_DOT
 #undef CMI_ELL_LAUNCH
     CMI_LAUNCH_CHECK("ell spmv");
     return CMI_SUCCESS;
@@ -256,8 +304,10 @@ static int spmv_ell(int dtype, int64_t rows, int64_t cols, int64_t width, int64_
 
 template <typename T>
 static int spmv_dia(int dtype, int64_t rows, int64_t cols, int64_t ndiag, int64_t pitch, const int *offsets,
-                    const T *vals, const T *x, T *y, int accumulate, const cmi_config *user, void *stream)
+                    const T *vals, const T *x, T *y, int accumulate, const cmi_config *user, void *stream,
+                    const T *wdot = nullptr, double *dot_partial = nullptr, int *dot_partials = nullptr)
 {
+    if (dot_partials) *dot_partials = 0;
     if (rows < 0 || cols < 0 || ndiag < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_dia: negative size");
     if (rows > INT32_MAX || cols > INT32_MAX || ndiag > INT32_MAX)
         return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_dia: sizes exceed the int32 index type");
@@ -268,19 +318,30 @@ static int spmv_dia(int dtype, int64_t rows, int64_t cols, int64_t ndiag, int64_
     select_config(CMI_FORMAT_DIA, dtype, rows, cols, rows * ndiag, user, &c);
     if (c.kernel != CMI_DIA_ROW) return fail(CMI_ERROR_NOT_SUPPORTED, "cmi_spmv_dia: config.kernel is not a DIA kernel");
     hipStream_t s = as_stream(stream);
-    const int block = c.block_size;
+    int block = c.block_size;
     const int pol = c.nontemporal & 3;
     int rpl = c.items_per_thread >= 2 ? 2 : 1;
     if (rpl == 2 && !(pitch % 2 == 0 && reinterpret_cast<uintptr_t>(vals) % (2 * sizeof(T)) == 0)) rpl = 1;
+    if (wdot && dot_partial) // one partial per workgroup: widen the workgroups until they fit the workspace
+        while (block < 1024 && ceil_div(rows, (int64_t)block * rpl) > kPartialCapacity) block *= 2;
     const int64_t grid64 = ceil_div(rows, (int64_t)block * rpl);
     if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_dia: grid too large");
     const int grid = (int)grid64, nd = (int)ndiag;
+    const bool dot = wdot && dot_partial && std::is_same<T, double>::value && grid <= kPartialCapacity;
     with_policy(pol, [&](auto P) {
         constexpr int POL = decltype(P)::value;
+        if constexpr (std::is_same<T, double>::value) {
+            if (dot) {
+                if (rpl == 1) hipLaunchKernelGGL((dia_row_kernel<T, POL, true>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate, wdot, dot_partial);
+                else          hipLaunchKernelGGL((dia_row2_kernel<T, POL, true>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate, wdot, dot_partial);
+                return;
+            }
+        }
         if (rpl == 1) hipLaunchKernelGGL((dia_row_kernel<T, POL>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate);
         else          hipLaunchKernelGGL((dia_row2_kernel<T, POL>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate);
     });
     CMI_LAUNCH_CHECK("dia spmv");
+    if (dot && dot_partials) *dot_partials = grid;
     return CMI_SUCCESS;
 }
 
@@ -309,4 +370,32 @@ CMI_API int cmi_spmv_dia_f32(int64_t num_rows, int64_t num_cols, int64_t num_dia
                              int accumulate, const cmi_config *cfg, void *stream)
 {
     return cmi::spmv_dia<float>(CMI_F32, num_rows, num_cols, num_diagonals, pitch, diagonal_offsets, values, x, y, accumulate, cfg, stream);
+}
+
+// y <- A x and *dot_dev <- <y, w> in one pass (see cmi_spmv_csr_dot_f64); when the launch shape cannot fuse the
+// dot (more workgroups than the workspace holds partials), the plain SpMV followed by cmi_blas_dot_f64.
+CMI_API int cmi_spmv_ell_dot_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries_per_row, int64_t pitch,
+                                 const int32_t *Aj, const double *Ax, const int32_t *row_lengths, const double *x,
+                                 double *y, const double *w, double *dot_dev, void *workspace, const cmi_config *cfg, void *stream)
+{
+    if ((!w && num_rows > 0) || !dot_dev || !workspace) return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_ell_dot: null w, result or workspace");
+    int partials = 0;
+    const int st = cmi::spmv_ell<double>(CMI_F64, num_rows, num_cols, num_entries_per_row, pitch, Aj, Ax, row_lengths, x, y, 0, cfg, stream,
+                                         w, (double *)workspace, &partials);
+    if (st) return st;
+    if (partials > 0) return cmi::reduce_partials_f64(partials, (double *)workspace, dot_dev, cmi::as_stream(stream));
+    return cmi_blas_dot_f64(num_rows, y, w, dot_dev, workspace, stream);
+}
+
+CMI_API int cmi_spmv_dia_dot_f64(int64_t num_rows, int64_t num_cols, int64_t num_diagonals, int64_t pitch,
+                                 const int32_t *diagonal_offsets, const double *values, const double *x, double *y,
+                                 const double *w, double *dot_dev, void *workspace, const cmi_config *cfg, void *stream)
+{
+    if ((!w && num_rows > 0) || !dot_dev || !workspace) return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_dia_dot: null w, result or workspace");
+    int partials = 0;
+    const int st = cmi::spmv_dia<double>(CMI_F64, num_rows, num_cols, num_diagonals, pitch, diagonal_offsets, values, x, y, 0, cfg, stream,
+                                         w, (double *)workspace, &partials);
+    if (st) return st;
+    if (partials > 0) return cmi::reduce_partials_f64(partials, (double *)workspace, dot_dev, cmi::as_stream(stream));
+    return cmi_blas_dot_f64(num_rows, y, w, dot_dev, workspace, stream);
 }

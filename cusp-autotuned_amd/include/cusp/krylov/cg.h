@@ -73,6 +73,19 @@ template <typename A, typename V> void multiply_dot(const A &a, const V &p, V &y
     cusp::detail::check(cmi_spmv_csr_dot_f64(a.num_rows, a.num_cols, a.num_entries, a.row_offsets.data(), a.column_indices.data(),
                                              a.values.data(), p.data(), y.data(), p.data(), yp, ws, cusp::detail::forced_config(), nullptr));
 }
+template <typename A, typename V> void multiply_dot(const A &a, const V &p, V &y, double *yp, void *ws, cusp::ell_format)
+{
+    cusp::detail::require_int_index<A>();
+    cusp::detail::check(cmi_spmv_ell_dot_f64(a.num_rows, a.num_cols, a.column_indices.num_cols, a.column_indices.pitch, cusp::detail::data_of(a.column_indices),
+                                             cusp::detail::data_of(a.values), cusp::detail::row_lengths_of(a, 0), p.data(), y.data(), p.data(), yp, ws,
+                                             cusp::detail::forced_config(), nullptr));
+}
+template <typename A, typename V> void multiply_dot(const A &a, const V &p, V &y, double *yp, void *ws, cusp::dia_format)
+{
+    cusp::detail::require_int_index<A>();
+    cusp::detail::check(cmi_spmv_dia_dot_f64(a.num_rows, a.num_cols, a.values.num_cols, a.values.pitch, a.diagonal_offsets.data(),
+                                             cusp::detail::data_of(a.values), p.data(), y.data(), p.data(), yp, ws, cusp::detail::forced_config(), nullptr));
+}
 template <typename A, typename V, typename Format> void multiply_dot(const A &a, const V &p, V &y, double *yp, void *ws, Format)
 {
     cusp::multiply(a, p, y);

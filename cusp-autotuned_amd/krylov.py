@@ -152,7 +152,7 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
     import torch
     from . import binding as B
     from .distributed import ShardedCsr
-    from .matrices import CsrMatrix
+    from .matrices import CsrMatrix, DiaMatrix, EllMatrix
     dev = x.device
     rr = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(2)]  # <r,r> ping-pong
     yp = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -169,6 +169,11 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
             A.multiply_dot(y, yp, ops.ws)        # p IS A.x_local
         elif isinstance(A, CsrMatrix):
             B.spmv_csr_dot(A.num_rows, A.num_cols, A.row_offsets, A.column_indices, A.values, p, y, p, yp, ops.ws)
+        elif isinstance(A, EllMatrix):
+            B.spmv_ell_dot(A.num_rows, A.num_cols, A.num_entries_per_row, A.pitch, A.column_indices, A.values, p, y, p, yp, ops.ws,
+                           row_lengths=A.row_lengths)
+        elif isinstance(A, DiaMatrix):
+            B.spmv_dia_dot(A.num_rows, A.num_cols, A.diagonal_offsets.numel(), A.pitch, A.diagonal_offsets, A.values, p, y, p, yp, ops.ws)
         else:
             spmv(p, y)
             B.blas_dot(y, p, yp, ops.ws)

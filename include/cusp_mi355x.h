@@ -181,6 +181,15 @@ int cmi_spmv_csr_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries, co
 int cmi_spmv_csr_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ap,
                      const int32_t *Aj, const float *Ax, const float *x, float *y, int accumulate,
                      const cmi_config *cfg, void *stream);
+/* The same fusion for ELL (ELLR with row_lengths) and DIA: one lane per row owns y[row], so <y, w> costs one  */
+/* extra coalesced read of w and one partial per workgroup.                                                    */
+int cmi_spmv_ell_dot_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries_per_row, int64_t pitch,
+                         const int32_t *ell_Aj, const double *ell_Ax, const int32_t *row_lengths, const double *x,
+                         double *y, const double *w, double *dot_dev, void *workspace, const cmi_config *cfg,
+                         void *stream);
+int cmi_spmv_dia_dot_f64(int64_t num_rows, int64_t num_cols, int64_t num_diagonals, int64_t pitch,
+                         const int32_t *diagonal_offsets, const double *values, const double *x, double *y,
+                         const double *w, double *dot_dev, void *workspace, const cmi_config *cfg, void *stream);
 /* Row-length profile.  With cfg == NULL (or kernel AUTO) cmi_spmv_csr_* measures the longest row of a    */
 /* matrix the first time it sees it (key: row-offset pointer, rows, entries, device; ~20 us, one stream    */
 /* synchronisation; skipped while the stream is being captured) and switches from the table's row-tile     */

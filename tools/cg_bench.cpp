@@ -1,9 +1,13 @@
 // tools/cg_bench.cpp -- CG iterations/s through the C++ layer (cusp::krylov::cg on device_memory), the
 // caller of the SpMV hot path: poisson5pt(grid, grid), b = deterministic x pattern, fixed iteration count.
-//   cg_bench [--grid=3162] [--iterations=200]
+//   cg_bench [--grid=3162] [--iterations=200] [--format=csr|ell|dia|hyb|coo]
 // Prints the fused device path (default: identity preconditioner, double) and, for comparison, the plain
 // operation-by-operation path (forced by passing an explicit non-identity-typed preconditioner).
+#include <cusp/coo_matrix.h>
 #include <cusp/csr_matrix.h>
+#include <cusp/dia_matrix.h>
+#include <cusp/ell_matrix.h>
+#include <cusp/hyb_matrix.h>
 #include <cusp/gallery/poisson.h>
 #include <cusp/krylov/cg.h>
 #include <cusp/monitor.h>
@@ -19,17 +23,13 @@ struct copy_preconditioner {
     template <typename X, typename Y> void operator()(const X &x, Y &y) const { cusp::blas::copy(x, y); }
 };
 
-int main(int argc, char **argv)
+template <typename Matrix> int run(size_t grid, size_t iters, const char *name)
 {
-    size_t grid = 3162, iters = 200;
-    for (int i = 1; i < argc; i++) {
-        if (!std::strncmp(argv[i], "--grid=", 7)) grid = std::strtoul(argv[i] + 7, nullptr, 10);
-        if (!std::strncmp(argv[i], "--iterations=", 13)) iters = std::strtoul(argv[i] + 13, nullptr, 10);
-    }
-    try {
-        cusp::csr_matrix<int, double, cusp::device_memory> A;
+    {
+        Matrix A;
         cusp::gallery::poisson5pt(A, grid, grid);
         const size_t N = A.num_rows;
+        std::printf("format %s\n", name);
         cusp::array1d<double, cusp::host_memory> hb(N);
         for (size_t i = 0; i < N; i++) hb[i] = double((unsigned(i) * 2654435761u) % 1000u) / 997.0 - 0.5;
         cusp::array1d<double, cusp::device_memory> b(hb);
@@ -46,6 +46,26 @@ int main(int argc, char **argv)
             std::printf("%-5s  %zu iterations in %8.1f ms = %7.0f it/s, %7.1f us/iteration; final ||r|| = %.6e\n", fused ? "fused" : "plain",
                         monitor.iteration_count(), sec * 1e3, monitor.iteration_count() / sec, sec / monitor.iteration_count() * 1e6, monitor.residual_norm());
         }
-    } catch (const std::exception &e) { std::fprintf(stderr, "ERROR: %s\n", e.what()); return 1; }
+    }
     return 0;
+}
+
+int main(int argc, char **argv)
+{
+    size_t grid = 3162, iters = 200;
+    std::string format = "csr";
+    for (int i = 1; i < argc; i++) {
+        if (!std::strncmp(argv[i], "--grid=", 7)) grid = std::strtoul(argv[i] + 7, nullptr, 10);
+        if (!std::strncmp(argv[i], "--iterations=", 13)) iters = std::strtoul(argv[i] + 13, nullptr, 10);
+        if (!std::strncmp(argv[i], "--format=", 9)) format = argv[i] + 9;
+    }
+    try {
+        if (format == "csr") return run<cusp::csr_matrix<int, double, cusp::device_memory>>(grid, iters, "csr");
+        if (format == "ell") return run<cusp::ell_matrix<int, double, cusp::device_memory>>(grid, iters, "ell");
+        if (format == "dia") return run<cusp::dia_matrix<int, double, cusp::device_memory>>(grid, iters, "dia");
+        if (format == "hyb") return run<cusp::hyb_matrix<int, double, cusp::device_memory>>(grid, iters, "hyb");
+        if (format == "coo") return run<cusp::coo_matrix<int, double, cusp::device_memory>>(grid, iters, "coo");
+        std::fprintf(stderr, "unknown --format=%s\n", format.c_str());
+        return 2;
+    } catch (const std::exception &e) { std::fprintf(stderr, "ERROR: %s\n", e.what()); return 1; }
 }
