@@ -63,6 +63,9 @@ def test_argument_validation_of_the_newer_entry_points(cmi):
     i64 = ctypes.c_int64
     assert L.cmi_spmv_csr_dot_f64(5, 5, 3, None, None, None, None, None, None, None, None, None, None) == 1
     assert b"cmi_spmv_csr_dot" in L.cmi_last_error()
+    assert L.cmi_spmv_ell_dot_f64(5, 5, 2, 8, None, None, None, None, None, None, None, None, None, None) == 1
+    assert L.cmi_spmv_dia_dot_f64(5, 5, 2, 8, None, None, None, None, None, None, None, None, None) == 1
+    assert b"cmi_spmv_dia_dot" in L.cmi_last_error()
     assert L.cmi_cg_update_f64(-1, None, None, None, None, None, None, None, None, None, None) == 1
     assert L.cmi_cg_update_f64(4, None, None, None, None, None, None, None, None, None, None) == 1  # null scalars
     assert L.cmi_cg_direction_f64(4, None, None, None, None, None) == 1
