@@ -39,6 +39,23 @@ def partition_rows(num_rows, world):
     return [min(r * count, num_rows) for r in range(world + 1)]
 
 
+def partition_by_entries(row_offsets, world):
+    """Row blocks balanced by ENTRIES ("balanced by nnz"): block r ends at the first row whose
+    cumulative entry count reaches (r+1)/world of the total.  row_offsets: the GLOBAL CSR row offsets (host
+    sequence or tensor, length num_rows + 1).  Returns world+1 row offsets; slices may differ in length (the
+    halo and one-sided exchanges take any partition; the all-gather pads to the longest slice)."""
+    import bisect
+    ro = row_offsets.tolist() if hasattr(row_offsets, "tolist") else list(row_offsets)
+    num_rows, nnz = len(ro) - 1, ro[-1]
+    cuts = [0]
+    for r in range(1, world):
+        target = (nnz * r + world - 1) // world
+        row = bisect.bisect_left(ro, target, lo=cuts[-1], hi=num_rows)  # first row offset >= target
+        cuts.append(min(max(row, cuts[-1]), num_rows))
+    cuts.append(num_rows)
+    return cuts
+
+
 @dataclass
 class ExchangePlan:
     mode: str                 # "allgather" | "halo"
@@ -52,19 +69,25 @@ class ExchangePlan:
 class ShardedVectorExchange:
     """Owns the full-length x buffer of one rank and fills it before a multiply."""
 
-    def __init__(self, num_cols, rank, world, col_min, col_max, dtype, device, mode="auto", group=None):
+    def __init__(self, num_cols, rank, world, col_min, col_max, dtype, device, mode="auto", group=None, offsets=None):
         import torch
         import torch.distributed as dist
         self.dist, self.torch = dist, torch
         self.rank, self.world, self.group = rank, world, group
         self.num_cols = num_cols
         self._span = (col_min, col_max)
-        self.offsets = partition_rows(num_cols, world)
-        self.count = self.offsets[1] - self.offsets[0] if world > 0 else 0
+        # the partition of x (= of the rows): equal counts by default, any monotone cut list on request
+        # (partition_by_entries); `count` = the longest slice = the all-gather's padded piece
+        self.offsets = list(offsets) if offsets is not None else partition_rows(num_cols, world)
+        if len(self.offsets) != world + 1 or self.offsets[0] != 0 or self.offsets[-1] != num_cols or \
+                any(b < a for a, b in zip(self.offsets, self.offsets[1:])):
+            raise ValueError(f"offsets must be {world + 1} non-decreasing cuts from 0 to {num_cols}")
+        self.count = max((b - a for a, b in zip(self.offsets, self.offsets[1:])), default=0)
+        self.uniform = all(self.offsets[r] == min(r * self.count, num_cols) for r in range(world + 1))
         self.lo, self.hi = self.offsets[rank], self.offsets[rank + 1]
-        # buffer padded to world*count so the all-gather can write equal-sized pieces; in HBM it is an
-        # allocation of its own (not a slice of torch's caching allocator) so that peers can map it
-        numel = max(world * self.count, 1)
+        # buffer padded to world*count so the all-gather of a uniform partition can write straight into it; in
+        # HBM it is an allocation of its own (not a slice of torch's caching allocator) so that peers can map it
+        numel = max(world * self.count, num_cols, 1)
         self._buffer = None
         if torch.device(device).type == "cuda":
             from . import binding as B
@@ -111,6 +134,8 @@ class ShardedVectorExchange:
             elif mode == "peer":
                 raise RuntimeError("exchange mode 'peer' requested but a rank could not map or verify its neighbours' buffers")
         self._gather_in = None
+        self._gather_out = None  # non-uniform partition: padded landing zone of the all-gather
+        self._unpad = None
         self._ops = None
         # RCCL orders its transfers after the work already queued on the compute stream.  A host
         # transport (gloo in the one-GPU tests) reads the send buffer from the CPU with no such
@@ -242,7 +267,14 @@ class ShardedVectorExchange:
         if plan.mode == "allgather":
             n = self.hi - self.lo
             self._gather_in[:n].copy_(self.x_local)
-            return [dist.all_gather_into_tensor(self.x_full, self._gather_in, group=self.group, async_op=True)]
+            if self.uniform:
+                return [dist.all_gather_into_tensor(self.x_full, self._gather_in, group=self.group, async_op=True)]
+            # slices of different lengths: gather the padded pieces, then move each to its global position
+            if self._gather_out is None:
+                self._gather_out = self.torch.zeros(self.world * self.count, dtype=self.x_full.dtype, device=self.x_full.device)
+            dist.all_gather_into_tensor(self._gather_out, self._gather_in, group=self.group)
+            self._unpad_gathered()
+            return []
         if self._ops is None:
             self._ops = self._build_ops()  # built once: the ranges never change
         if not self._ops:
@@ -257,6 +289,21 @@ class ShardedVectorExchange:
             if self._gather_in is None:
                 self._gather_in = self.torch.zeros(self.count, dtype=self.x_full.dtype, device=self.x_full.device)
             return self.start()
+
+    def _unpad_gathered(self):
+        item = self.x_full.element_size()
+        pieces = [(p * self.count, self.offsets[p], self.offsets[p + 1] - self.offsets[p]) for p in range(self.world) if p != self.rank]
+        if self.x_full.is_cuda:
+            if self._unpad is None:
+                from . import binding as B
+                src, dst = self._gather_out.data_ptr(), self.x_full.data_ptr()
+                rs = [(src + a * item, dst + b * item, n * item) for a, b, n in pieces if n > 0]
+                self._unpad = [B.CopyRanges(rs[i:i + B.MAX_COPY_RANGES]) for i in range(0, len(rs), B.MAX_COPY_RANGES)]
+            for c in self._unpad:
+                c.launch()
+        else:
+            for a, b, n in pieces:
+                self.x_full[b:b + n].copy_(self._gather_out[a:a + n])
 
     @staticmethod
     def finish(works):
@@ -276,7 +323,7 @@ class ShardedCsr:
     exchange logic without a GPU.)"""
 
     def __init__(self, A_local, num_cols, rank, world, mode="auto", group=None, local_multiply=None,
-                 col_span=None, overlap=True, interior=None):
+                 col_span=None, overlap=True, interior=None, offsets=None):
         import torch
         self.A = A_local
         self.rank, self.world = rank, world
@@ -287,7 +334,7 @@ class ShardedCsr:
             else:
                 col_span = (0, -1)
         self.vec = ShardedVectorExchange(num_cols, rank, world, col_span[0], col_span[1], A_local.values.dtype, dev,
-                                         mode=mode, group=group)
+                                         mode=mode, group=group, offsets=offsets)
         if A_local.num_rows != self.vec.hi - self.vec.lo:
             raise ValueError(f"rank {rank}: local block has {A_local.num_rows} rows, partition expects "
                              f"{self.vec.hi - self.vec.lo}")
@@ -355,7 +402,7 @@ class ShardedCsr:
         rank calls it).  krylov.cg keeps its residual in one so that peers can pull its boundary values."""
         v = self.vec
         return ShardedVectorExchange(v.num_cols, v.rank, v.world, v._span[0], v._span[1], v.x_full.dtype, v.x_full.device,
-                                     mode=v.plan.mode, group=v.group)
+                                     mode=v.plan.mode, group=v.group, offsets=v.offsets)
 
     def halo_ranges(self):
         """[lo, hi) of this rank's slice merged with the ranges it receives: the contiguous pieces of the

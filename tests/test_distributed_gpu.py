@@ -76,6 +76,61 @@ def test_ranks_share_one_gpu_real_kernels(tmp_path, orc, mode, world):
         assert all(int(parts[r]["recv"]) == (2 * m if r in inner else m) for r in range(world))
 
 
+def _worker_by_entries(rank, world, port, mode, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from test_distributed_cpu import _irregular
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cusp_autotuned_amd as cmi
+        N, Ap, Aj, Ax = _irregular()
+        offs = cmi.distributed.partition_by_entries(Ap, world)
+        lo, hi = offs[rank], offs[rank + 1]
+        lAp = torch.from_numpy((Ap[lo:hi + 1] - Ap[lo]).astype(np.int32)).cuda()
+        lAj = torch.from_numpy(Aj[Ap[lo]:Ap[hi]].copy()).cuda()
+        lAx = torch.from_numpy(Ax[Ap[lo]:Ap[hi]].copy()).cuda()
+        A = cmi.CsrMatrix(hi - lo, N, lAx.numel(), lAp, lAj, lAx)
+        sh = cmi.distributed.ShardedCsr(A, N, rank, world, mode=mode, offsets=offs)
+        sh.x_local.copy_(cmi.fill_x(hi - lo, start=lo).cuda())
+        y = torch.empty(hi - lo, dtype=torch.float64, device="cuda")
+        sh.vec.fence()
+        sh.multiply(y)
+        sh.vec.fence()
+        sh.x_local.mul_(3.0)
+        sh.vec.fence()
+        y2 = torch.empty_like(y)
+        sh.multiply(y2)
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), y=y.cpu().numpy(), y2=y2.cpu().numpy(), mode=sh.vec.plan.mode, rows=hi - lo)
+        sh.vec.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["peer", "allgather", "halo"])
+def test_unequal_row_blocks_balanced_by_entries(tmp_path, orc, mode):
+    """Three ranks, row blocks of different lengths (equal entry counts) of a heavy-tailed matrix: every exchange
+    reassembles x at its global positions; the all-gather pads and un-pads with cmi_copy_ranges."""
+    import oracle
+    import torch.multiprocessing as mp
+    from test_distributed_cpu import _irregular
+    world = 3
+    mp.spawn(_worker_by_entries, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    N, Ap, Aj, Ax = _irregular()
+    x = oracle.fill_x(N)
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    assert len({int(p["rows"]) for p in parts}) > 1 and all(str(p["mode"]) == mode for p in parts)
+    want, want2 = orc.spmv_csr(Ap, Aj, Ax, x), orc.spmv_csr(Ap, Aj, Ax, 3.0 * x)
+    bound = orc.spmv_csr(Ap, Aj, np.abs(Ax), np.abs(x))
+    got, got2 = np.concatenate([p["y"] for p in parts]), np.concatenate([p["y2"] for p in parts])
+    assert np.all(np.abs(got - want) <= 1e-12 * bound + 1e-300) and np.all(np.abs(got2 - want2) <= 3e-12 * bound + 1e-300)
+
+
 def test_bench_two_ranks_rehearsal(tmp_path):
     """bench.py --gpus 2 end to end on the one GPU of the box (CMI_BENCH_REHEARSAL=1: both ranks on GPU 0,
     gloo): launch line as the driver's, one JSON line from rank 0, one-sided exchange selected."""
