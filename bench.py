@@ -116,6 +116,32 @@ def cpu_baseline(cmi, A, x_host, y_gpu_host, seconds):
     return out, omp
 
 
+def stencil_expected(torch, cmi, m, n, lo, hi, dev, scale=1.0):
+    """Rows [lo, hi) of y = poisson5pt(m, n) * x for the bench's x (cmi.fill_x), from the stencil itself:
+    no matrix, no exchange, no kernel of the library.  Same arithmetic as the reference host loop
+    (sequential/multiply/csr_spmv.h:60-72) on the gallery layout (columns ascending: i-m, i-1, i, i+1, i+m;
+    values -1,-1,4,-1,-1): sum = 0, then sum = sum + a*x in storage order -- bit-exact in fp64 because -1*x
+    and 4*x are exact.  Used to validate an N>1 exchange before it is timed and by the 1e8-row test."""
+    N = m * n
+    e0, e1 = max(lo - m, 0), min(hi + m, N)
+    xe = (cmi.fill_x(e1 - e0, start=e0) * scale).to(dev)          # this rank's rows +- one grid line
+    i = torch.arange(lo, hi, dtype=torch.int64, device=dev)
+    ix = i % m
+    zero = torch.zeros((), dtype=torch.float64, device=dev)
+
+    def term(off, mask, coef):
+        j = (i + off - e0).clamp_(0, e1 - e0 - 1)
+        return torch.where(mask, coef * xe[j], zero)
+
+    s = torch.zeros(hi - lo, dtype=torch.float64, device=dev)
+    s = s + term(-m, i >= m, -1.0)
+    s = s + term(-1, ix > 0, -1.0)
+    s = s + term(0, i >= 0, 4.0)
+    s = s + term(1, ix < m - 1, -1.0)
+    s = s + term(m, i + m < N, -1.0)
+    return s
+
+
 def main():
     args = parse()
     import torch
@@ -169,13 +195,35 @@ def main():
         step = lambda: cmi.multiply(Afmt, x, y)  # noqa: E731
         exchange_info = None
     else:
-        sh = cmi.distributed.ShardedCsr(A, N_global, rank, world, mode=args.exchange,
-                                        col_span=(max(lo - m, 0), min(hi + m, N_global) - 1))
-        sh.x_local.copy_(torch.from_numpy(x_host).to(dev))
+        # The exchange is validated BEFORE anything is timed: one sharded multiply against the stencil's closed
+        # form (bit-exact, no other exchange involved).  A transport that maps its neighbours' buffers but
+        # delivers wrong halos is dropped for the next one (peer -> halo -> allgather), on every rank alike.
+        span = (max(lo - m, 0), min(hi + m, N_global) - 1)
+        want = stencil_expected(torch, cmi, m, n, lo, hi, dev)
+        rejected = []
+        sh = None
+        for mode_try in {"auto": ["auto", "halo", "allgather"], "peer": ["peer", "halo", "allgather"],
+                         "halo": ["halo", "allgather"], "allgather": ["allgather"]}[args.exchange]:
+            if sh is not None:
+                sh.vec.close()
+            sh = cmi.distributed.ShardedCsr(A, N_global, rank, world, mode=mode_try, col_span=span)
+            sh.x_local.copy_(torch.from_numpy(x_host).to(dev))
+            sh.vec.fence()
+            y.fill_(10.0)
+            sh.multiply(y)
+            good = torch.tensor([int(torch.equal(y, want))], dtype=torch.int32, device=dev)
+            dist.all_reduce(good, op=dist.ReduceOp.MIN)
+            if int(good.item()) == 1:
+                break
+            rejected.append(sh.vec.plan.mode)
+        else:
+            raise SystemExit(f"parity gate failed: sharded y differs from the stencil's closed form with every exchange {rejected}")
+        del want
         step = lambda: sh.multiply(y)  # noqa: E731
         p = sh.vec.plan
         exchange_info = {"mode": p.mode, "values_received_per_rank": p.allgather_values if p.mode == "allgather" else p.recv_values,
-                         "allgather_values": p.allgather_values}
+                         "allgather_values": p.allgather_values, "validated_against": "stencil closed form (bit-exact)",
+                         "rejected_exchanges": rejected}
 
     def barrier():
         if dist is not None:

@@ -775,6 +775,68 @@ def test_full_size_properties(cmi, torch_cuda, big):
 
 
 # ------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4] size on ONE device: poisson5pt 10000 x 10000 (N = 1e8, nnz = 499 960 000) -- value arrays
+# of 4 GB, i.e. byte offsets beyond 2^32 and entry positions near the int32 limit, in every format and kernel.
+# Checked against the stencil's closed form (bench.stencil_expected: bit-identical to the oracle, tests/
+# test_bench_helpers.py) so that no 1e8-row host oracle run is needed.
+# ------------------------------------------------------------------------------------------------
+def test_1e8_rows_every_format_and_kernel(cmi, torch_cuda):
+    import bench
+    torch = torch_cuda
+    if torch.cuda.get_device_properties(0).total_memory < 64 * 2**30:
+        pytest.skip("needs 64 GiB of device memory")
+    m = n = 10000
+    N = m * n
+    want = bench.stencil_expected(torch, cmi, m, n, 0, N, "cuda")
+    bound = 8.0 * 0.51
+    dx = cmi.fill_x(N).to("cuda")
+    y = torch.full((N,), 10.0, dtype=torch.float64, device="cuda")
+
+    def check(M, cfg, exact, what):
+        y.fill_(10.0)
+        cmi.multiply(M, dx, y, cfg=cfg)
+        if exact:
+            assert torch.equal(y, want), what
+        else:
+            assert float((y - want).abs().max()) <= 1e-6 * bound, what
+
+    A = cmi.poisson5pt(m, n, "csr")
+    assert A.num_rows == N and A.num_entries == 499960000 == cmi.poisson5pt_num_entries(m, n)
+    assert int(A.row_offsets[-1]) == 499960000 and int(A.column_indices[-1]) == N - 1
+    check(A, None, True, "csr default")
+    for cfg in (cmi.Config(kernel=cmi.CSR_SCALAR), cmi.Config(kernel=cmi.CSR_STREAM, items_per_thread=2, block_size=512),
+                cmi.Config(kernel=cmi.CSR_STREAM_PIPE), cmi.Config(kernel=cmi.CSR_STREAM_PIPE, xcd_swizzle=1, blocks_per_cu=4)):
+        check(A, cfg, True, f"csr {cfg.as_dict()}")
+    for cfg in (cmi.Config(kernel=cmi.CSR_VECTOR, threads_per_row=4), cmi.Config(kernel=cmi.CSR_BALANCED)):
+        check(A, cfg, False, f"csr {cfg.as_dict()}")
+    # fused SpMV + dot at this size (more tiles than the partial list holds -> the plain dot follows the SpMV)
+    res = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ws = cmi.blas_workspace("cuda")
+    y.fill_(10.0)
+    cmi.spmv_csr_dot(N, N, A.row_offsets, A.column_indices, A.values, dx, y, dx, res, ws)
+    assert torch.equal(y, want)
+    ref_dot = float((want * dx).sum())
+    assert abs(float(res.item()) - ref_dot) <= 1e-9 * float((want.abs() * dx.abs()).sum())
+    C = cmi.convert(A, "coo")
+    assert C.num_entries == A.num_entries and int(C.row_indices[-1]) == N - 1
+    check(C, None, False, "coo default")
+    check(C, cmi.Config(kernel=cmi.COO_SEGMENTED), False, "coo segmented")
+    del C
+    H = cmi.convert(A, "hyb", num_entries_per_row=4)
+    assert H.coo.num_entries == (m - 2) * (n - 2)
+    check(H, None, False, "hyb K=4")
+    del H
+    E = cmi.convert(A, "ell")
+    assert E.num_entries_per_row == 5 and E.pitch >= N
+    check(E, None, True, "ell default")
+    check(E, cmi.Config(kernel=cmi.ELL_ROW, items_per_thread=2), True, "ell 2 rows per lane")
+    del E, A
+    D = cmi.poisson5pt(m, n, "dia")
+    for rpl in (1, 2):
+        check(D, cmi.Config(kernel=cmi.DIA_ROW, items_per_thread=rpl), True, f"dia {rpl} rows per lane")
+
+
+# ------------------------------------------------------------------------------------------------
 # CSR -> DIA on the device
 # ------------------------------------------------------------------------------------------------
 def test_device_csr_to_dia_matches_oracle(cmi, torch_cuda, orc, golden_irregular):
