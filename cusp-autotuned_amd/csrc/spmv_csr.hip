@@ -63,6 +63,20 @@ csr_vector_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__res
     }
 }
 
+// s + p[0] + p[1] + ... + p[n-1], added in that order (the reference host loop's order), with the LDS
+// reads of eight terms issued before the first add: a dependent read -> add chain costs ~40 ns per entry,
+// batched reads ~8 ns, and the bits are the same.
+template <typename T> __device__ __forceinline__ T sum_in_order(T s, const T *p, int n)
+{
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        const T v0 = p[j], v1 = p[j + 1], v2 = p[j + 2], v3 = p[j + 3], v4 = p[j + 4], v5 = p[j + 5], v6 = p[j + 6], v7 = p[j + 7];
+        s = s + v0; s = s + v1; s = s + v2; s = s + v3; s = s + v4; s = s + v5; s = s + v6; s = s + v7;
+    }
+    for (; j < n; j++) s = s + p[j];
+    return s;
+}
+
 // ---------------------------------------------------------------------------------------------
 // csr_stream
 // ---------------------------------------------------------------------------------------------
@@ -72,16 +86,18 @@ csr_vector_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__res
 // DOT: the workgroup also leaves sum_r y[r] * w[r] over its rows in dot_partial[tile] (double; lanes
 // folded by a fixed wave butterfly, waves in order), so <A x, w> costs no second pass over y -- the
 // CG step <A p, p> (reference cusp/krylov/detail/cg.inl:80-83) with w == x == p.
-template <typename T, int IPT, bool VEC, int POL, bool DOT = false>
+template <typename T, int IPT, bool VEC, int POL, bool DOT = false, bool LONG = false>
 __global__ void __launch_bounds__(1024)
 csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ Ap,
                   const int *__restrict__ Aj, const T *__restrict__ Ax, const T *__restrict__ x,
                   T *__restrict__ y, int rows_per_block, int64_t num_tiles, int64_t tiles_per_xcd,
-                  int swizzle, int accumulate, int tpr, const T *__restrict__ w = nullptr,
+                  int swizzle, int accumulate, int tpr, int long_len, const T *__restrict__ w = nullptr,
                   double *__restrict__ dot_partial = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double dot_slots[DOT ? 1024 / kWave : 1];
+    __shared__ int long_next[LONG ? 1024 / kWave : 1]; // long-row path only: per-wave candidates / partial sums
+    __shared__ T long_part[LONG ? 1024 / kWave : 1];
     constexpr bool NT = (POL & kPolLoadNT) != 0;
     const int block = blockDim.x;
     const int tid = threadIdx.x;
@@ -151,75 +167,153 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
         acc[q] = (accumulate && sub == 0 && r < nr) ? y[r0 + r] : T(0);
     }
 
-    for (int base = VEC ? (nz0 & ~3) : nz0; base < nz1; base += tile_entries) {
-        // ---- phase 1: stream Aj/Ax, gather x, park products in LDS ----
+    // Rows [ra, rb) of the tile = entries [rowptr[ra], rowptr[rb]), streamed through LDS in passes of
+    // tile_entries.  (With VEC the first vector may start up to 3 entries early: those products belong to
+    // rows before ra, are parked and never read.)
+    auto run = [&](int ra, int rb) {
+        const int e_lo = rowptr[ra], e_hi = rowptr[rb];
+        for (int base = VEC ? (e_lo & ~3) : e_lo; base < e_hi; base += tile_entries) {
+            // ---- phase 1: stream Aj/Ax, gather x, park products in LDS ----
 #pragma unroll
-        for (int k = 0; k < IPT; k++) {
-            if constexpr (VEC) {
-                const int slot = (k * block + tid) * 4;
-                const int e = base + slot;
-                if (e < nz1) {
-                    T p0, p1, p2, p3;
-                    if ((int64_t)e + 4 <= num_entries) {
-                        const int4v c = ld<NT>(reinterpret_cast<const int4v *>(Aj + e));
-                        if constexpr (sizeof(T) == 8) {
-                            const double2v v01 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e));
-                            const double2v v23 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e + 2));
-                            p0 = v01.x * x[c.x]; p1 = v01.y * x[c.y];
-                            p2 = v23.x * x[c.z]; p3 = v23.y * x[c.w];
-                        } else {
-                            const float4v v = ld<NT>(reinterpret_cast<const float4v *>(Ax + e));
-                            p0 = v.x * x[c.x]; p1 = v.y * x[c.y];
-                            p2 = v.z * x[c.z]; p3 = v.w * x[c.w];
-                        }
-                    } else { // last (partial) vector of the arrays
-                        p0 = (int64_t)e + 0 < num_entries ? Ax[e + 0] * x[Aj[e + 0]] : T(0);
-                        p1 = (int64_t)e + 1 < num_entries ? Ax[e + 1] * x[Aj[e + 1]] : T(0);
-                        p2 = (int64_t)e + 2 < num_entries ? Ax[e + 2] * x[Aj[e + 2]] : T(0);
-                        p3 = (int64_t)e + 3 < num_entries ? Ax[e + 3] * x[Aj[e + 3]] : T(0);
-                    }
-                    prod[slot + 0] = p0; prod[slot + 1] = p1; prod[slot + 2] = p2; prod[slot + 3] = p3;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int slot = (k * 4 + i) * block + tid;
+            for (int k = 0; k < IPT; k++) {
+                if constexpr (VEC) {
+                    const int slot = (k * block + tid) * 4;
                     const int e = base + slot;
-                    if (e < nz1) prod[slot] = ld<NT>(Ax + e) * x[ld<NT>(Aj + e)];
+                    if (e < e_hi) {
+                        T p0, p1, p2, p3;
+                        if ((int64_t)e + 4 <= num_entries) {
+                            const int4v c = ld<NT>(reinterpret_cast<const int4v *>(Aj + e));
+                            if constexpr (sizeof(T) == 8) {
+                                const double2v v01 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e));
+                                const double2v v23 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e + 2));
+                                p0 = v01.x * x[c.x]; p1 = v01.y * x[c.y];
+                                p2 = v23.x * x[c.z]; p3 = v23.y * x[c.w];
+                            } else {
+                                const float4v v = ld<NT>(reinterpret_cast<const float4v *>(Ax + e));
+                                p0 = v.x * x[c.x]; p1 = v.y * x[c.y];
+                                p2 = v.z * x[c.z]; p3 = v.w * x[c.w];
+                            }
+                        } else { // last (partial) vector of the arrays
+                            p0 = (int64_t)e + 0 < num_entries ? Ax[e + 0] * x[Aj[e + 0]] : T(0);
+                            p1 = (int64_t)e + 1 < num_entries ? Ax[e + 1] * x[Aj[e + 1]] : T(0);
+                            p2 = (int64_t)e + 2 < num_entries ? Ax[e + 2] * x[Aj[e + 2]] : T(0);
+                            p3 = (int64_t)e + 3 < num_entries ? Ax[e + 3] * x[Aj[e + 3]] : T(0);
+                        }
+                        prod[slot + 0] = p0; prod[slot + 1] = p1; prod[slot + 2] = p2; prod[slot + 3] = p3;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int slot = (k * 4 + i) * block + tid;
+                        const int e = base + slot;
+                        if (e < e_hi) prod[slot] = ld<NT>(Ax + e) * x[ld<NT>(Aj + e)];
+                    }
                 }
             }
+            __syncthreads();
+            // ---- phase 2: row sums out of LDS ----
+            if (tpr == 1) { // one lane per row, products added in storage order
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int r = tid + q * block;
+                    if (r >= ra && r < rb) {
+                        int a = rowptr[r], b = rowptr[r + 1];
+                        a = a > base ? a : base;
+                        b = b < base + tile_entries ? b : base + tile_entries;
+                        acc[q] = sum_in_order(acc[q], prod + (a - base), b - a);
+                    }
+                }
+            } else { // tpr lanes per row (wave-uniform branch: tpr is a kernel argument)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int r = grp + q * groups;
+                    if (r >= ra && r < rb) { // the same for every lane of a group
+                        int a = rowptr[r], b = rowptr[r + 1];
+                        a = a > base ? a : base;
+                        b = b < base + tile_entries ? b : base + tile_entries;
+                        T s = T(0);
+                        for (int j = a + sub; j < b; j += tpr) s = s + prod[j - base];
+                        for (int o = tpr >> 1; o > 0; o >>= 1) s = s + __shfl_down(s, o, tpr);
+                        if (sub == 0) acc[q] = acc[q] + s;
+                    }
+                }
+            }
+            if (base + tile_entries < e_hi) __syncthreads(); // another pass reuses prod (uniform condition)
         }
+    };
+
+    // A row of long_len entries or more is not left to one lane (or one lane group): the whole workgroup
+    // streams it straight from the arrays -- 16-byte vectors, partial sums in registers, nothing parked in
+    // LDS -- and folds lanes, then waves, in a fixed order.  Deterministic, but re-associated: such rows are
+    // in the <= 1e-6 class; every shorter row keeps the storage-order sum.  Compiled into the LONG instances
+    // only (the unrolled streaming loop costs ~40 VGPRs, i.e. occupancy, which the ordinary instances keep):
+    // the host launches one when the matrix's row-length profile shows such a row and threads_per_row != 1.
+    auto long_row = [&](int r) {
+        const int a = rowptr[r], b = rowptr[r + 1];
+        T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
+        if constexpr (VEC) {
+            const int a4 = (a + 3) & ~3, b4 = b & ~3; // a4 <= b4: the row has at least 8 entries
+            if (tid < a4 - a) s0 = ld<NT>(Ax + a + tid) * x[ld<NT>(Aj + a + tid)];
+            if (tid < b - b4) s1 = ld<NT>(Ax + b4 + tid) * x[ld<NT>(Aj + b4 + tid)];
+#pragma unroll 4
+            for (int e = a4 + tid * 4; e < b4; e += block * 4) {
+                const int4v c = ld<NT>(reinterpret_cast<const int4v *>(Aj + e));
+                if constexpr (sizeof(T) == 8) {
+                    const double2v v01 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e));
+                    const double2v v23 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e + 2));
+                    s0 = s0 + v01.x * x[c.x]; s1 = s1 + v01.y * x[c.y];
+                    s2 = s2 + v23.x * x[c.z]; s3 = s3 + v23.y * x[c.w];
+                } else {
+                    const float4v v = ld<NT>(reinterpret_cast<const float4v *>(Ax + e));
+                    s0 = s0 + v.x * x[c.x]; s1 = s1 + v.y * x[c.y];
+                    s2 = s2 + v.z * x[c.z]; s3 = s3 + v.w * x[c.w];
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int e = a + tid; e < b; e += block) s0 = s0 + ld<NT>(Ax + e) * x[ld<NT>(Aj + e)];
+        }
+        T s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) s = s + __shfl_down(s, o);
+        if ((tid & (kWave - 1)) == 0) long_part[tid / kWave] = s;
         __syncthreads();
-        // ---- phase 2: row sums out of LDS ----
-        if (tpr == 1) { // one lane per row, products added in storage order
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int r = tid + q * block;
-                if (r < nr) {
-                    int a = rowptr[r], b = rowptr[r + 1];
-                    a = a > base ? a : base;
-                    b = b < base + tile_entries ? b : base + tile_entries;
-                    T s = acc[q];
-                    for (int j = a; j < b; j++) s = s + prod[j - base];
-                    acc[q] = s;
-                }
-            }
-        } else { // tpr lanes per row (wave-uniform branch: tpr is a kernel argument)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int r = grp + q * groups;
-                if (r < nr) { // the same for every lane of a group
-                    int a = rowptr[r], b = rowptr[r + 1];
-                    a = a > base ? a : base;
-                    b = b < base + tile_entries ? b : base + tile_entries;
-                    T s = T(0);
-                    for (int j = a + sub; j < b; j += tpr) s = s + prod[j - base];
-                    for (int o = tpr >> 1; o > 0; o >>= 1) s = s + __shfl_down(s, o, tpr);
-                    if (sub == 0) acc[q] = acc[q] + s;
-                }
+        for (int q = 0; q < 4; q++) {
+            if (sub == 0 && grp + q * groups == r) { // the lane that stores this row
+                T t = T(0);
+                for (int wv = 0; wv < block / kWave; wv++) t = t + long_part[wv];
+                acc[q] = acc[q] + t;
             }
         }
-        if (base + tile_entries < nz1) __syncthreads(); // another pass reuses prod (uniform condition)
+        __syncthreads(); // long_part is free again
+    };
+
+    bool mine = false;
+    if constexpr (LONG)
+        for (int r = tid; r < nr; r += block) mine |= (rowptr[r + 1] - rowptr[r] >= long_len);
+    if (!LONG || !__syncthreads_or(mine)) {
+        run(0, nr);
+    } else { // runs of ordinary rows between the long ones (every branch below is workgroup-uniform)
+        int cur = 0;
+        while (cur < nr) {
+            int cand = nr;
+            for (int r = cur + tid; r < nr; r += block)
+                if (rowptr[r + 1] - rowptr[r] >= long_len) { cand = r; break; }
+#pragma unroll
+            for (int o = kWave / 2; o > 0; o >>= 1) { const int v = __shfl_down(cand, o); cand = v < cand ? v : cand; }
+            if ((tid & (kWave - 1)) == 0) long_next[tid / kWave] = cand;
+            __syncthreads();
+            int nxt = nr;
+            for (int wv = 0; wv < block / kWave; wv++) nxt = long_next[wv] < nxt ? long_next[wv] : nxt;
+            __syncthreads(); // long_next may be rewritten
+            if (nxt > cur) {
+                run(cur, nxt);
+                __syncthreads(); // the next run's first pass reuses prod
+            }
+            if (nxt < nr) long_row(nxt);
+            cur = nxt + 1;
+        }
     }
 
     double d = 0.0;
@@ -553,52 +647,70 @@ __global__ void __launch_bounds__(256) zero_fill_kernel(int64_t n, T *__restrict
 // row-length profile: which matrices get csr_balanced when the caller leaves the kernel choice open
 // ---------------------------------------------------------------------------------------------
 // The tuning table is keyed by the MEAN row length; skew is invisible to it, and skew is what breaks the
-// row-tile kernels: csr_stream's one-lane-per-row sum (the bit-exact order) spends ~40 ns per entry of a
-// long row, serially (tools/irregular_probe.py --sweep: 64 rows of 65536 entries turn 56 us into 2.6 ms).
-// So the first table-selected multiply of a matrix measures its longest row (one pass over the row
-// offsets + a 4-byte read-back, ~20 us) and the result is remembered, keyed by (row-offset pointer, rows,
-// entries, device).  A stale entry -- offsets edited in place, or the address reused -- can only cost
-// speed: every kernel is correct for every matrix.  CMI_CSR_PROFILE=0 turns the whole thing off.
-__global__ void __launch_bounds__(256) max_row_length_kernel(int64_t num_rows, const int *__restrict__ Ap, int *__restrict__ out)
+// row-tile kernels: csr_stream's one-lane-per-row sum (the bit-exact order) spends ~12 ns per entry of a
+// long row, serially (tools/irregular_probe.py --sweep: 64 rows of 65536 entries turn 55 us into 0.8 ms).
+// So the first multiply of a matrix measures its row lengths (one pass over the row offsets + a 16-byte
+// read-back, ~20 us: the longest row, and how many entries sit in rows of kLongRowMin or more) and the
+// result is remembered, keyed by (row-offset pointer, rows, entries, device).  It decides two things:
+//   * csr_stream launches its LONG instance (long rows streamed by their whole workgroup) when there is
+//     such a row and the caller did not ask for storage order everywhere (threads_per_row == 1);
+//   * with the kernel choice left open, csr_balanced replaces the row-tile kernel when the longest row
+//     alone would cost more than the whole multiply, or a quarter of the entries sit in long rows.
+// A stale entry -- offsets edited in place, or the address reused -- can only cost speed: every kernel
+// is correct for every matrix.  CMI_CSR_PROFILE=0 turns the whole thing off.
+constexpr int kLongRowMin = 512, kLongRowPerLane = 128; // csr_stream's cooperative long-row path (see the kernel)
+
+// out[0] = longest row, out[1] = entries that sit in rows of kLongRowMin entries or more (two 64-bit words)
+__global__ void __launch_bounds__(256) max_row_length_kernel(int64_t num_rows, const int *__restrict__ Ap, unsigned long long *__restrict__ out)
 {
     __shared__ int slots[256 / kWave];
+    __shared__ unsigned long long lslots[256 / kWave];
     int m = 0;
+    unsigned long long in_long = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows; i += stride) {
         const int len = Ap[i + 1] - Ap[i];
         m = len > m ? len : m;
+        if (len >= kLongRowMin) in_long += (unsigned long long)len;
     }
 #pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) { const int v = __shfl_down(m, o); m = v > m ? v : m; }
-    if ((threadIdx.x & (kWave - 1)) == 0) slots[threadIdx.x / kWave] = m;
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        const int v = __shfl_down(m, o);
+        m = v > m ? v : m;
+        in_long += __shfl_down(in_long, o);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) { slots[threadIdx.x / kWave] = m; lslots[threadIdx.x / kWave] = in_long; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 256 / kWave; w++) m = slots[w] > m ? slots[w] : m;
-        atomicMax(out, m);
+        for (int w = 1; w < 256 / kWave; w++) { m = slots[w] > m ? slots[w] : m; in_long += lslots[w]; }
+        atomicMax(out, (unsigned long long)(m > 0 ? m : 0));
+        if (in_long) atomicAdd(out + 1, in_long);
     }
 }
 
-static int measure_max_row_length(int64_t rows, const int *Ap, hipStream_t s, int64_t *out)
+static int measure_row_lengths(int64_t rows, const int *Ap, hipStream_t s, int64_t *max_len, int64_t *entries_in_long_rows)
 {
-    int *dev = nullptr;
-    CMI_HIP(hipMalloc((void **)&dev, sizeof(int)));
-    int host = 0;
-    hipError_t e = hipMemsetAsync(dev, 0, sizeof(int), s);
+    unsigned long long *dev = nullptr;
+    CMI_HIP(hipMalloc((void **)&dev, 2 * sizeof(unsigned long long)));
+    unsigned long long host[2] = {0, 0};
+    hipError_t e = hipMemsetAsync(dev, 0, sizeof(host), s);
     if (e == hipSuccess) {
         int64_t blocks = ceil_div(rows, 256 * 4);
         if (blocks > kCus * 8) blocks = kCus * 8;
         hipLaunchKernelGGL(max_row_length_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, rows, Ap, dev);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&host, dev, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(dev);
     if (e != hipSuccess) return hip_fail(e, "row-length profile");
-    *out = host;
+    *max_len = (int64_t)host[0];
+    if (entries_in_long_rows) *entries_in_long_rows = (int64_t)host[1];
     return CMI_SUCCESS;
 }
 
-struct profile_entry { const void *ap; int64_t rows, nnz; int device; int64_t max_len; uint64_t stamp; };
+struct row_profile { int64_t max_len = -1, in_long = 0; }; // max_len < 0: not available
+struct profile_entry { const void *ap; int64_t rows, nnz; int device; row_profile prof; uint64_t stamp; };
 static std::mutex g_profile_mu;
 static profile_entry g_profiles[64];
 static uint64_t g_profile_clock = 0;
@@ -609,34 +721,41 @@ static bool profile_enabled()
     return on;
 }
 
-// longest row of the matrix, from the cache or measured now; < 0 if it cannot be had (stream is capturing)
-static int64_t cached_max_row_length(int64_t rows, int64_t nnz, const int *Ap, hipStream_t s)
+// row-length profile of the matrix, from the cache or measured now; max_len < 0 if it cannot be had (stream is capturing)
+static row_profile cached_row_profile(int64_t rows, int64_t nnz, const int *Ap, hipStream_t s)
 {
     int device = 0;
-    if (hipGetDevice(&device) != hipSuccess) return -1;
+    if (hipGetDevice(&device) != hipSuccess) return {};
     {
         std::lock_guard<std::mutex> lk(g_profile_mu);
         for (auto &p : g_profiles)
-            if (p.ap == Ap && p.rows == rows && p.nnz == nnz && p.device == device && p.stamp) { p.stamp = ++g_profile_clock; return p.max_len; }
+            if (p.ap == Ap && p.rows == rows && p.nnz == nnz && p.device == device && p.stamp) { p.stamp = ++g_profile_clock; return p.prof; }
     }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return -1;
-    int64_t max_len = 0;
-    if (measure_max_row_length(rows, Ap, s, &max_len) != CMI_SUCCESS) return -1;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return {};
+    row_profile pr;
+    if (measure_row_lengths(rows, Ap, s, &pr.max_len, &pr.in_long) != CMI_SUCCESS) return {};
     std::lock_guard<std::mutex> lk(g_profile_mu);
     profile_entry *victim = &g_profiles[0];
     for (auto &p : g_profiles)
         if (p.stamp < victim->stamp) victim = &p;
-    *victim = profile_entry{Ap, rows, nnz, device, max_len, ++g_profile_clock};
-    return max_len;
+    *victim = profile_entry{Ap, rows, nnz, device, pr, ++g_profile_clock};
+    return pr;
 }
 
-// serial cost of the longest row under the one-lane-per-row sum vs the whole multiply at streaming speed
-static bool prefers_balanced(int64_t rows, int64_t nnz, int64_t max_len, size_t value_bytes)
+// cost of the longest row inside the row-tile kernel vs the whole multiply at streaming speed.  The row's
+// workgroup streams it cooperatively (kLongRowUs per entry: 1.2-2.4 ns measured, one workgroup is latency-bound at
+// ~10 GB/s; tools/irregular_probe.py --sweep, profiles/r01_irregular_rows.txt); with
+// threads_per_row == 1 asked for, one lane adds it in storage order (kSerialRowUs per entry).
+constexpr double kLongRowUs = 0.002, kSerialRowUs = 0.012;
+static bool prefers_balanced(int64_t rows, int64_t nnz, const row_profile &pr, size_t value_bytes, bool strict_order)
 {
     const double stream_us = ((double)nnz * (4 + value_bytes) + (double)rows * (4 + 2 * value_bytes)) / 5.0e6; // 5 TB/s
     const double floor_us = 20.0; // launch + latency floor of any multiply
-    return (double)max_len * 0.04 > (stream_us > floor_us ? stream_us : floor_us);
+    if ((double)pr.max_len * (strict_order ? kSerialRowUs : kLongRowUs) > (stream_us > floor_us ? stream_us : floor_us)) return true;
+    // a heavy tail: when a quarter of the entries sit in long rows, one workgroup per long row is the slower split
+    // (measured: 2000 rows of 2e4 among 2M short ones, power-law lengths; tools/irregular_probe.py)
+    return pr.in_long * 4 > nnz && stream_us > floor_us;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -672,14 +791,14 @@ static int launch_vector(int tpr, int grid, int block, hipStream_t s, int64_t ro
     return CMI_SUCCESS;
 }
 
-template <typename T, bool VEC, int POL, bool DOT = false>
+template <typename T, bool VEC, int POL, bool DOT = false, bool LONG = false>
 static int launch_stream_ipt(int ipt, int grid, int block, size_t lds, hipStream_t s, int64_t rows, int64_t nnz,
                              const int *Ap, const int *Aj, const T *Ax, const T *x, T *y, int rpb, int64_t tiles,
-                             int64_t tpx, int swz, int acc, int tpr, const T *w = nullptr, double *dot_partial = nullptr)
+                             int64_t tpx, int swz, int acc, int tpr, int long_len, const T *w = nullptr, double *dot_partial = nullptr)
 {
-#define CMI_STREAM_LAUNCH(IPT)                                                                                        \
-    hipLaunchKernelGGL((csr_stream_kernel<T, IPT, VEC, POL, DOT>), dim3(grid), dim3(block), lds, s, rows, nnz, Ap, Aj, \
-                       Ax, x, y, rpb, tiles, tpx, swz, acc, tpr, w, dot_partial)
+#define CMI_STREAM_LAUNCH(IPT)                                                                                              \
+    hipLaunchKernelGGL((csr_stream_kernel<T, IPT, VEC, POL, DOT, LONG>), dim3(grid), dim3(block), lds, s, rows, nnz, Ap, Aj, \
+                       Ax, x, y, rpb, tiles, tpx, swz, acc, tpr, long_len, w, dot_partial)
     switch (ipt) {
     case 1: CMI_STREAM_LAUNCH(1); break;
     case 2: CMI_STREAM_LAUNCH(2); break;
@@ -707,9 +826,11 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     cmi_config c;
     select_config(CMI_FORMAT_CSR, dtype, rows, cols, nnz, user, &c);
     hipStream_t s = as_stream(stream);
+    int64_t known_max_len = -1; // the matrix's longest row once the profile has been consulted
     if ((!user || user->kernel == CMI_KERNEL_AUTO) && nnz > 0 && profile_enabled()) {
-        const int64_t max_len = cached_max_row_length(rows, nnz, Ap, s);
-        if (max_len >= 0 && prefers_balanced(rows, nnz, max_len, sizeof(T))) {
+        const row_profile pr = cached_row_profile(rows, nnz, Ap, s);
+        known_max_len = pr.max_len;
+        if (pr.max_len >= 0 && prefers_balanced(rows, nnz, pr, sizeof(T), c.threads_per_row == 1)) {
             c.kernel = CMI_CSR_BALANCED;
             c.items_per_thread = 0; // the table's row-tile launch shape does not apply: balanced defaults
             c.blocks_per_cu = 0;
@@ -740,6 +861,9 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         const int ipt = c.items_per_thread;
         int tpr = c.threads_per_row <= 1 ? 1 : c.threads_per_row;
         if (tpr > 64 || (tpr & (tpr - 1)) != 0) return fail(CMI_ERROR_NOT_SUPPORTED, "csr_stream: threads_per_row must be 0/1 or a power of two <= 64");
+        // threads_per_row == 0: rows of kLongRowPerLane entries per lane of a group (at least kLongRowMin) or more
+        // are streamed by the whole workgroup (re-associated); == 1: storage order for every row, whatever its length
+        const int long_len = c.threads_per_row == 1 ? 0 : (tpr * kLongRowPerLane > kLongRowMin ? tpr * kLongRowPerLane : kLongRowMin);
         if (rpb < 1 || rpb > 4 * (block / tpr)) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream: rows_per_block must be in [1, 4*block_size/threads_per_row]");
         const int64_t tiles = ceil_div(rows, rpb);
         const int64_t tpx = ceil_div(tiles, kXcds);
@@ -750,17 +874,27 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         if (lds > 160 * 1024) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream: tile does not fit 160 KiB of LDS");
         const bool vec = (reinterpret_cast<uintptr_t>(Aj) % 16 == 0) && (reinterpret_cast<uintptr_t>(Ax) % 16 == 0);
         const bool dot = w && dot_partial && vec && tiles <= kPartialCapacity && std::is_same<T, double>::value;
+        // the LONG instance only for a matrix whose profile (cached per matrix; a stale or missing one costs speed,
+        // never correctness: the ordinary instance sums any row, one lane or lane group at a time) shows such a row
+        bool lng = false;
+        if (long_len > 0 && nnz >= long_len && profile_enabled()) {
+            if (known_max_len < 0) known_max_len = cached_row_profile(rows, nnz, Ap, s).max_len;
+            lng = known_max_len >= long_len;
+        }
+#define CMI_STREAM_GO(VEC_, DOT_, LONG_, ...) \
+    launch_stream_ipt<T, VEC_, POL, DOT_, LONG_>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate, tpr, long_len, ##__VA_ARGS__)
         with_policy(pol, [&](auto P) {
             constexpr int POL = decltype(P)::value;
             if constexpr (std::is_same<T, double>::value) {
                 if (dot) {
-                    st = launch_stream_ipt<T, true, POL, true>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate, tpr, w, dot_partial);
+                    st = lng ? CMI_STREAM_GO(true, true, true, w, dot_partial) : CMI_STREAM_GO(true, true, false, w, dot_partial);
                     return;
                 }
             }
-            st = vec ? launch_stream_ipt<T, true, POL>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate, tpr)
-                     : launch_stream_ipt<T, false, POL>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate, tpr);
+            if (vec) st = lng ? CMI_STREAM_GO(true, false, true) : CMI_STREAM_GO(true, false, false);
+            else     st = lng ? CMI_STREAM_GO(false, false, true) : CMI_STREAM_GO(false, false, false);
         });
+#undef CMI_STREAM_GO
         if (st) return st;
         if (dot && dot_partials) *dot_partials = (int)tiles;
         break;
@@ -848,7 +982,7 @@ CMI_API int cmi_csr_max_row_length(int64_t num_rows, const int32_t *Ap, int64_t 
     *max_length_host = 0;
     if (num_rows == 0) return CMI_SUCCESS;
     if (!Ap) return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_max_row_length: null row offsets");
-    return cmi::measure_max_row_length(num_rows, Ap, cmi::as_stream(stream), max_length_host);
+    return cmi::measure_row_lengths(num_rows, Ap, cmi::as_stream(stream), max_length_host, nullptr);
 }
 
 CMI_API int cmi_spmv_csr_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ap,

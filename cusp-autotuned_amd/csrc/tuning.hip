@@ -117,7 +117,7 @@ static void complete(int format, int dtype, int64_t rows, int64_t nnz, cmi_confi
             int tpr = c->threads_per_row <= 1 ? 1 : c->threads_per_row; // lanes per row in the LDS row-sum phase
             int p2 = 1;
             while (p2 < tpr && p2 < 64) p2 <<= 1;
-            c->threads_per_row = p2 == 1 ? 0 : p2;
+            c->threads_per_row = p2 == 1 ? (c->threads_per_row == 1 ? 1 : 0) : p2; // 1 = storage order for EVERY row (asked for); 0 = long rows cooperative
             const int64_t tile = (int64_t)c->block_size * c->items_per_thread * 4;
             if (c->rows_per_block <= 0) {
                 // largest row count whose entries fit one LDS pass (3 slots of alignment slack);

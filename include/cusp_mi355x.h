@@ -120,7 +120,10 @@ typedef enum cmi_kernel {
     /* CSR */
     CMI_CSR_SCALAR = 1, /* one lane per row          (ref: csr_scalar.h:51-73)                   */
     CMI_CSR_VECTOR = 2, /* threads_per_row lanes/row (ref: csr_vector_spmv.h:71-161, THREADS_PER_ROW) */
-    CMI_CSR_STREAM = 3, /* LDS-staged nnz tile, sequential per-row sum (bit-exact vs host order) */
+    CMI_CSR_STREAM = 3, /* LDS-staged nnz tile, sequential per-row sum (bit-exact vs host order); threads_per_row
+                           0: rows of 512+ entries are streamed by their whole workgroup instead (re-associated,
+                           <= 1e-6; ~1-2 ns instead of ~12 ns per entry), 1: storage order for every row,
+                           2..64: that many lanes per row (lane-strided partial sums)                    */
     CMI_CSR_STREAM_PIPE = 4, /* persistent, software-pipelined csr_stream (next tile's streams in flight) */
     CMI_CSR_BALANCED = 5,   /* merge-path split of row ends + entries: equal work per tile whatever the row
                                lengths (a few huge rows, power-law tails, runs of empty rows); replaces KTT's
@@ -142,7 +145,8 @@ typedef enum cmi_kernel {
 typedef struct cmi_config {
     int32_t kernel;           /* cmi_kernel; CMI_KERNEL_AUTO = pick by heuristics                  */
     int32_t block_size;       /* threads per workgroup: 64..1024, multiple of 64; 0 = default      */
-    int32_t threads_per_row;  /* CSR vector: 2,4,8,16,32,64; 0 = from mean row length              */
+    int32_t threads_per_row;  /* CSR vector: 2,4,8,16,32,64; 0 = from mean row length.  CSR stream: lanes per
+                                 row in the row-sum phase (0, 1, 2..64: see CMI_CSR_STREAM)                */
     int32_t rows_per_block;   /* CSR stream: rows per workgroup tile; 0 = from mean row length     */
     int32_t items_per_thread; /* CSR stream: 16-byte index vectors per lane per pass (1,2,4);
                                  ELL/DIA: rows per lane (1,2); COO: entries per lane; 0 = default   */

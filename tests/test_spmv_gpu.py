@@ -48,6 +48,20 @@ def assert_close(y, want, bound, dtype, what=""):
     assert bad.size == 0, f"{what}: {bad.size} rows out of tolerance, first {bad[:5]}, err {err[bad[:5]]}"
 
 
+LONG_ROW = 512  # csr_stream, threads_per_row = 0: shorter rows are summed in storage order (kLongRowMin, spmv_csr.hip)
+
+
+def assert_variant(got, want, bound, dtype, exact, Ap, what):
+    """exact True: bit-equal; "short": bit-equal on rows shorter than LONG_ROW, tolerance on the others; False: tolerance."""
+    if exact is True:
+        assert np.array_equal(got, want), f"{what}: not bit-exact"
+        return
+    assert_close(got, want, bound, dtype, what)
+    if exact == "short":
+        short = np.diff(Ap) < LONG_ROW
+        assert np.array_equal(got[short], want[short]), f"{what}: a row shorter than {LONG_ROW} entries is not bit-exact"
+
+
 def csr_variants(cmi, small=False):
     """Every CSR kernel variant worth distinguishing (launch shape x load policy)."""
     out = []
@@ -61,7 +75,12 @@ def csr_variants(cmi, small=False):
                                    (128, 1, 0, 0, 1), (512, 1, 0, 0, 1), (64, 1, 7, 2, 1), (256, 1, 1, 0, 0),
                                    (256, 1, 1024, 3, 1), (128, 2, 512, 1, 1), (1024, 1, 300, 0, 1), (256, 1, 192, 2, 0),
                                    (256, 1, 192, 2, 16), (128, 1, 5, 0, 3), (256, 2, 0, 2, 64)):
-        out.append((f"stream b{blk} i{ipt} r{rpb} nt{nt} x{swz}", True,
+        # threads_per_row = 1: storage order for every row; 0 (the table's value): rows of LONG_ROW entries or more
+        # are streamed by the whole workgroup (re-associated), every shorter row stays bit-exact
+        out.append((f"stream b{blk} i{ipt} r{rpb} nt{nt} x{swz} strict", True,
+                    cmi.Config(kernel=cmi.CSR_STREAM, block_size=blk, items_per_thread=ipt, rows_per_block=rpb,
+                               nontemporal=nt, xcd_swizzle=swz, threads_per_row=1)))
+        out.append((f"stream b{blk} i{ipt} r{rpb} nt{nt} x{swz}", "short",
                     cmi.Config(kernel=cmi.CSR_STREAM, block_size=blk, items_per_thread=ipt, rows_per_block=rpb,
                                nontemporal=nt, xcd_swizzle=swz)))
     for blk, ipt, rpb, tpr in ((256, 1, 0, 2), (256, 2, 0, 4), (256, 4, 64, 16), (128, 1, 8, 64), (512, 4, 0, 32), (64, 1, 3, 8)):
@@ -91,11 +110,7 @@ def run_all_formats(cmi, torch, orc, rows, cols, Ap, Aj, Ax, x, want, want_acc, 
         for name, exact, cfg in csr_variants(cmi, small=True):
             y = fresh(acc)
             cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, accumulate=acc, cfg=cfg)
-            got = host(y)
-            if exact:
-                assert np.array_equal(got, w), f"{label} csr {name} acc={acc}: not bit-exact"
-            else:
-                assert_close(got, w, bound, dtype, f"{label} csr {name} acc={acc}")
+            assert_variant(host(y), w, bound, dtype, exact, Ap, f"{label} csr {name} acc={acc}")
         y = fresh(acc)  # NULL config: tuning table / heuristics
         cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, accumulate=acc)
         assert_close(host(y), w, bound, dtype, f"{label} csr auto acc={acc}")
@@ -462,10 +477,7 @@ def test_pathological_row_length_distributions(cmi, torch_cuda, orc, shape):
     for name, exact, cfg in csr_variants(cmi, small=True) + [("auto", False, None)]:
         y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
         cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, cfg=cfg)
-        if exact:
-            assert np.array_equal(host(y), want), f"{shape} {name}"
-        else:
-            assert_close(host(y), want, bound, np.float64, f"{shape} {name}")
+        assert_variant(host(y), want, bound, np.float64, exact, Ap, f"{shape} {name}")
     Ai = orc.csr_row_indices(Ap)
     for kern in (cmi.COO_SEGMENTED, cmi.COO_LANE4):
         y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
@@ -509,9 +521,16 @@ def test_row_length_profile_selects_the_balanced_kernel(cmi, torch_cuda, orc):
     t_auto = timed(None)
     assert_close(host(y), want, bound, np.float64, "auto (profile)")
     table = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, rows, cols, nnz)   # what the mean row length alone selects
+    assert table.kernel == cmi.CSR_STREAM and table.threads_per_row == 0
+    # the row-tile kernel as the table shapes it: the three long rows are streamed by their whole workgroup
+    # (re-associated), every other row is bit-exact
     t_table = timed(table)
-    assert np.array_equal(host(y), want)                                  # ... bit-exact, but one lane sums each long row
-    assert t_auto * 5 < t_table, (t_auto, t_table)
+    assert_variant(host(y), want, bound, np.float64, "short", Ap, "table config")
+    # threads_per_row = 1: storage order for EVERY row -- bit-exact, but one lane sums each long row
+    table.threads_per_row = 1
+    t_strict = timed(table)
+    assert np.array_equal(host(y), want)
+    assert t_auto * 5 < t_strict and t_table * 3 < t_strict, (t_auto, t_table, t_strict)
     # accumulate mode through the balanced kernel: no zero fill, y += A x
     y0 = rng.standard_normal(rows)
     dy = dev(y0, torch)
@@ -581,11 +600,12 @@ def test_unaligned_views_take_the_scalar_load_paths(cmi, torch_cuda, orc, golden
         dAx = bufv[shift_v:shift_v + len(Ax)]
         dAj.copy_(dev(Aj, torch))
         dAx.copy_(dev(Ax, torch))
-        for ipt in (1, 2, 4):
+        bound = row_abs(orc, Ap, Aj, Ax, x)
+        for ipt, tpr in itertools.product((1, 2, 4), (1, 0)):  # 1: storage order everywhere; 0: the 5000-entry row is streamed
             y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
             cmi.spmv_csr(rows, cols, dev(Ap, torch), dAj, dAx, dev(x, torch), y,
-                         cfg=cmi.Config(kernel=cmi.CSR_STREAM, items_per_thread=ipt))
-            assert np.array_equal(host(y), want), (shift_i, shift_v, ipt)
+                         cfg=cmi.Config(kernel=cmi.CSR_STREAM, items_per_thread=ipt, threads_per_row=tpr))
+            assert_variant(host(y), want, bound, np.float64, True if tpr == 1 else "short", Ap, f"{shift_i} {shift_v} {ipt} {tpr}")
     # ELL with an odd pitch: the two-rows-per-lane request silently uses one row per lane (same result)
     width = int(np.diff(Ap).max())
     pitch, eAj, eAx = orc.csr_to_ell(Ap, Aj, Ax, width, alignment=1)

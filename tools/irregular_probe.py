@@ -24,7 +24,7 @@ def sweep():
     import cusp_autotuned_amd as cmi
     n = 2_000_000
     g = torch.Generator(device="cuda").manual_seed(3)
-    for L in (0, 256, 1024, 4096, 16384, 65536, 262144):
+    for L in (0, 256, 1024, 4096, 16384, 65536, 262144, 1048576):
         lens = torch.randint(3, 12, (n,), generator=g, device="cuda")
         if L:
             lens[torch.randint(0, n, (64,), generator=g, device="cuda")] = L
@@ -39,21 +39,29 @@ def sweep():
         x = torch.rand(n, device="cuda", dtype=torch.float64)
         y = torch.empty(n, device="cuda", dtype=torch.float64)
         out = []
-        variants = [("table", None)] + [(f"bal/{per}", cmi.Config(kernel=cmi.CSR_BALANCED, items_per_thread=per)) for per in (1, 2, 4, 8, 16)] + \
+        # 'table' = cfg NULL (table + row-length profile); 'stream' = the table's row-tile config forced (long rows
+        # streamed by their whole workgroup); 'strict' = the same with threads_per_row = 1 (storage order for every row)
+        tcfg = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, n, n, nnz)
+        strict = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, n, n, nnz)
+        strict.threads_per_row = 1
+        variants = [("table", None), ("stream", tcfg), ("strict", strict)] + \
+            [(f"bal/{per}", cmi.Config(kernel=cmi.CSR_BALANCED, items_per_thread=per)) for per in (4, 8)] + \
             [("bal/persistent8", cmi.Config(kernel=cmi.CSR_BALANCED, blocks_per_cu=8))]
         for vn, cfg in variants:
-            for _ in range(3):
+            reps = 3 if (vn == "strict" and L > 65536) else 10
+            for _ in range(2):
                 cmi.spmv_csr(n, n, Ap, Aj, Ax, x, y, cfg=cfg)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(10):
+            for _ in range(reps):
                 cmi.spmv_csr(n, n, Ap, Aj, Ax, x, y, cfg=cfg)
             torch.cuda.synchronize()
-            out.append((time.perf_counter() - t0) / 10 * 1e6)
+            out.append((time.perf_counter() - t0) / reps * 1e6)
         print(f"64 rows of {L:7d}: nnz {nnz:9d}  " + "  ".join(f"{v[0]} {o:7.1f}" for v, o in zip(variants, out)), flush=True)
     A = cmi.poisson5pt(3162, 3162, "csr")
     x = cmi.fill_x(A.num_rows).cuda()
     y = torch.empty(A.num_rows, dtype=torch.float64, device="cuda")
+    variants = [v for v in variants if v[0] not in ("stream", "strict")]  # those configs were shaped for the last matrix
     for vn, cfg in variants:
         for _ in range(3):
             cmi.multiply(A, x, y, cfg=cfg)
