@@ -625,11 +625,23 @@ def test_coo_unsorted_entries(cmi, torch_cuda, orc, golden_irregular):
     Ai = orc.csr_row_indices(Ap)
     perm = np.random.default_rng(5).permutation(len(Ax))
     bound = row_abs(orc, Ap, Aj, Ax, x)
-    for kern, ipt in ((cmi.COO_SEGMENTED, 1), (cmi.COO_SEGMENTED, 4), (cmi.COO_LANE4, 1), (cmi.COO_LANE4, 3)):
+    for kern, ipt in ((cmi.COO_SEGMENTED, 1), (cmi.COO_SEGMENTED, 4), (cmi.COO_LANE4, 1), (cmi.COO_LANE4, 3), (None, 0)):
         y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
         cmi.spmv_coo(rows, cols, dev(Ai[perm], torch), dev(Aj[perm], torch), dev(Ax[perm], torch), dev(x, torch), y,
-                     cfg=cmi.Config(kernel=kern, items_per_thread=ipt))
-        assert_close(host(y), g["f64_y_coo"], bound, np.float64, "coo unsorted")
+                     cfg=cmi.Config(kernel=kern, items_per_thread=ipt) if kern is not None else None)
+        assert_close(host(y), g["f64_y_coo"], bound, np.float64, f"coo unsorted k{kern} ipt{ipt}")
+    # a single swapped pair at an interval boundary, at a lane boundary and inside a lane
+    for pos in (255, 256, 3, 5, 1023, len(Ai) - 2):
+        I2, J2, V2 = Ai.copy(), Aj.copy(), Ax.copy()
+        q = pos + 1
+        while q < len(Ai) - 1 and I2[q] == I2[pos]:
+            q += 1
+        for arr in (I2, J2, V2):
+            arr[[pos, q]] = arr[[q, pos]]
+        y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
+        cmi.spmv_coo(rows, cols, dev(I2, torch), dev(J2, torch), dev(V2, torch), dev(x, torch), y,
+                     cfg=cmi.Config(kernel=cmi.COO_LANE4, items_per_thread=1, block_size=64))
+        assert_close(host(y), g["f64_y_coo"], bound, np.float64, f"coo one swap at {pos}")
     # unaligned index / value arrays: the lane4 request runs the segmented kernel
     buf_i = torch.zeros(len(Ai) + 4, dtype=torch.int32, device="cuda")
     buf_i[1:1 + len(Ai)].copy_(dev(Ai, torch))
@@ -637,6 +649,70 @@ def test_coo_unsorted_entries(cmi, torch_cuda, orc, golden_irregular):
     cmi.spmv_coo(rows, cols, buf_i[1:1 + len(Ai)], dev(Aj, torch), dev(Ax, torch), dev(x, torch), y,
                  cfg=cmi.Config(kernel=cmi.COO_LANE4))
     assert_close(host(y), g["f64_y_coo"], bound, np.float64, "coo lane4 unaligned")
+
+
+@pytest.mark.parametrize("shape", ["gaps", "one_row", "long_rows", "all_rows_shared", "tiny", "dense_rows_and_deserts"])
+def test_coo_row_sorted_shapes(cmi, torch_cuda, orc, shape):
+    """Row-sorted COO (the reference's contract, cusp/coo_matrix.h:72) in the shapes that stress run handling: rows
+    without entries (singles, runs, deserts of 10^5 rows, both ends of the matrix), one row holding everything, rows
+    of several wave intervals, every row straddling an interval boundary -- y starts poisoned, so a row nobody
+    wrote shows, and rows without entries must come out as +0 exactly."""
+    torch = torch_cuda
+    rng = np.random.default_rng(41)
+    if shape == "gaps":           # empty rows everywhere: singles, runs of 2..8, runs of hundreds, both ends
+        rows, cols = 60000, 700
+        lens = rng.integers(0, 7, size=rows)
+        lens[rng.random(rows) < 0.3] = 0
+        lens[:37] = 0
+        lens[-1500:] = 0
+        lens[20000:20900] = 0
+        lens[40000:40009] = 0
+    elif shape == "one_row":      # one row holds everything: every interval shares it with its neighbours
+        rows, cols = 9, 5000
+        lens = np.zeros(rows, np.int64)
+        lens[4] = 30001
+    elif shape == "long_rows":    # rows of several intervals between short ones
+        rows, cols = 3000, 4000
+        lens = rng.integers(1, 6, size=rows)
+        lens[[0, 17, 1500, 2999]] = [777, 2600, 257, 1025]
+    elif shape == "all_rows_shared":  # 256-entry rows shifted by one entry: every row straddles a boundary
+        rows, cols = 400, 300
+        lens = np.full(rows, 256, np.int64)
+        lens[0] = 1
+    elif shape == "tiny":
+        rows, cols = 5, 5
+        lens = np.array([0, 2, 0, 1, 0])
+    else:                         # dense rows separated by deserts of 10^5 empty rows
+        rows, cols = 400000, 1000
+        lens = np.zeros(rows, np.int64)
+        lens[[5, 100000, 100001, 250000, 399990]] = [900, 3, 1, 4000, 2]
+    Ap = np.r_[0, np.cumsum(lens)].astype(np.int32)
+    nnz = int(Ap[-1])
+    Ai = orc.csr_row_indices(Ap)
+    Aj = rng.integers(0, cols, size=nnz).astype(np.int32)   # unsorted columns, duplicates: allowed
+    Ax = rng.standard_normal(nnz)
+    x = rng.standard_normal(cols)
+    want = orc.spmv_csr(Ap, Aj, Ax, x)
+    bound = row_abs(orc, Ap, Aj, Ax, x)
+    dAi, dAj, dAx, dx = dev(Ai, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+    for kern, blk, ipt in itertools.product((cmi.COO_LANE4, cmi.COO_SEGMENTED), (64, 256, 512), (1, 2, 3, 8)):
+        y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
+        cmi.spmv_coo(rows, cols, dAi, dAj, dAx, dx, y, cfg=cmi.Config(kernel=kern, block_size=blk, items_per_thread=ipt))
+        got = host(y)
+        assert_close(got, want, bound, np.float64, f"coo {shape} k{kern} b{blk} i{ipt}")
+        assert np.array_equal(got[lens == 0], np.zeros(int((lens == 0).sum()))), f"{shape}: an empty row is not +0"
+    # the same through the table (NULL config), on another stream, and accumulating (order-agnostic kernel)
+    y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        cmi.spmv_coo(rows, cols, dAi, dAj, dAx, dx, y)
+    s.synchronize()
+    assert_close(host(y), want, bound, np.float64, f"coo {shape} table")
+    y0 = rng.standard_normal(rows)
+    y = dev(y0, torch)
+    cmi.spmv_coo(rows, cols, dAi, dAj, dAx, dx, y, accumulate=True)
+    assert_close(host(y), orc.spmv_csr(Ap, Aj, Ax, x, y0), bound + np.abs(y0), np.float64, f"coo {shape} accumulate")
 
 
 def test_non_default_stream(cmi, torch_cuda, golden_poisson, orc):
