@@ -59,12 +59,10 @@ static void heuristic(int format, int dtype, double mean, cmi_config *c)
         // power-of-two group of lanes (lane-strided partial sums + butterfly)
         c->kernel = CMI_CSR_STREAM;
         c->nontemporal = kPolStoreNT; // measured: nt y stores, plain loads, no XCD swizzle
-        // measured on FEM-like stencil matrices (5/9/27-point, 27-point x 2/3/8 dof): one lane per row
-        // wins up to ~32 entries per row, then 4 / 8 / 32 lanes per row
+        // measured on FEM-like stencil matrices (5/9/27-point, 27-point x 2/3/8 dof): one lane per row (its LDS
+        // reads batched eight at a time) wins up to ~80 entries per row, then 32 lanes per row
         if (mean <= 12.0) { c->items_per_thread = 1; c->threads_per_row = 0; }
-        else if (mean <= 32.0) { c->items_per_thread = 2; c->threads_per_row = 0; }
-        else if (mean <= 64.0) { c->items_per_thread = 2; c->threads_per_row = 4; }
-        else if (mean <= 128.0) { c->items_per_thread = 2; c->threads_per_row = 8; }
+        else if (mean <= 96.0) { c->items_per_thread = 2; c->threads_per_row = 0; }
         else { c->items_per_thread = 2; c->threads_per_row = 32; }
         break;
     case CMI_FORMAT_ELL: c->kernel = CMI_ELL_ROW; c->items_per_thread = 1; break;

@@ -134,7 +134,7 @@ def test_tuning_heuristics_and_table_roundtrip(cmi, tmp_path):
     assert c.rows_per_block == 192 and c.nontemporal == 2
     # long rows -> still the LDS-staged stream, summed by a power-of-two group of lanes per row
     c = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 100000)
-    assert c.kernel == cmi.CSR_STREAM and c.threads_per_row == 8 and c.items_per_thread == 2
+    assert c.kernel == cmi.CSR_STREAM and c.threads_per_row == 32 and c.items_per_thread == 2
     c = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F32, 1000, 1000, 20000)
     assert c.kernel == cmi.CSR_STREAM and c.threads_per_row == 0 and c.items_per_thread == 2
     assert cmi.tuning_select(cmi.FORMAT_ELL, cmi.F64, 100, 100, 500).kernel == cmi.ELL_ROW

@@ -41,9 +41,9 @@ def csr_space(cmi, mean, quick):
     tprs = [t for t in (2, 4, 8, 16, 32, 64) if t <= max(2, 4 * mean) and 4 * t >= mean / 4]
     for t, b, nt in itertools.product(tprs, blocks, (0, 1)):
         out.append(cmi.Config(kernel=cmi.CSR_VECTOR, block_size=b, threads_per_row=t, nontemporal=nt))
-    if mean <= 40:
-        for b, ipt, nt, swz in itertools.product(blocks, (1, 2, 4), (0, 2) if quick else (0, 1, 2, 3),
-                                                 (0, 1) if quick else (0, 1, 32)):
+    if mean <= 100:  # one lane per row (storage order, bit-exact): its LDS reads are batched, so it holds up to ~80/row
+        for b, ipt, nt, swz in itertools.product(blocks, (1, 2, 4), (0, 2) if quick or mean > 12 else (0, 1, 2, 3),
+                                                 (0, 8) if quick else (0, 1, 8, 32, 64)):
             tile = b * ipt * 4
             base = max(1, int((tile - 3) / max(mean, 0.25)))
             aligned = max(1, base // 16 * 16)
@@ -55,7 +55,7 @@ def csr_space(cmi, mean, quick):
                                       nontemporal=nt, xcd_swizzle=swz))
     if mean >= 6:
         # longer rows: the same LDS-staged tile, but a power-of-two group of lanes sums each row
-        for b, ipt, tpr, nt in itertools.product(blocks, (1, 2, 4), (2, 4, 8, 16, 32, 64), (0, 2)):
+        for b, ipt, tpr, nt, swz in itertools.product(blocks, (1, 2, 4), (2, 4, 8, 16, 32, 64), (0, 2), (0, 8)):
             if tpr > 8 * mean or tpr * 16 < mean:
                 continue
             tile = b * ipt * 4
@@ -63,7 +63,7 @@ def csr_space(cmi, mean, quick):
             base = min(base, 4 * (b // tpr))
             for rpb in sorted({base, max(1, base // 16 * 16)}):
                 out.append(cmi.Config(kernel=cmi.CSR_STREAM, block_size=b, items_per_thread=ipt, rows_per_block=rpb,
-                                      threads_per_row=tpr, nontemporal=nt))
+                                      threads_per_row=tpr, nontemporal=nt, xcd_swizzle=swz))
     if mean <= 40:
         for b, nt, chunked, bpc in itertools.product(blocks, (0, 2) if quick else (0, 1, 2, 3), (0, 1),
                                                      (4, 8) if quick else (2, 3, 4, 6, 8, 12)):
@@ -217,6 +217,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--grid", type=int, default=3162)
     ap.add_argument("--skip-synthetic", action="store_true")
+    ap.add_argument("--merge", action="store_true", help="start from the table at --out (tune some formats, keep the others)")
     args = ap.parse_args()
 
     import torch
@@ -234,6 +235,8 @@ def main():
         logf.flush()
 
     cmi.tuning_clear()
+    if args.merge and os.path.exists(args.out):
+        cmi.tuning_load(args.out)  # explicit configs are timed below, so the loaded entries do not steer the search
     formats = args.formats.split(",")
     t_start = time.time()
     summary = []
