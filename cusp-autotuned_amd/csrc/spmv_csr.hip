@@ -63,9 +63,23 @@ csr_vector_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__res
     }
 }
 
-// s + p[0] + p[1] + ... + p[n-1], added in that order (the reference host loop's order), with the LDS
-// reads of eight terms issued before the first add: a dependent read -> add chain costs ~40 ns per entry,
-// batched reads ~8 ns, and the bits are the same.
+// s + p[0] + p[stride] + ... + p[(n-1)*stride], added in that order (stride 1: the reference host loop's order),
+// with the LDS reads of eight terms issued before the first add: a dependent read -> add chain costs ~40 ns per
+// entry, batched reads ~8-12 ns, and the bits are the same.  (Also tried: reading the last 1..7 terms with clamped
+// positions so that a five-entry row costs one LDS round trip -- 1.4 % SLOWER on the headline matrix, whose
+// workgroups hide that latency anyway; the short tail stays a plain loop.)
+template <typename T> __device__ __forceinline__ T sum_strided(T s, const T *p, int n, int stride)
+{
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        const T *q = p + (size_t)j * stride;
+        const T v0 = q[0], v1 = q[stride], v2 = q[2 * stride], v3 = q[3 * stride], v4 = q[4 * stride], v5 = q[5 * stride],
+                v6 = q[6 * stride], v7 = q[7 * stride];
+        s = s + v0; s = s + v1; s = s + v2; s = s + v3; s = s + v4; s = s + v5; s = s + v6; s = s + v7;
+    }
+    for (; j < n; j++) s = s + p[(size_t)j * stride];
+    return s;
+}
 template <typename T> __device__ __forceinline__ T sum_in_order(T s, const T *p, int n)
 {
     int j = 0;
@@ -231,7 +245,7 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
                         int a = rowptr[r], b = rowptr[r + 1];
                         a = a > base ? a : base;
                         b = b < base + tile_entries ? b : base + tile_entries;
-                        T s = T(0);
+                        T s = T(0); // (batching these strided reads as sum_strided does costs the whole kernel 6 VGPRs: not here)
                         for (int j = a + sub; j < b; j += tpr) s = s + prod[j - base];
                         for (int o = tpr >> 1; o > 0; o >>= 1) s = s + __shfl_down(s, o, tpr);
                         if (sub == 0) acc[q] = acc[q] + s;
@@ -621,8 +635,8 @@ csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict
             const bool whole = (a >= j0) && (k < c); // starts and ends inside this tile
             if (a < j0) a = j0;
             if (b > j1) b = j1;
-            T sum = T(0);
-            for (int64_t j = a + sub; j < b; j += tpr) sum = sum + prod[j - base];
+            const int first = (int)(a - base) + sub, span = (int)(b - a) - sub;
+            T sum = sum_strided(T(0), prod + first, span > 0 ? (span + tpr - 1) / tpr : 0, tpr);
             for (int o = tpr >> 1; o > 0; o >>= 1) sum = sum + __shfl_down(sum, o, tpr);
             if (sub == 0) {
                 T *dst = y + i0 + k;
