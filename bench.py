@@ -212,6 +212,8 @@ def main():
             y.fill_(10.0)
             sh.multiply(y)
             good = torch.tensor([int(torch.equal(y, want))], dtype=torch.int32, device=dev)
+            if sh.vec.plan.mode in os.environ.get("CMI_BENCH_REJECT", "").split(","):
+                good.zero_()  # tests only: pretend this exchange delivered wrong halos, to exercise the hand-over
             dist.all_reduce(good, op=dist.ReduceOp.MIN)
             if int(good.item()) == 1:
                 break

@@ -154,3 +154,22 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert line["config"]["x_exchange"]["exchange_only_ms"] > 0
     ag = line["allgather_exchange"]  # the north-star's literal exchange, timed beside the default
     assert "error" not in ag and ag["y_identical_to_default_exchange"] and ag["values_received_per_rank"] == 3162 * 3162
+
+
+def test_bench_hands_over_to_the_next_exchange_when_one_is_rejected(tmp_path):
+    """bench.py validates the exchange against the stencil's closed form before timing; an exchange that fails is closed and
+    the next one takes over on every rank (CMI_BENCH_REJECT pretends the one-sided pull failed): two-sided halo exchange."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, CMI_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1", CMI_BENCH_REJECT="peer")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--cg-iterations", "5"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    ex = line["config"]["x_exchange"]
+    assert ex["rejected_exchanges"] == ["peer"] and ex["mode"] == "halo" and ex["validated_against"].startswith("stencil")
+    assert line["value"] > 0 and line["cg"]["residual_consistent"] and line["cg"]["exchange"] == "halo"
+    assert line["allgather_exchange"]["y_identical_to_default_exchange"]
