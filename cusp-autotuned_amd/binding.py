@@ -128,6 +128,7 @@ def _declare(L):
         getattr(L, f"cmi_blas_nrm2_{suf}").argtypes = [i64, vp, vp, vp, vp]
     L.cmi_cg_update_f64.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.cmi_cg_direction_f64.argtypes = [i64, vp, vp, vp, vp, vp]
+    L.cmi_cg_direction_x_f64.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp]
 
 
 def lib():
@@ -450,9 +451,10 @@ def blas_nrm2(x, result, workspace, stream=None):
 
 
 def cg_update(rz, yp, p, y, x, r, rr_out, workspace, stream=None, mirror=None):
-    """alpha = rz/yp (device scalars); x += alpha p; r -= alpha y; rr_out = <r, r> -- one pass.
+    """alpha = rz/yp (device scalars); x += alpha p (x None: left to cg_direction_x); r -= alpha y; rr_out = <r, r> -- one pass.
     mirror: a HostScalar that also receives <r, r> (no copy); its event is recorded behind the call."""
-    check(lib().cmi_cg_update_f64(x.numel(), _ptr(rz), _ptr(yp), _ptr(p), _ptr(y), _ptr(x), _ptr(r), _ptr(rr_out),
+    check(lib().cmi_cg_update_f64(r.numel(), _ptr(rz), _ptr(yp), _ptr(p) if x is not None else None, _ptr(y),
+                                  _ptr(x) if x is not None else None, _ptr(r), _ptr(rr_out),
                                   mirror.ptr if mirror is not None else None, _ptr(workspace), _stream(stream)))
     if mirror is not None:
         mirror.record(stream)
@@ -592,3 +594,8 @@ class CopyRanges:
 def cg_direction(rr_new, rr_old, r, p, stream=None):
     """beta = rr_new/rr_old (device scalars); p = r + beta p."""
     check(lib().cmi_cg_direction_f64(p.numel(), _ptr(rr_new), _ptr(rr_old), _ptr(r), _ptr(p), _stream(stream)))
+
+
+def cg_direction_x(rr_new, rr_old, yp, r, p, x, stream=None):
+    """alpha = rr_old/yp, beta = rr_new/rr_old (device scalars); x += alpha p (old p), then p = r + beta p -- one pass."""
+    check(lib().cmi_cg_direction_x_f64(p.numel(), _ptr(rr_new), _ptr(rr_old), _ptr(yp), _ptr(r), _ptr(p), _ptr(x), _stream(stream)))

@@ -199,7 +199,7 @@ int reduce_partials_f64(int npartial, double *workspace, double *result, hipStre
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlasBlock)
 cg_update_kernel(int64_t n, const double *__restrict__ rz, const double *__restrict__ yp, const double *__restrict__ p,
-                 const double *__restrict__ y, double *__restrict__ x, double *__restrict__ r, double *__restrict__ partial, int vec)
+                 const double *__restrict__ y, double *__restrict__ x /* may be null */, double *__restrict__ r, double *__restrict__ partial, int vec)
 {
     __shared__ double slots[kBlasBlock / kWave];
     const double alpha = *rz / *yp; // alpha <- <r,z>/<y,p>   (cg.inl:83)
@@ -209,25 +209,29 @@ cg_update_kernel(int64_t n, const double *__restrict__ rz, const double *__restr
     if (vec) {
         const int64_t nv = n / 2;
         for (int64_t i = t; i < nv; i += stride) {
-            const double2v pv = reinterpret_cast<const double2v *>(p)[i], yv = reinterpret_cast<const double2v *>(y)[i];
-            double2v xv = reinterpret_cast<double2v *>(x)[i], rv = reinterpret_cast<double2v *>(r)[i];
-            xv.x = alpha * pv.x + xv.x; xv.y = alpha * pv.y + xv.y;         // x <- x + alpha p   (:86)
+            const double2v yv = reinterpret_cast<const double2v *>(y)[i];
+            double2v rv = reinterpret_cast<double2v *>(r)[i];
+            if (x) { // (uniform) x == nullptr: the x update rides with the direction kernel, which has p in registers anyway
+                const double2v pv = reinterpret_cast<const double2v *>(p)[i];
+                double2v xv = reinterpret_cast<double2v *>(x)[i];
+                xv.x = alpha * pv.x + xv.x; xv.y = alpha * pv.y + xv.y;     // x <- x + alpha p   (:86)
+                reinterpret_cast<double2v *>(x)[i] = xv;
+            }
             rv.x = (-alpha) * yv.x + rv.x; rv.y = (-alpha) * yv.y + rv.y;   // r <- r - alpha y   (:89)
-            reinterpret_cast<double2v *>(x)[i] = xv;
             reinterpret_cast<double2v *>(r)[i] = rv;
             acc += rv.x * rv.x;
             acc += rv.y * rv.y;                                             // <r, r>             (:97, z == r)
         }
         if (t == 0 && (n & 1)) {
             const int64_t i = n - 1;
-            x[i] = alpha * p[i] + x[i];
+            if (x) x[i] = alpha * p[i] + x[i];
             const double ri = (-alpha) * y[i] + r[i];
             r[i] = ri;
             acc += ri * ri;
         }
     } else {
         for (int64_t i = t; i < n; i += stride) {
-            x[i] = alpha * p[i] + x[i];
+            if (x) x[i] = alpha * p[i] + x[i];
             const double ri = (-alpha) * y[i] + r[i];
             r[i] = ri;
             acc += ri * ri;
@@ -258,6 +262,40 @@ cg_direction_kernel(int64_t n, const double *__restrict__ rr_new, const double *
         if (t == 0 && (n & 1)) p[n - 1] = 1.0 * r[n - 1] + beta * p[n - 1];
     } else {
         for (int64_t i = t; i < n; i += stride) p[i] = 1.0 * r[i] + beta * p[i];
+    }
+}
+
+// The same, and x <- x + alpha p with the OLD p (alpha = rr_old / yp, as cmi_cg_update computes it) before p is
+// overwritten: the direction pass reads p anyway, so moving the x update here saves one read of p per iteration
+// (8 vector passes instead of 9); the expressions are the update kernel's, term for term.
+__global__ void __launch_bounds__(kBlasBlock)
+cg_direction_x_kernel(int64_t n, const double *__restrict__ rr_new, const double *__restrict__ rr_old, const double *__restrict__ yp,
+                      const double *__restrict__ r, double *__restrict__ p, double *__restrict__ x, int vec)
+{
+    const double alpha = *rr_old / *yp;
+    const double beta = *rr_new / *rr_old;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        const int64_t nv = n / 2;
+        for (int64_t i = t; i < nv; i += stride) {
+            const double2v rv = reinterpret_cast<const double2v *>(r)[i];
+            double2v pv = reinterpret_cast<double2v *>(p)[i], xv = reinterpret_cast<double2v *>(x)[i];
+            xv.x = alpha * pv.x + xv.x; xv.y = alpha * pv.y + xv.y;
+            pv.x = 1.0 * rv.x + beta * pv.x;
+            pv.y = 1.0 * rv.y + beta * pv.y;
+            reinterpret_cast<double2v *>(x)[i] = xv;
+            reinterpret_cast<double2v *>(p)[i] = pv;
+        }
+        if (t == 0 && (n & 1)) {
+            x[n - 1] = alpha * p[n - 1] + x[n - 1];
+            p[n - 1] = 1.0 * r[n - 1] + beta * p[n - 1];
+        }
+    } else {
+        for (int64_t i = t; i < n; i += stride) {
+            x[i] = alpha * p[i] + x[i];
+            p[i] = 1.0 * r[i] + beta * p[i];
+        }
     }
 }
 
@@ -343,9 +381,9 @@ CMI_API int cmi_cg_update_f64(int64_t n, const double *rz_dev, const double *yp_
 {
     if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_update: negative n");
     if (!rz_dev || !yp_dev || !rr_dev || !workspace) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_update: null scalar or workspace");
-    if (n > 0 && (!p || !y || !x || !r)) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_update: null array");
+    if (n > 0 && (!y || !r || (x && !p))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_update: null array");
     const int grid = fused_grid(n);
-    const int vec = aligned16(p) && aligned16(y) && aligned16(x) && aligned16(r);
+    const int vec = aligned16(y) && aligned16(r) && (!x || (aligned16(p) && aligned16(x)));
     hipLaunchKernelGGL(cg_update_kernel, dim3(grid), dim3(kBlasBlock), 0, as_stream(stream), n, rz_dev, yp_dev, p, y, x, r, (double *)workspace, vec);
     reduce_partials<double>(grid, (double *)workspace, rr_dev, 0, as_stream(stream), rr_host_mirror);
     CMI_LAUNCH_CHECK("cg_update");
@@ -362,5 +400,18 @@ CMI_API int cmi_cg_direction_f64(int64_t n, const double *rr_new_dev, const doub
     const int vec = aligned16(r) && aligned16(p);
     hipLaunchKernelGGL(cg_direction_kernel, dim3(stream_grid(n, 2)), dim3(kBlasBlock), 0, as_stream(stream), n, rr_new_dev, rr_old_dev, r, p, vec);
     CMI_LAUNCH_CHECK("cg_direction");
+    return CMI_SUCCESS;
+}
+
+CMI_API int cmi_cg_direction_x_f64(int64_t n, const double *rr_new_dev, const double *rr_old_dev, const double *yp_dev, const double *r,
+                                   double *p, double *x, void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_direction_x: negative n");
+    if (!rr_new_dev || !rr_old_dev || !yp_dev) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_direction_x: null scalar");
+    if (n == 0) return CMI_SUCCESS;
+    if (!r || !p || !x) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_direction_x: null array");
+    const int vec = aligned16(r) && aligned16(p) && aligned16(x);
+    hipLaunchKernelGGL(cg_direction_x_kernel, dim3(stream_grid(n, 2)), dim3(kBlasBlock), 0, as_stream(stream), n, rr_new_dev, rr_old_dev, yp_dev, r, p, x, vec);
+    CMI_LAUNCH_CHECK("cg_direction_x");
     return CMI_SUCCESS;
 }

@@ -32,9 +32,9 @@ namespace detail {
 // Fused unpreconditioned CG on the device (f64): z == r is folded away, alpha and beta stay in device
 // memory, and an iteration is
 //     cmi_spmv_csr_dot_f64 (y <- A p and <y,p> in one pass; other formats: SpMV + cmi_blas_dot)
-//     cmi_cg_update_f64    (x, r, <r,r> in one pass)
-//     cmi_cg_direction_f64 (p <- r + beta p)
-// i.e. 3 passes and ONE host read (the convergence check) instead of cg.inl's 7 passes and 3 host syncs.
+//     cmi_cg_update_f64      (r, <r,r> in one pass)
+//     cmi_cg_direction_x_f64 (x <- x + alpha p, p <- r + beta p in one pass)
+// i.e. 3 launches, 8 vector passes and ONE host read (the convergence check) instead of cg.inl's 7 passes and 3 host syncs.
 // The host read needs no copy: cmi_cg_update's reduction also writes <r,r> into page-locked host
 // memory, and the host waits for the event behind it only AFTER it has queued the next iteration's SpMV (which reads p and writes the scratch y -- no solver state -- so
 // running it speculatively is harmless if the monitor then stops), so the device never idles on the
@@ -120,9 +120,10 @@ void cg_fused_device(const LinearOperator &A, VectorType1 &x, const VectorType2 
     for (;;) {
         multiply_dot(A, p, y, yp, w.ws, 0);                                               // the hot path (speculative, see above)
         if (monitor.finished_norm(std::sqrt(rr_host.wait()))) break;                      // the one host read
-        cusp::detail::check(cmi_cg_update_f64(N, rr[cur], yp, p.data(), y.data(), x.data(), r.data(), rr[cur ^ 1], rr_host.host, w.ws, nullptr));
+        cusp::detail::check(cmi_cg_update_f64(N, rr[cur], yp, nullptr, y.data(), nullptr, r.data(), rr[cur ^ 1], rr_host.host, w.ws, nullptr));
         rr_host.record();
-        cusp::detail::check(cmi_cg_direction_f64(N, rr[cur ^ 1], rr[cur], r.data(), p.data(), nullptr));
+        // x <- x + alpha p rides with the direction pass (it reads p anyway): 8 vector passes per iteration, not 9
+        cusp::detail::check(cmi_cg_direction_x_f64(N, rr[cur ^ 1], rr[cur], yp, r.data(), p.data(), x.data(), nullptr));
         cur ^= 1;
         ++monitor;
     }

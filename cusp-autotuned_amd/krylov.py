@@ -144,7 +144,7 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
     """Unpreconditioned CG with z == r folded away and the scalars resident on the device.
 
     Per iteration: y <- A p together with <y, p> (one launch for CSR: cmi_spmv_csr_dot_f64), then
-    cmi_cg_update (x, r, <r,r>), then cmi_cg_direction.  The single host read (the monitor's residual
+    cmi_cg_update (r, <r,r>), then cmi_cg_direction_x (x, p).  The single host read (the monitor's residual
     norm) lands in page-locked memory (written by the reduction itself on one GPU, an asynchronous
     copy behind the all-reduce when sharded) that the host waits for only AFTER queueing the next
     iteration's SpMV: that SpMV reads p and writes the scratch y -- no solver state -- so it
@@ -190,8 +190,14 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
     if one_sided:
         r_ex = A.new_exchanged_vector()
         r = r_ex.x_local
-        pieces = A.halo_ranges()
         p_full, r_full = A.vec.x_full, r_ex.x_full
+        p = A.x_local                                               # (a view of p_full; r likewise of r_full)
+        halo_only = []                                              # the pieces of the full-length buffers this rank reads
+        for l, h in A.halo_ranges():                                # ... minus its own slice
+            if l < A.vec.lo:
+                halo_only.append((l, min(h, A.vec.lo)))
+            if h > A.vec.hi:
+                halo_only.append((max(l, A.vec.hi), h))
 
     spmv(x, y)                                   # y <- A x
     B.blas_axpby(1.0, b, -1.0, y, r)             # r <- b - A x
@@ -212,16 +218,16 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
             spmv_dot()                           # THE HOT PATH (queued before the host waits)
         if monitor.finished(math.sqrt(rr_host.wait())):             # the one host read per iteration
             break
-        B.cg_update(rr[cur], yp, p, y, x, r, rr[cur ^ 1], ops.ws, mirror=mirror)   # x, r, <r,r> in one pass
+        B.cg_update(rr[cur], yp, None, y, None, r, rr[cur ^ 1], ops.ws, mirror=mirror)   # r, <r,r> in one pass
         if mirror is None:
             reduce_(rr[cur ^ 1])
             rr_host.fetch(rr[cur ^ 1])
+        # x <- x + alpha p rides with the direction pass (which reads p anyway): 8 vector passes per iteration, not 9
         if one_sided:
             r_ex.exchange()                                         # pull the peers' boundary r
-            for l, h in pieces:                                     # own slice + halo: p <- r + beta p
+            for l, h in halo_only:                                  # halo: p <- r + beta p (the owner's arithmetic)
                 B.cg_direction(rr[cur ^ 1], rr[cur], r_full[l:h], p_full[l:h])
-        else:
-            B.cg_direction(rr[cur ^ 1], rr[cur], r, p)              # p <- r + beta p
+        B.cg_direction_x(rr[cur ^ 1], rr[cur], yp, r, p, x)         # own slice: x <- x + alpha p; p <- r + beta p
         cur ^= 1
         monitor.increment()
     if one_sided:

@@ -347,7 +347,7 @@ int cmi_blas_nrm2_f32(int64_t n, const float *x, float *result_dev, void *worksp
 /* Fused steps of unpreconditioned CG (identity M, so z == r), scalars taken from DEVICE memory:
  * replaces dotc -> host -> axpy -> axpy -> copy -> dotc -> host -> axpby of
  * cusp/krylov/detail/cg.inl:83-103 (seven vector passes, three host syncs per iteration) by
- *   cmi_cg_update:    alpha = *rz / *yp;  x += alpha p;  r -= alpha y;  *rr = <r, r>   (one pass)
+ *   cmi_cg_update:    alpha = *rz / *yp;  x += alpha p (skipped when x == NULL);  r -= alpha y;  *rr = <r, r>   (one pass)
  *   cmi_cg_direction: beta = *rr_new / *rr_old;  p = r + beta p                         (one pass)
  * The element arithmetic is the reference's (one multiply and one add per update, unfused).
  * rr_host_mirror (may be NULL): cmi_malloc_host memory that also receives <r, r> -- written by the
@@ -357,6 +357,12 @@ int cmi_cg_update_f64(int64_t n, const double *rz_dev, const double *yp_dev, con
                       double *x, double *r, double *rr_dev, double *rr_host_mirror, void *workspace, void *stream);
 int cmi_cg_direction_f64(int64_t n, const double *rr_new_dev, const double *rr_old_dev, const double *r,
                          double *p, void *stream);
+/* The 8-pass split of the same iteration: cmi_cg_update_f64 with x == NULL leaves x alone (r and <r,r> only; p is then
+ * not read), and cmi_cg_direction_x applies x += alpha p (alpha = *rr_old / *yp, the value cmi_cg_update used) with the
+ * OLD p before it forms p = r + beta p -- the direction pass holds p in registers anyway, so p is read once less per
+ * iteration.  Same expressions, same bits as the two calls above. */
+int cmi_cg_direction_x_f64(int64_t n, const double *rr_new_dev, const double *rr_old_dev, const double *yp_dev,
+                           const double *r, double *p, double *x, void *stream);
 
 #ifdef __cplusplus
 }

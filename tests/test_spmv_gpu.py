@@ -1127,6 +1127,38 @@ def test_cg_update_long_partial_list(cmi, torch_cuda):
     assert abs(float(rr) - float(np.dot(r_new, r_new))) <= 1e-12 * float(np.dot(r_new, r_new))
 
 
+@pytest.mark.parametrize("n", [1, 2, 7, 1000, 3_000_001])
+def test_cg_eight_pass_split_is_the_nine_pass_iteration(cmi, torch_cuda, n):
+    """cmi_cg_update(x = NULL) + cmi_cg_direction_x == cmi_cg_update + cmi_cg_direction, bit for bit: the x update moved
+    to the pass that already holds p (one read of p less), with the update kernel's own expressions; odd lengths and
+    unaligned views take the scalar paths."""
+    torch = torch_cuda
+    rng = np.random.default_rng(n)
+    for shift in (0, 1):  # 1: views that are not 16-byte aligned
+        def vec():
+            buf = dev(rng.standard_normal(n + 2), torch)
+            return buf[shift:shift + n]
+        p, y, x, r = vec(), vec(), vec(), vec()
+        p2, x2, r2 = p.clone(), x.clone(), r.clone()
+        if shift:  # clone() re-aligns: put the copies back on odd offsets
+            def odd(t):
+                buf = torch.empty(n + 2, dtype=torch.float64, device="cuda")
+                buf[1:1 + n].copy_(t)
+                return buf[1:1 + n]
+            p2, x2, r2 = odd(p), odd(x), odd(r)
+        rz = torch.tensor([1.75], dtype=torch.float64, device="cuda")
+        yp = torch.tensor([0.6], dtype=torch.float64, device="cuda")
+        rr_a = torch.zeros(1, dtype=torch.float64, device="cuda")
+        rr_b = torch.zeros(1, dtype=torch.float64, device="cuda")
+        ws = cmi.blas_workspace()
+        cmi.cg_update(rz, yp, p, y, x, r, rr_a, ws)
+        cmi.cg_direction(rr_a, rz, r, p)
+        cmi.cg_update(rz, yp, None, y, None, r2, rr_b, ws)
+        cmi.cg_direction_x(rr_b, rz, yp, r2, p2, x2)
+        assert float(rr_a) == float(rr_b)
+        assert torch.equal(r, r2) and torch.equal(x, x2) and torch.equal(p, p2)
+
+
 # ------------------------------------------------------------------------------------------------
 # BLAS-1 used by cg
 # ------------------------------------------------------------------------------------------------
