@@ -485,6 +485,69 @@ def test_pathological_row_length_distributions(cmi, torch_cuda, orc, shape):
         assert_close(host(y), want, bound, np.float64, f"{shape} coo{kern}")
 
 
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_long_rows_streamed_by_the_workgroup(cmi, torch_cuda, orc, tag):
+    """csr_stream's cooperative long-row path at its edges: rows of exactly 511 / 512 / 513 entries (the threshold), long
+    rows first and last in the matrix and in a tile, two long rows side by side, long rows whose first entry sits at every
+    offset modulo 4 (head / tail handling of the 16-byte vector loop), unaligned arrays, y += A x, the fused dot, lane
+    groups (threshold 128 entries per lane of the group) -- shorter rows must stay bit-exact next to them."""
+    torch = torch_cuda
+    dt = np.float64 if tag == "f64" else np.float32
+    rng = np.random.default_rng(77)
+    rows, cols = 3000, 5000
+    lens = rng.integers(0, 9, size=rows)
+    special = {0: 700, 1: 512, 2: 511, 3: 513, 175: 2048, 176: 1500, 177: 3, 178: 4097, 1000: 515, 1001: 514, 1002: 513,
+               1003: 512, 2047: 9000, 2999: 1234}
+    for r, l in special.items():
+        lens[r] = l
+    Ap = np.r_[0, np.cumsum(lens)].astype(np.int32)
+    nnz = int(Ap[-1])
+    Aj = rng.integers(0, cols, size=nnz).astype(np.int32)
+    Ax = rng.standard_normal(nnz).astype(dt)
+    x = rng.standard_normal(cols).astype(dt)
+    y0 = rng.standard_normal(rows).astype(dt)
+    want, want_acc = orc.spmv_csr(Ap, Aj, Ax, x), orc.spmv_csr(Ap, Aj, Ax, x, y0)
+    bound = row_abs(orc, Ap, Aj, Ax, x)
+    dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+    tdt = torch.float64 if tag == "f64" else torch.float32
+    shapes = [(256, 1, 0), (256, 1, 176), (128, 2, 64), (512, 4, 0), (64, 1, 7), (1024, 1, 300), (256, 2, 1)]
+    for blk, ipt, rpb in shapes:
+        for acc in (False, True):
+            cfg = cmi.Config(kernel=cmi.CSR_STREAM, block_size=blk, items_per_thread=ipt, rows_per_block=rpb, nontemporal=2)
+            y = dev(y0, torch).clone() if acc else torch.full((rows,), 10.0, dtype=tdt, device="cuda")
+            cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, accumulate=acc, cfg=cfg)
+            assert_variant(host(y), want_acc if acc else want, bound + (np.abs(y0) if acc else 0), dt, "short", Ap,
+                           f"long rows b{blk} i{ipt} r{rpb} acc={acc}")
+    # lane groups: the threshold moves to 128 entries per lane (tpr 8 -> 1024): rows of 1500+ are streamed, 700 is not
+    for tpr, rpb in ((8, 64), (32, 16), (2, 0)):
+        y = torch.full((rows,), 10.0, dtype=tdt, device="cuda")
+        cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, cfg=cmi.Config(kernel=cmi.CSR_STREAM, block_size=256, items_per_thread=2,
+                                                                        rows_per_block=rpb, threads_per_row=tpr))
+        assert_close(host(y), want, bound, dt, f"long rows tpr{tpr}")
+    # unaligned column / value arrays: the scalar-load instances have the same path
+    bj = torch.zeros(nnz + 8, dtype=torch.int32, device="cuda")
+    bv = torch.zeros(nnz + 8, dtype=tdt, device="cuda")
+    bj[1:1 + nnz].copy_(dAj)
+    bv[3:3 + nnz].copy_(dAx)
+    y = torch.full((rows,), 10.0, dtype=tdt, device="cuda")
+    cmi.spmv_csr(rows, cols, dAp, bj[1:1 + nnz], bv[3:3 + nnz], dx, y, cfg=cmi.Config(kernel=cmi.CSR_STREAM))
+    assert_variant(host(y), want, bound, dt, "short", Ap, "long rows, unaligned arrays")
+    # storage order on request: every row bit-exact
+    y = torch.full((rows,), 10.0, dtype=tdt, device="cuda")
+    cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, cfg=cmi.Config(kernel=cmi.CSR_STREAM, threads_per_row=1))
+    assert np.array_equal(host(y), want)
+    if tag == "f64":  # the fused dot runs the same instances: y identical to the plain call, dot within rounding
+        wv = dev(rng.standard_normal(rows), torch)
+        res = torch.zeros(1, dtype=torch.float64, device="cuda")
+        y1 = torch.full((rows,), 10.0, dtype=tdt, device="cuda")
+        y2 = torch.full((rows,), -3.0, dtype=tdt, device="cuda")
+        cfg = cmi.Config(kernel=cmi.CSR_STREAM, block_size=256, rows_per_block=176)
+        cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y1, cfg=cfg)
+        cmi.spmv_csr_dot(rows, cols, dAp, dAj, dAx, dx, y2, wv, res, cmi.blas_workspace(), cfg=cfg)
+        assert torch.equal(y1, y2)
+        assert abs(float(res) - float((y2 * wv).sum())) <= 1e-11 * float((y2 * wv).abs().sum())
+
+
 def test_row_length_profile_selects_the_balanced_kernel(cmi, torch_cuda, orc):
     """With no explicit kernel the library measures the longest row once per matrix and leaves the row-tile
     kernel for the merge-path one when that row would dominate: results stay within tolerance, and the
