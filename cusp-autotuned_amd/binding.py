@@ -129,6 +129,10 @@ def _declare(L):
     L.cmi_cg_update_f64.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.cmi_cg_direction_f64.argtypes = [i64, vp, vp, vp, vp, vp]
     L.cmi_cg_direction_x_f64.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp]
+    L.cmi_cg_update_f32.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.cmi_cg_direction_f32.argtypes = [i64, vp, vp, vp, vp, vp]
+    L.cmi_cg_direction_x_f32.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp]
+    L.cmi_blas_dotd_f32.argtypes = [i64, vp, vp, vp, vp, vp]
 
 
 def lib():
@@ -453,7 +457,7 @@ def blas_nrm2(x, result, workspace, stream=None):
 def cg_update(rz, yp, p, y, x, r, rr_out, workspace, stream=None, mirror=None):
     """alpha = rz/yp (device scalars); x += alpha p (x None: left to cg_direction_x); r -= alpha y; rr_out = <r, r> -- one pass.
     mirror: a HostScalar that also receives <r, r> (no copy); its event is recorded behind the call."""
-    check(lib().cmi_cg_update_f64(r.numel(), _ptr(rz), _ptr(yp), _ptr(p) if x is not None else None, _ptr(y),
+    check(getattr(lib(), "cmi_cg_update_" + _suffix(r))(r.numel(), _ptr(rz), _ptr(yp), _ptr(p) if x is not None else None, _ptr(y),
                                   _ptr(x) if x is not None else None, _ptr(r), _ptr(rr_out),
                                   mirror.ptr if mirror is not None else None, _ptr(workspace), _stream(stream)))
     if mirror is not None:
@@ -593,9 +597,19 @@ class CopyRanges:
 
 def cg_direction(rr_new, rr_old, r, p, stream=None):
     """beta = rr_new/rr_old (device scalars); p = r + beta p."""
-    check(lib().cmi_cg_direction_f64(p.numel(), _ptr(rr_new), _ptr(rr_old), _ptr(r), _ptr(p), _stream(stream)))
+    check(getattr(lib(), "cmi_cg_direction_" + _suffix(p))(p.numel(), _ptr(rr_new), _ptr(rr_old), _ptr(r), _ptr(p), _stream(stream)))
 
 
 def cg_direction_x(rr_new, rr_old, yp, r, p, x, stream=None):
     """alpha = rr_old/yp, beta = rr_new/rr_old (device scalars); x += alpha p (old p), then p = r + beta p -- one pass."""
-    check(lib().cmi_cg_direction_x_f64(p.numel(), _ptr(rr_new), _ptr(rr_old), _ptr(yp), _ptr(r), _ptr(p), _ptr(x), _stream(stream)))
+    check(getattr(lib(), "cmi_cg_direction_x_" + _suffix(p))(p.numel(), _ptr(rr_new), _ptr(rr_old), _ptr(yp), _ptr(r), _ptr(p), _ptr(x),
+                                                             _stream(stream)))
+
+
+def blas_dotd(x, y, result, workspace, stream=None):
+    """<x, y> as a DOUBLE in device memory whatever the vectors' type (the scalar type of the fused CG steps)."""
+    import torch
+    if x.dtype == torch.float64:
+        check(lib().cmi_blas_dot_f64(x.numel(), _ptr(x), _ptr(y), _ptr(result), _ptr(workspace), _stream(stream)))
+    else:
+        check(lib().cmi_blas_dotd_f32(x.numel(), _ptr(x), _ptr(y), _ptr(result), _ptr(workspace), _stream(stream)))

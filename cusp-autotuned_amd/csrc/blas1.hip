@@ -197,44 +197,51 @@ int reduce_partials_f64(int npartial, double *workspace, double *result, hipStre
 // dot -> host -> axpy -> axpy -> copy -> dot -> host -> axpby: seven passes and three host syncs;
 // here: update (x, r, <r,r>) in ONE pass over p, y, x, r and the direction in one pass over r, p).
 // ---------------------------------------------------------------------------------------------
+// T = double or float; the scalars (<r,r>, <y,p>) are doubles in device memory for both (the partials of every
+// reduction here are doubles), alpha / beta are rounded to T once per kernel and the vectors are updated in T.
+template <typename T>
 __global__ void __launch_bounds__(kBlasBlock)
-cg_update_kernel(int64_t n, const double *__restrict__ rz, const double *__restrict__ yp, const double *__restrict__ p,
-                 const double *__restrict__ y, double *__restrict__ x /* may be null */, double *__restrict__ r, double *__restrict__ partial, int vec)
+cg_update_kernel(int64_t n, const double *__restrict__ rz, const double *__restrict__ yp, const T *__restrict__ p,
+                 const T *__restrict__ y, T *__restrict__ x /* may be null */, T *__restrict__ r, double *__restrict__ partial, int vec)
 {
+    typedef typename vec16<T>::type V;
+    constexpr int W = vec16<T>::n;
     __shared__ double slots[kBlasBlock / kWave];
-    const double alpha = *rz / *yp; // alpha <- <r,z>/<y,p>   (cg.inl:83)
+    const T alpha = (T)(*rz / *yp); // alpha <- <r,z>/<y,p>   (cg.inl:83)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double acc = 0.0;
     if (vec) {
-        const int64_t nv = n / 2;
+        const int64_t nv = n / W;
         for (int64_t i = t; i < nv; i += stride) {
-            const double2v yv = reinterpret_cast<const double2v *>(y)[i];
-            double2v rv = reinterpret_cast<double2v *>(r)[i];
+            const V yv = reinterpret_cast<const V *>(y)[i];
+            V rv = reinterpret_cast<V *>(r)[i];
             if (x) { // (uniform) x == nullptr: the x update rides with the direction kernel, which has p in registers anyway
-                const double2v pv = reinterpret_cast<const double2v *>(p)[i];
-                double2v xv = reinterpret_cast<double2v *>(x)[i];
-                xv.x = alpha * pv.x + xv.x; xv.y = alpha * pv.y + xv.y;     // x <- x + alpha p   (:86)
-                reinterpret_cast<double2v *>(x)[i] = xv;
+                const V pv = reinterpret_cast<const V *>(p)[i];
+                V xv = reinterpret_cast<V *>(x)[i];
+#pragma unroll
+                for (int k = 0; k < W; k++) xv[k] = alpha * pv[k] + xv[k];      // x <- x + alpha p   (:86)
+                reinterpret_cast<V *>(x)[i] = xv;
             }
-            rv.x = (-alpha) * yv.x + rv.x; rv.y = (-alpha) * yv.y + rv.y;   // r <- r - alpha y   (:89)
-            reinterpret_cast<double2v *>(r)[i] = rv;
-            acc += rv.x * rv.x;
-            acc += rv.y * rv.y;                                             // <r, r>             (:97, z == r)
+#pragma unroll
+            for (int k = 0; k < W; k++) rv[k] = (-alpha) * yv[k] + rv[k];       // r <- r - alpha y   (:89)
+            reinterpret_cast<V *>(r)[i] = rv;
+#pragma unroll
+            for (int k = 0; k < W; k++) acc += (double)rv[k] * (double)rv[k];   // <r, r>             (:97, z == r)
         }
-        if (t == 0 && (n & 1)) {
-            const int64_t i = n - 1;
+        if (t < n - nv * W) { // the last n % W elements: one lane each
+            const int64_t i = nv * W + t;
             if (x) x[i] = alpha * p[i] + x[i];
-            const double ri = (-alpha) * y[i] + r[i];
+            const T ri = (-alpha) * y[i] + r[i];
             r[i] = ri;
-            acc += ri * ri;
+            acc += (double)ri * (double)ri;
         }
     } else {
         for (int64_t i = t; i < n; i += stride) {
             if (x) x[i] = alpha * p[i] + x[i];
-            const double ri = (-alpha) * y[i] + r[i];
+            const T ri = (-alpha) * y[i] + r[i];
             r[i] = ri;
-            acc += ri * ri;
+            acc += (double)ri * (double)ri;
         }
     }
     const double s = block_sum(acc, slots);
@@ -242,59 +249,45 @@ cg_update_kernel(int64_t n, const double *__restrict__ rz, const double *__restr
     if (blockIdx.x == 0 && threadIdx.x == 0) *ticket_of(partial) = 0;
 }
 
-// p <- r + beta p with beta = rr_new / rr_old read from device memory (cg.inl:100-103, z == r)
+// p <- r + beta p with beta = rr_new / rr_old read from device memory (cg.inl:100-103, z == r).  With x != null also
+// x <- x + alpha p with the OLD p (alpha = rr_old / yp, as cg_update computes it) before p is overwritten: the direction
+// pass reads p anyway, so moving the x update here saves one read of p per iteration (8 vector passes instead of 9);
+// the expressions are the update kernel's, term for term.
+template <typename T>
 __global__ void __launch_bounds__(kBlasBlock)
-cg_direction_kernel(int64_t n, const double *__restrict__ rr_new, const double *__restrict__ rr_old,
-                    const double *__restrict__ r, double *__restrict__ p, int vec)
+cg_direction_kernel(int64_t n, const double *__restrict__ rr_new, const double *__restrict__ rr_old, const double *__restrict__ yp,
+                    const T *__restrict__ r, T *__restrict__ p, T *__restrict__ x /* may be null */, int vec)
 {
-    const double beta = *rr_new / *rr_old;
+    typedef typename vec16<T>::type V;
+    constexpr int W = vec16<T>::n;
+    const T alpha = x ? (T)(*rr_old / *yp) : T(0);
+    const T beta = (T)(*rr_new / *rr_old);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (vec) {
-        const int64_t nv = n / 2;
+        const int64_t nv = n / W;
         for (int64_t i = t; i < nv; i += stride) {
-            const double2v rv = reinterpret_cast<const double2v *>(r)[i];
-            double2v pv = reinterpret_cast<double2v *>(p)[i];
-            pv.x = 1.0 * rv.x + beta * pv.x;
-            pv.y = 1.0 * rv.y + beta * pv.y;
-            reinterpret_cast<double2v *>(p)[i] = pv;
+            const V rv = reinterpret_cast<const V *>(r)[i];
+            V pv = reinterpret_cast<V *>(p)[i];
+            if (x) {
+                V xv = reinterpret_cast<V *>(x)[i];
+#pragma unroll
+                for (int k = 0; k < W; k++) xv[k] = alpha * pv[k] + xv[k];
+                reinterpret_cast<V *>(x)[i] = xv;
+            }
+#pragma unroll
+            for (int k = 0; k < W; k++) pv[k] = T(1) * rv[k] + beta * pv[k];
+            reinterpret_cast<V *>(p)[i] = pv;
         }
-        if (t == 0 && (n & 1)) p[n - 1] = 1.0 * r[n - 1] + beta * p[n - 1];
-    } else {
-        for (int64_t i = t; i < n; i += stride) p[i] = 1.0 * r[i] + beta * p[i];
-    }
-}
-
-// The same, and x <- x + alpha p with the OLD p (alpha = rr_old / yp, as cmi_cg_update computes it) before p is
-// overwritten: the direction pass reads p anyway, so moving the x update here saves one read of p per iteration
-// (8 vector passes instead of 9); the expressions are the update kernel's, term for term.
-__global__ void __launch_bounds__(kBlasBlock)
-cg_direction_x_kernel(int64_t n, const double *__restrict__ rr_new, const double *__restrict__ rr_old, const double *__restrict__ yp,
-                      const double *__restrict__ r, double *__restrict__ p, double *__restrict__ x, int vec)
-{
-    const double alpha = *rr_old / *yp;
-    const double beta = *rr_new / *rr_old;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (vec) {
-        const int64_t nv = n / 2;
-        for (int64_t i = t; i < nv; i += stride) {
-            const double2v rv = reinterpret_cast<const double2v *>(r)[i];
-            double2v pv = reinterpret_cast<double2v *>(p)[i], xv = reinterpret_cast<double2v *>(x)[i];
-            xv.x = alpha * pv.x + xv.x; xv.y = alpha * pv.y + xv.y;
-            pv.x = 1.0 * rv.x + beta * pv.x;
-            pv.y = 1.0 * rv.y + beta * pv.y;
-            reinterpret_cast<double2v *>(x)[i] = xv;
-            reinterpret_cast<double2v *>(p)[i] = pv;
-        }
-        if (t == 0 && (n & 1)) {
-            x[n - 1] = alpha * p[n - 1] + x[n - 1];
-            p[n - 1] = 1.0 * r[n - 1] + beta * p[n - 1];
+        if (t < n - nv * W) {
+            const int64_t i = nv * W + t;
+            if (x) x[i] = alpha * p[i] + x[i];
+            p[i] = T(1) * r[i] + beta * p[i];
         }
     } else {
         for (int64_t i = t; i < n; i += stride) {
-            x[i] = alpha * p[i] + x[i];
-            p[i] = 1.0 * r[i] + beta * p[i];
+            if (x) x[i] = alpha * p[i] + x[i];
+            p[i] = T(1) * r[i] + beta * p[i];
         }
     }
 }
@@ -368,50 +361,88 @@ CMI_API int cmi_blas_dot_f32(int64_t n, const float *x, const float *y, float *r
 CMI_API int cmi_blas_nrm2_f64(int64_t n, const double *x, double *r, void *ws, void *stream) { return dot_impl<double>(n, x, x, r, ws, stream, 1); }
 CMI_API int cmi_blas_nrm2_f32(int64_t n, const float *x, float *r, void *ws, void *stream) { return dot_impl<float>(n, x, x, r, ws, stream, 1); }
 
-// ---- fused CG steps (f64) ----
-static int fused_grid(int64_t n)
+// ---- fused CG steps ----
+static int fused_grid(int64_t n, int per_thread)
 {
-    int64_t b = ceil_div(n, (int64_t)kBlasBlock * 2);
+    int64_t b = ceil_div(n, (int64_t)kBlasBlock * per_thread);
     if (b > kFusedMaxGrid) b = kFusedMaxGrid;
     return b < 1 ? 1 : (int)b;
 }
 
-CMI_API int cmi_cg_update_f64(int64_t n, const double *rz_dev, const double *yp_dev, const double *p, const double *y,
-                              double *x, double *r, double *rr_dev, double *rr_host_mirror, void *workspace, void *stream)
+namespace {
+
+template <typename T>
+int cg_update_impl(int64_t n, const double *rz_dev, const double *yp_dev, const T *p, const T *y, T *x, T *r, double *rr_dev,
+                   double *rr_host_mirror, void *workspace, void *stream)
 {
     if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_update: negative n");
     if (!rz_dev || !yp_dev || !rr_dev || !workspace) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_update: null scalar or workspace");
     if (n > 0 && (!y || !r || (x && !p))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_update: null array");
-    const int grid = fused_grid(n);
+    const int grid = fused_grid(n, vec16<T>::n);
     const int vec = aligned16(y) && aligned16(r) && (!x || (aligned16(p) && aligned16(x)));
-    hipLaunchKernelGGL(cg_update_kernel, dim3(grid), dim3(kBlasBlock), 0, as_stream(stream), n, rz_dev, yp_dev, p, y, x, r, (double *)workspace, vec);
+    hipLaunchKernelGGL((cg_update_kernel<T>), dim3(grid), dim3(kBlasBlock), 0, as_stream(stream), n, rz_dev, yp_dev, p, y, x, r, (double *)workspace, vec);
     reduce_partials<double>(grid, (double *)workspace, rr_dev, 0, as_stream(stream), rr_host_mirror);
     CMI_LAUNCH_CHECK("cg_update");
     return CMI_SUCCESS;
 }
 
-CMI_API int cmi_cg_direction_f64(int64_t n, const double *rr_new_dev, const double *rr_old_dev, const double *r, double *p,
-                                 void *stream)
+template <typename T>
+int cg_direction_impl(int64_t n, const double *rr_new_dev, const double *rr_old_dev, const double *yp_dev, const T *r, T *p, T *x,
+                      bool with_x, void *stream)
 {
-    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_direction: negative n");
-    if (!rr_new_dev || !rr_old_dev) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_direction: null scalar");
+    const char *who = with_x ? "cmi_cg_direction_x" : "cmi_cg_direction";
+    if (n < 0) { set_error("%s: negative n", who); return CMI_ERROR_INVALID_VALUE; }
+    if (!rr_new_dev || !rr_old_dev || (with_x && !yp_dev)) { set_error("%s: null scalar", who); return CMI_ERROR_INVALID_VALUE; }
     if (n == 0) return CMI_SUCCESS;
-    if (!r || !p) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_direction: null array");
-    const int vec = aligned16(r) && aligned16(p);
-    hipLaunchKernelGGL(cg_direction_kernel, dim3(stream_grid(n, 2)), dim3(kBlasBlock), 0, as_stream(stream), n, rr_new_dev, rr_old_dev, r, p, vec);
+    if (!r || !p || (with_x && !x)) { set_error("%s: null array", who); return CMI_ERROR_INVALID_VALUE; }
+    const int vec = aligned16(r) && aligned16(p) && (!with_x || aligned16(x));
+    hipLaunchKernelGGL((cg_direction_kernel<T>), dim3(stream_grid(n, vec16<T>::n)), dim3(kBlasBlock), 0, as_stream(stream), n, rr_new_dev,
+                       rr_old_dev, yp_dev, r, p, with_x ? x : (T *)nullptr, vec);
     CMI_LAUNCH_CHECK("cg_direction");
     return CMI_SUCCESS;
 }
 
+} // namespace
+
+CMI_API int cmi_cg_update_f64(int64_t n, const double *rz_dev, const double *yp_dev, const double *p, const double *y,
+                              double *x, double *r, double *rr_dev, double *rr_host_mirror, void *workspace, void *stream)
+{
+    return cg_update_impl<double>(n, rz_dev, yp_dev, p, y, x, r, rr_dev, rr_host_mirror, workspace, stream);
+}
+CMI_API int cmi_cg_update_f32(int64_t n, const double *rz_dev, const double *yp_dev, const float *p, const float *y,
+                              float *x, float *r, double *rr_dev, double *rr_host_mirror, void *workspace, void *stream)
+{
+    return cg_update_impl<float>(n, rz_dev, yp_dev, p, y, x, r, rr_dev, rr_host_mirror, workspace, stream);
+}
+CMI_API int cmi_cg_direction_f64(int64_t n, const double *rr_new_dev, const double *rr_old_dev, const double *r, double *p, void *stream)
+{
+    return cg_direction_impl<double>(n, rr_new_dev, rr_old_dev, nullptr, r, p, nullptr, false, stream);
+}
+CMI_API int cmi_cg_direction_f32(int64_t n, const double *rr_new_dev, const double *rr_old_dev, const float *r, float *p, void *stream)
+{
+    return cg_direction_impl<float>(n, rr_new_dev, rr_old_dev, nullptr, r, p, nullptr, false, stream);
+}
 CMI_API int cmi_cg_direction_x_f64(int64_t n, const double *rr_new_dev, const double *rr_old_dev, const double *yp_dev, const double *r,
                                    double *p, double *x, void *stream)
 {
-    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_direction_x: negative n");
-    if (!rr_new_dev || !rr_old_dev || !yp_dev) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_direction_x: null scalar");
-    if (n == 0) return CMI_SUCCESS;
-    if (!r || !p || !x) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_direction_x: null array");
-    const int vec = aligned16(r) && aligned16(p) && aligned16(x);
-    hipLaunchKernelGGL(cg_direction_x_kernel, dim3(stream_grid(n, 2)), dim3(kBlasBlock), 0, as_stream(stream), n, rr_new_dev, rr_old_dev, yp_dev, r, p, x, vec);
-    CMI_LAUNCH_CHECK("cg_direction_x");
+    return cg_direction_impl<double>(n, rr_new_dev, rr_old_dev, yp_dev, r, p, x, true, stream);
+}
+CMI_API int cmi_cg_direction_x_f32(int64_t n, const double *rr_new_dev, const double *rr_old_dev, const double *yp_dev, const float *r,
+                                   float *p, float *x, void *stream)
+{
+    return cg_direction_impl<float>(n, rr_new_dev, rr_old_dev, yp_dev, r, p, x, true, stream);
+}
+
+// <x, y> of float vectors as a DOUBLE in device memory (the scalar type of the fused CG steps)
+CMI_API int cmi_blas_dotd_f32(int64_t n, const float *x, const float *y, double *result_dev, void *workspace, void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_dotd: negative n");
+    if (!result_dev || !workspace) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_dotd: null result or workspace");
+    if (n > 0 && (!x || !y)) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_dotd: null array");
+    const int grid = blas_grid(n, vec16<float>::n);
+    const int vec = aligned16(x) && aligned16(y);
+    hipLaunchKernelGGL((dot_partial_kernel<float>), dim3(grid), dim3(kBlasBlock), 0, as_stream(stream), n, x, y, (double *)workspace, vec);
+    reduce_partials<double>(grid, (double *)workspace, result_dev, 0, as_stream(stream));
+    CMI_LAUNCH_CHECK("dotd");
     return CMI_SUCCESS;
 }

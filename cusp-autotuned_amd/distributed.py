@@ -429,7 +429,7 @@ class ShardedCsr:
                            self.vec.x_local, result, workspace)
             return y_local
         self.multiply(y_local, exchange=exchange)
-        B.blas_dot(y_local, self.vec.x_local, result, workspace)
+        B.blas_dotd(y_local, self.vec.x_local, result, workspace)  # result is a double whatever the vectors' type
         return y_local
 
     def multiply(self, y_local, exchange=True):

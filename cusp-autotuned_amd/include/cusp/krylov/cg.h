@@ -29,7 +29,7 @@ template <typename M, typename X, typename Y> void apply(const M &m, const X &x,
 
 namespace detail {
 
-// Fused unpreconditioned CG on the device (f64): z == r is folded away, alpha and beta stay in device
+// Fused unpreconditioned CG on the device (f64 and f32): z == r is folded away, alpha and beta stay in device
 // memory, and an iteration is
 //     cmi_spmv_csr_dot_f64 (y <- A p and <y,p> in one pass; other formats: SpMV + cmi_blas_dot)
 //     cmi_cg_update_f64      (r, <r,r> in one pass)
@@ -102,28 +102,54 @@ template <typename A, typename V> void multiply_dot(const A &a, const V &p, V &y
     cusp::detail::check(cmi_blas_dot_f64(y.size(), y.data(), p.data(), yp, ws, nullptr));
 }
 
+// the fused steps by value type (scalars are doubles in device memory for both)
+inline int cg_update_(size_t n, const double *rz, const double *yp, const double *y, double *r, double *rr, double *mirror, void *ws)
+{ return cmi_cg_update_f64(n, rz, yp, nullptr, y, nullptr, r, rr, mirror, ws, nullptr); }
+inline int cg_update_(size_t n, const double *rz, const double *yp, const float *y, float *r, double *rr, double *mirror, void *ws)
+{ return cmi_cg_update_f32(n, rz, yp, nullptr, y, nullptr, r, rr, mirror, ws, nullptr); }
+inline int cg_direction_x_(size_t n, const double *rn, const double *ro, const double *yp, const double *r, double *p, double *x)
+{ return cmi_cg_direction_x_f64(n, rn, ro, yp, r, p, x, nullptr); }
+inline int cg_direction_x_(size_t n, const double *rn, const double *ro, const double *yp, const float *r, float *p, float *x)
+{ return cmi_cg_direction_x_f32(n, rn, ro, yp, r, p, x, nullptr); }
+inline int dotd_(size_t n, const double *x, const double *y, double *res, void *ws) { return cmi_blas_dot_f64(n, x, y, res, ws, nullptr); }
+inline int dotd_(size_t n, const float *x, const float *y, double *res, void *ws) { return cmi_blas_dotd_f32(n, x, y, res, ws, nullptr); }
+
+// y <- A p and *yp <- <y, p> for either value type: f64 matrices fuse the dot into the SpMV where the format can,
+// f32 runs the SpMV and a dot that accumulates in double
+template <typename A, typename V> void multiply_dot_any(const A &a, const V &p, V &y, double *yp, void *ws, std::true_type /* double */)
+{
+    multiply_dot(a, p, y, yp, ws, 0);
+}
+template <typename A, typename V> void multiply_dot_any(const A &a, const V &p, V &y, double *yp, void *ws, std::false_type /* float */)
+{
+    cusp::multiply(a, p, y);
+    cusp::detail::check(dotd_(y.size(), y.data(), p.data(), yp, ws));
+}
+
 template <typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor>
 void cg_fused_device(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &monitor)
 {
+    typedef typename LinearOperator::value_type T;
     const size_t N = A.num_rows;
-    cusp::array1d<double, cusp::device_memory> y(N), r(N), p(N), scalars(3); // scalars: rr[0], rr[1], <y,p>
+    cusp::array1d<T, cusp::device_memory> y(N), r(N), p(N);
+    cusp::array1d<double, cusp::device_memory> scalars(3); // rr[0], rr[1], <y,p>
     cusp::blas::detail::device_workspace &w = cusp::blas::detail::workspace();
     double *rr[2] = {scalars.data(), scalars.data() + 1};
     double *yp = scalars.data() + 2;
     pinned_scalar rr_host;
     cusp::multiply(A, x, y);
-    cusp::blas::axpby(b, y, r, 1.0, -1.0);
+    cusp::blas::axpby(b, y, r, T(1), T(-1));
     cusp::blas::copy(r, p);
-    cusp::detail::check(cmi_blas_dot_f64(N, r.data(), r.data(), rr[0], w.ws, nullptr));
+    cusp::detail::check(dotd_(N, r.data(), r.data(), rr[0], w.ws));
     rr_host.fetch(rr[0]);
     int cur = 0;
     for (;;) {
-        multiply_dot(A, p, y, yp, w.ws, 0);                                               // the hot path (speculative, see above)
-        if (monitor.finished_norm(std::sqrt(rr_host.wait()))) break;                      // the one host read
-        cusp::detail::check(cmi_cg_update_f64(N, rr[cur], yp, nullptr, y.data(), nullptr, r.data(), rr[cur ^ 1], rr_host.host, w.ws, nullptr));
+        multiply_dot_any(A, p, y, yp, w.ws, std::is_same<T, double>());                   // the hot path (speculative, see above)
+        if (monitor.finished_norm(static_cast<typename Monitor::Real>(std::sqrt(rr_host.wait())))) break; // the one host read
+        cusp::detail::check(cg_update_(N, rr[cur], yp, y.data(), r.data(), rr[cur ^ 1], rr_host.host, w.ws));
         rr_host.record();
         // x <- x + alpha p rides with the direction pass (it reads p anyway): 8 vector passes per iteration, not 9
-        cusp::detail::check(cmi_cg_direction_x_f64(N, rr[cur ^ 1], rr[cur], yp, r.data(), p.data(), x.data(), nullptr));
+        cusp::detail::check(cg_direction_x_(N, rr[cur ^ 1], rr[cur], yp, r.data(), p.data(), x.data()));
         cur ^= 1;
         ++monitor;
     }
@@ -131,9 +157,10 @@ void cg_fused_device(const LinearOperator &A, VectorType1 &x, const VectorType2 
 }
 
 template <typename A, typename X, typename M, typename Mon> struct use_fused {
+    typedef typename A::value_type T;
     static const bool value = std::is_same<typename A::memory_space, cusp::device_memory>::value &&
-                              std::is_same<typename A::value_type, double>::value && std::is_same<typename X::value_type, double>::value &&
-                              std::is_same<M, cusp::identity_operator<double, cusp::device_memory>>::value &&
+                              (std::is_same<T, double>::value || std::is_same<T, float>::value) && std::is_same<typename X::value_type, T>::value &&
+                              std::is_same<M, cusp::identity_operator<T, cusp::device_memory>>::value &&
                               decltype(has_finished_norm(static_cast<Mon *>(nullptr)))::value;
 };
 

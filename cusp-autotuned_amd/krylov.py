@@ -54,7 +54,7 @@ class _Ops:
         self.group, self.world = group, world
 
     def dot(self, x, y):
-        self.B.blas_dot(x, y, self.res, self.ws)
+        self.B.blas_dotd(x, y, self.res, self.ws)  # a double in device memory, f64 or f32 vectors
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.res, group=self.group)
@@ -70,8 +70,8 @@ def cg(A, x, b, monitor=None, iteration_limit=500, relative_tolerance=1e-5, abso
     distributed.ShardedCsr (x, b = this rank's slices).  x holds the initial guess and the result.
     Returns the Monitor (residual history in .residuals).
 
-    fused=True (default, f64): the unpreconditioned iteration runs as SpMV(+dot) + cmi_cg_update +
-    cmi_cg_direction with alpha / beta kept in device memory -- 3 vector passes and ONE host read per
+    fused=True (default; f64 and f32): the unpreconditioned iteration runs as SpMV(+dot) + cmi_cg_update +
+    cmi_cg_direction_x with alpha / beta kept in device memory (as doubles) -- 3-4 launches and ONE host read per
     iteration (the convergence check, hidden behind the next SpMV) instead of the reference's 7 passes
     and 3 host syncs; the per-element arithmetic is unchanged.  fused=False replays cg.inl operation
     by operation."""
@@ -88,7 +88,9 @@ def cg(A, x, b, monitor=None, iteration_limit=500, relative_tolerance=1e-5, abso
     if monitor is None:
         monitor = Monitor(ops.nrm2(b), iteration_limit, relative_tolerance, absolute_tolerance)
 
-    y = torch.empty(n, dtype=torch.float64, device=dev)
+    if x.dtype not in (torch.float64, torch.float32) or b.dtype != x.dtype:
+        raise TypeError(f"cg: x and b must both be float64 or float32 device vectors, got {x.dtype} / {b.dtype}")
+    y = torch.empty(n, dtype=x.dtype, device=dev)
     z = torch.empty_like(y)
     r = torch.empty_like(y)
     # the search direction lives in the exchange buffer when sharded: A p needs no staging copy
@@ -108,7 +110,7 @@ def cg(A, x, b, monitor=None, iteration_limit=500, relative_tolerance=1e-5, abso
         else:
             multiply(A, v, out)
 
-    if fused and x.dtype == torch.float64:
+    if fused:
         return _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group)
 
     spmv(x, y)                                   # y <- A x            (cg.inl:63)
@@ -165,8 +167,12 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
             dist.all_reduce(t, group=group)
 
     def spmv_dot():                              # y <- A p, yp <- <y, p>
+        f64 = p.dtype == torch.float64          # the SpMV kernels fuse the dot for f64; f32: SpMV, then a dot into a double
         if isinstance(A, ShardedCsr):
             A.multiply_dot(y, yp, ops.ws)        # p IS A.x_local
+        elif not f64:
+            spmv(p, y)
+            B.blas_dotd(y, p, yp, ops.ws)
         elif isinstance(A, CsrMatrix):
             B.spmv_csr_dot(A.num_rows, A.num_cols, A.row_offsets, A.column_indices, A.values, p, y, p, yp, ops.ws)
         elif isinstance(A, EllMatrix):
@@ -176,7 +182,7 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
             B.spmv_dia_dot(A.num_rows, A.num_cols, A.diagonal_offsets.numel(), A.pitch, A.diagonal_offsets, A.values, p, y, p, yp, ops.ws)
         else:
             spmv(p, y)
-            B.blas_dot(y, p, yp, ops.ws)
+            B.blas_dotd(y, p, yp, ops.ws)
         reduce_(yp)
 
     # One-sided sharding ("peer" exchange): p is exchanged ONCE.  Afterwards every rank keeps the p
@@ -204,7 +210,7 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
     if one_sided:
         A.vec.fence()                            # (setup) the peers have pulled x out of the buffer p reuses
     B.blas_copy(r, p)                            # p <- z = r
-    B.blas_dot(r, r, rr[0], ops.ws)              # rz = <r, r>
+    B.blas_dotd(r, r, rr[0], ops.ws)             # rz = <r, r>
     reduce_(rr[0])
     if one_sided:
         A.vec.exchange()                         # p halos, ordered behind every rank's copy by the all-reduce

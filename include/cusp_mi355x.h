@@ -363,6 +363,16 @@ int cmi_cg_direction_f64(int64_t n, const double *rr_new_dev, const double *rr_o
  * iteration.  Same expressions, same bits as the two calls above. */
 int cmi_cg_direction_x_f64(int64_t n, const double *rr_new_dev, const double *rr_old_dev, const double *yp_dev,
                            const double *r, double *p, double *x, void *stream);
+/* The same steps on float vectors.  The scalars stay DOUBLES in device memory (every reduction here accumulates in
+ * double); alpha and beta are rounded to float once per kernel and the vectors are updated in float, as the reference's
+ * float CG does (cg.inl with ValueType = float).  cmi_blas_dotd_f32: <x, y> of float vectors as such a double. */
+int cmi_cg_update_f32(int64_t n, const double *rz_dev, const double *yp_dev, const float *p, const float *y,
+                      float *x, float *r, double *rr_dev, double *rr_host_mirror, void *workspace, void *stream);
+int cmi_cg_direction_f32(int64_t n, const double *rr_new_dev, const double *rr_old_dev, const float *r,
+                         float *p, void *stream);
+int cmi_cg_direction_x_f32(int64_t n, const double *rr_new_dev, const double *rr_old_dev, const double *yp_dev,
+                           const float *r, float *p, float *x, void *stream);
+int cmi_blas_dotd_f32(int64_t n, const float *x, const float *y, double *result_dev, void *workspace, void *stream);
 
 #ifdef __cplusplus
 }

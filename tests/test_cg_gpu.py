@@ -75,6 +75,41 @@ def test_cg_fused_equals_plain_large(cmi):
     assert float((hist[True][1] - hist[False][1]).abs().max()) <= 1e-9 * float(hist[False][1].abs().max())
 
 
+@pytest.mark.parametrize("fmt", ["csr", "ell", "dia", "coo"])
+def test_cg_float32(cmi, fmt):
+    """float matrices and vectors (the reference's testing/cg.cu protocol is float): the fused driver (cmi_cg_update_f32 /
+    cmi_cg_direction_x_f32, scalars kept as doubles on the device) and the plain cg.inl replay follow the f64 history to
+    float rounding, reproduce the quickstart trace, and agree on x."""
+    import torch
+    A32 = cmi.poisson5pt(10, 10, fmt, dtype=torch.float32) if fmt in ("csr", "dia") else cmi.convert(cmi.poisson5pt(10, 10, "csr", dtype=torch.float32), fmt)
+    for fused in (True, False):
+        x = torch.zeros(100, dtype=torch.float32, device="cuda")
+        b = torch.ones(100, dtype=torch.float32, device="cuda")
+        mon = cmi.krylov.cg(A32, x, b, iteration_limit=100, relative_tolerance=1e-3, fused=fused)
+        assert mon.converged() and mon.iteration_count == 12
+        for got, want in zip(mon.residuals, QUICKSTART_TRACE):
+            assert abs(got - want) <= 5e-4 * want + 1e-6
+    m, n = 300, 200
+    A64 = cmi.poisson5pt(m, n, "csr")
+    A32 = cmi.poisson5pt(m, n, "csr", dtype=torch.float32)
+    if fmt != "csr":
+        A32 = cmi.poisson5pt(m, n, "dia", dtype=torch.float32) if fmt == "dia" else cmi.convert(A32, fmt)
+    b64 = cmi.fill_x(m * n, device="cuda")
+    x64 = torch.zeros(m * n, dtype=torch.float64, device="cuda")
+    h64 = cmi.krylov.cg(A64, x64, b64, iteration_limit=40, relative_tolerance=1e-30).residuals
+    out = {}
+    for fused in (True, False):
+        x = torch.zeros(m * n, dtype=torch.float32, device="cuda")
+        mon = cmi.krylov.cg(A32, x, b64.float(), iteration_limit=40, relative_tolerance=1e-30, fused=fused)
+        assert len(mon.residuals) == len(h64) == 41
+        assert np.allclose(mon.residuals, h64, rtol=2e-3), (fused, mon.residuals[-1], h64[-1])
+        out[fused] = x
+    assert float((out[True] - out[False]).abs().max()) <= 1e-4 * float(out[False].abs().max())
+    assert float((out[True].double() - x64).abs().max()) <= 1e-3 * float(x64.abs().max())
+    with pytest.raises(TypeError):
+        cmi.krylov.cg(A32, torch.zeros(m * n, dtype=torch.float32, device="cuda"), b64)  # mixed types
+
+
 @pytest.mark.parametrize("fmt", ["csr", "ell", "dia", "coo", "hyb"])
 def test_cg_every_format_larger_grid(cmi, orc, fmt):
     import torch
