@@ -536,6 +536,13 @@ def test_long_rows_streamed_by_the_workgroup(cmi, torch_cuda, orc, tag):
     y = torch.full((rows,), 10.0, dtype=tdt, device="cuda")
     cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, cfg=cmi.Config(kernel=cmi.CSR_STREAM, threads_per_row=1))
     assert np.array_equal(host(y), want)
+    # the streamed rows are re-associated but deterministic (fixed fold order: lanes, then waves): same bits every time
+    ya = torch.full((rows,), 10.0, dtype=tdt, device="cuda")
+    cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, ya)
+    for _ in range(20):
+        yb = torch.full((rows,), -1.0, dtype=tdt, device="cuda")
+        cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, yb)
+        assert torch.equal(ya, yb)
     if tag == "f64":  # the fused dot runs the same instances: y identical to the plain call, dot within rounding
         wv = dev(rng.standard_normal(rows), torch)
         res = torch.zeros(1, dtype=torch.float64, device="cuda")
