@@ -38,6 +38,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver of this pool only supports dmabuf IPC (needed by RCCL and by the one-sided exchange's buffer mapping);
+# normally exported already -- set before the HIP runtime is loaded in case it is not
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 M = 3162  # grid side: 3162^2 = 9 998 244 rows per GPU
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
