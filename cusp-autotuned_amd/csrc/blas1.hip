@@ -132,8 +132,18 @@ dot_fold_final_kernel(int npartial, double *__restrict__ workspace, T *__restric
     double *folded = workspace + kPartialCapacity;
     const int lo = blockIdx.x * kFoldChunk;
     const int hi = lo + kFoldChunk < npartial ? lo + kFoldChunk : npartial;
+    // kFoldChunk / kBlasBlock = 4 partials per lane: all four loads in flight at once (a plain loop pays four
+    // dependent round trips -- half of this kernel's 6 us), added in the loop's order
+    static_assert(kFoldChunk == 4 * kBlasBlock, "the fold reads four partials per lane");
+    double v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = lo + (int)threadIdx.x + k * kBlasBlock;
+        v[k] = i < hi ? partial[i] : 0.0;
+    }
     double acc = 0.0;
-    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += partial[i];
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc += v[k];
     double s = block_sum(acc, slots);
     if (threadIdx.x == 0) {
         __hip_atomic_store(folded + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
