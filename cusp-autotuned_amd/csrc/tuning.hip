@@ -251,9 +251,21 @@ void select_config(int format, int dtype, int64_t rows, int64_t cols, int64_t nn
         std::lock_guard<std::mutex> lk(g_mu);
         ensure_default_loaded();
         const int b = bucket_of(mean);
-        if (format >= 0 && format < CMI_FORMAT_COUNT && g_table.valid[format][dtype][b])
+        if (format >= 0 && format < CMI_FORMAT_COUNT && g_table.valid[format][dtype][b]) {
             *out = g_table.cfg[format][dtype][b];
-        else
+            // A table entry was tuned at ONE mean row length of its bucket [2^b, 2^(b+1)); its rows per tile is scaled
+            // to this matrix so that a tile's entries still fit one LDS pass (176 rows of 5 fit 1024 slots, 176 rows
+            // of 7 do not: the tile would fall off the single-pass path -- 25.3 vs 21.8 us on a 1.2M-row
+            // unstructured FEM matrix, tools/unstructured_probe.py).  Never enlarged, whole y lines kept.
+            if (format == CMI_FORMAT_CSR && out->kernel == CMI_CSR_STREAM && out->rows_per_block > 0 && mean > 0.0) {
+                const int blk = round_block(out->block_size);
+                const int ipt = out->items_per_thread <= 1 ? 1 : out->items_per_thread <= 2 ? 2 : 4;
+                double fit = std::floor((double)((int64_t)blk * ipt * 4 - 3) / mean);
+                if (fit >= 32.0) fit = std::floor(fit / 16.0) * 16.0;
+                if (fit < 1.0) fit = 1.0;
+                if ((double)out->rows_per_block > fit) out->rows_per_block = (int)fit;
+            }
+        } else
             heuristic(format, dtype, mean, out);
         if (user) { // AUTO kernel but explicit launch-shape overrides
             if (user->block_size) out->block_size = user->block_size;

@@ -146,6 +146,13 @@ def test_tuning_heuristics_and_table_roundtrip(cmi, tmp_path):
     assert cmi.tuning_select(cmi.FORMAT_DIA, cmi.F64, 100, 100, 500).kernel == cmi.DIA_ROW
     assert cmi.tuning_select(cmi.FORMAT_COO, cmi.F64, 100, 100, 500).kernel == cmi.COO_LANE4
 
+    # a table entry is scaled to the matrix: rows per tile shrink (never grow) until a tile's entries fit one LDS pass
+    cmi.tuning_set(cmi.FORMAT_CSR, cmi.F64, 5.0, cmi.Config(kernel=cmi.CSR_STREAM, block_size=256, rows_per_block=176, items_per_thread=1))
+    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 5000).rows_per_block == 176      # 176 x 5 = 880 <= 1021
+    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 7000).rows_per_block == 144      # 144 x 7 = 1008
+    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 7990).rows_per_block == 112      # 127 -> whole y lines
+    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 4100).rows_per_block == 176      # never enlarged
+    cmi.tuning_clear()
     # persist an override, clear, reload: the selection follows the table
     cfg = cmi.Config(kernel=cmi.CSR_VECTOR, block_size=128, threads_per_row=4, nontemporal=1)
     cmi.tuning_set(cmi.FORMAT_CSR, cmi.F64, 4.99, cfg)
