@@ -24,6 +24,7 @@ constexpr int kBuckets = 8; // mean entries/row in [2^b, 2^(b+1)), last bucket o
 struct Table {
     cmi_config cfg[CMI_FORMAT_COUNT][2][kBuckets];
     bool valid[CMI_FORMAT_COUNT][2][kBuckets];
+    double mean[CMI_FORMAT_COUNT][2][kBuckets]; // mean entries per row of the matrix the entry was tuned on (0: unknown)
 };
 
 static Table g_table;
@@ -150,6 +151,21 @@ static bool find_int(const std::string &obj, const char *key, long *out)
     return true;
 }
 
+static bool find_double(const std::string &obj, const char *key, double *out)
+{
+    std::string k = std::string("\"") + key + "\"";
+    size_t p = obj.find(k);
+    if (p == std::string::npos) return false;
+    p = obj.find(':', p + k.size());
+    if (p == std::string::npos) return false;
+    char *end = nullptr;
+    const char *s = obj.c_str() + p + 1;
+    const double v = std::strtod(s, &end);
+    if (end == s) return false;
+    *out = v;
+    return true;
+}
+
 static bool find_str(const std::string &obj, const char *key, std::string *out)
 {
     std::string k = std::string("\"") + key + "\"";
@@ -203,8 +219,11 @@ static int load_file(const char *path)
                 if (find_int(obj, "nontemporal", &v)) c.nontemporal = (int)v;
                 if (find_int(obj, "xcd_swizzle", &v)) c.xcd_swizzle = (int)v;
                 if (find_int(obj, "blocks_per_cu", &v)) c.blocks_per_cu = (int)v;
+                double tuned_mean = 0.0;
+                if (!find_double(obj, "mean", &tuned_mean) || !(tuned_mean > 0.0)) tuned_mean = 0.0;
                 g_table.cfg[fi][di][bucket] = c;
                 g_table.valid[fi][di][bucket] = true;
+                g_table.mean[fi][di][bucket] = tuned_mean;
                 loaded++;
             }
         }
@@ -253,17 +272,26 @@ void select_config(int format, int dtype, int64_t rows, int64_t cols, int64_t nn
         const int b = bucket_of(mean);
         if (format >= 0 && format < CMI_FORMAT_COUNT && g_table.valid[format][dtype][b]) {
             *out = g_table.cfg[format][dtype][b];
-            // A table entry was tuned at ONE mean row length of its bucket [2^b, 2^(b+1)); its rows per tile is scaled
-            // to this matrix so that a tile's entries still fit one LDS pass (176 rows of 5 fit 1024 slots, 176 rows
-            // of 7 do not: the tile would fall off the single-pass path -- 25.3 vs 21.8 us on a 1.2M-row
-            // unstructured FEM matrix, tools/unstructured_probe.py).  Never enlarged, whole y lines kept.
+            // A table entry was tuned at ONE mean row length of its bucket [2^b, 2^(b+1)); its rows per tile are scaled
+            // to this matrix so that a tile keeps the tuned fill of the LDS pass: 176 rows of 5 fill 86 % of 1024 slots,
+            // 176 rows of 7 would overflow the pass and fall off the single-pass path (25.3 vs 22.6 us on a 1.2M-row
+            // unstructured FEM matrix), 64 rows of 16.5 where 64 rows of 26.6 were tuned leave half of it empty (20.1 vs
+            // 17.6 us on a tetrahedral mesh; tools/unstructured_probe.py, tools/tet_mesh_probe.py).  Whole y lines kept;
+            // an entry without a recorded mean is only ever shrunk to fit.
             if (format == CMI_FORMAT_CSR && out->kernel == CMI_CSR_STREAM && out->rows_per_block > 0 && mean > 0.0) {
                 const int blk = round_block(out->block_size);
                 const int ipt = out->items_per_thread <= 1 ? 1 : out->items_per_thread <= 2 ? 2 : 4;
+                const int tpr = out->threads_per_row <= 1 ? 1 : out->threads_per_row;
                 double fit = std::floor((double)((int64_t)blk * ipt * 4 - 3) / mean);
-                if (fit >= 32.0) fit = std::floor(fit / 16.0) * 16.0;
-                if (fit < 1.0) fit = 1.0;
-                if ((double)out->rows_per_block > fit) out->rows_per_block = (int)fit;
+                const double max_rows = 4.0 * (blk / tpr);
+                if (fit > max_rows) fit = max_rows;
+                double want = (double)out->rows_per_block;
+                const double tuned_mean = g_table.mean[format][dtype][b];
+                if (tuned_mean > 0.0) want = std::floor(want * tuned_mean / mean + 0.5);
+                if (want > fit) want = fit;
+                if (want >= 32.0) want = std::floor(want / 16.0) * 16.0;
+                if (want < 1.0) want = 1.0;
+                out->rows_per_block = (int)want;
             }
         } else
             heuristic(format, dtype, mean, out);
@@ -304,10 +332,11 @@ CMI_API int cmi_tuning_save(const char *path)
                 std::fprintf(f,
                              "%s    {\"format\": \"%s\", \"dtype\": \"%s\", \"bucket\": %d, \"kernel\": %d, "
                              "\"block_size\": %d, \"threads_per_row\": %d, \"rows_per_block\": %d, "
-                             "\"items_per_thread\": %d, \"nontemporal\": %d, \"xcd_swizzle\": %d, \"blocks_per_cu\": %d}",
+                             "\"items_per_thread\": %d, \"nontemporal\": %d, \"xcd_swizzle\": %d, \"blocks_per_cu\": %d, "
+                             "\"mean\": %.4f}",
                              first ? "" : ",\n", kFormatNames[fi], kDtypeNames[di], b, c.kernel, c.block_size,
                              c.threads_per_row, c.rows_per_block, c.items_per_thread, c.nontemporal, c.xcd_swizzle,
-                             c.blocks_per_cu);
+                             c.blocks_per_cu, g_table.mean[fi][di][b]);
                 first = false;
             }
     std::fprintf(f, "\n  ]\n}\n");
@@ -331,6 +360,7 @@ CMI_API int cmi_tuning_set(int format, int dtype, double mean_entries_per_row, c
     const int b = bucket_of(mean_entries_per_row);
     g_table.cfg[format][dtype][b] = *cfg;
     g_table.valid[format][dtype][b] = true;
+    g_table.mean[format][dtype][b] = mean_entries_per_row > 0.0 ? mean_entries_per_row : 0.0;
     return CMI_SUCCESS;
 }
 

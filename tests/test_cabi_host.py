@@ -146,12 +146,19 @@ def test_tuning_heuristics_and_table_roundtrip(cmi, tmp_path):
     assert cmi.tuning_select(cmi.FORMAT_DIA, cmi.F64, 100, 100, 500).kernel == cmi.DIA_ROW
     assert cmi.tuning_select(cmi.FORMAT_COO, cmi.F64, 100, 100, 500).kernel == cmi.COO_LANE4
 
-    # a table entry is scaled to the matrix: rows per tile shrink (never grow) until a tile's entries fit one LDS pass
+    # a table entry is scaled to the matrix: rows per tile follow tuned_rows * tuned_mean / mean (the tuned fill of the LDS
+    # pass), capped by what fits one pass, whole y lines kept
     cmi.tuning_set(cmi.FORMAT_CSR, cmi.F64, 5.0, cmi.Config(kernel=cmi.CSR_STREAM, block_size=256, rows_per_block=176, items_per_thread=1))
-    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 5000).rows_per_block == 176      # 176 x 5 = 880 <= 1021
-    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 7000).rows_per_block == 144      # 144 x 7 = 1008
-    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 7990).rows_per_block == 112      # 127 -> whole y lines
-    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 4100).rows_per_block == 176      # never enlarged
+    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 5000).rows_per_block == 176      # the tuned mean: as tuned
+    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 7000).rows_per_block == 112      # 176 * 5/7 = 126 -> 112
+    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 7990).rows_per_block == 96       # 110 -> 96 (fits: 767)
+    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 4100).rows_per_block == 208      # 215 -> 208 (fits: 853)
+    path2 = str(tmp_path / "means.json")
+    cmi.tuning_save(path2)
+    assert json.load(open(path2))["entries"][0]["mean"] == 5.0
+    cmi.tuning_clear()
+    cmi.tuning_load(path2)                                                                          # the mean survives the file
+    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 7000).rows_per_block == 112
     cmi.tuning_clear()
     # persist an override, clear, reload: the selection follows the table
     cfg = cmi.Config(kernel=cmi.CSR_VECTOR, block_size=128, threads_per_row=4, nontemporal=1)
