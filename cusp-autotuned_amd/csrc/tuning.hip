@@ -287,8 +287,10 @@ void select_config(int format, int dtype, int64_t rows, int64_t cols, int64_t nn
                 if (fit > max_rows) fit = max_rows;
                 double want = (double)out->rows_per_block;
                 const double tuned_mean = g_table.mean[format][dtype][b];
+                const bool one_row_per_lane = out->rows_per_block <= blk / tpr; // the tuned shape's regime: keep it
                 if (tuned_mean > 0.0) want = std::floor(want * tuned_mean / mean + 0.5);
                 if (want > fit) want = fit;
+                if (one_row_per_lane && want > (double)(blk / tpr)) want = (double)(blk / tpr);
                 if (want >= 32.0) want = std::floor(want / 16.0) * 16.0;
                 if (want < 1.0) want = 1.0;
                 out->rows_per_block = (int)want;
