@@ -113,6 +113,7 @@ def _declare(L):
     L.cmi_poisson5pt_shard_entries.restype = c_int64
     L.cmi_poisson5pt_shard_entries.argtypes = [i64, i64, i64, i64]
     L.cmi_csr_row_indices.argtypes = [i64, vp, vp, vp]
+    L.cmi_coo_row_offsets.argtypes = [i64, i64, vp, vp, POINTER(ctypes.c_int), vp]
     L.cmi_csr_max_row_length.argtypes = [i64, vp, POINTER(c_int64), vp]
     L.cmi_csr_diagonals.argtypes = [i64, i64, vp, vp, vp, vp, i64, POINTER(c_int64), vp]
     for suf in ("f64", "f32"):
@@ -613,3 +614,14 @@ def blas_dotd(x, y, result, workspace, stream=None):
         check(lib().cmi_blas_dot_f64(x.numel(), _ptr(x), _ptr(y), _ptr(result), _ptr(workspace), _stream(stream)))
     else:
         check(lib().cmi_blas_dotd_f32(x.numel(), _ptr(x), _ptr(y), _ptr(result), _ptr(workspace), _stream(stream)))
+
+
+def coo_row_offsets(num_rows, Ai, Ap, stream=None):
+    """Ap[num_rows + 1] <- row offsets of row-sorted COO row indices (device); returns False (Ap unspecified) when the
+    entries turn out not to be sorted by row."""
+    import torch
+    _need(Ai, "Ai", torch.int32)
+    _need(Ap, "Ap", torch.int32)
+    ok = ctypes.c_int(0)
+    check(lib().cmi_coo_row_offsets(num_rows, Ai.numel(), _ptr(Ai), _ptr(Ap), byref(ok), _stream(stream)))
+    return bool(ok.value)

@@ -347,6 +347,46 @@ CMI_API int cmi_csr_row_indices(int64_t num_rows, const int32_t *Ap, int32_t *Ai
     return CMI_SUCCESS;
 }
 
+// Row offsets of a row-sorted COO matrix: entry e with row r closes the offsets of every row in (row of entry e-1, r]
+// at e; the thread past the last entry closes the rest at num_entries.  Also the order check: *unsorted != 0 afterwards
+// means some row index was smaller than its predecessor (or out of range) and Ap is not to be used.
+namespace cmi {
+__global__ void __launch_bounds__(256)
+coo_row_offsets_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ Ai, int *__restrict__ Ap, int *__restrict__ unsorted)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e <= num_entries; e += stride) {
+        const int64_t prev = e > 0 ? Ai[e - 1] : -1;
+        const int64_t cur = e < num_entries ? Ai[e] : num_rows;
+        if (cur < prev || cur < 0 || cur > num_rows || (e < num_entries && cur >= num_rows)) { atomicOr(unsorted, 1); continue; }
+        const int64_t hi = e < num_entries ? cur : num_rows; // rows (prev, hi] start at e (the last thread: rows beyond the last entry, and Ap[num_rows])
+        for (int64_t r = prev + 1; r <= hi; r++) Ap[r] = (int)e;
+    }
+}
+} // namespace cmi
+
+CMI_API int cmi_coo_row_offsets(int64_t num_rows, int64_t num_entries, const int32_t *Ai, int32_t *Ap, int *sorted_host, void *stream)
+{
+    if (num_rows < 0 || num_entries < 0 || num_entries > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_coo_row_offsets: bad size");
+    if (!Ap || !sorted_host || (num_entries > 0 && !Ai)) return fail(CMI_ERROR_INVALID_VALUE, "cmi_coo_row_offsets: null array");
+    *sorted_host = 0;
+    hipStream_t s = as_stream(stream);
+    int *flag = nullptr;
+    CMI_HIP(hipMalloc((void **)&flag, sizeof(int)));
+    int host = 1;
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(coo_row_offsets_kernel, dim3(grid_1d(num_entries + 1)), dim3(256), 0, s, num_rows, num_entries, Ai, Ap, flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&host, flag, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(flag);
+    if (e != hipSuccess) return hip_fail(e, "cmi_coo_row_offsets");
+    *sorted_host = host == 0;
+    return CMI_SUCCESS;
+}
+
 CMI_API int cmi_ell_row_lengths(int64_t num_rows, int64_t width, int64_t pitch, const int32_t *ell_Aj,
                                 int32_t *row_lengths, void *stream)
 {

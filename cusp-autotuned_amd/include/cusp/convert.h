@@ -388,6 +388,25 @@ struct device_fast_path<csr_matrix<int, V, device_memory>, coo_matrix<int, V, de
     }
 };
 
+// device COO (row-sorted, the container's contract: cusp/coo_matrix.h:72) -> device CSR: the offsets from the row indices
+// in one pass with the order checked on the way; unsorted entries take the general (host) path, which sorts
+template <typename V>
+struct device_fast_path<coo_matrix<int, V, device_memory>, csr_matrix<int, V, device_memory>, coo_format, csr_format> {
+    static bool run(const coo_matrix<int, V, device_memory> &s, csr_matrix<int, V, device_memory> &d)
+    {
+        array1d<int, device_memory> offsets(s.num_rows + 1);
+        int sorted = 0;
+        check(cmi_coo_row_offsets(s.num_rows, s.num_entries, s.row_indices.data(), offsets.data(), &sorted, nullptr));
+        if (!sorted) return false;
+        d.resize(s.num_rows, s.num_cols, s.num_entries);
+        d.row_offsets = offsets;
+        d.column_indices = s.column_indices;
+        d.values = s.values;
+        check(cmi_stream_synchronize(nullptr));
+        return true;
+    }
+};
+
 inline int csr_to_hyb_coo_device(int64_t rows, const int *Ap, const int *Aj, const double *Ax, int64_t w, const int *off, int *cAi, int *cAj, double *cAx)
 { return cmi_csr_to_hyb_coo_f64(rows, Ap, Aj, Ax, w, off, cAi, cAj, cAx, nullptr); }
 inline int csr_to_hyb_coo_device(int64_t rows, const int *Ap, const int *Aj, const float *Ax, int64_t w, const int *off, int *cAi, int *cAj, float *cAx)

@@ -132,12 +132,20 @@ def poisson5pt(m, n, fmt="csr", dtype=None, device="cuda", row_begin=0, row_end=
 
 
 def convert(csr, fmt, num_entries_per_row=None, ell_alignment=32):
-    """CSR -> {coo, ell, hyb, dia} on the device (reference conversions/csr_to_other.h:56-306).
+    """CSR -> {coo, ell, hyb, dia} and row-sorted COO -> CSR on the device (reference conversions/csr_to_other.h:56-306,
+    coo_to_other.h).
     For ELL the width defaults to the longest row; for HYB pass num_entries_per_row (the reference's
     compute_optimal_entries_per_row heuristic lives in the C++ layer / oracle)."""
     import torch
+    if isinstance(csr, CooMatrix) and fmt == "csr":
+        # row-sorted COO -> CSR on the device: the offsets from the row indices in one pass (order checked on the way)
+        coo = csr
+        Ap = torch.empty(coo.num_rows + 1, dtype=torch.int32, device=coo.values.device)
+        if not B.coo_row_offsets(coo.num_rows, coo.row_indices, Ap):
+            raise ValueError("convert: the COO entries are not sorted by row (cusp/coo_matrix.h:72 requires it); sort them first")
+        return CsrMatrix(coo.num_rows, coo.num_cols, coo.num_entries, Ap, coo.column_indices, coo.values)
     if not isinstance(csr, CsrMatrix):
-        raise TypeError("convert: source must be a CsrMatrix")
+        raise TypeError("convert: source must be a CsrMatrix (or a CooMatrix for fmt='csr')")
     dev = csr.values.device
     if fmt == "csr":
         return csr

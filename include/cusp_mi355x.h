@@ -314,6 +314,11 @@ int cmi_csr_to_dia_f32(int64_t num_rows, int64_t num_cols, const int32_t *Ap, co
                        float *values, void *stream);
 /* CSR -> COO row indices (offsets_to_indices, csr_to_other.h:56-70). */
 int cmi_csr_row_indices(int64_t num_rows, const int32_t *Ap, int32_t *Ai, void *stream);
+/* The way back for ROW-SORTED entries (coo -> csr on the device; reference: cusp/system/detail/generic/conversions/
+ * coo_to_other.h, which sorts first and then builds the offsets with lower_bound): Ap[num_rows + 1] from the row indices
+ * in one pass, with the order checked on the way.  *sorted_host == 0 afterwards: the entries were not sorted by row (or a
+ * row index was out of range) and Ap is unspecified -- the caller sorts, or converts on the host.  Synchronises the stream. */
+int cmi_coo_row_offsets(int64_t num_rows, int64_t num_entries, const int32_t *Ai, int32_t *Ap, int *sorted_host, void *stream);
 /* ELL -> per-row length of the leading valid run (cusp/ktt/detail/ellr_matrix.inl:16-53). */
 int cmi_ell_row_lengths(int64_t num_rows, int64_t width, int64_t pitch, const int32_t *ell_Aj,
                         int32_t *row_lengths, void *stream);

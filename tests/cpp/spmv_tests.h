@@ -278,6 +278,47 @@ template <typename Space> void TestCsrToDiaMatchesHostConversion()
 }
 DECLARE_SPACE_UNITTEST(TestCsrToDiaMatchesHostConversion);
 
+// COO -> CSR in the matrix's own memory space: row-sorted entries take the device pass (cmi_coo_row_offsets: offsets from
+// the row indices, order checked on the way), unsorted ones the general path, which sorts -- the same CSR either way
+template <typename Space> void TestCooToCsrSortedAndUnsorted()
+{
+    cusp::csr_matrix<int, double, cusp::host_memory> h;
+    cusp::gallery::poisson5pt(h, 31, 17);
+    cusp::coo_matrix<int, double, cusp::host_memory> hc(h);
+    { // sorted, with empty rows at both ends and in the middle: append 5 empty rows, blank two rows
+        cusp::coo_matrix<int, double, cusp::host_memory> g(hc.num_rows + 5, hc.num_cols, 0);
+        std::vector<int> ri, ci; std::vector<double> v;
+        for (size_t k = 0; k < hc.num_entries; k++) {
+            const int r = hc.row_indices[k];
+            if (r == 0 || r == 100 || r == 101) continue;
+            ri.push_back(r); ci.push_back(hc.column_indices[k]); v.push_back(hc.values[k]);
+        }
+        g.resize(hc.num_rows + 5, hc.num_cols, ri.size());
+        for (size_t k = 0; k < ri.size(); k++) { g.row_indices[k] = ri[k]; g.column_indices[k] = ci[k]; g.values[k] = v[k]; }
+        cusp::csr_matrix<int, double, cusp::host_memory> want(g);
+        cusp::coo_matrix<int, double, Space> dg(g);
+        cusp::csr_matrix<int, double, Space> got(dg);
+        ASSERT_ARRAYS_EQUAL(got.row_offsets, want.row_offsets);
+        ASSERT_ARRAYS_EQUAL(got.column_indices, want.column_indices);
+        ASSERT_ARRAYS_EQUAL(got.values, want.values);
+        ASSERT_EQUAL(int(want.row_offsets[1]), 0); ASSERT_EQUAL(int(want.row_offsets[102]) - int(want.row_offsets[100]), 0);
+    }
+    { // rows in reverse order (each row's entries in their own order): not sorted by row -> general path, a stable sort by row
+        cusp::coo_matrix<int, double, cusp::host_memory> rev(hc.num_rows, hc.num_cols, hc.num_entries);
+        size_t k = 0;
+        for (size_t r = h.num_rows; r-- > 0;)
+            for (int q = h.row_offsets[r]; q < h.row_offsets[r + 1]; q++, k++) {
+                rev.row_indices[k] = int(r); rev.column_indices[k] = h.column_indices[q]; rev.values[k] = h.values[q];
+            }
+        cusp::coo_matrix<int, double, Space> dr(rev);
+        cusp::csr_matrix<int, double, Space> got(dr);
+        ASSERT_ARRAYS_EQUAL(got.row_offsets, h.row_offsets);
+        ASSERT_ARRAYS_EQUAL(got.column_indices, h.column_indices);
+        ASSERT_ARRAYS_EQUAL(got.values, h.values);
+    }
+}
+DECLARE_SPACE_UNITTEST(TestCooToCsrSortedAndUnsorted);
+
 // ------------------------------------------------------------------------------------------------
 // testing/array1d.cu:7-193 (push_back, cross-space construction and assignment, std::vector interop,
 // iterator-range construction, equality across spaces); Thrust vectors are not part of this layer.  The

@@ -74,6 +74,9 @@ def test_argument_validation_of_the_newer_entry_points(cmi):
     assert L.cmi_cg_direction_f32(-1, None, None, None, None, None) == 1 and L.cmi_cg_direction_x_f32(4, None, None, None, None, None, None, None) == 1
     assert L.cmi_blas_dotd_f32(-1, None, None, None, None, None) == 1 and L.cmi_blas_dotd_f32(4, None, None, None, None, None) == 1
     assert L.cmi_cg_direction_x_f64(4, None, None, None, None, None, None, None) == 1 and b"cmi_cg_direction_x" in L.cmi_last_error()
+    ok = ctypes.c_int(5)
+    assert L.cmi_coo_row_offsets(-1, 0, None, None, ctypes.byref(ok), None) == 1 and L.cmi_coo_row_offsets(4, 2, None, None, ctypes.byref(ok), None) == 1
+    assert L.cmi_coo_row_offsets(4, 0, None, None, None, None) == 1 and b"cmi_coo_row_offsets" in L.cmi_last_error()
     assert L.cmi_copy_ranges(17, None, None, None, None) == 1 and b"CMI_MAX_COPY_RANGES" in L.cmi_last_error()
     assert L.cmi_copy_ranges(-1, None, None, None, None) == 1
     assert L.cmi_copy_ranges(0, None, None, None, None) == 0                    # nothing to copy

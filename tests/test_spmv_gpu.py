@@ -785,6 +785,37 @@ def test_coo_row_sorted_shapes(cmi, torch_cuda, orc, shape):
     assert_close(host(y), orc.spmv_csr(Ap, Aj, Ax, x, y0), bound + np.abs(y0), np.float64, f"coo {shape} accumulate")
 
 
+def test_device_coo_to_csr(cmi, torch_cuda, orc, golden_irregular):
+    """cmi_coo_row_offsets: row offsets from row-sorted row indices on the device (empty rows at both ends and inside,
+    a 5000-entry row), identical to the CSR the COO came from; unsorted or out-of-range indices are reported, not used."""
+    torch, g = torch_cuda, golden_irregular
+    rows, cols = int(g["rows"]), int(g["cols"])
+    Ap, Aj, Ax = g["f64_Ap"], g["f64_Aj"], g["f64_Ax"]
+    Ai = orc.csr_row_indices(Ap)
+    C = cmi.CooMatrix(rows, cols, len(Aj), dev(Ai, torch), dev(Aj, torch), dev(Ax, torch))
+    A = cmi.convert(C, "csr")
+    assert np.array_equal(host(A.row_offsets), Ap) and A.num_entries == len(Aj)
+    assert A.column_indices.data_ptr() == C.column_indices.data_ptr()       # the entry arrays are shared, not copied
+    y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
+    cmi.multiply(A, dev(g["f64_x"], torch), y, cfg=cmi.Config(kernel=cmi.CSR_STREAM, threads_per_row=1))
+    assert np.array_equal(host(y), g["f64_y_csr"])
+    # shapes: no entries at all, one entry, entries only in the last row, deserts of empty rows
+    for rws, idx in ((7, []), (7, [3]), (7, [6, 6, 6]), (100000, [0, 5, 5, 99998]), (1, [0, 0])):
+        ai = torch.tensor(idx, dtype=torch.int32, device="cuda")
+        ap = torch.full((rws + 1,), -7, dtype=torch.int32, device="cuda")
+        assert cmi.coo_row_offsets(rws, ai, ap)
+        want = np.searchsorted(np.asarray(idx, dtype=np.int64), np.arange(rws + 1), side="left")
+        assert np.array_equal(host(ap), want.astype(np.int32)), (rws, idx)
+    # not sorted / out of range: reported
+    for rws, idx in ((7, [3, 2]), (7, [0, 7]), (7, [-1, 2]), (7, [1, 2, 3, 2, 5])):
+        ai = torch.tensor(idx, dtype=torch.int32, device="cuda")
+        ap = torch.empty(rws + 1, dtype=torch.int32, device="cuda")
+        assert not cmi.coo_row_offsets(rws, ai, ap), (rws, idx)
+    perm = np.random.default_rng(3).permutation(len(Aj))
+    with pytest.raises(ValueError):
+        cmi.convert(cmi.CooMatrix(rows, cols, len(Aj), dev(Ai[perm], torch), dev(Aj[perm], torch), dev(Ax[perm], torch)), "csr")
+
+
 def test_non_default_stream(cmi, torch_cuda, golden_poisson, orc):
     torch, g = torch_cuda, golden_poisson
     Ap, Aj, Ax = orc.poisson5pt_csr(100, 100)
