@@ -54,8 +54,12 @@ def golden_banded():
 
 @pytest.fixture(scope="session")
 def cmi():
-    """The product's Python plumbing over the C-ABI (loads lib/libcusp_mi355x.so or raises)."""
+    """The product's Python plumbing over the C-ABI (loads lib/libcusp_mi355x.so or raises).  A checkout that has not
+    been built yet is built first (hipcc cross-compiles gfx950 without a GPU; the oracle and the C++ test programs
+    build themselves on demand): `python -m pytest tests -m "not gpu"` works on a fresh clone."""
     import cusp_autotuned_amd
+    if not os.path.exists(cusp_autotuned_amd.lib_path()):
+        cusp_autotuned_amd.build()
     cusp_autotuned_amd.lib()
     return cusp_autotuned_amd
 
