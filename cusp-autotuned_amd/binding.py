@@ -114,6 +114,9 @@ def _declare(L):
     L.cmi_poisson5pt_shard_entries.argtypes = [i64, i64, i64, i64]
     L.cmi_csr_row_indices.argtypes = [i64, vp, vp, vp]
     L.cmi_coo_row_offsets.argtypes = [i64, i64, vp, vp, POINTER(ctypes.c_int), vp]
+    for sfx in ("f64", "f32"):
+        getattr(L, "cmi_ell_to_csr_" + sfx).argtypes = [i64, i64, i64, vp, vp, vp, vp, vp, i64, POINTER(c_int64), vp]
+        getattr(L, "cmi_dia_to_csr_" + sfx).argtypes = [i64, i64, i64, i64, vp, vp, vp, vp, vp, i64, POINTER(c_int64), vp]
     L.cmi_csr_max_row_length.argtypes = [i64, vp, POINTER(c_int64), vp]
     L.cmi_csr_diagonals.argtypes = [i64, i64, vp, vp, vp, vp, i64, POINTER(c_int64), vp]
     for suf in ("f64", "f32"):
@@ -625,3 +628,34 @@ def coo_row_offsets(num_rows, Ai, Ap, stream=None):
     ok = ctypes.c_int(0)
     check(lib().cmi_coo_row_offsets(num_rows, Ai.numel(), _ptr(Ai), _ptr(Ap), byref(ok), _stream(stream)))
     return bool(ok.value)
+
+
+def ell_to_csr(num_rows, width, pitch, ell_Aj, ell_Ax, stream=None):
+    """(Ap, Aj, Ax) of the entries of an ELL matrix with a valid column, row by row, built on the device."""
+    import torch
+    fn = getattr(lib(), "cmi_ell_to_csr_" + _suffix(ell_Ax))
+    dev = ell_Ax.device
+    Ap = torch.empty(num_rows + 1, dtype=torch.int32, device=dev)
+    n = c_int64(0)
+    check(fn(num_rows, width, pitch, _ptr(ell_Aj), _ptr(ell_Ax), _ptr(Ap), None, None, 0, byref(n), _stream(stream)))
+    Aj = torch.empty(n.value, dtype=torch.int32, device=dev)
+    Ax = torch.empty(n.value, dtype=ell_Ax.dtype, device=dev)
+    if n.value:
+        check(fn(num_rows, width, pitch, _ptr(ell_Aj), _ptr(ell_Ax), _ptr(Ap), _ptr(Aj), _ptr(Ax), n.value, byref(n), _stream(stream)))
+    return Ap, Aj, Ax
+
+
+def dia_to_csr(num_rows, num_cols, num_diagonals, pitch, offsets, values, stream=None):
+    """(Ap, Aj, Ax) of the non-zero entries of a DIA matrix with a valid column, row by row, built on the device."""
+    import torch
+    fn = getattr(lib(), "cmi_dia_to_csr_" + _suffix(values))
+    dev = values.device
+    Ap = torch.empty(num_rows + 1, dtype=torch.int32, device=dev)
+    n = c_int64(0)
+    check(fn(num_rows, num_cols, num_diagonals, pitch, _ptr(offsets), _ptr(values), _ptr(Ap), None, None, 0, byref(n), _stream(stream)))
+    Aj = torch.empty(n.value, dtype=torch.int32, device=dev)
+    Ax = torch.empty(n.value, dtype=values.dtype, device=dev)
+    if n.value:
+        check(fn(num_rows, num_cols, num_diagonals, pitch, _ptr(offsets), _ptr(values), _ptr(Ap), _ptr(Aj), _ptr(Ax), n.value, byref(n),
+                 _stream(stream)))
+    return Ap, Aj, Ax

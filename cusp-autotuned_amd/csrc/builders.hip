@@ -398,3 +398,202 @@ CMI_API int cmi_ell_row_lengths(int64_t num_rows, int64_t width, int64_t pitch, 
     CMI_LAUNCH_CHECK("ell_row_lengths");
     return CMI_SUCCESS;
 }
+
+// ---------------------------------------------------------------------------------------------
+// ELL -> CSR and DIA -> CSR on the device (reference conversions/ell_to_other.h, dia_to_other.h:107-160: keep the
+// entries with a valid column -- DIA: and a non-zero value -- in row-major order): count per row, exclusive scan,
+// scatter.  Setup-time code: the scan is the plain three-pass one (tile sums, scan of the sums, apply).
+// ---------------------------------------------------------------------------------------------
+namespace cmi {
+
+constexpr int kScanTile = 2048; // 256 lanes x 8
+
+__global__ void __launch_bounds__(256) scan_tile_sums_kernel(int64_t n, const int *__restrict__ in, int *__restrict__ sums)
+{
+    __shared__ int slots[256 / kWave];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile;
+    int acc = 0;
+    for (int k = 0; k < 8; k++) {
+        const int64_t i = base + threadIdx.x * 8 + k;
+        if (i < n) acc += in[i];
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & (kWave - 1)) == 0) slots[threadIdx.x / kWave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = slots[0] + slots[1] + slots[2] + slots[3];
+}
+
+// one workgroup: sums[] -> exclusive scan in place, the grand total to *total
+__global__ void __launch_bounds__(256) scan_sums_kernel(int64_t ntiles, int *__restrict__ sums, int *__restrict__ total)
+{
+    __shared__ int buf[256];
+    int carry = 0;
+    for (int64_t base = 0; base < ntiles; base += 256) {
+        const int64_t i = base + threadIdx.x;
+        const int v = i < ntiles ? sums[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) { // Hillis-Steele inclusive scan of 256 values
+            const int t = (int)threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < ntiles) sums[i] = carry + buf[threadIdx.x] - v;
+        const int chunk = buf[255];
+        __syncthreads();
+        carry += chunk;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void __launch_bounds__(256) scan_apply_kernel(int64_t n, const int *__restrict__ in, const int *__restrict__ sums, int *__restrict__ out)
+{
+    __shared__ int wave_tot[256 / kWave];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * 8;
+    int v[8], local = 0;
+    for (int k = 0; k < 8; k++) { v[k] = base + k < n ? in[base + k] : 0; local += v[k]; }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    int incl = local; // inclusive scan of the lanes' totals inside the wave
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == kWave - 1) wave_tot[wave] = incl;
+    __syncthreads();
+    int off = sums[blockIdx.x] + incl - local;
+    for (int w = 0; w < wave; w++) off += wave_tot[w];
+    for (int k = 0; k < 8; k++) { if (base + k < n) out[base + k] = off; off += v[k]; }
+}
+
+__global__ void __launch_bounds__(256)
+ell_valid_counts_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict__ ell_Aj, int *__restrict__ counts)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows; i += stride) {
+        int c = 0;
+        for (int k = 0; k < width; k++) c += ell_Aj[(int64_t)k * pitch + i] >= 0;
+        counts[i] = c;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+ell_to_csr_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict__ ell_Aj, const T *__restrict__ ell_Ax,
+                  const int *__restrict__ Ap, int *__restrict__ Aj, T *__restrict__ Ax)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows; i += stride) {
+        int p = Ap[i];
+        for (int k = 0; k < width; k++) {
+            const int c = ell_Aj[(int64_t)k * pitch + i];
+            if (c >= 0) { Aj[p] = c; Ax[p] = ell_Ax[(int64_t)k * pitch + i]; p++; }
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+dia_valid_counts_kernel(int64_t num_rows, int64_t num_cols, int nd, int64_t pitch, const int *__restrict__ offsets,
+                        const T *__restrict__ vals, int *__restrict__ counts)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows; i += stride) {
+        int c = 0;
+        for (int d = 0; d < nd; d++) {
+            const int64_t j = i + offsets[d];
+            c += j >= 0 && j < num_cols && vals[(int64_t)d * pitch + i] != T(0);
+        }
+        counts[i] = c;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+dia_to_csr_kernel(int64_t num_rows, int64_t num_cols, int nd, int64_t pitch, const int *__restrict__ offsets, const T *__restrict__ vals,
+                  const int *__restrict__ Ap, int *__restrict__ Aj, T *__restrict__ Ax)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows; i += stride) {
+        int p = Ap[i];
+        for (int d = 0; d < nd; d++) {
+            const int64_t j = i + offsets[d];
+            const T v = vals[(int64_t)d * pitch + i];
+            if (j >= 0 && j < num_cols && v != T(0)) { Aj[p] = (int)j; Ax[p] = v; p++; }
+        }
+    }
+}
+
+// out[0..n] <- exclusive scan of in[0..n) (out[n] = the total); returns the total to the host.  Synchronises the stream.
+static int exclusive_scan_i32(int64_t n, const int *in, int *out, int64_t *total_host, hipStream_t s)
+{
+    const int64_t ntiles = ceil_div(n > 0 ? n : 1, (int64_t)kScanTile);
+    int *sums = nullptr;
+    CMI_HIP(hipMalloc((void **)&sums, (size_t)ntiles * sizeof(int)));
+    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, n, in, sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, s, ntiles, sums, out + n);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, n, in, sums, out);
+    hipError_t e = hipGetLastError();
+    int total = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&total, out + n, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(sums);
+    if (e != hipSuccess) return hip_fail(e, "exclusive scan");
+    if (total_host) *total_host = total;
+    return CMI_SUCCESS;
+}
+
+template <typename T>
+static int ell_to_csr(int64_t rows, int64_t width, int64_t pitch, const int *eAj, const T *eAx, int *Ap, int *Aj, T *Ax,
+                      int64_t capacity, int64_t *nnz_host, void *stream)
+{
+    if (rows < 0 || width < 0 || width > INT32_MAX || (width > 0 && pitch < rows)) return fail(CMI_ERROR_INVALID_VALUE, "cmi_ell_to_csr: bad size");
+    if (!Ap || !nnz_host || (rows > 0 && width > 0 && (!eAj || !eAx))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_ell_to_csr: null array");
+    hipStream_t s = as_stream(stream);
+    int *counts = nullptr;
+    CMI_HIP(hipMalloc((void **)&counts, (size_t)(rows > 0 ? rows : 1) * sizeof(int)));
+    if (rows > 0) hipLaunchKernelGGL(ell_valid_counts_kernel, dim3(grid_1d(rows)), dim3(256), 0, s, rows, (int)width, pitch, eAj, counts);
+    int st = exclusive_scan_i32(rows, counts, Ap, nnz_host, s);
+    if (st == CMI_SUCCESS && *nnz_host > 0 && Aj && Ax && *nnz_host <= capacity) { // Aj == NULL: a sizing call
+        hipLaunchKernelGGL((ell_to_csr_kernel<T>), dim3(grid_1d(rows)), dim3(256), 0, s, rows, (int)width, pitch, eAj, eAx, Ap, Aj, Ax);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) st = fail(CMI_ERROR_HIP, "cmi_ell_to_csr: scatter failed");
+    }
+    (void)hipFree(counts);
+    return st;
+}
+
+template <typename T>
+static int dia_to_csr(int64_t rows, int64_t cols, int64_t nd, int64_t pitch, const int *offsets, const T *vals, int *Ap, int *Aj, T *Ax,
+                      int64_t capacity, int64_t *nnz_host, void *stream)
+{
+    if (rows < 0 || cols < 0 || nd < 0 || nd > INT32_MAX || (nd > 0 && pitch < rows)) return fail(CMI_ERROR_INVALID_VALUE, "cmi_dia_to_csr: bad size");
+    if (!Ap || !nnz_host || (rows > 0 && nd > 0 && (!offsets || !vals))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_dia_to_csr: null array");
+    hipStream_t s = as_stream(stream);
+    int *counts = nullptr;
+    CMI_HIP(hipMalloc((void **)&counts, (size_t)(rows > 0 ? rows : 1) * sizeof(int)));
+    if (rows > 0) hipLaunchKernelGGL((dia_valid_counts_kernel<T>), dim3(grid_1d(rows)), dim3(256), 0, s, rows, cols, (int)nd, pitch, offsets, vals, counts);
+    int st = exclusive_scan_i32(rows, counts, Ap, nnz_host, s);
+    if (st == CMI_SUCCESS && *nnz_host > 0 && Aj && Ax && *nnz_host <= capacity) {
+        hipLaunchKernelGGL((dia_to_csr_kernel<T>), dim3(grid_1d(rows)), dim3(256), 0, s, rows, cols, (int)nd, pitch, offsets, vals, Ap, Aj, Ax);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) st = fail(CMI_ERROR_HIP, "cmi_dia_to_csr: scatter failed");
+    }
+    (void)hipFree(counts);
+    return st;
+}
+
+} // namespace cmi
+
+// Two-call protocol: first with Aj == Ax == NULL (Ap and *num_entries_host are filled: size the arrays), then with the arrays
+// and their capacity.  (The second call recomputes the offsets: setup-time code, simplicity over speed.)
+CMI_API int cmi_ell_to_csr_f64(int64_t num_rows, int64_t width, int64_t pitch, const int32_t *ell_Aj, const double *ell_Ax, int32_t *Ap,
+                               int32_t *Aj, double *Ax, int64_t capacity, int64_t *num_entries_host, void *stream)
+{ return cmi::ell_to_csr<double>(num_rows, width, pitch, ell_Aj, ell_Ax, Ap, Aj, Ax, capacity, num_entries_host, stream); }
+CMI_API int cmi_ell_to_csr_f32(int64_t num_rows, int64_t width, int64_t pitch, const int32_t *ell_Aj, const float *ell_Ax, int32_t *Ap,
+                               int32_t *Aj, float *Ax, int64_t capacity, int64_t *num_entries_host, void *stream)
+{ return cmi::ell_to_csr<float>(num_rows, width, pitch, ell_Aj, ell_Ax, Ap, Aj, Ax, capacity, num_entries_host, stream); }
+CMI_API int cmi_dia_to_csr_f64(int64_t num_rows, int64_t num_cols, int64_t num_diagonals, int64_t pitch, const int32_t *offsets,
+                               const double *values, int32_t *Ap, int32_t *Aj, double *Ax, int64_t capacity, int64_t *num_entries_host, void *stream)
+{ return cmi::dia_to_csr<double>(num_rows, num_cols, num_diagonals, pitch, offsets, values, Ap, Aj, Ax, capacity, num_entries_host, stream); }
+CMI_API int cmi_dia_to_csr_f32(int64_t num_rows, int64_t num_cols, int64_t num_diagonals, int64_t pitch, const int32_t *offsets,
+                               const float *values, int32_t *Ap, int32_t *Aj, float *Ax, int64_t capacity, int64_t *num_entries_host, void *stream)
+{ return cmi::dia_to_csr<float>(num_rows, num_cols, num_diagonals, pitch, offsets, values, Ap, Aj, Ax, capacity, num_entries_host, stream); }
+

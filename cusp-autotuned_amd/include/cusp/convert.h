@@ -407,6 +407,53 @@ struct device_fast_path<coo_matrix<int, V, device_memory>, csr_matrix<int, V, de
     }
 };
 
+inline int ell_to_csr_device(int64_t rows, int64_t w, int64_t pitch, const int *eAj, const double *eAx, int *Ap, int *Aj, double *Ax, int64_t cap, int64_t *n)
+{ return cmi_ell_to_csr_f64(rows, w, pitch, eAj, eAx, Ap, Aj, Ax, cap, n, nullptr); }
+inline int ell_to_csr_device(int64_t rows, int64_t w, int64_t pitch, const int *eAj, const float *eAx, int *Ap, int *Aj, float *Ax, int64_t cap, int64_t *n)
+{ return cmi_ell_to_csr_f32(rows, w, pitch, eAj, eAx, Ap, Aj, Ax, cap, n, nullptr); }
+inline int dia_to_csr_device(int64_t rows, int64_t cols, int64_t nd, int64_t pitch, const int *off, const double *va, int *Ap, int *Aj, double *Ax, int64_t cap, int64_t *n)
+{ return cmi_dia_to_csr_f64(rows, cols, nd, pitch, off, va, Ap, Aj, Ax, cap, n, nullptr); }
+inline int dia_to_csr_device(int64_t rows, int64_t cols, int64_t nd, int64_t pitch, const int *off, const float *va, int *Ap, int *Aj, float *Ax, int64_t cap, int64_t *n)
+{ return cmi_dia_to_csr_f32(rows, cols, nd, pitch, off, va, Ap, Aj, Ax, cap, n, nullptr); }
+
+// device ELL / DIA -> device CSR: count per row, exclusive scan, scatter (two calls: sizes first, then the arrays)
+template <typename V>
+struct device_fast_path<ell_matrix<int, V, device_memory>, csr_matrix<int, V, device_memory>, ell_format, csr_format> {
+    static bool run(const ell_matrix<int, V, device_memory> &s, csr_matrix<int, V, device_memory> &d)
+    {
+        array1d<int, device_memory> offsets(s.num_rows + 1);
+        int64_t n = 0;
+        const int64_t w = s.column_indices.num_cols, pitch = s.column_indices.pitch;
+        check(ell_to_csr_device(s.num_rows, w, pitch, s.column_indices.values.data(), s.values.values.data(), offsets.data(), nullptr,
+                                static_cast<V *>(nullptr), 0, &n));
+        d.resize(s.num_rows, s.num_cols, static_cast<size_t>(n));
+        if (n > 0)
+            check(ell_to_csr_device(s.num_rows, w, pitch, s.column_indices.values.data(), s.values.values.data(), d.row_offsets.data(),
+                                    d.column_indices.data(), d.values.data(), n, &n));
+        else
+            d.row_offsets = offsets;
+        return true;
+    }
+};
+template <typename V>
+struct device_fast_path<dia_matrix<int, V, device_memory>, csr_matrix<int, V, device_memory>, dia_format, csr_format> {
+    static bool run(const dia_matrix<int, V, device_memory> &s, csr_matrix<int, V, device_memory> &d)
+    {
+        array1d<int, device_memory> offsets(s.num_rows + 1);
+        int64_t n = 0;
+        const int64_t nd = s.values.num_cols, pitch = s.values.pitch;
+        check(dia_to_csr_device(s.num_rows, s.num_cols, nd, pitch, s.diagonal_offsets.data(), s.values.values.data(), offsets.data(), nullptr,
+                                static_cast<V *>(nullptr), 0, &n));
+        d.resize(s.num_rows, s.num_cols, static_cast<size_t>(n));
+        if (n > 0)
+            check(dia_to_csr_device(s.num_rows, s.num_cols, nd, pitch, s.diagonal_offsets.data(), s.values.values.data(), d.row_offsets.data(),
+                                    d.column_indices.data(), d.values.data(), n, &n));
+        else
+            d.row_offsets = offsets;
+        return true;
+    }
+};
+
 inline int csr_to_hyb_coo_device(int64_t rows, const int *Ap, const int *Aj, const double *Ax, int64_t w, const int *off, int *cAi, int *cAj, double *cAx)
 { return cmi_csr_to_hyb_coo_f64(rows, Ap, Aj, Ax, w, off, cAi, cAj, cAx, nullptr); }
 inline int csr_to_hyb_coo_device(int64_t rows, const int *Ap, const int *Aj, const float *Ax, int64_t w, const int *off, int *cAi, int *cAj, float *cAx)

@@ -144,8 +144,14 @@ def convert(csr, fmt, num_entries_per_row=None, ell_alignment=32):
         if not B.coo_row_offsets(coo.num_rows, coo.row_indices, Ap):
             raise ValueError("convert: the COO entries are not sorted by row (cusp/coo_matrix.h:72 requires it); sort them first")
         return CsrMatrix(coo.num_rows, coo.num_cols, coo.num_entries, Ap, coo.column_indices, coo.values)
+    if isinstance(csr, EllMatrix) and fmt == "csr":
+        Ap, Aj, Ax = B.ell_to_csr(csr.num_rows, csr.num_entries_per_row, csr.pitch, csr.column_indices, csr.values)
+        return CsrMatrix(csr.num_rows, csr.num_cols, Aj.numel(), Ap, Aj, Ax)
+    if isinstance(csr, DiaMatrix) and fmt == "csr":
+        Ap, Aj, Ax = B.dia_to_csr(csr.num_rows, csr.num_cols, csr.diagonal_offsets.numel(), csr.pitch, csr.diagonal_offsets, csr.values)
+        return CsrMatrix(csr.num_rows, csr.num_cols, Aj.numel(), Ap, Aj, Ax)
     if not isinstance(csr, CsrMatrix):
-        raise TypeError("convert: source must be a CsrMatrix (or a CooMatrix for fmt='csr')")
+        raise TypeError("convert: source must be a CsrMatrix (or a Coo / Ell / Dia matrix for fmt='csr')")
     dev = csr.values.device
     if fmt == "csr":
         return csr

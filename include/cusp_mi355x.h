@@ -319,6 +319,20 @@ int cmi_csr_row_indices(int64_t num_rows, const int32_t *Ap, int32_t *Ai, void *
  * in one pass, with the order checked on the way.  *sorted_host == 0 afterwards: the entries were not sorted by row (or a
  * row index was out of range) and Ap is unspecified -- the caller sorts, or converts on the host.  Synchronises the stream. */
 int cmi_coo_row_offsets(int64_t num_rows, int64_t num_entries, const int32_t *Ai, int32_t *Ap, int *sorted_host, void *stream);
+/* ELL -> CSR and DIA -> CSR on the device (reference conversions/ell_to_other.h and dia_to_other.h:107-160: the entries
+ * with a valid column -- DIA: and a non-zero value -- in row-major order): count per row, exclusive scan, scatter.
+ * Two-call protocol: first with Aj == Ax == NULL -- Ap[num_rows + 1] and *num_entries_host are filled, size the arrays --
+ * then with the arrays and their capacity (in entries).  Synchronise the stream. */
+int cmi_ell_to_csr_f64(int64_t num_rows, int64_t width, int64_t pitch, const int32_t *ell_Aj, const double *ell_Ax,
+                       int32_t *Ap, int32_t *Aj, double *Ax, int64_t capacity, int64_t *num_entries_host, void *stream);
+int cmi_ell_to_csr_f32(int64_t num_rows, int64_t width, int64_t pitch, const int32_t *ell_Aj, const float *ell_Ax,
+                       int32_t *Ap, int32_t *Aj, float *Ax, int64_t capacity, int64_t *num_entries_host, void *stream);
+int cmi_dia_to_csr_f64(int64_t num_rows, int64_t num_cols, int64_t num_diagonals, int64_t pitch, const int32_t *offsets,
+                       const double *values, int32_t *Ap, int32_t *Aj, double *Ax, int64_t capacity,
+                       int64_t *num_entries_host, void *stream);
+int cmi_dia_to_csr_f32(int64_t num_rows, int64_t num_cols, int64_t num_diagonals, int64_t pitch, const int32_t *offsets,
+                       const float *values, int32_t *Ap, int32_t *Aj, float *Ax, int64_t capacity,
+                       int64_t *num_entries_host, void *stream);
 /* ELL -> per-row length of the leading valid run (cusp/ktt/detail/ellr_matrix.inl:16-53). */
 int cmi_ell_row_lengths(int64_t num_rows, int64_t width, int64_t pitch, const int32_t *ell_Aj,
                         int32_t *row_lengths, void *stream);

@@ -74,6 +74,11 @@ def test_argument_validation_of_the_newer_entry_points(cmi):
     assert L.cmi_cg_direction_f32(-1, None, None, None, None, None) == 1 and L.cmi_cg_direction_x_f32(4, None, None, None, None, None, None, None) == 1
     assert L.cmi_blas_dotd_f32(-1, None, None, None, None, None) == 1 and L.cmi_blas_dotd_f32(4, None, None, None, None, None) == 1
     assert L.cmi_cg_direction_x_f64(4, None, None, None, None, None, None, None) == 1 and b"cmi_cg_direction_x" in L.cmi_last_error()
+    n64 = ctypes.c_int64(0)
+    assert L.cmi_ell_to_csr_f64(-1, 0, 0, None, None, None, None, None, 0, ctypes.byref(n64), None) == 1
+    assert L.cmi_ell_to_csr_f32(4, 2, 8, None, None, None, None, None, 0, ctypes.byref(n64), None) == 1 and b"cmi_ell_to_csr" in L.cmi_last_error()
+    assert L.cmi_dia_to_csr_f64(4, 4, 2, 2, None, None, None, None, None, 0, ctypes.byref(n64), None) == 1     # pitch < rows
+    assert L.cmi_dia_to_csr_f32(4, 4, 2, 8, None, None, None, None, None, 0, None, None) == 1
     ok = ctypes.c_int(5)
     assert L.cmi_coo_row_offsets(-1, 0, None, None, ctypes.byref(ok), None) == 1 and L.cmi_coo_row_offsets(4, 2, None, None, ctypes.byref(ok), None) == 1
     assert L.cmi_coo_row_offsets(4, 0, None, None, None, None) == 1 and b"cmi_coo_row_offsets" in L.cmi_last_error()

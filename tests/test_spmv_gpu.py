@@ -816,6 +816,41 @@ def test_device_coo_to_csr(cmi, torch_cuda, orc, golden_irregular):
         cmi.convert(cmi.CooMatrix(rows, cols, len(Aj), dev(Ai[perm], torch), dev(Aj[perm], torch), dev(Ax[perm], torch)), "csr")
 
 
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_device_ell_and_dia_to_csr(cmi, torch_cuda, orc, golden_irregular, golden_banded, tag):
+    """ELL -> CSR and DIA -> CSR built on the device (count per row, exclusive scan over more than one scan tile, scatter):
+    the round trips CSR -> ELL -> CSR and CSR -> DIA -> CSR give the matrix back (empty rows, a 5000-entry row, a banded
+    rectangular matrix); padding and explicit zeros of the DIA array are dropped as the reference does."""
+    torch, g = torch_cuda, golden_irregular
+    rows, cols = int(g["rows"]), int(g["cols"])
+    Ap, Aj, Ax = g[f"{tag}_Ap"], g[f"{tag}_Aj"], g[f"{tag}_Ax"]
+    A = cmi.CsrMatrix(rows, cols, len(Aj), dev(Ap, torch), dev(Aj, torch), dev(Ax, torch))
+    E = cmi.convert(A, "ell")
+    back = cmi.convert(E, "csr")
+    assert back.num_entries == len(Aj)
+    assert np.array_equal(host(back.row_offsets), Ap) and np.array_equal(host(back.column_indices), Aj) and np.array_equal(host(back.values), Ax)
+    # a bigger matrix: more rows than one scan tile holds several times over, through DIA and ELL
+    m, n = 301, 127
+    P = cmi.poisson5pt(m, n, "csr", dtype=torch.float64 if tag == "f64" else torch.float32)
+    for fmt in ("dia", "ell"):
+        Q = cmi.convert(cmi.convert(P, fmt), "csr")
+        assert torch.equal(Q.row_offsets, P.row_offsets) and torch.equal(Q.column_indices, P.column_indices) and torch.equal(Q.values, P.values)
+    # the gallery's own DIA (built directly) converts to the gallery's CSR
+    Q = cmi.convert(cmi.poisson5pt(m, n, "dia", dtype=P.values.dtype), "csr")
+    assert torch.equal(Q.row_offsets, P.row_offsets) and torch.equal(Q.column_indices, P.column_indices) and torch.equal(Q.values, P.values)
+    # explicit zeros inside the band are dropped (dia_to_other.h: copy_if value != 0); an all-empty matrix works
+    D = cmi.poisson5pt(9, 7, "dia", dtype=P.values.dtype)
+    D.values[: D.pitch].zero_()      # the first diagonal (offset -m) becomes explicit zeros
+    Z = cmi.convert(D, "csr")
+    want_cols = [c for c in host(cmi.poisson5pt(9, 7, "csr").column_indices)]
+    Pp, Pj = host(cmi.poisson5pt(9, 7, "csr").row_offsets), host(cmi.poisson5pt(9, 7, "csr").column_indices)
+    keep = np.concatenate([[j for j in Pj[Pp[i]:Pp[i + 1]] if j != i - 9] for i in range(63)]).astype(np.int32)
+    assert np.array_equal(host(Z.column_indices), keep) and Z.num_entries == len(keep) and len(want_cols) > len(keep)
+    empty = cmi.EllMatrix(5, 5, 0, 0, 32, torch.empty(0, dtype=torch.int32, device="cuda"), torch.empty(0, dtype=P.values.dtype, device="cuda"))
+    Zc = cmi.convert(empty, "csr")
+    assert Zc.num_entries == 0 and host(Zc.row_offsets).tolist() == [0] * 6
+
+
 def test_non_default_stream(cmi, torch_cuda, golden_poisson, orc):
     torch, g = torch_cuda, golden_poisson
     Ap, Aj, Ax = orc.poisson5pt_csr(100, 100)
