@@ -20,7 +20,7 @@ from .binding import (  # noqa: F401
     spmv_csr, spmv_csr_dot, spmv_ell_dot, spmv_dia_dot, spmv_ell, spmv_dia, spmv_coo, spmv_hyb,
     tuning_select, tuning_set, tuning_load, tuning_save, tuning_clear,
     poisson5pt_num_entries, poisson5pt_shard_entries, poisson5pt_csr, poisson5pt_dia,
-    csr_to_ell, csr_to_hyb_coo, csr_row_indices, coo_row_offsets, ell_to_csr, dia_to_csr, ell_row_lengths,
+    csr_to_ell, csr_to_hyb_coo, csr_row_indices, coo_row_offsets, ell_to_csr, dia_to_csr, hyb_to_csr, ell_row_lengths,
     blas_axpy, blas_axpby, blas_copy, blas_fill, blas_dot, blas_dotd, blas_nrm2, blas_workspace,
     cg_update, cg_direction, cg_direction_x, HostScalar,
 )

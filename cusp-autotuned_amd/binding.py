@@ -117,6 +117,7 @@ def _declare(L):
     for sfx in ("f64", "f32"):
         getattr(L, "cmi_ell_to_csr_" + sfx).argtypes = [i64, i64, i64, vp, vp, vp, vp, vp, i64, POINTER(c_int64), vp]
         getattr(L, "cmi_dia_to_csr_" + sfx).argtypes = [i64, i64, i64, i64, vp, vp, vp, vp, vp, i64, POINTER(c_int64), vp]
+        getattr(L, "cmi_hyb_to_csr_" + sfx).argtypes = [i64, i64, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, POINTER(c_int64), vp]
     L.cmi_csr_max_row_length.argtypes = [i64, vp, POINTER(c_int64), vp]
     L.cmi_csr_diagonals.argtypes = [i64, i64, vp, vp, vp, vp, i64, POINTER(c_int64), vp]
     for suf in ("f64", "f32"):
@@ -658,4 +659,20 @@ def dia_to_csr(num_rows, num_cols, num_diagonals, pitch, offsets, values, stream
     if n.value:
         check(fn(num_rows, num_cols, num_diagonals, pitch, _ptr(offsets), _ptr(values), _ptr(Ap), _ptr(Aj), _ptr(Ax), n.value, byref(n),
                  _stream(stream)))
+    return Ap, Aj, Ax
+
+
+def hyb_to_csr(num_rows, width, pitch, ell_Aj, ell_Ax, coo_Ai, coo_Aj, coo_Ax, stream=None):
+    """(Ap, Aj, Ax): each row's ELL entries, then its COO entries (row-sorted COO part), built on the device."""
+    import torch
+    fn = getattr(lib(), "cmi_hyb_to_csr_" + _suffix(ell_Ax))
+    dev = ell_Ax.device
+    Ap = torch.empty(num_rows + 1, dtype=torch.int32, device=dev)
+    n = c_int64(0)
+    args = (num_rows, width, pitch, _ptr(ell_Aj), _ptr(ell_Ax), coo_Ai.numel(), _ptr(coo_Ai), _ptr(coo_Aj), _ptr(coo_Ax), _ptr(Ap))
+    check(fn(*args, None, None, 0, byref(n), _stream(stream)))
+    Aj = torch.empty(n.value, dtype=torch.int32, device=dev)
+    Ax = torch.empty(n.value, dtype=ell_Ax.dtype, device=dev)
+    if n.value:
+        check(fn(*args, _ptr(Aj), _ptr(Ax), n.value, byref(n), _stream(stream)))
     return Ap, Aj, Ax

@@ -580,6 +580,70 @@ static int dia_to_csr(int64_t rows, int64_t cols, int64_t nd, int64_t pitch, con
     return st;
 }
 
+// HYB -> CSR: a row's ELL entries, then its COO entries (the order hyb_matrix keeps: the first K entries of a row live in
+// the ELL part, the rest in the COO part; reference conversions/hyb_to_other.h goes through COO and sorts by row)
+__global__ void __launch_bounds__(256)
+hyb_counts_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict__ ell_Aj, const int *__restrict__ coo_off, int *__restrict__ counts)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows; i += stride) {
+        int c = coo_off[i + 1] - coo_off[i];
+        for (int k = 0; k < width; k++) c += ell_Aj[(int64_t)k * pitch + i] >= 0;
+        counts[i] = c;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+hyb_to_csr_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict__ ell_Aj, const T *__restrict__ ell_Ax,
+                  const int *__restrict__ coo_off, const int *__restrict__ coo_Aj, const T *__restrict__ coo_Ax,
+                  const int *__restrict__ Ap, int *__restrict__ Aj, T *__restrict__ Ax)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows; i += stride) {
+        int p = Ap[i];
+        for (int k = 0; k < width; k++) {
+            const int c = ell_Aj[(int64_t)k * pitch + i];
+            if (c >= 0) { Aj[p] = c; Ax[p] = ell_Ax[(int64_t)k * pitch + i]; p++; }
+        }
+        for (int q = coo_off[i]; q < coo_off[i + 1]; q++, p++) { Aj[p] = coo_Aj[q]; Ax[p] = coo_Ax[q]; }
+    }
+}
+
+template <typename T>
+static int hyb_to_csr(int64_t rows, int64_t width, int64_t pitch, const int *eAj, const T *eAx, int64_t ncoo, const int *cAi,
+                      const int *cAj, const T *cAx, int *Ap, int *Aj, T *Ax, int64_t capacity, int64_t *nnz_host, void *stream)
+{
+    if (rows < 0 || width < 0 || width > INT32_MAX || ncoo < 0 || ncoo > INT32_MAX || (width > 0 && pitch < rows))
+        return fail(CMI_ERROR_INVALID_VALUE, "cmi_hyb_to_csr: bad size");
+    if (!Ap || !nnz_host || (rows > 0 && width > 0 && (!eAj || !eAx)) || (ncoo > 0 && (!cAi || !cAj || !cAx)))
+        return fail(CMI_ERROR_INVALID_VALUE, "cmi_hyb_to_csr: null array");
+    hipStream_t s = as_stream(stream);
+    int *scratch = nullptr; // [rows + 1] COO row offsets | [rows] counts | order flag
+    const size_t n1 = (size_t)rows + 1;
+    CMI_HIP(hipMalloc((void **)&scratch, (2 * n1 + 1) * sizeof(int)));
+    int *coo_off = scratch, *counts = scratch + n1, *flag = scratch + 2 * n1;
+    int st = CMI_SUCCESS, unsorted = 0;
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(coo_row_offsets_kernel, dim3(grid_1d(ncoo + 1)), dim3(256), 0, s, rows, ncoo, cAi, coo_off, flag);
+        e = hipMemcpyAsync(&unsorted, flag, sizeof(int), hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) st = hip_fail(e, "cmi_hyb_to_csr");
+    else if (unsorted) st = fail(CMI_ERROR_NOT_SUPPORTED, "cmi_hyb_to_csr: the COO part is not sorted by row");
+    if (st == CMI_SUCCESS) {
+        if (rows > 0) hipLaunchKernelGGL(hyb_counts_kernel, dim3(grid_1d(rows)), dim3(256), 0, s, rows, (int)width, pitch, eAj, coo_off, counts);
+        st = exclusive_scan_i32(rows, counts, Ap, nnz_host, s);
+    }
+    if (st == CMI_SUCCESS && *nnz_host > 0 && Aj && Ax && *nnz_host <= capacity) {
+        hipLaunchKernelGGL((hyb_to_csr_kernel<T>), dim3(grid_1d(rows)), dim3(256), 0, s, rows, (int)width, pitch, eAj, eAx, coo_off, cAj, cAx, Ap, Aj, Ax);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) st = fail(CMI_ERROR_HIP, "cmi_hyb_to_csr: scatter failed");
+    }
+    (void)hipFree(scratch);
+    return st;
+}
+
 } // namespace cmi
 
 // Two-call protocol: first with Aj == Ax == NULL (Ap and *num_entries_host are filled: size the arrays), then with the arrays
@@ -596,4 +660,11 @@ CMI_API int cmi_dia_to_csr_f64(int64_t num_rows, int64_t num_cols, int64_t num_d
 CMI_API int cmi_dia_to_csr_f32(int64_t num_rows, int64_t num_cols, int64_t num_diagonals, int64_t pitch, const int32_t *offsets,
                                const float *values, int32_t *Ap, int32_t *Aj, float *Ax, int64_t capacity, int64_t *num_entries_host, void *stream)
 { return cmi::dia_to_csr<float>(num_rows, num_cols, num_diagonals, pitch, offsets, values, Ap, Aj, Ax, capacity, num_entries_host, stream); }
-
+CMI_API int cmi_hyb_to_csr_f64(int64_t num_rows, int64_t ell_width, int64_t ell_pitch, const int32_t *ell_Aj, const double *ell_Ax,
+                               int64_t coo_entries, const int32_t *coo_Ai, const int32_t *coo_Aj, const double *coo_Ax, int32_t *Ap,
+                               int32_t *Aj, double *Ax, int64_t capacity, int64_t *num_entries_host, void *stream)
+{ return cmi::hyb_to_csr<double>(num_rows, ell_width, ell_pitch, ell_Aj, ell_Ax, coo_entries, coo_Ai, coo_Aj, coo_Ax, Ap, Aj, Ax, capacity, num_entries_host, stream); }
+CMI_API int cmi_hyb_to_csr_f32(int64_t num_rows, int64_t ell_width, int64_t ell_pitch, const int32_t *ell_Aj, const float *ell_Ax,
+                               int64_t coo_entries, const int32_t *coo_Ai, const int32_t *coo_Aj, const float *coo_Ax, int32_t *Ap,
+                               int32_t *Aj, float *Ax, int64_t capacity, int64_t *num_entries_host, void *stream)
+{ return cmi::hyb_to_csr<float>(num_rows, ell_width, ell_pitch, ell_Aj, ell_Ax, coo_entries, coo_Ai, coo_Aj, coo_Ax, Ap, Aj, Ax, capacity, num_entries_host, stream); }

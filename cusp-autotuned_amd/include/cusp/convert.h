@@ -454,6 +454,35 @@ struct device_fast_path<dia_matrix<int, V, device_memory>, csr_matrix<int, V, de
     }
 };
 
+inline int hyb_to_csr_device(int64_t rows, int64_t w, int64_t pitch, const int *eAj, const double *eAx, int64_t nc, const int *cAi, const int *cAj, const double *cAx, int *Ap, int *Aj, double *Ax, int64_t cap, int64_t *n)
+{ return cmi_hyb_to_csr_f64(rows, w, pitch, eAj, eAx, nc, cAi, cAj, cAx, Ap, Aj, Ax, cap, n, nullptr); }
+inline int hyb_to_csr_device(int64_t rows, int64_t w, int64_t pitch, const int *eAj, const float *eAx, int64_t nc, const int *cAi, const int *cAj, const float *cAx, int *Ap, int *Aj, float *Ax, int64_t cap, int64_t *n)
+{ return cmi_hyb_to_csr_f32(rows, w, pitch, eAj, eAx, nc, cAi, cAj, cAx, Ap, Aj, Ax, cap, n, nullptr); }
+
+// device HYB -> device CSR: a row's ELL entries, then its COO entries; a COO part that is not row-sorted takes the general path
+template <typename V>
+struct device_fast_path<hyb_matrix<int, V, device_memory>, csr_matrix<int, V, device_memory>, hyb_format, csr_format> {
+    static bool run(const hyb_matrix<int, V, device_memory> &s, csr_matrix<int, V, device_memory> &d)
+    {
+        array1d<int, device_memory> offsets(s.num_rows + 1);
+        int64_t n = 0;
+        const int64_t w = s.ell.column_indices.num_cols, pitch = s.ell.column_indices.pitch;
+        int st = hyb_to_csr_device(s.num_rows, w, pitch, s.ell.column_indices.values.data(), s.ell.values.values.data(), s.coo.num_entries,
+                                   s.coo.row_indices.data(), s.coo.column_indices.data(), s.coo.values.data(), offsets.data(), nullptr,
+                                   static_cast<V *>(nullptr), 0, &n);
+        if (st == CMI_ERROR_NOT_SUPPORTED) return false;
+        check(st);
+        d.resize(s.num_rows, s.num_cols, static_cast<size_t>(n));
+        if (n > 0)
+            check(hyb_to_csr_device(s.num_rows, w, pitch, s.ell.column_indices.values.data(), s.ell.values.values.data(), s.coo.num_entries,
+                                    s.coo.row_indices.data(), s.coo.column_indices.data(), s.coo.values.data(), d.row_offsets.data(),
+                                    d.column_indices.data(), d.values.data(), n, &n));
+        else
+            d.row_offsets = offsets;
+        return true;
+    }
+};
+
 inline int csr_to_hyb_coo_device(int64_t rows, const int *Ap, const int *Aj, const double *Ax, int64_t w, const int *off, int *cAi, int *cAj, double *cAx)
 { return cmi_csr_to_hyb_coo_f64(rows, Ap, Aj, Ax, w, off, cAi, cAj, cAx, nullptr); }
 inline int csr_to_hyb_coo_device(int64_t rows, const int *Ap, const int *Aj, const float *Ax, int64_t w, const int *off, int *cAi, int *cAj, float *cAx)

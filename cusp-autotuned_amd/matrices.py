@@ -150,8 +150,12 @@ def convert(csr, fmt, num_entries_per_row=None, ell_alignment=32):
     if isinstance(csr, DiaMatrix) and fmt == "csr":
         Ap, Aj, Ax = B.dia_to_csr(csr.num_rows, csr.num_cols, csr.diagonal_offsets.numel(), csr.pitch, csr.diagonal_offsets, csr.values)
         return CsrMatrix(csr.num_rows, csr.num_cols, Aj.numel(), Ap, Aj, Ax)
+    if isinstance(csr, HybMatrix) and fmt == "csr":
+        e, c = csr.ell, csr.coo
+        Ap, Aj, Ax = B.hyb_to_csr(csr.num_rows, e.num_entries_per_row, e.pitch, e.column_indices, e.values, c.row_indices, c.column_indices, c.values)
+        return CsrMatrix(csr.num_rows, csr.num_cols, Aj.numel(), Ap, Aj, Ax)
     if not isinstance(csr, CsrMatrix):
-        raise TypeError("convert: source must be a CsrMatrix (or a Coo / Ell / Dia matrix for fmt='csr')")
+        raise TypeError("convert: source must be a CsrMatrix (or a Coo / Ell / Dia / Hyb matrix for fmt='csr')")
     dev = csr.values.device
     if fmt == "csr":
         return csr

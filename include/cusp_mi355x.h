@@ -333,6 +333,14 @@ int cmi_dia_to_csr_f64(int64_t num_rows, int64_t num_cols, int64_t num_diagonals
 int cmi_dia_to_csr_f32(int64_t num_rows, int64_t num_cols, int64_t num_diagonals, int64_t pitch, const int32_t *offsets,
                        const float *values, int32_t *Ap, int32_t *Aj, float *Ax, int64_t capacity,
                        int64_t *num_entries_host, void *stream);
+/* HYB -> CSR, same protocol: a row's ELL entries, then its COO entries (the COO part row-sorted, as hyb_matrix keeps it;
+ * CMI_ERROR_NOT_SUPPORTED if it is not -- convert on the host then). */
+int cmi_hyb_to_csr_f64(int64_t num_rows, int64_t ell_width, int64_t ell_pitch, const int32_t *ell_Aj, const double *ell_Ax,
+                       int64_t coo_entries, const int32_t *coo_Ai, const int32_t *coo_Aj, const double *coo_Ax,
+                       int32_t *Ap, int32_t *Aj, double *Ax, int64_t capacity, int64_t *num_entries_host, void *stream);
+int cmi_hyb_to_csr_f32(int64_t num_rows, int64_t ell_width, int64_t ell_pitch, const int32_t *ell_Aj, const float *ell_Ax,
+                       int64_t coo_entries, const int32_t *coo_Ai, const int32_t *coo_Aj, const float *coo_Ax,
+                       int32_t *Ap, int32_t *Aj, float *Ax, int64_t capacity, int64_t *num_entries_host, void *stream);
 /* ELL -> per-row length of the leading valid run (cusp/ktt/detail/ellr_matrix.inl:16-53). */
 int cmi_ell_row_lengths(int64_t num_rows, int64_t width, int64_t pitch, const int32_t *ell_Aj,
                         int32_t *row_lengths, void *stream);

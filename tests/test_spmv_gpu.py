@@ -846,6 +846,11 @@ def test_device_ell_and_dia_to_csr(cmi, torch_cuda, orc, golden_irregular, golde
     Pp, Pj = host(cmi.poisson5pt(9, 7, "csr").row_offsets), host(cmi.poisson5pt(9, 7, "csr").column_indices)
     keep = np.concatenate([[j for j in Pj[Pp[i]:Pp[i + 1]] if j != i - 9] for i in range(63)]).astype(np.int32)
     assert np.array_equal(host(Z.column_indices), keep) and Z.num_entries == len(keep) and len(want_cols) > len(keep)
+    # HYB -> CSR: a row's ELL entries, then its COO entries -- the CSR it came from, at every split width
+    for w in (0, 1, 3, 7, 5000):
+        H = cmi.convert(A, "hyb", num_entries_per_row=w)
+        back = cmi.convert(H, "csr")
+        assert np.array_equal(host(back.row_offsets), Ap) and np.array_equal(host(back.column_indices), Aj) and np.array_equal(host(back.values), Ax), w
     empty = cmi.EllMatrix(5, 5, 0, 0, 32, torch.empty(0, dtype=torch.int32, device="cuda"), torch.empty(0, dtype=P.values.dtype, device="cuda"))
     Zc = cmi.convert(empty, "csr")
     assert Zc.num_entries == 0 and host(Zc.row_offsets).tolist() == [0] * 6
