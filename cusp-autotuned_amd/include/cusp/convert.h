@@ -559,6 +559,17 @@ template <typename Src, typename Dst> void convert_impl(const Src &src, Dst &dst
     if (device_fast_path<Src, Dst, typename Src::format, typename Dst::format>::run(src, dst)) return;
     typedef typename Dst::index_type I;
     typedef typename Dst::value_type V;
+    // two device matrices, neither of them CSR (ELL -> DIA, COO -> HYB, ...): pivot through a CSR matrix that stays in HBM
+    if constexpr (std::is_same<typename Src::memory_space, device_memory>::value && std::is_same<typename Dst::memory_space, device_memory>::value &&
+                  std::is_same<typename Src::index_type, int>::value && std::is_same<I, int>::value &&
+                  std::is_same<typename Src::value_type, V>::value && !std::is_same<typename Src::format, csr_format>::value &&
+                  !std::is_same<typename Dst::format, csr_format>::value && !std::is_same<typename Src::format, array2d_format>::value &&
+                  !std::is_same<typename Dst::format, array2d_format>::value) {
+        csr_matrix<int, V, device_memory> pivot;
+        if (device_fast_path<Src, csr_matrix<int, V, device_memory>, typename Src::format, csr_format>::run(src, pivot) &&
+            device_fast_path<csr_matrix<int, V, device_memory>, Dst, csr_format, typename Dst::format>::run(pivot, dst))
+            return;
+    }
     host_csr<I, V> csr;
     to_host_csr(src, csr, typename Src::format());
     from_host_csr(csr, dst, typename Dst::format());

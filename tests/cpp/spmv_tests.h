@@ -319,6 +319,34 @@ template <typename Space> void TestCooToCsrSortedAndUnsorted()
 }
 DECLARE_SPACE_UNITTEST(TestCooToCsrSortedAndUnsorted);
 
+// every ordered pair of formats converts inside one memory space (on the device: directly, or through a CSR matrix that stays
+// in HBM) and the matrix survives: back in CSR it is the gallery matrix again
+template <typename Space, typename Src> void convert_to_every_format(const Src &src, const cusp::csr_matrix<int, double, cusp::host_memory> &want)
+{
+    auto same = [&](const cusp::csr_matrix<int, double, Space> &got) {
+        ASSERT_ARRAYS_EQUAL(got.row_offsets, want.row_offsets);
+        ASSERT_ARRAYS_EQUAL(got.column_indices, want.column_indices);
+        ASSERT_ARRAYS_EQUAL(got.values, want.values);
+    };
+    { cusp::coo_matrix<int, double, Space> d(src); cusp::csr_matrix<int, double, Space> c(d); same(c); }
+    { cusp::ell_matrix<int, double, Space> d(src); cusp::csr_matrix<int, double, Space> c(d); same(c); }
+    { cusp::hyb_matrix<int, double, Space> d(src); cusp::csr_matrix<int, double, Space> c(d); same(c); }
+    { cusp::dia_matrix<int, double, Space> d(src); cusp::csr_matrix<int, double, Space> c(d); same(c); }
+    { cusp::csr_matrix<int, double, Space> c(src); same(c); }
+}
+template <typename Space> void TestEveryFormatPairConverts()
+{
+    cusp::csr_matrix<int, double, cusp::host_memory> h;
+    cusp::gallery::poisson5pt(h, 19, 13);
+    cusp::csr_matrix<int, double, Space> a(h);
+    convert_to_every_format<Space>(a, h);
+    { cusp::coo_matrix<int, double, Space> s(a); convert_to_every_format<Space>(s, h); }
+    { cusp::ell_matrix<int, double, Space> s(a); convert_to_every_format<Space>(s, h); }
+    { cusp::hyb_matrix<int, double, Space> s(a); convert_to_every_format<Space>(s, h); }
+    { cusp::dia_matrix<int, double, Space> s(a); convert_to_every_format<Space>(s, h); }
+}
+DECLARE_SPACE_UNITTEST(TestEveryFormatPairConverts);
+
 // ------------------------------------------------------------------------------------------------
 // testing/array1d.cu:7-193 (push_back, cross-space construction and assignment, std::vector interop,
 // iterator-range construction, equality across spaces); Thrust vectors are not part of this layer.  The
