@@ -15,8 +15,9 @@ from .binding import (  # noqa: F401
     Config,
     FORMAT_CSR, FORMAT_ELL, FORMAT_DIA, FORMAT_COO, FORMAT_HYB,
     F64, F32,
-    KERNEL_AUTO, CSR_SCALAR, CSR_VECTOR, CSR_STREAM, CSR_STREAM_PIPE, CSR_BALANCED, ELL_ROW, DIA_ROW, COO_SEGMENTED, COO_LANE4,
+    KERNEL_AUTO, CSR_SCALAR, CSR_VECTOR, CSR_STREAM, CSR_STREAM_PIPE, CSR_BALANCED, ELL_ROW, DIA_ROW, COO_SEGMENTED, COO_LANE4, COO_TILE,
     lib, lib_path, build, version, check,
+    Plan, spmv_csr_plan, spmv_coo_plan,
     spmv_csr, spmv_csr_dot, spmv_ell_dot, spmv_dia_dot, spmv_ell, spmv_dia, spmv_coo, spmv_hyb,
     tuning_select, tuning_set, tuning_load, tuning_save, tuning_clear,
     poisson5pt_num_entries, poisson5pt_shard_entries, poisson5pt_csr, poisson5pt_dia,

@@ -14,7 +14,7 @@ FORMAT_CSR, FORMAT_ELL, FORMAT_DIA, FORMAT_COO, FORMAT_HYB = 0, 1, 2, 3, 4
 F64, F32 = 0, 1
 KERNEL_AUTO = 0
 CSR_SCALAR, CSR_VECTOR, CSR_STREAM, CSR_STREAM_PIPE, CSR_BALANCED = 1, 2, 3, 4, 5
-ELL_ROW, DIA_ROW, COO_SEGMENTED, COO_LANE4 = 10, 20, 30, 31
+ELL_ROW, DIA_ROW, COO_SEGMENTED, COO_LANE4, COO_TILE = 10, 20, 30, 31, 32
 
 
 class CmiError(RuntimeError):
@@ -138,6 +138,15 @@ def _declare(L):
     L.cmi_cg_direction_f32.argtypes = [i64, vp, vp, vp, vp, vp]
     L.cmi_cg_direction_x_f32.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp]
     L.cmi_blas_dotd_f32.argtypes = [i64, vp, vp, vp, vp, vp]
+    L.cmi_plan_create.argtypes = [c_int, c_int, i64, i64, i64, vp, cfgp, vp, POINTER(c_void_p)]
+    L.cmi_plan_destroy.argtypes = [vp]
+    L.cmi_plan_config.argtypes = [vp, cfgp]
+    L.cmi_plan_info.argtypes = [vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int), POINTER(c_int)]
+    for suf in ("f64", "f32"):
+        getattr(L, f"cmi_spmv_csr_plan_{suf}").argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
+        getattr(L, f"cmi_spmv_coo_plan_{suf}").argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
+        getattr(L, f"cmi_spmv_csr_dot_plan_{suf}").argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.cmi_spmv_csr_dot_f32.argtypes = [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, cfgp, vp]
 
 
 def lib():
@@ -223,18 +232,90 @@ def spmv_csr(num_rows, num_cols, Ap, Aj, Ax, x, y, accumulate=False, cfg=None, s
              _cfg(cfg), _stream(stream)))
 
 
-def spmv_csr_dot(num_rows, num_cols, Ap, Aj, Ax, x, y, w, result, workspace, cfg=None, stream=None):
-    """y <- A x and result[0] <- <y, w> in one pass (f64; cmi_spmv_csr_dot_f64)."""
+class Plan:
+    """cmi_plan: what the library learns about one matrix before its first multiply (launch shape; CSR: row-length
+    profile; COO: row-sortedness).  Creating one synchronises the stream; multiplies through it never do."""
+
+    def __init__(self, fmt, dtype, num_rows, num_cols, num_entries, index_array=None, cfg=None, stream=None):
+        import torch
+        self._h = c_void_p()
+        if index_array is not None:
+            _need(index_array, "index_array", torch.int32)
+        code = F64 if dtype in (F64, torch.float64) else F32
+        check(lib().cmi_plan_create(fmt, code, num_rows, num_cols, num_entries, _ptr(index_array), _cfg(cfg), _stream(stream),
+                                    byref(self._h)))
+        self.format, self.dtype = fmt, code
+        self.num_rows, self.num_cols, self.num_entries = num_rows, num_cols, num_entries
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.cmi_plan_destroy(h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def config(self):
+        c = Config()
+        check(lib().cmi_plan_config(self._h, byref(c)))
+        return c
+
+    def info(self):
+        """dict: max_row_length, entries_in_long_rows (CSR; -1 otherwise), coo_sorted (COO: True/False, else None),
+        storage_order_sums (every result bit-identical to the host loop?)."""
+        a, b, s, e = c_int64(), c_int64(), c_int(), c_int()
+        check(lib().cmi_plan_info(self._h, byref(a), byref(b), byref(s), byref(e)))
+        return {"max_row_length": a.value, "entries_in_long_rows": b.value,
+                "coo_sorted": None if s.value < 0 else bool(s.value), "storage_order_sums": bool(e.value)}
+
+
+def spmv_csr_plan(plan, Ap, Aj, Ax, x, y, accumulate=False, stream=None):
+    """cmi_spmv_csr_plan_*: the multiply steered by a plan (no table lookup, no measurement, no sync)."""
     import torch
     for t, n in ((Ap, "Ap"), (Aj, "Aj")):
         _need(t, n, torch.int32)
-    for t, n in ((Ax, "Ax"), (x, "x"), (y, "y"), (w, "w"), (result, "result")):
-        _need(t, n, torch.float64)
+    for t, n in ((Ax, "Ax"), (x, "x"), (y, "y")):
+        _need(t, n, y.dtype)
+    if (Ap.numel() != plan.num_rows + 1 or x.numel() != plan.num_cols or y.numel() != plan.num_rows
+            or Aj.numel() != plan.num_entries or Ax.numel() != plan.num_entries):
+        raise ValueError("spmv_csr_plan: array lengths do not match the plan's matrix shape")
+    fn = getattr(lib(), "cmi_spmv_csr_plan_" + _suffix(y))
+    check(fn(plan.handle, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(y), int(bool(accumulate)), _stream(stream)))
+
+
+def spmv_coo_plan(plan, Ai, Aj, Ax, x, y, accumulate=False, stream=None):
+    import torch
+    for t, n in ((Ai, "Ai"), (Aj, "Aj")):
+        _need(t, n, torch.int32)
+    for t, n in ((Ax, "Ax"), (x, "x"), (y, "y")):
+        _need(t, n, y.dtype)
+    if (Ai.numel() != plan.num_entries or Aj.numel() != plan.num_entries or Ax.numel() != plan.num_entries
+            or x.numel() != plan.num_cols or y.numel() != plan.num_rows):
+        raise ValueError("spmv_coo_plan: array lengths do not match the plan's matrix shape")
+    fn = getattr(lib(), "cmi_spmv_coo_plan_" + _suffix(y))
+    check(fn(plan.handle, _ptr(Ai), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(y), int(bool(accumulate)), _stream(stream)))
+
+
+def spmv_csr_dot(num_rows, num_cols, Ap, Aj, Ax, x, y, w, result, workspace, cfg=None, stream=None, plan=None):
+    """y <- A x and result[0] <- <y, w> in one pass (cmi_spmv_csr_dot_{f64,f32}[_plan]); result is a float64 tensor
+    for both value types (f32: products and partial sums accumulate in double)."""
+    import torch
+    for t, n in ((Ap, "Ap"), (Aj, "Aj")):
+        _need(t, n, torch.int32)
+    for t, n in ((Ax, "Ax"), (x, "x"), (y, "y"), (w, "w")):
+        _need(t, n, y.dtype)
+    _need(result, "result", torch.float64)
     if (Ap.numel() != num_rows + 1 or x.numel() != num_cols or y.numel() != num_rows or w.numel() != num_rows
             or Aj.numel() != Ax.numel() or result.numel() < 1):
         raise ValueError("spmv_csr_dot: array lengths do not match the matrix shape")
-    check(lib().cmi_spmv_csr_dot_f64(num_rows, num_cols, Aj.numel(), _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(y), _ptr(w),
-                                     _ptr(result), _ptr(workspace), _cfg(cfg), _stream(stream)))
+    suf = _suffix(y)
+    if plan is not None:
+        check(getattr(lib(), "cmi_spmv_csr_dot_plan_" + suf)(plan.handle, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(y), _ptr(w),
+                                                             _ptr(result), _ptr(workspace), _stream(stream)))
+    else:
+        check(getattr(lib(), "cmi_spmv_csr_dot_" + suf)(num_rows, num_cols, Aj.numel(), _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(y),
+                                                        _ptr(w), _ptr(result), _ptr(workspace), _cfg(cfg), _stream(stream)))
 
 
 def spmv_ell_dot(num_rows, num_cols, width, pitch, Aj, Ax, x, y, w, result, workspace, row_lengths=None, cfg=None, stream=None):

@@ -358,7 +358,10 @@ coo_row_offsets_kernel(int64_t num_rows, int64_t num_entries, const int *__restr
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e <= num_entries; e += stride) {
         const int64_t prev = e > 0 ? Ai[e - 1] : -1;
         const int64_t cur = e < num_entries ? Ai[e] : num_rows;
-        if (cur < prev || cur < 0 || cur > num_rows || (e < num_entries && cur >= num_rows)) { atomicOr(unsorted, 1); continue; }
+        // prev is validated HERE too (thread e-1 also flags it, but this thread's fill loop starts at prev + 1: a negative
+        // row index in front of a valid one would otherwise write in front of Ap)
+        if (prev < -1 || (e > 0 && prev < 0) || prev >= num_rows || cur < prev || cur < 0 || cur > num_rows ||
+            (e < num_entries && cur >= num_rows)) { atomicOr(unsorted, 1); continue; }
         const int64_t hi = e < num_entries ? cur : num_rows; // rows (prev, hi] start at e (the last thread: rows beyond the last entry, and Ap[num_rows])
         for (int64_t r = prev + 1; r <= hi; r++) Ap[r] = (int)e;
     }
@@ -407,6 +410,7 @@ CMI_API int cmi_ell_row_lengths(int64_t num_rows, int64_t width, int64_t pitch, 
 namespace cmi {
 
 constexpr int kScanTile = 2048; // 256 lanes x 8
+constexpr int64_t kScanMaxCount = INT32_MAX / kScanTile; // per-row counts up to this keep a tile's int32 sum exact
 
 __global__ void __launch_bounds__(256) scan_tile_sums_kernel(int64_t n, const int *__restrict__ in, int *__restrict__ sums)
 {
@@ -424,28 +428,29 @@ __global__ void __launch_bounds__(256) scan_tile_sums_kernel(int64_t n, const in
     if (threadIdx.x == 0) sums[blockIdx.x] = slots[0] + slots[1] + slots[2] + slots[3];
 }
 
-// one workgroup: sums[] -> exclusive scan in place, the grand total to *total
+// one workgroup: sums[] -> exclusive scan in place, the grand total to *total.  The running total is kept in 64 bits:
+// a total beyond INT32_MAX (rows*width or rows*diagonals can exceed it) is reported as *total = -1, never wrapped.
 __global__ void __launch_bounds__(256) scan_sums_kernel(int64_t ntiles, int *__restrict__ sums, int *__restrict__ total)
 {
-    __shared__ int buf[256];
-    int carry = 0;
+    __shared__ long long buf[256];
+    long long carry = 0;
     for (int64_t base = 0; base < ntiles; base += 256) {
         const int64_t i = base + threadIdx.x;
-        const int v = i < ntiles ? sums[i] : 0;
+        const long long v = i < ntiles ? sums[i] : 0;
         buf[threadIdx.x] = v;
         __syncthreads();
         for (int o = 1; o < 256; o <<= 1) { // Hillis-Steele inclusive scan of 256 values
-            const int t = (int)threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
+            const long long t = (int)threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
             __syncthreads();
             buf[threadIdx.x] += t;
             __syncthreads();
         }
-        if (i < ntiles) sums[i] = carry + buf[threadIdx.x] - v;
-        const int chunk = buf[255];
+        if (i < ntiles) sums[i] = (int)(carry + buf[threadIdx.x] - v); // meaningless past an overflow; the caller stops on total < 0
+        const long long chunk = buf[255];
         __syncthreads();
         carry += chunk;
     }
-    if (threadIdx.x == 0) *total = carry;
+    if (threadIdx.x == 0) *total = carry > (long long)INT32_MAX ? -1 : (int)carry;
 }
 
 __global__ void __launch_bounds__(256) scan_apply_kernel(int64_t n, const int *__restrict__ in, const int *__restrict__ sums, int *__restrict__ out)
@@ -538,6 +543,7 @@ static int exclusive_scan_i32(int64_t n, const int *in, int *out, int64_t *total
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(sums);
     if (e != hipSuccess) return hip_fail(e, "exclusive scan");
+    if (total < 0) return fail(CMI_ERROR_NOT_SUPPORTED, "conversion to CSR: more than INT32_MAX entries (int32 row offsets cannot address them)");
     if (total_host) *total_host = total;
     return CMI_SUCCESS;
 }
@@ -546,14 +552,15 @@ template <typename T>
 static int ell_to_csr(int64_t rows, int64_t width, int64_t pitch, const int *eAj, const T *eAx, int *Ap, int *Aj, T *Ax,
                       int64_t capacity, int64_t *nnz_host, void *stream)
 {
-    if (rows < 0 || width < 0 || width > INT32_MAX || (width > 0 && pitch < rows)) return fail(CMI_ERROR_INVALID_VALUE, "cmi_ell_to_csr: bad size");
+    if (rows < 0 || width < 0 || width > kScanMaxCount || (width > 0 && pitch < rows)) return fail(CMI_ERROR_INVALID_VALUE, "cmi_ell_to_csr: bad size");
     if (!Ap || !nnz_host || (rows > 0 && width > 0 && (!eAj || !eAx))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_ell_to_csr: null array");
     hipStream_t s = as_stream(stream);
     int *counts = nullptr;
     CMI_HIP(hipMalloc((void **)&counts, (size_t)(rows > 0 ? rows : 1) * sizeof(int)));
     if (rows > 0) hipLaunchKernelGGL(ell_valid_counts_kernel, dim3(grid_1d(rows)), dim3(256), 0, s, rows, (int)width, pitch, eAj, counts);
     int st = exclusive_scan_i32(rows, counts, Ap, nnz_host, s);
-    if (st == CMI_SUCCESS && *nnz_host > 0 && Aj && Ax && *nnz_host <= capacity) { // Aj == NULL: a sizing call
+    if (st == CMI_SUCCESS && Aj && Ax && *nnz_host > capacity) st = fail(CMI_ERROR_INVALID_VALUE, "cmi_ell_to_csr: capacity is smaller than the entry count");
+    if (st == CMI_SUCCESS && *nnz_host > 0 && Aj && Ax) { // Aj == NULL: a sizing call
         hipLaunchKernelGGL((ell_to_csr_kernel<T>), dim3(grid_1d(rows)), dim3(256), 0, s, rows, (int)width, pitch, eAj, eAx, Ap, Aj, Ax);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) st = fail(CMI_ERROR_HIP, "cmi_ell_to_csr: scatter failed");
     }
@@ -565,14 +572,15 @@ template <typename T>
 static int dia_to_csr(int64_t rows, int64_t cols, int64_t nd, int64_t pitch, const int *offsets, const T *vals, int *Ap, int *Aj, T *Ax,
                       int64_t capacity, int64_t *nnz_host, void *stream)
 {
-    if (rows < 0 || cols < 0 || nd < 0 || nd > INT32_MAX || (nd > 0 && pitch < rows)) return fail(CMI_ERROR_INVALID_VALUE, "cmi_dia_to_csr: bad size");
+    if (rows < 0 || cols < 0 || nd < 0 || nd > kScanMaxCount || (nd > 0 && pitch < rows)) return fail(CMI_ERROR_INVALID_VALUE, "cmi_dia_to_csr: bad size");
     if (!Ap || !nnz_host || (rows > 0 && nd > 0 && (!offsets || !vals))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_dia_to_csr: null array");
     hipStream_t s = as_stream(stream);
     int *counts = nullptr;
     CMI_HIP(hipMalloc((void **)&counts, (size_t)(rows > 0 ? rows : 1) * sizeof(int)));
     if (rows > 0) hipLaunchKernelGGL((dia_valid_counts_kernel<T>), dim3(grid_1d(rows)), dim3(256), 0, s, rows, cols, (int)nd, pitch, offsets, vals, counts);
     int st = exclusive_scan_i32(rows, counts, Ap, nnz_host, s);
-    if (st == CMI_SUCCESS && *nnz_host > 0 && Aj && Ax && *nnz_host <= capacity) {
+    if (st == CMI_SUCCESS && Aj && Ax && *nnz_host > capacity) st = fail(CMI_ERROR_INVALID_VALUE, "cmi_dia_to_csr: capacity is smaller than the entry count");
+    if (st == CMI_SUCCESS && *nnz_host > 0 && Aj && Ax) {
         hipLaunchKernelGGL((dia_to_csr_kernel<T>), dim3(grid_1d(rows)), dim3(256), 0, s, rows, cols, (int)nd, pitch, offsets, vals, Ap, Aj, Ax);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) st = fail(CMI_ERROR_HIP, "cmi_dia_to_csr: scatter failed");
     }
@@ -614,7 +622,7 @@ template <typename T>
 static int hyb_to_csr(int64_t rows, int64_t width, int64_t pitch, const int *eAj, const T *eAx, int64_t ncoo, const int *cAi,
                       const int *cAj, const T *cAx, int *Ap, int *Aj, T *Ax, int64_t capacity, int64_t *nnz_host, void *stream)
 {
-    if (rows < 0 || width < 0 || width > INT32_MAX || ncoo < 0 || ncoo > INT32_MAX || (width > 0 && pitch < rows))
+    if (rows < 0 || width < 0 || width > kScanMaxCount / 2 || ncoo < 0 || ncoo > INT32_MAX / 2 || (width > 0 && pitch < rows))
         return fail(CMI_ERROR_INVALID_VALUE, "cmi_hyb_to_csr: bad size");
     if (!Ap || !nnz_host || (rows > 0 && width > 0 && (!eAj || !eAx)) || (ncoo > 0 && (!cAi || !cAj || !cAx)))
         return fail(CMI_ERROR_INVALID_VALUE, "cmi_hyb_to_csr: null array");
@@ -636,7 +644,8 @@ static int hyb_to_csr(int64_t rows, int64_t width, int64_t pitch, const int *eAj
         if (rows > 0) hipLaunchKernelGGL(hyb_counts_kernel, dim3(grid_1d(rows)), dim3(256), 0, s, rows, (int)width, pitch, eAj, coo_off, counts);
         st = exclusive_scan_i32(rows, counts, Ap, nnz_host, s);
     }
-    if (st == CMI_SUCCESS && *nnz_host > 0 && Aj && Ax && *nnz_host <= capacity) {
+    if (st == CMI_SUCCESS && Aj && Ax && *nnz_host > capacity) st = fail(CMI_ERROR_INVALID_VALUE, "cmi_hyb_to_csr: capacity is smaller than the entry count");
+    if (st == CMI_SUCCESS && *nnz_host > 0 && Aj && Ax) {
         hipLaunchKernelGGL((hyb_to_csr_kernel<T>), dim3(grid_1d(rows)), dim3(256), 0, s, rows, (int)width, pitch, eAj, eAx, coo_off, cAj, cAx, Ap, Aj, Ax);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) st = fail(CMI_ERROR_HIP, "cmi_hyb_to_csr: scatter failed");
     }

@@ -53,6 +53,13 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 void select_config(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
                    const cmi_config *user, cmi_config *out);
 
+// row-length profile of a CSR matrix (spmv_csr.hip): longest row, entries sitting in rows of kLongRowMin or more
+struct row_profile { int64_t max_len = -1, in_long = 0; }; // max_len < 0: not measured
+int measure_row_lengths(int64_t rows, const int *Ap, hipStream_t s, int64_t *max_len, int64_t *entries_in_long_rows);
+bool prefers_balanced(int64_t rows, int64_t nnz, const row_profile &pr, size_t value_bytes, bool strict_order);
+// are the row indices of a COO matrix non-decreasing and inside [0, rows)?  (spmv_coo_hyb.hip; synchronises the stream)
+int coo_rows_sorted(int64_t rows, int64_t nnz, const int *Ai, hipStream_t s, int *sorted);
+
 // Deterministic fold of `npartial` (<= kPartialCapacity) doubles at the start of a
 // cmi_blas_workspace_bytes() buffer into *result (blas1.hip; fixed tree, no atomics).
 constexpr int kPartialCapacity = 1 << 16;
@@ -95,6 +102,14 @@ __device__ __forceinline__ int64_t tile_of_block(int64_t b, int64_t tiles_per_xc
     return ((q / C) * kXcds + r) * C + q % C;
 }
 
+// grid of a tile kernel: one workgroup per tile, padded so that tile_of_block maps whole chunk rounds
+inline int64_t padded_grid(int64_t tiles, int swizzle)
+{
+    if (swizzle <= 0) return tiles;
+    if (swizzle == 1) return ceil_div(tiles, kXcds) * kXcds;
+    return ceil_div(tiles, (int64_t)kXcds * swizzle) * kXcds * swizzle;
+}
+
 template <typename T> struct vec2;
 template <> struct vec2<double> { typedef double __attribute__((ext_vector_type(2))) type; };
 template <> struct vec2<float>  { typedef float  __attribute__((ext_vector_type(2))) type; };
@@ -132,3 +147,13 @@ template <typename F> inline void with_policy(int pol, F f)
 }
 
 } // namespace cmi
+
+// The plan object of include/cusp_mi355x.h (plan.hip): what the library learnt about one matrix.  Plain data, read-only
+// after cmi_plan_create; owns no device memory.
+struct cmi_plan {
+    int format, dtype;
+    int64_t rows, cols, nnz;
+    cmi_config cfg;        // resolved launch shape (kernel CMI_CSR_BALANCED when the profile switched kernels)
+    cmi::row_profile prof; // CSR
+    int coo_sorted;        // COO: 1 / 0; -1 otherwise
+};

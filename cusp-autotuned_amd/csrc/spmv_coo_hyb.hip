@@ -200,18 +200,187 @@ coo_lane4_kernel(int64_t num_entries, const int *__restrict__ Ai, const int *__r
     if (lane == 0) emit(carry_row, carry_val);
 }
 
+// ---------------------------------------------------------------------------------------------
+// coo_tile: ROW-SORTED entries, no zero fill, no atomics, storage-order sums
+// ---------------------------------------------------------------------------------------------
+// The order-agnostic kernels above pay for not knowing the order: y is zero-filled first (80 MB on the headline
+// matrix) and every run end is a read-modify-write at the memory side -- 1.10 GB moved for 0.96 GB of compulsory bytes
+// (profiles/r02_formats_pmc.json).  The reference's contract for coo_matrix IS sorted entries (cusp/coo_matrix.h:72);
+// a plan (plan.hip) checks that once, and then this kernel runs.
+//
+// A workgroup of 256 lanes owns tile t = entries [E0, E1) = 1024 consecutive entries, and with them every row that
+// STARTS there (rows whose first entry lies in [E0, E1)), plus the rows without entries in front of each such row;
+// the last tile also owns the empty rows behind the last entry.  Owned rows are a contiguous range
+// [Rfirst, Rlast] = [row(E0 - 1) + 1, row(E1 - 1)] known from two uniform loads, so:
+//   1. every lane loads four entries as 16-byte vectors (row, column, value), gathers x, parks products and row
+//      indices in LDS; sixteen lanes also park the 64 entries BEHIND the tile (the tail of the row that straddles
+//      into the next tile -- those lines are the neighbour's, an L2 hit when the tiles share an XCD);  the y window
+//      yl[] of the owned rows starts at 0 (or at y, when accumulating);
+//   2. barrier; a lane whose entry k starts a row adds that row's products from LDS IN STORAGE ORDER -- the host
+//      loop's order (sequential/multiply/coo_spmv.h:60-66: y[i] = y[i] + V*x for the entries as stored), so the
+//      result is bit-identical to it -- walking on into the parked tail and, for rows longer than that, straight
+//      through the arrays;
+//   3. barrier; the window is stored as whole contiguous runs of y (nt hint), empty rows included.
+// More owned rows than the window holds (runs of empty rows): the window moves on, cooperatively.
+constexpr int kCooTile = 1024, kCooTail = 64, kCooWindow = 1024, kCooBlock = 256;
+
+template <typename T, int POL, bool ACC>
+__global__ void __launch_bounds__(kCooBlock)
+coo_tile_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ Ai, const int *__restrict__ Aj,
+                const T *__restrict__ Ax, const T *__restrict__ x, T *__restrict__ y, int64_t tiles, int64_t tiles_per_xcd,
+                int swizzle)
+{
+    constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
+    __shared__ __attribute__((aligned(16))) T prod[kCooTile + kCooTail];
+    __shared__ int rowidx[1 + kCooTile + kCooTail + 1]; // [0]: row of entry E0 - 1; [1 + k]: row of entry E0 + k; one sentinel behind
+    __shared__ T yl[kCooWindow];
+    const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle);
+    if (tile >= tiles) return;
+    const int tid = threadIdx.x;
+    const int64_t E0 = tile * kCooTile;
+    const int64_t E1 = E0 + kCooTile < num_entries ? E0 + kCooTile : num_entries;
+    const int n_main = (int)(E1 - E0);
+    const int n_tail = (int)((num_entries - E1) < kCooTail ? (num_entries - E1) : kCooTail);
+    // owned rows (uniform loads).  Clamped into [0, num_rows): with the sorted, in-range indices a plan vouches for the
+    // clamps never bind; with anything else they keep every access inside y.
+    int64_t prev_row = E0 > 0 ? Ai[E0 - 1] : -1;
+    int64_t last_row = E1 == num_entries ? num_rows - 1 : Ai[E1 - 1];
+    if (prev_row < -1) prev_row = -1;
+    if (prev_row >= num_rows) prev_row = num_rows - 1;
+    if (last_row >= num_rows) last_row = num_rows - 1;
+    const int64_t Rfirst = prev_row + 1;
+
+    // ---- 1. stream the tile (+ its tail) into LDS --------------------------------------------------------------
+    auto park = [&](int64_t e, int slot, int live) { // entries [e, e + 4) -> slots [slot, slot + 4); `live` of them exist
+        int r[4];
+        T p[4];
+        if (live == 4) {
+            const int4v rv = ld<NT>(reinterpret_cast<const int4v *>(Ai + e));
+            const int4v cv = ld<NT>(reinterpret_cast<const int4v *>(Aj + e));
+            r[0] = rv.x; r[1] = rv.y; r[2] = rv.z; r[3] = rv.w;
+            if constexpr (sizeof(T) == 8) {
+                const double2v a = ld<NT>(reinterpret_cast<const double2v *>(Ax + e));
+                const double2v b = ld<NT>(reinterpret_cast<const double2v *>(Ax + e + 2));
+                p[0] = a.x * x[cv.x]; p[1] = a.y * x[cv.y]; p[2] = b.x * x[cv.z]; p[3] = b.y * x[cv.w];
+            } else {
+                const float4v a = ld<NT>(reinterpret_cast<const float4v *>(Ax + e));
+                p[0] = a.x * x[cv.x]; p[1] = a.y * x[cv.y]; p[2] = a.z * x[cv.z]; p[3] = a.w * x[cv.w];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                r[k] = k < live ? Ai[e + k] : -2; // -2: no such entry (never equal to a row)
+                p[k] = k < live ? Ax[e + k] * x[Aj[e + k]] : T(0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { prod[slot + k] = p[k]; rowidx[1 + slot + k] = r[k]; }
+    };
+    {
+        const int k0 = tid * 4;
+        const int live = n_main - k0 >= 4 ? 4 : (n_main - k0 > 0 ? n_main - k0 : 0);
+        park(E0 + k0, k0, live);
+        if (tid < kCooTail / 4) {
+            const int t0 = tid * 4;
+            const int tl = n_tail - t0 >= 4 ? 4 : (n_tail - t0 > 0 ? n_tail - t0 : 0);
+            park(E1 + t0, kCooTile + t0, n_main == kCooTile ? tl : 0); // a short (last) tile has nothing behind it
+        }
+        if (tid == kCooBlock - 1) { rowidx[0] = (int)prev_row; rowidx[1 + kCooTile + kCooTail] = -2; }
+    }
+
+    // ---- 2./3. windows of owned rows ------------------------------------------------------------------------------
+    for (int64_t w0 = Rfirst; w0 <= last_row; w0 += kCooWindow) {
+        const int wn = (int)((last_row - w0 + 1) < kCooWindow ? (last_row - w0 + 1) : kCooWindow);
+        for (int i = tid; i < wn; i += kCooBlock) yl[i] = ACC ? y[w0 + i] : T(0);
+        __syncthreads(); // products, row indices (first window) and the window's start values are in LDS
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int k = tid * 4 + i;
+            if (k >= n_main) break;
+            const int R = rowidx[1 + k];
+            if (R == rowidx[k]) continue;                   // not the first entry of its row
+            if (R < w0 || R >= w0 + wn) continue;           // another window's row (or an index a plan would have refused)
+            T s = yl[R - w0];
+            int j = k;
+            while (rowidx[1 + j] == R) { s = s + prod[j]; j++; } // ends at another row, a missing entry (-2) or the sentinel
+            if (j == kCooTile + kCooTail) {                 // longer than tile + parked tail: on through the arrays
+                for (int64_t e = E0 + j; e < num_entries && Ai[e] == R; e++) s = s + Ax[e] * x[Aj[e]];
+            }
+            yl[R - w0] = s;
+        }
+        __syncthreads();
+        for (int i = tid; i < wn; i += kCooBlock) st<NTS>(y + w0 + i, yl[i]);
+        if (w0 + kCooWindow <= last_row) __syncthreads(); // the next window reuses yl
+    }
+}
+
+// Row indices non-decreasing and inside [0, rows)?  One pass, a flag.
+__global__ void __launch_bounds__(256)
+coo_sorted_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ Ai, int *__restrict__ bad)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int mine = 0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < num_entries; e += stride) {
+        const int r = Ai[e];
+        mine |= r < 0 || r >= num_rows || (e > 0 && Ai[e - 1] > r);
+    }
+    if (__any(mine) && (threadIdx.x & (kWave - 1)) == 0) atomicOr(bad, 1);
+}
+
+int coo_rows_sorted(int64_t rows, int64_t nnz, const int *Ai, hipStream_t s, int *sorted)
+{
+    *sorted = 0;
+    int *flag = nullptr;
+    CMI_HIP(hipMalloc((void **)&flag, sizeof(int)));
+    int host = 1;
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), s);
+    if (e == hipSuccess) {
+        int64_t blocks = ceil_div(nnz, 256 * 8);
+        if (blocks > kCus * 16) blocks = kCus * 16;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(coo_sorted_kernel, dim3((unsigned)blocks), dim3(256), 0, s, rows, nnz, Ai, flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&host, flag, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(flag);
+    if (e != hipSuccess) return hip_fail(e, "coo order check");
+    *sorted = host == 0;
+    return CMI_SUCCESS;
+}
+
 template <typename T>
 static int spmv_coo(int dtype, int64_t rows, int64_t cols, int64_t nnz, const int *Ai, const int *Aj, const T *Ax,
-                    const T *x, T *y, int accumulate, const cmi_config *user, void *stream)
+                    const T *x, T *y, int accumulate, const cmi_config *user, void *stream, const cmi_plan *plan = nullptr)
 {
     if (rows < 0 || cols < 0 || nnz < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_coo: negative size");
     if (rows > INT32_MAX || cols > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_coo: sizes exceed the int32 index type");
     if (rows == 0) return CMI_SUCCESS;
     if (!y || (nnz > 0 && (!Ai || !Aj || !Ax || !x))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_coo: null array");
     cmi_config c;
-    select_config(CMI_FORMAT_COO, dtype, rows, cols, nnz, user, &c);
-    if (c.kernel != CMI_COO_SEGMENTED && c.kernel != CMI_COO_LANE4) return fail(CMI_ERROR_NOT_SUPPORTED, "cmi_spmv_coo: config.kernel is not a COO kernel");
+    if (plan) c = plan->cfg;
+    else select_config(CMI_FORMAT_COO, dtype, rows, cols, nnz, user, &c);
+    if (c.kernel != CMI_COO_SEGMENTED && c.kernel != CMI_COO_LANE4 && c.kernel != CMI_COO_TILE)
+        return fail(CMI_ERROR_NOT_SUPPORTED, "cmi_spmv_coo: config.kernel is not a COO kernel");
     hipStream_t s = as_stream(stream);
+    const bool aligned = reinterpret_cast<uintptr_t>(Ai) % 16 == 0 && reinterpret_cast<uintptr_t>(Aj) % 16 == 0 &&
+                         reinterpret_cast<uintptr_t>(Ax) % 16 == 0;
+    if (c.kernel == CMI_COO_TILE && aligned && nnz > 0) { // sorted entries (a plan checked, or the caller's explicit config vouches)
+        if (nnz > INT32_MAX - 4096) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_coo: too many entries for the tile kernel");
+        const int64_t tiles = ceil_div(nnz, kCooTile);
+        const int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
+        const int64_t tpx = ceil_div(tiles, kXcds);
+        const int64_t grid64 = padded_grid(tiles, swz);
+        if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_coo: grid too large");
+        with_policy(c.nontemporal & 3, [&](auto P) {
+            constexpr int POL = decltype(P)::value;
+            if (accumulate) hipLaunchKernelGGL((coo_tile_kernel<T, POL, true>), dim3((unsigned)grid64), dim3(kCooBlock), 0, s, rows, nnz, Ai, Aj, Ax, x, y, tiles, tpx, swz);
+            else            hipLaunchKernelGGL((coo_tile_kernel<T, POL, false>), dim3((unsigned)grid64), dim3(kCooBlock), 0, s, rows, nnz, Ai, Aj, Ax, x, y, tiles, tpx, swz);
+        });
+        CMI_LAUNCH_CHECK("coo tile spmv");
+        return CMI_SUCCESS;
+    }
+    if (c.kernel == CMI_COO_TILE) { c.kernel = CMI_COO_LANE4; if (c.items_per_thread > 32 || c.items_per_thread < 1) c.items_per_thread = 4; } // unaligned views / no entries: the order-agnostic path
     // y = initialize(y): zero bytes are +0.0 (sequential/multiply/coo_spmv.h:56-57)
     if (!accumulate) CMI_HIP(hipMemsetAsync(y, 0, (size_t)rows * sizeof(T), s));
     if (nnz == 0) return CMI_SUCCESS;
@@ -219,8 +388,6 @@ static int spmv_coo(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     const int steps = c.items_per_thread < 1 ? 1 : c.items_per_thread; // steps per wave interval
     const int waves_per_block = block / kWave;
     const bool nt = (c.nontemporal & kPolLoadNT) != 0;
-    const bool aligned = reinterpret_cast<uintptr_t>(Ai) % 16 == 0 && reinterpret_cast<uintptr_t>(Aj) % 16 == 0 &&
-                         reinterpret_cast<uintptr_t>(Ax) % 16 == 0;
     if (c.kernel == CMI_COO_LANE4 && aligned) {
         const int64_t interval = (int64_t)steps * 4 * kWave; // 256 entries per step
         const int64_t grid64 = ceil_div(ceil_div(nnz, interval), waves_per_block);
@@ -251,6 +418,21 @@ CMI_API int cmi_spmv_coo_f32(int64_t num_rows, int64_t num_cols, int64_t num_ent
                              const cmi_config *cfg, void *stream)
 {
     return cmi::spmv_coo<float>(CMI_F32, num_rows, num_cols, num_entries, Ai, Aj, Ax, x, y, accumulate, cfg, stream);
+}
+
+CMI_API int cmi_spmv_coo_plan_f64(const cmi_plan *plan, const int32_t *Ai, const int32_t *Aj, const double *Ax,
+                                  const double *x, double *y, int accumulate, void *stream)
+{
+    if (!plan || plan->format != CMI_FORMAT_COO || plan->dtype != CMI_F64)
+        return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_coo_plan_f64: null plan, or a plan made for another format or value type");
+    return cmi::spmv_coo<double>(CMI_F64, plan->rows, plan->cols, plan->nnz, Ai, Aj, Ax, x, y, accumulate, nullptr, stream, plan);
+}
+CMI_API int cmi_spmv_coo_plan_f32(const cmi_plan *plan, const int32_t *Ai, const int32_t *Aj, const float *Ax,
+                                  const float *x, float *y, int accumulate, void *stream)
+{
+    if (!plan || plan->format != CMI_FORMAT_COO || plan->dtype != CMI_F32)
+        return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_coo_plan_f32: null plan, or a plan made for another format or value type");
+    return cmi::spmv_coo<float>(CMI_F32, plan->rows, plan->cols, plan->nnz, Ai, Aj, Ax, x, y, accumulate, nullptr, stream, plan);
 }
 
 // HYB = ELL part with the caller's accumulate, then the COO part accumulating on top, same stream.

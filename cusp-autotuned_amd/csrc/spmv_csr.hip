@@ -124,17 +124,19 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
     const int64_t r0 = tile * rows_per_block;
     const int nr = (int)((num_rows - r0) < rows_per_block ? (num_rows - r0) : rows_per_block);
 
-    for (int i = tid; i <= nr; i += block) rowptr[i] = Ap[r0 + i];
-    __syncthreads();
-    const int nz0 = rowptr[0], nz1 = rowptr[nr];
-
     // ---- fast path (wave-uniform test): the whole tile fits ONE LDS pass of one vector per lane,
     // every row has its own lane and the tile's last vector lies inside the arrays.  This is the
     // shape the tuned short-row configurations produce; it is the general code below with every
     // loop peeled away (measured 3-4 % faster on the 5-point Poisson matrix, same arithmetic).
+    // Row pointers stay in REGISTERS here: the tile bounds come from two uniform (scalar) loads, each lane
+    // loads the two offsets of its own row, and nothing waits at a barrier before the index / value
+    // vectors are requested -- 126.5 us instead of 129.0 on the headline matrix (tools/r2_probe.hip,
+    // profiles/r02_probe_timing.txt: csrx flags 1 vs 0), same bits.
     if constexpr (VEC && IPT == 1) {
+        const int nz0 = Ap[r0], nz1 = Ap[r0 + nr];
         const int fbase = nz0 & ~3;
         if (tpr == 1 && nr <= block && nz1 - fbase <= tile_entries && (int64_t)((nz1 + 3) & ~3) <= num_entries) {
+            const int a = Ap[r0 + (tid < nr ? tid : nr)], b = Ap[r0 + (tid + 1 < nr ? tid + 1 : nr)];
             const int e = fbase + tid * 4;
             T p0 = T(0), p1 = T(0), p2 = T(0), p3 = T(0);
             if (e < nz1) {
@@ -155,7 +157,6 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
             double d = 0.0;
             if (tid < nr) {
                 T s = accumulate ? y[r0 + tid] : T(0);
-                const int a = rowptr[tid], b = rowptr[tid + 1];
                 for (int j = a; j < b; j++) s = s + prod[j - fbase];
                 st<(POL & kPolStoreNT) != 0>(y + r0 + tid, s);
                 if constexpr (DOT) d = (double)s * (double)wv;
@@ -167,6 +168,11 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
             return;
         }
     }
+
+    for (int i = tid; i <= nr; i += block) rowptr[i] = Ap[r0 + i];
+    __syncthreads();
+    const int nz0 = rowptr[0], nz1 = rowptr[nr];
+    (void)nz0; (void)nz1;
 
     // tpr lanes share a row (tpr = 1: one lane per row, storage order, bit-exact; tpr > 1 for long
     // rows: lane-strided partial sums + a butterfly inside the tpr-lane group).  A group owns rows
@@ -702,7 +708,7 @@ __global__ void __launch_bounds__(256) max_row_length_kernel(int64_t num_rows, c
     }
 }
 
-static int measure_row_lengths(int64_t rows, const int *Ap, hipStream_t s, int64_t *max_len, int64_t *entries_in_long_rows)
+int measure_row_lengths(int64_t rows, const int *Ap, hipStream_t s, int64_t *max_len, int64_t *entries_in_long_rows)
 {
     unsigned long long *dev = nullptr;
     CMI_HIP(hipMalloc((void **)&dev, 2 * sizeof(unsigned long long)));
@@ -723,46 +729,12 @@ static int measure_row_lengths(int64_t rows, const int *Ap, hipStream_t s, int64
     return CMI_SUCCESS;
 }
 
-struct row_profile { int64_t max_len = -1, in_long = 0; }; // max_len < 0: not available
-struct profile_entry { const void *ap; int64_t rows, nnz; int device; row_profile prof; uint64_t stamp; };
-static std::mutex g_profile_mu;
-static profile_entry g_profiles[64];
-static uint64_t g_profile_clock = 0;
-
-static bool profile_enabled()
-{
-    static const bool on = [] { const char *e = std::getenv("CMI_CSR_PROFILE"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
-// row-length profile of the matrix, from the cache or measured now; max_len < 0 if it cannot be had (stream is capturing)
-static row_profile cached_row_profile(int64_t rows, int64_t nnz, const int *Ap, hipStream_t s)
-{
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess) return {};
-    {
-        std::lock_guard<std::mutex> lk(g_profile_mu);
-        for (auto &p : g_profiles)
-            if (p.ap == Ap && p.rows == rows && p.nnz == nnz && p.device == device && p.stamp) { p.stamp = ++g_profile_clock; return p.prof; }
-    }
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return {};
-    row_profile pr;
-    if (measure_row_lengths(rows, Ap, s, &pr.max_len, &pr.in_long) != CMI_SUCCESS) return {};
-    std::lock_guard<std::mutex> lk(g_profile_mu);
-    profile_entry *victim = &g_profiles[0];
-    for (auto &p : g_profiles)
-        if (p.stamp < victim->stamp) victim = &p;
-    *victim = profile_entry{Ap, rows, nnz, device, pr, ++g_profile_clock};
-    return pr;
-}
-
 // cost of the longest row inside the row-tile kernel vs the whole multiply at streaming speed.  The row's
 // workgroup streams it cooperatively (kLongRowUs per entry: 1.2-2.4 ns measured, one workgroup is latency-bound at
 // ~10 GB/s; tools/irregular_probe.py --sweep, profiles/r01_irregular_rows.txt); with
 // threads_per_row == 1 asked for, one lane adds it in storage order (kSerialRowUs per entry).
 constexpr double kLongRowUs = 0.002, kSerialRowUs = 0.012;
-static bool prefers_balanced(int64_t rows, int64_t nnz, const row_profile &pr, size_t value_bytes, bool strict_order)
+bool prefers_balanced(int64_t rows, int64_t nnz, const row_profile &pr, size_t value_bytes, bool strict_order)
 {
     const double stream_us = ((double)nnz * (4 + value_bytes) + (double)rows * (4 + 2 * value_bytes)) / 5.0e6; // 5 TB/s
     const double floor_us = 20.0; // launch + latency floor of any multiply
@@ -823,10 +795,12 @@ static int launch_stream_ipt(int ipt, int grid, int block, size_t lds, hipStream
     return CMI_SUCCESS;
 }
 
+// `plan` (may be NULL): the matrix's resolved launch shape and row-length profile (plan.hip).  Without one the table's
+// row-tile kernel runs whatever the row lengths -- nothing is measured, allocated or waited for inside a multiply.
 template <typename T>
 static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const int *Ap, const int *Aj, const T *Ax,
                     const T *x, T *y, int accumulate, const cmi_config *user, void *stream, const T *w = nullptr,
-                    double *dot_partial = nullptr, int *dot_partials = nullptr)
+                    double *dot_partial = nullptr, int *dot_partials = nullptr, const cmi_plan *plan = nullptr)
 {
     // w != nullptr: the caller wants <y, w> too.  *dot_partials = number of per-tile partials the kernel
     // left in dot_partial, or 0 when the selected kernel cannot fuse it (the caller then runs a plain dot).
@@ -838,18 +812,13 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     if (!Ap || !y || (nnz > 0 && (!Aj || !Ax || !x)))
         return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_csr: null array");
     cmi_config c;
-    select_config(CMI_FORMAT_CSR, dtype, rows, cols, nnz, user, &c);
+    int64_t known_max_len = -1; // the matrix's longest row: known only through a plan
+    if (plan) {
+        c = plan->cfg; // resolved at plan creation (table / caller's config, completed; balanced if the profile says so)
+        known_max_len = plan->prof.max_len;
+    } else
+        select_config(CMI_FORMAT_CSR, dtype, rows, cols, nnz, user, &c);
     hipStream_t s = as_stream(stream);
-    int64_t known_max_len = -1; // the matrix's longest row once the profile has been consulted
-    if ((!user || user->kernel == CMI_KERNEL_AUTO) && nnz > 0 && profile_enabled()) {
-        const row_profile pr = cached_row_profile(rows, nnz, Ap, s);
-        known_max_len = pr.max_len;
-        if (pr.max_len >= 0 && prefers_balanced(rows, nnz, pr, sizeof(T), c.threads_per_row == 1)) {
-            c.kernel = CMI_CSR_BALANCED;
-            c.items_per_thread = 0; // the table's row-tile launch shape does not apply: balanced defaults
-            c.blocks_per_cu = 0;
-        }
-    }
     const int block = c.block_size;
     const int pol = c.nontemporal & 3;
     int st = CMI_SUCCESS;
@@ -887,23 +856,17 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         const size_t lds = (size_t)block * ipt * 4 * sizeof(T) + (size_t)(rpb + 1) * sizeof(int);
         if (lds > 160 * 1024) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream: tile does not fit 160 KiB of LDS");
         const bool vec = (reinterpret_cast<uintptr_t>(Aj) % 16 == 0) && (reinterpret_cast<uintptr_t>(Ax) % 16 == 0);
-        const bool dot = w && dot_partial && vec && tiles <= kPartialCapacity && std::is_same<T, double>::value;
-        // the LONG instance only for a matrix whose profile (cached per matrix; a stale or missing one costs speed,
-        // never correctness: the ordinary instance sums any row, one lane or lane group at a time) shows such a row
-        bool lng = false;
-        if (long_len > 0 && nnz >= long_len && profile_enabled()) {
-            if (known_max_len < 0) known_max_len = cached_row_profile(rows, nnz, Ap, s).max_len;
-            lng = known_max_len >= long_len;
-        }
+        const bool dot = w && dot_partial && vec && tiles <= kPartialCapacity;
+        // the LONG instance only for a matrix whose plan shows such a row (no plan: the ordinary instance, which sums
+        // any row, one lane or lane group at a time -- correct, slow on a long row)
+        const bool lng = long_len > 0 && nnz >= long_len && known_max_len >= long_len;
 #define CMI_STREAM_GO(VEC_, DOT_, LONG_, ...) \
     launch_stream_ipt<T, VEC_, POL, DOT_, LONG_>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate, tpr, long_len, ##__VA_ARGS__)
         with_policy(pol, [&](auto P) {
             constexpr int POL = decltype(P)::value;
-            if constexpr (std::is_same<T, double>::value) {
-                if (dot) {
-                    st = lng ? CMI_STREAM_GO(true, true, true, w, dot_partial) : CMI_STREAM_GO(true, true, false, w, dot_partial);
-                    return;
-                }
+            if (dot) {
+                st = lng ? CMI_STREAM_GO(true, true, true, w, dot_partial) : CMI_STREAM_GO(true, true, false, w, dot_partial);
+                return;
             }
             if (vec) st = lng ? CMI_STREAM_GO(true, false, true) : CMI_STREAM_GO(true, false, false);
             else     st = lng ? CMI_STREAM_GO(false, false, true) : CMI_STREAM_GO(false, false, false);
@@ -967,29 +930,82 @@ CMI_API int cmi_spmv_csr_f64(int64_t num_rows, int64_t num_cols, int64_t num_ent
 {
     return cmi::spmv_csr<double>(CMI_F64, num_rows, num_cols, num_entries, Ap, Aj, Ax, x, y, accumulate, cfg, stream);
 }
+CMI_API int cmi_spmv_csr_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ap,
+                             const int32_t *Aj, const float *Ax, const float *x, float *y, int accumulate,
+                             const cmi_config *cfg, void *stream)
+{
+    return cmi::spmv_csr<float>(CMI_F32, num_rows, num_cols, num_entries, Ap, Aj, Ax, x, y, accumulate, cfg, stream);
+}
+
+namespace cmi {
+static int plan_is_csr(const cmi_plan *plan, int dtype, const char *who)
+{
+    if (!plan) { set_error("%s: null plan", who); return CMI_ERROR_INVALID_VALUE; }
+    if (plan->format != CMI_FORMAT_CSR || plan->dtype != dtype) { set_error("%s: the plan was made for another format or value type", who); return CMI_ERROR_INVALID_VALUE; }
+    return CMI_SUCCESS;
+}
 
 // y <- A x and *dot_dev <- <y, w> in one pass where the selected kernel can (csr_stream, aligned
-// arrays); otherwise the plain SpMV followed by cmi_blas_dot_f64.  Either way deterministic.
-CMI_API int cmi_spmv_csr_dot_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ap,
-                                 const int32_t *Aj, const double *Ax, const double *x, double *y, const double *w,
-                                 double *dot_dev, void *workspace, const cmi_config *cfg, void *stream)
+// arrays); otherwise the plain SpMV followed by the library's dot.  Either way deterministic.
+template <typename T>
+static int spmv_csr_dot(int dtype, int64_t rows, int64_t cols, int64_t nnz, const int *Ap, const int *Aj, const T *Ax, const T *x,
+                        T *y, const T *w, double *dot_dev, void *workspace, const cmi_config *cfg, void *stream, const cmi_plan *plan)
 {
-    if ((!w && num_rows > 0) || !dot_dev || !workspace) return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_csr_dot: null w, result or workspace");
+    if ((!w && rows > 0) || !dot_dev || !workspace) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_csr_dot: null w, result or workspace");
     int partials = 0;
-    const int st = cmi::spmv_csr<double>(CMI_F64, num_rows, num_cols, num_entries, Ap, Aj, Ax, x, y, 0, cfg, stream, w,
-                                         (double *)workspace, &partials);
+    const int st = spmv_csr<T>(dtype, rows, cols, nnz, Ap, Aj, Ax, x, y, 0, cfg, stream, w, (double *)workspace, &partials, plan);
     if (st) return st;
     if (partials > 0) {
-        const int st2 = cmi::reduce_partials_f64(partials, (double *)workspace, dot_dev, cmi::as_stream(stream));
+        const int st2 = reduce_partials_f64(partials, (double *)workspace, dot_dev, as_stream(stream));
         if (st2) return st2;
         CMI_LAUNCH_CHECK("csr spmv dot");
         return CMI_SUCCESS;
     }
-    return cmi_blas_dot_f64(num_rows, y, w, dot_dev, workspace, stream);
+    if constexpr (std::is_same<T, double>::value) return cmi_blas_dot_f64(rows, y, w, dot_dev, workspace, stream);
+    else return cmi_blas_dotd_f32(rows, y, w, dot_dev, workspace, stream);
+}
+} // namespace cmi
+
+CMI_API int cmi_spmv_csr_plan_f64(const cmi_plan *plan, const int32_t *Ap, const int32_t *Aj, const double *Ax,
+                                  const double *x, double *y, int accumulate, void *stream)
+{
+    if (int st = cmi::plan_is_csr(plan, CMI_F64, "cmi_spmv_csr_plan_f64")) return st;
+    return cmi::spmv_csr<double>(CMI_F64, plan->rows, plan->cols, plan->nnz, Ap, Aj, Ax, x, y, accumulate, nullptr, stream, nullptr, nullptr, nullptr, plan);
+}
+CMI_API int cmi_spmv_csr_plan_f32(const cmi_plan *plan, const int32_t *Ap, const int32_t *Aj, const float *Ax,
+                                  const float *x, float *y, int accumulate, void *stream)
+{
+    if (int st = cmi::plan_is_csr(plan, CMI_F32, "cmi_spmv_csr_plan_f32")) return st;
+    return cmi::spmv_csr<float>(CMI_F32, plan->rows, plan->cols, plan->nnz, Ap, Aj, Ax, x, y, accumulate, nullptr, stream, nullptr, nullptr, nullptr, plan);
 }
 
-// Longest row of a CSR matrix (device pass + read-back; synchronises the stream).  cmi_spmv_csr_* with no
-// explicit kernel does this itself, once per matrix; exposed for hosts that keep their own profile.
+CMI_API int cmi_spmv_csr_dot_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ap,
+                                 const int32_t *Aj, const double *Ax, const double *x, double *y, const double *w,
+                                 double *dot_dev, void *workspace, const cmi_config *cfg, void *stream)
+{
+    return cmi::spmv_csr_dot<double>(CMI_F64, num_rows, num_cols, num_entries, Ap, Aj, Ax, x, y, w, dot_dev, workspace, cfg, stream, nullptr);
+}
+CMI_API int cmi_spmv_csr_dot_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ap,
+                                 const int32_t *Aj, const float *Ax, const float *x, float *y, const float *w,
+                                 double *dot_dev, void *workspace, const cmi_config *cfg, void *stream)
+{
+    return cmi::spmv_csr_dot<float>(CMI_F32, num_rows, num_cols, num_entries, Ap, Aj, Ax, x, y, w, dot_dev, workspace, cfg, stream, nullptr);
+}
+CMI_API int cmi_spmv_csr_dot_plan_f64(const cmi_plan *plan, const int32_t *Ap, const int32_t *Aj, const double *Ax,
+                                      const double *x, double *y, const double *w, double *dot_dev, void *workspace, void *stream)
+{
+    if (int st = cmi::plan_is_csr(plan, CMI_F64, "cmi_spmv_csr_dot_plan_f64")) return st;
+    return cmi::spmv_csr_dot<double>(CMI_F64, plan->rows, plan->cols, plan->nnz, Ap, Aj, Ax, x, y, w, dot_dev, workspace, nullptr, stream, plan);
+}
+CMI_API int cmi_spmv_csr_dot_plan_f32(const cmi_plan *plan, const int32_t *Ap, const int32_t *Aj, const float *Ax,
+                                      const float *x, float *y, const float *w, double *dot_dev, void *workspace, void *stream)
+{
+    if (int st = cmi::plan_is_csr(plan, CMI_F32, "cmi_spmv_csr_dot_plan_f32")) return st;
+    return cmi::spmv_csr_dot<float>(CMI_F32, plan->rows, plan->cols, plan->nnz, Ap, Aj, Ax, x, y, w, dot_dev, workspace, nullptr, stream, plan);
+}
+
+// Longest row of a CSR matrix (device pass + read-back; synchronises the stream).  A plan does this itself;
+// exposed for hosts that keep their own profile.
 CMI_API int cmi_csr_max_row_length(int64_t num_rows, const int32_t *Ap, int64_t *max_length_host, void *stream)
 {
     if (num_rows < 0 || !max_length_host) return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_max_row_length: bad argument");
@@ -997,11 +1013,4 @@ CMI_API int cmi_csr_max_row_length(int64_t num_rows, const int32_t *Ap, int64_t 
     if (num_rows == 0) return CMI_SUCCESS;
     if (!Ap) return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_max_row_length: null row offsets");
     return cmi::measure_row_lengths(num_rows, Ap, cmi::as_stream(stream), max_length_host, nullptr);
-}
-
-CMI_API int cmi_spmv_csr_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ap,
-                             const int32_t *Aj, const float *Ax, const float *x, float *y, int accumulate,
-                             const cmi_config *cfg, void *stream)
-{
-    return cmi::spmv_csr<float>(CMI_F32, num_rows, num_cols, num_entries, Ap, Aj, Ax, x, y, accumulate, cfg, stream);
 }

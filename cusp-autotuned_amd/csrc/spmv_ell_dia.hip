@@ -32,13 +32,21 @@ template <typename T, int RPL, bool ELLR, int POL, bool DOT = false>
 __global__ void __launch_bounds__(1024)
 ell_row_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict__ Aj, const T *__restrict__ Ax,
                const int *__restrict__ row_lengths, const T *__restrict__ x, T *__restrict__ y, int accumulate,
+               int64_t tiles, int64_t tiles_per_xcd, int swizzle,
                const T *__restrict__ w = nullptr, double *__restrict__ dot_partial = nullptr)
 {
     constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
     __shared__ double dot_slots[DOT ? 1024 / kWave : 1];
     double dsum = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x * RPL;
-    for (int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * RPL; row < num_rows; row += stride) {
+    // A tile = the blockDim.x * RPL consecutive rows of one workgroup (one-shot grid).  Tiles are dealt to the XCDs in
+    // chunks (`swizzle`: common.h tile_of_block) so that the x window a chunk gathers -- its rows +- the matrix
+    // bandwidth -- is fetched into ONE L2; in launch order x is fetched ~2.5x on the headline matrix
+    // (profiles/r02_formats_pmc.json).  The grid is padded to whole chunk rounds: a workgroup whose tile lies past the
+    // end leaves as a whole.
+    const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle);
+    if (tile >= tiles) return;
+    const int64_t row = (tile * blockDim.x + threadIdx.x) * RPL;
+    if (row < num_rows) {
         if constexpr (RPL == 1) {
             T acc = accumulate ? y[row] : T(0);
             const int len = ELLR ? row_lengths[row] : width; // ELLR: valid leading slots of THIS row
@@ -114,8 +122,8 @@ ell_row_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict
         }
     }
     if constexpr (DOT) {
-        tile_dot_store(dsum, dot_slots, dot_partial + blockIdx.x);
-        if (blockIdx.x == 0 && threadIdx.x == 0) *ticket_of(dot_partial) = 0;
+        tile_dot_store(dsum, dot_slots, dot_partial + tile);
+        if (tile == 0 && threadIdx.x == 0) *ticket_of(dot_partial) = 0;
     }
 }
 
@@ -131,12 +139,18 @@ template <typename T, int POL, bool DOT = false>
 __global__ void __launch_bounds__(1024)
 dia_row_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t pitch,
                const int *__restrict__ offsets, const T *__restrict__ vals, const T *__restrict__ x,
-               T *__restrict__ y, int accumulate, const T *__restrict__ w = nullptr, double *__restrict__ dot_partial = nullptr)
+               T *__restrict__ y, int accumulate, int64_t tiles, int64_t tiles_per_xcd, int swizzle,
+               const T *__restrict__ w = nullptr, double *__restrict__ dot_partial = nullptr)
 {
     constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
     __shared__ int soff[kDiaChunk];
     __shared__ double dot_slots[DOT ? 1024 / kWave : 1];
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // tiles (one workgroup's rows) dealt to the XCDs in chunks: see ell_row_kernel.  Measured on the headline matrix
+    // (tools/r2_probe.hip, profiles/r02_probe_*): launch order 98-101 us with x fetched 2.9x (651 MB read), chunks of 32
+    // tiles 85 us with 498 MB read (compulsory: 480 MB).
+    const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle);
+    if (tile >= tiles) return;
+    const int64_t row = tile * blockDim.x + threadIdx.x;
     const bool live = row < num_rows;
     const int64_t lrow = live ? row : num_rows - 1; // dead lanes shadow the last row (loads stay valid)
     T acc = (accumulate && live) ? y[row] : T(0);
@@ -169,8 +183,8 @@ dia_row_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t pi
     }
     if (live) st<NTS>(y + row, acc);
     if constexpr (DOT) {
-        tile_dot_store(live ? (double)acc * (double)w[row] : 0.0, dot_slots, dot_partial + blockIdx.x);
-        if (blockIdx.x == 0 && threadIdx.x == 0) *ticket_of(dot_partial) = 0;
+        tile_dot_store(live ? (double)acc * (double)w[row] : 0.0, dot_slots, dot_partial + tile);
+        if (tile == 0 && threadIdx.x == 0) *ticket_of(dot_partial) = 0;
     }
 }
 
@@ -179,13 +193,16 @@ template <typename T, int POL, bool DOT = false>
 __global__ void __launch_bounds__(1024)
 dia_row2_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t pitch,
                 const int *__restrict__ offsets, const T *__restrict__ vals, const T *__restrict__ x,
-                T *__restrict__ y, int accumulate, const T *__restrict__ w = nullptr, double *__restrict__ dot_partial = nullptr)
+                T *__restrict__ y, int accumulate, int64_t tiles, int64_t tiles_per_xcd, int swizzle,
+                const T *__restrict__ w = nullptr, double *__restrict__ dot_partial = nullptr)
 {
     typedef typename vec2<T>::type T2;
     constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
     __shared__ int soff[kDiaChunk];
     __shared__ double dot_slots[DOT ? 1024 / kWave : 1];
-    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle);
+    if (tile >= tiles) return;
+    const int64_t row = (tile * blockDim.x + threadIdx.x) * 2;
     const bool live0 = row < num_rows, live1 = row + 1 < num_rows;
     // dead lanes shadow the last even row pair that is fully inside the pitch (loads stay valid)
     const int64_t lrow = live0 ? row : ((num_rows - 1) & ~(int64_t)1);
@@ -232,8 +249,8 @@ dia_row2_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t p
     if constexpr (DOT) {
         double d = live0 ? (double)acc0 * (double)w[row] : 0.0;
         if (live1) d += (double)acc1 * (double)w[row + 1];
-        tile_dot_store(d, dot_slots, dot_partial + blockIdx.x);
-        if (blockIdx.x == 0 && threadIdx.x == 0) *ticket_of(dot_partial) = 0;
+        tile_dot_store(d, dot_slots, dot_partial + tile);
+        if (tile == 0 && threadIdx.x == 0) *ticket_of(dot_partial) = 0;
     }
 }
 
@@ -268,29 +285,30 @@ static int spmv_ell(int dtype, int64_t rows, int64_t cols, int64_t width, int64_
     // a fused dot leaves one partial per workgroup: widen the workgroups until they fit the workspace
     if (wdot && dot_partial)
         while (block < 1024 && ceil_div(rows, (int64_t)block * rpl) > kPartialCapacity) block *= 2;
-    int64_t blocks = ceil_div(rows, (int64_t)block * rpl); // one-shot grid (see spmv_csr.hip grid_for)
-    const int64_t cap = (int64_t)1 << 22;
-    if (blocks > cap) blocks = cap;
-    const int grid = (int)blocks;
+    const int64_t tiles = ceil_div(rows, (int64_t)block * rpl); // one-shot grid (see spmv_csr.hip grid_for), padded to chunk rounds
+    const int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
+    const int64_t tpx = ceil_div(tiles, kXcds);
+    const int64_t grid64 = padded_grid(tiles, swz);
+    if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_ell: grid too large");
+    const int grid = (int)grid64;
     const int w = (int)width;
 #define CMI_ELL_LAUNCH(RPL, ELLR)                                                                             \
     with_policy(pol, [&](auto P) {                                                                                \
         hipLaunchKernelGGL((ell_row_kernel<T, RPL, ELLR, decltype(P)::value>), dim3(grid), dim3(block), 0, s, rows, w, \
-                           pitch, Aj, Ax, row_lengths, x, y, accumulate);                                         \
+                           pitch, Aj, Ax, row_lengths, x, y, accumulate, tiles, tpx, swz);                        \
     })
 #define CMI_ELL_LAUNCH_DOT(RPL, ELLR)                                                                         \
     with_policy(pol, [&](auto P) {                                                                                \
         hipLaunchKernelGGL((ell_row_kernel<T, RPL, ELLR, decltype(P)::value, true>), dim3(grid), dim3(block), 0, s, rows, w, \
-                           pitch, Aj, Ax, row_lengths, x, y, accumulate, wdot, dot_partial);                      \
+                           pitch, Aj, Ax, row_lengths, x, y, accumulate, tiles, tpx, swz, wdot, dot_partial);     \
     })
-    const bool dot = wdot && dot_partial && std::is_same<T, double>::value && grid <= kPartialCapacity &&
-                     (int64_t)grid * block * rpl >= rows; // one-shot grid: every workgroup leaves exactly one partial
+    const bool dot = wdot && dot_partial && std::is_same<T, double>::value && tiles <= kPartialCapacity; // one partial per tile
     if constexpr (std::is_same<T, double>::value) {
         if (dot) {
             if (rpl == 1) { if (ellr) CMI_ELL_LAUNCH_DOT(1, true); else CMI_ELL_LAUNCH_DOT(1, false); }
             else          { if (ellr) CMI_ELL_LAUNCH_DOT(2, true); else CMI_ELL_LAUNCH_DOT(2, false); }
             CMI_LAUNCH_CHECK("ell spmv dot");
-            if (dot_partials) *dot_partials = grid;
+            if (dot_partials) *dot_partials = (int)tiles;
             return CMI_SUCCESS;
         }
     }
@@ -324,24 +342,27 @@ static int spmv_dia(int dtype, int64_t rows, int64_t cols, int64_t ndiag, int64_
     if (rpl == 2 && !(pitch % 2 == 0 && reinterpret_cast<uintptr_t>(vals) % (2 * sizeof(T)) == 0)) rpl = 1;
     if (wdot && dot_partial) // one partial per workgroup: widen the workgroups until they fit the workspace
         while (block < 1024 && ceil_div(rows, (int64_t)block * rpl) > kPartialCapacity) block *= 2;
-    const int64_t grid64 = ceil_div(rows, (int64_t)block * rpl);
+    const int64_t tiles = ceil_div(rows, (int64_t)block * rpl);
+    const int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
+    const int64_t tpx = ceil_div(tiles, kXcds);
+    const int64_t grid64 = padded_grid(tiles, swz);
     if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_dia: grid too large");
     const int grid = (int)grid64, nd = (int)ndiag;
-    const bool dot = wdot && dot_partial && std::is_same<T, double>::value && grid <= kPartialCapacity;
+    const bool dot = wdot && dot_partial && std::is_same<T, double>::value && tiles <= kPartialCapacity;
     with_policy(pol, [&](auto P) {
         constexpr int POL = decltype(P)::value;
         if constexpr (std::is_same<T, double>::value) {
             if (dot) {
-                if (rpl == 1) hipLaunchKernelGGL((dia_row_kernel<T, POL, true>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate, wdot, dot_partial);
-                else          hipLaunchKernelGGL((dia_row2_kernel<T, POL, true>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate, wdot, dot_partial);
+                if (rpl == 1) hipLaunchKernelGGL((dia_row_kernel<T, POL, true>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate, tiles, tpx, swz, wdot, dot_partial);
+                else          hipLaunchKernelGGL((dia_row2_kernel<T, POL, true>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate, tiles, tpx, swz, wdot, dot_partial);
                 return;
             }
         }
-        if (rpl == 1) hipLaunchKernelGGL((dia_row_kernel<T, POL>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate);
-        else          hipLaunchKernelGGL((dia_row2_kernel<T, POL>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate);
+        if (rpl == 1) hipLaunchKernelGGL((dia_row_kernel<T, POL>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate, tiles, tpx, swz);
+        else          hipLaunchKernelGGL((dia_row2_kernel<T, POL>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate, tiles, tpx, swz);
     });
     CMI_LAUNCH_CHECK("dia spmv");
-    if (dot && dot_partials) *dot_partials = grid;
+    if (dot && dot_partials) *dot_partials = (int)tiles;
     return CMI_SUCCESS;
 }
 

@@ -322,6 +322,7 @@ CMI_API int cmi_tuning_save(const char *path)
 {
     if (!path) return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_save: null path");
     std::lock_guard<std::mutex> lk(g_mu);
+    ensure_default_loaded(); // save what select_config would use, not an empty table
     FILE *f = std::fopen(path, "wb");
     if (!f) { set_error("cmi_tuning_save: cannot open %s", path); return CMI_ERROR_IO; }
     std::fprintf(f, "{\n  \"arch\": \"gfx950\",\n  \"version\": %d,\n  \"entries\": [\n", CMI_VERSION);
@@ -359,6 +360,7 @@ CMI_API int cmi_tuning_set(int format, int dtype, double mean_entries_per_row, c
     if (format < 0 || format >= CMI_FORMAT_COUNT || dtype < 0 || dtype > 1 || !cfg)
         return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_set: bad format/dtype/config");
     std::lock_guard<std::mutex> lk(g_mu);
+    ensure_default_loaded(); // explicit entries layer ON TOP of the shipped table: a later AUTO multiply must not reload over them
     const int b = bucket_of(mean_entries_per_row);
     g_table.cfg[format][dtype][b] = *cfg;
     g_table.valid[format][dtype][b] = true;

@@ -17,8 +17,24 @@ def _round_up(n, k):
     return k * ((n + k - 1) // k)
 
 
+class _Planned:
+    """The container owns its plan (binding.Plan): made at the first multiply without an explicit config -- that call
+    synchronises once -- and kept until the structure arrays are replaced (`invalidate()` after editing them in place)."""
+
+    def _plan_for(self, fmt_code, index_array, stream):
+        key = (index_array.data_ptr(), self.num_rows, self.num_cols, self.num_entries, self.values.dtype)
+        if getattr(self, "_plan_key", None) != key:
+            self._plan = B.Plan(fmt_code, self.values.dtype, self.num_rows, self.num_cols, self.num_entries, index_array, None, stream)
+            self._plan_key = key
+        return self._plan
+
+    def invalidate(self):
+        self._plan_key = None
+        self._plan = None
+
+
 @dataclass
-class CsrMatrix:
+class CsrMatrix(_Planned):
     """reference cusp/csr_matrix.h:107-208: row_offsets, column_indices, values."""
     num_rows: int
     num_cols: int
@@ -28,9 +44,12 @@ class CsrMatrix:
     values: object
     format = "csr"
 
+    def plan(self, stream=None):
+        return self._plan_for(B.FORMAT_CSR, self.row_offsets, stream)
+
 
 @dataclass
-class CooMatrix:
+class CooMatrix(_Planned):
     """reference cusp/coo_matrix.h:116-224: row_indices, column_indices, values."""
     num_rows: int
     num_cols: int
@@ -39,6 +58,9 @@ class CooMatrix:
     column_indices: object
     values: object
     format = "coo"
+
+    def plan(self, stream=None):
+        return self._plan_for(B.FORMAT_COO, self.row_indices, stream)
 
 
 @dataclass
@@ -81,9 +103,24 @@ class HybMatrix:
     format = "hyb"
 
 
+def _capturing(stream):
+    import torch
+    try:
+        return torch.cuda.is_current_stream_capturing() if stream is None else stream.is_capturing()
+    except AttributeError:
+        return False
+
+
 def multiply(A, x, y, accumulate=False, cfg=None, stream=None):
-    """y = A*x (or y += A*x).  Mirrors the 3-argument cusp::multiply (cusp/multiply.h:40)."""
-    if isinstance(A, CsrMatrix):
+    """y = A*x (or y += A*x).  Mirrors the 3-argument cusp::multiply (cusp/multiply.h:40).  Without an explicit config
+    CSR and COO matrices multiply through their plan (made once, at the first such call; not while a stream capture is
+    recording -- then the plan-less entry point runs the table's kernel)."""
+    if isinstance(A, (CsrMatrix, CooMatrix)) and cfg is None and A.num_entries > 0 and not _capturing(stream):
+        if isinstance(A, CsrMatrix):
+            B.spmv_csr_plan(A.plan(stream), A.row_offsets, A.column_indices, A.values, x, y, accumulate, stream)
+        else:
+            B.spmv_coo_plan(A.plan(stream), A.row_indices, A.column_indices, A.values, x, y, accumulate, stream)
+    elif isinstance(A, CsrMatrix):
         B.spmv_csr(A.num_rows, A.num_cols, A.row_offsets, A.column_indices, A.values, x, y, accumulate, cfg, stream)
     elif isinstance(A, CooMatrix):
         B.spmv_coo(A.num_rows, A.num_cols, A.row_indices, A.column_indices, A.values, x, y, accumulate, cfg, stream)

@@ -8,8 +8,12 @@
  * entry point returns a cmi_status (0 = success); launches are asynchronous on
  * `stream` like the reference's, but -- unlike the reference, which never checks
  * a launch (cusp/system/cuda/detail/multiply/csr_vector_spmv.h:204-208) -- launch
- * errors are reported.  Nothing here takes ownership of caller memory and no
- * SpMV entry point allocates.
+ * errors are reported.  Nothing here takes ownership of caller memory; no
+ * cmi_spmv_* entry point allocates device memory or synchronises the stream
+ * (what a multiply needs to know about a matrix beyond its arrays -- the
+ * row-length profile that steers the CSR kernels, whether a COO matrix is
+ * sorted by row -- is found ONCE by cmi_plan_create, which does synchronise,
+ * and handed to the cmi_spmv_*_plan_* entry points).
  *
  * Each declaration cites the reference interface it replaces (paths relative to
  * the reference tree).  The header-only C++ layer in
@@ -28,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CMI_VERSION 100 /* 0.1.0 */
+#define CMI_VERSION 200 /* 0.2.0: plans, COO tile kernel, XCD dealing in ELL / DIA / COO, HYB width rule */
 
 typedef enum cmi_status {
     CMI_SUCCESS = 0,
@@ -140,6 +144,11 @@ typedef enum cmi_kernel {
     CMI_COO_LANE4 = 31,     /* four consecutive entries per lane (16-byte vector loads), runs reduced in
                                registers, one wave scan per 256 entries (ref: ktt coo_direct_multi,
                                kernels/coo_kernel.h:64-106, VALUES_PER_THREAD)                     */
+    CMI_COO_TILE = 32,      /* ROW-SORTED entries only (cmi_spmv_coo_plan_*, or an explicit config: then the
+                               caller vouches for the order): 1024 entries per workgroup through LDS, row
+                               boundaries from the row indices, storage-order sums, plain stores of whole
+                               runs of y -- no zero fill, no atomics (ref: coo_flat_spmv.h:231-463 needs
+                               three launches and two temporaries for the same contract)            */
 } cmi_kernel;
 
 typedef struct cmi_config {
@@ -152,9 +161,10 @@ typedef struct cmi_config {
                                  ELL/DIA: rows per lane (1,2); COO: entries per lane; 0 = default   */
     int32_t nontemporal;      /* cache policy bits: 1 = once-read matrix streams loaded with the nt
                                  hint, 2 = y stored with the nt hint (3 = both)                     */
-    int32_t xcd_swizzle;      /* CSR stream: 0 = tiles in launch order, 1 = one contiguous eighth of
-                                 the tiles per XCD, C >= 2 = chunks of C tiles dealt round the XCDs
-                                 (L2 reuse of x); CSR stream_pipe: != 0 = chunked tile schedule     */
+    int32_t xcd_swizzle;      /* CSR stream, ELL, DIA, COO tile: 0 = tiles (a workgroup's rows / entries) in
+                                 launch order, 1 = one contiguous eighth of the tiles per XCD, C >= 2 =
+                                 chunks of C tiles dealt round the XCDs (a chunk's x window is fetched into
+                                 ONE L2); CSR stream_pipe: != 0 = chunked tile schedule               */
     int32_t blocks_per_cu;    /* persistent kernels: workgroups per CU in the grid; 0 = default (8)  */
 } cmi_config;
 
@@ -168,6 +178,41 @@ int cmi_tuning_set(int format, int dtype, double mean_entries_per_row, const cmi
 /* The config a NULL-config call with this shape would run. */
 int cmi_tuning_select(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
                       cmi_config *out);
+
+/* ------------------------------------------------------------------------- */
+/* Plans (cmi_plan_create / destroy / select).        */
+/* A plan holds what the library learns about ONE matrix before its first      */
+/* multiply, so that no multiply has to: the launch shape (tuning table or the  */
+/* caller's config, completed), for CSR the row-length profile (longest row,    */
+/* entries in rows of 512+: picks the long-row instance of csr_stream or the     */
+/* merge-path kernel), for COO whether the entries are sorted by row (then the   */
+/* tile kernel runs: plain stores, no zero fill, no atomics, storage-order sums). */
+/* The reference has no equivalent object: its KTT path keeps such state in       */
+/* function-local statics keyed by nothing (cuda/ktt/csr_multiply.h:22-29,239-247) */
+/* and recomputes `row_starts` on the host per call.                               */
+/*   cmi_plan_create reads the index array on the device and SYNCHRONISES `stream`  */
+/*   (one small kernel + a 16-byte read-back); everything after it is asynchronous.  */
+/*   A plan owns no device memory and does not keep the pointers: the arrays are     */
+/*   passed again at every multiply; they must be the ones the plan was made for     */
+/*   (same sizes are checked; contents are the caller's promise -- a plan made for    */
+/*   other contents can cost speed or, for COO, give wrong sums: make a new plan      */
+/*   when the structure changes).  Thread-safe once created (read-only).              */
+/* ------------------------------------------------------------------------- */
+typedef struct cmi_plan cmi_plan;
+/* index_array: CSR row offsets (num_rows + 1), COO row indices (num_entries), NULL for ELL / DIA / HYB  */
+/* (their plan is the resolved launch shape only).  `num_entries`: entries for CSR / COO, slots          */
+/* (num_rows * width or * diagonals) for ELL / DIA -- what the tuning table is keyed by.  cfg may be NULL. */
+int cmi_plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
+                    const int32_t *index_array, const cmi_config *cfg, void *stream, cmi_plan **plan);
+int cmi_plan_destroy(cmi_plan *plan);
+/* The launch shape the plan's multiplies run (SURVEY's cmi_plan_select): kernel CMI_CSR_BALANCED means   */
+/* the profile switched kernels.                                                                            */
+int cmi_plan_config(const cmi_plan *plan, cmi_config *out);
+/* What was measured: longest row and entries sitting in rows of 512+ (CSR; -1 otherwise), row-sortedness   */
+/* (COO: 1/0; -1 otherwise), and whether every result is the storage-order sum (bit-identical to the host   */
+/* loop: 1) or some rows are re-associated (within 1e-6: 0).                                                  */
+int cmi_plan_info(const cmi_plan *plan, int64_t *max_row_length, int64_t *entries_in_long_rows, int *coo_sorted,
+                  int *storage_order_sums);
 
 /* ------------------------------------------------------------------------- */
 /* SpMV: y = A*x (accumulate == 0; the reference's 3-argument cusp::multiply,  */
@@ -185,6 +230,11 @@ int cmi_spmv_csr_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries, co
 int cmi_spmv_csr_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ap,
                      const int32_t *Aj, const float *Ax, const float *x, float *y, int accumulate,
                      const cmi_config *cfg, void *stream);
+/* The same multiply steered by a plan (no table lookup, no profile measurement, no allocation, no sync). */
+int cmi_spmv_csr_plan_f64(const cmi_plan *plan, const int32_t *Ap, const int32_t *Aj, const double *Ax,
+                          const double *x, double *y, int accumulate, void *stream);
+int cmi_spmv_csr_plan_f32(const cmi_plan *plan, const int32_t *Ap, const int32_t *Aj, const float *Ax,
+                          const float *x, float *y, int accumulate, void *stream);
 /* The same fusion for ELL (ELLR with row_lengths) and DIA: one lane per row owns y[row], so <y, w> costs one  */
 /* extra coalesced read of w and one partial per workgroup.                                                    */
 int cmi_spmv_ell_dot_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries_per_row, int64_t pitch,
@@ -194,12 +244,11 @@ int cmi_spmv_ell_dot_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries
 int cmi_spmv_dia_dot_f64(int64_t num_rows, int64_t num_cols, int64_t num_diagonals, int64_t pitch,
                          const int32_t *diagonal_offsets, const double *values, const double *x, double *y,
                          const double *w, double *dot_dev, void *workspace, const cmi_config *cfg, void *stream);
-/* Row-length profile.  With cfg == NULL (or kernel AUTO) cmi_spmv_csr_* measures the longest row of a    */
-/* matrix the first time it sees it (key: row-offset pointer, rows, entries, device; ~20 us, one stream    */
-/* synchronisation; skipped while the stream is being captured) and switches from the table's row-tile     */
-/* kernel to CMI_CSR_BALANCED when that row alone would cost more than the whole multiply.  A stale       */
-/* profile can only cost speed.  CMI_CSR_PROFILE=0 disables it.  cmi_csr_max_row_length is the same pass   */
-/* for hosts that want to decide themselves.                                                               */
+/* Row-length profile.  cmi_spmv_csr_* WITHOUT a plan runs the table's row-tile kernel whatever the row    */
+/* lengths (correct for every matrix; a row of 10^5 entries is then summed by one lane).  A plan measures  */
+/* the longest row once and switches to the long-row instance of csr_stream or to CMI_CSR_BALANCED when    */
+/* that row alone would cost more than the whole multiply.  cmi_csr_max_row_length is the same measurement  */
+/* for hosts that want to decide themselves (synchronises the stream).                                      */
 int cmi_csr_max_row_length(int64_t num_rows, const int32_t *Ap, int64_t *max_length_host, void *stream);
 /* y <- A x AND *dot_dev <- <y, w> (w: num_rows values; w may be x).  The CG step                  */
 /* `y = A p; alpha = rz / dot(y, p)` (reference cusp/krylov/detail/cg.inl:80-83) in ONE pass: the   */
@@ -209,6 +258,16 @@ int cmi_csr_max_row_length(int64_t num_rows, const int32_t *Ap, int64_t *max_len
 int cmi_spmv_csr_dot_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ap,
                          const int32_t *Aj, const double *Ax, const double *x, double *y, const double *w,
                          double *dot_dev, void *workspace, const cmi_config *cfg, void *stream);
+int cmi_spmv_csr_dot_plan_f64(const cmi_plan *plan, const int32_t *Ap, const int32_t *Aj, const double *Ax,
+                              const double *x, double *y, const double *w, double *dot_dev, void *workspace,
+                              void *stream);
+/* f32 matrix and vectors, <y, w> accumulated and returned as a DOUBLE (the scalars of the float CG stay doubles). */
+int cmi_spmv_csr_dot_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ap,
+                         const int32_t *Aj, const float *Ax, const float *x, float *y, const float *w,
+                         double *dot_dev, void *workspace, const cmi_config *cfg, void *stream);
+int cmi_spmv_csr_dot_plan_f32(const cmi_plan *plan, const int32_t *Ap, const int32_t *Aj, const float *Ax,
+                              const float *x, float *y, const float *w, double *dot_dev, void *workspace,
+                              void *stream);
 
 /* Replaces cuda::detail::multiply(ell) (ell_spmv.h:103-155) and ktt_ell_kernel / ktt_ellr_kernel
  * (ktt/kernels/ell_kernel.h:181-213).  Column-major num_rows x num_entries_per_row arrays with
@@ -243,6 +302,16 @@ int cmi_spmv_coo_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries, co
 int cmi_spmv_coo_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ai,
                      const int32_t *Aj, const float *Ax, const float *x, float *y, int accumulate,
                      const cmi_config *cfg, void *stream);
+/* With a plan that found the entries sorted by row (the reference's contract for coo_matrix,
+ * cusp/coo_matrix.h:72) the tile kernel CMI_COO_TILE runs: a workgroup owns the rows that START in its
+ * 1024 entries, finds the row boundaries from the row indices in LDS, adds each row's products in STORAGE
+ * ORDER (bit-identical to sequential/multiply/coo_spmv.h:42-68) and stores whole runs of y: no zero fill,
+ * no atomics; rows without entries are zeroed (or left, when accumulating) by the tile that owns the gap.
+ * A plan that found them unsorted runs the order-agnostic kernels above. */
+int cmi_spmv_coo_plan_f64(const cmi_plan *plan, const int32_t *Ai, const int32_t *Aj, const double *Ax,
+                          const double *x, double *y, int accumulate, void *stream);
+int cmi_spmv_coo_plan_f32(const cmi_plan *plan, const int32_t *Ai, const int32_t *Aj, const float *Ax,
+                          const float *x, float *y, int accumulate, void *stream);
 
 /* HYB = ELL part (caller's accumulate) then COO part accumulating on top
  * (generic/multiply/spmv.h:275-290; oracle sequential/multiply/hyb_spmv.h:42-57).

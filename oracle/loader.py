@@ -108,6 +108,28 @@ class Oracle(_SpmvMixin):
     def num_threads(self):
         return int(self._lib.orc_num_threads())
 
+    def bench_csr_omp(self, num_cols, Ap, Aj, Ax, x, threads=None, seconds=4.0, min_reps=3, max_reps=500):
+        """The multi-core CPU baseline (orc_bench_csr_omp_f64): OpenMP row-parallel CSR SpMV on copies first-touched in
+        parallel by their users, threads pinned one per allowed CPU, timed inside C.  Returns a dict."""
+        Ap, Aj = _i32(Ap), _i32(Aj)
+        Ax = np.ascontiguousarray(Ax, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        rows = len(Ap) - 1
+        if threads is None:
+            threads = self.num_threads()
+        y = np.empty(rows, dtype=np.float64)
+        reps, pinned = c_int(0), c_int(0)
+        cpus = (c_int * threads)(*([-1] * threads))
+        fn = self._lib.orc_bench_csr_omp_f64
+        fn.restype = ctypes.c_double
+        fn.argtypes = [c_int64, c_int64] + [c_void_p] * 5 + [c_int, ctypes.c_double, c_int, c_int, c_void_p, c_void_p, c_void_p]
+        sec = fn(rows, int(num_cols), _p(Ap), _p(Aj), _p(Ax), _p(x), _p(y), int(threads), float(seconds), int(min_reps),
+                 int(max_reps), ctypes.addressof(reps), ctypes.addressof(cpus), ctypes.addressof(pinned))
+        if sec < 0:
+            raise MemoryError("orc_bench_csr_omp_f64: allocation failed")
+        return {"seconds_per_spmv": sec, "reps": reps.value, "threads": threads, "cpus": list(cpus),
+                "pinned": bool(pinned.value), "y": y}
+
     def set_num_threads(self, n):
         self._lib.orc_set_num_threads(int(n))
 

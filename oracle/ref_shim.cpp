@@ -16,7 +16,7 @@
 // (cusp/system/detail/generic/multiply.inl:173-191).
 //
 // Build (oracle/Makefile, target ref): host code only, no GPU needed:
-//   hipcc -std=c++17 -O2 -ffp-contract=off -DTHRUST_DEVICE_SYSTEM=THRUST_DEVICE_SYSTEM_CPP
+//   hipcc -std=c++17 -O3 -ffp-contract=off -DTHRUST_DEVICE_SYSTEM=THRUST_DEVICE_SYSTEM_CPP
 //         -I/root/reference -shared -fPIC oracle/ref_shim.cpp -o oracle/_ref/libcusp_ref.so
 #include <cstddef>
 #include <cstdint>
@@ -152,5 +152,5 @@ REF_DEFINE(float, f32)
 REF_API const char *ref_describe(void)
 {
     return "reference cusp/system/detail/sequential/multiply/{csr,coo,ell,dia,hyb}_spmv.h, "
-           "compiled from /root/reference, -O2 -ffp-contract=off, single thread";
+           "compiled from /root/reference, -O3 -ffp-contract=off, single thread";
 }

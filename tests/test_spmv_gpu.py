@@ -139,10 +139,16 @@ def run_all_formats(cmi, torch, orc, rows, cols, Ap, Aj, Ax, x, want, want_acc, 
     assert np.array_equal(host(rl), np.diff(Ap).astype(np.int32)), f"{label}: ELLR row lengths"
     for acc, w in ((False, want["ell"]), (True, want_acc["ell"])):
         for rpl, nt, ellr, blk in itertools.product((1, 2), (0, 1, 2, 3), (False, True), (256,)):
+            swz = (0, 1, 3, 32)[(rpl + nt + ellr) % 4]  # tiles dealt to the XCDs: launch order, eighths, chunks of 3 / 32
             y = fresh(acc)
             cmi.spmv_ell(rows, cols, width, pitch, deAj, deAx, dx, y, row_lengths=rl if ellr else None, accumulate=acc,
-                         cfg=cmi.Config(kernel=cmi.ELL_ROW, block_size=blk, items_per_thread=rpl, nontemporal=nt))
-            assert np.array_equal(host(y), w), f"{label} ell rpl{rpl} nt{nt} ellr{ellr} acc={acc}: not bit-exact"
+                         cfg=cmi.Config(kernel=cmi.ELL_ROW, block_size=blk, items_per_thread=rpl, nontemporal=nt, xcd_swizzle=swz))
+            assert np.array_equal(host(y), w), f"{label} ell rpl{rpl} nt{nt} ellr{ellr} x{swz} acc={acc}: not bit-exact"
+        for blk, swz in ((64, 1), (64, 2), (128, 5), (1024, 8)):  # small workgroups: many tiles, padded chunk rounds
+            y = fresh(acc)
+            cmi.spmv_ell(rows, cols, width, pitch, deAj, deAx, dx, y, accumulate=acc,
+                         cfg=cmi.Config(kernel=cmi.ELL_ROW, block_size=blk, items_per_thread=1, xcd_swizzle=swz))
+            assert np.array_equal(host(y), w), f"{label} ell b{blk} x{swz} acc={acc}: not bit-exact"
 
     # HYB at the fixture's split
     p, hAj, hAx, cAi, cAj, cAx = orc.csr_to_hyb(Ap, Aj, Ax, hyb_width)
@@ -194,11 +200,11 @@ def test_banded_dia_golden(cmi, torch_cuda, golden_banded, tag):
     off, vals, x, y0 = g["offsets"], g[f"{tag}_vals"], g[f"{tag}_x"], g[f"{tag}_y0"]
     doff, dvals, dx = dev(off, torch), dev(vals, torch), dev(x, torch)
     for acc, w in ((False, g[f"{tag}_y"]), (True, g[f"{tag}_yacc"])):
-        for rpl, nt in itertools.product((1, 2), (0, 2, 3)):
+        for rpl, nt, (blk, swz) in itertools.product((1, 2), (0, 2, 3), ((256, 0), (64, 1), (64, 3), (128, 32), (1024, 2))):
             y = dev(y0, torch).clone() if acc else torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
             cmi.spmv_dia(rows, cols, len(off), pitch, doff, dvals, dx, y, accumulate=acc,
-                         cfg=cmi.Config(kernel=cmi.DIA_ROW, items_per_thread=rpl, nontemporal=nt))
-            assert np.array_equal(host(y), w), f"banded dia rpl{rpl} nt{nt} acc={acc}"
+                         cfg=cmi.Config(kernel=cmi.DIA_ROW, block_size=blk, items_per_thread=rpl, nontemporal=nt, xcd_swizzle=swz))
+            assert np.array_equal(host(y), w), f"banded dia rpl{rpl} nt{nt} b{blk} x{swz} acc={acc}"
 
 
 def test_dia_more_than_256_diagonals(cmi, torch_cuda, orc):
@@ -212,10 +218,10 @@ def test_dia_more_than_256_diagonals(cmi, torch_cuda, orc):
     vals = rng.standard_normal(nd * pitch)
     x = rng.standard_normal(cols)
     want = orc.spmv_dia(rows, cols, pitch, off, vals, x)
-    for rpl in (1, 2):
+    for rpl, swz in itertools.product((1, 2), (0, 1, 4)):
         y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
         cmi.spmv_dia(rows, cols, nd, pitch, dev(off, torch), dev(vals, torch), dev(x, torch), y,
-                     cfg=cmi.Config(kernel=cmi.DIA_ROW, items_per_thread=rpl))
+                     cfg=cmi.Config(kernel=cmi.DIA_ROW, block_size=64, items_per_thread=rpl, xcd_swizzle=swz))
         assert np.array_equal(host(y), want)
 
 
@@ -1206,7 +1212,8 @@ def test_spmv_ell_and_dia_dot(cmi, torch_cuda, orc):
     rl = torch.empty(N, dtype=torch.int32, device="cuda")
     cmi.ell_row_lengths(N, 5, pitch, deAj, rl)
     for rpl, nt, ellr, blk in itertools.product((1, 2), (0, 3), (False, True), (64, 256, 1024)):
-        cfg = cmi.Config(kernel=cmi.ELL_ROW, block_size=blk, items_per_thread=rpl, nontemporal=nt)
+        cfg = cmi.Config(kernel=cmi.ELL_ROW, block_size=blk, items_per_thread=rpl, nontemporal=nt,
+                         xcd_swizzle=(0, 1, 5, 32)[(rpl + nt + blk // 64) % 4])  # partial index = tile, whatever the dealing
         y0 = torch.full((N,), 3.0, dtype=torch.float64, device="cuda")
         y1 = torch.full((N,), -3.0, dtype=torch.float64, device="cuda")
         cmi.spmv_ell(N, N, 5, pitch, deAj, deAx, dx, y0, row_lengths=rl if ellr else None, cfg=cfg)
@@ -1218,7 +1225,8 @@ def test_spmv_ell_and_dia_dot(cmi, torch_cuda, orc):
     pd, off, vals = orc.csr_to_dia(N, N, Ap, Aj, Ax)
     doff, dvals = dev(off, torch), dev(vals, torch)
     for rpl, nt, blk in itertools.product((1, 2), (0, 2), (64, 256, 512)):
-        cfg = cmi.Config(kernel=cmi.DIA_ROW, block_size=blk, items_per_thread=rpl, nontemporal=nt)
+        cfg = cmi.Config(kernel=cmi.DIA_ROW, block_size=blk, items_per_thread=rpl, nontemporal=nt,
+                         xcd_swizzle=(0, 1, 5, 32)[(rpl + nt + blk // 64) % 4])
         y0 = torch.full((N,), 3.0, dtype=torch.float64, device="cuda")
         y1 = torch.full((N,), -3.0, dtype=torch.float64, device="cuda")
         cmi.spmv_dia(N, N, len(off), pd, doff, dvals, dx, y0, cfg=cfg)

@@ -76,13 +76,16 @@ def csr_space(cmi, mean, quick):
 
 
 def ell_space(cmi, quick):
-    return [cmi.Config(kernel=cmi.ELL_ROW, block_size=b, items_per_thread=r, nontemporal=nt)
-            for b, r, nt in itertools.product((256,) if quick else (128, 256, 512, 1024), (1, 2), (0, 1, 2, 3))]
+    # xcd_swizzle: tiles (one workgroup's rows) dealt to the XCDs in chunks, so that a chunk's x window lands in one L2
+    return [cmi.Config(kernel=cmi.ELL_ROW, block_size=b, items_per_thread=r, nontemporal=nt, xcd_swizzle=swz)
+            for b, r, nt, swz in itertools.product((256,) if quick else (128, 256, 512, 1024), (1, 2), (0, 1, 2, 3),
+                                                   (0, 32) if quick else (0, 8, 16, 32, 64, 128))]
 
 
 def dia_space(cmi, quick):
-    return [cmi.Config(kernel=cmi.DIA_ROW, block_size=b, items_per_thread=r, nontemporal=nt)
-            for b, r, nt in itertools.product((256,) if quick else (128, 256, 512, 1024), (1, 2), (0, 1, 2, 3))]
+    return [cmi.Config(kernel=cmi.DIA_ROW, block_size=b, items_per_thread=r, nontemporal=nt, xcd_swizzle=swz)
+            for b, r, nt, swz in itertools.product((256,) if quick else (128, 256, 512, 1024), (1, 2), (0, 1, 2, 3),
+                                                   (0, 32) if quick else (0, 8, 16, 32, 64, 128))]
 
 
 def coo_space(cmi, quick):

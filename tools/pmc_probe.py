@@ -17,18 +17,25 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import cusp_autotuned_amd as cmi  # noqa: E402
 
-fmt = sys.argv[1] if len(sys.argv) > 1 else "csr"
+fmts = (sys.argv[1] if len(sys.argv) > 1 else "csr").split(",")  # several formats in one process: one profiler start-up
 M = 3162
 N = M * M
 A = cmi.poisson5pt(M, M, "csr")
-Afmt = A if fmt == "csr" else (cmi.poisson5pt(M, M, "dia") if fmt == "dia" else cmi.convert(A, fmt))
 x = cmi.fill_x(N, device="cuda")
 y = torch.empty(N, dtype=torch.float64, device="cuda")
-z = torch.empty(N, dtype=torch.float64, device="cuda")
-torch.cuda.synchronize()
-for _ in range(10):
-    cmi.multiply(Afmt, x, y)
-torch.cuda.synchronize()
+alg = {}
+for fmt in fmts:
+    # hyb: width 4 leaves the fifth entry of the interior rows to the COO part (a width of 5 would time ELL alone)
+    Afmt = A if fmt == "csr" else (cmi.poisson5pt(M, M, "dia") if fmt == "dia" else
+                                   cmi.convert(A, fmt, num_entries_per_row=4 if fmt == "hyb" else None))
+    torch.cuda.synchronize()
+    for _ in range(10):
+        cmi.multiply(Afmt, x, y)
+    torch.cuda.synchronize()
+    alg[fmt] = {"csr": cmi.csr_bytes(N, A.num_entries), "ell": cmi.ell_bytes(N, 5, 9998272), "dia": cmi.dia_bytes(N, 5, N),
+                "coo": cmi.coo_bytes(N, A.num_entries),
+                "hyb": cmi.ell_bytes(N, 4, 9998272) + 16 * (A.num_entries - 4 * N if fmt != "hyb" else Afmt.coo.num_entries)}[fmt]
+    del Afmt
 # calibration: z = 2x + 3y over 2^25 doubles (256 MiB per vector: far beyond the 256 MiB Infinity Cache in total)
 n_cal = 1 << 25
 a = torch.ones(n_cal, dtype=torch.float64, device="cuda")
@@ -38,8 +45,6 @@ torch.cuda.synchronize()
 for _ in range(10):
     cmi.blas_axpby(2.0, a, 3.0, b, c)
 torch.cuda.synchronize()
-alg = {"csr": cmi.csr_bytes(N, A.num_entries), "ell": cmi.ell_bytes(N, 5, 9998272), "dia": cmi.dia_bytes(N, 5, N),
-       "coo": cmi.coo_bytes(N, A.num_entries)}[fmt]
-print(json.dumps({"format": fmt, "spmv_algorithmic_bytes": alg, "spmv_read_bytes": alg - 8 * N, "spmv_write_bytes": 8 * N,
+print(json.dumps({"formats": fmts, "spmv_algorithmic_bytes": alg, "spmv_write_bytes": 8 * N,
                   "calibration_kernel": "axpby_kernel", "calibration_read_bytes": 16 * n_cal,
                   "calibration_write_bytes": 8 * n_cal}))

@@ -1,0 +1,339 @@
+// tools/r2_probe.hip -- round-2 experiments on the headline matrix (poisson5pt 3162^2, fp64), one standalone
+// program so that a GPU session pays no Python start-up:
+//   * the library's csr_stream under every XCD dealing mode (timing here; the same runs under rocprofv3 --pmc give the
+//     fabric-side counters per mode: VERDICT r1 "explain with counters why the compulsory-traffic dealing is slower");
+//   * `mix`: a kernel with csr_stream's ACCESS PATTERN (same tiles, same arrays, same bytes, same dealing) but no
+//     dependent chain, no LDS, no barrier -- what the memory system gives this traffic mix;
+//   * `csrx`: experimental variants of the csr_stream fast path (row pointers in registers, paired 16-byte y stores);
+//   * `diax`: DIA with the x window of the central diagonals staged in LDS, offsets as in the library, XCD chunk dealing.
+// Every result-producing variant is checked bit for bit against the library's csr_scalar (pinned by tests/).
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -Iinclude tools/r2_probe.hip -o tools/bin/r2_probe \
+//         -Lcusp-autotuned_amd/lib -lcusp_mi355x -Wl,-rpath,'$ORIGIN/../../cusp-autotuned_amd/lib'
+//   tools/bin/r2_probe [--only SUBSTR] [--batches B] [--launches L] [--m 3162]
+#include "../cusp-autotuned_amd/csrc/common.h"
+#include <algorithm>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+using namespace cmi;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+#define CM(x) do { int s_ = (x); if (s_ != 0) { printf("cmi error %d (%s) line %d\n", s_, cmi_last_error(), __LINE__); exit(1);} } while (0)
+
+// ------------------------------------------------------------------------------------------------------------
+// mix: the access pattern of csr_stream without its dependences
+// ------------------------------------------------------------------------------------------------------------
+template <int XW, bool NTS>
+__global__ void __launch_bounds__(256)
+mix_kernel(int64_t N, int64_t nnz, const int *__restrict__ Ap, const int *__restrict__ Aj, const double *__restrict__ Ax,
+           const double *__restrict__ x, double *__restrict__ y, int rpb, int64_t tiles, int64_t tpx, int swz, int m)
+{
+    const int64_t tile = tile_of_block(blockIdx.x, tpx, swz);
+    if (tile >= tiles) return;
+    const int tid = threadIdx.x;
+    const int64_t r0 = tile * rpb;
+    const int nr = (int)((N - r0) < rpb ? (N - r0) : rpb);
+    int64_t e0 = (5 * r0) & ~(int64_t)3;
+    if (e0 + 1024 > nnz) e0 = (nnz - 1024) & ~(int64_t)3;
+    double s = 0.0;
+    if (tid * 4 < nr * 5 + 4) {
+        const int4v c = *reinterpret_cast<const int4v *>(Aj + e0 + tid * 4);
+        const double2v a = *reinterpret_cast<const double2v *>(Ax + e0 + tid * 4);
+        const double2v b = *reinterpret_cast<const double2v *>(Ax + e0 + tid * 4 + 2);
+        s = (double)(c.x ^ c.y ^ c.z ^ c.w) + a.x + a.y + b.x + b.y;
+    }
+    if (tid <= nr) s += (double)Ap[r0 + tid];
+    if (tid < nr) {
+        s += x[r0 + tid];
+        if constexpr (XW == 3) {
+            const int64_t lo = r0 + tid - m, hi = r0 + tid + m;
+            s += x[lo < 0 ? 0 : lo];
+            s += x[hi >= N ? N - 1 : hi];
+        }
+        st<NTS>(y + r0 + tid, s);
+    } else if (s == 123.456) y[0] = s; // keeps the loads of the lanes that own no row
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// csrx: variants of csr_stream's single-pass fast path (one 16-byte index vector per lane, one lane per row)
+//   FLAGS bit 0: row pointers in registers (each lane loads its own two; tile bounds by uniform loads): no LDS
+//                copy of the row pointers, no barrier in front of the streams
+//         bit 1: rows are stored in pairs (even lane gets its neighbour's sum by DPP): 16-byte y stores
+// ------------------------------------------------------------------------------------------------------------
+template <int FLAGS>
+__global__ void __launch_bounds__(256)
+csrx_kernel(int64_t N, int64_t nnz, const int *__restrict__ Ap, const int *__restrict__ Aj, const double *__restrict__ Ax,
+            const double *__restrict__ x, double *__restrict__ y, int rpb, int64_t tiles, int64_t tpx, int swz)
+{
+    __shared__ double prod[1024];
+    __shared__ int rowptr[260];
+    const int64_t tile = tile_of_block(blockIdx.x, tpx, swz);
+    if (tile >= tiles) return;
+    const int tid = threadIdx.x;
+    const int64_t r0 = tile * rpb;
+    const int nr = (int)((N - r0) < rpb ? (N - r0) : rpb);
+    int nz0, nz1, a = 0, b = 0;
+    if constexpr (FLAGS & 1) {
+        nz0 = Ap[r0];
+        nz1 = Ap[r0 + nr];
+        a = Ap[r0 + (tid < nr ? tid : nr)];
+        b = Ap[r0 + (tid + 1 < nr ? tid + 1 : nr)];
+    } else {
+        if (tid <= nr) rowptr[tid] = Ap[r0 + tid];
+        __syncthreads();
+        nz0 = rowptr[0];
+        nz1 = rowptr[nr];
+    }
+    const int fbase = nz0 & ~3;
+    // (probe only: assumes the tile fits one pass -- true for rpb <= 204 on the 5-point matrix -- and that the last
+    //  vector lies inside the arrays, which the host guarantees by padding the arrays)
+    const int e = fbase + tid * 4;
+    double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+    if (e < nz1) {
+        const int4v c = *reinterpret_cast<const int4v *>(Aj + e);
+        const double2v v01 = *reinterpret_cast<const double2v *>(Ax + e);
+        const double2v v23 = *reinterpret_cast<const double2v *>(Ax + e + 2);
+        p0 = v01.x * x[c.x]; p1 = v01.y * x[c.y]; p2 = v23.x * x[c.z]; p3 = v23.y * x[c.w];
+    }
+    prod[tid * 4 + 0] = p0; prod[tid * 4 + 1] = p1; prod[tid * 4 + 2] = p2; prod[tid * 4 + 3] = p3;
+    __syncthreads();
+    double s = 0.0;
+    if (tid < nr) {
+        if constexpr (!(FLAGS & 1)) { a = rowptr[tid]; b = rowptr[tid + 1]; }
+        for (int j = a; j < b; j++) s = s + prod[j - fbase];
+    }
+    if constexpr (FLAGS & 2) {
+        const double up = __shfl_down(s, 1); // the odd neighbour's sum
+        if ((tid & 1) == 0 && tid < nr) {
+            if (tid + 1 < nr && ((r0 + tid) & 1) == 0) {
+                double2v o; o.x = s; o.y = up;
+                __builtin_nontemporal_store(o, reinterpret_cast<double2v *>(y + r0 + tid));
+            } else {
+                __builtin_nontemporal_store(s, y + r0 + tid);
+                if (tid + 1 < nr) __builtin_nontemporal_store(up, y + r0 + tid + 1);
+            }
+        }
+    } else {
+        if (tid < nr) __builtin_nontemporal_store(s, y + r0 + tid);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// diax: DIA, two rows per lane, optional LDS window for the diagonals with |offset| <= H
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kH = 8; // halo of the staged window, even
+template <bool WIN, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+diax_kernel(int64_t num_rows, int64_t num_cols, int nd, int64_t pitch, const int *__restrict__ offsets,
+            const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y, int64_t tiles,
+            int64_t tpx, int swz)
+{
+    constexpr int R = BLOCK * 2;
+    __shared__ int soff[16];
+    __shared__ __attribute__((aligned(16))) double xs[WIN ? R + 2 * kH : 2];
+    const int64_t tile = tile_of_block(blockIdx.x, tpx, swz);
+    if (tile >= tiles) return;
+    const int tid = threadIdx.x;
+    const int64_t r0 = tile * R;
+    const int64_t row = r0 + 2 * tid;
+    const bool live0 = row < num_rows, live1 = row + 1 < num_rows;
+    const int64_t lrow = live0 ? row : ((num_rows - 1) & ~(int64_t)1);
+    if (tid < nd) soff[tid] = offsets[tid]; // probe: nd <= 16
+    if constexpr (WIN) {
+        for (int i = tid * 2; i < R + 2 * kH; i += BLOCK * 2) {
+            const int64_t g = r0 - kH + i;
+            double2v v;
+            if (g >= 0 && g + 1 < num_cols) v = *reinterpret_cast<const double2v *>(x + g);
+            else { v.x = (g >= 0 && g < num_cols) ? x[g] : 0.0; v.y = (g + 1 >= 0 && g + 1 < num_cols) ? x[g + 1] : 0.0; }
+            *reinterpret_cast<double2v *>(xs + i) = v;
+        }
+    }
+    __syncthreads();
+    double acc0 = 0.0, acc1 = 0.0;
+    // five diagonals at a time would be the library's grouping; the probe handles nd <= 8 in one group
+    double2v v[8];
+    double x0[8], x1[8];
+    bool ok0[8], ok1[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k < nd) {
+            const int off = __builtin_amdgcn_readfirstlane(soff[k]);
+            const int64_t c0 = lrow + off, c1 = c0 + 1;
+            ok0[k] = live0 && c0 >= 0 && c0 < num_cols;
+            ok1[k] = live1 && c1 >= 0 && c1 < num_cols;
+            v[k] = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(vals + (int64_t)k * pitch + lrow));
+            if (WIN && off >= -kH && off + 1 < kH && live0) { // uniform: staged window
+                x0[k] = xs[2 * tid + kH + off];
+                x1[k] = xs[2 * tid + kH + off + 1];
+            } else {
+                x0[k] = x[c0 < 0 ? 0 : (c0 >= num_cols ? num_cols - 1 : c0)];
+                x1[k] = x[c1 < 0 ? 0 : (c1 >= num_cols ? num_cols - 1 : c1)];
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k < nd) {
+            if (ok0[k]) acc0 = acc0 + v[k].x * x0[k];
+            if (ok1[k]) acc1 = acc1 + v[k].y * x1[k];
+        }
+    }
+    if (live1) {
+        double2v o; o.x = acc0; o.y = acc1;
+        __builtin_nontemporal_store(o, reinterpret_cast<double2v *>(y + row));
+    } else if (live0) __builtin_nontemporal_store(acc0, y + row);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+struct Timing { double med, mn; };
+static Timing time_us(const std::function<void()> &f, int batches, int launches)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    f(); f(); CK(hipDeviceSynchronize());
+    std::vector<double> t;
+    for (int r = 0; r < batches; r++) {
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < launches; i++) f();
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        t.push_back(ms / launches * 1000.0);
+    }
+    std::sort(t.begin(), t.end());
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    return {t[t.size() / 2], t[0]};
+}
+
+int main(int argc, char **argv)
+{
+    std::string only;
+    int batches = 10, launches = 20, pmc = 0;
+    int64_t m = 3162;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        if (a == "--only" && i + 1 < argc) only = argv[++i];
+        else if (a == "--batches" && i + 1 < argc) batches = atoi(argv[++i]);
+        else if (a == "--launches" && i + 1 < argc) launches = atoi(argv[++i]);
+        else if (a == "--m" && i + 1 < argc) m = atoll(argv[++i]);
+        else if (a == "--pmc" && i + 1 < argc) pmc = atoi(argv[++i]); // PMC pass: K plain launches per variant, manifest on stdout
+    }
+    const int64_t N = m * m, nnz = cmi_poisson5pt_num_entries(m, m);
+    int *Ap, *Aj, *doff;
+    double *Ax, *x, *y, *yref, *dvals;
+    const int64_t pad = 2048; // the probe kernels read whole vectors past the tile: keep them inside the allocation
+    CK(hipMalloc(&Ap, (N + 1 + pad) * 4)); CK(hipMalloc(&Aj, (nnz + pad) * 4)); CK(hipMalloc(&Ax, (nnz + pad) * 8));
+    CK(hipMalloc(&x, N * 8)); CK(hipMalloc(&y, N * 8)); CK(hipMalloc(&yref, N * 8));
+    CK(hipMemset(Aj + nnz, 0, pad * 4)); CK(hipMemset(Ax + nnz, 0, pad * 8));
+    CM(cmi_poisson5pt_csr_f64(m, m, 0, N, Ap, Aj, Ax, nullptr));
+    const int64_t pitch = N;
+    CK(hipMalloc(&doff, 5 * 4)); CK(hipMalloc(&dvals, 5 * pitch * 8));
+    CM(cmi_poisson5pt_dia_f64(m, m, pitch, doff, dvals, nullptr));
+    {
+        std::vector<double> hx(N);
+        for (int64_t i = 0; i < N; i++) hx[i] = (double)((uint32_t)((uint32_t)i * 2654435761u) % 1000u) / 997.0 - 0.5;
+        CK(hipMemcpy(x, hx.data(), N * 8, hipMemcpyHostToDevice));
+    }
+    cmi_config scalar = {CMI_CSR_SCALAR, 256, 0, 0, 0, 0, 0, 0};
+    CM(cmi_spmv_csr_f64(N, N, nnz, Ap, Aj, Ax, x, yref, 0, &scalar, nullptr));
+    CK(hipDeviceSynchronize());
+    std::vector<double> href(N), hy(N);
+    CK(hipMemcpy(href.data(), yref, N * 8, hipMemcpyDeviceToHost));
+
+    const double B_csr = 12.0 * nnz + 20.0 * N + 4, B_dia = 5.0 * pitch * 8 + 20 + 16.0 * N;
+    auto run = [&](const std::string &name, double bytes, bool check, const std::function<void()> &f) {
+        if (!only.empty() && name.find(only) == std::string::npos) return;
+        if (pmc > 0) { // launches in manifest order; tools/r2_pmc_table.py maps the counter rows back by dispatch order
+            for (int i = 0; i < pmc; i++) f();
+            CK(hipDeviceSynchronize());
+            printf("MANIFEST\t%s\t%d\t%.0f\n", name.c_str(), pmc, bytes);
+            return;
+        }
+        CK(hipMemset(y, 0xff, N * 8));
+        f();
+        CK(hipDeviceSynchronize());
+        const char *verdict = "unchecked";
+        if (check) {
+            CK(hipMemcpy(hy.data(), y, N * 8, hipMemcpyDeviceToHost));
+            verdict = memcmp(hy.data(), href.data(), N * 8) == 0 ? "bit-exact" : "DIFFERS";
+        }
+        const Timing t = time_us(f, batches, launches);
+        printf("%-44s median %7.2f us  min %7.2f us  %6.0f GB/s alg (median)  frac %.3f  %s\n", name.c_str(), t.med, t.mn,
+               bytes / t.med / 1e3, bytes / t.med / 1e3 / 8000.0, verdict);
+        fflush(stdout);
+    };
+
+    // ---- the library's kernel under each dealing mode -------------------------------------------------------
+    run("lib csr table (NULL cfg)", B_csr, true, [&] { CM(cmi_spmv_csr_f64(N, N, nnz, Ap, Aj, Ax, x, y, 0, nullptr, nullptr)); });
+    for (int swz : {0, 16, 32, 64, 1}) {
+        for (int rpb : {176, 192}) {
+            cmi_config c = {CMI_CSR_STREAM, 256, 0, rpb, 1, 2, swz, 0};
+            char nm[96];
+            snprintf(nm, sizeof nm, "lib csr_stream rpb %d swz %d", rpb, swz);
+            run(nm, B_csr, true, [&, c] { CM(cmi_spmv_csr_f64(N, N, nnz, Ap, Aj, Ax, x, y, 0, &c, nullptr)); });
+        }
+    }
+    // ---- mix ------------------------------------------------------------------------------------------------
+    for (int swz : {0, 32, 128, 1}) {
+        const int rpb = 176;
+        const int64_t tiles = (N + rpb - 1) / rpb, tpx = (tiles + 7) / 8;
+        const int64_t grid = swz == 0 ? tiles : swz == 1 ? tpx * 8 : ((tiles + 8 * swz - 1) / (8 * swz)) * 8 * swz;
+        char nm[96];
+        snprintf(nm, sizeof nm, "mix x-once   nt-store swz %d", swz);
+        run(nm, B_csr, false, [&, swz] { hipLaunchKernelGGL((mix_kernel<1, true>), dim3((unsigned)grid), dim3(256), 0, 0, N, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, (int)m); });
+        snprintf(nm, sizeof nm, "mix x-thrice nt-store swz %d", swz);
+        run(nm, B_csr, false, [&, swz] { hipLaunchKernelGGL((mix_kernel<3, true>), dim3((unsigned)grid), dim3(256), 0, 0, N, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, (int)m); });
+    }
+    // ---- csrx -----------------------------------------------------------------------------------------------
+    for (int swz : {32}) {
+        for (int rpb : {176, 192}) {
+            const int64_t tiles = (N + rpb - 1) / rpb, tpx = (tiles + 7) / 8;
+            const int64_t grid = ((tiles + 8 * swz - 1) / (8 * swz)) * 8 * swz;
+            char nm[96];
+#define CSRX(F)                                                                                                          \
+    snprintf(nm, sizeof nm, "csrx flags %d rpb %d swz %d", F, rpb, swz);                                                 \
+    run(nm, B_csr, true, [&, swz] { hipLaunchKernelGGL((csrx_kernel<F>), dim3((unsigned)grid), dim3(256), 0, 0, N, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz); })
+            CSRX(0); CSRX(1); CSRX(2); CSRX(3);
+#undef CSRX
+        }
+    }
+    // ---- ell (library kernel, launch shapes x XCD dealing) -----------------------------------------------------
+    {
+        const int64_t epitch = (N + 31) / 32 * 32;
+        int *eAj; double *eAx;
+        CK(hipMalloc(&eAj, 5 * epitch * 4)); CK(hipMalloc(&eAx, 5 * epitch * 8));
+        CM(cmi_csr_to_ell_f64(N, Ap, Aj, Ax, 5, epitch, eAj, eAx, nullptr));
+        CK(hipDeviceSynchronize());
+        const double B_ell = 5.0 * epitch * 12 + 16.0 * N;
+        run("lib ell table (NULL cfg)", B_ell, true, [&] { CM(cmi_spmv_ell_f64(N, N, 5, epitch, eAj, eAx, nullptr, x, y, 0, nullptr, nullptr)); });
+        for (int blk : {256, 512}) for (int rpl : {1, 2}) for (int swz : {0, 8, 16, 32, 64, 128}) {
+            cmi_config c = {CMI_ELL_ROW, blk, 0, 0, rpl, 3, swz, 0};
+            char nm[96];
+            snprintf(nm, sizeof nm, "lib ell block %d rpl %d swz %d", blk, rpl, swz);
+            run(nm, B_ell, true, [&, c] { CM(cmi_spmv_ell_f64(N, N, 5, epitch, eAj, eAx, nullptr, x, y, 0, &c, nullptr)); });
+        }
+        CK(hipFree(eAj)); CK(hipFree(eAx));
+    }
+    // ---- dia ------------------------------------------------------------------------------------------------
+    run("lib dia table (NULL cfg)", B_dia, true, [&] { CM(cmi_spmv_dia_f64(N, N, 5, pitch, doff, dvals, x, y, 0, nullptr, nullptr)); });
+    for (int blk : {256, 512, 1024}) for (int rpl : {1, 2}) for (int swz : {0, 8, 16, 32, 64, 128}) {
+        cmi_config c = {CMI_DIA_ROW, blk, 0, 0, rpl, 3, swz, 0};
+        char nm[96];
+        snprintf(nm, sizeof nm, "lib dia block %d rpl %d swz %d", blk, rpl, swz);
+        run(nm, B_dia, true, [&, c] { CM(cmi_spmv_dia_f64(N, N, 5, pitch, doff, dvals, x, y, 0, &c, nullptr)); });
+    }
+    for (int swz : {32}) {
+        char nm[96];
+#define DIAX(WIN, BLOCK)                                                                                                 \
+    {                                                                                                                    \
+        const int64_t tiles = (N + 2 * BLOCK - 1) / (2 * BLOCK), tpx = (tiles + 7) / 8;                                  \
+        const int64_t grid = swz == 0 ? tiles : ((tiles + 8 * swz - 1) / (8 * swz)) * 8 * swz;                           \
+        snprintf(nm, sizeof nm, "diax win %d block %d swz %d", WIN, BLOCK, swz);                                         \
+        run(nm, B_dia, true, [&, swz] { hipLaunchKernelGGL((diax_kernel<WIN, BLOCK>), dim3((unsigned)grid), dim3(BLOCK), 0, 0, N, N, 5, pitch, doff, dvals, x, y, tiles, tpx, swz); }); \
+    }
+        DIAX(false, 512) DIAX(true, 512)
+#undef DIAX
+    }
+    return 0;
+}
