@@ -11,23 +11,31 @@ C-ABI (cmi_spmv_csr_f64) with A, x, y resident in HBM.
 N = 1: BASELINE.json configs[1], poisson5pt 3162x3162 (9 998 244 rows, 49 978 572 entries), CSR,
        int32/f64, kernel + launch shape from the persisted tuning table.
 N > 1: weak scaling -- every rank owns a 3162x3162-point row block of the global
-       poisson5pt(3162, 3162*N) (N=8: 8.0e7 rows; BASELINE.json configs[4] shape), global column
-       indices; a step = exchange of x over xGMI + the local SpMV.  Default exchange ("auto"): the
-       one-sided halo pull -- each rank copies the 2*3162 boundary values its rows reference straight
-       out of its neighbours' mapped buffers with one small kernel on its own stream ("peer"); if the
-       buffers cannot be mapped, the two-sided RCCL halo exchange ("halo"); "allgather" on request
-       (cusp-autotuned_amd/distributed.py).  value = 2*global_nnz / max-over-ranks time.  The north-star's
-       literal exchange (RCCL all-gather of the whole x before each multiply) is timed beside it on up
-       to 20 steps and reported as `allgather_exchange` (never as `value`).
+       poisson5pt(3162, 3162*N) (N=8: 8.0e7 rows), global column indices; a step = exchange of x over xGMI + the
+       local SpMV.  BOTH exchanges are timed with the same protocol and K and reported under `exchanges`:
+         * the default ("auto"): the one-sided halo pull -- each rank copies the 2*3162 boundary values its rows
+           reference straight out of its neighbours' mapped buffers with one small kernel on its own stream ("peer") --
+           PROVEN FIRST IN A CHILD PROCESS that every rank starts before it makes any GPU call (a fault in the
+           cross-GPU peer access then costs the child, and the run goes on with the two-sided RCCL halo exchange
+           "halo"); it carries `value`;
+         * "allgather": the north-star's literal exchange, an RCCL all-gather of the whole x before each multiply
+           (cusp-autotuned_amd/distributed.py), with its y compared against the default exchange's.
+       Per exchange: end-to-end GFLOP/s and ms per step, the exchange alone, the SpMV alone.
+       `configs4` (N == 8, or --configs4 on): BASELINE.json configs[4]'s literal shape -- poisson5pt(10000, 10000),
+       1e8 rows, row blocks of 1250 grid lines per rank -- SpMV with both exchanges and the fused CG on top, each
+       validated (stencil closed form; recurrence residual against b - A x).
 
 Timing protocol (reference performance/spmv/benchmark.h:84-120): W untimed warm-up steps, then
 exactly K steps between a barrier + device synchronise on both sides; MAX over ranks.
-The dominant kernel's average launch duration is measured live with HIP events on the stream the
-kernel is launched on (cmi_event_*), for the roofline object.
+The dominant kernel's launch duration is measured live with HIP events on the stream the kernel is launched
+on (cmi_event_*): 10 batches of >= 20 launches (>= 200 in all, whatever --steps says), mean / median / fastest
+batch; roofline.achieved uses the mean.
 
 The `cpu_baseline` leg (rank 0, N = 1 only) times the REFERENCE's own sequential host kernel
-(oracle/_ref, kind "reference") -- or the C restatement (kind "port") when that library is absent --
-on the same matrix for ~10-20 s, and also checks the GPU result against it.
+(oracle/_ref, kind "reference", 1 core) -- or the C restatement (kind "port") when that library is absent --
+on the same matrix for ~12 s, and checks the GPU result against it bit for bit; `cpu_baseline_omp` is the
+OpenMP row-parallel kernel (kind "port": the reference's omp header does not compile here) on copies first-touched
+in parallel, one pinned thread per allowed CPU (at most 16), timed in C.
 """
 import argparse
 import ctypes
@@ -61,7 +69,67 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--format", default="csr", choices=["csr", "ell", "dia", "coo", "hyb"],
                     help="N=1 only: bench another format of the same matrix (BASELINE.json configs[2])")
+    ap.add_argument("--configs4", default="auto", choices=["auto", "on", "off"],
+                    help="N>1: the secondary leg on BASELINE.json configs[4]'s literal shape, poisson5pt(10000,10000) row-block "
+                         "sharded over the N ranks, SpMV with both exchanges + CG (auto: when N == 8)")
+    ap.add_argument("--configs4-grid", type=int, default=int(os.environ.get("CMI_BENCH_CONFIGS4_GRID", "10000")),
+                    help="grid side of that leg (tests shrink it)")
+    ap.add_argument("--probe-peer", action="store_true", help=argparse.SUPPRESS)  # child mode, see peer_probe_child
     return ap.parse_args()
+
+
+def peer_probe_child(args):
+    """CHILD process (started by every rank of an N>1 run before the parent has made a single GPU call): maps the
+    neighbours' exchange buffers over IPC and pulls from them with cmi_copy_ranges -- the one-sided exchange end to end on
+    a small vector -- and reports through its exit code.  A GPU fault in the peer access kills this process, not the
+    benchmark: the parent then times the two-sided / all-gather exchange instead.  Control plane: gloo on
+    a port of its own (the probe must not depend on RCCL or disturb the parent's rendezvous)."""
+    import torch
+    import torch.distributed as dist
+    import cusp_autotuned_amd as cmi
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = 0 if os.environ.get("CMI_BENCH_REHEARSAL", "0") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist.init_process_group("gloo", init_method=f"tcp://{os.environ.get('MASTER_ADDR', '127.0.0.1')}:{os.environ['MASTER_PORT']}",
+                            rank=rank, world_size=world)
+    piece, halo = 1 << 16, M  # the bench's halo: one grid line from each neighbour
+    n = world * piece
+    lo, hi = rank * piece, (rank + 1) * piece
+    vec = cmi.distributed.ShardedVectorExchange(n, rank, world, max(lo - halo, 0), min(hi + halo, n) - 1, torch.float64, dev, mode="auto")
+    ok = vec.plan.mode == "peer"  # _setup_peer mapped the neighbours and verified one pull on every rank
+    if ok:  # and the steady state: repeated pulls of fresh values
+        for it in range(3):
+            vec.x_local.fill_(float(100 * it + rank + 1))
+            vec.fence()
+            vec.exchange()
+            torch.cuda.synchronize()
+            for p, (l, h) in enumerate(vec.plan.recv):
+                if h > l and not bool((vec.x_full[l:h] == float(100 * it + p + 1)).all()):
+                    ok = False
+            vec.fence()
+    vec.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 3)
+
+
+def run_peer_probe(world):
+    """Parent side: spawn the probe, (ok, note).  Called before anything in this process touches the GPU."""
+    import subprocess
+    # (torchrun's TORCHELASTIC_USE_AGENT_STORE would make every child a CLIENT of a store nobody serves: the children run
+    # their own tcp:// rendezvous, rank 0 serving)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 23)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-peer", "--gpus", str(world)], env=env, timeout=150,
+                           capture_output=True, text=True)
+    except subprocess.TimeoutExpired:
+        return False, "probe timed out"
+    if r.returncode == 0:
+        return True, "ok"
+    return False, f"probe exit {r.returncode}: {(r.stderr or r.stdout)[-200:]}"
 
 
 def pmc_traffic(kernel_substr):
@@ -164,14 +232,88 @@ def stencil_expected(torch, cmi, m, n, lo, hi, dev, scale=1.0):
     return s
 
 
+def configs4_leg(torch, cmi, dist, args, rank, world, dev, barrier, timed_steps):
+    """poisson5pt(g, g) (g = 10000: 1e8 rows, 499 960 000 entries) in row blocks of whole grid lines, one per rank, global
+    column indices: SpMV with the default exchange and with the all-gather, each validated against the stencil's closed
+    form, then the fused CG (p exchanged once with the one-sided exchange, cusp/krylov/detail/cg.inl:77-105 otherwise)."""
+    g = args.configs4_grid
+    lines = -(-g // world)
+    l0, l1 = min(rank * lines, g), min((rank + 1) * lines, g)
+    lo, hi = l0 * g, l1 * g
+    N, nnz = g * g, cmi.poisson5pt_num_entries(g, g)
+    offsets = [min(r * lines, g) * g for r in range(world + 1)]
+    A = cmi.poisson5pt(g, g, "csr", dtype=torch.float64, device=dev, row_begin=lo, row_end=hi)
+    xh = cmi.fill_x(hi - lo, start=lo).to(dev)
+    want = stencil_expected(torch, cmi, g, g, lo, hi, dev)
+    span = (max(lo - g, 0), min(hi + g, N) - 1)
+    out = {"workload": f"poisson5pt {g}x{g} CSR int32/f64 ({N} rows, {nnz} entries), row blocks of {lines} grid lines x{world}",
+           "rows_per_gpu": hi - lo, "exchanges": {}}
+    y = torch.empty(hi - lo, dtype=torch.float64, device=dev)
+    steps = max(5, min(args.steps, 50))
+    default_mode = None
+    for mode in (args.exchange, "allgather"):
+        if mode == default_mode:
+            continue
+        sh = cmi.distributed.ShardedCsr(A, N, rank, world, mode=mode, col_span=span, offsets=offsets)
+        got_mode = sh.vec.plan.mode
+        if default_mode is None:
+            default_mode = got_mode
+        elif got_mode in out["exchanges"]:
+            sh.vec.close()
+            continue
+        sh.x_local.copy_(xh)
+        sh.vec.fence()
+        y.fill_(10.0)
+        sh.multiply(y)
+        good = torch.tensor([int(torch.equal(y, want))], dtype=torch.int32, device=dev)
+        dist.all_reduce(good, op=dist.ReduceOp.MIN)
+        sec = timed_steps(lambda: sh.multiply(y), steps)
+        rec = {"value": round(2.0 * nnz / sec / 1e9, 3), "unit": "GFLOP/s", "ms_per_step": round(sec * 1e3, 5), "steps": steps,
+               "bit_exact_vs_stencil_closed_form": bool(int(good.item())),
+               "exchange_only_ms": round(timed_steps(sh.vec.exchange, steps) * 1e3, 5)}
+        if args.cg_iterations > 0:
+            its = min(args.cg_iterations, 50)
+            x_sol = torch.zeros(hi - lo, dtype=torch.float64, device=dev)
+            cmi.krylov.cg(sh, x_sol.clone(), xh, iteration_limit=2, relative_tolerance=0.0)
+            barrier()
+            t0 = time.perf_counter()
+            mon = cmi.krylov.cg(sh, x_sol, xh, iteration_limit=its, relative_tolerance=0.0)
+            barrier()
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sh.vec.fence()
+            sh.x_local.copy_(x_sol)
+            sh.vec.fence()
+            r_true = torch.empty_like(xh)
+            sh.multiply(r_true)
+            rr = ((xh - r_true) ** 2).sum().reshape(1)
+            dist.all_reduce(rr)
+            true_norm = float(rr.item()) ** 0.5
+            rec["cg"] = {"iterations": mon.iteration_count, "iterations_per_s": round(mon.iteration_count / float(tt.item()), 1),
+                         "us_per_iteration": round(float(tt.item()) / max(mon.iteration_count, 1) * 1e6, 2),
+                         "final_residual_norm": mon.residuals[-1], "true_residual_norm": true_norm,
+                         "residual_consistent": bool(abs(true_norm - mon.residuals[-1]) <= 1e-6 * mon.residuals[0])}
+        out["exchanges"][got_mode] = rec
+        sh.vec.close()
+    return out
+
+
 def main():
     args = parse()
-    import torch
-    import cusp_autotuned_amd as cmi
-
+    if args.probe_peer:
+        return peer_probe_child(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # N>1 with the one-sided exchange in play: prove it in a CHILD process first -- before this process makes any GPU call --
+    # so that a fault in the cross-GPU peer access (never exercised between two devices before the driver's 8-GPU run)
+    # costs a child, not the benchmark.  Every rank spawns its child; the verdicts are agreed on below (all-reduce MIN).
+    peer_probe = None
+    if world > 1 and world == args.gpus and args.exchange in ("auto", "peer") and os.environ.get("CMI_EXCHANGE_PEER", "1") != "0":
+        peer_probe = run_peer_probe(world)
+    import torch
+    import cusp_autotuned_amd as cmi
+
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
@@ -193,6 +335,17 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if peer_probe is not None:
+            flag = torch.tensor([int(peer_probe[0])], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if os.environ.get("CMI_BENCH_FAIL_PROBE", "0") == "1":
+                flag.zero_()  # tests only: pretend a child faulted, to exercise the hand-over
+            if int(flag.item()) == 0:
+                os.environ["CMI_EXCHANGE_PEER"] = "0"  # distributed.py: "auto" then means the two-sided halo exchange
+                if args.exchange == "peer":
+                    args.exchange = "halo"
+                peer_probe = (False, peer_probe[1] if not peer_probe[0] else "another rank's probe failed")
+                print(f"[bench] rank {rank}: one-sided exchange not used: {peer_probe[1]}", file=sys.stderr, flush=True)
 
     lib = cmi.lib()
     stream = torch.cuda.current_stream()
@@ -247,7 +400,8 @@ def main():
         p = sh.vec.plan
         exchange_info = {"mode": p.mode, "values_received_per_rank": p.allgather_values if p.mode == "allgather" else p.recv_values,
                          "allgather_values": p.allgather_values, "validated_against": "stencil closed form (bit-exact)",
-                         "rejected_exchanges": rejected}
+                         "rejected_exchanges": rejected,
+                         "peer_probe_in_child_process": None if peer_probe is None else {"ok": peer_probe[0], "note": peer_probe[1]}}
 
     def barrier():
         if dist is not None:
@@ -274,48 +428,45 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- N>1: the north-star's literal exchange (RCCL all-gather of the whole x before each multiply) timed
-    #      beside the default one, same protocol, fewer steps (it moves (N-1)/N of x per rank per step) ------
-    allgather_leg = None
-    if dist is not None and exchange_info["mode"] != "allgather":
-        try:
-            sh_ag = cmi.distributed.ShardedCsr(A, N_global, rank, world, mode="allgather")
-            sh_ag.x_local.copy_(sh.x_local)
-            y_ag = torch.empty_like(y)
-            ag_steps = max(1, min(args.steps, 20))
-            for _ in range(2):
-                sh_ag.multiply(y_ag)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(ag_steps):
-                sh_ag.multiply(y_ag)
-            barrier()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            same = torch.tensor([int(torch.equal(y_ag, y))], dtype=torch.int32, device=dev)
-            dist.all_reduce(same, op=dist.ReduceOp.MIN)
-            ag_s = float(t.item()) / ag_steps
+    # ---- N>1: BOTH exchanges are first-class results: the default one (one-sided halo pull where it
+    #      validated) carries `value`; the north-star's literal exchange -- RCCL all-gather of the whole x before each
+    #      multiply -- is timed beside it with the SAME protocol and the same K, and its y compared with the default's.
+    #      Per exchange: end-to-end GFLOP/s and ms per step, the exchange alone, and (below) the SpMV alone. ------------------
+    def timed_steps(fn, steps, warm=3):
+        for _ in range(warm):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item()) / steps
 
-            def exchange_only(vec):  # the exchange alone, same protocol (make the xGMI bound visible)
-                for _ in range(2):
-                    vec.exchange()
-                barrier()
-                t0 = time.perf_counter()
-                for _ in range(ag_steps):
-                    vec.exchange()
-                barrier()
-                tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                return round(float(tt.item()) / ag_steps * 1e3, 5)
-
-            exchange_info["exchange_only_ms"] = exchange_only(sh.vec)
-            allgather_leg = {"ms_per_step": round(ag_s * 1e3, 5), "value": round(2.0 * nnz_global / ag_s / 1e9, 3), "unit": "GFLOP/s",
-                             "steps": ag_steps, "values_received_per_rank": sh_ag.vec.plan.allgather_values,
-                             "exchange_only_ms": exchange_only(sh_ag.vec),
-                             "y_identical_to_default_exchange": bool(int(same.item()))}
-            del sh_ag, y_ag
-        except Exception as e:  # noqa: BLE001 -- the secondary leg must never take the main line down
-            allgather_leg = {"error": f"{type(e).__name__}: {e}"[:300]}
+    exchanges = None
+    if dist is not None:
+        exchanges = {exchange_info["mode"]: {"value": round(2.0 * nnz_global / (elapsed / args.steps) / 1e9, 3), "unit": "GFLOP/s",
+                                             "ms_per_step": round(elapsed / args.steps * 1e3, 5), "steps": args.steps,
+                                             "values_received_per_rank": exchange_info["values_received_per_rank"],
+                                             "exchange_only_ms": round(timed_steps(sh.vec.exchange, args.steps) * 1e3, 5),
+                                             "carries_value": True}}
+        if exchange_info["mode"] != "allgather":
+            try:
+                sh_ag = cmi.distributed.ShardedCsr(A, N_global, rank, world, mode="allgather")
+                sh_ag.x_local.copy_(sh.x_local)
+                y_ag = torch.empty_like(y)
+                ag_s = timed_steps(lambda: sh_ag.multiply(y_ag), args.steps)
+                same = torch.tensor([int(torch.equal(y_ag, y))], dtype=torch.int32, device=dev)
+                dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                exchanges["allgather"] = {"value": round(2.0 * nnz_global / ag_s / 1e9, 3), "unit": "GFLOP/s", "ms_per_step": round(ag_s * 1e3, 5),
+                                          "steps": args.steps, "values_received_per_rank": sh_ag.vec.plan.allgather_values,
+                                          "exchange_only_ms": round(timed_steps(sh_ag.vec.exchange, args.steps) * 1e3, 5),
+                                          "y_identical_to_default_exchange": bool(int(same.item())), "carries_value": False}
+                del sh_ag, y_ag
+            except Exception as e:  # noqa: BLE001 -- a secondary leg must never take the main line down
+                exchanges["allgather"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # ---- dominant kernel: launch duration with HIP events on ITS stream ---------------------------------------
     # >= 200 launches whatever --steps says, as KERNEL_BATCHES batches of launches each bracketed by its own event pair
@@ -393,6 +544,15 @@ def main():
         except Exception as e:  # noqa: BLE001 -- a secondary leg
             cg_leg = {"error": f"{type(e).__name__}: {e}"[:300]}
 
+    # ---- N>1: BASELINE.json configs[4]'s literal shape -- poisson5pt(10000, 10000), 1e8 rows, row-block sharded over the
+    #      N ranks, inside cusp::krylov::cg -- as a secondary leg (the headline stays weak-scaled: 3162^2 rows per GPU) ----
+    configs4 = None
+    if dist is not None and (args.configs4 == "on" or (args.configs4 == "auto" and world == 8)):
+        try:
+            configs4 = configs4_leg(torch, cmi, dist, args, rank, world, dev, barrier, timed_steps)
+        except Exception as e:  # noqa: BLE001
+            configs4 = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     # ---- numbers -------------------------------------------------------------------------------
     ms_per_step = elapsed / args.steps * 1e3
     gflops = 2.0 * nnz_global / (elapsed / args.steps) / 1e9
@@ -445,8 +605,13 @@ def main():
                          "kernel_gflops": round(2.0 * local_nnz / (kernel_ms * 1e-3) / 1e9, 2)},
             "settle_launches": SETTLE,
         }
-        if allgather_leg is not None:
-            line["allgather_exchange"] = allgather_leg
+        if exchanges is not None:
+            for v in exchanges.values():
+                if "error" not in v:
+                    v["spmv_only_ms"] = round(kernel_ms, 6)
+            line["exchanges"] = exchanges
+        if configs4 is not None:
+            line["configs4"] = configs4
         if cg_leg is not None:
             line["cg"] = cg_leg
         if world == 1 and not args.no_cpu_baseline and fmt == "csr":

@@ -11,6 +11,7 @@ _LIB_PATH = os.path.join(_HERE, "lib", "libcusp_mi355x.so")
 _lib = None
 
 FORMAT_CSR, FORMAT_ELL, FORMAT_DIA, FORMAT_COO, FORMAT_HYB = 0, 1, 2, 3, 4
+TABLE_COO_SORTED = 5  # tuning-table key only: the launch shape of a COO multiply whose plan found the entries row-sorted
 F64, F32 = 0, 1
 KERNEL_AUTO = 0
 CSR_SCALAR, CSR_VECTOR, CSR_STREAM, CSR_STREAM_PIPE, CSR_BALANCED = 1, 2, 3, 4, 5
@@ -138,6 +139,9 @@ def _declare(L):
     L.cmi_cg_direction_f32.argtypes = [i64, vp, vp, vp, vp, vp]
     L.cmi_cg_direction_x_f32.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp]
     L.cmi_blas_dotd_f32.argtypes = [i64, vp, vp, vp, vp, vp]
+    L.cmi_tuning_hyb_rule.argtypes = [c_int, POINTER(c_int), POINTER(c_double), POINTER(c_int64)]
+    L.cmi_tuning_set_hyb_rule.argtypes = [c_int, c_int, c_double, i64]
+    L.cmi_hyb_entries_per_row.argtypes = [c_int, i64, vp, c_int, c_double, i64, POINTER(c_int64), vp]
     L.cmi_plan_create.argtypes = [c_int, c_int, i64, i64, i64, vp, cfgp, vp, POINTER(c_void_p)]
     L.cmi_plan_destroy.argtypes = [vp]
     L.cmi_plan_config.argtypes = [vp, cfgp]
@@ -402,6 +406,33 @@ def tuning_select(fmt, dtype, num_rows, num_cols, num_entries):
     c = Config()
     check(lib().cmi_tuning_select(fmt, dtype, num_rows, num_cols, num_entries, ctypes.byref(c)))
     return c
+
+
+HYB_RULE_REFERENCE, HYB_RULE_COST = 0, 1
+
+
+def tuning_hyb_rule(dtype):
+    """(kind, relative_speed, threshold) of the HYB split rule for F64 / F32; without a table the reference's
+    (HYB_RULE_REFERENCE, 3.0, 4096)."""
+    k, rs, th = c_int(), c_double(), c_int64()
+    check(lib().cmi_tuning_hyb_rule(dtype, byref(k), byref(rs), byref(th)))
+    return k.value, rs.value, th.value
+
+
+def tuning_set_hyb_rule(dtype, kind, relative_speed, threshold):
+    check(lib().cmi_tuning_set_hyb_rule(dtype, int(kind), float(relative_speed), int(threshold)))
+
+
+def hyb_entries_per_row(dtype, num_rows, Ap, kind=-1, relative_speed=0.0, threshold=0, stream=None):
+    """ELL width of the HYB split for the CSR matrix with row offsets Ap (device): the tuned rule (kind < 0), or an explicit
+    rule -- (HYB_RULE_REFERENCE, 3.0, 4096) reproduces the reference's widths."""
+    import torch
+    _need(Ap, "Ap", torch.int32)
+    code = F64 if dtype in (F64, torch.float64) else F32
+    w = c_int64()
+    check(lib().cmi_hyb_entries_per_row(code, num_rows, _ptr(Ap), int(kind), float(relative_speed), int(threshold), byref(w),
+                                        _stream(stream)))
+    return w.value
 
 
 def tuning_set(fmt, dtype, mean_entries_per_row, cfg):

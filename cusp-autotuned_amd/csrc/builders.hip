@@ -15,6 +15,7 @@
 // {r+1 | ix<m-1}, {r+m | iy<n-1}; its offset has the closed form used below, so every lane writes
 // its row independently (no scan).
 #include "common.h"
+#include <vector>
 
 namespace cmi {
 
@@ -677,3 +678,78 @@ CMI_API int cmi_hyb_to_csr_f32(int64_t num_rows, int64_t ell_width, int64_t ell_
                                int64_t coo_entries, const int32_t *coo_Ai, const int32_t *coo_Aj, const float *coo_Ax, int32_t *Ap,
                                int32_t *Aj, float *Ax, int64_t capacity, int64_t *num_entries_host, void *stream)
 { return cmi::hyb_to_csr<float>(num_rows, ell_width, ell_pitch, ell_Aj, ell_Ax, coo_entries, coo_Ai, coo_Aj, coo_Ax, Ap, Aj, Ax, capacity, num_entries_host, stream); }
+
+// ---------------------------------------------------------------------------------------------
+// HYB ELL-width cutoff under the tuned rule (cmi_tuning_hyb_rule): histogram of the row lengths on the device,
+// the reference's threshold search (format_utils.inl:281-325: cumulative histogram + find_if with
+// speed_threshold_functor, functional.inl:114-132) on the host.  Row lengths of kHybCap or more share the last bin: a
+// width beyond that is never returned (an ELL part 4096 slots wide is no ELL part).
+// ---------------------------------------------------------------------------------------------
+namespace cmi {
+constexpr int kHybCap = 4096;
+__global__ void __launch_bounds__(256) row_length_histogram_kernel(int64_t num_rows, const int *__restrict__ Ap, unsigned int *__restrict__ hist)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows; i += stride) {
+        int len = Ap[i + 1] - Ap[i];
+        len = len < 0 ? 0 : (len > kHybCap ? kHybCap : len);
+        atomicAdd(hist + len, 1u);
+    }
+}
+} // namespace cmi
+
+CMI_API int cmi_hyb_entries_per_row(int dtype, int64_t num_rows, const int32_t *Ap, int kind, double relative_speed,
+                                    int64_t threshold, int64_t *width_host, void *stream)
+{
+    if (dtype < 0 || dtype > 1 || num_rows < 0 || !width_host) return fail(CMI_ERROR_INVALID_VALUE, "cmi_hyb_entries_per_row: bad argument");
+    *width_host = 0;
+    if (num_rows == 0) return CMI_SUCCESS;
+    if (!Ap) return fail(CMI_ERROR_INVALID_VALUE, "cmi_hyb_entries_per_row: null row offsets");
+    if (kind < 0) {
+        const int st = cmi_tuning_hyb_rule(dtype, &kind, &relative_speed, &threshold);
+        if (st) return st;
+    }
+    if ((kind != CMI_HYB_RULE_REFERENCE && kind != CMI_HYB_RULE_COST) || !(relative_speed > 0.0) || threshold < 0)
+        return fail(CMI_ERROR_INVALID_VALUE, "cmi_hyb_entries_per_row: bad rule");
+    hipStream_t s = as_stream(stream);
+    unsigned int *dev = nullptr;
+    const size_t bytes = (size_t)(kHybCap + 1) * sizeof(unsigned int);
+    CMI_HIP(hipMalloc((void **)&dev, bytes));
+    std::vector<unsigned int> hist(kHybCap + 1);
+    hipError_t e = hipMemsetAsync(dev, 0, bytes, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(row_length_histogram_kernel, dim3(grid_1d(num_rows)), dim3(256), 0, s, num_rows, Ap, dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(hist.data(), dev, bytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return hip_fail(e, "cmi_hyb_entries_per_row");
+    int max_len = 0;
+    for (int k = 0; k <= kHybCap; k++) if (hist[k]) max_len = k;
+    int64_t K = max_len;
+    if (kind == CMI_HYB_RULE_REFERENCE) {
+        // the smallest k with  relative_speed * #{rows longer than k} < num_rows  or  #{rows longer than k} < threshold
+        // (float arithmetic as the reference's functor, so that (3.0, 4096) reproduces its widths exactly)
+        int64_t cum = 0;
+        for (int k = 0; k < max_len; k++) {
+            cum += hist[k];
+            const int64_t longer = num_rows - cum;
+            if ((float)relative_speed * (float)longer < (float)num_rows || longer < threshold) { K = k; break; }
+        }
+    } else {
+        // argmin over k of  num_rows * k + [coo(k) > 0] * (threshold + relative_speed * coo(k)),  coo(k) = sum over rows of
+        // max(0, len - k): walked from the longest row down (coo(max_len) = 0; coo(k) = coo(k+1) + #{rows longer than k})
+        double best = (double)num_rows * (double)max_len;
+        int64_t longer = 0;
+        double coo = 0.0;
+        for (int k = max_len - 1; k >= 0; k--) {
+            longer += hist[k + 1]; // rows of length > k
+            coo += (double)longer;
+            const double cost = (double)num_rows * (double)k + (double)threshold + relative_speed * coo;
+            if (cost < best) { best = cost; K = k; } // strict: ties go to the wider ELL part (fewer launches)
+        }
+    }
+    *width_host = K;
+    return CMI_SUCCESS;
+}

@@ -135,6 +135,34 @@ template <bool NT, typename V> __device__ __forceinline__ void st(V *p, V v)
     else *p = v;
 }
 
+// s + p[0] + p[stride] + ... + p[(n-1)*stride], added in that order (stride 1: the reference host loop's order),
+// with the LDS reads of eight terms issued before the first add: a dependent read -> add chain costs ~40 ns per
+// entry, batched reads ~8-12 ns, and the bits are the same.  (Also tried: reading the last 1..7 terms with clamped
+// positions so that a five-entry row costs one LDS round trip -- 1.4 % SLOWER on the headline matrix, whose
+// workgroups hide that latency anyway; the short tail stays a plain loop.)
+template <typename T> __device__ __forceinline__ T sum_strided(T s, const T *p, int n, int stride)
+{
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        const T *q = p + (size_t)j * stride;
+        const T v0 = q[0], v1 = q[stride], v2 = q[2 * stride], v3 = q[3 * stride], v4 = q[4 * stride], v5 = q[5 * stride],
+                v6 = q[6 * stride], v7 = q[7 * stride];
+        s = s + v0; s = s + v1; s = s + v2; s = s + v3; s = s + v4; s = s + v5; s = s + v6; s = s + v7;
+    }
+    for (; j < n; j++) s = s + p[(size_t)j * stride];
+    return s;
+}
+template <typename T> __device__ __forceinline__ T sum_in_order(T s, const T *p, int n)
+{
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        const T v0 = p[j], v1 = p[j + 1], v2 = p[j + 2], v3 = p[j + 3], v4 = p[j + 4], v5 = p[j + 5], v6 = p[j + 6], v7 = p[j + 7];
+        s = s + v0; s = s + v1; s = s + v2; s = s + v3; s = s + v4; s = s + v5; s = s + v6; s = s + v7;
+    }
+    for (; j < n; j++) s = s + p[j];
+    return s;
+}
+
 // run `f(std::integral_constant<int, POL>)` for the runtime policy value 0..3
 template <typename F> inline void with_policy(int pol, F f)
 {

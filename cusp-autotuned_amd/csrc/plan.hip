@@ -50,6 +50,7 @@ CMI_API int cmi_plan_create(int format, int dtype, int64_t num_rows, int64_t num
             p->cfg.kernel = CMI_CSR_BALANCED;
             p->cfg.items_per_thread = 0; // the table's row-tile launch shape does not apply: balanced defaults
             p->cfg.blocks_per_cu = 0;
+            p->cfg.xcd_swizzle = 0;      // (chunks in launch order: a skewed matrix has no x window worth dealing for)
         }
     } else if (format == CMI_FORMAT_COO) {
         int sorted = 1;
@@ -57,7 +58,8 @@ CMI_API int cmi_plan_create(int format, int dtype, int64_t num_rows, int64_t num
         if (st == CMI_SUCCESS) {
             p->coo_sorted = sorted;
             const bool auto_kernel = !cfg || cfg->kernel == CMI_KERNEL_AUTO;
-            if (sorted && auto_kernel) p->cfg.kernel = CMI_COO_TILE;
+            // sorted entries: the table's CMI_TABLE_COO_SORTED key (the tile kernel with its tuned cache policy / XCD dealing)
+            if (sorted && auto_kernel) select_config(CMI_TABLE_COO_SORTED, dtype, num_rows, num_cols, num_entries, cfg, &p->cfg);
             // an explicit CMI_COO_TILE on unsorted entries would add rows up wrongly: refuse it here, where it is known
             if (!sorted && p->cfg.kernel == CMI_COO_TILE) st = fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: CMI_COO_TILE needs row-sorted entries");
         }

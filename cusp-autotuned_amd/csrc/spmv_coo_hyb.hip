@@ -205,24 +205,30 @@ coo_lane4_kernel(int64_t num_entries, const int *__restrict__ Ai, const int *__r
 // ---------------------------------------------------------------------------------------------
 // The order-agnostic kernels above pay for not knowing the order: y is zero-filled first (80 MB on the headline
 // matrix) and every run end is a read-modify-write at the memory side -- 1.10 GB moved for 0.96 GB of compulsory bytes
-// (profiles/r02_formats_pmc.json).  The reference's contract for coo_matrix IS sorted entries (cusp/coo_matrix.h:72);
-// a plan (plan.hip) checks that once, and then this kernel runs.
+// (profiles/r02_formats_pmc_before.json).  The reference's contract for coo_matrix IS sorted entries
+// (cusp/coo_matrix.h:72); a plan (plan.hip) checks that once, and then this kernel runs: csr_stream's single-pass tile
+// with the row pointers built on the fly from the row indices.
 //
 // A workgroup of 256 lanes owns tile t = entries [E0, E1) = 1024 consecutive entries, and with them every row that
-// STARTS there (rows whose first entry lies in [E0, E1)), plus the rows without entries in front of each such row;
-// the last tile also owns the empty rows behind the last entry.  Owned rows are a contiguous range
-// [Rfirst, Rlast] = [row(E0 - 1) + 1, row(E1 - 1)] known from two uniform loads, so:
-//   1. every lane loads four entries as 16-byte vectors (row, column, value), gathers x, parks products and row
-//      indices in LDS; sixteen lanes also park the 64 entries BEHIND the tile (the tail of the row that straddles
-//      into the next tile -- those lines are the neighbour's, an L2 hit when the tiles share an XCD);  the y window
-//      yl[] of the owned rows starts at 0 (or at y, when accumulating);
-//   2. barrier; a lane whose entry k starts a row adds that row's products from LDS IN STORAGE ORDER -- the host
-//      loop's order (sequential/multiply/coo_spmv.h:60-66: y[i] = y[i] + V*x for the entries as stored), so the
-//      result is bit-identical to it -- walking on into the parked tail and, for rows longer than that, straight
-//      through the arrays;
-//   3. barrier; the window is stored as whole contiguous runs of y (nt hint), empty rows included.
-// More owned rows than the window holds (runs of empty rows): the window moves on, cooperatively.
-constexpr int kCooTile = 1024, kCooTail = 64, kCooWindow = 1024, kCooBlock = 256;
+// STARTS there, plus the rows without entries in front of each such row; the last tile also owns the empty rows behind
+// the last entry.  Owned rows are the contiguous range [row(E0 - 1) + 1, row(E1 - 1)], known from two uniform loads.
+//   1. every lane requests four entries as 16-byte vectors (row, column, value); sixteen lanes of wave 0 ALSO request the
+//      64 entries BEHIND the tile -- the tail of the row that straddles into the next tile (those lines are the
+//      neighbour's: an L2 hit when the tiles share an XCD) -- before anyone waits, so that wave 0 pays no second round
+//      trip; then x is gathered, products and row indices are parked in LDS, and every lane flags the entries that
+//      START a row (row differs from the predecessor's: the left neighbour's last entry, by DPP);
+//   2. still without a barrier, each WAVE compacts the positions of the row starts among its own 256 entries into its
+//      own list (a wave scan of the flag counts) and publishes the first of them;
+//   3. ONE barrier; lane i of wave w adds the products of the i-th row that starts in wave w's entries, positions
+//      [start_i, start_i+1) -- the wave's last row ends at the first start of a later wave, or in the parked tail, or,
+//      if longer than that, is walked on through the arrays -- IN STORAGE ORDER with the LDS reads batched
+//      (sum_in_order): the host loop's order (sequential/multiply/coo_spmv.h:60-66: y[i] = y[i] + V*x for the entries
+//      as stored), bit-identical to it.  Consecutive lanes hold consecutive rows: y is stored in contiguous runs (nt).
+// Rows without entries inside the owned range are rare: when there are any (owned range longer than the number of row
+// starts: a uniform test) the range is zero-filled cooperatively first (not when accumulating).
+constexpr int kCooTile = 1024, kCooTail = 64, kCooBlock = 256, kCooWaves = kCooBlock / kWave, kCooPerWave = kCooTile / kCooWaves;
+
+template <typename T> struct coo_vec { int r[4], c[4]; T v[4]; };
 
 template <typename T, int POL, bool ACC>
 __global__ void __launch_bounds__(kCooBlock)
@@ -232,15 +238,17 @@ coo_tile_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ A
 {
     constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
     __shared__ __attribute__((aligned(16))) T prod[kCooTile + kCooTail];
-    __shared__ int rowidx[1 + kCooTile + kCooTail + 1]; // [0]: row of entry E0 - 1; [1 + k]: row of entry E0 + k; one sentinel behind
-    __shared__ T yl[kCooWindow];
+    __shared__ __attribute__((aligned(16))) int rowidx[kCooTile + kCooTail]; // row of entry E0 + k
+    __shared__ unsigned short starts[kCooWaves][kCooPerWave];                 // per wave: positions of its row starts, ascending
+    __shared__ int wave_count[kCooWaves], wave_first[kCooWaves];              // per wave: number of starts, the first one (or 1 << 30)
+    __shared__ int tail_first;                                                // first row start among the parked tail, or 1 << 30
     const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle);
     if (tile >= tiles) return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const int64_t E0 = tile * kCooTile;
     const int64_t E1 = E0 + kCooTile < num_entries ? E0 + kCooTile : num_entries;
     const int n_main = (int)(E1 - E0);
-    const int n_tail = (int)((num_entries - E1) < kCooTail ? (num_entries - E1) : kCooTail);
+    const int n_tail = n_main == kCooTile ? (int)((num_entries - E1) < kCooTail ? (num_entries - E1) : kCooTail) : 0;
     // owned rows (uniform loads).  Clamped into [0, num_rows): with the sorted, in-range indices a plan vouches for the
     // clamps never bind; with anything else they keep every access inside y.
     int64_t prev_row = E0 > 0 ? Ai[E0 - 1] : -1;
@@ -250,67 +258,118 @@ coo_tile_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ A
     if (last_row >= num_rows) last_row = num_rows - 1;
     const int64_t Rfirst = prev_row + 1;
 
-    // ---- 1. stream the tile (+ its tail) into LDS --------------------------------------------------------------
-    auto park = [&](int64_t e, int slot, int live) { // entries [e, e + 4) -> slots [slot, slot + 4); `live` of them exist
-        int r[4];
-        T p[4];
+    // ---- 1. request the tile (+ its tail), then gather, park and flag ---------------------------------------------
+    auto request = [&](int64_t e, int live, coo_vec<T> &q) { // entries [e, e + 4), `live` of them exist
         if (live == 4) {
             const int4v rv = ld<NT>(reinterpret_cast<const int4v *>(Ai + e));
             const int4v cv = ld<NT>(reinterpret_cast<const int4v *>(Aj + e));
-            r[0] = rv.x; r[1] = rv.y; r[2] = rv.z; r[3] = rv.w;
+            q.r[0] = rv.x; q.r[1] = rv.y; q.r[2] = rv.z; q.r[3] = rv.w;
+            q.c[0] = cv.x; q.c[1] = cv.y; q.c[2] = cv.z; q.c[3] = cv.w;
             if constexpr (sizeof(T) == 8) {
                 const double2v a = ld<NT>(reinterpret_cast<const double2v *>(Ax + e));
                 const double2v b = ld<NT>(reinterpret_cast<const double2v *>(Ax + e + 2));
-                p[0] = a.x * x[cv.x]; p[1] = a.y * x[cv.y]; p[2] = b.x * x[cv.z]; p[3] = b.y * x[cv.w];
+                q.v[0] = a.x; q.v[1] = a.y; q.v[2] = b.x; q.v[3] = b.y;
             } else {
                 const float4v a = ld<NT>(reinterpret_cast<const float4v *>(Ax + e));
-                p[0] = a.x * x[cv.x]; p[1] = a.y * x[cv.y]; p[2] = a.z * x[cv.z]; p[3] = a.w * x[cv.w];
+                q.v[0] = a.x; q.v[1] = a.y; q.v[2] = a.z; q.v[3] = a.w;
             }
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                r[k] = k < live ? Ai[e + k] : -2; // -2: no such entry (never equal to a row)
-                p[k] = k < live ? Ax[e + k] * x[Aj[e + k]] : T(0);
+                q.r[k] = k < live ? Ai[e + k] : -2; // -2: no such entry (never equal to a row)
+                q.c[k] = k < live ? Aj[e + k] : 0;
+                q.v[k] = k < live ? Ax[e + k] : T(0);
             }
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++) { prod[slot + k] = p[k]; rowidx[1 + slot + k] = r[k]; }
     };
-    {
-        const int k0 = tid * 4;
-        const int live = n_main - k0 >= 4 ? 4 : (n_main - k0 > 0 ? n_main - k0 : 0);
-        park(E0 + k0, k0, live);
-        if (tid < kCooTail / 4) {
-            const int t0 = tid * 4;
-            const int tl = n_tail - t0 >= 4 ? 4 : (n_tail - t0 > 0 ? n_tail - t0 : 0);
-            park(E1 + t0, kCooTile + t0, n_main == kCooTile ? tl : 0); // a short (last) tile has nothing behind it
-        }
-        if (tid == kCooBlock - 1) { rowidx[0] = (int)prev_row; rowidx[1 + kCooTile + kCooTail] = -2; }
-    }
-
-    // ---- 2./3. windows of owned rows ------------------------------------------------------------------------------
-    for (int64_t w0 = Rfirst; w0 <= last_row; w0 += kCooWindow) {
-        const int wn = (int)((last_row - w0 + 1) < kCooWindow ? (last_row - w0 + 1) : kCooWindow);
-        for (int i = tid; i < wn; i += kCooBlock) yl[i] = ACC ? y[w0 + i] : T(0);
-        __syncthreads(); // products, row indices (first window) and the window's start values are in LDS
+    // products and row indices into slots [slot, slot + 4); returns the flags of the row starts (bit k)
+    auto park = [&](int64_t e, int slot, int live, const coo_vec<T> &q) -> int {
+        T p[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int k = tid * 4 + i;
-            if (k >= n_main) break;
-            const int R = rowidx[1 + k];
-            if (R == rowidx[k]) continue;                   // not the first entry of its row
-            if (R < w0 || R >= w0 + wn) continue;           // another window's row (or an index a plan would have refused)
-            T s = yl[R - w0];
-            int j = k;
-            while (rowidx[1 + j] == R) { s = s + prod[j]; j++; } // ends at another row, a missing entry (-2) or the sentinel
-            if (j == kCooTile + kCooTail) {                 // longer than tile + parked tail: on through the arrays
-                for (int64_t e = E0 + j; e < num_entries && Ai[e] == R; e++) s = s + Ax[e] * x[Aj[e]];
-            }
-            yl[R - w0] = s;
+        for (int k = 0; k < 4; k++) p[k] = k < live ? q.v[k] * x[q.c[k]] : T(0);
+        // the row in front of this vector: the previous lane's last entry (a live lane's left neighbour holds four entries);
+        // the first lane of a wave reads it from the array
+        const int up = __shfl_up(q.r[3], 1);
+        int pr = up;
+        if (lane == 0) pr = live > 0 ? (e > 0 ? Ai[e - 1] : -1) : -2;
+        int flags = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            prod[slot + k] = p[k];
+            rowidx[slot + k] = q.r[k];
+            if (k < live && q.r[k] != (k ? q.r[k - 1] : pr)) flags |= 1 << k;
         }
+        return flags;
+    };
+    const int k0 = tid * 4;
+    const int live = n_main - k0 >= 4 ? 4 : (n_main - k0 > 0 ? n_main - k0 : 0);
+    const bool tail_lane = tid < kCooTail / 4; // sixteen lanes of wave 0
+    const int t0 = tid * 4;
+    const int tlive = tail_lane ? (n_tail - t0 >= 4 ? 4 : (n_tail - t0 > 0 ? n_tail - t0 : 0)) : 0;
+    coo_vec<T> qm, qt;
+    request(E0 + k0, live, qm);
+    if (tail_lane) request(E1 + t0, tlive, qt); // in flight together with the main vectors
+    const int flags = park(E0 + k0, k0, live, qm);
+
+    // ---- 2. this wave's row starts, compacted (no barrier: the list is the wave's own) ---------------------------------
+    const int cnt = __builtin_popcount(flags);
+    int incl = cnt; // inclusive scan of the counts inside the wave
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    {
+        int pos = incl - cnt;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (flags & (1 << k)) starts[wave][pos++] = (unsigned short)(k0 + k);
+        int first = flags ? k0 + __builtin_ctz(flags) : 1 << 30;
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) { const int v = __shfl_down(first, o); first = v < first ? v : first; }
+        if (lane == kWave - 1) wave_count[wave] = incl;
+        if (lane == 0) wave_first[wave] = first;
+    }
+    if (wave == 0) { // the parked tail: first row start among its entries (wave-uniform branch)
+        int first = 1 << 30;
+        if (tail_lane) {
+            const int tf = park(E1 + t0, kCooTile + t0, tlive, qt);
+            if (tf) first = kCooTile + t0 + __builtin_ctz(tf);
+        }
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) { const int v = __shfl_down(first, o); first = v < first ? v : first; }
+        if (lane == 0) tail_first = first;
+    }
+    __syncthreads();
+
+    // ---- 3. one lane per row, storage order -------------------------------------------------------------------------
+    const int my_count = wave_count[wave];
+    int next_first = tail_first; // where this wave's last row ends: the first row start behind the wave's entries
+    int nstarts = 0;
+#pragma unroll
+    for (int w = kCooWaves - 1; w >= 0; w--) {
+        if (w > wave && wave_first[w] < (1 << 30)) next_first = wave_first[w];
+        nstarts += wave_count[w];
+    }
+    // rows without entries inside the owned range (uniform): zero them first; the row sums then overwrite their own rows
+    const int64_t owned = last_row - Rfirst + 1;
+    if (!ACC && owned > nstarts) {
+        for (int64_t g = Rfirst + tid; g <= last_row; g += kCooBlock) st<NTS>(y + g, T(0));
+        __threadfence_block();
         __syncthreads();
-        for (int i = tid; i < wn; i += kCooBlock) st<NTS>(y + w0 + i, yl[i]);
-        if (w0 + kCooWindow <= last_row) __syncthreads(); // the next window reuses yl
+    }
+    for (int i = lane; i < my_count; i += kWave) { // (more than one turn only for rows of fewer than four entries)
+        const int a = starts[wave][i];
+        const int R = rowidx[a];
+        int b;
+        bool open_end = false; // the row runs past everything parked
+        if (i + 1 < my_count) b = starts[wave][i + 1];
+        else if (next_first < (1 << 30)) b = next_first;
+        else { b = n_main + n_tail; open_end = n_tail == kCooTail; }
+        if (R >= 0 && R < num_rows) {
+            T s = ACC ? y[R] : T(0);
+            s = sum_in_order(s, prod + a, b - a);
+            if (open_end)
+                for (int64_t e = E1 + kCooTail; e < num_entries && Ai[e] == R; e++) s = s + Ax[e] * x[Aj[e]];
+            st<NTS>(y + R, s);
+        }
     }
 }
 

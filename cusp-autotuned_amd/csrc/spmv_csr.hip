@@ -63,34 +63,6 @@ csr_vector_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__res
     }
 }
 
-// s + p[0] + p[stride] + ... + p[(n-1)*stride], added in that order (stride 1: the reference host loop's order),
-// with the LDS reads of eight terms issued before the first add: a dependent read -> add chain costs ~40 ns per
-// entry, batched reads ~8-12 ns, and the bits are the same.  (Also tried: reading the last 1..7 terms with clamped
-// positions so that a five-entry row costs one LDS round trip -- 1.4 % SLOWER on the headline matrix, whose
-// workgroups hide that latency anyway; the short tail stays a plain loop.)
-template <typename T> __device__ __forceinline__ T sum_strided(T s, const T *p, int n, int stride)
-{
-    int j = 0;
-    for (; j + 8 <= n; j += 8) {
-        const T *q = p + (size_t)j * stride;
-        const T v0 = q[0], v1 = q[stride], v2 = q[2 * stride], v3 = q[3 * stride], v4 = q[4 * stride], v5 = q[5 * stride],
-                v6 = q[6 * stride], v7 = q[7 * stride];
-        s = s + v0; s = s + v1; s = s + v2; s = s + v3; s = s + v4; s = s + v5; s = s + v6; s = s + v7;
-    }
-    for (; j < n; j++) s = s + p[(size_t)j * stride];
-    return s;
-}
-template <typename T> __device__ __forceinline__ T sum_in_order(T s, const T *p, int n)
-{
-    int j = 0;
-    for (; j + 8 <= n; j += 8) {
-        const T v0 = p[j], v1 = p[j + 1], v2 = p[j + 2], v3 = p[j + 3], v4 = p[j + 4], v5 = p[j + 5], v6 = p[j + 6], v7 = p[j + 7];
-        s = s + v0; s = s + v1; s = s + v2; s = s + v3; s = s + v4; s = s + v5; s = s + v6; s = s + v7;
-    }
-    for (; j < n; j++) s = s + p[j];
-    return s;
-}
-
 // ---------------------------------------------------------------------------------------------
 // csr_stream
 // ---------------------------------------------------------------------------------------------
@@ -529,7 +501,8 @@ constexpr int kBalItems = 2048; // items per tile = 4 per lane
 template <typename T, bool VEC>
 __global__ void __launch_bounds__(kBalBlock)
 csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ Ap, const int *__restrict__ Aj,
-                    const T *__restrict__ Ax, const T *__restrict__ x, T *__restrict__ y, int64_t num_tiles, int64_t per, int accumulate)
+                    const T *__restrict__ Ax, const T *__restrict__ x, T *__restrict__ y, int64_t num_tiles, int64_t per, int accumulate,
+                    int64_t num_chunks, int64_t chunks_per_xcd, int swizzle)
 {
     // LDS is double-buffered by tile parity: a tile's two barriers (offsets+counts, products) are then all the
     // synchronisation there is -- whoever writes buffer b for tile t+2 has passed tile t+1's barriers, which
@@ -543,8 +516,12 @@ csr_balanced_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict
     // Only the chunk's ends sit on multiples of kBalItems (all the independent search below needs); inside the
     // chunk a tile ends after kBalItems items OR after the kBalBlock-th row end, whichever comes first, so at
     // most one row per lane ends in a tile (runs of empty or one-entry rows simply make shorter tiles).
+    // workgroup -> chunk of `per` tiles: in launch order, or dealt to the XCDs in runs of `swizzle` chunks (tile_of_block) so
+    // that the x window a run gathers lands in one L2
     const int64_t total_items = num_rows + num_entries;
-    int64_t d = (int64_t)blockIdx.x * per * kBalItems;
+    const int64_t chunk = tile_of_block(blockIdx.x, chunks_per_xcd, swizzle);
+    if (chunk >= num_chunks) return; // whole workgroup
+    int64_t d = chunk * per * kBalItems;
     int64_t d_end = d + per * kBalItems;
     if (d_end > total_items) d_end = total_items;
     if (d >= d_end) return; // whole workgroup
@@ -908,12 +885,16 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
             if (grid64 > tiles) grid64 = tiles;
             per = ceil_div(tiles, grid64);
         }
+        const int64_t chunks = grid64;
+        const int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
+        const int64_t cpx = ceil_div(chunks, kXcds);
+        grid64 = padded_grid(chunks, swz);
         if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "csr_balanced: grid too large");
         if (!accumulate) // rows split across tiles are completed with atomics: they start from zero
             hipLaunchKernelGGL((zero_fill_kernel<T>), dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, s, rows, y);
         const bool vec = (reinterpret_cast<uintptr_t>(Aj) % 16 == 0) && (reinterpret_cast<uintptr_t>(Ax) % 16 == 0);
-        if (vec) hipLaunchKernelGGL((csr_balanced_kernel<T, true>), dim3((unsigned)grid64), dim3(kBalBlock), 0, s, rows, nnz, Ap, Aj, Ax, x, y, tiles, per, accumulate);
-        else     hipLaunchKernelGGL((csr_balanced_kernel<T, false>), dim3((unsigned)grid64), dim3(kBalBlock), 0, s, rows, nnz, Ap, Aj, Ax, x, y, tiles, per, accumulate);
+        if (vec) hipLaunchKernelGGL((csr_balanced_kernel<T, true>), dim3((unsigned)grid64), dim3(kBalBlock), 0, s, rows, nnz, Ap, Aj, Ax, x, y, tiles, per, accumulate, chunks, cpx, swz);
+        else     hipLaunchKernelGGL((csr_balanced_kernel<T, false>), dim3((unsigned)grid64), dim3(kBalBlock), 0, s, rows, nnz, Ap, Aj, Ax, x, y, tiles, per, accumulate, chunks, cpx, swz);
         break;
     }
     default: return fail(CMI_ERROR_NOT_SUPPORTED, "cmi_spmv_csr: config.kernel is not a CSR kernel");

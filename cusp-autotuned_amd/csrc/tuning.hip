@@ -22,10 +22,17 @@ namespace cmi {
 constexpr int kBuckets = 8; // mean entries/row in [2^b, 2^(b+1)), last bucket open-ended
 
 struct Table {
-    cmi_config cfg[CMI_FORMAT_COUNT][2][kBuckets];
-    bool valid[CMI_FORMAT_COUNT][2][kBuckets];
-    double mean[CMI_FORMAT_COUNT][2][kBuckets]; // mean entries per row of the matrix the entry was tuned on (0: unknown)
+    cmi_config cfg[CMI_TABLE_KEYS][2][kBuckets];
+    bool valid[CMI_TABLE_KEYS][2][kBuckets];
+    double mean[CMI_TABLE_KEYS][2][kBuckets]; // mean entries per row of the matrix the entry was tuned on (0: unknown)
+    // HYB split rule per value type (cmi_tuning_hyb_rule); not set: the reference's constants
+    bool hyb_valid[2];
+    int hyb_kind[2];
+    double hyb_relative_speed[2];
+    long hyb_threshold[2];
 };
+constexpr double kRefRelativeSpeed = 3.0; // reference csr_to_other.h:248-254
+constexpr long kRefBreakeven = 4096;
 
 static Table g_table;
 static std::mutex g_mu;
@@ -38,7 +45,7 @@ static int bucket_of(double mean)
     return b < 0 ? 0 : (b >= kBuckets ? kBuckets - 1 : b);
 }
 
-static const char *kFormatNames[CMI_FORMAT_COUNT] = {"csr", "ell", "dia", "coo", "hyb"};
+static const char *kFormatNames[CMI_TABLE_KEYS] = {"csr", "ell", "dia", "coo", "hyb", "coo_sorted"};
 static const char *kDtypeNames[2] = {"f64", "f32"};
 
 static int round_block(int b)
@@ -66,9 +73,11 @@ static void heuristic(int format, int dtype, double mean, cmi_config *c)
         else if (mean <= 96.0) { c->items_per_thread = 2; c->threads_per_row = 0; }
         else { c->items_per_thread = 2; c->threads_per_row = 32; }
         break;
-    case CMI_FORMAT_ELL: c->kernel = CMI_ELL_ROW; c->items_per_thread = 1; break;
-    case CMI_FORMAT_DIA: c->kernel = CMI_DIA_ROW; c->items_per_thread = 1; break;
+    // measured (tools/r2_probe.hip, profiles/r02_probe_timing_session2.txt): nt policy, tiles dealt to the XCDs in chunks
+    case CMI_FORMAT_ELL: c->kernel = CMI_ELL_ROW; c->items_per_thread = 1; c->nontemporal = 3; c->xcd_swizzle = 64; break;
+    case CMI_FORMAT_DIA: c->kernel = CMI_DIA_ROW; c->items_per_thread = 2; c->block_size = 512; c->nontemporal = 3; c->xcd_swizzle = 32; break;
     case CMI_FORMAT_COO: c->kernel = CMI_COO_LANE4; c->items_per_thread = 4; break;
+    case CMI_TABLE_COO_SORTED: c->kernel = CMI_COO_TILE; c->nontemporal = kPolStoreNT; c->xcd_swizzle = 32; break;
     default: break;
     }
     (void)dtype;
@@ -190,6 +199,28 @@ static int load_file(const char *path)
     size_t n;
     while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) s.append(buf, n);
     std::fclose(f);
+    // "hyb_rule": {"f64": {"relative_speed": r, "breakeven_threshold": n}, "f32": {...}}
+    size_t h = s.find("\"hyb_rule\"");
+    if (h != std::string::npos) {
+        const size_t hend = s.find("\"entries\"", h); // the rule object precedes the entries (cmi_tuning_save's layout)
+        for (int di = 0; di < 2; di++) {
+            size_t k = s.find(std::string("\"") + kDtypeNames[di] + "\"", h);
+            if (k != std::string::npos && hend != std::string::npos && k > hend) k = std::string::npos;
+            const size_t a = k == std::string::npos ? k : s.find('{', k);
+            const size_t b = a == std::string::npos ? a : s.find('}', a);
+            if (b == std::string::npos) continue;
+            const std::string obj = s.substr(a, b - a + 1);
+            double rs = 0.0;
+            long be = -1;
+            std::string kind;
+            if (find_double(obj, "relative_speed", &rs) && find_int(obj, "threshold", &be) && rs > 0.0 && be >= 0) {
+                g_table.hyb_valid[di] = true;
+                g_table.hyb_kind[di] = (find_str(obj, "kind", &kind) && kind == "cost") ? CMI_HYB_RULE_COST : CMI_HYB_RULE_REFERENCE;
+                g_table.hyb_relative_speed[di] = rs;
+                g_table.hyb_threshold[di] = be;
+            }
+        }
+    }
     size_t p = s.find("\"entries\"");
     if (p == std::string::npos) { set_error("cmi_tuning_load: %s has no \"entries\"", path); return CMI_ERROR_IO; }
     p = s.find('[', p);
@@ -205,7 +236,7 @@ static int load_file(const char *path)
         long bucket = -1;
         if (find_str(obj, "format", &fmt) && find_str(obj, "dtype", &dt) && find_int(obj, "bucket", &bucket)) {
             int fi = -1, di = -1;
-            for (int i = 0; i < CMI_FORMAT_COUNT; i++) if (fmt == kFormatNames[i]) fi = i;
+            for (int i = 0; i < CMI_TABLE_KEYS; i++) if (fmt == kFormatNames[i]) fi = i;
             for (int i = 0; i < 2; i++) if (dt == kDtypeNames[i]) di = i;
             if (fi >= 0 && di >= 0 && bucket >= 0 && bucket < kBuckets) {
                 cmi_config c;
@@ -270,7 +301,7 @@ void select_config(int format, int dtype, int64_t rows, int64_t cols, int64_t nn
         std::lock_guard<std::mutex> lk(g_mu);
         ensure_default_loaded();
         const int b = bucket_of(mean);
-        if (format >= 0 && format < CMI_FORMAT_COUNT && g_table.valid[format][dtype][b]) {
+        if (format >= 0 && format < CMI_TABLE_KEYS && g_table.valid[format][dtype][b]) {
             *out = g_table.cfg[format][dtype][b];
             // A table entry was tuned at ONE mean row length of its bucket [2^b, 2^(b+1)); its rows per tile are scaled
             // to this matrix so that a tile keeps the tuned fill of the LDS pass: 176 rows of 5 fill 86 % of 1024 slots,
@@ -325,9 +356,21 @@ CMI_API int cmi_tuning_save(const char *path)
     ensure_default_loaded(); // save what select_config would use, not an empty table
     FILE *f = std::fopen(path, "wb");
     if (!f) { set_error("cmi_tuning_save: cannot open %s", path); return CMI_ERROR_IO; }
-    std::fprintf(f, "{\n  \"arch\": \"gfx950\",\n  \"version\": %d,\n  \"entries\": [\n", CMI_VERSION);
+    std::fprintf(f, "{\n  \"arch\": \"gfx950\",\n  \"version\": %d,\n", CMI_VERSION);
+    if (g_table.hyb_valid[0] || g_table.hyb_valid[1]) {
+        std::fprintf(f, "  \"hyb_rule\": {");
+        bool first_rule = true;
+        for (int di = 0; di < 2; di++)
+            if (g_table.hyb_valid[di]) {
+                std::fprintf(f, "%s\"%s\": {\"kind\": \"%s\", \"relative_speed\": %.4f, \"threshold\": %ld}", first_rule ? "" : ", ", kDtypeNames[di],
+                             g_table.hyb_kind[di] == CMI_HYB_RULE_COST ? "cost" : "reference", g_table.hyb_relative_speed[di], g_table.hyb_threshold[di]);
+                first_rule = false;
+            }
+        std::fprintf(f, "},\n");
+    }
+    std::fprintf(f, "  \"entries\": [\n");
     bool first = true;
-    for (int fi = 0; fi < CMI_FORMAT_COUNT; fi++)
+    for (int fi = 0; fi < CMI_TABLE_KEYS; fi++)
         for (int di = 0; di < 2; di++)
             for (int b = 0; b < kBuckets; b++) {
                 if (!g_table.valid[fi][di][b]) continue;
@@ -357,8 +400,10 @@ CMI_API int cmi_tuning_clear(void)
 
 CMI_API int cmi_tuning_set(int format, int dtype, double mean_entries_per_row, const cmi_config *cfg)
 {
-    if (format < 0 || format >= CMI_FORMAT_COUNT || dtype < 0 || dtype > 1 || !cfg)
+    if (format < 0 || format >= CMI_TABLE_KEYS || dtype < 0 || dtype > 1 || !cfg)
         return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_set: bad format/dtype/config");
+    if (format == CMI_FORMAT_COO && cfg->kernel == CMI_COO_TILE) // a plan-less multiply runs this key on entries in ANY order
+        return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_set: CMI_COO_TILE needs row-sorted entries: it belongs under CMI_TABLE_COO_SORTED");
     std::lock_guard<std::mutex> lk(g_mu);
     ensure_default_loaded(); // explicit entries layer ON TOP of the shipped table: a later AUTO multiply must not reload over them
     const int b = bucket_of(mean_entries_per_row);
@@ -368,10 +413,35 @@ CMI_API int cmi_tuning_set(int format, int dtype, double mean_entries_per_row, c
     return CMI_SUCCESS;
 }
 
+CMI_API int cmi_tuning_hyb_rule(int dtype, int *kind, double *relative_speed, int64_t *threshold)
+{
+    if (dtype < 0 || dtype > 1) return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_hyb_rule: bad value type");
+    std::lock_guard<std::mutex> lk(g_mu);
+    ensure_default_loaded();
+    const bool v = g_table.hyb_valid[dtype];
+    if (kind) *kind = v ? g_table.hyb_kind[dtype] : CMI_HYB_RULE_REFERENCE;
+    if (relative_speed) *relative_speed = v ? g_table.hyb_relative_speed[dtype] : kRefRelativeSpeed;
+    if (threshold) *threshold = v ? g_table.hyb_threshold[dtype] : kRefBreakeven;
+    return CMI_SUCCESS;
+}
+
+CMI_API int cmi_tuning_set_hyb_rule(int dtype, int kind, double relative_speed, int64_t threshold)
+{
+    if (dtype < 0 || dtype > 1 || (kind != CMI_HYB_RULE_REFERENCE && kind != CMI_HYB_RULE_COST) || !(relative_speed > 0.0) || threshold < 0)
+        return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_set_hyb_rule: bad value type, kind, speed or threshold");
+    std::lock_guard<std::mutex> lk(g_mu);
+    ensure_default_loaded();
+    g_table.hyb_valid[dtype] = true;
+    g_table.hyb_kind[dtype] = kind;
+    g_table.hyb_relative_speed[dtype] = relative_speed;
+    g_table.hyb_threshold[dtype] = (long)threshold;
+    return CMI_SUCCESS;
+}
+
 CMI_API int cmi_tuning_select(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
                               cmi_config *out)
 {
-    if (format < 0 || format >= CMI_FORMAT_COUNT || dtype < 0 || dtype > 1 || !out)
+    if (format < 0 || format >= CMI_TABLE_KEYS || dtype < 0 || dtype > 1 || !out)
         return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_select: bad format/dtype/out");
     select_config(format, dtype, num_rows, num_cols, num_entries, nullptr, out);
     return CMI_SUCCESS;

@@ -422,11 +422,11 @@ class ShardedCsr:
         overlapped (interior / boundary) schedule keeps its three launches and adds a dot."""
         from . import binding as B
         A = self.A
-        if (self.interior is None or not exchange) and not self._custom and A.values.dtype == self.torch.float64:
+        if (self.interior is None or not exchange) and not self._custom and self.vec.x_full.is_cuda:
             if exchange:
                 self.vec.exchange()
             B.spmv_csr_dot(A.num_rows, A.num_cols, A.row_offsets, A.column_indices, A.values, self.x_view, y_local,
-                           self.vec.x_local, result, workspace)
+                           self.vec.x_local, result, workspace, plan=A.plan() if A.num_entries > 0 else None)
             return y_local
         self.multiply(y_local, exchange=exchange)
         B.blas_dotd(y_local, self.vec.x_local, result, workspace)  # result is a double whatever the vectors' type

@@ -495,7 +495,12 @@ struct device_fast_path<csr_matrix<int, V, device_memory>, hyb_matrix<int, V, de
     {
         if (s.num_entries == 0) return false;
         array1d<int, host_memory> off(s.row_offsets);
-        const size_t width = compute_optimal_entries_per_row(off, 3.0f, 4096);
+        // the ELL width cutoff: the rule MEASURED on MI355X (tools/autotune_hyb.py, persisted in the tuning table: the width that
+        // minimises the modelled time of the ELL + COO launches; cusp::ktt::reset_tuning() / no table: the reference's
+        // compute_optimal_entries_per_row(3.0, 4096)).  Host conversions keep the reference's rule.
+        int64_t tuned_width = 0;
+        check(cmi_hyb_entries_per_row(detail::dtype_code<V>::value, s.num_rows, s.row_offsets.data(), -1, 0.0, 0, &tuned_width, nullptr));
+        const size_t width = static_cast<size_t>(tuned_width);
         array1d<int, host_memory> coo_off(s.num_rows);
         size_t n_coo = 0;
         for (size_t i = 0; i < s.num_rows; i++) {

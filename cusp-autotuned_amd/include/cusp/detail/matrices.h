@@ -11,6 +11,7 @@
 // converting constructors / operator= (any format, any memory space) are complete.
 #pragma once
 #include <algorithm>
+#include <memory>
 #include <numeric>
 
 #include "../array1d.h"
@@ -37,6 +38,32 @@ public:
     void resize(size_t r, size_t c, size_t n) { num_rows = r; num_cols = c; num_entries = n; }
     void swap(matrix_base &o) { std::swap(num_rows, o.num_rows); std::swap(num_cols, o.num_cols); std::swap(num_entries, o.num_entries); }
 };
+
+// What the engine learnt about a device-resident CSR / COO matrix before its first multiply (cmi_plan, cusp_mi355x.h):
+// launch shape, the CSR row-length profile, COO row-sortedness.  Owned by the CONTAINER (views have none and multiply
+// through the plan-less entry points); made at the first cusp::multiply -- that one call synchronises the stream -- or
+// ahead of time by A.plan(); re-made when the index array or the sizes change; `invalidate_plan()` after editing the
+// structure in place.  The reference has no such object (its KTT path recomputes `row_starts` on the host per call,
+// cusp/system/cuda/ktt/csr_multiply.h:239-247).
+struct plan_slot {
+    std::shared_ptr<cmi_plan> plan;
+    const void *index_ptr = nullptr;
+    size_t rows = 0, cols = 0, entries = 0;
+    void reset() { plan.reset(); index_ptr = nullptr; }
+    const cmi_plan *get(int format, int dtype, size_t r, size_t c, size_t n, const int *index, void *stream)
+    {
+        if (!plan || index_ptr != index || rows != r || cols != c || entries != n) {
+            cmi_plan *p = nullptr;
+            check(cmi_plan_create(format, dtype, (int64_t)r, (int64_t)c, (int64_t)n, index, nullptr, stream, &p));
+            plan.reset(p, [](cmi_plan *q) { cmi_plan_destroy(q); });
+            index_ptr = index; rows = r; cols = c; entries = n;
+        }
+        return plan.get();
+    }
+};
+template <typename V> struct dtype_code;
+template <> struct dtype_code<double> { static const int value = CMI_F64; };
+template <> struct dtype_code<float> { static const int value = CMI_F32; };
 
 // true for cusp containers / views (anything with a format tag)
 template <typename M, typename = void> struct has_format { static const bool value = false; };
@@ -83,7 +110,17 @@ public:
         column_indices.resize(entries);
         values.resize(entries);
     }
-    void swap(csr_matrix &o) { Parent::swap(o); row_offsets.swap(o.row_offsets); column_indices.swap(o.column_indices); values.swap(o.values); }
+    void swap(csr_matrix &o) { Parent::swap(o); row_offsets.swap(o.row_offsets); column_indices.swap(o.column_indices); values.swap(o.values); std::swap(plan_, o.plan_); }
+
+    // device_memory, int indices, float / double values: the engine's plan for this matrix (see detail::plan_slot)
+    const cmi_plan *plan(void *stream = nullptr) const
+    {
+        return plan_.get(CMI_FORMAT_CSR, detail::dtype_code<ValueType>::value, this->num_rows, this->num_cols, this->num_entries,
+                         reinterpret_cast<const int *>(row_offsets.data()), stream);
+    }
+    void invalidate_plan() const { plan_.reset(); }
+private:
+    mutable detail::plan_slot plan_;
 };
 
 template <typename I, typename V, typename M>
@@ -151,7 +188,16 @@ public:
         column_indices.resize(entries);
         values.resize(entries);
     }
-    void swap(coo_matrix &o) { Parent::swap(o); row_indices.swap(o.row_indices); column_indices.swap(o.column_indices); values.swap(o.values); }
+    void swap(coo_matrix &o) { Parent::swap(o); row_indices.swap(o.row_indices); column_indices.swap(o.column_indices); values.swap(o.values); std::swap(plan_, o.plan_); }
+
+    // device_memory: the engine's plan (row-sortedness checked once: sorted entries run the tile kernel -- storage-order
+    // sums, no atomics; see detail::plan_slot)
+    const cmi_plan *plan(void *stream = nullptr) const
+    {
+        return plan_.get(CMI_FORMAT_COO, detail::dtype_code<ValueType>::value, this->num_rows, this->num_cols, this->num_entries,
+                         reinterpret_cast<const int *>(row_indices.data()), stream);
+    }
+    void invalidate_plan() const { plan_.reset(); }
 
     // reference cusp/coo_matrix.h: sort_by_row / sort_by_row_and_column / is_sorted_by_row[_and_column]
     // (set-up operations; done on the host, stable, like the reference's stable_sort_by_key)
@@ -161,8 +207,10 @@ public:
     bool is_sorted_by_row_and_column() const { return sorted_impl(true); }
 
 private:
+    mutable detail::plan_slot plan_;
     void sort_impl(bool and_column)
     {
+        plan_.reset();
         array1d<IndexType, host_memory> ri(row_indices), ci(column_indices);
         array1d<ValueType, host_memory> va(values);
         std::vector<size_t> perm(ri.size());

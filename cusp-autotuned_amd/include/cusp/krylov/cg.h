@@ -67,11 +67,24 @@ struct pinned_scalar { // 8 page-locked bytes + the event that says they have la
 };
 
 // y <- A p and *yp <- <y, p>: one fused launch for CSR, SpMV + dot for the other formats
+inline int csr_dot_(int64_t r, int64_t c, int64_t n, const int *Ap, const int *Aj, const double *Ax, const double *x, double *y, double *yp, void *ws)
+{ return cmi_spmv_csr_dot_f64(r, c, n, Ap, Aj, Ax, x, y, x, yp, ws, cusp::detail::forced_config(), nullptr); }
+inline int csr_dot_(int64_t r, int64_t c, int64_t n, const int *Ap, const int *Aj, const float *Ax, const float *x, float *y, double *yp, void *ws)
+{ return cmi_spmv_csr_dot_f32(r, c, n, Ap, Aj, Ax, x, y, x, yp, ws, cusp::detail::forced_config(), nullptr); }
+inline int csr_dot_plan_(const cmi_plan *pl, const int *Ap, const int *Aj, const double *Ax, const double *x, double *y, double *yp, void *ws)
+{ return cmi_spmv_csr_dot_plan_f64(pl, Ap, Aj, Ax, x, y, x, yp, ws, nullptr); }
+inline int csr_dot_plan_(const cmi_plan *pl, const int *Ap, const int *Aj, const float *Ax, const float *x, float *y, double *yp, void *ws)
+{ return cmi_spmv_csr_dot_plan_f32(pl, Ap, Aj, Ax, x, y, x, yp, ws, nullptr); }
+// CSR, double or float: the fused launch, steered by the container's plan where there is one
 template <typename A, typename V> void multiply_dot(const A &a, const V &p, V &y, double *yp, void *ws, cusp::csr_format)
 {
     cusp::detail::require_int_index<A>();
-    cusp::detail::check(cmi_spmv_csr_dot_f64(a.num_rows, a.num_cols, a.num_entries, a.row_offsets.data(), a.column_indices.data(),
-                                             a.values.data(), p.data(), y.data(), p.data(), yp, ws, cusp::detail::forced_config(), nullptr));
+    if (const cmi_plan *pl = cusp::detail::plan_of(a, nullptr, 0)) {
+        cusp::detail::check(csr_dot_plan_(pl, a.row_offsets.data(), a.column_indices.data(), a.values.data(), p.data(), y.data(), yp, ws));
+        return;
+    }
+    cusp::detail::check(csr_dot_(a.num_rows, a.num_cols, a.num_entries, a.row_offsets.data(), a.column_indices.data(), a.values.data(), p.data(),
+                                 y.data(), yp, ws));
 }
 template <typename A, typename V> void multiply_dot(const A &a, const V &p, V &y, double *yp, void *ws, cusp::ell_format)
 {
@@ -120,10 +133,28 @@ template <typename A, typename V> void multiply_dot_any(const A &a, const V &p, 
 {
     multiply_dot(a, p, y, yp, ws, 0);
 }
-template <typename A, typename V> void multiply_dot_any(const A &a, const V &p, V &y, double *yp, void *ws, std::false_type /* float */)
+template <typename A, typename V> void multiply_dot_f32(const A &a, const V &p, V &y, double *yp, void *ws, cusp::csr_format)
+{
+    if (p.size() != a.num_cols || y.size() != a.num_rows) throw cusp::invalid_input_exception("cg: vector sizes do not match the matrix");
+    multiply_dot(a, p, y, yp, ws, cusp::csr_format()); // CSR fuses the dot for float too (the scalar stays a double)
+}
+template <typename A, typename V, typename Format> void multiply_dot_f32(const A &a, const V &p, V &y, double *yp, void *ws, Format)
 {
     cusp::multiply(a, p, y);
     cusp::detail::check(dotd_(y.size(), y.data(), p.data(), yp, ws));
+}
+template <typename A, typename V> auto multiply_dot_f32_any(const A &a, const V &p, V &y, double *yp, void *ws, int) -> decltype(typename A::format(), void())
+{
+    multiply_dot_f32(a, p, y, yp, ws, typename A::format());
+}
+template <typename A, typename V> void multiply_dot_f32_any(const A &a, const V &p, V &y, double *yp, void *ws, long)
+{
+    cusp::multiply(a, p, y);
+    cusp::detail::check(dotd_(y.size(), y.data(), p.data(), yp, ws));
+}
+template <typename A, typename V> void multiply_dot_any(const A &a, const V &p, V &y, double *yp, void *ws, std::false_type /* float */)
+{
+    multiply_dot_f32_any(a, p, y, yp, ws, 0);
 }
 
 template <typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor>

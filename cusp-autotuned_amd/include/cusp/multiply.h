@@ -154,6 +154,22 @@ inline int spmv_hyb(int64_t r, int64_t c, int64_t w, int64_t p, const int *eAj, 
                     const float *cAx, const float *x, float *y, int acc, void *s)
 { return cmi_spmv_hyb_f32(r, c, w, p, eAj, eAx, n, cAi, cAj, cAx, x, y, acc, nullptr, nullptr, s); }
 
+inline int spmv_csr_plan(const cmi_plan *p, const int *Ap, const int *Aj, const double *Ax, const double *x, double *y, int acc, void *s)
+{ return cmi_spmv_csr_plan_f64(p, Ap, Aj, Ax, x, y, acc, s); }
+inline int spmv_csr_plan(const cmi_plan *p, const int *Ap, const int *Aj, const float *Ax, const float *x, float *y, int acc, void *s)
+{ return cmi_spmv_csr_plan_f32(p, Ap, Aj, Ax, x, y, acc, s); }
+inline int spmv_coo_plan(const cmi_plan *p, const int *Ai, const int *Aj, const double *Ax, const double *x, double *y, int acc, void *s)
+{ return cmi_spmv_coo_plan_f64(p, Ai, Aj, Ax, x, y, acc, s); }
+inline int spmv_coo_plan(const cmi_plan *p, const int *Ai, const int *Aj, const float *Ax, const float *x, float *y, int acc, void *s)
+{ return cmi_spmv_coo_plan_f32(p, Ai, Aj, Ax, x, y, acc, s); }
+
+// the container's plan (views, and anything while cusp::ktt::tune forces a configuration: none)
+template <typename A> auto plan_of(const A &a, void *stream, int) -> decltype(a.plan(stream))
+{
+    return (forced_config() || a.num_entries == 0) ? nullptr : a.plan(stream);
+}
+template <typename A> const cmi_plan *plan_of(const A &, void *, long) { return nullptr; }
+
 template <typename A> void require_int_index()
 {
     static_assert(std::is_same<typename A::index_type, int>::value, "device_memory matrices use 32-bit int indices (the reference's default IndexType)");
@@ -166,11 +182,19 @@ template <typename A> const int *row_lengths_of(const A &, long) { return nullpt
 template <typename A, typename X, typename Y> void device_multiply(const A &a, const X &x, Y &y, int acc, void *stream, csr_format)
 {
     require_int_index<A>();
+    if (const cmi_plan *p = plan_of(a, stream, 0)) {
+        check(spmv_csr_plan(p, a.row_offsets.data(), a.column_indices.data(), a.values.data(), x.data(), y.data(), acc, stream));
+        return;
+    }
     check(spmv_csr(a.num_rows, a.num_cols, a.num_entries, a.row_offsets.data(), a.column_indices.data(), a.values.data(), x.data(), y.data(), acc, stream));
 }
 template <typename A, typename X, typename Y> void device_multiply(const A &a, const X &x, Y &y, int acc, void *stream, coo_format)
 {
     require_int_index<A>();
+    if (const cmi_plan *p = plan_of(a, stream, 0)) {
+        check(spmv_coo_plan(p, a.row_indices.data(), a.column_indices.data(), a.values.data(), x.data(), y.data(), acc, stream));
+        return;
+    }
     check(spmv_coo(a.num_rows, a.num_cols, a.num_entries, a.row_indices.data(), a.column_indices.data(), a.values.data(), x.data(), y.data(), acc, stream));
 }
 template <typename A, typename X, typename Y> void device_multiply(const A &a, const X &x, Y &y, int acc, void *stream, ell_format)
@@ -189,6 +213,12 @@ template <typename A, typename X, typename Y> void device_multiply(const A &a, c
 template <typename A, typename X, typename Y> void device_multiply(const A &a, const X &x, Y &y, int acc, void *stream, hyb_format)
 {
     require_int_index<A>();
+    if (const cmi_plan *p = plan_of(a.coo, stream, 0)) { // the COO part through its plan (kept sorted by row: tile kernel, no atomics)
+        check(spmv_ell(a.num_rows, a.num_cols, a.ell.column_indices.num_cols, a.ell.column_indices.pitch, data_of(a.ell.column_indices),
+                       data_of(a.ell.values), nullptr, x.data(), y.data(), acc, stream));
+        check(spmv_coo_plan(p, a.coo.row_indices.data(), a.coo.column_indices.data(), a.coo.values.data(), x.data(), y.data(), 1, stream));
+        return;
+    }
     check(spmv_hyb(a.num_rows, a.num_cols, a.ell.column_indices.num_cols, a.ell.column_indices.pitch, data_of(a.ell.column_indices), data_of(a.ell.values),
                    a.coo.num_entries, a.coo.row_indices.data(), a.coo.column_indices.data(), a.coo.values.data(), x.data(), y.data(), acc, stream));
 }

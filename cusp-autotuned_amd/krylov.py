@@ -167,14 +167,15 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
             dist.all_reduce(t, group=group)
 
     def spmv_dot():                              # y <- A p, yp <- <y, p>
-        f64 = p.dtype == torch.float64          # the SpMV kernels fuse the dot for f64; f32: SpMV, then a dot into a double
-        if isinstance(A, ShardedCsr):
+        f64 = p.dtype == torch.float64          # CSR fuses the dot for f64 and f32 (the scalar is a double either way);
+        if isinstance(A, ShardedCsr):            # ELL / DIA for f64; everything else: SpMV, then a dot into a double
             A.multiply_dot(y, yp, ops.ws)        # p IS A.x_local
+        elif isinstance(A, CsrMatrix) and p.is_cuda:
+            B.spmv_csr_dot(A.num_rows, A.num_cols, A.row_offsets, A.column_indices, A.values, p, y, p, yp, ops.ws,
+                           plan=A.plan() if A.num_entries > 0 else None)
         elif not f64:
             spmv(p, y)
             B.blas_dotd(y, p, yp, ops.ws)
-        elif isinstance(A, CsrMatrix):
-            B.spmv_csr_dot(A.num_rows, A.num_cols, A.row_offsets, A.column_indices, A.values, p, y, p, yp, ops.ws)
         elif isinstance(A, EllMatrix):
             B.spmv_ell_dot(A.num_rows, A.num_cols, A.num_entries_per_row, A.pitch, A.column_indices, A.values, p, y, p, yp, ops.ws,
                            row_lengths=A.row_lengths)

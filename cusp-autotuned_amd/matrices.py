@@ -21,9 +21,14 @@ class _Planned:
     """The container owns its plan (binding.Plan): made at the first multiply without an explicit config -- that call
     synchronises once -- and kept until the structure arrays are replaced (`invalidate()` after editing them in place)."""
 
-    def _plan_for(self, fmt_code, index_array, stream):
+    _plan = None
+    _plan_key = None
+
+    def _plan_for(self, fmt_code, index_array, stream, create=True):
         key = (index_array.data_ptr(), self.num_rows, self.num_cols, self.num_entries, self.values.dtype)
-        if getattr(self, "_plan_key", None) != key:
+        if self._plan_key != key:
+            if not create:
+                return None
             self._plan = B.Plan(fmt_code, self.values.dtype, self.num_rows, self.num_cols, self.num_entries, index_array, None, stream)
             self._plan_key = key
         return self._plan
@@ -44,8 +49,8 @@ class CsrMatrix(_Planned):
     values: object
     format = "csr"
 
-    def plan(self, stream=None):
-        return self._plan_for(B.FORMAT_CSR, self.row_offsets, stream)
+    def plan(self, stream=None, create=True):
+        return self._plan_for(B.FORMAT_CSR, self.row_offsets, stream, create)
 
 
 @dataclass
@@ -59,8 +64,8 @@ class CooMatrix(_Planned):
     values: object
     format = "coo"
 
-    def plan(self, stream=None):
-        return self._plan_for(B.FORMAT_COO, self.row_indices, stream)
+    def plan(self, stream=None, create=True):
+        return self._plan_for(B.FORMAT_COO, self.row_indices, stream, create)
 
 
 @dataclass
@@ -115,11 +120,13 @@ def multiply(A, x, y, accumulate=False, cfg=None, stream=None):
     """y = A*x (or y += A*x).  Mirrors the 3-argument cusp::multiply (cusp/multiply.h:40).  Without an explicit config
     CSR and COO matrices multiply through their plan (made once, at the first such call; not while a stream capture is
     recording -- then the plan-less entry point runs the table's kernel)."""
-    if isinstance(A, (CsrMatrix, CooMatrix)) and cfg is None and A.num_entries > 0 and not _capturing(stream):
-        if isinstance(A, CsrMatrix):
-            B.spmv_csr_plan(A.plan(stream), A.row_offsets, A.column_indices, A.values, x, y, accumulate, stream)
-        else:
-            B.spmv_coo_plan(A.plan(stream), A.row_indices, A.column_indices, A.values, x, y, accumulate, stream)
+    plan = None
+    if isinstance(A, (CsrMatrix, CooMatrix)) and cfg is None and A.num_entries > 0:
+        plan = A.plan(stream, create=not _capturing(stream))  # an existing plan is used inside a capture, none is made there
+    if plan is not None and isinstance(A, CsrMatrix):
+        B.spmv_csr_plan(plan, A.row_offsets, A.column_indices, A.values, x, y, accumulate, stream)
+    elif plan is not None:
+        B.spmv_coo_plan(plan, A.row_indices, A.column_indices, A.values, x, y, accumulate, stream)
     elif isinstance(A, CsrMatrix):
         B.spmv_csr(A.num_rows, A.num_cols, A.row_offsets, A.column_indices, A.values, x, y, accumulate, cfg, stream)
     elif isinstance(A, CooMatrix):
@@ -132,8 +139,15 @@ def multiply(A, x, y, accumulate=False, cfg=None, stream=None):
                    accumulate, cfg, stream)
     elif isinstance(A, HybMatrix):
         e, c = A.ell, A.coo
-        B.spmv_hyb(A.num_rows, A.num_cols, e.num_entries_per_row, e.pitch, e.column_indices, e.values,
-                   c.row_indices, c.column_indices, c.values, x, y, accumulate, cfg, None, stream)
+        if cfg is None and c.num_entries > 0 and c.plan(stream, create=not _capturing(stream)) is not None:
+            # the two launches of cmi_spmv_hyb_* issued here so that the COO part runs through ITS plan (hyb_matrix keeps
+            # that part sorted by row: the tile kernel, no atomics): ELL with the caller's accumulate, COO on top
+            B.spmv_ell(A.num_rows, A.num_cols, e.num_entries_per_row, e.pitch, e.column_indices, e.values, x, y, None, accumulate,
+                       None, stream)
+            B.spmv_coo_plan(c.plan(stream), c.row_indices, c.column_indices, c.values, x, y, True, stream)
+        else:
+            B.spmv_hyb(A.num_rows, A.num_cols, e.num_entries_per_row, e.pitch, e.column_indices, e.values,
+                       c.row_indices, c.column_indices, c.values, x, y, accumulate, cfg, None, stream)
     else:
         raise TypeError(f"multiply: unsupported matrix type {type(A).__name__}")
     return y
@@ -171,8 +185,8 @@ def poisson5pt(m, n, fmt="csr", dtype=None, device="cuda", row_begin=0, row_end=
 def convert(csr, fmt, num_entries_per_row=None, ell_alignment=32):
     """CSR -> {coo, ell, hyb, dia} and row-sorted COO -> CSR on the device (reference conversions/csr_to_other.h:56-306,
     coo_to_other.h).
-    For ELL the width defaults to the longest row; for HYB pass num_entries_per_row (the reference's
-    compute_optimal_entries_per_row heuristic lives in the C++ layer / oracle)."""
+    For ELL the width defaults to the longest row; for HYB to the tuned split rule (cmi_hyb_entries_per_row: the
+    reference's compute_optimal_entries_per_row with the pair measured on MI355X, tools/autotune_hyb.py)."""
     import torch
     if isinstance(csr, CooMatrix) and fmt == "csr":
         # row-sorted COO -> CSR on the device: the offsets from the row indices in one pass (order checked on the way)
@@ -203,7 +217,12 @@ def convert(csr, fmt, num_entries_per_row=None, ell_alignment=32):
     if fmt in ("ell", "hyb"):
         lens = (csr.row_offsets[1:] - csr.row_offsets[:-1])
         max_len = int(lens.max().item()) if csr.num_rows else 0
-        width = max_len if num_entries_per_row is None else int(num_entries_per_row)
+        if num_entries_per_row is not None:
+            width = int(num_entries_per_row)
+        elif fmt == "hyb" and csr.num_rows:
+            width = B.hyb_entries_per_row(csr.values.dtype, csr.num_rows, csr.row_offsets)
+        else:
+            width = max_len
         pitch = _round_up(csr.num_rows, ell_alignment)
         eAj = torch.empty(width * pitch, dtype=torch.int32, device=dev)
         eAx = torch.empty(width * pitch, dtype=csr.values.dtype, device=dev)

@@ -114,7 +114,12 @@ typedef enum cmi_format {
     CMI_FORMAT_DIA = 2,
     CMI_FORMAT_COO = 3,
     CMI_FORMAT_HYB = 4,
-    CMI_FORMAT_COUNT = 5
+    CMI_FORMAT_COUNT = 5,     /* number of matrix formats */
+    CMI_TABLE_COO_SORTED = 5, /* a key of the tuning table only, not a matrix format: the launch shape of a COO multiply
+                                 whose plan found the entries sorted by row (CMI_COO_TILE and its cache policy / XCD
+                                 dealing); the CMI_FORMAT_COO key stays with the order-agnostic kernels, which is what a
+                                 plan-less call must run */
+    CMI_TABLE_KEYS = 6
 } cmi_format;
 
 typedef enum cmi_dtype { CMI_F64 = 0, CMI_F32 = 1 } cmi_dtype;
@@ -178,6 +183,28 @@ int cmi_tuning_set(int format, int dtype, double mean_entries_per_row, const cmi
 /* The config a NULL-config call with this shape would run. */
 int cmi_tuning_select(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
                       cmi_config *out);
+
+/* HYB split rule = the ELL width cutoff, tuned offline (tools/autotune_hyb.py) and persisted in the same table file.
+ * Two rule kinds, both functions of the row-length histogram alone:
+ *   CMI_HYB_RULE_REFERENCE  the reference's cusp::compute_optimal_entries_per_row
+ *       (cusp/system/detail/generic/format_utils.inl:281-325 with cusp/detail/functional.inl:114-132): the smallest k with
+ *       relative_speed * #{rows longer than k} < num_rows  or  #{rows longer than k} < threshold.  The reference hard-wires
+ *       (3.0, 4096), "chosen empirically for a GTX280" (csr_to_other.h:248-254); this is what applies without a table.
+ *   CMI_HYB_RULE_COST  the width that minimises the modelled time of the two launches
+ *       num_rows * k  +  [the COO part is not empty] * (threshold + relative_speed * coo_entries(k))      (in ELL slots)
+ *       -- relative_speed = cost of a COO entry in ELL slots, threshold = fixed cost of the second launch in ELL slots.
+ *       The reference's rule is this model's marginal test without the launch term; on MI355X the launch term decides
+ *       small matrices (one launch of a padded ELL beats two) and the measured pair is (1.3, 5e6), not (3, 4096):
+ *       geometric-mean regret over the tuning set 1.01 against 1.22 for the best pair of the reference's form
+ *       (profiles/r02_autotune_hyb.jsonl).                                                                            */
+typedef enum cmi_hyb_rule_kind { CMI_HYB_RULE_REFERENCE = 0, CMI_HYB_RULE_COST = 1 } cmi_hyb_rule_kind;
+int cmi_tuning_hyb_rule(int dtype, int *kind, double *relative_speed, int64_t *threshold);
+int cmi_tuning_set_hyb_rule(int dtype, int kind, double relative_speed, int64_t threshold);
+/* The width a rule gives for the CSR matrix with these row offsets: histogram of the row lengths on the device, rule on
+ * the host.  kind < 0: the tuned rule (then relative_speed / threshold are ignored).  Set-up call: allocates scratch and
+ * synchronises `stream`.  Row lengths beyond 4096 count as 4096 (no width beyond that is returned). */
+int cmi_hyb_entries_per_row(int dtype, int64_t num_rows, const int32_t *Ap, int kind, double relative_speed,
+                            int64_t threshold, int64_t *width_host, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* Plans (cmi_plan_create / destroy / select).        */

@@ -188,6 +188,58 @@ def test_tuning_heuristics_and_table_roundtrip(cmi, tmp_path):
         cmi.tuning_load(str(tmp_path / "missing.json"))
 
 
+def test_tuning_set_before_any_lookup_survives_the_default_table(tmp_path):
+    """cmi_tuning_set as the FIRST tuning call of a process must layer on top of the shipped table -- the first
+    AUTO lookup afterwards used to load the shipped file over it.  Needs a fresh process (the table is process-wide)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import cusp_autotuned_amd as cmi\n"
+        "cfg = cmi.Config(kernel=cmi.CSR_VECTOR, block_size=128, threads_per_row=8)\n"
+        "cmi.tuning_set(cmi.FORMAT_CSR, cmi.F64, 5.0, cfg)            # first tuning call of the process\n"
+        "c = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 5000)  # AUTO lookup: loads nothing over it\n"
+        "assert (c.kernel, c.block_size, c.threads_per_row) == (cmi.CSR_VECTOR, 128, 8), c\n"
+        "e = cmi.tuning_select(cmi.FORMAT_ELL, cmi.F64, 1000, 1000, 5000)   # ... and the shipped entries are there underneath\n"
+        "assert e.kernel == cmi.ELL_ROW and e.block_size > 0\n"
+        "d = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 30000)  # another bucket: the shipped CSR entry\n"
+        "assert d.kernel == cmi.CSR_STREAM, d\n"
+        "cmi.tuning_save(%r)\n"
+    ) % (ROOT, str(tmp_path / "layered.json"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    doc = json.load(open(tmp_path / "layered.json"))
+    assert len(doc["entries"]) > 10            # the shipped table was loaded before the save, not an empty one
+
+
+def test_hyb_rule_and_sorted_coo_key_in_the_table(cmi, tmp_path):
+    cmi.tuning_clear()
+    assert cmi.tuning_hyb_rule(cmi.F64) == (cmi.HYB_RULE_REFERENCE, 3.0, 4096)   # no table: the reference's rule (csr_to_other.h:248-254)
+    c = cmi.tuning_select(cmi.TABLE_COO_SORTED, cmi.F64, 1000, 1000, 5000)
+    assert c.kernel == cmi.COO_TILE
+    cmi.tuning_set_hyb_rule(cmi.F64, cmi.HYB_RULE_COST, 1.6, 512)
+    cmi.tuning_set(cmi.TABLE_COO_SORTED, cmi.F32, 5.0, cmi.Config(kernel=cmi.COO_TILE, nontemporal=3, xcd_swizzle=64))
+    with pytest.raises(cmi.CmiError):                          # the plan-less COO key must stay order-agnostic
+        cmi.tuning_set(cmi.FORMAT_COO, cmi.F64, 5.0, cmi.Config(kernel=cmi.COO_TILE))
+    with pytest.raises(cmi.CmiError):
+        cmi.tuning_set_hyb_rule(cmi.F64, cmi.HYB_RULE_COST, 0.0, 10)
+    with pytest.raises(cmi.CmiError):
+        cmi.tuning_set_hyb_rule(cmi.F64, 7, 1.0, 10)
+    path = str(tmp_path / "rule.json")
+    cmi.tuning_save(path)
+    doc = json.load(open(path))
+    assert doc["hyb_rule"] == {"f64": {"kind": "cost", "relative_speed": 1.6, "threshold": 512}}
+    assert [e["format"] for e in doc["entries"]] == ["coo_sorted"]
+    cmi.tuning_clear()
+    assert cmi.tuning_hyb_rule(cmi.F64) == (cmi.HYB_RULE_REFERENCE, 3.0, 4096)
+    cmi.tuning_load(path)
+    assert cmi.tuning_hyb_rule(cmi.F64) == (cmi.HYB_RULE_COST, 1.6, 512)
+    assert cmi.tuning_hyb_rule(cmi.F32) == (cmi.HYB_RULE_REFERENCE, 3.0, 4096)
+    c = cmi.tuning_select(cmi.TABLE_COO_SORTED, cmi.F32, 1000, 1000, 5000)
+    assert (c.kernel, c.nontemporal, c.xcd_swizzle) == (cmi.COO_TILE, 3, 64)
+    cmi.tuning_clear()
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     """No CPU fallback: without the HIP library the binding raises at first use."""
     import cusp_autotuned_amd.binding as b

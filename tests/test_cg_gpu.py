@@ -178,3 +178,50 @@ def test_cg_sharded_matches_single(tmp_path, cmi, orc, mode, world):
     xs, hist = numpy_cg(orc, Ap, Aj, Ax, oracle.fill_x(m * n), iters, 1e-12)
     assert np.allclose(parts[0]["hist"], hist, rtol=1e-9)
     assert np.allclose(np.concatenate([p["x"] for p in parts]), xs, rtol=1e-8, atol=1e-12)
+
+
+def test_cg_1e8_rows_single_gpu(cmi):
+    """BASELINE.json configs[4]'s matrix on ONE device (it fits 288 GB): poisson5pt(10000, 10000), 1e8 rows, 499 960 000
+    entries, inside the fused CG (cusp/krylov/detail/cg.inl:77-105 with the SpMV + <Ap,p> fusion).  Checked without a
+    1e8-row host oracle run: (1) the recurrence residual against b - A x computed from the stencil's closed form
+    (bench.stencil_expected -- no kernel of the library), (2) the fused history against the plain driver's (cg.inl replayed
+    operation by operation; itself pinned to the numpy restatement driven by the CPU oracle at sizes the oracle handles,
+    tests above), (3) the SpMV on this matrix bit for bit against the closed form."""
+    import torch
+    import bench
+    if torch.cuda.get_device_properties(0).total_memory < 64 * 2**30:
+        pytest.skip("needs 64 GiB of device memory")
+    m = n = 10000
+    N = m * n
+    A = cmi.poisson5pt(m, n, "csr")
+    assert A.num_rows == N and A.num_entries == 499_960_000
+    b = cmi.fill_x(N).to("cuda")
+    its = 40
+    x = torch.zeros(N, dtype=torch.float64, device="cuda")
+    mon = cmi.krylov.cg(A, x, b, iteration_limit=its, relative_tolerance=0.0, fused=True)
+    assert mon.iteration_count == its and len(mon.residuals) == its + 1
+    assert all(np.isfinite(mon.residuals)) and mon.residuals[-1] < mon.residuals[0]
+    # (1) true residual through the closed form (x scaled into the stencil helper's input by linearity: A x computed in pieces)
+    #     stencil_expected multiplies the bench's fixed x; for an arbitrary vector use the library-free torch expression below
+    i = torch.arange(N, dtype=torch.int64, device="cuda")
+    ix = i % m
+    Ax_ = 4.0 * x
+    Ax_[m:] -= x[:-m]
+    Ax_[:-m] -= x[m:]
+    left = torch.zeros_like(x)
+    left[1:] = x[:-1]
+    Ax_ -= torch.where(ix > 0, left, torch.zeros_like(x))
+    right = torch.zeros_like(x)
+    right[:-1] = x[1:]
+    Ax_ -= torch.where(ix < m - 1, right, torch.zeros_like(x))
+    true_norm = float((b - Ax_).norm())
+    assert abs(true_norm - mon.residuals[-1]) <= 1e-8 * mon.residuals[0], (true_norm, mon.residuals[-1])
+    del Ax_, left, right, i, ix
+    # (2) plain driver, same history
+    x2 = torch.zeros(N, dtype=torch.float64, device="cuda")
+    mon2 = cmi.krylov.cg(A, x2, b, iteration_limit=8, relative_tolerance=0.0, fused=False)
+    assert np.allclose(mon.residuals[:9], mon2.residuals, rtol=1e-10)
+    # the SpMV inside is the bit-exact one: y = A b against the closed form
+    y = torch.empty(N, dtype=torch.float64, device="cuda")
+    cmi.multiply(A, b, y)
+    assert torch.equal(y, bench.stencil_expected(torch, cmi, m, n, 0, N, "cuda"))

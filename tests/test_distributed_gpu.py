@@ -139,7 +139,8 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     import sys
     env = dict(os.environ, CMI_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--configs4", "on", "--configs4-grid", "400"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -151,9 +152,38 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert line["config"]["rows_per_gpu"] == 3162 * 3162 and "cpu_baseline" not in line
     cg = line["cg"]                  # the caller, sharded: one-sided scheme, recurrence residual == b - A x
     assert "error" not in cg and cg["iterations"] == 100 and cg["residual_consistent"] and cg["exchange"] == "peer"
-    assert line["config"]["x_exchange"]["exchange_only_ms"] > 0
-    ag = line["allgather_exchange"]  # the north-star's literal exchange, timed beside the default
+    # the one-sided exchange was proven in a child process before the parents touched the GPU
+    assert line["config"]["x_exchange"]["peer_probe_in_child_process"] == {"ok": True, "note": "ok"}
+    # both exchanges are first-class: same steps, value + exchange alone + SpMV alone each
+    ex = line["exchanges"]
+    assert set(ex) == {"peer", "allgather"} and ex["peer"]["carries_value"] and ex["peer"]["value"] == line["value"]
+    ag = ex["allgather"]             # the north-star's literal exchange, timed beside the default
     assert "error" not in ag and ag["y_identical_to_default_exchange"] and ag["values_received_per_rank"] == 3162 * 3162
+    for v in ex.values():
+        assert v["steps"] == 5 and v["value"] > 0 and v["exchange_only_ms"] > 0 and v["spmv_only_ms"] > 0
+    # BASELINE.json configs[4]'s shape (shrunk: 400x400 over 2 ranks), SpMV with both exchanges + CG, each validated
+    c4 = line["configs4"]
+    assert "error" not in c4 and c4["rows_per_gpu"] == 200 * 400 and set(c4["exchanges"]) == {"peer", "allgather"}
+    for v in c4["exchanges"].values():
+        assert v["bit_exact_vs_stencil_closed_form"] and v["value"] > 0 and v["cg"]["residual_consistent"]
+
+
+def test_bench_survives_a_failed_peer_probe(tmp_path):
+    """The child-process probe of the one-sided exchange reports failure (CMI_BENCH_FAIL_PROBE pretends a child faulted):
+    every rank agrees, the one-sided exchange is never attempted in the parents, the two-sided halo exchange carries value."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, CMI_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1", CMI_BENCH_FAIL_PROBE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--cg-iterations", "5"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    ex = line["config"]["x_exchange"]
+    assert ex["mode"] == "halo" and ex["rejected_exchanges"] == [] and ex["peer_probe_in_child_process"]["ok"] is False
+    assert set(line["exchanges"]) == {"halo", "allgather"} and line["cg"]["exchange"] == "halo" and line["cg"]["residual_consistent"]
 
 
 def test_bench_hands_over_to_the_next_exchange_when_one_is_rejected(tmp_path):
@@ -172,4 +202,4 @@ def test_bench_hands_over_to_the_next_exchange_when_one_is_rejected(tmp_path):
     ex = line["config"]["x_exchange"]
     assert ex["rejected_exchanges"] == ["peer"] and ex["mode"] == "halo" and ex["validated_against"].startswith("stencil")
     assert line["value"] > 0 and line["cg"]["residual_consistent"] and line["cg"]["exchange"] == "halo"
-    assert line["allgather_exchange"]["y_identical_to_default_exchange"]
+    assert line["exchanges"]["allgather"]["y_identical_to_default_exchange"] and line["exchanges"]["halo"]["carries_value"]

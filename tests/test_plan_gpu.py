@@ -1,0 +1,187 @@
+"""cmi_plan, the sorted-COO table key and the tuned HYB split rule, through the C-ABI on an MI355X."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    return torch
+
+
+def dev(a, torch):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_plan_lifecycle_and_errors(cmi, torch_cuda, orc):
+    torch = torch_cuda
+    Ap, Aj, Ax = orc.poisson5pt_csr(37, 29)
+    n = 37 * 29
+    dAp, dAj, dAx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch)
+    x = orc.fill_x(n)
+    want = orc.spmv_csr(Ap, Aj, Ax, x)
+    plan = cmi.Plan(cmi.FORMAT_CSR, torch.float64, n, n, len(Aj), dAp)
+    info = plan.info()
+    assert info == {"max_row_length": 5, "entries_in_long_rows": 0, "coo_sorted": None, "storage_order_sums": True}
+    table = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, n, n, len(Aj))
+    assert plan.config().as_dict() == table.as_dict()          # nothing in the profile overrides the table here
+    y = torch.full((n,), 10.0, dtype=torch.float64, device="cuda")
+    cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dev(x, torch), y)
+    assert np.array_equal(y.cpu().numpy(), want)
+    # a plan made with an explicit config keeps it
+    cfg = cmi.Config(kernel=cmi.CSR_VECTOR, threads_per_row=4)
+    pv = cmi.Plan(cmi.FORMAT_CSR, torch.float64, n, n, len(Aj), dAp, cfg)
+    assert pv.config().kernel == cmi.CSR_VECTOR and not pv.info()["storage_order_sums"]
+    # wrong value type / format for the entry point
+    L = cmi.lib()
+    yf = torch.zeros(n, dtype=torch.float32, device="cuda")
+    st = L.cmi_spmv_csr_plan_f32(plan.handle, ctypes.c_void_p(dAp.data_ptr()), ctypes.c_void_p(dAj.data_ptr()), ctypes.c_void_p(yf.data_ptr()),
+                                 ctypes.c_void_p(yf.data_ptr()), ctypes.c_void_p(yf.data_ptr()), 0, None)
+    assert st == 1  # CMI_ERROR_INVALID_VALUE
+    st = L.cmi_spmv_coo_plan_f64(plan.handle, ctypes.c_void_p(dAp.data_ptr()), ctypes.c_void_p(dAj.data_ptr()), ctypes.c_void_p(dAx.data_ptr()),
+                                 ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(y.data_ptr()), 0, None)
+    assert st == 1
+    with pytest.raises(cmi.CmiError):
+        cmi.Plan(cmi.FORMAT_CSR, torch.float64, n, n, len(Aj), None)   # CSR needs its row offsets
+    with pytest.raises(cmi.CmiError):
+        cmi.Plan(7, torch.float64, n, n, len(Aj), dAp)
+    # ELL / DIA / HYB: the resolved launch shape only
+    pe = cmi.Plan(cmi.FORMAT_ELL, torch.float64, n, n, 5 * n)
+    assert pe.config().kernel == cmi.ELL_ROW and pe.info()["storage_order_sums"] and pe.info()["max_row_length"] == -1
+    assert cmi.Plan(cmi.FORMAT_DIA, torch.float32, n, n, 5 * n).config().kernel == cmi.DIA_ROW
+    # an empty matrix plans (and multiplies) without touching the device arrays
+    p0 = cmi.Plan(cmi.FORMAT_CSR, torch.float64, 0, 0, 0, None)
+    assert p0.info()["max_row_length"] == -1
+
+
+def test_coo_plan_sorted_and_unsorted(cmi, torch_cuda, orc, golden_irregular):
+    torch, g = torch_cuda, golden_irregular
+    rows, cols = int(g["rows"]), int(g["cols"])
+    Ap, Aj, Ax, x = (g[f"f64_{k}"] for k in ("Ap", "Aj", "Ax", "x"))
+    Ai = orc.csr_row_indices(Ap)
+    want = orc.spmv_coo(rows, Ai, Aj, Ax, x)
+    dx = dev(x, torch)
+    ps = cmi.Plan(cmi.FORMAT_COO, torch.float64, rows, cols, len(Aj), dev(Ai, torch))
+    assert ps.info()["coo_sorted"] is True and ps.config().kernel == cmi.COO_TILE and ps.info()["storage_order_sums"]
+    assert ps.config().as_dict() == cmi.tuning_select(cmi.TABLE_COO_SORTED, cmi.F64, rows, cols, len(Aj)).as_dict()
+    y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
+    cmi.spmv_coo_plan(ps, dev(Ai, torch), dev(Aj, torch), dev(Ax, torch), dx, y)
+    assert np.array_equal(y.cpu().numpy(), want)
+    # shuffled entries: the plan says so and runs an order-agnostic kernel (tolerance class)
+    perm = np.random.default_rng(8).permutation(len(Aj))
+    dAi, dAj, dAx = dev(Ai[perm], torch), dev(Aj[perm], torch), dev(Ax[perm], torch)
+    pu = cmi.Plan(cmi.FORMAT_COO, torch.float64, rows, cols, len(Aj), dAi)
+    assert pu.info()["coo_sorted"] is False and pu.config().kernel in (cmi.COO_LANE4, cmi.COO_SEGMENTED)
+    assert not pu.info()["storage_order_sums"]
+    y.fill_(10.0)
+    cmi.spmv_coo_plan(pu, dAi, dAj, dAx, dx, y)
+    bound = orc.spmv_csr(Ap, Aj, np.abs(Ax), np.abs(x))
+    assert np.all(np.abs(y.cpu().numpy() - want) <= 1e-6 * np.maximum(bound, 1e-300))
+    # asking for the tile kernel on unsorted entries is refused where it is known
+    with pytest.raises(cmi.CmiError):
+        cmi.Plan(cmi.FORMAT_COO, torch.float64, rows, cols, len(Aj), dAi, cmi.Config(kernel=cmi.COO_TILE))
+    # out-of-range row index: not "sorted"
+    bad = Ai.copy()
+    bad[-1] = rows
+    assert cmi.Plan(cmi.FORMAT_COO, torch.float64, rows, cols, len(Aj), dev(bad, torch)).info()["coo_sorted"] is False
+    # the plan-less table key never holds the tile kernel
+    assert cmi.tuning_select(cmi.FORMAT_COO, cmi.F64, rows, cols, len(Aj)).kernel != cmi.COO_TILE
+    with pytest.raises(cmi.CmiError):
+        cmi.tuning_set(cmi.FORMAT_COO, cmi.F64, 5.0, cmi.Config(kernel=cmi.COO_TILE))
+
+
+def test_containers_plan_once_and_replan_when_the_arrays_change(cmi, torch_cuda, orc):
+    torch = torch_cuda
+    A = cmi.poisson5pt(40, 30, "csr")
+    x = cmi.fill_x(1200).cuda()
+    y = torch.empty(1200, dtype=torch.float64, device="cuda")
+    assert A._plan is None
+    cmi.multiply(A, x, y)
+    p1 = A._plan
+    assert p1 is not None
+    cmi.multiply(A, x, y)
+    assert A._plan is p1                       # made once
+    cmi.multiply(A, x, y, cfg=cmi.Config(kernel=cmi.CSR_SCALAR))
+    assert A._plan is p1                       # an explicit config bypasses the plan, it does not replace it
+    A.row_offsets = A.row_offsets.clone()      # new structure array: a new plan
+    cmi.multiply(A, x, y)
+    assert A._plan is not p1
+    A.invalidate()
+    assert A._plan is None
+    # HYB: the COO part multiplies through its own plan (sorted by construction -> tile kernel)
+    H = cmi.convert(A, "hyb", num_entries_per_row=3)
+    Ap, Aj, Ax = (t.cpu().numpy() for t in (A.row_offsets, A.column_indices, A.values))
+    y.fill_(10.0)
+    cmi.multiply(H, x, y)
+    assert H.coo._plan is not None and H.coo._plan.config().kernel == cmi.COO_TILE
+    p, hAj, hAx, cAi, cAj, cAx = orc.csr_to_hyb(Ap, Aj, Ax, 3)
+    assert np.array_equal(y.cpu().numpy(), orc.spmv_hyb(1200, 3, p, hAj, hAx, cAi, cAj, cAx, x.cpu().numpy()))
+
+
+def test_hyb_width_rule(cmi, torch_cuda, orc, golden_irregular):
+    """cmi_hyb_entries_per_row: the reference rule kind with the reference's pair reproduces
+    cusp::compute_optimal_entries_per_row (oracle restatement, pinned to the reference tests' examples by
+    tests/test_oracle_golden.py); the launch-cost kind is the argmin of its model (numpy restatement here); the tuned rule
+    comes from the table."""
+    import os
+    torch, g = torch_cuda, golden_irregular
+    rng = np.random.default_rng(77)
+    cases = [g["f64_Ap"]]
+    for rows, lo, hi in ((5000, 0, 9), (20000, 1, 40), (300, 2, 3), (100000, 0, 4)):
+        lens = rng.integers(lo, hi + 1, size=rows)
+        lens[rng.integers(0, rows, size=3)] = 5000          # a few rows beyond the histogram's last bin
+        cases.append(np.r_[0, np.cumsum(lens)].astype(np.int32))
+
+    def cost_width(Ap, rs, th):
+        lens = np.minimum(np.diff(Ap).astype(np.int64), 4096)
+        N, mx = len(lens), int(lens.max())
+        ks = np.arange(mx + 1)
+        coo = np.array([np.maximum(lens - k, 0).sum() for k in ks], dtype=np.float64)
+        cost = N * ks.astype(np.float64) + np.where(coo > 0, th + rs * coo, 0.0)
+        return int(ks[cost == cost.min()].max())            # ties: the wider ELL part
+
+    for Ap in cases:
+        rows = len(Ap) - 1
+        dAp = dev(Ap, torch)
+        for rs, be in ((3.0, 4096), (3.0, 0), (1.5, 100), (10.0, 1), (1.0, 0)):
+            got = cmi.hyb_entries_per_row(cmi.F64, rows, dAp, cmi.HYB_RULE_REFERENCE, rs, be)
+            want = min(orc.optimal_entries_per_row(Ap, rs, be), 4096)
+            assert got == want, (rows, rs, be, got, want)
+        for rs, th in ((1.3, 5_000_000), (1.3, 0), (2.0, 1000), (1.0, 10**9), (4.0, 50_000)):
+            got = cmi.hyb_entries_per_row(cmi.F64, rows, dAp, cmi.HYB_RULE_COST, rs, th)
+            assert got == cost_width(Ap, rs, th), (rows, rs, th, got, cost_width(Ap, rs, th))
+    # the tuned rule: what the table (or, with none, the reference's constants) says
+    kind, rs, th = cmi.tuning_hyb_rule(cmi.F64)
+    assert kind in (cmi.HYB_RULE_REFERENCE, cmi.HYB_RULE_COST) and rs > 0 and th >= 0
+    Ap = cases[2]
+    expect = cost_width(Ap, rs, th) if kind == cmi.HYB_RULE_COST else min(orc.optimal_entries_per_row(Ap, rs, th), 4096)
+    assert cmi.hyb_entries_per_row(cmi.F64, len(Ap) - 1, dev(Ap, torch)) == expect
+    # set / get / clear
+    shipped = os.path.join(os.path.dirname(cmi.lib_path()), "..", "tuned", "gfx950.json")
+    try:
+        cmi.tuning_set_hyb_rule(cmi.F32, cmi.HYB_RULE_COST, 2.25, 123)
+        assert cmi.tuning_hyb_rule(cmi.F32) == (cmi.HYB_RULE_COST, 2.25, 123)
+        cmi.tuning_clear()
+        assert cmi.tuning_hyb_rule(cmi.F32) == (cmi.HYB_RULE_REFERENCE, 3.0, 4096)
+        # convert(..., "hyb") without a width uses the rule, and the result multiplies to the CSR result
+        A = cmi.CsrMatrix(len(Ap) - 1, len(Ap) - 1, int(Ap[-1]), dev(Ap, torch),
+                          dev(rng.integers(0, len(Ap) - 1, size=int(Ap[-1])).astype(np.int32), torch), dev(rng.standard_normal(int(Ap[-1])), torch))
+        H = cmi.convert(A, "hyb")
+        assert H.ell.num_entries_per_row == min(orc.optimal_entries_per_row(Ap, 3.0, 4096), 4096)   # table cleared above
+        cmi.tuning_load(shipped)
+        H2 = cmi.convert(A, "hyb")                                                                    # the shipped rule
+        assert H2.ell.num_entries_per_row == expect
+        x = dev(rng.standard_normal(len(Ap) - 1), torch)
+        y0 = torch.empty(len(Ap) - 1, dtype=torch.float64, device="cuda")
+        cmi.multiply(A, x, y0, cfg=cmi.Config(kernel=cmi.CSR_SCALAR))
+        for M in (H, H2):
+            y1 = torch.full_like(y0, 10.0)
+            cmi.multiply(M, x, y1)
+            assert torch.allclose(y1, y0, rtol=1e-9, atol=1e-9)
+    finally:
+        cmi.tuning_load(shipped)   # the rest of the session runs on the shipped table again

@@ -62,6 +62,14 @@ def assert_variant(got, want, bound, dtype, exact, Ap, what):
         assert np.array_equal(got[short], want[short]), f"{what}: a row shorter than {LONG_ROW} entries is not bit-exact"
 
 
+def spmv_csr_planned(cmi, rows, cols, dAp, dAj, dAx, dx, y, accumulate=False, cfg=None):
+    """y = A x through a plan made for (matrix, cfg): the row-length profile is what lets csr_stream launch its long-row
+    instance or switch to the merge-path kernel (a plan-less call never measures anything)."""
+    plan = cmi.Plan(cmi.FORMAT_CSR, y.dtype, rows, cols, dAj.numel(), dAp, cfg)
+    cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y, accumulate=accumulate)
+    return plan
+
+
 def csr_variants(cmi, small=False):
     """Every CSR kernel variant worth distinguishing (launch shape x load policy)."""
     out = []
@@ -114,6 +122,12 @@ def run_all_formats(cmi, torch, orc, rows, cols, Ap, Aj, Ax, x, want, want_acc, 
         y = fresh(acc)  # NULL config: tuning table / heuristics
         cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, accumulate=acc)
         assert_close(host(y), w, bound, dtype, f"{label} csr auto acc={acc}")
+        if rows:
+            y = fresh(acc)  # the same through a plan: profile-steered (long-row instance / merge-path where it pays)
+            plan = spmv_csr_planned(cmi, rows, cols, dAp, dAj, dAx, dx, y, acc)
+            assert_close(host(y), w, bound, dtype, f"{label} csr plan acc={acc}")
+            if plan.info()["storage_order_sums"]:
+                assert np.array_equal(host(y), w), f"{label} csr plan claims storage-order sums"
 
     # COO (sorted, as csr_to_coo produces)
     Ai = orc.csr_row_indices(Ap)
@@ -129,6 +143,18 @@ def run_all_formats(cmi, torch, orc, rows, cols, Ap, Aj, Ax, x, want, want_acc, 
         y = fresh(acc)
         cmi.spmv_coo(rows, cols, dAi, dAj, dAx, dx, y, accumulate=acc)  # NULL config
         assert_close(host(y), w, bound, dtype, f"{label} coo auto acc={acc}")
+        # row-sorted entries through a plan: the tile kernel, storage-order sums = the host loop's bits
+        plan = cmi.Plan(cmi.FORMAT_COO, dx.dtype, rows, cols, len(Aj), dAi)
+        assert plan.info()["coo_sorted"] is True
+        if len(Aj):
+            assert plan.config().kernel == cmi.COO_TILE and plan.info()["storage_order_sums"]
+        for swz, nt in ((0, 0), (1, 2), (3, 3), (32, 1)):
+            y = fresh(acc)
+            cmi.spmv_coo(rows, cols, dAi, dAj, dAx, dx, y, accumulate=acc, cfg=cmi.Config(kernel=cmi.COO_TILE, xcd_swizzle=swz, nontemporal=nt))
+            assert np.array_equal(host(y), w), f"{label} coo tile x{swz} nt{nt} acc={acc}: not bit-exact"
+        y = fresh(acc)
+        cmi.spmv_coo_plan(plan, dAi, dAj, dAx, dx, y, accumulate=acc)
+        assert np.array_equal(host(y), w), f"{label} coo plan acc={acc}: not bit-exact"
 
     # ELL / ELLR
     width = int(np.diff(Ap).max()) if rows else 0
@@ -521,14 +547,19 @@ def test_long_rows_streamed_by_the_workgroup(cmi, torch_cuda, orc, tag):
         for acc in (False, True):
             cfg = cmi.Config(kernel=cmi.CSR_STREAM, block_size=blk, items_per_thread=ipt, rows_per_block=rpb, nontemporal=2)
             y = dev(y0, torch).clone() if acc else torch.full((rows,), 10.0, dtype=tdt, device="cuda")
-            cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, accumulate=acc, cfg=cfg)
+            plan = spmv_csr_planned(cmi, rows, cols, dAp, dAj, dAx, dx, y, acc, cfg)
+            assert plan.info()["max_row_length"] == 9000 and not plan.info()["storage_order_sums"]
             assert_variant(host(y), want_acc if acc else want, bound + (np.abs(y0) if acc else 0), dt, "short", Ap,
                            f"long rows b{blk} i{ipt} r{rpb} acc={acc}")
+            # without a plan nothing is known about the rows: the ordinary instance, storage order for every row
+            y = dev(y0, torch).clone() if acc else torch.full((rows,), 10.0, dtype=tdt, device="cuda")
+            cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, accumulate=acc, cfg=cfg)
+            assert np.array_equal(host(y), want_acc if acc else want), f"long rows, no plan b{blk} i{ipt} r{rpb} acc={acc}"
     # lane groups: the threshold moves to 128 entries per lane (tpr 8 -> 1024): rows of 1500+ are streamed, 700 is not
     for tpr, rpb in ((8, 64), (32, 16), (2, 0)):
         y = torch.full((rows,), 10.0, dtype=tdt, device="cuda")
-        cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, cfg=cmi.Config(kernel=cmi.CSR_STREAM, block_size=256, items_per_thread=2,
-                                                                        rows_per_block=rpb, threads_per_row=tpr))
+        spmv_csr_planned(cmi, rows, cols, dAp, dAj, dAx, dx, y, False,
+                         cmi.Config(kernel=cmi.CSR_STREAM, block_size=256, items_per_thread=2, rows_per_block=rpb, threads_per_row=tpr))
         assert_close(host(y), want, bound, dt, f"long rows tpr{tpr}")
     # unaligned column / value arrays: the scalar-load instances have the same path
     bj = torch.zeros(nnz + 8, dtype=torch.int32, device="cuda")
@@ -536,29 +567,31 @@ def test_long_rows_streamed_by_the_workgroup(cmi, torch_cuda, orc, tag):
     bj[1:1 + nnz].copy_(dAj)
     bv[3:3 + nnz].copy_(dAx)
     y = torch.full((rows,), 10.0, dtype=tdt, device="cuda")
-    cmi.spmv_csr(rows, cols, dAp, bj[1:1 + nnz], bv[3:3 + nnz], dx, y, cfg=cmi.Config(kernel=cmi.CSR_STREAM))
+    pu = cmi.Plan(cmi.FORMAT_CSR, tdt, rows, cols, nnz, dAp, cmi.Config(kernel=cmi.CSR_STREAM))
+    cmi.spmv_csr_plan(pu, dAp, bj[1:1 + nnz], bv[3:3 + nnz], dx, y)
     assert_variant(host(y), want, bound, dt, "short", Ap, "long rows, unaligned arrays")
-    # storage order on request: every row bit-exact
+    # storage order on request: every row bit-exact, and the plan says so
     y = torch.full((rows,), 10.0, dtype=tdt, device="cuda")
-    cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, cfg=cmi.Config(kernel=cmi.CSR_STREAM, threads_per_row=1))
-    assert np.array_equal(host(y), want)
+    ps = spmv_csr_planned(cmi, rows, cols, dAp, dAj, dAx, dx, y, False, cmi.Config(kernel=cmi.CSR_STREAM, threads_per_row=1))
+    assert np.array_equal(host(y), want) and ps.info()["storage_order_sums"]
     # the streamed rows are re-associated but deterministic (fixed fold order: lanes, then waves): same bits every time
     ya = torch.full((rows,), 10.0, dtype=tdt, device="cuda")
-    cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, ya)
+    pa = spmv_csr_planned(cmi, rows, cols, dAp, dAj, dAx, dx, ya)
     for _ in range(20):
         yb = torch.full((rows,), -1.0, dtype=tdt, device="cuda")
-        cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, yb)
+        cmi.spmv_csr_plan(pa, dAp, dAj, dAx, dx, yb)
         assert torch.equal(ya, yb)
-    if tag == "f64":  # the fused dot runs the same instances: y identical to the plain call, dot within rounding
-        wv = dev(rng.standard_normal(rows), torch)
-        res = torch.zeros(1, dtype=torch.float64, device="cuda")
-        y1 = torch.full((rows,), 10.0, dtype=tdt, device="cuda")
-        y2 = torch.full((rows,), -3.0, dtype=tdt, device="cuda")
-        cfg = cmi.Config(kernel=cmi.CSR_STREAM, block_size=256, rows_per_block=176)
-        cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y1, cfg=cfg)
-        cmi.spmv_csr_dot(rows, cols, dAp, dAj, dAx, dx, y2, wv, res, cmi.blas_workspace(), cfg=cfg)
-        assert torch.equal(y1, y2)
-        assert abs(float(res) - float((y2 * wv).sum())) <= 1e-11 * float((y2 * wv).abs().sum())
+    # the fused dot runs the same instances (f64 and f32): y identical to the plain call, dot within rounding
+    wv = dev(rng.standard_normal(rows).astype(dt), torch)
+    res = torch.zeros(1, dtype=torch.float64, device="cuda")
+    y1 = torch.full((rows,), 10.0, dtype=tdt, device="cuda")
+    y2 = torch.full((rows,), -3.0, dtype=tdt, device="cuda")
+    cfg = cmi.Config(kernel=cmi.CSR_STREAM, block_size=256, rows_per_block=176)
+    pd = spmv_csr_planned(cmi, rows, cols, dAp, dAj, dAx, dx, y1, False, cfg)
+    cmi.spmv_csr_dot(rows, cols, dAp, dAj, dAx, dx, y2, wv, res, cmi.blas_workspace(), plan=pd)
+    assert torch.equal(y1, y2)
+    ref = float((y2.double() * wv.double()).sum())
+    assert abs(float(res) - ref) <= 1e-11 * float((y2.double() * wv.double()).abs().sum())
 
 
 def test_row_length_profile_selects_the_balanced_kernel(cmi, torch_cuda, orc):
@@ -587,24 +620,31 @@ def test_row_length_profile_selects_the_balanced_kernel(cmi, torch_cuda, orc):
     y = torch.empty(rows, dtype=torch.float64, device="cuda")
 
     def timed(cfg):
-        cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, cfg=cfg)  # first call: profile / warm-up
+        plan = cmi.Plan(cmi.FORMAT_CSR, torch.float64, rows, cols, nnz, dAp, cfg)  # measures the rows: the one synchronisation
+        assert plan.info()["max_row_length"] == 400_000 and plan.info()["entries_in_long_rows"] == 1_200_000
+        cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)  # warm-up
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, cfg=cfg)
+        cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
         torch.cuda.synchronize()
-        return time.perf_counter() - t0
+        return time.perf_counter() - t0, plan
 
-    t_auto = timed(None)
+    t_auto, p_auto = timed(None)
+    assert p_auto.config().kernel == cmi.CSR_BALANCED and not p_auto.info()["storage_order_sums"]
     assert_close(host(y), want, bound, np.float64, "auto (profile)")
     table = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, rows, cols, nnz)   # what the mean row length alone selects
     assert table.kernel == cmi.CSR_STREAM and table.threads_per_row == 0
     # the row-tile kernel as the table shapes it: the three long rows are streamed by their whole workgroup
     # (re-associated), every other row is bit-exact
-    t_table = timed(table)
+    t_table, p_table = timed(table)
+    assert p_table.config().kernel == cmi.CSR_STREAM  # an explicit kernel is kept; the profile picks its long-row instance
     assert_variant(host(y), want, bound, np.float64, "short", Ap, "table config")
     # threads_per_row = 1: storage order for EVERY row -- bit-exact, but one lane sums each long row
     table.threads_per_row = 1
-    t_strict = timed(table)
+    t_strict, p_strict = timed(table)
+    assert np.array_equal(host(y), want) and p_strict.info()["storage_order_sums"]
+    # no plan, no config: nothing is measured inside a multiply -- the table's row-tile kernel, storage order everywhere
+    cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y)
     assert np.array_equal(host(y), want)
     assert t_auto * 5 < t_strict and t_table * 3 < t_strict, (t_auto, t_table, t_strict)
     # accumulate mode through the balanced kernel: no zero fill, y += A x
@@ -615,9 +655,9 @@ def test_row_length_profile_selects_the_balanced_kernel(cmi, torch_cuda, orc):
 
 
 def test_multiply_inside_hip_graph_capture(cmi, torch_cuda, orc):
-    """cmi_spmv_* is capturable: launches only, nothing synchronises -- in particular the row-length profile of
-    a matrix the library has never seen is skipped while the stream is capturing (it needs a read-back), and
-    the table-selected kernel is recorded instead.  Replays reproduce the eager result in every format."""
+    """cmi_spmv_* is capturable: launches only, nothing allocates or synchronises.  A matrix that has no plan yet gets
+    none inside a capture (making one needs a read-back): the plan-less entry point records the table's kernel; a
+    matrix planned before the capture records its plan's kernel.  Replays reproduce the eager result in every format."""
     torch = torch_cuda
     Ap, Aj, Ax = orc.poisson5pt_csr(83, 61)
     n = 83 * 61
@@ -628,6 +668,9 @@ def test_multiply_inside_hip_graph_capture(cmi, torch_cuda, orc):
             "dia": cmi.convert(A, "dia")}
     dx = dev(x, torch)
     side = torch.cuda.Stream()
+    mats["coo planned"] = cmi.convert(A, "coo")
+    mats["coo planned"].plan()
+    assert mats["coo planned"].plan().config().kernel == cmi.COO_TILE
     for fmt, M in mats.items():
         y = torch.full((n,), 7.0, dtype=torch.float64, device="cuda")
         side.wait_stream(torch.cuda.current_stream())
@@ -638,8 +681,10 @@ def test_multiply_inside_hip_graph_capture(cmi, torch_cuda, orc):
         g.replay()
         torch.cuda.synchronize()
         got = host(y)
-        if fmt in ("csr", "ell", "dia"):
+        if fmt in ("csr", "ell", "dia", "coo planned"):
             assert np.array_equal(got, want), fmt
+            if fmt in ("csr", "coo"):
+                assert getattr(M, "_plan", None) is None, "a capture must not have made a plan"
         else:
             assert np.allclose(got, want, rtol=1e-12, atol=1e-12), fmt
         dx2 = dx * 2.0            # same graph, new input values in the same buffers
@@ -777,6 +822,18 @@ def test_coo_row_sorted_shapes(cmi, torch_cuda, orc, shape):
         got = host(y)
         assert_close(got, want, bound, np.float64, f"coo {shape} k{kern} b{blk} i{ipt}")
         assert np.array_equal(got[lens == 0], np.zeros(int((lens == 0).sum()))), f"{shape}: an empty row is not +0"
+    # the tile kernel (what a plan selects for sorted entries): the host COO loop's bits, rows without entries +0
+    want_coo = orc.spmv_coo(rows, Ai, Aj, Ax, x)
+    plan = cmi.Plan(cmi.FORMAT_COO, torch.float64, rows, cols, nnz, dAi)
+    assert plan.info()["coo_sorted"] and plan.config().kernel == cmi.COO_TILE
+    for swz in (0, 1, 2, 64):
+        y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
+        cmi.spmv_coo(rows, cols, dAi, dAj, dAx, dx, y, cfg=cmi.Config(kernel=cmi.COO_TILE, xcd_swizzle=swz, nontemporal=2))
+        assert np.array_equal(host(y), want_coo), f"coo tile {shape} x{swz}"
+    y0t = rng.standard_normal(rows)
+    y = dev(y0t, torch)
+    cmi.spmv_coo_plan(plan, dAi, dAj, dAx, dx, y, accumulate=True)
+    assert np.array_equal(host(y), orc.spmv_coo(rows, Ai, Aj, Ax, x, y0t)), f"coo tile {shape} accumulate"
     # the same through the table (NULL config), on another stream, and accumulating (order-agnostic kernel)
     y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
     s = torch.cuda.Stream()
@@ -1354,3 +1411,48 @@ def test_blas1(cmi, torch_cuda):
     v = buf[1:]
     cmi.blas_dot(v, v, res, ws)
     assert float(res) == float((np.arange(1, 1001, dtype=np.float64) ** 2).sum())
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json configs[3]: the SuiteSparse irregular set (nlpkkt120, ldoor, thermal2)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,scale", [("thermal2", 0.03), ("ldoor", 0.03), ("nlpkkt120", 0.01)])
+def test_suitesparse_like_matrices_every_kernel(cmi, torch_cuda, orc, name, scale):
+    """The three matrices of the reference's CSR-vector threads-per-row sweep (performance/csr_vector/csr_vector.cu:41-62,
+    86-110 over testing/UF downloads): the real file when CMI_SUITESPARSE_DIR provides it (dimensions from the file), else a
+    seeded stand-in with the collection's published row-length statistics (tools/suitesparse_like.py) -- every CSR variant,
+    the table, a plan, COO / ELL / HYB against the oracle."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import suitesparse_like as ssl
+    torch = torch_cuda
+    Ap, Aj, Ax, source = ssl.load(name, scale)
+    st = ssl.stats(Ap, Aj)
+    pub = ssl.PUBLISHED[name]
+    print(f"{name}: {source}: {st}")
+    if source.startswith("seeded"):  # the stand-in must look like the matrix it stands for
+        assert abs(st["mean"] - pub["mean"]) <= 0.08 * pub["mean"], (st, pub)
+        assert st["max"] <= pub["max"] and st["max"] >= 0.85 * pub["max"], (st, pub)
+    rows = cols = st["rows"]
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(cols)
+    y0 = rng.standard_normal(rows)
+    Ai = orc.csr_row_indices(Ap)
+    width = int(np.diff(Ap).max())
+    pitch, eAj, eAx = orc.csr_to_ell(Ap, Aj, Ax, width)
+    hw = max(1, int(round(st["mean"])))
+    p, hAj, hAx, cAi, cAj, cAx = orc.csr_to_hyb(Ap, Aj, Ax, hw)
+
+    def all_of(y0_):
+        return {"csr": orc.spmv_csr(Ap, Aj, Ax, x, y0_), "coo": orc.spmv_coo(rows, Ai, Aj, Ax, x, y0_),
+                "ell": orc.spmv_ell(rows, width, pitch, eAj, eAx, x, y0_), "hyb": orc.spmv_hyb(rows, hw, p, hAj, hAx, cAi, cAj, cAx, x, y0_)}
+
+    run_all_formats(cmi, torch, orc, rows, cols, Ap, Aj, Ax, x, all_of(None), all_of(y0), y0, hw, f"{name}-like")
+    # the reference's sweep itself: csr_vector at every threads-per-row, against the oracle
+    bound = row_abs(orc, Ap, Aj, Ax, x)
+    dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+    want = orc.spmv_csr(Ap, Aj, Ax, x)
+    for tpr in (2, 4, 8, 16, 32, 64):
+        y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
+        cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, cfg=cmi.Config(kernel=cmi.CSR_VECTOR, threads_per_row=tpr))
+        assert_close(host(y), want, bound, np.float64, f"{name}-like csr_vector tpr{tpr}")

@@ -13,7 +13,7 @@ import os
 import sys
 from collections import defaultdict
 
-KERNELS = ("csr_stream_kernel", "mix_kernel", "csrx_kernel", "dia_row", "diax_kernel")
+KERNELS = ("csr_stream_kernel", "mix_kernel", "csrx_kernel", "dia_row", "diax_kernel", "csr_balanced_kernel", "ell_row_kernel")
 
 
 def main():

@@ -60,14 +60,21 @@ mix_kernel(int64_t N, int64_t nnz, const int *__restrict__ Ap, const int *__rest
 //   FLAGS bit 0: row pointers in registers (each lane loads its own two; tile bounds by uniform loads): no LDS
 //                copy of the row pointers, no barrier in front of the streams
 //         bit 1: rows are stored in pairs (even lane gets its neighbour's sum by DPP): 16-byte y stores
+//         bits 2..4: also leave <y, w> partials (w = x, the CG step): 4 = the library's tile_dot_store (wave butterfly, LDS
+//                slot per wave, barrier, thread 0 adds the four and stores one partial per tile); 8 = the same slots, but
+//                the LAST wave to arrive (LDS counter) adds them in wave order -- no barrier, the others leave at once;
+//                16 = one partial per WAVE stored straight to global memory (no LDS, no barrier, 4x the partials)
 // ------------------------------------------------------------------------------------------------------------
 template <int FLAGS>
 __global__ void __launch_bounds__(256)
 csrx_kernel(int64_t N, int64_t nnz, const int *__restrict__ Ap, const int *__restrict__ Aj, const double *__restrict__ Ax,
-            const double *__restrict__ x, double *__restrict__ y, int rpb, int64_t tiles, int64_t tpx, int swz)
+            const double *__restrict__ x, double *__restrict__ y, int rpb, int64_t tiles, int64_t tpx, int swz, double *__restrict__ partial)
 {
     __shared__ double prod[1024];
     __shared__ int rowptr[260];
+    __shared__ double dslots[4];
+    __shared__ int arrived;
+    if ((FLAGS & 8) && threadIdx.x == 0) arrived = 0; // visible after the barrier below
     const int64_t tile = tile_of_block(blockIdx.x, tpx, swz);
     if (tile >= tiles) return;
     const int tid = threadIdx.x;
@@ -98,10 +105,26 @@ csrx_kernel(int64_t N, int64_t nnz, const int *__restrict__ Ap, const int *__res
     }
     prod[tid * 4 + 0] = p0; prod[tid * 4 + 1] = p1; prod[tid * 4 + 2] = p2; prod[tid * 4 + 3] = p3;
     __syncthreads();
+    double wv = 0.0;
+    if constexpr (FLAGS & 28) { if (tid < nr) wv = x[r0 + tid]; }
     double s = 0.0;
     if (tid < nr) {
         if constexpr (!(FLAGS & 1)) { a = rowptr[tid]; b = rowptr[tid + 1]; }
         for (int j = a; j < b; j++) s = s + prod[j - fbase];
+    }
+    if constexpr (FLAGS & 28) {
+        double d = tid < nr ? s * wv : 0.0;
+        if constexpr (FLAGS & 4) tile_dot_store(d, dslots, partial + tile);
+        else {
+#pragma unroll
+            for (int o = kWave / 2; o > 0; o >>= 1) d += __shfl_down(d, o);
+            const int lane = tid & 63, wave = tid >> 6;
+            if constexpr (FLAGS & 16) { if (lane == 0) partial[tile * 4 + wave] = d; }
+            else if (lane == 0) {
+                dslots[wave] = d;
+                if (atomicAdd(&arrived, 1) == 3) partial[tile] = ((dslots[0] + dslots[1]) + dslots[2]) + dslots[3];
+            }
+        }
     }
     if constexpr (FLAGS & 2) {
         const double up = __shfl_down(s, 1); // the odd neighbour's sum
@@ -243,7 +266,18 @@ int main(int argc, char **argv)
 
     const double B_csr = 12.0 * nnz + 20.0 * N + 4, B_dia = 5.0 * pitch * 8 + 20 + 16.0 * N;
     auto run = [&](const std::string &name, double bytes, bool check, const std::function<void()> &f) {
-        if (!only.empty() && name.find(only) == std::string::npos) return;
+        if (!only.empty()) { // --only a|b|c: any of the substrings
+            bool hit = false;
+            size_t from = 0;
+            while (from <= only.size()) {
+                const size_t bar = only.find('|', from);
+                const std::string part = only.substr(from, bar == std::string::npos ? std::string::npos : bar - from);
+                if (!part.empty() && name.find(part) != std::string::npos) hit = true;
+                if (bar == std::string::npos) break;
+                from = bar + 1;
+            }
+            if (!hit) return;
+        }
         if (pmc > 0) { // launches in manifest order; tools/r2_pmc_table.py maps the counter rows back by dispatch order
             for (int i = 0; i < pmc; i++) f();
             CK(hipDeviceSynchronize());
@@ -266,16 +300,27 @@ int main(int argc, char **argv)
 
     // ---- the library's kernel under each dealing mode -------------------------------------------------------
     run("lib csr table (NULL cfg)", B_csr, true, [&] { CM(cmi_spmv_csr_f64(N, N, nnz, Ap, Aj, Ax, x, y, 0, nullptr, nullptr)); });
-    for (int swz : {0, 16, 32, 64, 1}) {
-        for (int rpb : {176, 192}) {
+    for (int swz : {32}) {
+        for (int rpb : {176}) {
             cmi_config c = {CMI_CSR_STREAM, 256, 0, rpb, 1, 2, swz, 0};
             char nm[96];
             snprintf(nm, sizeof nm, "lib csr_stream rpb %d swz %d", rpb, swz);
             run(nm, B_csr, true, [&, c] { CM(cmi_spmv_csr_f64(N, N, nnz, Ap, Aj, Ax, x, y, 0, &c, nullptr)); });
         }
     }
+    // ---- the merge-path kernel on this regular matrix (why 1.5-1.7x the row-tile kernel?) -------------
+    for (int swz : {0, 4, 8, 16}) {
+        cmi_config c = {CMI_CSR_BALANCED, 512, 0, 0, 0, 0, swz, 0};
+        char nm[96];
+        snprintf(nm, sizeof nm, "lib csr_balanced swz %d (zero fill + kernel)", swz);
+        run(nm, B_csr, false, [&, c] { CM(cmi_spmv_csr_f64(N, N, nnz, Ap, Aj, Ax, x, y, 0, &c, nullptr)); });
+    }
+    {
+        cmi_config c = {CMI_CSR_BALANCED, 512, 0, 0, 0, 0, 0, 0};
+        run("lib csr_balanced accumulate (no zero fill)", B_csr, false, [&, c] { CM(cmi_spmv_csr_f64(N, N, nnz, Ap, Aj, Ax, x, y, 1, &c, nullptr)); });
+    }
     // ---- mix ------------------------------------------------------------------------------------------------
-    for (int swz : {0, 32, 128, 1}) {
+    for (int swz : {32}) {
         const int rpb = 176;
         const int64_t tiles = (N + rpb - 1) / rpb, tpx = (tiles + 7) / 8;
         const int64_t grid = swz == 0 ? tiles : swz == 1 ? tpx * 8 : ((tiles + 8 * swz - 1) / (8 * swz)) * 8 * swz;
@@ -286,6 +331,9 @@ int main(int argc, char **argv)
         run(nm, B_csr, false, [&, swz] { hipLaunchKernelGGL((mix_kernel<3, true>), dim3((unsigned)grid), dim3(256), 0, 0, N, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, (int)m); });
     }
     // ---- csrx -----------------------------------------------------------------------------------------------
+    double *dpart, *dres, *dws;
+    CK(hipMalloc(&dpart, 262144 * 8)); CK(hipMalloc(&dres, 8)); CK(hipMalloc(&dws, cmi_blas_workspace_bytes()));
+    run("lib csr_dot (SpMV + <y,x> + fold launch)", B_csr, true, [&] { CM(cmi_spmv_csr_dot_f64(N, N, nnz, Ap, Aj, Ax, x, y, x, dres, dws, nullptr, nullptr)); });
     for (int swz : {32}) {
         for (int rpb : {176, 192}) {
             const int64_t tiles = (N + rpb - 1) / rpb, tpx = (tiles + 7) / 8;
@@ -293,8 +341,8 @@ int main(int argc, char **argv)
             char nm[96];
 #define CSRX(F)                                                                                                          \
     snprintf(nm, sizeof nm, "csrx flags %d rpb %d swz %d", F, rpb, swz);                                                 \
-    run(nm, B_csr, true, [&, swz] { hipLaunchKernelGGL((csrx_kernel<F>), dim3((unsigned)grid), dim3(256), 0, 0, N, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz); })
-            CSRX(0); CSRX(1); CSRX(2); CSRX(3);
+    run(nm, B_csr, true, [&, swz] { hipLaunchKernelGGL((csrx_kernel<F>), dim3((unsigned)grid), dim3(256), 0, 0, N, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, dpart); })
+            CSRX(0); CSRX(1); CSRX(5); CSRX(9); CSRX(17);
 #undef CSRX
         }
     }
@@ -307,7 +355,7 @@ int main(int argc, char **argv)
         CK(hipDeviceSynchronize());
         const double B_ell = 5.0 * epitch * 12 + 16.0 * N;
         run("lib ell table (NULL cfg)", B_ell, true, [&] { CM(cmi_spmv_ell_f64(N, N, 5, epitch, eAj, eAx, nullptr, x, y, 0, nullptr, nullptr)); });
-        for (int blk : {256, 512}) for (int rpl : {1, 2}) for (int swz : {0, 8, 16, 32, 64, 128}) {
+        for (int blk : {256}) for (int rpl : {1}) for (int swz : {64}) {
             cmi_config c = {CMI_ELL_ROW, blk, 0, 0, rpl, 3, swz, 0};
             char nm[96];
             snprintf(nm, sizeof nm, "lib ell block %d rpl %d swz %d", blk, rpl, swz);
@@ -317,7 +365,7 @@ int main(int argc, char **argv)
     }
     // ---- dia ------------------------------------------------------------------------------------------------
     run("lib dia table (NULL cfg)", B_dia, true, [&] { CM(cmi_spmv_dia_f64(N, N, 5, pitch, doff, dvals, x, y, 0, nullptr, nullptr)); });
-    for (int blk : {256, 512, 1024}) for (int rpl : {1, 2}) for (int swz : {0, 8, 16, 32, 64, 128}) {
+    for (int blk : {512}) for (int rpl : {2}) for (int swz : {16, 32}) {
         cmi_config c = {CMI_DIA_ROW, blk, 0, 0, rpl, 3, swz, 0};
         char nm[96];
         snprintf(nm, sizeof nm, "lib dia block %d rpl %d swz %d", blk, rpl, swz);
