@@ -138,14 +138,17 @@ def pmc_traffic(kernel_substr):
     matrix and tuning-table config), or (None, None).  PMC collection needs the profiler around the process, so the
     figure is a committed measurement of this kernel, not one taken in this run: the line says so (`traffic_source`)."""
     pdir = os.path.join(ROOT, "profiles")
+    # the SpMV kernel of each format (not the builders / converters that carry the format's name too)
+    names = {"csr": ("csr_stream_kernel", "csr_balanced_kernel", "csr_vector_kernel", "csr_scalar_kernel"), "ell": ("ell_row_kernel",),
+             "dia": ("dia_row_kernel", "dia_row2_kernel"), "coo": ("coo_tile_kernel", "coo_lane4_kernel", "coo_segmented_kernel")}[kernel_substr]
     best, src = None, None
     if os.path.isdir(pdir):
         for f in sorted(os.listdir(pdir)):
-            if f.endswith(".json") and "pmc" in f:
+            if f.endswith(".json") and "pmc" in f and "before" not in f:
                 try:
                     doc = json.load(open(os.path.join(pdir, f)))
                     for k in doc.get("kernels", []):
-                        if kernel_substr in k.get("kernel", "") and k.get("hbm_bytes_per_launch"):
+                        if any(n in k.get("kernel", "") for n in names) and k.get("hbm_bytes_per_launch") and k.get("launches", 0) >= 5:
                             best, src = float(k["hbm_bytes_per_launch"]), "profiles/" + f
                 except Exception:
                     pass

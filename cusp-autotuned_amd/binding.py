@@ -139,6 +139,8 @@ def _declare(L):
     L.cmi_cg_direction_f32.argtypes = [i64, vp, vp, vp, vp, vp]
     L.cmi_cg_direction_x_f32.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp]
     L.cmi_blas_dotd_f32.argtypes = [i64, vp, vp, vp, vp, vp]
+    L.cmi_count_zeros_f64.argtypes = [i64, vp, POINTER(c_int64), vp]
+    L.cmi_count_zeros_f32.argtypes = [i64, vp, POINTER(c_int64), vp]
     L.cmi_tuning_hyb_rule.argtypes = [c_int, POINTER(c_int), POINTER(c_double), POINTER(c_int64)]
     L.cmi_tuning_set_hyb_rule.argtypes = [c_int, c_int, c_double, i64]
     L.cmi_hyb_entries_per_row.argtypes = [c_int, i64, vp, c_int, c_double, i64, POINTER(c_int64), vp]
@@ -409,6 +411,13 @@ def tuning_select(fmt, dtype, num_rows, num_cols, num_entries):
 
 
 HYB_RULE_REFERENCE, HYB_RULE_COST = 0, 1
+
+
+def count_zeros(values, stream=None):
+    """explicit zeros in a device value array (cmi_count_zeros_*: the reference's ELL num_entries excludes them)"""
+    c = c_int64()
+    check(getattr(lib(), "cmi_count_zeros_" + _suffix(values))(values.numel(), _ptr(values), byref(c), _stream(stream)))
+    return c.value
 
 
 def tuning_hyb_rule(dtype):

@@ -72,13 +72,13 @@ fill_kernel(int64_t n, T v, T *__restrict__ y)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = v;
 }
 
-// wave64 butterfly, then one LDS slot per wave, folded by lane order: fixed summation tree
+// wave64 DPP tree (common.h wave_sum_to_last: no LDS-crossbar round trips at the tail of a one-shot workgroup), then one LDS
+// slot per wave, folded in wave order: fixed summation tree
 __device__ __forceinline__ double block_sum(double v, double *slots)
 {
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o);
+    v = wave_sum_to_last(v);
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    if (lane == 0) slots[wave] = v;
+    if (lane == kWave - 1) slots[wave] = v;
     __syncthreads();
     double s = 0.0;
     if (threadIdx.x == 0)
@@ -146,14 +146,20 @@ dot_fold_final_kernel(int npartial, double *__restrict__ workspace, T *__restric
     for (int k = 0; k < 4; k++) acc += v[k];
     double s = block_sum(acc, slots);
     if (threadIdx.x == 0) {
+        // Hand-off of the chunk sums to whichever workgroup arrives last, WITHOUT agent-scope fences (a __threadfence() pair
+        // is buffer_wbl2 + buffer_inv: ~3.5 us each, most of this kernel's 5 us).  The form MI355X_MICROARCH.md lists as
+        // measured-valid (inter-workgroup visibility table, first row): the payload is stored write-through (relaxed
+        // agent-scope atomic store = global_store ... sc1), the storing wave drains it (s_waitcnt vmcnt(0): inline asm, the
+        // compiler may not drop it), ONE lane then adds to the unsharded counter (agent-scope atomic), the workgroup whose
+        // add returned the last ticket reads the payload with sc1 loads (relaxed agent-scope atomic loads) -- its other waves
+        // behind the barrier below.  The grid is at most 64 workgroups: one per CU, the measured configuration.
         __hip_atomic_store(folded + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        const unsigned int t = atomicAdd(ticket_of(workspace), 1u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(ticket_of(workspace), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         is_last = (t == gridDim.x - 1);
     }
     __syncthreads();
     if (!is_last) return;
-    __threadfence();
     acc = 0.0;
     for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) acc += __hip_atomic_load(folded + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads(); // slots are reused

@@ -753,3 +753,43 @@ CMI_API int cmi_hyb_entries_per_row(int dtype, int64_t num_rows, const int32_t *
     *width_host = K;
     return CMI_SUCCESS;
 }
+
+// explicit zeros among n values (reference csr_to_other.h:188)
+namespace cmi {
+template <typename T>
+__global__ void __launch_bounds__(256) count_zeros_kernel(int64_t n, const T *__restrict__ v, unsigned long long *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) c += v[i] == T(0);
+    const unsigned long long m = __ballot(1);
+    (void)m;
+    for (int o = kWave / 2; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & (kWave - 1)) == 0 && c) atomicAdd(out, c);
+}
+template <typename T> static int count_zeros(int64_t n, const T *v, int64_t *count_host, void *stream)
+{
+    if (n < 0 || !count_host) return fail(CMI_ERROR_INVALID_VALUE, "cmi_count_zeros: bad argument");
+    *count_host = 0;
+    if (n == 0) return CMI_SUCCESS;
+    if (!v) return fail(CMI_ERROR_INVALID_VALUE, "cmi_count_zeros: null array");
+    hipStream_t s = as_stream(stream);
+    unsigned long long *dev = nullptr, host = 0;
+    CMI_HIP(hipMalloc((void **)&dev, sizeof(host)));
+    hipError_t e = hipMemsetAsync(dev, 0, sizeof(host), s);
+    if (e == hipSuccess) {
+        int64_t blocks = ceil_div(n, 256 * 8);
+        if (blocks > kCus * 16) blocks = kCus * 16;
+        hipLaunchKernelGGL((count_zeros_kernel<T>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, n, v, dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&host, dev, sizeof(host), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return hip_fail(e, "cmi_count_zeros");
+    *count_host = (int64_t)host;
+    return CMI_SUCCESS;
+}
+} // namespace cmi
+CMI_API int cmi_count_zeros_f64(int64_t n, const double *values, int64_t *count_host, void *stream) { return cmi::count_zeros<double>(n, values, count_host, stream); }
+CMI_API int cmi_count_zeros_f32(int64_t n, const float *values, int64_t *count_host, void *stream) { return cmi::count_zeros<float>(n, values, count_host, stream); }

@@ -73,14 +73,67 @@ __device__ __forceinline__ unsigned int *ticket_of(double *workspace)
     return reinterpret_cast<unsigned int *>(workspace + kPartialCapacity + kFoldedMax);
 }
 
-// One partial of a fused dot product per workgroup: lanes folded by a fixed wave butterfly, waves in order
+// ---- cross-lane steps on the DPP path (gfx9 family: row_shr, row_bcast:15/31, wave_shr:1) -----------------------------
+// `__shfl_*` compiles to ds_bpermute_b32: a trip through the LDS crossbar per step, and a wave-wide reduction or scan is
+// six DEPENDENT steps -- ~1500 cycles at the very end of a workgroup's life, i.e. residency: the fused <y, w> of
+// csr_stream cost 10-15 us of 128 on the headline matrix with it (tools/r2_probe.hip: csrx flags 5/9/17 against 1,
+// profiles/r02_probe_timing_session5.txt).  DPP moves ride on the VALU.  All deterministic: a fixed tree.
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118, kDppRowBcast15 = 0x142,
+              kDppRowBcast31 = 0x143, kDppWaveShr1 = 0x138;
+// value of the source lane selected by CTRL, `fill` where there is none (or the row is masked off)
+template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ int dpp_take(int v, int fill)
+{
+    return __builtin_amdgcn_update_dpp(fill, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ double dpp_take(double v, double fill)
+{
+    const int lo = dpp_take<CTRL, ROW_MASK>(__double2loint(v), __double2loint(fill));
+    const int hi = dpp_take<CTRL, ROW_MASK>(__double2hiint(v), __double2hiint(fill));
+    return __hiloint2double(hi, lo);
+}
+// inclusive prefix sum over the 64 lanes of the wave
+__device__ __forceinline__ int wave_inclusive_sum(int v)
+{
+    v += dpp_take<kDppRowShr1>(v, 0);
+    v += dpp_take<kDppRowShr2>(v, 0);
+    v += dpp_take<kDppRowShr4>(v, 0);
+    v += dpp_take<kDppRowShr8>(v, 0);            // inclusive inside every row of 16 lanes
+    v += dpp_take<kDppRowBcast15, 0xa>(v, 0);    // rows 1 and 3 add the total of the row before them
+    v += dpp_take<kDppRowBcast31, 0xc>(v, 0);    // rows 2 and 3 add the total of rows 0-1
+    return v;
+}
+// lane 63 receives the reduction of all 64 lanes (other lanes: partial results)
+__device__ __forceinline__ double wave_sum_to_last(double v)
+{
+    v += dpp_take<kDppRowShr1>(v, 0.0);
+    v += dpp_take<kDppRowShr2>(v, 0.0);
+    v += dpp_take<kDppRowShr4>(v, 0.0);
+    v += dpp_take<kDppRowShr8>(v, 0.0);
+    v += dpp_take<kDppRowBcast15, 0xa>(v, 0.0);
+    v += dpp_take<kDppRowBcast31, 0xc>(v, 0.0);
+    return v;
+}
+__device__ __forceinline__ int wave_min_to_last(int v, int big)
+{
+    int t;
+    t = dpp_take<kDppRowShr1>(v, big); v = t < v ? t : v;
+    t = dpp_take<kDppRowShr2>(v, big); v = t < v ? t : v;
+    t = dpp_take<kDppRowShr4>(v, big); v = t < v ? t : v;
+    t = dpp_take<kDppRowShr8>(v, big); v = t < v ? t : v;
+    t = dpp_take<kDppRowBcast15, 0xa>(v, big); v = t < v ? t : v;
+    t = dpp_take<kDppRowBcast31, 0xc>(v, big); v = t < v ? t : v;
+    return v;
+}
+// the left neighbour's value (lane - 1); lane 0 gets `fill`
+__device__ __forceinline__ int wave_shift_up(int v, int fill) { return dpp_take<kDppWaveShr1>(v, fill); }
+
+// One partial of a fused dot product per workgroup: lanes folded by a fixed DPP tree (wave_sum_to_last), waves in order
 // (`slots`: one double per wave of the workgroup, in LDS).  Every thread of the workgroup must call it.
 __device__ __forceinline__ void tile_dot_store(double d, double *slots, double *out)
 {
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) d += __shfl_down(d, o);
+    d = wave_sum_to_last(d);
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    if (lane == 0) slots[wave] = d;
+    if (lane == kWave - 1) slots[wave] = d;
     __syncthreads();
     if (threadIdx.x == 0) {
         double s = 0.0;

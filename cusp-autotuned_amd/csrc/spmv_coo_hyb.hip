@@ -259,38 +259,57 @@ coo_tile_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ A
     const int64_t Rfirst = prev_row + 1;
 
     // ---- 1. request the tile (+ its tail), then gather, park and flag ---------------------------------------------
-    auto request = [&](int64_t e, int live, coo_vec<T> &q) { // entries [e, e + 4), `live` of them exist
-        if (live == 4) {
-            const int4v rv = ld<NT>(reinterpret_cast<const int4v *>(Ai + e));
-            const int4v cv = ld<NT>(reinterpret_cast<const int4v *>(Aj + e));
-            q.r[0] = rv.x; q.r[1] = rv.y; q.r[2] = rv.z; q.r[3] = rv.w;
-            q.c[0] = cv.x; q.c[1] = cv.y; q.c[2] = cv.z; q.c[3] = cv.w;
-            if constexpr (sizeof(T) == 8) {
-                const double2v a = ld<NT>(reinterpret_cast<const double2v *>(Ax + e));
-                const double2v b = ld<NT>(reinterpret_cast<const double2v *>(Ax + e + 2));
-                q.v[0] = a.x; q.v[1] = a.y; q.v[2] = b.x; q.v[3] = b.y;
-            } else {
-                const float4v a = ld<NT>(reinterpret_cast<const float4v *>(Ax + e));
-                q.v[0] = a.x; q.v[1] = a.y; q.v[2] = a.z; q.v[3] = a.w;
-            }
+    // Entries [e, e + 4), `live` of them exist.  BRANCH-FREE: every lane issues the same three 16-byte loads, from
+    // min(e, num_entries - 4) (the launcher guarantees num_entries >= 4) -- only the array's last, partial vector and lanes
+    // past the end are moved, by `shift` entries, and pick their entries out of the loaded ones afterwards.  (A vector
+    // path and a scalar path side by side made the compiler drain the loads at the join: the tail's loads then started
+    // only after the tile's had returned.)  The moved loads are 4-byte aligned: int4u / vec_u.
+    typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef T vec2u __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+    typedef T vec4u __attribute__((ext_vector_type(4), aligned(sizeof(T))));
+    auto request = [&](int64_t e, int live, coo_vec<T> &q) {
+        const int64_t last = num_entries - 4;
+        const int64_t el = e < last ? e : last;
+        const int shift = (int)(e - el); // 0 for every whole vector
+#define CMI_LDU(TYPE, PTR) (NT ? __builtin_nontemporal_load(reinterpret_cast<const TYPE *>(PTR)) : *reinterpret_cast<const TYPE *>(PTR))
+        const int4u rv = CMI_LDU(int4u, Ai + el); // (spelled out: a template parameter would drop the typedef's alignment)
+        const int4u cv = CMI_LDU(int4u, Aj + el);
+        int r[8] = {rv.x, rv.y, rv.z, rv.w, -2, -2, -2, -2}, c[8] = {cv.x, cv.y, cv.z, cv.w, 0, 0, 0, 0};
+        T v[8];
+        if constexpr (sizeof(T) == 8) {
+            const vec2u a = CMI_LDU(vec2u, Ax + el);
+            const vec2u b = CMI_LDU(vec2u, Ax + el + 2);
+            v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
         } else {
+            const vec4u a = CMI_LDU(vec4u, Ax + el);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        }
+#undef CMI_LDU
+        v[4] = v[5] = v[6] = v[7] = T(0);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                q.r[k] = k < live ? Ai[e + k] : -2; // -2: no such entry (never equal to a row)
-                q.c[k] = k < live ? Aj[e + k] : 0;
-                q.v[k] = k < live ? Ax[e + k] : T(0);
-            }
+        for (int k = 0; k < 4; k++) { // entry k of this lane = loaded entry k + shift (selects; shift is 0 almost everywhere)
+            const int j = k + (shift < 4 ? shift : 4);
+            int rr = r[k], cc = c[k];
+            T vv = v[k];
+#pragma unroll
+            for (int t = 1; t <= 4; t++)
+                if (j == k + t) { rr = r[k + t]; cc = c[k + t]; vv = v[k + t]; }
+            const bool dead = k >= live; // -2: no such entry (never equal to a row); column 0, value 0
+            q.r[k] = dead ? -2 : rr;
+            q.c[k] = dead ? 0 : cc;
+            q.v[k] = dead ? T(0) : vv;
         }
     };
     // products and row indices into slots [slot, slot + 4); returns the flags of the row starts (bit k)
     auto park = [&](int64_t e, int slot, int live, const coo_vec<T> &q) -> int {
+        // the four gathers are UNCONDITIONAL (an entry that does not exist has column 0 and value 0; its slot is never summed):
+        // a gather behind a per-entry test is serialised by the compiler -- four round trips instead of one
         T p[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) p[k] = k < live ? q.v[k] * x[q.c[k]] : T(0);
+        const T x0 = x[q.c[0]], x1 = x[q.c[1]], x2 = x[q.c[2]], x3 = x[q.c[3]];
+        p[0] = q.v[0] * x0; p[1] = q.v[1] * x1; p[2] = q.v[2] * x2; p[3] = q.v[3] * x3;
         // the row in front of this vector: the previous lane's last entry (a live lane's left neighbour holds four entries);
         // the first lane of a wave reads it from the array
-        const int up = __shfl_up(q.r[3], 1);
-        int pr = up;
+        int pr = wave_shift_up(q.r[3], -2);
         if (lane == 0) pr = live > 0 ? (e > 0 ? Ai[e - 1] : -1) : -2;
         int flags = 0;
 #pragma unroll
@@ -313,19 +332,14 @@ coo_tile_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ A
 
     // ---- 2. this wave's row starts, compacted (no barrier: the list is the wave's own) ---------------------------------
     const int cnt = __builtin_popcount(flags);
-    int incl = cnt; // inclusive scan of the counts inside the wave
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    const int incl = wave_inclusive_sum(cnt); // DPP scan (no LDS crossbar round trips)
     {
         int pos = incl - cnt;
 #pragma unroll
         for (int k = 0; k < 4; k++)
             if (flags & (1 << k)) starts[wave][pos++] = (unsigned short)(k0 + k);
-        int first = flags ? k0 + __builtin_ctz(flags) : 1 << 30;
-#pragma unroll
-        for (int o = kWave / 2; o > 0; o >>= 1) { const int v = __shfl_down(first, o); first = v < first ? v : first; }
-        if (lane == kWave - 1) wave_count[wave] = incl;
-        if (lane == 0) wave_first[wave] = first;
+        const int first = wave_min_to_last(flags ? k0 + __builtin_ctz(flags) : 1 << 30, 1 << 30);
+        if (lane == kWave - 1) { wave_count[wave] = incl; wave_first[wave] = first; }
     }
     if (wave == 0) { // the parked tail: first row start among its entries (wave-uniform branch)
         int first = 1 << 30;
@@ -333,9 +347,8 @@ coo_tile_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ A
             const int tf = park(E1 + t0, kCooTile + t0, tlive, qt);
             if (tf) first = kCooTile + t0 + __builtin_ctz(tf);
         }
-#pragma unroll
-        for (int o = kWave / 2; o > 0; o >>= 1) { const int v = __shfl_down(first, o); first = v < first ? v : first; }
-        if (lane == 0) tail_first = first;
+        first = wave_min_to_last(first, 1 << 30);
+        if (lane == kWave - 1) tail_first = first;
     }
     __syncthreads();
 
@@ -424,7 +437,7 @@ static int spmv_coo(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     hipStream_t s = as_stream(stream);
     const bool aligned = reinterpret_cast<uintptr_t>(Ai) % 16 == 0 && reinterpret_cast<uintptr_t>(Aj) % 16 == 0 &&
                          reinterpret_cast<uintptr_t>(Ax) % 16 == 0;
-    if (c.kernel == CMI_COO_TILE && aligned && nnz > 0) { // sorted entries (a plan checked, or the caller's explicit config vouches)
+    if (c.kernel == CMI_COO_TILE && aligned && nnz >= 4) { // sorted entries (a plan checked, or the caller's explicit config vouches)
         if (nnz > INT32_MAX - 4096) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_coo: too many entries for the tile kernel");
         const int64_t tiles = ceil_div(nnz, kCooTile);
         const int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;

@@ -817,8 +817,18 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         break;
     }
     case CMI_CSR_STREAM: {
-        const int rpb = c.rows_per_block;
+        int rpb = c.rows_per_block;
         const int ipt = c.items_per_thread;
+        // The fused <y, w> instance wants whole waves of rows: with the table's 176 rows per tile (2.75 waves) the dot costs
+        // +9.3 us on the headline matrix, with 192 (3 waves) +3.7 us (tools/r2_probe.hip csrx flags 5 vs 1 at rpb 176 / 192,
+        // profiles/r02_probe_dot_ablation.txt).  So a table-chosen shape (not a caller's explicit one) is rounded up to the
+        // next multiple of 64 rows when the tile's single LDS pass still holds them.
+        if (w && dot_partial && (!user || user->kernel == CMI_KERNEL_AUTO || user->rows_per_block == 0) && c.threads_per_row <= 1 && rows > 0) {
+            const int up = (rpb + kWave - 1) / kWave * kWave;
+            const double mean = (double)nnz / (double)rows;
+            const int64_t tile_entries = (int64_t)block * ipt * 4;
+            if (up != rpb && up <= block && (double)up * mean + 3.0 <= (double)tile_entries) rpb = up;
+        }
         int tpr = c.threads_per_row <= 1 ? 1 : c.threads_per_row;
         if (tpr > 64 || (tpr & (tpr - 1)) != 0) return fail(CMI_ERROR_NOT_SUPPORTED, "csr_stream: threads_per_row must be 0/1 or a power of two <= 64");
         // threads_per_row == 0: rows of kLongRowPerLane entries per lane of a group (at least kLongRowMin) or more

@@ -357,6 +357,9 @@ inline int csr_to_ell_device(int64_t rows, const int *Ap, const int *Aj, const d
 inline int csr_to_ell_device(int64_t rows, const int *Ap, const int *Aj, const float *Ax, int64_t w, int64_t pitch, int *eAj, float *eAx)
 { return cmi_csr_to_ell_f32(rows, Ap, Aj, Ax, w, pitch, eAj, eAx, nullptr); }
 
+inline int count_zeros_device(int64_t n, const double *v, int64_t *c) { return cmi_count_zeros_f64(n, v, c, nullptr); }
+inline int count_zeros_device(int64_t n, const float *v, int64_t *c) { return cmi_count_zeros_f32(n, v, c, nullptr); }
+
 template <typename Src, typename Dst, typename SF, typename DF> struct device_fast_path {
     static bool run(const Src &, Dst &) { return false; }
 };
@@ -367,7 +370,9 @@ struct device_fast_path<csr_matrix<int, V, device_memory>, ell_matrix<int, V, de
         if (s.num_entries == 0) return false;
         const size_t width = compute_max_entries_per_row(s.row_offsets); // one D2H copy of the offsets
         check_fill("ell_matrix", width * s.num_rows, s.num_entries);
-        d.resize(s.num_rows, s.num_cols, s.num_entries, width);
+        int64_t zeros = 0; // reference csr_to_other.h:188: the ELL matrix reports num_entries without the explicit zeros
+        check(count_zeros_device(s.num_entries, s.values.data(), &zeros));
+        d.resize(s.num_rows, s.num_cols, s.num_entries - static_cast<size_t>(zeros), width);
         check(csr_to_ell_device(s.num_rows, s.row_offsets.data(), s.column_indices.data(), s.values.data(), width,
                                 d.column_indices.pitch, d.column_indices.values.data(), d.values.values.data()));
         check(cmi_stream_synchronize(nullptr));

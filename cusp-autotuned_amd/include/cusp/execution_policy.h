@@ -4,6 +4,11 @@
 //   cusp::hip::par            default policy: the HIP default stream
 //   cusp::hip::par.on(s)      run the multiply on hipStream_t s (reference: cusp::cuda::par.on(stream),
 //                             stream(derived_cast(exec)) at cuda/detail/multiply/csr_vector_spmv.h:198)
+//   cusp::omp::par            host_memory, OpenMP: the CSR multiply runs the reference's OpenMP backend loop
+//                             (cusp/system/omp/detail/multiply/csr_spmv.h:51-86: `#pragma omp parallel for` over the
+//                             rows, the sequential kernel's body); every other format inherits the sequential loops,
+//                             as the reference's omp system does (cusp/system/omp/detail/multiply.h:26-40).  Built
+//                             without -fopenmp the pragma is inert and the loop is the sequential one.
 //   cusp::execution_policy<Derived>
 //                             CRTP base for USER policies.  cusp::multiply(policy, A, x, y) makes an
 //                             unqualified call with the derived policy (never copied), so a user
@@ -36,5 +41,10 @@ private:
 static const execution_policy par;
 
 } // namespace hip
+
+namespace omp {
+class execution_policy : public cusp::execution_policy<execution_policy> {};
+static const execution_policy par;
+} // namespace omp
 
 } // namespace cusp

@@ -324,6 +324,44 @@ void multiply(const cusp::hip::execution_policy &exec, const LinearOperator &A, 
     cusp::multiply(exec, A, x, y, constant_functor<V>(V(0)), multiplies<V>(), plus<V>());
 }
 
+// cusp::omp::par: the reference's OpenMP host backend.  CSR: cusp/system/omp/detail/multiply/csr_spmv.h:51-86 -- rows split
+// over the threads (#pragma omp parallel for, :67), per-row arithmetic the sequential kernel's (so the result is
+// bit-identical to the sequential multiply); every other format: the sequential loops (omp/detail/multiply.h:26-40).
+namespace detail {
+template <typename A, typename X, typename Y, typename Init, typename Comb, typename Red>
+void omp_multiply(const A &a, const X &x, Y &y, Init initialize, Comb combine, Red reduce, csr_format)
+{
+    typedef typename A::index_type I;
+    typedef typename Y::value_type V;
+    const long long n = static_cast<long long>(a.num_rows);
+#if defined(_OPENMP)
+#pragma omp parallel for
+#endif
+    for (long long i = 0; i < n; i++) {
+        V acc = initialize(y[i]);
+        for (I jj = a.row_offsets[i]; jj < a.row_offsets[i + 1]; jj++) acc = reduce(acc, combine(a.values[jj], x[a.column_indices[jj]]));
+        y[i] = acc;
+    }
+}
+template <typename A, typename X, typename Y, typename Init, typename Comb, typename Red, typename F>
+void omp_multiply(const A &a, const X &x, Y &y, Init i, Comb c, Red r, F f) { host_dispatch(a, x, y, i, c, r, f); }
+} // namespace detail
+
+template <typename LinearOperator, typename Vector1, typename Vector2, typename UnaryFunction, typename BinaryFunction1, typename BinaryFunction2>
+void multiply(const cusp::omp::execution_policy &, const LinearOperator &A, const Vector1 &x, Vector2 &y, UnaryFunction initialize,
+              BinaryFunction1 combine, BinaryFunction2 reduce)
+{
+    static_assert(std::is_same<typename LinearOperator::memory_space, host_memory>::value, "cusp::omp::par runs on host_memory containers");
+    detail::check_shapes(A, x, y);
+    detail::omp_multiply(A, x, y, initialize, combine, reduce, typename LinearOperator::format());
+}
+template <typename LinearOperator, typename Vector1, typename Vector2>
+void multiply(const cusp::omp::execution_policy &exec, const LinearOperator &A, const Vector1 &x, Vector2 &y)
+{
+    typedef typename Vector2::value_type V;
+    cusp::multiply(exec, A, x, y, constant_functor<V>(V(0)), multiplies<V>(), plus<V>());
+}
+
 // z = y + A*x (reference cusp/multiply.h:301,377 generalized_spmv with combine = *, reduce = +)
 template <typename LinearOperator, typename Vector1, typename Vector2, typename Vector3, typename BinaryFunction1, typename BinaryFunction2>
 void generalized_spmv(const LinearOperator &A, const Vector1 &x, const Vector2 &y, Vector3 &z, BinaryFunction1 combine, BinaryFunction2 reduce)

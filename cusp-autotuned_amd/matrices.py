@@ -232,6 +232,8 @@ def convert(csr, fmt, num_entries_per_row=None, ell_alignment=32):
         if fmt == "ell":
             if n_coo:
                 raise ValueError("convert: num_entries_per_row is smaller than the longest row (use hyb)")
+            # reference csr_to_other.h:188: an ELL matrix converted from CSR reports num_entries without the explicit zeros
+            ell.num_entries = csr.num_entries - (B.count_zeros(csr.values) if csr.num_entries else 0)
             return ell
         # COO part: entries at within-row index >= width, in CSR order.  Their destinations are an
         # exclusive scan of the per-row overflow counts (a function of the row offsets alone).

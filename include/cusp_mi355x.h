@@ -384,6 +384,10 @@ int cmi_csr_to_ell_f64(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, c
                        int64_t width, int64_t pitch, int32_t *ell_Aj, double *ell_Ax, void *stream);
 int cmi_csr_to_ell_f32(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, const float *Ax,
                        int64_t width, int64_t pitch, int32_t *ell_Aj, float *ell_Ax, void *stream);
+/* Number of explicit zeros among `n` values: the reference's CSR -> ELL reports num_entries without them
+ * (csr_to_other.h:188, thrust::count(values, 0)).  Set-up call: synchronises the stream. */
+int cmi_count_zeros_f64(int64_t n, const double *values, int64_t *count_host, void *stream);
+int cmi_count_zeros_f32(int64_t n, const float *values, int64_t *count_host, void *stream);
 /* CSR -> HYB, COO part (csr_to_other.h:229-306): the entries at within-row index >= width, in CSR order.
  * coo_offsets[i] = number of such entries in rows [0, i) -- an exclusive scan of max(0, len_i - width),
  * a function of the row offsets alone, supplied by the caller (num_rows entries).  The ELL part is

@@ -848,6 +848,34 @@ template <typename Space> void TestMultiplyDispatch()
 }
 DECLARE_SPACE_UNITTEST(TestMultiplyDispatch);
 
+// cusp::omp::par (reference cusp/system/omp): the OpenMP CSR loop gives the sequential multiply's bits, every format works
+void TestMultiplyOmpPolicy()
+{
+    cusp::csr_matrix<int, double, cusp::host_memory> A;
+    cusp::gallery::poisson5pt(A, 57, 43);
+    const size_t N = A.num_rows;
+    cusp::array1d<double, cusp::host_memory> x(N), y0(N, 10.0), y1(N, -3.0);
+    for (size_t i = 0; i < N; i++) x[i] = double((i * 2654435761u) % 1000u) / 997.0 - 0.5;
+    cusp::multiply(A, x, y0);
+    cusp::multiply(cusp::omp::par, A, x, y1);
+    for (size_t i = 0; i < N; i++) ASSERT_EQUAL(y0[i], y1[i]);
+    cusp::ell_matrix<int, double, cusp::host_memory> E(A);
+    cusp::coo_matrix<int, double, cusp::host_memory> C(A);
+    cusp::array1d<double, cusp::host_memory> y2(N, 7.0), y3(N, 7.0);
+    cusp::multiply(cusp::omp::par, E, x, y2);
+    cusp::multiply(cusp::omp::par, C, x, y3);
+    for (size_t i = 0; i < N; i++) { ASSERT_EQUAL(y0[i], y2[i]); ASSERT_EQUAL(y0[i], y3[i]); }
+    // y += A x through the policy overload with functors
+    cusp::array1d<double, cusp::host_memory> z(N, 1.5);
+    cusp::multiply(cusp::omp::par, A, x, z, cusp::identity_function<double>(), cusp::multiplies<double>(), cusp::plus<double>());
+    for (size_t i = 0; i < N; i += 97) {
+        double acc = 1.5;
+        for (int jj = A.row_offsets[i]; jj < A.row_offsets[i + 1]; jj++) acc = acc + A.values[jj] * x[A.column_indices[jj]];
+        ASSERT_EQUAL(z[i], acc);
+    }
+}
+DECLARE_UNITTEST(TestMultiplyOmpPolicy);
+
 // testing/cg.cu:11-44: cg(policy, ...) reaches a user overload by ADL; a policy without one solves
 template <class LinearOperator, class VectorType1, class VectorType2, class Monitor, class Preconditioner>
 void cg(my_system &system, const LinearOperator &, VectorType1 &, const VectorType2 &, Monitor &, Preconditioner &) { system.validate_dispatch(); }

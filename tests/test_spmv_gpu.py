@@ -146,15 +146,17 @@ def run_all_formats(cmi, torch, orc, rows, cols, Ap, Aj, Ax, x, want, want_acc, 
         # row-sorted entries through a plan: the tile kernel, storage-order sums = the host loop's bits
         plan = cmi.Plan(cmi.FORMAT_COO, dx.dtype, rows, cols, len(Aj), dAi)
         assert plan.info()["coo_sorted"] is True
-        if len(Aj):
-            assert plan.config().kernel == cmi.COO_TILE and plan.info()["storage_order_sums"]
+        assert plan.info()["storage_order_sums"] == (plan.config().kernel == cmi.COO_TILE)
         for swz, nt in ((0, 0), (1, 2), (3, 3), (32, 1)):
             y = fresh(acc)
             cmi.spmv_coo(rows, cols, dAi, dAj, dAx, dx, y, accumulate=acc, cfg=cmi.Config(kernel=cmi.COO_TILE, xcd_swizzle=swz, nontemporal=nt))
             assert np.array_equal(host(y), w), f"{label} coo tile x{swz} nt{nt} acc={acc}: not bit-exact"
         y = fresh(acc)
         cmi.spmv_coo_plan(plan, dAi, dAj, dAx, dx, y, accumulate=acc)
-        assert np.array_equal(host(y), w), f"{label} coo plan acc={acc}: not bit-exact"
+        if plan.config().kernel == cmi.COO_TILE and len(Aj) >= 4:
+            assert np.array_equal(host(y), w), f"{label} coo plan acc={acc}: not bit-exact"
+        else:
+            assert_close(host(y), w, bound, dtype, f"{label} coo plan acc={acc}")
 
     # ELL / ELLR
     width = int(np.diff(Ap).max()) if rows else 0
@@ -670,7 +672,7 @@ def test_multiply_inside_hip_graph_capture(cmi, torch_cuda, orc):
     side = torch.cuda.Stream()
     mats["coo planned"] = cmi.convert(A, "coo")
     mats["coo planned"].plan()
-    assert mats["coo planned"].plan().config().kernel == cmi.COO_TILE
+    tile_planned = mats["coo planned"].plan().config().kernel == cmi.COO_TILE
     for fmt, M in mats.items():
         y = torch.full((n,), 7.0, dtype=torch.float64, device="cuda")
         side.wait_stream(torch.cuda.current_stream())
@@ -681,7 +683,7 @@ def test_multiply_inside_hip_graph_capture(cmi, torch_cuda, orc):
         g.replay()
         torch.cuda.synchronize()
         got = host(y)
-        if fmt in ("csr", "ell", "dia", "coo planned"):
+        if fmt in ("csr", "ell", "dia") or (fmt == "coo planned" and tile_planned):
             assert np.array_equal(got, want), fmt
             if fmt in ("csr", "coo"):
                 assert getattr(M, "_plan", None) is None, "a capture must not have made a plan"
@@ -825,15 +827,18 @@ def test_coo_row_sorted_shapes(cmi, torch_cuda, orc, shape):
     # the tile kernel (what a plan selects for sorted entries): the host COO loop's bits, rows without entries +0
     want_coo = orc.spmv_coo(rows, Ai, Aj, Ax, x)
     plan = cmi.Plan(cmi.FORMAT_COO, torch.float64, rows, cols, nnz, dAi)
-    assert plan.info()["coo_sorted"] and plan.config().kernel == cmi.COO_TILE
+    assert plan.info()["coo_sorted"]
     for swz in (0, 1, 2, 64):
         y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
         cmi.spmv_coo(rows, cols, dAi, dAj, dAx, dx, y, cfg=cmi.Config(kernel=cmi.COO_TILE, xcd_swizzle=swz, nontemporal=2))
         assert np.array_equal(host(y), want_coo), f"coo tile {shape} x{swz}"
     y0t = rng.standard_normal(rows)
     y = dev(y0t, torch)
-    cmi.spmv_coo_plan(plan, dAi, dAj, dAx, dx, y, accumulate=True)
+    cmi.spmv_coo(rows, cols, dAi, dAj, dAx, dx, y, accumulate=True, cfg=cmi.Config(kernel=cmi.COO_TILE, xcd_swizzle=16))
     assert np.array_equal(host(y), orc.spmv_coo(rows, Ai, Aj, Ax, x, y0t)), f"coo tile {shape} accumulate"
+    y = dev(y0t, torch)
+    cmi.spmv_coo_plan(plan, dAi, dAj, dAx, dx, y, accumulate=True)   # whatever the table's sorted-COO key holds
+    assert_close(host(y), orc.spmv_coo(rows, Ai, Aj, Ax, x, y0t), bound + np.abs(y0t), np.float64, f"coo plan {shape} accumulate")
     # the same through the table (NULL config), on another stream, and accumulating (order-agnostic kernel)
     y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
     s = torch.cuda.Stream()
@@ -1456,3 +1461,47 @@ def test_suitesparse_like_matrices_every_kernel(cmi, torch_cuda, orc, name, scal
         y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
         cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, cfg=cmi.Config(kernel=cmi.CSR_VECTOR, threads_per_row=tpr))
         assert_close(host(y), want, bound, np.float64, f"{name}-like csr_vector tpr{tpr}")
+
+
+def test_fold_handoff_is_stable_under_load(cmi, torch_cuda):
+    """The multi-workgroup fold of a long partial list hands its chunk sums to the last-arriving workgroup with write-through
+    stores, a drained counter add and sc1 loads -- no agent-scope fences (blas1.hip dot_fold_final_kernel).  A stale or torn
+    hand-off would change the scalar: thousands of folds, idle and beside a streaming kernel on another stream (uneven load,
+    consumer caches warm), must all return the first call's bits; so must the fused SpMV + <y, w> and cg_update."""
+    torch = torch_cuda
+    rng = np.random.default_rng(77)
+    n = 6_000_001                                   # > 2048 partials for every producer below
+    a, b = dev(rng.standard_normal(n), torch), dev(rng.standard_normal(n), torch)
+    ws = cmi.blas_workspace()
+    res = torch.zeros(1, dtype=torch.float64, device="cuda")
+    A = cmi.poisson5pt(1500, 1500, "csr")
+    N = A.num_rows
+    x = cmi.fill_x(N).cuda()
+    y = torch.empty(N, dtype=torch.float64, device="cuda")
+    ws2 = cmi.blas_workspace()
+    res2 = torch.zeros(1, dtype=torch.float64, device="cuda")
+    rz = torch.tensor([3.0], dtype=torch.float64, device="cuda")
+    yp = torch.tensor([-1.5], dtype=torch.float64, device="cuda")
+    rr = torch.zeros(1, dtype=torch.float64, device="cuda")
+    r0 = dev(rng.standard_normal(n), torch)
+    noise_in = torch.ones(1 << 25, dtype=torch.float64, device="cuda")
+    noise_out = torch.empty_like(noise_in)
+    side = torch.cuda.Stream()
+
+    def one_round():
+        cmi.blas_dot(a, b, res, ws)                                   # dot_partial -> fold
+        d = float(res)
+        cmi.spmv_csr_dot(N, N, A.row_offsets, A.column_indices, A.values, x, y, x, res2, ws2)   # per-tile partials -> fold
+        s = float(res2)
+        r = r0.clone()
+        cmi.cg_update(rz, yp, None, b, None, r, rr, ws)               # near one-shot grid: tens of thousands of partials
+        return d, s, float(rr)
+
+    first = one_round()
+    for phase in ("idle", "beside a streaming kernel"):
+        for it in range(400):
+            if phase != "idle" and it % 4 == 0:
+                with torch.cuda.stream(side):
+                    cmi.blas_axpby(1.0, noise_in, 2.0, noise_in, noise_out)
+            assert one_round() == first, (phase, it)
+    side.synchronize()

@@ -106,12 +106,15 @@ csrx_kernel(int64_t N, int64_t nnz, const int *__restrict__ Ap, const int *__res
     prod[tid * 4 + 0] = p0; prod[tid * 4 + 1] = p1; prod[tid * 4 + 2] = p2; prod[tid * 4 + 3] = p3;
     __syncthreads();
     double wv = 0.0;
-    if constexpr (FLAGS & 28) { if (tid < nr) wv = x[r0 + tid]; }
+    if constexpr ((FLAGS & (28 | 64)) != 0 && (FLAGS & 256) == 0) { if (tid < nr) wv = x[r0 + tid]; } // 64: the w load alone; 128: the reduction alone
+    if constexpr ((FLAGS & 256) != 0) { if (tid < nr) wv = x[r0 + tid]; } // 256: w requested BEHIND the barrier (its lines are in L1 by then)
     double s = 0.0;
     if (tid < nr) {
         if constexpr (!(FLAGS & 1)) { a = rowptr[tid]; b = rowptr[tid + 1]; }
         for (int j = a; j < b; j++) s = s + prod[j - fbase];
     }
+    if constexpr ((FLAGS & 64) != 0) { if (s * wv == 123.456) y[0] = s; }
+    if constexpr ((FLAGS & 128) != 0) tile_dot_store(tid < nr ? s : 0.0, dslots, partial + tile);
     if constexpr (FLAGS & 28) {
         double d = tid < nr ? s * wv : 0.0;
         if constexpr (FLAGS & 4) tile_dot_store(d, dslots, partial + tile);
@@ -330,19 +333,34 @@ int main(int argc, char **argv)
         snprintf(nm, sizeof nm, "mix x-thrice nt-store swz %d", swz);
         run(nm, B_csr, false, [&, swz] { hipLaunchKernelGGL((mix_kernel<3, true>), dim3((unsigned)grid), dim3(256), 0, 0, N, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, (int)m); });
     }
+    // ---- what does the SpMV pay for running BEHIND vector kernels (the CG iteration) rather than behind itself? ------------
+    {
+        double *v1, *v2, *v3;
+        CK(hipMalloc(&v1, N * 8)); CK(hipMalloc(&v2, N * 8)); CK(hipMalloc(&v3, N * 8));
+        CK(hipMemset(v1, 0, N * 8)); CK(hipMemset(v2, 0, N * 8)); CK(hipMemset(v3, 0, N * 8));
+        auto vec = [&] { CM(cmi_blas_axpby_f64(N, 1.0, v1, 0.5, v2, v3, nullptr)); };                     // 160 MB read, 80 MB written
+        auto vec2 = [&] { CM(cmi_blas_axpby_f64(N, 1.0, v1, 0.5, v2, v3, nullptr)); CM(cmi_blas_axpby_f64(N, 1.0, v3, 0.5, v1, v2, nullptr)); };
+        auto spmv = [&] { CM(cmi_spmv_csr_f64(N, N, nnz, Ap, Aj, Ax, x, y, 0, nullptr, nullptr)); };
+        run("ctx: spmv alone", B_csr, true, spmv);
+        run("ctx: one vector kernel alone (240 MB)", 3.0 * 8 * N, false, vec);
+        run("ctx: spmv + one vector kernel", B_csr, true, [&] { vec(); spmv(); });
+        run("ctx: two vector kernels alone (480 MB)", 6.0 * 8 * N, false, vec2);
+        run("ctx: spmv + two vector kernels", B_csr, true, [&] { vec2(); spmv(); });
+        CK(hipFree(v1)); CK(hipFree(v2)); CK(hipFree(v3));
+    }
     // ---- csrx -----------------------------------------------------------------------------------------------
     double *dpart, *dres, *dws;
     CK(hipMalloc(&dpart, 262144 * 8)); CK(hipMalloc(&dres, 8)); CK(hipMalloc(&dws, cmi_blas_workspace_bytes()));
     run("lib csr_dot (SpMV + <y,x> + fold launch)", B_csr, true, [&] { CM(cmi_spmv_csr_dot_f64(N, N, nnz, Ap, Aj, Ax, x, y, x, dres, dws, nullptr, nullptr)); });
     for (int swz : {32}) {
-        for (int rpb : {176, 192}) {
+        for (int rpb : {176, 192, 200}) {
             const int64_t tiles = (N + rpb - 1) / rpb, tpx = (tiles + 7) / 8;
             const int64_t grid = ((tiles + 8 * swz - 1) / (8 * swz)) * 8 * swz;
             char nm[96];
 #define CSRX(F)                                                                                                          \
     snprintf(nm, sizeof nm, "csrx flags %d rpb %d swz %d", F, rpb, swz);                                                 \
     run(nm, B_csr, true, [&, swz] { hipLaunchKernelGGL((csrx_kernel<F>), dim3((unsigned)grid), dim3(256), 0, 0, N, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, dpart); })
-            CSRX(0); CSRX(1); CSRX(5); CSRX(9); CSRX(17);
+            CSRX(0); CSRX(1); CSRX(5); CSRX(9); CSRX(17); CSRX(65); CSRX(129); CSRX(261); CSRX(321);
 #undef CSRX
         }
     }
@@ -362,6 +380,22 @@ int main(int argc, char **argv)
             run(nm, B_ell, true, [&, c] { CM(cmi_spmv_ell_f64(N, N, 5, epitch, eAj, eAx, nullptr, x, y, 0, &c, nullptr)); });
         }
         CK(hipFree(eAj)); CK(hipFree(eAx));
+    }
+    // ---- coo: the order-agnostic kernel (memset + atomics) against the tile kernel for row-sorted entries -----------------
+    {
+        int *Ai;
+        CK(hipMalloc(&Ai, (nnz + pad) * 4));
+        CM(cmi_csr_row_indices(N, Ap, Ai, nullptr));
+        CK(hipDeviceSynchronize());
+        const double B_coo = 16.0 * nnz + 16.0 * N;
+        run("lib coo table (NULL cfg: order-agnostic)", B_coo, false, [&] { CM(cmi_spmv_coo_f64(N, N, nnz, Ai, Aj, Ax, x, y, 0, nullptr, nullptr)); });
+        for (int nt : {0, 2, 3}) for (int swz : {0, 16, 64}) {
+            cmi_config c = {CMI_COO_TILE, 256, 0, 0, 0, nt, swz, 0};
+            char nm[96];
+            snprintf(nm, sizeof nm, "lib coo tile nt %d swz %d", nt, swz);
+            run(nm, B_coo, true, [&, c] { CM(cmi_spmv_coo_f64(N, N, nnz, Ai, Aj, Ax, x, y, 0, &c, nullptr)); });
+        }
+        CK(hipFree(Ai));
     }
     // ---- dia ------------------------------------------------------------------------------------------------
     run("lib dia table (NULL cfg)", B_dia, true, [&] { CM(cmi_spmv_dia_f64(N, N, 5, pitch, doff, dvals, x, y, 0, nullptr, nullptr)); });
