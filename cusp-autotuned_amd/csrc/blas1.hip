@@ -10,10 +10,12 @@
 // index order and writes the scalar to device memory -- no host sync, no atomics, no per-call
 // allocation (the reference's Thrust reductions allocate temporaries and synchronise every call).
 #include "common.h"
+#include <cstdlib>
 
 namespace cmi {
 
 constexpr int kBlasBlock = 256;
+constexpr int kCgStorePolicy = 1; // x with the nt hint; see cg_store_policy() and the note in cg_update_kernel
 constexpr int kBlasMaxGrid = kCus * 8;   // reductions: 2048 partials
 constexpr int kFusedMaxGrid = kPartialCapacity;  // fused update+reduce kernels store too: near one-shot grids (65536 partials)
 
@@ -215,10 +217,17 @@ int reduce_partials_f64(int npartial, double *workspace, double *result, hipStre
 // ---------------------------------------------------------------------------------------------
 // T = double or float; the scalars (<r,r>, <y,p>) are doubles in device memory for both (the partials of every
 // reduction here are doubles), alpha / beta are rounded to T once per kernel and the vectors are updated in T.
+// store with or without the nt hint by a run-time flag (uniform)
+template <typename V> __device__ __forceinline__ void st_policy(V *p, V v, bool nt)
+{
+    if (nt) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kBlasBlock)
 cg_update_kernel(int64_t n, const double *__restrict__ rz, const double *__restrict__ yp, const T *__restrict__ p,
-                 const T *__restrict__ y, T *__restrict__ x /* may be null */, T *__restrict__ r, double *__restrict__ partial, int vec)
+                 const T *__restrict__ y, T *__restrict__ x /* may be null */, T *__restrict__ r, double *__restrict__ partial, int vec, int pol)
 {
     typedef typename vec16<T>::type V;
     constexpr int W = vec16<T>::n;
@@ -237,11 +246,15 @@ cg_update_kernel(int64_t n, const double *__restrict__ rz, const double *__restr
                 V xv = reinterpret_cast<V *>(x)[i];
 #pragma unroll
                 for (int k = 0; k < W; k++) xv[k] = alpha * pv[k] + xv[k];      // x <- x + alpha p   (:86)
-                reinterpret_cast<V *>(x)[i] = xv;
+                st_policy(reinterpret_cast<V *>(x) + i, xv, (pol & 1) != 0);
             }
 #pragma unroll
             for (int k = 0; k < W; k++) rv[k] = (-alpha) * yv[k] + rv[k];       // r <- r - alpha y   (:89)
-            reinterpret_cast<V *>(r)[i] = rv;
+            // (r is read again by the direction kernel right behind this one: plain store.  x is not read before the matrix
+            // streams of the next SpMV have flushed every cache: nt -- stored plainly it is written back DURING that SpMV, which
+            // then runs ~6 us longer: tools/r2_probe.hip "ctx:" lines, profiles/r02_probe_ctx.txt.  p is gathered by that SpMV:
+            // plain; with the nt hint on p the SpMV lost 5 us, profiles/r02_cg_store_policy.txt)
+            st_policy(reinterpret_cast<V *>(r) + i, rv, (pol & 4) != 0);
 #pragma unroll
             for (int k = 0; k < W; k++) acc += (double)rv[k] * (double)rv[k];   // <r, r>             (:97, z == r)
         }
@@ -272,7 +285,7 @@ cg_update_kernel(int64_t n, const double *__restrict__ rz, const double *__restr
 template <typename T>
 __global__ void __launch_bounds__(kBlasBlock)
 cg_direction_kernel(int64_t n, const double *__restrict__ rr_new, const double *__restrict__ rr_old, const double *__restrict__ yp,
-                    const T *__restrict__ r, T *__restrict__ p, T *__restrict__ x /* may be null */, int vec)
+                    const T *__restrict__ r, T *__restrict__ p, T *__restrict__ x /* may be null */, int vec, int pol)
 {
     typedef typename vec16<T>::type V;
     constexpr int W = vec16<T>::n;
@@ -289,11 +302,11 @@ cg_direction_kernel(int64_t n, const double *__restrict__ rr_new, const double *
                 V xv = reinterpret_cast<V *>(x)[i];
 #pragma unroll
                 for (int k = 0; k < W; k++) xv[k] = alpha * pv[k] + xv[k];
-                reinterpret_cast<V *>(x)[i] = xv;
+                st_policy(reinterpret_cast<V *>(x) + i, xv, (pol & 1) != 0);
             }
 #pragma unroll
             for (int k = 0; k < W; k++) pv[k] = T(1) * rv[k] + beta * pv[k];
-            reinterpret_cast<V *>(p)[i] = pv;
+            st_policy(reinterpret_cast<V *>(p) + i, pv, (pol & 2) != 0);
         }
         if (t < n - nv * W) {
             const int64_t i = nv * W + t;
@@ -387,6 +400,13 @@ static int fused_grid(int64_t n, int per_thread)
 
 namespace {
 
+// which of the vectors a CG step writes get the nt hint: bit 0 x, bit 1 p, bit 2 r (CMI_CG_STORE_POLICY overrides: measurements)
+static int cg_store_policy()
+{
+    static const int pol = [] { const char *e = std::getenv("CMI_CG_STORE_POLICY"); return e ? std::atoi(e) : kCgStorePolicy; }();
+    return pol;
+}
+
 template <typename T>
 int cg_update_impl(int64_t n, const double *rz_dev, const double *yp_dev, const T *p, const T *y, T *x, T *r, double *rr_dev,
                    double *rr_host_mirror, void *workspace, void *stream)
@@ -396,7 +416,7 @@ int cg_update_impl(int64_t n, const double *rz_dev, const double *yp_dev, const 
     if (n > 0 && (!y || !r || (x && !p))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_update: null array");
     const int grid = fused_grid(n, vec16<T>::n);
     const int vec = aligned16(y) && aligned16(r) && (!x || (aligned16(p) && aligned16(x)));
-    hipLaunchKernelGGL((cg_update_kernel<T>), dim3(grid), dim3(kBlasBlock), 0, as_stream(stream), n, rz_dev, yp_dev, p, y, x, r, (double *)workspace, vec);
+    hipLaunchKernelGGL((cg_update_kernel<T>), dim3(grid), dim3(kBlasBlock), 0, as_stream(stream), n, rz_dev, yp_dev, p, y, x, r, (double *)workspace, vec, cg_store_policy());
     reduce_partials<double>(grid, (double *)workspace, rr_dev, 0, as_stream(stream), rr_host_mirror);
     CMI_LAUNCH_CHECK("cg_update");
     return CMI_SUCCESS;
@@ -413,7 +433,7 @@ int cg_direction_impl(int64_t n, const double *rr_new_dev, const double *rr_old_
     if (!r || !p || (with_x && !x)) { set_error("%s: null array", who); return CMI_ERROR_INVALID_VALUE; }
     const int vec = aligned16(r) && aligned16(p) && (!with_x || aligned16(x));
     hipLaunchKernelGGL((cg_direction_kernel<T>), dim3(stream_grid(n, vec16<T>::n)), dim3(kBlasBlock), 0, as_stream(stream), n, rr_new_dev,
-                       rr_old_dev, yp_dev, r, p, with_x ? x : (T *)nullptr, vec);
+                       rr_old_dev, yp_dev, r, p, with_x ? x : (T *)nullptr, vec, cg_store_policy());
     CMI_LAUNCH_CHECK("cg_direction");
     return CMI_SUCCESS;
 }

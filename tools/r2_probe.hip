@@ -212,6 +212,18 @@ diax_kernel(int64_t num_rows, int64_t num_cols, int nd, int64_t pitch, const int
     } else if (live0) __builtin_nontemporal_store(acc0, y + row);
 }
 
+// z = a + 0.5 b over 16-byte vectors, one-shot grid: the store plain or with the nt hint (ctx experiment)
+template <bool NTS>
+__global__ void __launch_bounds__(256) vecop_kernel(int64_t nv, const double2v *__restrict__ a, const double2v *__restrict__ b, double2v *__restrict__ z)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nv) {
+        const double2v u = a[i], v = b[i];
+        double2v o; o.x = u.x + 0.5 * v.x; o.y = u.y + 0.5 * v.y;
+        if constexpr (NTS) __builtin_nontemporal_store(o, z + i); else z[i] = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 struct Timing { double med, mn; };
 static Timing time_us(const std::function<void()> &f, int batches, int launches)
@@ -344,6 +356,18 @@ int main(int argc, char **argv)
         run("ctx: spmv alone", B_csr, true, spmv);
         run("ctx: one vector kernel alone (240 MB)", 3.0 * 8 * N, false, vec);
         run("ctx: spmv + one vector kernel", B_csr, true, [&] { vec(); spmv(); });
+        {
+            const int64_t nv = N / 2;
+            const unsigned g = (unsigned)((nv + 255) / 256);
+            auto vp = [&] { hipLaunchKernelGGL((vecop_kernel<false>), dim3(g), dim3(256), 0, 0, nv, (const double2v *)v1, (const double2v *)v2, (double2v *)v3); };
+            auto vn = [&] { hipLaunchKernelGGL((vecop_kernel<true>), dim3(g), dim3(256), 0, 0, nv, (const double2v *)v1, (const double2v *)v2, (double2v *)v3); };
+            run("ctx: own vector kernel, plain store, alone", 3.0 * 8 * N, false, vp);
+            run("ctx: own vector kernel, nt store, alone", 3.0 * 8 * N, false, vn);
+            run("ctx: spmv + own vector kernel (plain store)", B_csr, true, [&] { vp(); spmv(); });
+            run("ctx: spmv + own vector kernel (nt store)", B_csr, true, [&] { vn(); spmv(); });
+            run("ctx: spmv + 2x own vector kernel (plain)", B_csr, true, [&] { vp(); vp(); spmv(); });
+            run("ctx: spmv + 2x own vector kernel (nt)", B_csr, true, [&] { vn(); vn(); spmv(); });
+        }
         run("ctx: two vector kernels alone (480 MB)", 6.0 * 8 * N, false, vec2);
         run("ctx: spmv + two vector kernels", B_csr, true, [&] { vec2(); spmv(); });
         CK(hipFree(v1)); CK(hipFree(v2)); CK(hipFree(v3));
