@@ -123,7 +123,7 @@ def run_peer_probe(world):
     env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 23)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-peer", "--gpus", str(world)], env=env, timeout=150,
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-peer", "--gpus", str(world)], env=env, timeout=300,  # a cold box pages torch in for a minute or two; the parents import it from a warm cache afterwards
                            capture_output=True, text=True)
     except subprocess.TimeoutExpired:
         return False, "probe timed out"

@@ -59,7 +59,8 @@ CMI_API int cmi_plan_create(int format, int dtype, int64_t num_rows, int64_t num
             p->coo_sorted = sorted;
             const bool auto_kernel = !cfg || cfg->kernel == CMI_KERNEL_AUTO;
             // sorted entries: the table's CMI_TABLE_COO_SORTED key (the tile kernel with its tuned cache policy / XCD dealing)
-            if (sorted && auto_kernel) select_config(CMI_TABLE_COO_SORTED, dtype, num_rows, num_cols, num_entries, cfg, &p->cfg);
+            // (fewer than four entries: the tile kernel's vector loads have nothing to read -- the order-agnostic kernel stays)
+            if (sorted && auto_kernel && num_entries >= 4) select_config(CMI_TABLE_COO_SORTED, dtype, num_rows, num_cols, num_entries, cfg, &p->cfg);
             // an explicit CMI_COO_TILE on unsorted entries would add rows up wrongly: refuse it here, where it is known
             if (!sorted && p->cfg.kernel == CMI_COO_TILE) st = fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: CMI_COO_TILE needs row-sorted entries");
         }

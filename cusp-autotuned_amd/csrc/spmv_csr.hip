@@ -104,32 +104,50 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
     // loads the two offsets of its own row, and nothing waits at a barrier before the index / value
     // vectors are requested -- 126.5 us instead of 129.0 on the headline matrix (tools/r2_probe.hip,
     // profiles/r02_probe_timing.txt: csrx flags 1 vs 0), same bits.
-    if constexpr (VEC && IPT == 1) {
+    if constexpr (VEC) {
         const int nz0 = Ap[r0], nz1 = Ap[r0 + nr];
         const int fbase = nz0 & ~3;
         if (tpr == 1 && nr <= block && nz1 - fbase <= tile_entries && (int64_t)((nz1 + 3) & ~3) <= num_entries) {
             const int a = Ap[r0 + (tid < nr ? tid : nr)], b = Ap[r0 + (tid + 1 < nr ? tid + 1 : nr)];
-            const int e = fbase + tid * 4;
-            T p0 = T(0), p1 = T(0), p2 = T(0), p3 = T(0);
-            if (e < nz1) {
-                const int4v c = ld<NT>(reinterpret_cast<const int4v *>(Aj + e));
-                if constexpr (sizeof(T) == 8) {
-                    const double2v v01 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e));
-                    const double2v v23 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e + 2));
-                    p0 = v01.x * x[c.x]; p1 = v01.y * x[c.y]; p2 = v23.x * x[c.z]; p3 = v23.y * x[c.w];
+            // IPT vectors per lane, all requested before the first product is formed (round 2: the path also serves the
+            // longer-row shapes of the table, IPT 2 and 4 -- FEM-like matrices of 27-80 entries per row)
+            int4v c[IPT];
+            T v[IPT][4];
+#pragma unroll
+            for (int k = 0; k < IPT; k++) {
+                const int e = fbase + (k * block + tid) * 4;
+                if (e < nz1) {
+                    c[k] = ld<NT>(reinterpret_cast<const int4v *>(Aj + e));
+                    if constexpr (sizeof(T) == 8) {
+                        const double2v v01 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e));
+                        const double2v v23 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e + 2));
+                        v[k][0] = v01.x; v[k][1] = v01.y; v[k][2] = v23.x; v[k][3] = v23.y;
+                    } else {
+                        const float4v vv = ld<NT>(reinterpret_cast<const float4v *>(Ax + e));
+                        v[k][0] = vv.x; v[k][1] = vv.y; v[k][2] = vv.z; v[k][3] = vv.w;
+                    }
                 } else {
-                    const float4v v = ld<NT>(reinterpret_cast<const float4v *>(Ax + e));
-                    p0 = v.x * x[c.x]; p1 = v.y * x[c.y]; p2 = v.z * x[c.z]; p3 = v.w * x[c.w];
+                    c[k] = int4v{0, 0, 0, 0};
+                    v[k][0] = v[k][1] = v[k][2] = v[k][3] = T(0);
                 }
             }
-            prod[tid * 4 + 0] = p0; prod[tid * 4 + 1] = p1; prod[tid * 4 + 2] = p2; prod[tid * 4 + 3] = p3;
+#pragma unroll
+            for (int k = 0; k < IPT; k++) {
+                const int slot = (k * block + tid) * 4;
+                if (fbase + slot < nz1) { // (uniform per wave except at the tile's end: the gathers of a wave stay together)
+                    const T x0 = x[c[k].x], x1 = x[c[k].y], x2 = x[c[k].z], x3 = x[c[k].w];
+                    prod[slot + 0] = v[k][0] * x0; prod[slot + 1] = v[k][1] * x1;
+                    prod[slot + 2] = v[k][2] * x2; prod[slot + 3] = v[k][3] * x3;
+                }
+            }
             T wv = T(0);
             if constexpr (DOT) { if (tid < nr) wv = w[r0 + tid]; } // requested before the barrier
             __syncthreads();
             double d = 0.0;
             if (tid < nr) {
                 T s = accumulate ? y[r0 + tid] : T(0);
-                for (int j = a; j < b; j++) s = s + prod[j - fbase];
+                if constexpr (IPT == 1) { for (int j = a; j < b; j++) s = s + prod[j - fbase]; } // short rows: the plain loop is faster
+                else s = sum_in_order(s, prod + (a - fbase), b - a);
                 st<(POL & kPolStoreNT) != 0>(y + r0 + tid, s);
                 if constexpr (DOT) d = (double)s * (double)wv;
             }
