@@ -14,7 +14,7 @@ FORMAT_CSR, FORMAT_ELL, FORMAT_DIA, FORMAT_COO, FORMAT_HYB = 0, 1, 2, 3, 4
 TABLE_COO_SORTED = 5  # tuning-table key only: the launch shape of a COO multiply whose plan found the entries row-sorted
 F64, F32 = 0, 1
 KERNEL_AUTO = 0
-CSR_SCALAR, CSR_VECTOR, CSR_STREAM, CSR_STREAM_PIPE, CSR_BALANCED = 1, 2, 3, 4, 5
+CSR_SCALAR, CSR_VECTOR, CSR_STREAM, CSR_STREAM_PIPE, CSR_BALANCED, CSR_STREAM_C16 = 1, 2, 3, 4, 5, 6
 ELL_ROW, DIA_ROW, COO_SEGMENTED, COO_LANE4, COO_TILE = 10, 20, 30, 31, 32
 
 
@@ -148,6 +148,11 @@ def _declare(L):
     L.cmi_plan_destroy.argtypes = [vp]
     L.cmi_plan_config.argtypes = [vp, cfgp]
     L.cmi_plan_info.argtypes = [vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int), POINTER(c_int)]
+    L.cmi_plan_create_csr.argtypes = [c_int, i64, i64, i64, vp, vp, cfgp, vp, POINTER(c_void_p)]
+    L.cmi_set_index_compression.argtypes = [c_int]
+    L.cmi_plan_create_hyb.argtypes = [c_int, i64, i64, i64, i64, vp, cfgp, cfgp, vp, POINTER(c_void_p)]
+    for suf in ("f64", "f32"):
+        getattr(L, f"cmi_spmv_hyb_plan_{suf}").argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp]
     for suf in ("f64", "f32"):
         getattr(L, f"cmi_spmv_csr_plan_{suf}").argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
         getattr(L, f"cmi_spmv_coo_plan_{suf}").argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
@@ -252,6 +257,39 @@ class Plan:
                                     byref(self._h)))
         self.format, self.dtype = fmt, code
         self.num_rows, self.num_cols, self.num_entries = num_rows, num_cols, num_entries
+
+    @classmethod
+    def csr(cls, dtype, num_rows, num_cols, Ap, Aj, cfg=None, stream=None):
+        """cmi_plan_create_csr: a CSR plan made from both structure arrays -- with cfg.kernel == CSR_STREAM_C16 (or after
+        set_index_compression(True)) it also builds the 16-bit column copy; config().kernel tells whether it was granted."""
+        import torch
+        self = cls.__new__(cls)
+        self._h = c_void_p()
+        _need(Ap, "Ap", torch.int32)
+        _need(Aj, "Aj", torch.int32)
+        if Ap.numel() != num_rows + 1:
+            raise ValueError("Plan.csr: row offsets must have num_rows + 1 entries")
+        code = F64 if dtype in (F64, torch.float64) else F32
+        check(lib().cmi_plan_create_csr(code, num_rows, num_cols, Aj.numel(), _ptr(Ap), _ptr(Aj), _cfg(cfg), _stream(stream), byref(self._h)))
+        self.format, self.dtype = FORMAT_CSR, code
+        self.num_rows, self.num_cols, self.num_entries = num_rows, num_cols, Aj.numel()
+        return self
+
+    @classmethod
+    def hyb(cls, dtype, num_rows, num_cols, width, coo_row_indices, cfg_ell=None, cfg_coo=None, stream=None):
+        """cmi_plan_create_hyb: both parts' launch shapes and -- COO part sorted by row -- the per-tile entry ranges of the
+        one-launch HYB kernel (spmv_hyb_plan)."""
+        import torch
+        self = cls.__new__(cls)
+        self._h = c_void_p()
+        _need(coo_row_indices, "coo_row_indices", torch.int32)
+        code = F64 if dtype in (F64, torch.float64) else F32
+        check(lib().cmi_plan_create_hyb(code, num_rows, num_cols, width, coo_row_indices.numel(), _ptr(coo_row_indices),
+                                        _cfg(cfg_ell), _cfg(cfg_coo), _stream(stream), byref(self._h)))
+        self.format, self.dtype = FORMAT_HYB, code
+        self.num_rows, self.num_cols, self.num_entries = num_rows, num_cols, num_rows * width
+        self.width, self.coo_entries = width, coo_row_indices.numel()
+        return self
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -399,6 +437,33 @@ def spmv_hyb(num_rows, num_cols, width, pitch, ell_Aj, ell_Ax, coo_Ai, coo_Aj, c
     fn = getattr(lib(), "cmi_spmv_hyb_" + _suffix(y))
     check(fn(num_rows, num_cols, width, pitch, _ptr(ell_Aj), _ptr(ell_Ax), coo_Ax.numel(), _ptr(coo_Ai), _ptr(coo_Aj),
              _ptr(coo_Ax), _ptr(x), _ptr(y), int(bool(accumulate)), _cfg(cfg_ell), _cfg(cfg_coo), _stream(stream)))
+
+
+def set_index_compression(on):
+    """cmi_set_index_compression: every later AUTO-kernel plan of Plan.csr / CsrMatrix tries the 16-bit column copy."""
+    check(lib().cmi_set_index_compression(int(bool(on))))
+
+
+def get_index_compression():
+    return bool(lib().cmi_get_index_compression())
+
+
+def spmv_hyb_plan(plan, pitch, ell_Aj, ell_Ax, coo_Ai, coo_Aj, coo_Ax, x, y, accumulate=False, stream=None):
+    """cmi_spmv_hyb_plan_*: one launch when the plan found the COO part sorted by row (storage-order sums, y written once)."""
+    import torch
+    for t, n in ((ell_Aj, "ell_Aj"), (coo_Ai, "coo_Ai"), (coo_Aj, "coo_Aj")):
+        _need(t, n, torch.int32)
+    for t, n in ((ell_Ax, "ell_Ax"), (coo_Ax, "coo_Ax"), (x, "x"), (y, "y")):
+        _need(t, n, y.dtype)
+    if plan.format != FORMAT_HYB:
+        raise ValueError("spmv_hyb_plan: not a HYB plan")
+    if (coo_Ai.numel() != plan.coo_entries or coo_Aj.numel() != plan.coo_entries or coo_Ax.numel() != plan.coo_entries
+            or ell_Aj.numel() < plan.width * pitch or ell_Ax.numel() < plan.width * pitch or pitch < plan.num_rows
+            or x.numel() != plan.num_cols or y.numel() != plan.num_rows):
+        raise ValueError("spmv_hyb_plan: array lengths do not match the plan's matrix shape")
+    fn = getattr(lib(), "cmi_spmv_hyb_plan_" + _suffix(y))
+    check(fn(plan.handle, pitch, _ptr(ell_Aj), _ptr(ell_Ax), _ptr(coo_Ai), _ptr(coo_Aj), _ptr(coo_Ax), _ptr(x), _ptr(y),
+             int(bool(accumulate)), _stream(stream)))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -59,6 +59,13 @@ int measure_row_lengths(int64_t rows, const int *Ap, hipStream_t s, int64_t *max
 bool prefers_balanced(int64_t rows, int64_t nnz, const row_profile &pr, size_t value_bytes, bool strict_order);
 // are the row indices of a COO matrix non-decreasing and inside [0, rows)?  (spmv_coo_hyb.hip; synchronises the stream)
 int coo_rows_sorted(int64_t rows, int64_t nnz, const int *Ai, hipStream_t s, int *sorted);
+// ELL lanes per row (spmv_ell_dia.hip): 1 = the row kernel (storage-order sums), 2..16 = the slices kernel.  Auto rule,
+// from tools/ell_wide_probe.py (profiles/r02_ell_wide_lanes_f64.txt): every lane keeps >= kEllSliceMinSlots slots
+// (lanes = width / 16 rounded down to a power of two, at most 16); two lanes only pay below kEllSliceMaxRows2 rows
+// (one lane per row no longer fills 256 CUs x 8 waves x 64 lanes), four or more up to kEllSliceMaxRows.
+constexpr int64_t kEllSliceMaxRows2 = 131072, kEllSliceMaxRows = 524288;
+constexpr int kEllSliceMinSlots = 16;
+int ell_lanes_per_row(const cmi_config &c, int64_t rows, int64_t width);
 
 // Deterministic fold of `npartial` (<= kPartialCapacity) doubles at the start of a
 // cmi_blas_workspace_bytes() buffer into *result (blas1.hip; fixed tree, no atomics).
@@ -229,12 +236,32 @@ template <typename F> inline void with_policy(int pol, F f)
 
 } // namespace cmi
 
-// The plan object of include/cusp_mi355x.h (plan.hip): what the library learnt about one matrix.  Plain data, read-only
-// after cmi_plan_create; owns no device memory.
+// The plan object of include/cusp_mi355x.h (plan.hip): what the library learnt about one matrix.  Read-only after
+// cmi_plan_create*; owns no device memory except a HYB plan's `hyb_tile_start` (one int per 256 rows) and the opt-in
+// 16-bit column copy of a CMI_CSR_STREAM_C16 plan.
 struct cmi_plan {
     int format, dtype;
     int64_t rows, cols, nnz;
     cmi_config cfg;        // resolved launch shape (kernel CMI_CSR_BALANCED when the profile switched kernels)
     cmi::row_profile prof; // CSR
-    int coo_sorted;        // COO: 1 / 0; -1 otherwise
+    int coo_sorted;        // COO, HYB's COO part: 1 / 0; -1 otherwise
+    // HYB (cmi_plan_create_hyb): ELL width, COO entries, the COO part's launch shape for the two-launch path, and -- when the
+    // COO part is sorted by row -- for every tile of kHybTileRows rows the first COO entry at or after its first row
+    int64_t hyb_width = 0, hyb_coo = 0;
+    cmi_config hyb_coo_cfg = {};
+    int32_t *hyb_tile_start = nullptr; // device, tiles + 1 entries; null: two launches
+    // CSR with cfg.kernel == CMI_CSR_STREAM_C16 (spmv_csr16.hip): per-tile smallest column and the 16-bit offsets from it
+    int32_t *csr16_base = nullptr;  // device, one per tile of cfg.rows_per_block rows
+    uint16_t *csr16_cols = nullptr; // device, nnz (+ padding) entries
 };
+
+namespace cmi {
+constexpr int kHybTileRows = 256; // rows per workgroup of the one-launch HYB kernel = its block size
+int hyb_tile_starts(int64_t rows, int64_t coo_entries, const int *coo_Ai, int32_t *tile_start, hipStream_t s);
+// spmv_csr16.hip: the plan's 16-bit column copy (built only if every tile qualifies) and the multiply that reads it
+int csr16_build(cmi_plan *p, const int *Ap, const int *Aj, hipStream_t s);
+int csr16_multiply_f64(const cmi_plan *p, const int *Ap, const double *Ax, const double *x, double *y, int accumulate,
+                       hipStream_t s, const double *w, double *dot_partial, int *dot_partials);
+int csr16_multiply_f32(const cmi_plan *p, const int *Ap, const float *Ax, const float *x, float *y, int accumulate,
+                       hipStream_t s, const float *w, double *dot_partial, int *dot_partials);
+}

@@ -11,14 +11,51 @@
 //         in rows of 512+) decides between the row-tile kernel, its long-row instance and the merge-path kernel.
 //   COO : launch shape + "are the entries sorted by row?" -- sorted input runs the tile kernel (plain stores, storage-
 //         order sums), anything else the order-agnostic atomics kernels.
-//   ELL / DIA / HYB : the resolved launch shape only (nothing to measure).
+//   ELL / DIA : the resolved launch shape only (nothing to measure).
+//   HYB (cmi_plan_create_hyb) : is the COO part sorted by row?  Then one int per 256 rows -- where that tile's COO entries
+//         begin -- lets ONE kernel finish a row (ELL slots, then its COO entries) instead of two launches over y.
 #include "common.h"
+#include <cstdlib>
 #include <new>
 
 using namespace cmi;
 
+// opt-in default for cmi_plan_create_csr with an AUTO kernel: try the 16-bit column copy ($CMI_COMPRESS_INDICES=1 at load,
+// cmi_set_index_compression afterwards)
+static int g_compress = -1;
+static int compress_default()
+{
+    if (g_compress < 0) {
+        const char *e = std::getenv("CMI_COMPRESS_INDICES");
+        g_compress = (e && e[0] && e[0] != '0') ? 1 : 0;
+    }
+    return g_compress;
+}
+CMI_API int cmi_set_index_compression(int on) { g_compress = on ? 1 : 0; return CMI_SUCCESS; }
+CMI_API int cmi_get_index_compression(void) { return compress_default(); }
+
+static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
+                       const int32_t *index_array, const int32_t *csr_columns, const cmi_config *cfg, void *stream, cmi_plan **plan_out);
+
 CMI_API int cmi_plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
                             const int32_t *index_array, const cmi_config *cfg, void *stream, cmi_plan **plan_out)
+{
+    if (format == CMI_FORMAT_CSR && cfg && cfg->kernel == CMI_CSR_STREAM_C16)
+        return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: CMI_CSR_STREAM_C16 needs the column indices -- use cmi_plan_create_csr");
+    return plan_create(format, dtype, num_rows, num_cols, num_entries, index_array, nullptr, cfg, stream, plan_out);
+}
+
+// CSR with both structure arrays: what cmi_plan_create(CMI_FORMAT_CSR, ...) does, plus -- asked for by
+// cfg->kernel == CMI_CSR_STREAM_C16, or by the process-wide default with an AUTO kernel -- the 16-bit column copy.
+CMI_API int cmi_plan_create_csr(int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *row_offsets,
+                                const int32_t *column_indices, const cmi_config *cfg, void *stream, cmi_plan **plan_out)
+{
+    if (num_entries > 0 && !column_indices) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create_csr: null column indices");
+    return plan_create(CMI_FORMAT_CSR, dtype, num_rows, num_cols, num_entries, row_offsets, column_indices, cfg, stream, plan_out);
+}
+
+static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
+                       const int32_t *index_array, const int32_t *csr_columns, const cmi_config *cfg, void *stream, cmi_plan **plan_out)
 {
     if (!plan_out) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: null result pointer");
     *plan_out = nullptr;
@@ -38,6 +75,19 @@ CMI_API int cmi_plan_create(int format, int dtype, int64_t num_rows, int64_t num
     p->nnz = num_entries;
     p->prof = row_profile{};
     p->coo_sorted = -1;
+    // CMI_CSR_STREAM_C16 is csr_stream's shape (the caller's launch-shape fields if any, else the table's) + the 16-bit copy
+    cmi_config shape;
+    bool want16 = false, table_shape = !cfg || cfg->kernel == CMI_KERNEL_AUTO;
+    if (format == CMI_FORMAT_CSR && csr_columns) {
+        if (cfg && cfg->kernel == CMI_CSR_STREAM_C16) {
+            want16 = true;
+            shape = *cfg;
+            table_shape = !(cfg->block_size || cfg->rows_per_block || cfg->items_per_thread);
+            shape.kernel = table_shape ? CMI_KERNEL_AUTO : CMI_CSR_STREAM;
+            cfg = &shape;
+        } else if (table_shape && compress_default())
+            want16 = true;
+    }
     // HYB's table key is its ELL part's (the COO part looks its own shape up per call)
     select_config(format == CMI_FORMAT_HYB ? CMI_FORMAT_ELL : format, dtype, num_rows, num_cols, num_entries, cfg, &p->cfg);
     hipStream_t s = as_stream(stream);
@@ -52,6 +102,18 @@ CMI_API int cmi_plan_create(int format, int dtype, int64_t num_rows, int64_t num
             p->cfg.blocks_per_cu = 0;
             p->cfg.xcd_swizzle = 0;      // (chunks in launch order: a skewed matrix has no x window worth dealing for)
         }
+        if (st == CMI_SUCCESS && want16 && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1) {
+            // the tiling is frozen into the copy, so the fused-dot instance cannot re-tile as spmv_csr.hip does for it: a
+            // table-chosen shape takes whole waves of rows per tile here, for every multiply, when one LDS pass holds them
+            const int tuned_rpb = p->cfg.rows_per_block;
+            if (table_shape) {
+                const int rpb = p->cfg.rows_per_block, up = (rpb + kWave - 1) / kWave * kWave;
+                const double mean = (double)num_entries / (double)num_rows;
+                if (up != rpb && up <= p->cfg.block_size && (double)up * mean + 3.0 <= (double)p->cfg.block_size * p->cfg.items_per_thread * 4) p->cfg.rows_per_block = up;
+            }
+            st = csr16_build(p, index_array, csr_columns, s); // all tiles qualify -> cfg.kernel = CMI_CSR_STREAM_C16, else unchanged
+            if (p->cfg.kernel != CMI_CSR_STREAM_C16) p->cfg.rows_per_block = tuned_rpb; // not granted: csr_stream as tuned
+        }
     } else if (format == CMI_FORMAT_COO) {
         int sorted = 1;
         if (num_entries > 0) st = coo_rows_sorted(num_rows, num_entries, index_array, s, &sorted);
@@ -65,13 +127,64 @@ CMI_API int cmi_plan_create(int format, int dtype, int64_t num_rows, int64_t num
             if (!sorted && p->cfg.kernel == CMI_COO_TILE) st = fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: CMI_COO_TILE needs row-sorted entries");
         }
     }
-    if (st != CMI_SUCCESS) { delete p; return st; }
+    if (st != CMI_SUCCESS) { (void)cmi_plan_destroy(p); return st; }
+    *plan_out = p;
+    return CMI_SUCCESS;
+}
+
+// HYB: the ELL part's launch shape, the COO part's order and -- when it is sorted by row -- the per-tile entry ranges the
+// one-launch kernel (spmv_coo_hyb.hip hyb_tile_kernel) reads.  The only plan that owns device memory: one int per 256 rows.
+CMI_API int cmi_plan_create_hyb(int dtype, int64_t num_rows, int64_t num_cols, int64_t ell_entries_per_row,
+                                int64_t coo_entries, const int32_t *coo_row_indices, const cmi_config *cfg_ell,
+                                const cmi_config *cfg_coo, void *stream, cmi_plan **plan_out)
+{
+    if (!plan_out) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create_hyb: null result pointer");
+    *plan_out = nullptr;
+    if (dtype < 0 || dtype > 1) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create_hyb: bad value type");
+    if (num_rows < 0 || num_cols < 0 || ell_entries_per_row < 0 || coo_entries < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create_hyb: negative size");
+    if (num_rows > INT32_MAX || num_cols > INT32_MAX || ell_entries_per_row > INT32_MAX)
+        return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create_hyb: sizes exceed the int32 index type");
+    if (coo_entries > 0 && !coo_row_indices) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create_hyb: the COO part's row indices are needed");
+    cmi_plan *p = new (std::nothrow) cmi_plan;
+    if (!p) return fail(CMI_ERROR_ALLOC, "cmi_plan_create_hyb: out of host memory");
+    p->format = CMI_FORMAT_HYB;
+    p->dtype = dtype;
+    p->rows = num_rows;
+    p->cols = num_cols;
+    p->nnz = num_rows * ell_entries_per_row;
+    p->prof = row_profile{};
+    p->coo_sorted = -1;
+    p->hyb_width = ell_entries_per_row;
+    p->hyb_coo = coo_entries;
+    select_config(CMI_FORMAT_ELL, dtype, num_rows, num_cols, p->nnz, cfg_ell, &p->cfg);
+    select_config(CMI_FORMAT_COO, dtype, num_rows, num_cols, coo_entries, cfg_coo, &p->hyb_coo_cfg);
+    hipStream_t s = as_stream(stream);
+    int st = CMI_SUCCESS;
+    if (coo_entries > 0 && num_rows > 0) {
+        int sorted = 0;
+        st = coo_rows_sorted(num_rows, coo_entries, coo_row_indices, s, &sorted);
+        if (st == CMI_SUCCESS) p->coo_sorted = sorted;
+        if (st == CMI_SUCCESS && sorted && coo_entries <= INT32_MAX - 4096) {
+            const int64_t tiles = ceil_div(num_rows, kHybTileRows);
+            hipError_t e = hipMalloc((void **)&p->hyb_tile_start, (size_t)(tiles + 1) * sizeof(int32_t));
+            if (e != hipSuccess) st = hip_fail(e, "cmi_plan_create_hyb: tile ranges");
+            if (st == CMI_SUCCESS) st = hyb_tile_starts(num_rows, coo_entries, coo_row_indices, p->hyb_tile_start, s);
+            if (st == CMI_SUCCESS) {
+                e = hipStreamSynchronize(s);
+                if (e != hipSuccess) st = hip_fail(e, "cmi_plan_create_hyb: tile ranges");
+            }
+        }
+    }
+    if (st != CMI_SUCCESS) { (void)cmi_plan_destroy(p); return st; }
     *plan_out = p;
     return CMI_SUCCESS;
 }
 
 CMI_API int cmi_plan_destroy(cmi_plan *plan)
 {
+    if (plan && plan->hyb_tile_start) (void)hipFree(plan->hyb_tile_start);
+    if (plan && plan->csr16_base) (void)hipFree(plan->csr16_base);
+    if (plan && plan->csr16_cols) (void)hipFree(plan->csr16_cols);
     delete plan;
     return CMI_SUCCESS;
 }
@@ -96,13 +209,15 @@ CMI_API int cmi_plan_info(const cmi_plan *plan, int64_t *max_row_length, int64_t
         switch (plan->format) {
         case CMI_FORMAT_CSR:
             // scalar / pipe: always; stream: one lane per row and no row long enough for the cooperative path
-            exact = c.kernel == CMI_CSR_SCALAR || c.kernel == CMI_CSR_STREAM_PIPE ||
+            exact = c.kernel == CMI_CSR_SCALAR || c.kernel == CMI_CSR_STREAM_PIPE || c.kernel == CMI_CSR_STREAM_C16 ||
                     (c.kernel == CMI_CSR_STREAM && c.threads_per_row <= 1 && (c.threads_per_row == 1 || plan->prof.max_len < 512));
             break;
-        case CMI_FORMAT_ELL:
+        case CMI_FORMAT_ELL: exact = ell_lanes_per_row(c, plan->rows, plan->rows > 0 ? plan->nnz / plan->rows : 0) == 1; break;
         case CMI_FORMAT_DIA: exact = 1; break;
         case CMI_FORMAT_COO: exact = c.kernel == CMI_COO_TILE; break;
-        default: exact = 0; break; // HYB: its COO half accumulates with atomics unless planned separately
+        default: // HYB: one launch = one chain per row; two launches: atomics in the COO half (an empty one: the ELL kernel's class)
+            exact = plan->hyb_tile_start != nullptr || (plan->hyb_coo == 0 && ell_lanes_per_row(c, plan->rows, plan->hyb_width) == 1);
+            break;
         }
         *storage_order_sums = exact;
     }

@@ -477,6 +477,154 @@ static int spmv_coo(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     return CMI_SUCCESS;
 }
 
+// ---------------------------------------------------------------------------------------------
+// HYB in ONE launch (needs a plan: cmi_plan_create_hyb found the COO part sorted by row)
+// ---------------------------------------------------------------------------------------------
+// The reference runs HYB as two multiplies -- ELL with the caller's `initialize`, then COO accumulating on top
+// (sequential/multiply/hyb_spmv.h:55-56; device: generic/multiply/spmv.h:275-290) -- so y is written, read again and
+// written again, and the COO half needs its own zero-fill-free accumulate path.  Per row the arithmetic is ONE chain:
+// init, + the ELL slots in slot order, + the row's COO entries in entry order.  Here a workgroup owns kHybTileRows
+// consecutive rows, one lane per row: the lane walks its ELL slots (as ell_row_kernel does), then the workgroup stages the
+// COO entries of ITS rows -- the plan's tile_start[] says which: entries [tile_start[t], tile_start[t+1]) -- through LDS
+// 256 at a time, marks where each row's run begins and ends, and every lane adds its run to the same accumulator in entry
+// order.  y is written once, with the bits of the host loops.  Bytes: ELL part + 16 per COO entry + 16 per row + 4 per tile.
+template <typename T, int POL, bool ACC>
+__global__ void __launch_bounds__(kHybTileRows)
+hyb_tile_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict__ eAj, const T *__restrict__ eAx,
+                const int *__restrict__ cAi, const int *__restrict__ cAj, const T *__restrict__ cAx,
+                const int32_t *__restrict__ tile_start, const T *__restrict__ x, T *__restrict__ y, int64_t tiles,
+                int64_t tiles_per_xcd, int swizzle)
+{
+    constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
+    constexpr int R = kHybTileRows;
+    __shared__ T prod[R];
+    __shared__ int lrow[R];
+    __shared__ int sbeg[R], send[R];
+    const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle);
+    if (tile >= tiles) return;
+    const int tid = threadIdx.x;
+    const int64_t row0 = tile * R, row = row0 + tid;
+    const bool live = row < num_rows;
+    const int cb = tile_start[tile], ce = tile_start[tile + 1];
+    // the first COO chunk's loads go out before the ELL walk (they do not depend on it)
+    int ci = 0, cj = 0;
+    T cv = T(0);
+    if (cb + tid < ce) {
+        ci = ld<NT>(cAi + cb + tid);
+        cj = ld<NT>(cAj + cb + tid);
+        cv = ld<NT>(cAx + cb + tid);
+    }
+    T cx = cb < ce ? x[cj] : T(0); // (lanes past the chunk gather x[0])
+    T acc = T(0);
+    if (live) {
+        if (ACC) acc = y[row];
+        auto chunk = [&](auto Kc, int n0) {
+            constexpr int K = decltype(Kc)::value;
+            int col[K];
+            T val[K], xv[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                col[k] = ld<NT>(eAj + (int64_t)(n0 + k) * pitch + row);
+                val[k] = ld<NT>(eAx + (int64_t)(n0 + k) * pitch + row);
+            }
+#pragma unroll
+            for (int k = 0; k < K; k++) xv[k] = x[col[k] < 0 ? 0 : col[k]];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if (col[k] != -1) acc = acc + val[k] * xv[k];
+        };
+        int n0 = 0;
+        for (; n0 + 8 <= width; n0 += 8) chunk(std::integral_constant<int, 8>(), n0);
+        if (n0 + 4 <= width) { chunk(std::integral_constant<int, 4>(), n0); n0 += 4; }
+        if (n0 + 2 <= width) { chunk(std::integral_constant<int, 2>(), n0); n0 += 2; }
+        if (n0 + 1 <= width) { chunk(std::integral_constant<int, 1>(), n0); }
+    }
+    for (int c0 = cb; c0 < ce; c0 += R) { // workgroup-uniform trip count
+        const int n = ce - c0 < R ? ce - c0 : R;
+        if (c0 != cb) {
+            __syncthreads(); // the previous chunk's runs have been added
+            if (tid < n) {
+                ci = ld<NT>(cAi + c0 + tid);
+                cj = ld<NT>(cAj + c0 + tid);
+                cv = ld<NT>(cAx + c0 + tid);
+                cx = x[cj];
+            }
+        }
+        const int r = ci - (int)row0; // 0 .. R-1: the plan's tile_start[] brackets exactly this tile's rows
+        sbeg[tid] = 0;
+        send[tid] = 0;
+        if (tid < n) {
+            prod[tid] = cv * cx;
+            lrow[tid] = r;
+        }
+        __syncthreads();
+        if (tid < n) {
+            if (tid == 0 || lrow[tid - 1] != r) sbeg[r] = tid;
+            if (tid == n - 1 || lrow[tid + 1] != r) send[r] = tid + 1;
+        }
+        __syncthreads();
+        const int a = sbeg[tid], b = send[tid];
+        acc = sum_in_order(acc, prod + a, b - a); // (rows without entries in this chunk: a == b == 0)
+    }
+    if (live) st<NTS>(y + row, acc);
+}
+
+// tile_start[t] = first COO entry whose row is >= t * kHybTileRows (entries sorted by row), t = 0 .. tiles
+__global__ void __launch_bounds__(256)
+hyb_tile_start_kernel(int64_t tiles, int coo_entries, const int *__restrict__ Ai, int32_t *__restrict__ tile_start)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > tiles) return;
+    const int64_t first_row = t * kHybTileRows;
+    int lo = 0, hi = coo_entries; // lower bound
+    while (lo < hi) {
+        const int mid = lo + (hi - lo) / 2;
+        if (Ai[mid] < first_row) lo = mid + 1; else hi = mid;
+    }
+    tile_start[t] = lo;
+}
+
+int hyb_tile_starts(int64_t rows, int64_t coo_entries, const int *coo_Ai, int32_t *tile_start, hipStream_t s)
+{
+    const int64_t tiles = ceil_div(rows, kHybTileRows);
+    hipLaunchKernelGGL(hyb_tile_start_kernel, dim3((unsigned)ceil_div(tiles + 1, 256)), dim3(256), 0, s, tiles, (int)coo_entries, coo_Ai, tile_start);
+    CMI_LAUNCH_CHECK("hyb tile starts");
+    return CMI_SUCCESS;
+}
+
+template <typename T>
+static int spmv_hyb_plan(const cmi_plan *plan, int dtype, int64_t pitch, const int *eAj, const T *eAx, const int *cAi,
+                         const int *cAj, const T *cAx, const T *x, T *y, int accumulate, void *stream)
+{
+    if (!plan || plan->format != CMI_FORMAT_HYB || plan->dtype != dtype)
+        return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_hyb_plan: null plan, or a plan made for another format or value type");
+    const int64_t rows = plan->rows, width = plan->hyb_width, coo = plan->hyb_coo;
+    if (!plan->hyb_tile_start) { // COO part empty or not sorted by row: the two launches of cmi_spmv_hyb_*
+        int st;
+        if constexpr (std::is_same<T, double>::value) st = cmi_spmv_ell_f64(rows, plan->cols, width, pitch, eAj, eAx, nullptr, x, y, accumulate, &plan->cfg, stream);
+        else st = cmi_spmv_ell_f32(rows, plan->cols, width, pitch, eAj, eAx, nullptr, x, y, accumulate, &plan->cfg, stream);
+        if (st || coo == 0) return st;
+        return spmv_coo<T>(dtype, rows, plan->cols, coo, cAi, cAj, cAx, x, y, 1, &plan->hyb_coo_cfg, stream);
+    }
+    if (rows == 0) return CMI_SUCCESS;
+    if (width > 0 && pitch < rows) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_hyb_plan: pitch < num_rows");
+    if (!y || !x || (width > 0 && (!eAj || !eAx)) || !cAi || !cAj || !cAx) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_hyb_plan: null array");
+    const int64_t tiles = ceil_div(rows, kHybTileRows);
+    const int swz = plan->cfg.xcd_swizzle < 0 ? 0 : plan->cfg.xcd_swizzle;
+    const int64_t tpx = ceil_div(tiles, kXcds);
+    const int64_t grid64 = padded_grid(tiles, swz);
+    if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_hyb_plan: grid too large");
+    hipStream_t s = as_stream(stream);
+    with_policy(plan->cfg.nontemporal & 3, [&](auto P) {
+        constexpr int POL = decltype(P)::value;
+        if (accumulate) hipLaunchKernelGGL((hyb_tile_kernel<T, POL, true>), dim3((unsigned)grid64), dim3(kHybTileRows), 0, s, rows, (int)width, pitch, eAj, eAx, cAi, cAj, cAx, plan->hyb_tile_start, x, y, tiles, tpx, swz);
+        else            hipLaunchKernelGGL((hyb_tile_kernel<T, POL, false>), dim3((unsigned)grid64), dim3(kHybTileRows), 0, s, rows, (int)width, pitch, eAj, eAx, cAi, cAj, cAx, plan->hyb_tile_start, x, y, tiles, tpx, swz);
+    });
+    CMI_LAUNCH_CHECK("hyb tile spmv");
+    return CMI_SUCCESS;
+}
+
 } // namespace cmi
 
 CMI_API int cmi_spmv_coo_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *Ai,
@@ -531,4 +679,19 @@ CMI_API int cmi_spmv_hyb_f32(int64_t num_rows, int64_t num_cols, int64_t ell_ent
     if (st) return st;
     if (coo_entries == 0) return CMI_SUCCESS;
     return cmi_spmv_coo_f32(num_rows, num_cols, coo_entries, coo_Ai, coo_Aj, coo_Ax, x, y, 1, cfg_coo, stream);
+}
+
+// HYB through a plan: one launch when the plan found the COO part sorted by row (hyb_tile_kernel: y written once, the host
+// loops' bits), else the two launches above with the plan's launch shapes.
+CMI_API int cmi_spmv_hyb_plan_f64(const cmi_plan *plan, int64_t ell_pitch, const int32_t *ell_Aj, const double *ell_Ax,
+                                  const int32_t *coo_Ai, const int32_t *coo_Aj, const double *coo_Ax, const double *x,
+                                  double *y, int accumulate, void *stream)
+{
+    return cmi::spmv_hyb_plan<double>(plan, CMI_F64, ell_pitch, ell_Aj, ell_Ax, coo_Ai, coo_Aj, coo_Ax, x, y, accumulate, stream);
+}
+CMI_API int cmi_spmv_hyb_plan_f32(const cmi_plan *plan, int64_t ell_pitch, const int32_t *ell_Aj, const float *ell_Ax,
+                                  const int32_t *coo_Ai, const int32_t *coo_Aj, const float *coo_Ax, const float *x,
+                                  float *y, int accumulate, void *stream)
+{
+    return cmi::spmv_hyb_plan<float>(plan, CMI_F32, ell_pitch, ell_Aj, ell_Ax, coo_Ai, coo_Aj, coo_Ax, x, y, accumulate, stream);
 }

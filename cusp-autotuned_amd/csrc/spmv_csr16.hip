@@ -1,0 +1,245 @@
+// spmv_csr16.hip -- CSR SpMV with the plan's 16-bit copy of the column indices (CMI_CSR_STREAM_C16, opt-in).
+//
+// csr_stream on the headline matrix runs at the rate the memory system delivers (profiles/r02_probe_*: a kernel that only
+// READS the same streams is no faster), so the only way left to make y = A x faster is to move fewer bytes.  Of CSR's
+// 12 nnz + 20 N bytes, 4 nnz are column indices -- and inside one row tile of a banded / FEM-ordered matrix they span a
+// few thousand columns, not 2^31.  A plan created with kernel = CMI_CSR_STREAM_C16 therefore keeps, on the device,
+//     tile_base[t] = smallest column index among the entries of tile t          (4 bytes per tile)
+//     Aj16[e]      = Aj[e] - tile_base[tile of e]   as uint16                     (2 bytes per entry)
+// and the multiply reads those instead of Aj: 10 nnz + 20 N bytes (headline matrix: 700 MB instead of 800 MB).  The
+// arithmetic is untouched -- same products, same storage-order sums, the bits of sequential/multiply/csr_spmv.h:56-73.
+// The reference has nothing comparable (its KTT path only re-blocks the same 32-bit arrays, cuda/ktt/kernels/csr_kernel.h).
+//
+// All or nothing, decided by cmi_plan_create: every tile must (a) span fewer than 65536 columns and (b) fit the single
+// LDS pass of csr_stream's fast path (one lane per row).  If any tile does not, the plan keeps CMI_CSR_STREAM and owns
+// nothing.  The kernel below is that fast path and only that.
+#include "common.h"
+
+namespace cmi {
+
+typedef unsigned short __attribute__((ext_vector_type(4))) ushort4v;
+
+// ---- plan time -------------------------------------------------------------------------------------------------------
+// one workgroup per tile: min / max column of the tile's entries, the single-pass test; then (second launch) the encoding
+__global__ void __launch_bounds__(256)
+csr16_scan_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ Aj, int rpb, int tile_entries,
+                  int32_t *__restrict__ tile_base, int *__restrict__ bad)
+{
+    __shared__ int smin[256 / kWave], smax[256 / kWave];
+    const int64_t r0 = (int64_t)blockIdx.x * rpb;
+    const int nr = (int)((num_rows - r0) < rpb ? (num_rows - r0) : rpb);
+    const int nz0 = Ap[r0], nz1 = Ap[r0 + nr];
+    int lo = INT32_MAX, hi = INT32_MIN;
+    for (int e = nz0 + (int)threadIdx.x; e < nz1; e += blockDim.x) {
+        const int c = Aj[e];
+        lo = c < lo ? c : lo;
+        hi = c > hi ? c : hi;
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        const int l2 = __shfl_down(lo, o), h2 = __shfl_down(hi, o);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) { smin[threadIdx.x / kWave] = lo; smax[threadIdx.x / kWave] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x / kWave); w++) {
+            lo = smin[w] < lo ? smin[w] : lo;
+            hi = smax[w] > hi ? smax[w] : hi;
+        }
+        const bool empty = nz1 <= nz0;
+        tile_base[blockIdx.x] = empty ? 0 : lo;
+        if (!empty && ((int64_t)hi - lo > 65535 || lo < 0)) atomicOr(bad, 1);
+        if (nz1 - (nz0 & ~3) > tile_entries) atomicOr(bad, 2); // would not fit one LDS pass
+    }
+}
+
+__global__ void __launch_bounds__(256)
+csr16_encode_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ Aj, int rpb,
+                    const int32_t *__restrict__ tile_base, uint16_t *__restrict__ Aj16)
+{
+    const int64_t r0 = (int64_t)blockIdx.x * rpb;
+    const int nr = (int)((num_rows - r0) < rpb ? (num_rows - r0) : rpb);
+    const int nz0 = Ap[r0], nz1 = Ap[r0 + nr], base = tile_base[blockIdx.x];
+    for (int e = nz0 + (int)threadIdx.x; e < nz1; e += blockDim.x) Aj16[e] = (uint16_t)(Aj[e] - base);
+}
+
+// Tries to give `p` (a CSR plan whose cfg is a completed CMI_CSR_STREAM shape) the 16-bit copy.  On success p->cfg.kernel
+// becomes CMI_CSR_STREAM_C16 and the plan owns csr16_cols / csr16_base; otherwise nothing changes.  Synchronises `s`.
+int csr16_build(cmi_plan *p, const int *Ap, const int *Aj, hipStream_t s)
+{
+    const cmi_config &c = p->cfg;
+    const int64_t rows = p->rows, nnz = p->nnz;
+    if (c.kernel != CMI_CSR_STREAM || c.threads_per_row > 1 || rows <= 0 || nnz < 4 || nnz > INT32_MAX - 65536) return CMI_SUCCESS;
+    const int rpb = c.rows_per_block, block = c.block_size, ipt = c.items_per_thread;
+    if (rpb < 1 || rpb > block) return CMI_SUCCESS; // the single-pass kernel gives every row its own lane
+    const int64_t tiles = ceil_div(rows, rpb);
+    if (tiles > INT32_MAX) return CMI_SUCCESS;
+    int32_t *base = nullptr;
+    uint16_t *cols16 = nullptr;
+    int *flag = nullptr;
+    int host = 1;
+    hipError_t e = hipMalloc((void **)&base, (size_t)tiles * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&flag, sizeof(int));
+    if (e == hipSuccess) e = hipMemsetAsync(flag, 0, sizeof(int), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(csr16_scan_kernel, dim3((unsigned)tiles), dim3(256), 0, s, rows, Ap, Aj, rpb, block * ipt * 4, base, flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&host, flag, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess && host == 0) {
+        // (nnz rounded up to whole 8-byte vectors + one: the kernel's last vector load stays inside the allocation)
+        e = hipMalloc((void **)&cols16, ((size_t)nnz + 8) * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMemsetAsync(cols16, 0, ((size_t)nnz + 8) * sizeof(uint16_t), s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(csr16_encode_kernel, dim3((unsigned)tiles), dim3(256), 0, s, rows, Ap, Aj, rpb, base, cols16);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    if (flag) (void)hipFree(flag);
+    if (e != hipSuccess || host != 0) {
+        if (base) (void)hipFree(base);
+        if (cols16) (void)hipFree(cols16);
+        return e != hipSuccess ? hip_fail(e, "cmi_plan_create: 16-bit column copy") : (int)CMI_SUCCESS;
+    }
+    p->csr16_base = base;
+    p->csr16_cols = cols16;
+    p->cfg.kernel = CMI_CSR_STREAM_C16;
+    return CMI_SUCCESS;
+}
+
+// ---- the multiply ----------------------------------------------------------------------------------------------------
+// csr_stream's single-pass path (spmv_csr.hip): tile bounds from two uniform loads, every lane its own row's two offsets,
+// IPT index / value vectors per lane requested at once, products parked in LDS, one lane per row adds them in storage
+// order.  The index vector is 8 bytes (four uint16) instead of 16; column = tile_base + offset, clamped into [0, cols)
+// because the first vector of a tile may begin with up to three entries of the tile before it (encoded against THAT
+// tile's base; their products are parked and never read, but the gather must stay inside x).
+template <typename T, int IPT, int POL, bool DOT>
+__global__ void __launch_bounds__(1024)
+csr_stream16_kernel(int64_t num_rows, int64_t num_entries, int num_cols, const int *__restrict__ Ap,
+                    const uint16_t *__restrict__ Aj16, const int32_t *__restrict__ tile_base, const T *__restrict__ Ax,
+                    const T *__restrict__ x, T *__restrict__ y, int rows_per_block, int64_t num_tiles, int64_t tiles_per_xcd,
+                    int swizzle, int accumulate, const T *__restrict__ w, double *__restrict__ dot_partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double dot_slots[DOT ? 1024 / kWave : 1];
+    constexpr bool NT = (POL & kPolLoadNT) != 0;
+    const int block = blockDim.x, tid = threadIdx.x;
+    T *prod = reinterpret_cast<T *>(smem);
+    const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle);
+    if (tile >= num_tiles) return;
+    const int64_t r0 = tile * rows_per_block;
+    const int nr = (int)((num_rows - r0) < rows_per_block ? (num_rows - r0) : rows_per_block);
+    const int nz0 = Ap[r0], nz1 = Ap[r0 + nr], base = tile_base[tile];
+    const int fbase = nz0 & ~3;
+    const int a = Ap[r0 + (tid < nr ? tid : nr)], b = Ap[r0 + (tid + 1 < nr ? tid + 1 : nr)];
+    const int cmax = num_cols - 1;
+    int c[IPT][4];
+    T v[IPT][4];
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+        const int e = fbase + (k * block + tid) * 4;
+        if (e < nz1) {
+            const ushort4v u = ld<NT>(reinterpret_cast<const ushort4v *>(Aj16 + e)); // (allocation padded: always inside)
+            c[k][0] = base + (int)u.x; c[k][1] = base + (int)u.y; c[k][2] = base + (int)u.z; c[k][3] = base + (int)u.w;
+            if ((int64_t)e + 4 <= num_entries) {
+                if constexpr (sizeof(T) == 8) {
+                    const double2v v01 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e));
+                    const double2v v23 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e + 2));
+                    v[k][0] = v01.x; v[k][1] = v01.y; v[k][2] = v23.x; v[k][3] = v23.y;
+                } else {
+                    const float4v vv = ld<NT>(reinterpret_cast<const float4v *>(Ax + e));
+                    v[k][0] = vv.x; v[k][1] = vv.y; v[k][2] = vv.z; v[k][3] = vv.w;
+                }
+            } else { // the arrays' last, partial vector
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[k][i] = (int64_t)e + i < num_entries ? Ax[e + i] : T(0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { c[k][i] = 0; v[k][i] = T(0); }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+        const int slot = (k * block + tid) * 4;
+        if (fbase + slot < nz1) {
+            T xv[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int col = c[k][i];
+                col = col > cmax ? cmax : col; // (base >= 0 and the offset is unsigned: never negative)
+                xv[i] = x[col];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) prod[slot + i] = v[k][i] * xv[i];
+        }
+    }
+    T wv = T(0);
+    if constexpr (DOT) { if (tid < nr) wv = w[r0 + tid]; }
+    __syncthreads();
+    double d = 0.0;
+    if (tid < nr) {
+        T s = accumulate ? y[r0 + tid] : T(0);
+        if constexpr (IPT == 1) { for (int j = a; j < b; j++) s = s + prod[j - fbase]; }
+        else s = sum_in_order(s, prod + (a - fbase), b - a);
+        st<(POL & kPolStoreNT) != 0>(y + r0 + tid, s);
+        if constexpr (DOT) d = (double)s * (double)wv;
+    }
+    if constexpr (DOT) {
+        tile_dot_store(d, dot_slots, dot_partial + tile);
+        if (tile == 0 && tid == 0) *ticket_of(dot_partial) = 0;
+    }
+}
+
+template <typename T>
+static int csr16_multiply(const cmi_plan *p, const int *Ap, const T *Ax, const T *x, T *y, int accumulate, hipStream_t s,
+                          const T *w, double *dot_partial, int *dot_partials)
+{
+    const cmi_config &c = p->cfg;
+    const int block = c.block_size, ipt = c.items_per_thread, rpb = c.rows_per_block;
+    const int64_t rows = p->rows, nnz = p->nnz;
+    const int64_t tiles = ceil_div(rows, rpb);
+    const int64_t tpx = ceil_div(tiles, kXcds);
+    const int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
+    const int64_t grid64 = padded_grid(tiles, swz);
+    if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream_c16: grid too large");
+    const size_t lds = (size_t)block * ipt * 4 * sizeof(T);
+    if (lds > 160 * 1024) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream_c16: tile does not fit 160 KiB of LDS");
+    const bool dot = w && dot_partial && tiles <= kPartialCapacity;
+    int st = CMI_SUCCESS;
+    with_policy(c.nontemporal & 3, [&](auto P) {
+        constexpr int POL = decltype(P)::value;
+        auto go = [&](auto I) {
+            constexpr int IPT = decltype(I)::value;
+            if (dot) hipLaunchKernelGGL((csr_stream16_kernel<T, IPT, POL, true>), dim3((unsigned)grid64), dim3(block), lds, s, rows, nnz, (int)p->cols, Ap, p->csr16_cols, p->csr16_base, Ax, x, y, rpb, tiles, tpx, swz, accumulate, w, dot_partial);
+            else     hipLaunchKernelGGL((csr_stream16_kernel<T, IPT, POL, false>), dim3((unsigned)grid64), dim3(block), lds, s, rows, nnz, (int)p->cols, Ap, p->csr16_cols, p->csr16_base, Ax, x, y, rpb, tiles, tpx, swz, accumulate, (const T *)nullptr, (double *)nullptr);
+        };
+        switch (ipt) {
+        case 1: go(std::integral_constant<int, 1>()); break;
+        case 2: go(std::integral_constant<int, 2>()); break;
+        case 4: go(std::integral_constant<int, 4>()); break;
+        default: st = fail(CMI_ERROR_NOT_SUPPORTED, "csr_stream_c16: items_per_thread must be 1, 2 or 4"); break;
+        }
+    });
+    if (st) return st;
+    CMI_LAUNCH_CHECK("csr_stream_c16 spmv");
+    if (dot && dot_partials) *dot_partials = (int)tiles;
+    return CMI_SUCCESS;
+}
+
+int csr16_multiply_f64(const cmi_plan *p, const int *Ap, const double *Ax, const double *x, double *y, int accumulate,
+                       hipStream_t s, const double *w, double *dot_partial, int *dot_partials)
+{
+    return csr16_multiply<double>(p, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials);
+}
+int csr16_multiply_f32(const cmi_plan *p, const int *Ap, const float *Ax, const float *x, float *y, int accumulate,
+                       hipStream_t s, const float *w, double *dot_partial, int *dot_partials)
+{
+    return csr16_multiply<float>(p, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials);
+}
+
+} // namespace cmi

@@ -128,6 +128,77 @@ ell_row_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// ELL: S lanes per row ("slices") -- few rows, wide rows
+// ---------------------------------------------------------------------------------------------
+// One lane per row leaves the chip idle when the matrix has fewer rows than the chip has lanes (256 CUs x 8 waves x 64 =
+// 131 072) and makes every lane walk `width` dependent chunks.  Here a workgroup owns R = blockDim.x / S consecutive rows
+// and thread (ri = tid % R, s = tid / R) takes the slots s, s + S, s + 2S, ... of row ri: lanes that are neighbours in a
+// wave are neighbours in a COLUMN of the column-major arrays (whole waves for R >= 64, 128-byte runs for R = 16), the
+// partial sums meet in LDS and lane s = 0 adds them in slice order.  Replaces the THREADS_PER_ROW parameter of
+// cusp/system/cuda/ktt/kernels/ell_kernel.h:102-109,165-173 (there: threadIdx.y and an LDS atomicAdd, so a row's sum order
+// changes from run to run; here it is fixed, but it is not the storage order: 1e-6 class like csr_vector).
+template <typename T, int S, bool ELLR, int POL>
+__global__ void __launch_bounds__(1024)
+ell_slices_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict__ Aj, const T *__restrict__ Ax,
+                  const int *__restrict__ row_lengths, const T *__restrict__ x, T *__restrict__ y, int accumulate)
+{
+    constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
+    __shared__ T part[1024];
+    const int R = blockDim.x / S;
+    const int ri = threadIdx.x % R, s = threadIdx.x / R;
+    const int64_t row = (int64_t)blockIdx.x * R + ri;
+    const bool live = row < num_rows;
+    T acc = T(0);
+    if (live) {
+        const int len = ELLR ? row_lengths[row] : width;
+        auto chunk = [&](auto Kc, int n0) { // slots n0, n0 + S, ...: every load issued before the first add
+            constexpr int K = decltype(Kc)::value;
+            int col[K];
+            T val[K], xv[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                col[k] = ld<NT>(Aj + (int64_t)(n0 + k * S) * pitch + row);
+                val[k] = ld<NT>(Ax + (int64_t)(n0 + k * S) * pitch + row);
+            }
+#pragma unroll
+            for (int k = 0; k < K; k++) xv[k] = x[col[k] < 0 ? 0 : col[k]];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if (ELLR ? (n0 + k * S < len) : (col[k] != -1)) acc = acc + val[k] * xv[k];
+        };
+        const int bound = ELLR ? len : width; // ELLR: slots past the row's length are never read
+        int n = s;
+        for (; n + 3 * S < bound; n += 4 * S) chunk(std::integral_constant<int, 4>(), n);
+        for (; n < bound; n += S) chunk(std::integral_constant<int, 1>(), n);
+    }
+    part[s * R + ri] = acc;
+    __syncthreads();
+    if (s == 0 && live) {
+        T sum = accumulate ? y[row] : T(0);
+#pragma unroll
+        for (int k = 0; k < S; k++) sum = sum + part[k * R + ri];
+        st<NTS>(y + row, sum);
+    }
+}
+
+// lanes per row for an ELL multiply: an explicit config.threads_per_row (1 = the row kernel, storage-order sums), else
+// slices only where one lane per row cannot fill the chip and rows are wide enough to split
+int ell_lanes_per_row(const cmi_config &c, int64_t rows, int64_t width)
+{
+    int t = c.threads_per_row;
+    if (t <= 0) {
+        t = 1;
+        while (t < 16 && (int64_t)t * 2 * kEllSliceMinSlots <= width) t *= 2;
+        if (t == 1 || rows >= (t == 2 ? kEllSliceMaxRows2 : kEllSliceMaxRows)) return 1;
+    }
+    int p = 1;
+    while (p < t && p < 16) p <<= 1;
+    while (p > 1 && p > width) p >>= 1;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
 // DIA: one lane per row, diagonal offsets staged through LDS in chunks
 // ---------------------------------------------------------------------------------------------
 // Same memory-level-parallelism scheme as ELL: U diagonals at a time, all value loads and all x
@@ -285,6 +356,29 @@ static int spmv_ell(int dtype, int64_t rows, int64_t cols, int64_t width, int64_
     // a fused dot leaves one partial per workgroup: widen the workgroups until they fit the workspace
     if (wdot && dot_partial)
         while (block < 1024 && ceil_div(rows, (int64_t)block * rpl) > kPartialCapacity) block *= 2;
+    const int lanes = ell_lanes_per_row(c, rows, width);
+    if (lanes > 1) { // (a fused dot falls back to the separate dot: *dot_partials stays 0)
+        const int R = block / lanes;
+        const int64_t g64 = ceil_div(rows, (int64_t)R);
+        if (g64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_ell: grid too large");
+        const int g = (int)g64, wd = (int)width;
+        with_policy(pol, [&](auto P) {
+            constexpr int POL = decltype(P)::value;
+            auto go = [&](auto Sc) {
+                constexpr int S = decltype(Sc)::value;
+                if (ellr) hipLaunchKernelGGL((ell_slices_kernel<T, S, true, POL>), dim3(g), dim3(block), 0, s, rows, wd, pitch, Aj, Ax, row_lengths, x, y, accumulate);
+                else      hipLaunchKernelGGL((ell_slices_kernel<T, S, false, POL>), dim3(g), dim3(block), 0, s, rows, wd, pitch, Aj, Ax, row_lengths, x, y, accumulate);
+            };
+            switch (lanes) {
+            case 2: go(std::integral_constant<int, 2>()); break;
+            case 4: go(std::integral_constant<int, 4>()); break;
+            case 8: go(std::integral_constant<int, 8>()); break;
+            default: go(std::integral_constant<int, 16>()); break;
+            }
+        });
+        CMI_LAUNCH_CHECK("ell slices spmv");
+        return CMI_SUCCESS;
+    }
     const int64_t tiles = ceil_div(rows, (int64_t)block * rpl); // one-shot grid (see spmv_csr.hip grid_for), padded to chunk rounds
     const int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
     const int64_t tpx = ceil_div(tiles, kXcds);

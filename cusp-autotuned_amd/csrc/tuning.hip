@@ -320,6 +320,7 @@ void select_config(int format, int dtype, int64_t rows, int64_t cols, int64_t nn
                 const double tuned_mean = g_table.mean[format][dtype][b];
                 const bool one_row_per_lane = out->rows_per_block <= blk / tpr; // the tuned shape's regime: keep it
                 if (tuned_mean > 0.0) want = std::floor(want * tuned_mean / mean + 0.5);
+                if (want >= 32.0) want = std::floor(want / 16.0 + 0.5) * 16.0; // whole y lines, nearest (keeps the tuned fill)
                 if (want > fit) want = fit;
                 if (one_row_per_lane && want > (double)(blk / tpr)) want = (double)(blk / tpr);
                 if (want >= 32.0) want = std::floor(want / 16.0) * 16.0;
@@ -404,6 +405,8 @@ CMI_API int cmi_tuning_set(int format, int dtype, double mean_entries_per_row, c
         return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_set: bad format/dtype/config");
     if (format == CMI_FORMAT_COO && cfg->kernel == CMI_COO_TILE) // a plan-less multiply runs this key on entries in ANY order
         return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_set: CMI_COO_TILE needs row-sorted entries: it belongs under CMI_TABLE_COO_SORTED");
+    if (cfg->kernel == CMI_CSR_STREAM_C16) // needs a plan's 16-bit copy: a plan-less multiply could not run it
+        return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_set: CMI_CSR_STREAM_C16 is asked for per plan (cmi_plan_create_csr), not per table entry");
     std::lock_guard<std::mutex> lk(g_mu);
     ensure_default_loaded(); // explicit entries layer ON TOP of the shipped table: a later AUTO multiply must not reload over them
     const int b = bucket_of(mean_entries_per_row);

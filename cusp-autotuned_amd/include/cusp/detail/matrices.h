@@ -47,16 +47,41 @@ public:
 // cusp/system/cuda/ktt/csr_multiply.h:239-247).
 struct plan_slot {
     std::shared_ptr<cmi_plan> plan;
-    const void *index_ptr = nullptr;
+    const void *index_ptr = nullptr, *columns_ptr = nullptr;
     size_t rows = 0, cols = 0, entries = 0;
-    void reset() { plan.reset(); index_ptr = nullptr; }
-    const cmi_plan *get(int format, int dtype, size_t r, size_t c, size_t n, const int *index, void *stream)
+    int compress = -1; // CSR: -1 follow cmi_set_index_compression / $CMI_COMPRESS_INDICES, 0 never, 1 ask for CMI_CSR_STREAM_C16
+    void reset() { plan.reset(); index_ptr = nullptr; columns_ptr = nullptr; }
+    // `columns`: CSR only -- with them the plan may hold the 16-bit column copy (cmi_plan_create_csr)
+    const cmi_plan *get(int format, int dtype, size_t r, size_t c, size_t n, const int *index, void *stream, const int *columns = nullptr)
     {
-        if (!plan || index_ptr != index || rows != r || cols != c || entries != n) {
+        if (!plan || index_ptr != index || columns_ptr != columns || rows != r || cols != c || entries != n) {
             cmi_plan *p = nullptr;
-            check(cmi_plan_create(format, dtype, (int64_t)r, (int64_t)c, (int64_t)n, index, nullptr, stream, &p));
+            if (format == CMI_FORMAT_CSR && columns && compress != 0) {
+                cmi_config want = {};
+                want.kernel = CMI_CSR_STREAM_C16;
+                check(cmi_plan_create_csr(dtype, (int64_t)r, (int64_t)c, (int64_t)n, index, columns, compress == 1 ? &want : nullptr, stream, &p));
+            } else
+                check(cmi_plan_create(format, dtype, (int64_t)r, (int64_t)c, (int64_t)n, index, nullptr, stream, &p));
             plan.reset(p, [](cmi_plan *q) { cmi_plan_destroy(q); });
-            index_ptr = index; rows = r; cols = c; entries = n;
+            index_ptr = index; columns_ptr = columns; rows = r; cols = c; entries = n;
+        }
+        return plan.get();
+    }
+};
+// The same for a HYB matrix (cmi_plan_create_hyb): keyed by the COO part's row indices; with that part sorted by row the
+// plan holds the per-tile entry ranges of the one-launch HYB kernel.
+struct hyb_plan_slot {
+    std::shared_ptr<cmi_plan> plan;
+    const void *index_ptr = nullptr;
+    size_t rows = 0, cols = 0, width = 0, coo = 0;
+    void reset() { plan.reset(); index_ptr = nullptr; }
+    const cmi_plan *get(int dtype, size_t r, size_t c, size_t w, size_t n, const int *index, void *stream)
+    {
+        if (!plan || index_ptr != index || rows != r || cols != c || width != w || coo != n) {
+            cmi_plan *p = nullptr;
+            check(cmi_plan_create_hyb(dtype, (int64_t)r, (int64_t)c, (int64_t)w, (int64_t)n, index, nullptr, nullptr, stream, &p));
+            plan.reset(p, [](cmi_plan *q) { cmi_plan_destroy(q); });
+            index_ptr = index; rows = r; cols = c; width = w; coo = n;
         }
         return plan.get();
     }
@@ -116,9 +141,13 @@ public:
     const cmi_plan *plan(void *stream = nullptr) const
     {
         return plan_.get(CMI_FORMAT_CSR, detail::dtype_code<ValueType>::value, this->num_rows, this->num_cols, this->num_entries,
-                         reinterpret_cast<const int *>(row_offsets.data()), stream);
+                         reinterpret_cast<const int *>(row_offsets.data()), stream, reinterpret_cast<const int *>(column_indices.data()));
     }
     void invalidate_plan() const { plan_.reset(); }
+    // Opt in to (or out of) the plan's 16-bit copy of the column indices for THIS matrix (CMI_CSR_STREAM_C16: 2 bytes per
+    // entry of extra HBM, 10 instead of 12 bytes per entry read by every multiply, same bits); granted only when every row
+    // tile spans < 65536 columns -- cmi_plan_config(A.plan()) tells.  Without a call the process-wide default applies.
+    void compress_indices(bool on) const { plan_.compress = on ? 1 : 0; plan_.reset(); }
 private:
     mutable detail::plan_slot plan_;
 };
@@ -411,8 +440,19 @@ public:
         Parent::resize(rows, cols, ell_entries + coo_entries);
         ell.resize(rows, cols, ell_entries, entries_per_row, alignment);
         coo.resize(rows, cols, coo_entries);
+        plan_.reset();
     }
-    void swap(hyb_matrix &o) { Parent::swap(o); ell.swap(o.ell); coo.swap(o.coo); }
+    void swap(hyb_matrix &o) { Parent::swap(o); ell.swap(o.ell); coo.swap(o.coo); std::swap(plan_, o.plan_); }
+
+    // device_memory: the engine's plan (detail::hyb_plan_slot) -- COO part sorted by row: cusp::multiply is ONE launch
+    const cmi_plan *plan(void *stream = nullptr) const
+    {
+        return plan_.get(detail::dtype_code<ValueType>::value, this->num_rows, this->num_cols, ell.column_indices.num_cols,
+                         coo.num_entries, coo.row_indices.data(), stream);
+    }
+    void invalidate_plan() const { plan_.reset(); }
+private:
+    mutable detail::hyb_plan_slot plan_;
 };
 
 template <typename I, typename V, typename M>

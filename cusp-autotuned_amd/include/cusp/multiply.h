@@ -163,6 +163,11 @@ inline int spmv_coo_plan(const cmi_plan *p, const int *Ai, const int *Aj, const 
 inline int spmv_coo_plan(const cmi_plan *p, const int *Ai, const int *Aj, const float *Ax, const float *x, float *y, int acc, void *s)
 { return cmi_spmv_coo_plan_f32(p, Ai, Aj, Ax, x, y, acc, s); }
 
+inline int spmv_hyb_plan(const cmi_plan *p, size_t pitch, const int *eAj, const double *eAx, const int *Ai, const int *Aj, const double *Ax, const double *x, double *y, int acc, void *s)
+{ return cmi_spmv_hyb_plan_f64(p, (int64_t)pitch, eAj, eAx, Ai, Aj, Ax, x, y, acc, s); }
+inline int spmv_hyb_plan(const cmi_plan *p, size_t pitch, const int *eAj, const float *eAx, const int *Ai, const int *Aj, const float *Ax, const float *x, float *y, int acc, void *s)
+{ return cmi_spmv_hyb_plan_f32(p, (int64_t)pitch, eAj, eAx, Ai, Aj, Ax, x, y, acc, s); }
+
 // the container's plan (views, and anything while cusp::ktt::tune forces a configuration: none)
 template <typename A> auto plan_of(const A &a, void *stream, int) -> decltype(a.plan(stream))
 {
@@ -213,10 +218,10 @@ template <typename A, typename X, typename Y> void device_multiply(const A &a, c
 template <typename A, typename X, typename Y> void device_multiply(const A &a, const X &x, Y &y, int acc, void *stream, hyb_format)
 {
     require_int_index<A>();
-    if (const cmi_plan *p = plan_of(a.coo, stream, 0)) { // the COO part through its plan (kept sorted by row: tile kernel, no atomics)
-        check(spmv_ell(a.num_rows, a.num_cols, a.ell.column_indices.num_cols, a.ell.column_indices.pitch, data_of(a.ell.column_indices),
-                       data_of(a.ell.values), nullptr, x.data(), y.data(), acc, stream));
-        check(spmv_coo_plan(p, a.coo.row_indices.data(), a.coo.column_indices.data(), a.coo.values.data(), x.data(), y.data(), 1, stream));
+    if (a.ell.column_indices.pitch != a.ell.values.pitch) throw cusp::invalid_input_exception("hyb_matrix: ell.column_indices.pitch != ell.values.pitch");
+    if (const cmi_plan *p = plan_of(a, stream, 0)) { // COO part sorted by row (every conversion's output): one launch, y written once
+        check(spmv_hyb_plan(p, a.ell.column_indices.pitch, data_of(a.ell.column_indices), data_of(a.ell.values), a.coo.row_indices.data(),
+                            a.coo.column_indices.data(), a.coo.values.data(), x.data(), y.data(), acc, stream));
         return;
     }
     check(spmv_hyb(a.num_rows, a.num_cols, a.ell.column_indices.num_cols, a.ell.column_indices.pitch, data_of(a.ell.column_indices), data_of(a.ell.values),

@@ -49,8 +49,24 @@ class CsrMatrix(_Planned):
     values: object
     format = "csr"
 
-    def plan(self, stream=None, create=True):
-        return self._plan_for(B.FORMAT_CSR, self.row_offsets, stream, create)
+    def plan(self, stream=None, create=True, compress=None):
+        """compress=True asks for the 16-bit column copy (CSR_STREAM_C16; granted only if every tile qualifies -- see
+        plan().config().kernel); None follows set_index_compression()."""
+        if compress is not None:
+            self._compress = bool(compress)  # sticky: later multiplies of this matrix keep the choice
+        compress = getattr(self, "_compress", None)
+        key = (self.row_offsets.data_ptr(), self.column_indices.data_ptr(), self.num_rows, self.num_cols, self.num_entries,
+               self.values.dtype, compress if compress is not None else B.get_index_compression())
+        if self._plan_key != key:
+            if not create:
+                return None
+            cfg = B.Config(kernel=B.CSR_STREAM_C16) if compress else None
+            if compress is False and B.get_index_compression():
+                self._plan = B.Plan(B.FORMAT_CSR, self.values.dtype, self.num_rows, self.num_cols, self.num_entries, self.row_offsets, None, stream)
+            else:
+                self._plan = B.Plan.csr(self.values.dtype, self.num_rows, self.num_cols, self.row_offsets, self.column_indices, cfg, stream)
+            self._plan_key = key
+        return self._plan
 
 
 @dataclass
@@ -99,13 +115,30 @@ class DiaMatrix:
 
 @dataclass
 class HybMatrix:
-    """reference cusp/hyb_matrix.h:142-246: ell + coo parts."""
+    """reference cusp/hyb_matrix.h:142-246: ell + coo parts.  Owns a HYB plan (binding.Plan.hyb): with the COO part sorted by
+    row -- what every conversion produces -- the whole multiply is one launch."""
     num_rows: int
     num_cols: int
     num_entries: int
     ell: EllMatrix
     coo: CooMatrix
     format = "hyb"
+    _plan = None
+    _plan_key = None
+
+    def plan(self, stream=None, create=True):
+        e, c = self.ell, self.coo
+        key = (c.row_indices.data_ptr(), self.num_rows, self.num_cols, e.num_entries_per_row, c.num_entries, e.values.dtype)
+        if self._plan_key != key:
+            if not create:
+                return None
+            self._plan = B.Plan.hyb(e.values.dtype, self.num_rows, self.num_cols, e.num_entries_per_row, c.row_indices, stream=stream)
+            self._plan_key = key
+        return self._plan
+
+    def invalidate(self):
+        self._plan_key = None
+        self._plan = None
 
 
 def _capturing(stream):
@@ -118,7 +151,7 @@ def _capturing(stream):
 
 def multiply(A, x, y, accumulate=False, cfg=None, stream=None):
     """y = A*x (or y += A*x).  Mirrors the 3-argument cusp::multiply (cusp/multiply.h:40).  Without an explicit config
-    CSR and COO matrices multiply through their plan (made once, at the first such call; not while a stream capture is
+    CSR, COO and HYB matrices multiply through their plan (made once, at the first such call; not while a stream capture is
     recording -- then the plan-less entry point runs the table's kernel)."""
     plan = None
     if isinstance(A, (CsrMatrix, CooMatrix)) and cfg is None and A.num_entries > 0:
@@ -139,12 +172,11 @@ def multiply(A, x, y, accumulate=False, cfg=None, stream=None):
                    accumulate, cfg, stream)
     elif isinstance(A, HybMatrix):
         e, c = A.ell, A.coo
-        if cfg is None and c.num_entries > 0 and c.plan(stream, create=not _capturing(stream)) is not None:
-            # the two launches of cmi_spmv_hyb_* issued here so that the COO part runs through ITS plan (hyb_matrix keeps
-            # that part sorted by row: the tile kernel, no atomics): ELL with the caller's accumulate, COO on top
-            B.spmv_ell(A.num_rows, A.num_cols, e.num_entries_per_row, e.pitch, e.column_indices, e.values, x, y, None, accumulate,
-                       None, stream)
-            B.spmv_coo_plan(c.plan(stream), c.row_indices, c.column_indices, c.values, x, y, True, stream)
+        hplan = A.plan(stream, create=not _capturing(stream)) if cfg is None and c.num_entries > 0 else None
+        if hplan is not None:
+            # COO part sorted by row (what the conversions produce): ONE launch, y written once, the host loops' bits
+            B.spmv_hyb_plan(hplan, e.pitch, e.column_indices, e.values, c.row_indices, c.column_indices, c.values, x, y,
+                            accumulate, stream)
         else:
             B.spmv_hyb(A.num_rows, A.num_cols, e.num_entries_per_row, e.pitch, e.column_indices, e.values,
                        c.row_indices, c.column_indices, c.values, x, y, accumulate, cfg, None, stream)

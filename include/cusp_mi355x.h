@@ -139,8 +139,18 @@ typedef enum cmi_kernel {
                                csr_kernel_balanced (cuda/ktt/kernels/csr_kernel.h:316-375); block_size 512 (fixed);
                                items_per_thread = consecutive tiles per workgroup (0: 4), blocks_per_cu > 0:
                                persistent grid of CUs*blocks_per_cu workgroups instead              */
+    CMI_CSR_STREAM_C16 = 6, /* OPT-IN, plans of cmi_plan_create_csr only: csr_stream's single-pass tile kernel reading a
+                               16-bit copy of the column indices that the plan builds and owns (per tile: smallest column
+                               + uint16 offsets; 2 bytes per entry of extra HBM) -- 10 nnz + 20 N bytes per multiply
+                               instead of 12 nnz + 20 N, same products, same storage-order sums, same bits.  Granted only
+                               if EVERY tile spans < 65536 columns and fits one LDS pass; otherwise the plan's config says
+                               CMI_CSR_STREAM and nothing is built.  config fields: csr_stream's (0 = the table's)      */
     /* ELL */
-    CMI_ELL_ROW = 10, /* one lane per row            (ref: ell_spmv.h:55-93)                     */
+    CMI_ELL_ROW = 10, /* one lane per row            (ref: ell_spmv.h:55-93); threads_per_row 2,4,8,16: that many
+                         lanes per row, each summing every 2nd / 4th / ... slot (ref: THREADS_PER_ROW of ktt
+                         kernels/ell_kernel.h:102-109,165-173) -- re-associated sums, <= 1e-6; threads_per_row 0
+                         picks width/16 lanes (<= 16) for matrices >= 32 slots wide with < 131072 rows (>= 64 wide:
+                         < 524288 rows): 6x on 2000 x 512, 1.2x on 200000 x 64; threads_per_row 1 never          */
     /* DIA */
     CMI_DIA_ROW = 20, /* one lane per row, offsets in LDS (ref: dia_spmv.h:69-126)               */
     /* COO */
@@ -160,7 +170,8 @@ typedef struct cmi_config {
     int32_t kernel;           /* cmi_kernel; CMI_KERNEL_AUTO = pick by heuristics                  */
     int32_t block_size;       /* threads per workgroup: 64..1024, multiple of 64; 0 = default      */
     int32_t threads_per_row;  /* CSR vector: 2,4,8,16,32,64; 0 = from mean row length.  CSR stream: lanes per
-                                 row in the row-sum phase (0, 1, 2..64: see CMI_CSR_STREAM)                */
+                                 row in the row-sum phase (0, 1, 2..64: see CMI_CSR_STREAM).  ELL: lanes per
+                                 row (0 = auto, 1, 2..16: see CMI_ELL_ROW)                                  */
     int32_t rows_per_block;   /* CSR stream: rows per workgroup tile; 0 = from mean row length     */
     int32_t items_per_thread; /* CSR stream: 16-byte index vectors per lane per pass (1,2,4);
                                  ELL/DIA: rows per lane (1,2); COO: entries per lane; 0 = default   */
@@ -219,7 +230,7 @@ int cmi_hyb_entries_per_row(int dtype, int64_t num_rows, const int32_t *Ap, int 
 /* and recomputes `row_starts` on the host per call.                               */
 /*   cmi_plan_create reads the index array on the device and SYNCHRONISES `stream`  */
 /*   (one small kernel + a 16-byte read-back); everything after it is asynchronous.  */
-/*   A plan owns no device memory and does not keep the pointers: the arrays are     */
+/*   A plan (HYB's aside) owns no device memory and does not keep the pointers: arrays are */
 /*   passed again at every multiply; they must be the ones the plan was made for     */
 /*   (same sizes are checked; contents are the caller's promise -- a plan made for    */
 /*   other contents can cost speed or, for COO, give wrong sums: make a new plan      */
@@ -231,6 +242,20 @@ typedef struct cmi_plan cmi_plan;
 /* (num_rows * width or * diagonals) for ELL / DIA -- what the tuning table is keyed by.  cfg may be NULL. */
 int cmi_plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
                     const int32_t *index_array, const cmi_config *cfg, void *stream, cmi_plan **plan);
+/* CSR with both structure arrays: cmi_plan_create(CMI_FORMAT_CSR, ...) plus, when asked for, the 16-bit column copy  */
+/* of CMI_CSR_STREAM_C16 -- asked for by cfg->kernel == CMI_CSR_STREAM_C16, or for every AUTO-kernel plan after             */
+/* cmi_set_index_compression(1) (initial value: $CMI_COMPRESS_INDICES).  cmi_plan_config tells whether it was granted.      */
+int cmi_plan_create_csr(int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *row_offsets,
+                        const int32_t *column_indices, const cmi_config *cfg, void *stream, cmi_plan **plan);
+int cmi_set_index_compression(int on);
+int cmi_get_index_compression(void);
+/* HYB: launch shapes of both parts (cfg_* may be NULL) and, when the COO part's row indices are sorted (what every     */
+/* conversion produces: csr_to_other.h:229-306), the per-tile entry ranges that let cmi_spmv_hyb_plan_* run the whole     */
+/* multiply as ONE launch.  That array (one int per 256 rows) is the only device memory a plan owns; cmi_plan_destroy     */
+/* frees it.  Synchronises `stream`.                                                                                       */
+int cmi_plan_create_hyb(int dtype, int64_t num_rows, int64_t num_cols, int64_t ell_entries_per_row, int64_t coo_entries,
+                        const int32_t *coo_row_indices, const cmi_config *cfg_ell, const cmi_config *cfg_coo, void *stream,
+                        cmi_plan **plan);
 int cmi_plan_destroy(cmi_plan *plan);
 /* The launch shape the plan's multiplies run (SURVEY's cmi_plan_select): kernel CMI_CSR_BALANCED means   */
 /* the profile switched kernels.                                                                            */
@@ -353,6 +378,16 @@ int cmi_spmv_hyb_f32(int64_t num_rows, int64_t num_cols, int64_t ell_entries_per
                      const int32_t *coo_Ai, const int32_t *coo_Aj, const float *coo_Ax, const float *x,
                      float *y, int accumulate, const cmi_config *cfg_ell, const cmi_config *cfg_coo,
                      void *stream);
+/* HYB through a plan of cmi_plan_create_hyb.  COO part sorted by row: ONE launch -- a workgroup owns 256 rows, a lane   */
+/* walks its row's ELL slots and then adds the row's COO entries (staged through LDS) to the same accumulator, in entry  */
+/* order: per row exactly the chain of sequential/multiply/hyb_spmv.h:55-56, so the result has the host loops' bits, y is  */
+/* written once and nothing is zero-filled or accumulated with atomics.  Otherwise: the two launches of cmi_spmv_hyb_*.    */
+int cmi_spmv_hyb_plan_f64(const cmi_plan *plan, int64_t ell_pitch, const int32_t *ell_Aj, const double *ell_Ax,
+                          const int32_t *coo_Ai, const int32_t *coo_Aj, const double *coo_Ax, const double *x, double *y,
+                          int accumulate, void *stream);
+int cmi_spmv_hyb_plan_f32(const cmi_plan *plan, int64_t ell_pitch, const int32_t *ell_Aj, const float *ell_Ax,
+                          const int32_t *coo_Ai, const int32_t *coo_Aj, const float *coo_Ax, const float *x, float *y,
+                          int accumulate, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* On-device builders of the benchmark inputs.      */

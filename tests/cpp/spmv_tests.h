@@ -876,6 +876,54 @@ void TestMultiplyOmpPolicy()
 }
 DECLARE_UNITTEST(TestMultiplyOmpPolicy);
 
+// Per-matrix plan options of the device containers: the 16-bit column copy (csr_matrix::compress_indices) and HYB's
+// one-launch plan give the host loops' bits; both are re-made when the structure changes.
+template <typename Space> void TestDevicePlanOptions()
+{
+    if constexpr (std::is_same<Space, cusp::device_memory>::value) {
+        cusp::csr_matrix<int, double, cusp::host_memory> Ah;
+        cusp::gallery::poisson5pt(Ah, 97, 61);
+        const size_t N = Ah.num_rows;
+        cusp::array1d<double, cusp::host_memory> xh(N), want(N, 10.0);
+        for (size_t i = 0; i < N; i++) xh[i] = double((i * 2654435761u) % 1000u) / 997.0 - 0.5;
+        cusp::multiply(Ah, xh, want);
+        cusp::csr_matrix<int, double, Space> A(Ah);
+        cusp::array1d<double, Space> x(xh), y(N, 10.0);
+        A.compress_indices(true);
+        cmi_config c;
+        ASSERT_EQUAL(cmi_plan_config(A.plan(), &c), 0);
+        ASSERT_EQUAL(c.kernel, (int)CMI_CSR_STREAM_C16); // a 5-point stencil: every tile spans a few hundred columns
+        cusp::multiply(A, x, y);
+        cusp::array1d<double, cusp::host_memory> got(y);
+        for (size_t i = 0; i < N; i++) ASSERT_EQUAL(got[i], want[i]);
+        // the solver runs on the compressed matrix too (fused SpMV + dot through the same plan)
+        cusp::array1d<double, Space> sol(N, 0.0), b(N, 1.0);
+        cusp::monitor<double> mon(b, 400, 1e-10);
+        cusp::krylov::cg(A, sol, b, mon);
+        ASSERT_EQUAL(mon.converged(), true);
+        A.compress_indices(false);
+        ASSERT_EQUAL(cmi_plan_config(A.plan(), &c), 0);
+        ASSERT_EQUAL(c.kernel == (int)CMI_CSR_STREAM_C16, false);
+        // HYB: one launch through the container's plan
+        cusp::hyb_matrix<int, double, cusp::host_memory> Hh;
+        cusp::convert(Ah, Hh);
+        cusp::hyb_matrix<int, double, Space> H(Ah);
+        cusp::array1d<double, cusp::host_memory> wh(N, 10.0);
+        cusp::multiply(Hh, xh, wh);
+        cusp::array1d<double, Space> yh(N, 10.0);
+        cusp::multiply(H, x, yh);
+        cusp::array1d<double, cusp::host_memory> goth(yh);
+        for (size_t i = 0; i < N; i++) ASSERT_EQUAL(goth[i], wh[i]);
+        if (H.coo.num_entries > 0) {
+            int sorted = -1, exact = -1;
+            ASSERT_EQUAL(cmi_plan_info(H.plan(), nullptr, nullptr, &sorted, &exact), 0);
+            ASSERT_EQUAL(sorted, 1);
+            ASSERT_EQUAL(exact, 1);
+        }
+    }
+}
+DECLARE_SPACE_UNITTEST(TestDevicePlanOptions);
+
 // testing/cg.cu:11-44: cg(policy, ...) reaches a user overload by ADL; a policy without one solves
 template <class LinearOperator, class VectorType1, class VectorType2, class Monitor, class Preconditioner>
 void cg(my_system &system, const LinearOperator &, VectorType1 &, const VectorType2 &, Monitor &, Preconditioner &) { system.validate_dispatch(); }

@@ -158,15 +158,15 @@ def test_tuning_heuristics_and_table_roundtrip(cmi, tmp_path):
     # pass), capped by what fits one pass, whole y lines kept
     cmi.tuning_set(cmi.FORMAT_CSR, cmi.F64, 5.0, cmi.Config(kernel=cmi.CSR_STREAM, block_size=256, rows_per_block=176, items_per_thread=1))
     assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 5000).rows_per_block == 176      # the tuned mean: as tuned
-    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 7000).rows_per_block == 112      # 176 * 5/7 = 126 -> 112
-    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 7990).rows_per_block == 96       # 110 -> 96 (fits: 767)
+    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 7000).rows_per_block == 128      # 176 * 5/7 = 126 -> 128 (nearest whole y line; fits: 896)
+    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 7990).rows_per_block == 112      # 110 -> 112 (fits: 895)
     assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 4100).rows_per_block == 208      # 215 -> 208 (fits: 853)
     path2 = str(tmp_path / "means.json")
     cmi.tuning_save(path2)
     assert json.load(open(path2))["entries"][0]["mean"] == 5.0
     cmi.tuning_clear()
     cmi.tuning_load(path2)                                                                          # the mean survives the file
-    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 7000).rows_per_block == 112
+    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 7000).rows_per_block == 128
     cmi.tuning_clear()
     # persist an override, clear, reload: the selection follows the table
     cfg = cmi.Config(kernel=cmi.CSR_VECTOR, block_size=128, threads_per_row=4, nontemporal=1)

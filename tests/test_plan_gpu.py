@@ -122,18 +122,93 @@ def test_containers_plan_once_and_replan_when_the_arrays_change(cmi, torch_cuda,
     assert A._plan is not p1
     A.invalidate()
     assert A._plan is None
-    # HYB: the COO part multiplies through its own plan (sorted by construction -> tile kernel)
+    # HYB: its own plan (COO part sorted by construction -> the one-launch kernel, the host loops' bits)
     H = cmi.convert(A, "hyb", num_entries_per_row=3)
     Ap, Aj, Ax = (t.cpu().numpy() for t in (A.row_offsets, A.column_indices, A.values))
     y.fill_(10.0)
     cmi.multiply(H, x, y)
-    assert H.coo._plan is not None and H.coo._plan.info()["coo_sorted"]
+    assert H._plan is not None and H._plan.info()["coo_sorted"] and H._plan.info()["storage_order_sums"]
     p, hAj, hAx, cAi, cAj, cAx = orc.csr_to_hyb(Ap, Aj, Ax, 3)
     want = orc.spmv_hyb(1200, 3, p, hAj, hAx, cAi, cAj, cAx, x.cpu().numpy())
-    if H.coo._plan.config().kernel == cmi.COO_TILE:
-        assert np.array_equal(y.cpu().numpy(), want)
+    assert np.array_equal(y.cpu().numpy(), want)
+    hp = H._plan
+    cmi.multiply(H, x, y)
+    assert H._plan is hp
+    H.invalidate()
+    assert H._plan is None
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("shape", ["irregular", "heavy_tail", "one_entry_rows", "desert", "width0"])
+def test_hyb_plan_one_launch(cmi, torch_cuda, orc, tag, shape):
+    """cmi_spmv_hyb_plan_*: with the COO part sorted by row ONE kernel finishes every row -- ELL slots, then the row's COO
+    entries, one accumulator (sequential/multiply/hyb_spmv.h:55-56 is that chain) -- bit for bit the host loops, overwrite and
+    accumulate; tiles whose COO range needs several 256-entry chunks, rows whose run straddles chunks, tiles without entries.
+    A COO part that is not sorted runs the two launches (1e-6 class); an empty one the ELL kernel."""
+    torch = torch_cuda
+    dtype = np.float64 if tag == "f64" else np.float32
+    rng = np.random.default_rng(31)
+    rows, cols = 3000, 2500
+    if shape == "irregular":
+        lens, width = rng.integers(0, 12, size=rows), 5
+    elif shape == "heavy_tail":  # rows of up to 2000 entries: a tile's COO range spans many chunks, one row several
+        lens = rng.integers(1, 6, size=rows)
+        lens[[5, 300, 301, 1500, 2999]] = [2000, 700, 900, 1999, 1200]
+        width = 3
+    elif shape == "one_entry_rows":
+        lens, width = np.full(rows, 5), 4
+    elif shape == "desert":  # long runs of rows without any COO entry (and without any entry at all)
+        lens = np.zeros(rows, np.int64)
+        lens[::97] = 9
+        lens[1000:1010] = 40
+        width = 2
     else:
-        assert np.allclose(y.cpu().numpy(), want, rtol=1e-12, atol=1e-12)
+        lens, width = rng.integers(0, 7, size=rows), 0
+    Ap = np.r_[0, np.cumsum(lens)].astype(np.int32)
+    Aj = np.concatenate([np.sort(rng.choice(cols, size=l, replace=False)) for l in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+    Ax = rng.standard_normal(len(Aj)).astype(dtype)
+    x = rng.standard_normal(cols).astype(dtype)
+    y0 = rng.standard_normal(rows).astype(dtype)
+    p, hAj, hAx, cAi, cAj, cAx = orc.csr_to_hyb(Ap, Aj, Ax, width)
+    want = orc.spmv_hyb(rows, width, p, hAj, hAx, cAi, cAj, cAx, x)
+    want_acc = orc.spmv_hyb(rows, width, p, hAj, hAx, cAi, cAj, cAx, x, y0)
+    d = [torch.from_numpy(a).cuda() for a in (hAj, hAx, cAi, cAj, cAx)]
+    dx = torch.from_numpy(x).cuda()
+    plan = cmi.Plan.hyb(dx.dtype, rows, cols, width, d[2])
+    info = plan.info()
+    assert info["coo_sorted"] is True and info["storage_order_sums"] is True
+    for swz, nt in ((0, 0), (1, 1), (3, 2), (64, 3)):
+        pl = cmi.Plan.hyb(dx.dtype, rows, cols, width, d[2], cfg_ell=cmi.Config(kernel=cmi.ELL_ROW, xcd_swizzle=swz, nontemporal=nt))
+        y = torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
+        cmi.spmv_hyb_plan(pl, p, *d, dx, y)
+        assert np.array_equal(y.cpu().numpy(), want), (shape, swz, nt)
+        y = torch.from_numpy(y0).cuda()
+        cmi.spmv_hyb_plan(pl, p, *d, dx, y, accumulate=True)
+        assert np.array_equal(y.cpu().numpy(), want_acc), (shape, swz, nt, "acc")
+    # COO part shuffled: the plan sees it, two launches, sums re-associated
+    if len(cAi) > 1:
+        perm = rng.permutation(len(cAi))
+        ds = [torch.from_numpy(a[perm].copy()).cuda() for a in (cAi, cAj, cAx)]
+        pu = cmi.Plan.hyb(dx.dtype, rows, cols, width, ds[0])
+        assert pu.info()["coo_sorted"] is False and pu.info()["storage_order_sums"] is False
+        y = torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
+        cmi.spmv_hyb_plan(pu, p, d[0], d[1], *ds, dx, y)
+        bound = orc.spmv_hyb(rows, width, p, hAj, np.abs(hAx), cAi, cAj, np.abs(cAx), np.abs(x))
+        tol = (1e-6 if tag == "f64" else 1e-4) * bound + 1e-30
+        assert np.all(np.abs(y.cpu().numpy() - want) <= tol)
+    # empty COO part
+    w2 = int(lens.max())
+    p2, hAj2, hAx2, cAi2, cAj2, cAx2 = orc.csr_to_hyb(Ap, Aj, Ax, w2)
+    assert len(cAi2) == 0
+    d2 = [torch.from_numpy(a).cuda() for a in (hAj2, hAx2, cAi2, cAj2, cAx2)]
+    pe = cmi.Plan.hyb(dx.dtype, rows, cols, w2, d2[2], cfg_ell=cmi.Config(kernel=cmi.ELL_ROW, threads_per_row=1))
+    y = torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
+    cmi.spmv_hyb_plan(pe, p2, *d2, dx, y)
+    assert np.array_equal(y.cpu().numpy(), orc.spmv_hyb(rows, w2, p2, hAj2, hAx2, cAi2, cAj2, cAx2, x))
+    with pytest.raises(ValueError):
+        cmi.spmv_hyb_plan(plan, p, *d, dx, y[:-1])
+    with pytest.raises(cmi.CmiError):  # a HYB plan is not a COO plan
+        cmi.check(cmi.lib().cmi_spmv_coo_plan_f64(plan.handle, None, None, None, None, None, 0, None))
 
 
 def test_hyb_width_rule(cmi, torch_cuda, orc, golden_irregular):

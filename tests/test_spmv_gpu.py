@@ -170,13 +170,23 @@ def run_all_formats(cmi, torch, orc, rows, cols, Ap, Aj, Ax, x, want, want_acc, 
             swz = (0, 1, 3, 32)[(rpl + nt + ellr) % 4]  # tiles dealt to the XCDs: launch order, eighths, chunks of 3 / 32
             y = fresh(acc)
             cmi.spmv_ell(rows, cols, width, pitch, deAj, deAx, dx, y, row_lengths=rl if ellr else None, accumulate=acc,
-                         cfg=cmi.Config(kernel=cmi.ELL_ROW, block_size=blk, items_per_thread=rpl, nontemporal=nt, xcd_swizzle=swz))
+                         cfg=cmi.Config(kernel=cmi.ELL_ROW, block_size=blk, threads_per_row=1, items_per_thread=rpl, nontemporal=nt, xcd_swizzle=swz))
             assert np.array_equal(host(y), w), f"{label} ell rpl{rpl} nt{nt} ellr{ellr} x{swz} acc={acc}: not bit-exact"
         for blk, swz in ((64, 1), (64, 2), (128, 5), (1024, 8)):  # small workgroups: many tiles, padded chunk rounds
             y = fresh(acc)
             cmi.spmv_ell(rows, cols, width, pitch, deAj, deAx, dx, y, accumulate=acc,
-                         cfg=cmi.Config(kernel=cmi.ELL_ROW, block_size=blk, items_per_thread=1, xcd_swizzle=swz))
+                         cfg=cmi.Config(kernel=cmi.ELL_ROW, block_size=blk, threads_per_row=1, items_per_thread=1, xcd_swizzle=swz))
             assert np.array_equal(host(y), w), f"{label} ell b{blk} x{swz} acc={acc}: not bit-exact"
+        # S lanes per row (slices of the slots, partial sums through LDS): re-associated, 1e-6 class
+        for lanes, blk, ellr, nt in ((2, 256, False, 0), (4, 256, True, 3), (8, 128, False, 2), (16, 256, True, 1), (16, 64, False, 0),
+                                     (4, 1024, False, 0), (3, 256, False, 0)):
+            y = fresh(acc)
+            cmi.spmv_ell(rows, cols, width, pitch, deAj, deAx, dx, y, row_lengths=rl if ellr else None, accumulate=acc,
+                         cfg=cmi.Config(kernel=cmi.ELL_ROW, block_size=blk, threads_per_row=lanes, nontemporal=nt))
+            assert_close(host(y), w, bound, dtype, f"{label} ell lanes{lanes} b{blk} ellr{ellr} acc={acc}")
+        y = fresh(acc)  # NULL config: the table's shape, lanes per row by the auto rule
+        cmi.spmv_ell(rows, cols, width, pitch, deAj, deAx, dx, y, accumulate=acc)
+        assert_close(host(y), w, bound, dtype, f"{label} ell auto acc={acc}")
 
     # HYB at the fixture's split
     p, hAj, hAx, cAi, cAj, cAx = orc.csr_to_hyb(Ap, Aj, Ax, hyb_width)
@@ -736,7 +746,7 @@ def test_unaligned_views_take_the_scalar_load_paths(cmi, torch_cuda, orc, golden
         pitch, eAj, eAx = orc.csr_to_ell(np.r_[Ap, Ap[-1]].astype(np.int32), Aj, Ax, width, alignment=1)
     y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
     cmi.spmv_ell(rows, cols, width, pitch, dev(eAj, torch), dev(eAx, torch), dev(x, torch), y,
-                 cfg=cmi.Config(kernel=cmi.ELL_ROW, items_per_thread=2))
+                 cfg=cmi.Config(kernel=cmi.ELL_ROW, threads_per_row=1, items_per_thread=2))
     assert np.array_equal(host(y), g["f64_y_ell"])
 
 
@@ -1309,6 +1319,55 @@ def test_spmv_ell_and_dia_dot(cmi, torch_cuda, orc):
     cmi.spmv_dia_dot(nb, nb, 5, big.pitch, big.diagonal_offsets, big.values, xb, yb1, xb, res, ws, cfg=cfg)
     assert torch.equal(yb0, yb1)
     assert abs(float(res) - float(torch.dot(yb1, xb))) <= 1e-10 * float((yb1 * xb).abs().sum())
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_ell_wide_rows_lanes_per_row(cmi, torch_cuda, orc, tag):
+    """Few, wide rows: the auto rule gives a row several lanes (ref: THREADS_PER_ROW of ktt kernels/ell_kernel.h:102-109); every
+    lane count agrees with the host loop within 1e-6 of sum|a_ij x_j|, one lane per row bit for bit; the fused dot falls back
+    to the separate dot and still returns <y, w>."""
+    torch = torch_cuda
+    dtype = np.float64 if tag == "f64" else np.float32
+    rng = np.random.default_rng(21)
+    rows, cols = 3001, 40000
+    lens = rng.integers(0, 200, size=rows)
+    lens[7] = 0
+    lens[11] = 199
+    Ap = np.r_[0, np.cumsum(lens)].astype(np.int32)
+    Aj = np.concatenate([np.sort(rng.choice(cols, size=l, replace=False)) for l in lens]).astype(np.int32)
+    Ax = rng.standard_normal(len(Aj)).astype(dtype)
+    x = rng.standard_normal(cols).astype(dtype)
+    width = int(lens.max())
+    pitch, eAj, eAx = orc.csr_to_ell(Ap, Aj, Ax, width)
+    want = orc.spmv_ell(rows, width, pitch, eAj, eAx, x)
+    y0 = rng.standard_normal(rows).astype(dtype)
+    want_acc = orc.spmv_ell(rows, width, pitch, eAj, eAx, x, y0)
+    bound = row_abs(orc, Ap, Aj, Ax, x)
+    deAj, deAx, dx = dev(eAj, torch), dev(eAx, torch), dev(x, torch)
+    rl = torch.empty(rows, dtype=torch.int32, device="cuda")
+    cmi.ell_row_lengths(rows, width, pitch, deAj, rl)
+    plan = cmi.Plan(cmi.FORMAT_ELL, dx.dtype, rows, cols, rows * width, None)
+    assert plan.info()["storage_order_sums"] is False  # 3001 rows x 199 slots: the auto rule splits the rows
+    one = cmi.Plan(cmi.FORMAT_ELL, dx.dtype, rows, cols, rows * width, None, cfg=cmi.Config(kernel=cmi.ELL_ROW, threads_per_row=1))
+    assert one.info()["storage_order_sums"] is True
+    for lanes, ellr, acc in itertools.product((0, 1, 2, 4, 8, 16), (False, True), (False, True)):
+        y = dev(y0, torch).clone() if acc else torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
+        cmi.spmv_ell(rows, cols, width, pitch, deAj, deAx, dx, y, row_lengths=rl if ellr else None, accumulate=acc,
+                     cfg=None if lanes == 0 else cmi.Config(kernel=cmi.ELL_ROW, threads_per_row=lanes))
+        w_ = want_acc if acc else want
+        if lanes == 1:
+            assert np.array_equal(host(y), w_), (lanes, ellr, acc)
+        else:
+            assert_close(host(y), w_, bound + (np.abs(y0) if acc else 0), dtype, f"ell lanes{lanes} ellr{ellr} acc{acc}")
+    if tag == "f64":
+        wv = rng.standard_normal(rows)
+        res = torch.zeros(1, dtype=torch.float64, device="cuda")
+        y = torch.zeros(rows, dtype=torch.float64, device="cuda")
+        cmi.spmv_ell_dot(rows, cols, width, pitch, deAj, deAx, dx, y, dev(wv, torch), res, cmi.blas_workspace(),
+                         cfg=cmi.Config(kernel=cmi.ELL_ROW, threads_per_row=8))
+        yh = host(y)
+        assert_close(yh, want, bound, dtype, "ell lanes8 dot: y")
+        assert abs(float(res) - float(np.dot(yh, wv))) <= 1e-12 * float(np.abs(yh * wv).sum())
 
 
 def test_cg_update_long_partial_list(cmi, torch_cuda):

@@ -1,6 +1,6 @@
 // tools/cg_bench.cpp -- CG iterations/s through the C++ layer (cusp::krylov::cg on device_memory), the
 // caller of the SpMV hot path: poisson5pt(grid, grid), b = deterministic x pattern, fixed iteration count.
-//   cg_bench [--grid=3162] [--iterations=200] [--format=csr|ell|dia|hyb|coo]
+//   [CMI_COMPRESS_INDICES=1] cg_bench [--grid=3162] [--iterations=200] [--format=csr|ell|dia|hyb|coo]
 // Prints the fused device path (default: identity preconditioner, double) and, for comparison, the plain
 // operation-by-operation path (forced by passing an explicit non-identity-typed preconditioner).
 #include <cusp/coo_matrix.h>
@@ -29,7 +29,7 @@ template <typename Matrix> int run(size_t grid, size_t iters, const char *name)
         Matrix A;
         cusp::gallery::poisson5pt(A, grid, grid);
         const size_t N = A.num_rows;
-        std::printf("format %s\n", name);
+        std::printf("format %s%s\n", name, cmi_get_index_compression() ? "  (CMI_COMPRESS_INDICES=1: CSR plans ask for the 16-bit column copy)" : "");
         cusp::array1d<double, cusp::host_memory> hb(N);
         for (size_t i = 0; i < N; i++) hb[i] = double((unsigned(i) * 2654435761u) % 1000u) / 997.0 - 0.5;
         cusp::array1d<double, cusp::device_memory> b(hb);

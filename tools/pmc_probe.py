@@ -26,13 +26,17 @@ y = torch.empty(N, dtype=torch.float64, device="cuda")
 alg = {}
 for fmt in fmts:
     # hyb: width 4 leaves the fifth entry of the interior rows to the COO part (a width of 5 would time ELL alone)
-    Afmt = A if fmt == "csr" else (cmi.poisson5pt(M, M, "dia") if fmt == "dia" else
-                                   cmi.convert(A, fmt, num_entries_per_row=4 if fmt == "hyb" else None))
+    if fmt == "csr16":  # the opt-in plan with the 16-bit column copy (CMI_CSR_STREAM_C16): same matrix, same arrays
+        Afmt = cmi.CsrMatrix(N, N, A.num_entries, A.row_offsets, A.column_indices, A.values)
+        assert Afmt.plan(compress=True).config().kernel == cmi.CSR_STREAM_C16
+    else:
+        Afmt = A if fmt == "csr" else (cmi.poisson5pt(M, M, "dia") if fmt == "dia" else
+                                       cmi.convert(A, fmt, num_entries_per_row=4 if fmt == "hyb" else None))
     torch.cuda.synchronize()
     for _ in range(10):
         cmi.multiply(Afmt, x, y)
     torch.cuda.synchronize()
-    alg[fmt] = {"csr": cmi.csr_bytes(N, A.num_entries), "ell": cmi.ell_bytes(N, 5, 9998272), "dia": cmi.dia_bytes(N, 5, N),
+    alg[fmt] = {"csr": cmi.csr_bytes(N, A.num_entries), "csr16": cmi.csr_bytes(N, A.num_entries) - 2 * A.num_entries, "ell": cmi.ell_bytes(N, 5, 9998272), "dia": cmi.dia_bytes(N, 5, N),
                 "coo": cmi.coo_bytes(N, A.num_entries),
                 "hyb": cmi.ell_bytes(N, 4, 9998272) + 16 * (A.num_entries - 4 * N if fmt != "hyb" else Afmt.coo.num_entries)}[fmt]
     del Afmt

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--shapes", action="store_true", help="also time explicit csr_stream tile shapes (block, vectors per lane, rows per tile)")
+    ap.add_argument("--only", default="", help="comma-separated subset of thermal2,ldoor,nlpkkt120")
     args = ap.parse_args()
     import torch
     import cusp_autotuned_amd as cmi
@@ -51,6 +53,8 @@ def main():
         return ms.value / args.iters * 1e3
 
     for name in ("thermal2", "ldoor", "nlpkkt120"):
+        if args.only and name not in args.only.split(","):
+            continue
         Ap, Aj, Ax, source = ssl.load(name, args.scale)
         st = ssl.stats(Ap, Aj)
         rows, nnz = st["rows"], st["entries"]
@@ -74,6 +78,12 @@ def main():
             for ipt in (1, 2):
                 cands.append((f"csr_stream lanes/row={T} vectors/lane={ipt}", cmi.Config(kernel=cmi.CSR_STREAM, threads_per_row=T, items_per_thread=ipt,
                                                                                        nontemporal=2), T == 1))
+        if args.shapes:  # explicit csr_stream tile shapes around the table's: block x vectors/lane, rows per tile by fill of the LDS pass
+            for blk, ipt in ((256, 1), (256, 2), (512, 2), (256, 4)):
+                fit = int((blk * ipt * 4 - 3) / mean)
+                for r in sorted({max(16, fit // 16 * 16), max(16, fit // 16 * 16 - 16), max(16, fit // 8 * 8), min(fit, blk)}):
+                    cands.append((f"csr_stream block {blk} vectors/lane={ipt} rows/tile={r} (fit {fit})",
+                                  cmi.Config(kernel=cmi.CSR_STREAM, block_size=blk, threads_per_row=1, items_per_thread=ipt, rows_per_block=r, nontemporal=2), True))
         plan = A.plan()
         cands.append((f"table (NULL config): {cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64 if vb == 8 else cmi.F32, rows, rows, nnz)}", None, False))
         runs = []
