@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--cg-iterations", type=int, default=100, help="iterations of the secondary CG leg (0 = skip)")
+    ap.add_argument("--cg-iterations", type=int, default=300, help="iterations of the secondary CG leg (0 = skip)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "peer", "halo", "allgather"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)

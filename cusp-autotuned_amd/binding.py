@@ -150,6 +150,7 @@ def _declare(L):
     L.cmi_plan_info.argtypes = [vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int), POINTER(c_int)]
     L.cmi_plan_create_csr.argtypes = [c_int, i64, i64, i64, vp, vp, cfgp, vp, POINTER(c_void_p)]
     L.cmi_set_index_compression.argtypes = [c_int]
+    L.cmi_plan_hyb_launches.argtypes = [vp, POINTER(c_int)]
     L.cmi_plan_create_hyb.argtypes = [c_int, i64, i64, i64, i64, vp, cfgp, cfgp, vp, POINTER(c_void_p)]
     for suf in ("f64", "f32"):
         getattr(L, f"cmi_spmv_hyb_plan_{suf}").argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp]
@@ -300,6 +301,12 @@ class Plan:
     def handle(self):
         return self._h
 
+    def hyb_launches(self):
+        """1 = the one-launch HYB kernel (or an empty COO part), 2 = ELL kernel + COO kernel."""
+        n = c_int()
+        check(lib().cmi_plan_hyb_launches(self._h, byref(n)))
+        return n.value
+
     def config(self):
         c = Config()
         check(lib().cmi_plan_config(self._h, byref(c)))
@@ -437,6 +444,31 @@ def spmv_hyb(num_rows, num_cols, width, pitch, ell_Aj, ell_Ax, coo_Ai, coo_Aj, c
     fn = getattr(lib(), "cmi_spmv_hyb_" + _suffix(y))
     check(fn(num_rows, num_cols, width, pitch, _ptr(ell_Aj), _ptr(ell_Ax), coo_Ax.numel(), _ptr(coo_Ai), _ptr(coo_Aj),
              _ptr(coo_Ax), _ptr(x), _ptr(y), int(bool(accumulate)), _cfg(cfg_ell), _cfg(cfg_coo), _stream(stream)))
+
+
+def hyb_plan_args(plan, pitch, ell_Aj, ell_Ax, coo_Ai, coo_Aj, coo_Ax):
+    """Validate a HYB matrix's arrays against its plan ONCE and return what spmv_hyb_plan_args passes per call (a container
+    that multiplies many times -- CG -- should not pay eight tensor checks per launch)."""
+    import torch
+    for t, n in ((ell_Aj, "ell_Aj"), (coo_Ai, "coo_Ai"), (coo_Aj, "coo_Aj")):
+        _need(t, n, torch.int32)
+    for t, n in ((ell_Ax, "ell_Ax"), (coo_Ax, "coo_Ax")):
+        _need(t, n, ell_Ax.dtype)
+    if plan.format != FORMAT_HYB:
+        raise ValueError("hyb_plan_args: not a HYB plan")
+    if (coo_Ai.numel() != plan.coo_entries or coo_Aj.numel() != plan.coo_entries or coo_Ax.numel() != plan.coo_entries
+            or ell_Aj.numel() < plan.width * pitch or ell_Ax.numel() < plan.width * pitch or pitch < plan.num_rows):
+        raise ValueError("hyb_plan_args: array lengths do not match the plan's matrix shape")
+    return (getattr(lib(), "cmi_spmv_hyb_plan_" + _suffix(ell_Ax)), plan.handle, pitch, _ptr(ell_Aj), _ptr(ell_Ax), _ptr(coo_Ai), _ptr(coo_Aj),
+            _ptr(coo_Ax), ell_Ax.dtype, plan.num_cols, plan.num_rows)
+
+
+def spmv_hyb_plan_args(args, x, y, accumulate=False, stream=None):
+    fn, h, pitch, eAj, eAx, cAi, cAj, cAx, dt, ncols, nrows = args
+    if x.dtype != dt or y.dtype != dt or not x.is_cuda or not y.is_cuda or x.numel() != ncols or y.numel() != nrows \
+            or not x.is_contiguous() or not y.is_contiguous():
+        raise ValueError("spmv_hyb_plan: x / y must be contiguous device vectors of the matrix's value type and shape")
+    check(fn(h, pitch, eAj, eAx, cAi, cAj, cAx, _ptr(x), _ptr(y), int(bool(accumulate)), _stream(stream)))
 
 
 def set_index_compression(on):

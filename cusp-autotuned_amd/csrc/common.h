@@ -58,7 +58,7 @@ struct row_profile { int64_t max_len = -1, in_long = 0; }; // max_len < 0: not m
 int measure_row_lengths(int64_t rows, const int *Ap, hipStream_t s, int64_t *max_len, int64_t *entries_in_long_rows);
 bool prefers_balanced(int64_t rows, int64_t nnz, const row_profile &pr, size_t value_bytes, bool strict_order);
 // are the row indices of a COO matrix non-decreasing and inside [0, rows)?  (spmv_coo_hyb.hip; synchronises the stream)
-int coo_rows_sorted(int64_t rows, int64_t nnz, const int *Ai, hipStream_t s, int *sorted);
+int coo_rows_sorted(int64_t rows, int64_t nnz, const int *Ai, hipStream_t s, int *sorted, int *long_runs = nullptr); // long_runs: a row of > 1024 entries
 // ELL lanes per row (spmv_ell_dia.hip): 1 = the row kernel (storage-order sums), 2..16 = the slices kernel.  Auto rule,
 // from tools/ell_wide_probe.py (profiles/r02_ell_wide_lanes_f64.txt): every lane keeps >= kEllSliceMinSlots slots
 // (lanes = width / 16 rounded down to a power of two, at most 16); two lanes only pay below kEllSliceMaxRows2 rows
@@ -257,7 +257,13 @@ struct cmi_plan {
 
 namespace cmi {
 constexpr int kHybTileRows = 256; // rows per workgroup of the one-launch HYB kernel = its block size
-int hyb_tile_starts(int64_t rows, int64_t coo_entries, const int *coo_Ai, int32_t *tile_start, hipStream_t s);
+int hyb_tile_starts(int64_t rows, int64_t coo_entries, const int *coo_Ai, int32_t *tile_start, int *max_in_tile_dev, hipStream_t s);
+// The one-launch kernel walks a tile's COO entries 256 at a time behind its ELL slots: right for a light COO part (the usual
+// HYB: a few entries in some rows), wrong for a heavy one, where the entry-tiled COO kernel in a second launch is faster
+// (tools/hyb_fuse_probe.py, profiles/r02_hyb_one_vs_two_launches.txt: the crossover lies at 3-6 entries per row).  One launch when the COO part averages at most
+// kHybFusedMaxPerRow entries per row and no tile holds more than kHybFusedMaxInTile; $CMI_HYB_ONE_LAUNCH=0/1 forces it.
+constexpr double kHybFusedMaxPerRow = 4.0;
+constexpr int kHybFusedMaxInTile = 4096;
 // spmv_csr16.hip: the plan's 16-bit column copy (built only if every tile qualifies) and the multiply that reads it
 int csr16_build(cmi_plan *p, const int *Ap, const int *Aj, hipStream_t s);
 int csr16_multiply_f64(const cmi_plan *p, const int *Ap, const double *Ax, const double *x, double *y, int accumulate,

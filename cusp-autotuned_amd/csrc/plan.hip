@@ -115,14 +115,15 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
             if (p->cfg.kernel != CMI_CSR_STREAM_C16) p->cfg.rows_per_block = tuned_rpb; // not granted: csr_stream as tuned
         }
     } else if (format == CMI_FORMAT_COO) {
-        int sorted = 1;
-        if (num_entries > 0) st = coo_rows_sorted(num_rows, num_entries, index_array, s, &sorted);
+        int sorted = 1, long_runs = 0;
+        if (num_entries > 0) st = coo_rows_sorted(num_rows, num_entries, index_array, s, &sorted, &long_runs);
         if (st == CMI_SUCCESS) {
             p->coo_sorted = sorted;
             const bool auto_kernel = !cfg || cfg->kernel == CMI_KERNEL_AUTO;
             // sorted entries: the table's CMI_TABLE_COO_SORTED key (the tile kernel with its tuned cache policy / XCD dealing)
             // (fewer than four entries: the tile kernel's vector loads have nothing to read -- the order-agnostic kernel stays)
-            if (sorted && auto_kernel && num_entries >= 4) select_config(CMI_TABLE_COO_SORTED, dtype, num_rows, num_cols, num_entries, cfg, &p->cfg);
+            // (a row of more than 1024 entries: the tile kernel would walk its tail serially -- the order-agnostic kernel stays)
+            if (sorted && !long_runs && auto_kernel && num_entries >= 4) select_config(CMI_TABLE_COO_SORTED, dtype, num_rows, num_cols, num_entries, cfg, &p->cfg);
             // an explicit CMI_COO_TILE on unsorted entries would add rows up wrongly: refuse it here, where it is known
             if (!sorted && p->cfg.kernel == CMI_COO_TILE) st = fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: CMI_COO_TILE needs row-sorted entries");
         }
@@ -161,22 +162,43 @@ CMI_API int cmi_plan_create_hyb(int dtype, int64_t num_rows, int64_t num_cols, i
     hipStream_t s = as_stream(stream);
     int st = CMI_SUCCESS;
     if (coo_entries > 0 && num_rows > 0) {
-        int sorted = 0;
-        st = coo_rows_sorted(num_rows, coo_entries, coo_row_indices, s, &sorted);
+        int sorted = 0, long_runs = 0;
+        st = coo_rows_sorted(num_rows, coo_entries, coo_row_indices, s, &sorted, &long_runs);
         if (st == CMI_SUCCESS) p->coo_sorted = sorted;
-        if (st == CMI_SUCCESS && sorted && coo_entries <= INT32_MAX - 4096) {
+        // sorted: the two-launch path's COO half is the tile kernel (storage-order sums on top of the ELL half: still one chain)
+        if (st == CMI_SUCCESS && sorted && !long_runs && coo_entries >= 4 && (!cfg_coo || cfg_coo->kernel == CMI_KERNEL_AUTO))
+            select_config(CMI_TABLE_COO_SORTED, dtype, num_rows, num_cols, coo_entries, cfg_coo, &p->hyb_coo_cfg);
+        const char *force = std::getenv("CMI_HYB_ONE_LAUNCH"); // "0": never, "1": whenever the COO part is sorted, else: by its weight
+        const bool never = force && force[0] == '0', always = force && force[0] == '1';
+        if (st == CMI_SUCCESS && sorted && !never && coo_entries <= INT32_MAX - 4096 &&
+            (always || (double)coo_entries <= kHybFusedMaxPerRow * (double)num_rows)) {
             const int64_t tiles = ceil_div(num_rows, kHybTileRows);
+            int *max_dev = nullptr, max_in_tile = 0;
             hipError_t e = hipMalloc((void **)&p->hyb_tile_start, (size_t)(tiles + 1) * sizeof(int32_t));
+            if (e == hipSuccess) e = hipMalloc((void **)&max_dev, sizeof(int));
             if (e != hipSuccess) st = hip_fail(e, "cmi_plan_create_hyb: tile ranges");
-            if (st == CMI_SUCCESS) st = hyb_tile_starts(num_rows, coo_entries, coo_row_indices, p->hyb_tile_start, s);
+            if (st == CMI_SUCCESS) st = hyb_tile_starts(num_rows, coo_entries, coo_row_indices, p->hyb_tile_start, max_dev, s);
             if (st == CMI_SUCCESS) {
-                e = hipStreamSynchronize(s);
+                e = hipMemcpyAsync(&max_in_tile, max_dev, sizeof(int), hipMemcpyDeviceToHost, s);
+                if (e == hipSuccess) e = hipStreamSynchronize(s);
                 if (e != hipSuccess) st = hip_fail(e, "cmi_plan_create_hyb: tile ranges");
+            }
+            if (max_dev) (void)hipFree(max_dev);
+            if (st == CMI_SUCCESS && !always && max_in_tile > kHybFusedMaxInTile) { // a few rows hold the COO part: two launches
+                (void)hipFree(p->hyb_tile_start);
+                p->hyb_tile_start = nullptr;
             }
         }
     }
     if (st != CMI_SUCCESS) { (void)cmi_plan_destroy(p); return st; }
     *plan_out = p;
+    return CMI_SUCCESS;
+}
+
+CMI_API int cmi_plan_hyb_launches(const cmi_plan *plan, int *launches)
+{
+    if (!plan || !launches || plan->format != CMI_FORMAT_HYB) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_hyb_launches: not a HYB plan");
+    *launches = (plan->hyb_tile_start || plan->hyb_coo == 0) ? 1 : 2;
     return CMI_SUCCESS;
 }
 
@@ -215,8 +237,9 @@ CMI_API int cmi_plan_info(const cmi_plan *plan, int64_t *max_row_length, int64_t
         case CMI_FORMAT_ELL: exact = ell_lanes_per_row(c, plan->rows, plan->rows > 0 ? plan->nnz / plan->rows : 0) == 1; break;
         case CMI_FORMAT_DIA: exact = 1; break;
         case CMI_FORMAT_COO: exact = c.kernel == CMI_COO_TILE; break;
-        default: // HYB: one launch = one chain per row; two launches: atomics in the COO half (an empty one: the ELL kernel's class)
-            exact = plan->hyb_tile_start != nullptr || (plan->hyb_coo == 0 && ell_lanes_per_row(c, plan->rows, plan->hyb_width) == 1);
+        default: // HYB: one launch = one chain per row; two launches: the same chain when the COO half is the tile kernel, else atomics
+            exact = plan->hyb_tile_start != nullptr ||
+                    (ell_lanes_per_row(c, plan->rows, plan->hyb_width) == 1 && (plan->hyb_coo == 0 || plan->hyb_coo_cfg.kernel == CMI_COO_TILE));
             break;
         }
         *storage_order_sums = exact;

@@ -386,7 +386,10 @@ coo_tile_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ A
     }
 }
 
-// Row indices non-decreasing and inside [0, rows)?  One pass, a flag.
+// Row indices non-decreasing and inside [0, rows)?  One pass, a flag (bit 0).  Bit 1: some row holds more than kCooTile
+// entries (Ai[e] == Ai[e + kCooTile], meaningful for sorted input) -- the tile kernel finishes such a row with a serial walk
+// past its tile (one lane, global loads: ~1 us per entry), so a plan keeps those matrices on the order-agnostic kernels
+// (tools/hyb_fuse_probe.py: a power-law tail of 3000-entry rows took 640 us through the tile kernel).
 __global__ void __launch_bounds__(256)
 coo_sorted_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ Ai, int *__restrict__ bad)
 {
@@ -395,13 +398,16 @@ coo_sorted_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < num_entries; e += stride) {
         const int r = Ai[e];
         mine |= r < 0 || r >= num_rows || (e > 0 && Ai[e - 1] > r);
+        if (e + kCooTile < num_entries && Ai[e + kCooTile] == r) mine |= 2;
     }
-    if (__any(mine) && (threadIdx.x & (kWave - 1)) == 0) atomicOr(bad, 1);
+    if (__any(mine & 1) && (threadIdx.x & (kWave - 1)) == 0) atomicOr(bad, 1);
+    if (__any(mine & 2) && (threadIdx.x & (kWave - 1)) == 0) atomicOr(bad, 2);
 }
 
-int coo_rows_sorted(int64_t rows, int64_t nnz, const int *Ai, hipStream_t s, int *sorted)
+int coo_rows_sorted(int64_t rows, int64_t nnz, const int *Ai, hipStream_t s, int *sorted, int *long_runs)
 {
     *sorted = 0;
+    if (long_runs) *long_runs = 0;
     int *flag = nullptr;
     CMI_HIP(hipMalloc((void **)&flag, sizeof(int)));
     int host = 1;
@@ -417,7 +423,8 @@ int coo_rows_sorted(int64_t rows, int64_t nnz, const int *Ai, hipStream_t s, int
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(flag);
     if (e != hipSuccess) return hip_fail(e, "coo order check");
-    *sorted = host == 0;
+    *sorted = (host & 1) == 0;
+    if (long_runs) *long_runs = (host & 2) != 0;
     return CMI_SUCCESS;
 }
 
@@ -542,14 +549,16 @@ hyb_tile_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restric
     }
     for (int c0 = cb; c0 < ce; c0 += R) { // workgroup-uniform trip count
         const int n = ce - c0 < R ? ce - c0 : R;
-        if (c0 != cb) {
-            __syncthreads(); // the previous chunk's runs have been added
-            if (tid < n) {
-                ci = ld<NT>(cAi + c0 + tid);
-                cj = ld<NT>(cAj + c0 + tid);
-                cv = ld<NT>(cAx + c0 + tid);
-                cx = x[cj];
-            }
+        // the next chunk's three streams are requested now, its x gather after the first barrier (the column has arrived by
+        // then): a chunk's global round trips overlap the LDS phase of the chunk before it
+        const int c1 = c0 + R;
+        const bool more = c1 < ce, mine = c1 + tid < ce;
+        int ni = 0, nj = 0;
+        T nv = T(0), nx = T(0);
+        if (mine) {
+            ni = ld<NT>(cAi + c1 + tid);
+            nj = ld<NT>(cAj + c1 + tid);
+            nv = ld<NT>(cAx + c1 + tid);
         }
         const int r = ci - (int)row0; // 0 .. R-1: the plan's tile_start[] brackets exactly this tile's rows
         sbeg[tid] = 0;
@@ -559,6 +568,7 @@ hyb_tile_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restric
             lrow[tid] = r;
         }
         __syncthreads();
+        if (more) nx = x[nj]; // (lanes past the chunk gather x[0])
         if (tid < n) {
             if (tid == 0 || lrow[tid - 1] != r) sbeg[r] = tid;
             if (tid == n - 1 || lrow[tid + 1] != r) send[r] = tid + 1;
@@ -566,6 +576,10 @@ hyb_tile_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restric
         __syncthreads();
         const int a = sbeg[tid], b = send[tid];
         acc = sum_in_order(acc, prod + a, b - a); // (rows without entries in this chunk: a == b == 0)
+        if (more) {
+            __syncthreads(); // this chunk's runs have been added: prod / lrow / sbeg / send are free again
+            ci = ni; cj = nj; cv = nv; cx = nx;
+        }
     }
     if (live) st<NTS>(y + row, acc);
 }
@@ -585,10 +599,24 @@ hyb_tile_start_kernel(int64_t tiles, int coo_entries, const int *__restrict__ Ai
     tile_start[t] = lo;
 }
 
-int hyb_tile_starts(int64_t rows, int64_t coo_entries, const int *coo_Ai, int32_t *tile_start, hipStream_t s)
+// most COO entries any one tile holds
+__global__ void __launch_bounds__(256)
+hyb_tile_max_kernel(int64_t tiles, const int32_t *__restrict__ tile_start, int *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int n = t < tiles ? tile_start[t + 1] - tile_start[t] : 0;
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) { const int v = __shfl_down(n, o); n = v > n ? v : n; }
+    if ((threadIdx.x & (kWave - 1)) == 0 && n > 0) atomicMax(out, n);
+}
+
+// tile_start[] for the COO part (sorted by row) and *max_in_tile_dev <- the most entries of one tile (zeroed here)
+int hyb_tile_starts(int64_t rows, int64_t coo_entries, const int *coo_Ai, int32_t *tile_start, int *max_in_tile_dev, hipStream_t s)
 {
     const int64_t tiles = ceil_div(rows, kHybTileRows);
+    CMI_HIP(hipMemsetAsync(max_in_tile_dev, 0, sizeof(int), s));
     hipLaunchKernelGGL(hyb_tile_start_kernel, dim3((unsigned)ceil_div(tiles + 1, 256)), dim3(256), 0, s, tiles, (int)coo_entries, coo_Ai, tile_start);
+    hipLaunchKernelGGL(hyb_tile_max_kernel, dim3((unsigned)ceil_div(tiles, 256)), dim3(256), 0, s, tiles, tile_start, max_in_tile_dev);
     CMI_LAUNCH_CHECK("hyb tile starts");
     return CMI_SUCCESS;
 }

@@ -125,20 +125,24 @@ class HybMatrix:
     format = "hyb"
     _plan = None
     _plan_key = None
+    _plan_args = None
 
     def plan(self, stream=None, create=True):
         e, c = self.ell, self.coo
-        key = (c.row_indices.data_ptr(), self.num_rows, self.num_cols, e.num_entries_per_row, c.num_entries, e.values.dtype)
+        key = (c.row_indices.data_ptr(), c.column_indices.data_ptr(), c.values.data_ptr(), e.column_indices.data_ptr(), e.values.data_ptr(),
+               e.pitch, self.num_rows, self.num_cols, e.num_entries_per_row, c.num_entries, e.values.dtype)
         if self._plan_key != key:
             if not create:
                 return None
             self._plan = B.Plan.hyb(e.values.dtype, self.num_rows, self.num_cols, e.num_entries_per_row, c.row_indices, stream=stream)
+            self._plan_args = B.hyb_plan_args(self._plan, e.pitch, e.column_indices, e.values, c.row_indices, c.column_indices, c.values)
             self._plan_key = key
         return self._plan
 
     def invalidate(self):
         self._plan_key = None
         self._plan = None
+        self._plan_args = None
 
 
 def _capturing(stream):
@@ -175,8 +179,7 @@ def multiply(A, x, y, accumulate=False, cfg=None, stream=None):
         hplan = A.plan(stream, create=not _capturing(stream)) if cfg is None and c.num_entries > 0 else None
         if hplan is not None:
             # COO part sorted by row (what the conversions produce): ONE launch, y written once, the host loops' bits
-            B.spmv_hyb_plan(hplan, e.pitch, e.column_indices, e.values, c.row_indices, c.column_indices, c.values, x, y,
-                            accumulate, stream)
+            B.spmv_hyb_plan_args(A._plan_args, x, y, accumulate, stream)  # (arrays validated when the plan was made)
         else:
             B.spmv_hyb(A.num_rows, A.num_cols, e.num_entries_per_row, e.pitch, e.column_indices, e.values,
                        c.row_indices, c.column_indices, c.values, x, y, accumulate, cfg, None, stream)

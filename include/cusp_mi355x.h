@@ -204,10 +204,11 @@ int cmi_tuning_select(int format, int dtype, int64_t num_rows, int64_t num_cols,
  *   CMI_HYB_RULE_COST  the width that minimises the modelled time of the two launches
  *       num_rows * k  +  [the COO part is not empty] * (threshold + relative_speed * coo_entries(k))      (in ELL slots)
  *       -- relative_speed = cost of a COO entry in ELL slots, threshold = fixed cost of the second launch in ELL slots.
- *       The reference's rule is this model's marginal test without the launch term; on MI355X the launch term decides
- *       small matrices (one launch of a padded ELL beats two) and the measured pair is (1.3, 5e6), not (3, 4096):
- *       geometric-mean regret over the tuning set 1.01 against 1.22 for the best pair of the reference's form
- *       (profiles/r02_autotune_hyb.jsonl).                                                                            */
+ *       The reference's rule is this model's marginal test without the launch term.  Measured on MI355X
+ *       (tools/autotune_hyb.py, profiles/r02_autotune_hyb*): while HYB was two launches the launch term decided small
+ *       matrices and the fit was (1.3, 5e6); with the one-launch kernel of cmi_spmv_hyb_plan_* the term vanishes and the
+ *       shipped pair is (2.0, 0) for f64 and (3.3, 0) for f32 -- geometric-mean regret over the tuning set 1.013 / 1.033
+ *       against 1.050 / 1.072 (worst 1.40) for the reference's (3, 4096).                                                */
 typedef enum cmi_hyb_rule_kind { CMI_HYB_RULE_REFERENCE = 0, CMI_HYB_RULE_COST = 1 } cmi_hyb_rule_kind;
 int cmi_tuning_hyb_rule(int dtype, int *kind, double *relative_speed, int64_t *threshold);
 int cmi_tuning_set_hyb_rule(int dtype, int kind, double relative_speed, int64_t threshold);
@@ -250,12 +251,16 @@ int cmi_plan_create_csr(int dtype, int64_t num_rows, int64_t num_cols, int64_t n
 int cmi_set_index_compression(int on);
 int cmi_get_index_compression(void);
 /* HYB: launch shapes of both parts (cfg_* may be NULL) and, when the COO part's row indices are sorted (what every     */
-/* conversion produces: csr_to_other.h:229-306), the per-tile entry ranges that let cmi_spmv_hyb_plan_* run the whole     */
-/* multiply as ONE launch.  That array (one int per 256 rows) is the only device memory a plan owns; cmi_plan_destroy     */
+/* conversion produces: csr_to_other.h:229-306) and the part is light (cmi_plan_hyb_launches), the per-tile entry ranges   */
+/* that let cmi_spmv_hyb_plan_* run the whole multiply as ONE launch.  That array (one int per 256 rows) is the only device memory a plan owns; cmi_plan_destroy     */
 /* frees it.  Synchronises `stream`.                                                                                       */
 int cmi_plan_create_hyb(int dtype, int64_t num_rows, int64_t num_cols, int64_t ell_entries_per_row, int64_t coo_entries,
                         const int32_t *coo_row_indices, const cmi_config *cfg_ell, const cmi_config *cfg_coo, void *stream,
                         cmi_plan **plan);
+/* How many kernels a multiply through this HYB plan launches: 1 (hyb_tile: COO part sorted and light -- at most 4       */
+/* entries per row on average, no 256-row tile holding more than 4096 -- or empty) or 2 (ELL kernel, then a COO kernel        */
+/* accumulating: heavy or unsorted COO parts).  $CMI_HYB_ONE_LAUNCH=0/1 at plan creation overrides the weight rule.           */
+int cmi_plan_hyb_launches(const cmi_plan *plan, int *launches);
 int cmi_plan_destroy(cmi_plan *plan);
 /* The launch shape the plan's multiplies run (SURVEY's cmi_plan_select): kernel CMI_CSR_BALANCED means   */
 /* the profile switched kernels.                                                                            */

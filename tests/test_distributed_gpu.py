@@ -140,7 +140,7 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     env = dict(os.environ, CMI_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
-           "--configs4", "on", "--configs4-grid", "400"]
+           "--cg-iterations", "100", "--configs4", "on", "--configs4-grid", "400"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
