@@ -132,6 +132,10 @@ def _declare(L):
         getattr(L, f"cmi_blas_fill_{suf}").argtypes = [i64, sc, vp, vp]
         getattr(L, f"cmi_blas_dot_{suf}").argtypes = [i64, vp, vp, vp, vp, vp]
         getattr(L, f"cmi_blas_nrm2_{suf}").argtypes = [i64, vp, vp, vp, vp]
+    for suf in ("f64", "f32"):
+        getattr(L, f"cmi_spmv_csr_dot_plan_partials_{suf}").argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, POINTER(c_int), vp]
+        getattr(L, f"cmi_cg_update_fold_{suf}").argtypes = [i64, vp, vp, c_int, vp, vp, vp, POINTER(c_int), vp]
+        getattr(L, f"cmi_cg_direction_x_fold_{suf}").argtypes = [i64, vp, vp, c_int, vp, vp, vp, vp, vp, vp, vp]
     L.cmi_cg_update_f64.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.cmi_cg_direction_f64.argtypes = [i64, vp, vp, vp, vp, vp]
     L.cmi_cg_direction_x_f64.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp]
@@ -683,6 +687,34 @@ def cg_update(rz, yp, p, y, x, r, rr_out, workspace, stream=None, mirror=None):
     check(getattr(lib(), "cmi_cg_update_" + _suffix(r))(r.numel(), _ptr(rz), _ptr(yp), _ptr(p) if x is not None else None, _ptr(y),
                                   _ptr(x) if x is not None else None, _ptr(r), _ptr(rr_out),
                                   mirror.ptr if mirror is not None else None, _ptr(workspace), _stream(stream)))
+    if mirror is not None:
+        mirror.record(stream)
+
+
+def spmv_csr_dot_partials(plan, Ap, Aj, Ax, x, y, w, workspace, stream=None):
+    """cmi_spmv_csr_dot_plan_partials_*: y <- A x, the per-tile partials of <y, w> left in the workspace for cg_update_fold.
+    Returns their count (0: this plan's kernel cannot fuse the dot)."""
+    n = c_int()
+    check(getattr(lib(), "cmi_spmv_csr_dot_plan_partials_" + _suffix(y))(plan.handle, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(y), _ptr(w),
+                                                                         _ptr(workspace), byref(n), _stream(stream)))
+    return n.value
+
+
+def cg_update_fold(rz, yp_out, npartials_yp, y, r, workspace, stream=None):
+    """cmi_cg_update_fold_*: yp <- fold of the workspace's <y, p> partials (also stored to yp_out); r -= (rz/yp) y; returns the
+    number of <r, r> partials left in the workspace's second area."""
+    n = c_int()
+    check(getattr(lib(), "cmi_cg_update_fold_" + _suffix(r))(r.numel(), _ptr(rz), _ptr(yp_out), int(npartials_yp), _ptr(y), _ptr(r),
+                                                             _ptr(workspace), byref(n), _stream(stream)))
+    return n.value
+
+
+def cg_direction_x_fold(rr_new_out, npartials_rr, rr_old, yp, r, p, x, workspace, stream=None, mirror=None):
+    """cmi_cg_direction_x_fold_*: rr_new <- fold of the <r, r> partials (stored to rr_new_out and the HostScalar `mirror`);
+    x += (rr_old/yp) p; p = r + (rr_new/rr_old) p."""
+    check(getattr(lib(), "cmi_cg_direction_x_fold_" + _suffix(r))(r.numel(), _ptr(rr_new_out), mirror.ptr if mirror is not None else None,
+                                                                  int(npartials_rr), _ptr(rr_old), _ptr(yp), _ptr(r), _ptr(p), _ptr(x),
+                                                                  _ptr(workspace), _stream(stream)))
     if mirror is not None:
         mirror.record(stream)
 

@@ -113,7 +113,7 @@ dot_partial_kernel(int64_t n, const T *__restrict__ x, const T *__restrict__ y, 
     }
     const double s = block_sum(acc, slots);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *ticket_of(partial) = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) reset_fold_state(partial);
 }
 
 // Long partial lists (one-shot fused kernels leave up to 65536 of them) are folded by several
@@ -275,7 +275,7 @@ cg_update_kernel(int64_t n, const double *__restrict__ rz, const double *__restr
     }
     const double s = block_sum(acc, slots);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *ticket_of(partial) = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) reset_fold_state(partial);
 }
 
 // p <- r + beta p with beta = rr_new / rr_old read from device memory (cg.inl:100-103, z == r).  With x != null also
@@ -321,13 +321,192 @@ cg_direction_kernel(int64_t n, const double *__restrict__ rr_new, const double *
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fold-ahead: the CONSUMER of a partial list folds it (cmi_cg_update_fold_* / cmi_cg_direction_x_fold_*)
+// ---------------------------------------------------------------------------------------------
+// A fused CG iteration had two one-workgroup-deep reductions between its three big kernels: 2 x (a 4.6 us fold kernel + a
+// launch gap).  Here the kernel that NEEDS the scalar folds the list itself: its first G workgroups (G = one per 1024
+// partials, <= 64; they are dispatched first) fold their chunks exactly as dot_fold_final_kernel does -- same tree, same
+// hand-off -- and the last of them to arrive publishes the sum in kScalarCopies slots (a single 8-byte store each: the value
+// IS the flag; "pending" is a NaN payload no sum produces).  Every workgroup requests its vectors first, then one lane polls
+// its slot (sc1 load, sleeping in between; the producer kernel left the slots pending) -- for all but the first ~2000
+// resident workgroups the first poll succeeds, and it replaces the plain load of the scalar the old kernels did anyway.
+// The spin is bounded: if the value never shows up the kernel goes on with a NaN (wrong result, no hang).
+constexpr int kFoldSpinLimit = 1 << 15; // x ~0.5 us of s_sleep
+
+__device__ __forceinline__ double fold_ahead(int npartial, double *area, double *result_out, double *mirror, double *slots_lds,
+                                             double *value_lds)
+{
+    const int groups = npartial <= kFoldDirect ? 1 : (npartial + kFoldChunk - 1) / kFoldChunk;
+    double *slots = slots_of(area);
+    if ((int)blockIdx.x < groups) { // (uniform per workgroup)
+        const double *partial = area;
+        double *folded = area + kPartialCapacity;
+        double acc = 0.0;
+        bool last = true;
+        if (groups == 1) {
+            for (int i = threadIdx.x; i < npartial; i += blockDim.x) acc += partial[i];
+        } else {
+            const int lo = blockIdx.x * kFoldChunk;
+            const int hi = lo + kFoldChunk < npartial ? lo + kFoldChunk : npartial;
+            double v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = lo + (int)threadIdx.x + k * kBlasBlock;
+                v[k] = i < hi ? partial[i] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc += v[k];
+        }
+        double s = block_sum(acc, slots_lds);
+        if (groups > 1) {
+            __shared__ int is_last;
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(folded + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned int t = __hip_atomic_fetch_add(ticket_of(area), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                is_last = (t == (unsigned)groups - 1);
+            }
+            __syncthreads();
+            last = is_last != 0;
+            if (last) {
+                acc = 0.0;
+                for (int i = threadIdx.x; i < groups; i += blockDim.x) acc += __hip_atomic_load(folded + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads(); // slots_lds is reused
+                s = block_sum(acc, slots_lds);
+            }
+        }
+        if (last) {
+            if (threadIdx.x == 0) {
+                *value_lds = s; // thread 0 holds the sum
+                if (result_out) *result_out = s; // for the kernels behind this one (plain memory, visible at the kernel boundary)
+                if (mirror) *mirror = s;
+                *ticket_of(area) = 0;
+            }
+            __syncthreads();
+            const double v = *value_lds;
+            if (threadIdx.x < kScalarCopies) __hip_atomic_store(slots + threadIdx.x * kScalarStride, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return v;
+        }
+        __syncthreads(); // (value_lds below is written after every thread has left block_sum)
+    }
+    if (threadIdx.x == 0) {
+        const double *slot = slots + (blockIdx.x % kScalarCopies) * kScalarStride;
+        double v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int spin = 0; (unsigned long long)__double_as_longlong(v) == kPendingBits && spin < kFoldSpinLimit; spin++) {
+            __builtin_amdgcn_s_sleep(16);
+            v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *value_lds = v;
+    }
+    __syncthreads();
+    return *value_lds;
+}
+
+// cg_update with the fold of <y, p> in front: yp = fold(area_in) (also left in *yp_out for the direction kernel)
+template <typename T>
+__global__ void __launch_bounds__(kBlasBlock)
+cg_update_fold_kernel(int64_t n, const double *__restrict__ rz, int npartial_in, double *__restrict__ area_in, double *__restrict__ yp_out,
+                      const T *__restrict__ y, T *__restrict__ r, double *__restrict__ area_out, int vec, int pol)
+{
+    typedef typename vec16<T>::type V;
+    constexpr int W = vec16<T>::n;
+    __shared__ double slots[kBlasBlock / kWave];
+    __shared__ double value;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nv = n / W;
+    // this workgroup's first vectors are requested before anybody waits for the scalar
+    V y0 = {}, r0 = {};
+    const bool first = vec && t < nv;
+    if (first) { y0 = reinterpret_cast<const V *>(y)[t]; r0 = reinterpret_cast<V *>(r)[t]; }
+    const double rzv = *rz;
+    const double ypv = fold_ahead(npartial_in, area_in, yp_out, nullptr, slots, &value);
+    const T alpha = (T)(rzv / ypv);
+    double acc = 0.0;
+    if (vec) {
+        for (int64_t i = t; i < nv; i += stride) {
+            V yv, rv;
+            if (i == t) { yv = y0; rv = r0; }
+            else { yv = reinterpret_cast<const V *>(y)[i]; rv = reinterpret_cast<V *>(r)[i]; }
+#pragma unroll
+            for (int k = 0; k < W; k++) rv[k] = (-alpha) * yv[k] + rv[k];
+            st_policy(reinterpret_cast<V *>(r) + i, rv, (pol & 4) != 0);
+#pragma unroll
+            for (int k = 0; k < W; k++) acc += (double)rv[k] * (double)rv[k];
+        }
+        if (t < n - nv * W) {
+            const int64_t i = nv * W + t;
+            const T ri = (-alpha) * y[i] + r[i];
+            r[i] = ri;
+            acc += (double)ri * (double)ri;
+        }
+    } else {
+        for (int64_t i = t; i < n; i += stride) {
+            const T ri = (-alpha) * y[i] + r[i];
+            r[i] = ri;
+            acc += (double)ri * (double)ri;
+        }
+    }
+    __syncthreads(); // slots (block_sum) may still be read by thread 0 of a folding workgroup
+    const double s = block_sum(acc, slots);
+    if (threadIdx.x == 0) area_out[blockIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) reset_fold_state(area_out);
+}
+
+// cg_direction_x with the fold of <r, r> in front: rr_new = fold(area_in) (left in *rr_new_out and the host mirror)
+template <typename T>
+__global__ void __launch_bounds__(kBlasBlock)
+cg_direction_fold_kernel(int64_t n, int npartial_in, double *__restrict__ area_in, double *__restrict__ rr_new_out, double *__restrict__ mirror,
+                         const double *__restrict__ rr_old, const double *__restrict__ yp, const T *__restrict__ r, T *__restrict__ p,
+                         T *__restrict__ x, int vec, int pol)
+{
+    typedef typename vec16<T>::type V;
+    constexpr int W = vec16<T>::n;
+    __shared__ double slots[kBlasBlock / kWave];
+    __shared__ double value;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nv = n / W;
+    V r0 = {}, p0 = {}, x0 = {};
+    const bool first = vec && t < nv;
+    if (first) { r0 = reinterpret_cast<const V *>(r)[t]; p0 = reinterpret_cast<V *>(p)[t]; x0 = reinterpret_cast<V *>(x)[t]; }
+    const double rro = *rr_old, ypv = *yp;
+    const double rrn = fold_ahead(npartial_in, area_in, rr_new_out, mirror, slots, &value);
+    const T alpha = (T)(rro / ypv);
+    const T beta = (T)(rrn / rro);
+    if (vec) {
+        for (int64_t i = t; i < nv; i += stride) {
+            V rv, pv, xv;
+            if (i == t) { rv = r0; pv = p0; xv = x0; }
+            else { rv = reinterpret_cast<const V *>(r)[i]; pv = reinterpret_cast<V *>(p)[i]; xv = reinterpret_cast<V *>(x)[i]; }
+#pragma unroll
+            for (int k = 0; k < W; k++) xv[k] = alpha * pv[k] + xv[k];
+            st_policy(reinterpret_cast<V *>(x) + i, xv, (pol & 1) != 0);
+#pragma unroll
+            for (int k = 0; k < W; k++) pv[k] = T(1) * rv[k] + beta * pv[k];
+            st_policy(reinterpret_cast<V *>(p) + i, pv, (pol & 2) != 0);
+        }
+        if (t < n - nv * W) {
+            const int64_t i = nv * W + t;
+            x[i] = alpha * p[i] + x[i];
+            p[i] = T(1) * r[i] + beta * p[i];
+        }
+    } else {
+        for (int64_t i = t; i < n; i += stride) {
+            x[i] = alpha * p[i] + x[i];
+            p[i] = T(1) * r[i] + beta * p[i];
+        }
+    }
+}
+
 static bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 
 } // namespace cmi
 
 using namespace cmi;
 
-CMI_API size_t cmi_blas_workspace_bytes(void) { return (size_t)(kPartialCapacity + kFoldedMax + 1) * sizeof(double); }
+CMI_API size_t cmi_blas_workspace_bytes(void) { return (size_t)2 * kFoldArea * sizeof(double); } // two fold areas (common.h)
 
 namespace {
 
@@ -438,7 +617,73 @@ int cg_direction_impl(int64_t n, const double *rr_new_dev, const double *rr_old_
     return CMI_SUCCESS;
 }
 
+template <typename T>
+int cg_update_fold_impl(int64_t n, const double *rz_dev, double *yp_dev, int npartials_yp, const T *y, T *r, void *workspace,
+                        int *npartials_rr, void *stream)
+{
+    if (npartials_rr) *npartials_rr = 0;
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_update_fold: negative n");
+    if (!rz_dev || !yp_dev || !workspace || !npartials_rr) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_update_fold: null scalar, workspace or count");
+    if (npartials_yp < 1 || npartials_yp > kPartialCapacity) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_update_fold: partial count out of range");
+    if (n > 0 && (!y || !r)) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_update_fold: null array");
+    const int groups = npartials_yp <= kFoldDirect ? 1 : (npartials_yp + kFoldChunk - 1) / kFoldChunk;
+    int grid = fused_grid(n, vec16<T>::n);
+    if (grid < groups) grid = groups; // the first `groups` workgroups fold; extra ones find no elements
+    const int vec = aligned16(y) && aligned16(r);
+    double *area_in = (double *)workspace, *area_out = (double *)workspace + kFoldArea;
+    hipLaunchKernelGGL((cg_update_fold_kernel<T>), dim3(grid), dim3(kBlasBlock), 0, as_stream(stream), n, rz_dev, npartials_yp, area_in, yp_dev,
+                       y, r, area_out, vec, cg_store_policy());
+    CMI_LAUNCH_CHECK("cg_update_fold");
+    *npartials_rr = grid;
+    return CMI_SUCCESS;
+}
+
+template <typename T>
+int cg_direction_fold_impl(int64_t n, double *rr_new_dev, double *rr_host_mirror, int npartials_rr, const double *rr_old_dev,
+                           const double *yp_dev, const T *r, T *p, T *x, void *workspace, void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_direction_x_fold: negative n");
+    if (!rr_new_dev || !rr_old_dev || !yp_dev || !workspace) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_direction_x_fold: null scalar or workspace");
+    if (npartials_rr < 1 || npartials_rr > kPartialCapacity) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_direction_x_fold: partial count out of range");
+    if (n > 0 && (!r || !p || !x)) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cg_direction_x_fold: null array");
+    const int groups = npartials_rr <= kFoldDirect ? 1 : (npartials_rr + kFoldChunk - 1) / kFoldChunk;
+    int grid = stream_grid(n, vec16<T>::n);
+    if (grid < groups) grid = groups;
+    const int vec = aligned16(r) && aligned16(p) && aligned16(x);
+    double *area_in = (double *)workspace + kFoldArea;
+    hipLaunchKernelGGL((cg_direction_fold_kernel<T>), dim3(grid), dim3(kBlasBlock), 0, as_stream(stream), n, npartials_rr, area_in, rr_new_dev,
+                       rr_host_mirror, rr_old_dev, yp_dev, r, p, x, vec, cg_store_policy());
+    CMI_LAUNCH_CHECK("cg_direction_x_fold");
+    return CMI_SUCCESS;
+}
+
 } // namespace
+
+// Fold-ahead forms of the two steps (see fold_ahead above): the reductions' folds ride at the front of their consumers.
+//   cmi_spmv_csr_dot_plan_partials_*  leaves npartials_yp partials of <y, p> in the workspace           (spmv_csr.hip)
+//   cmi_cg_update_fold_*              yp <- their sum (also stored to *yp_dev); r <- r - (rz/yp) y; leaves npartials_rr partials of <r, r>
+//   cmi_cg_direction_x_fold_*         rr_new <- their sum (stored to *rr_new_dev and the host mirror); x <- x + (rr_old/yp) p; p <- r + (rr_new/rr_old) p
+// Same arithmetic and the same summation trees as the plain forms: bit-identical results.
+CMI_API int cmi_cg_update_fold_f64(int64_t n, const double *rz_dev, double *yp_dev, int npartials_yp, const double *y, double *r,
+                                   void *workspace, int *npartials_rr, void *stream)
+{
+    return cg_update_fold_impl<double>(n, rz_dev, yp_dev, npartials_yp, y, r, workspace, npartials_rr, stream);
+}
+CMI_API int cmi_cg_update_fold_f32(int64_t n, const double *rz_dev, double *yp_dev, int npartials_yp, const float *y, float *r,
+                                   void *workspace, int *npartials_rr, void *stream)
+{
+    return cg_update_fold_impl<float>(n, rz_dev, yp_dev, npartials_yp, y, r, workspace, npartials_rr, stream);
+}
+CMI_API int cmi_cg_direction_x_fold_f64(int64_t n, double *rr_new_dev, double *rr_host_mirror, int npartials_rr, const double *rr_old_dev,
+                                        const double *yp_dev, const double *r, double *p, double *x, void *workspace, void *stream)
+{
+    return cg_direction_fold_impl<double>(n, rr_new_dev, rr_host_mirror, npartials_rr, rr_old_dev, yp_dev, r, p, x, workspace, stream);
+}
+CMI_API int cmi_cg_direction_x_fold_f32(int64_t n, double *rr_new_dev, double *rr_host_mirror, int npartials_rr, const double *rr_old_dev,
+                                        const double *yp_dev, const float *r, float *p, float *x, void *workspace, void *stream)
+{
+    return cg_direction_fold_impl<float>(n, rr_new_dev, rr_host_mirror, npartials_rr, rr_old_dev, yp_dev, r, p, x, workspace, stream);
+}
 
 CMI_API int cmi_cg_update_f64(int64_t n, const double *rz_dev, const double *yp_dev, const double *p, const double *y,
                               double *x, double *r, double *rr_dev, double *rr_host_mirror, void *workspace, void *stream)

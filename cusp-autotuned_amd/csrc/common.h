@@ -73,11 +73,28 @@ constexpr int kPartialCapacity = 1 << 16;
 constexpr int kFoldChunk = 1024;
 constexpr int kFoldedMax = kPartialCapacity / kFoldChunk;
 int reduce_partials_f64(int npartial, double *workspace, double *result, hipStream_t s);
-// workspace layout (doubles): [0, kPartialCapacity) partials | kFoldedMax folded | the fold's ticket counter.
-// Every kernel that leaves partials also zeroes the ticket, so the workspace needs no initialisation.
-__device__ __forceinline__ unsigned int *ticket_of(double *workspace)
+// workspace layout: TWO fold areas of kFoldArea doubles (cmi_blas_workspace_bytes); the plain entry points use the first.
+//   area (doubles): [0, kPartialCapacity) partials | kFoldedMax folded | the fold's ticket counter (+ pad) |
+//                   kScalarCopies copies of the folded scalar, one 128-byte line each ("slots", fold-ahead only)
+// Every kernel that leaves partials also resets the ticket and the slots (reset_fold_state), so the workspace needs no
+// initialisation.
+constexpr int kScalarCopies = 16, kScalarStride = 16; // doubles
+constexpr int kFoldArea = kPartialCapacity + kFoldedMax + 2 + kScalarCopies * kScalarStride;
+// "not folded yet": a quiet NaN with a payload no reduction produces
+constexpr unsigned long long kPendingBits = 0x7FF8C0DEC0DE0000ull;
+__device__ __forceinline__ unsigned int *ticket_of(double *area)
 {
-    return reinterpret_cast<unsigned int *>(workspace + kPartialCapacity + kFoldedMax);
+    return reinterpret_cast<unsigned int *>(area + kPartialCapacity + kFoldedMax);
+}
+__device__ __forceinline__ double *slots_of(double *area) { return area + kPartialCapacity + kFoldedMax + 2; }
+// by ONE thread of the kernel that leaves partials in `area` (the consumer's fold starts from a clean ticket and "pending" slots;
+// nobody reads either before that kernel has ended)
+__device__ __forceinline__ void reset_fold_state(double *area)
+{
+    *ticket_of(area) = 0;
+    double *s = slots_of(area);
+#pragma unroll
+    for (int c = 0; c < kScalarCopies; c++) reinterpret_cast<unsigned long long *>(s)[c * kScalarStride] = kPendingBits;
 }
 
 // ---- cross-lane steps on the DPP path (gfx9 family: row_shr, row_bcast:15/31, wave_shr:1) -----------------------------

@@ -153,7 +153,7 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
             }
             if constexpr (DOT) {
                 tile_dot_store(d, dot_slots, dot_partial + tile);
-                if (tile == 0 && tid == 0) *ticket_of(dot_partial) = 0;
+                if (tile == 0 && tid == 0) reset_fold_state(dot_partial);
             }
             return;
         }
@@ -337,7 +337,7 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
     }
     if constexpr (DOT) {
         tile_dot_store(d, dot_slots, dot_partial + tile);
-        if (tile == 0 && tid == 0) *ticket_of(dot_partial) = 0;
+        if (tile == 0 && tid == 0) reset_fold_state(dot_partial);
     }
 }
 
@@ -847,6 +847,11 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
             const int64_t tile_entries = (int64_t)block * ipt * 4;
             if (up != rpb && up <= block && (double)up * mean + 3.0 <= (double)tile_entries) rpb = up;
         }
+        // ... and one partial per tile must fit the workspace: a table shape with small tiles (f32's 96 rows of 128 lanes at 10^7
+        // rows: 104 000 tiles) is doubled -- lanes and rows together, the same fill of the LDS pass -- until it does
+        int block = c.block_size; // (shadows the function's: the dot instance may widen it)
+        if (w && dot_partial && (!user || user->kernel == CMI_KERNEL_AUTO || user->rows_per_block == 0) && c.threads_per_row <= 1)
+            while (ceil_div(rows, rpb) > kPartialCapacity && block * 2 <= 1024) { block *= 2; rpb *= 2; }
         int tpr = c.threads_per_row <= 1 ? 1 : c.threads_per_row;
         if (tpr > 64 || (tpr & (tpr - 1)) != 0) return fail(CMI_ERROR_NOT_SUPPORTED, "csr_stream: threads_per_row must be 0/1 or a power of two <= 64");
         // threads_per_row == 0: rows of kLongRowPerLane entries per lane of a group (at least kLongRowMin) or more
@@ -1017,6 +1022,24 @@ CMI_API int cmi_spmv_csr_dot_plan_f32(const cmi_plan *plan, const int32_t *Ap, c
 {
     if (int st = cmi::plan_is_csr(plan, CMI_F32, "cmi_spmv_csr_dot_plan_f32")) return st;
     return cmi::spmv_csr_dot<float>(CMI_F32, plan->rows, plan->cols, plan->nnz, Ap, Aj, Ax, x, y, w, dot_dev, workspace, nullptr, stream, plan);
+}
+
+// y <- A x and the per-tile partials of <y, w> LEFT in the workspace (no fold): the fold rides at the front of
+// cmi_cg_update_fold_* (blas1.hip).  *npartials = their count, or 0 when the plan's kernel cannot fuse the dot (y is computed;
+// the caller then runs cmi_blas_dot_* and the plain cmi_cg_update_*).
+CMI_API int cmi_spmv_csr_dot_plan_partials_f64(const cmi_plan *plan, const int32_t *Ap, const int32_t *Aj, const double *Ax,
+                                               const double *x, double *y, const double *w, void *workspace, int *npartials, void *stream)
+{
+    if (int st = cmi::plan_is_csr(plan, CMI_F64, "cmi_spmv_csr_dot_plan_partials_f64")) return st;
+    if ((!w && plan->rows > 0) || !workspace || !npartials) return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_csr_dot_plan_partials: null w, workspace or count");
+    return cmi::spmv_csr<double>(CMI_F64, plan->rows, plan->cols, plan->nnz, Ap, Aj, Ax, x, y, 0, nullptr, stream, w, (double *)workspace, npartials, plan);
+}
+CMI_API int cmi_spmv_csr_dot_plan_partials_f32(const cmi_plan *plan, const int32_t *Ap, const int32_t *Aj, const float *Ax,
+                                               const float *x, float *y, const float *w, void *workspace, int *npartials, void *stream)
+{
+    if (int st = cmi::plan_is_csr(plan, CMI_F32, "cmi_spmv_csr_dot_plan_partials_f32")) return st;
+    if ((!w && plan->rows > 0) || !workspace || !npartials) return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_csr_dot_plan_partials: null w, workspace or count");
+    return cmi::spmv_csr<float>(CMI_F32, plan->rows, plan->cols, plan->nnz, Ap, Aj, Ax, x, y, 0, nullptr, stream, w, (double *)workspace, npartials, plan);
 }
 
 // Longest row of a CSR matrix (device pass + read-back; synchronises the stream).  A plan does this itself;

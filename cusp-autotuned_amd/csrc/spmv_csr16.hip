@@ -191,7 +191,7 @@ csr_stream16_kernel(int64_t num_rows, int64_t num_entries, int num_cols, const i
     }
     if constexpr (DOT) {
         tile_dot_store(d, dot_slots, dot_partial + tile);
-        if (tile == 0 && tid == 0) *ticket_of(dot_partial) = 0;
+        if (tile == 0 && tid == 0) reset_fold_state(dot_partial);
     }
 }
 

@@ -123,7 +123,7 @@ ell_row_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict
     }
     if constexpr (DOT) {
         tile_dot_store(dsum, dot_slots, dot_partial + tile);
-        if (tile == 0 && threadIdx.x == 0) *ticket_of(dot_partial) = 0;
+        if (tile == 0 && threadIdx.x == 0) reset_fold_state(dot_partial);
     }
 }
 
@@ -255,7 +255,7 @@ dia_row_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t pi
     if (live) st<NTS>(y + row, acc);
     if constexpr (DOT) {
         tile_dot_store(live ? (double)acc * (double)w[row] : 0.0, dot_slots, dot_partial + tile);
-        if (tile == 0 && threadIdx.x == 0) *ticket_of(dot_partial) = 0;
+        if (tile == 0 && threadIdx.x == 0) reset_fold_state(dot_partial);
     }
 }
 
@@ -321,7 +321,7 @@ dia_row2_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t p
         double d = live0 ? (double)acc0 * (double)w[row] : 0.0;
         if (live1) d += (double)acc1 * (double)w[row + 1];
         tile_dot_store(d, dot_slots, dot_partial + tile);
-        if (tile == 0 && threadIdx.x == 0) *ticket_of(dot_partial) = 0;
+        if (tile == 0 && threadIdx.x == 0) reset_fold_state(dot_partial);
     }
 }
 

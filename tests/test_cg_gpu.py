@@ -225,3 +225,67 @@ def test_cg_1e8_rows_single_gpu(cmi):
     y = torch.empty(N, dtype=torch.float64, device="cuda")
     cmi.multiply(A, b, y)
     assert torch.equal(y, bench.stencil_expected(torch, cmi, m, n, 0, N, "cuda"))
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("grid", [(1, 1), (7, 1), (40, 25), (775, 774), (1733, 1731), (3162, 3162)])
+def test_fold_ahead_steps_are_the_plain_steps_bit_for_bit(cmi, grid, tag):
+    """cmi_spmv_csr_dot_plan_partials_* + cmi_cg_update_fold_* + cmi_cg_direction_x_fold_* (the folds of <y,p> and <r,r> at the
+    front of their consumers: three launches) against cmi_spmv_csr_dot_plan_* + cmi_cg_update_* + cmi_cg_direction_x_* (five
+    launches): the same summation trees, so y, <y,p>, r, <r,r> (device and host mirror), x and p agree BIT FOR BIT -- from one
+    partial (a single workgroup folds) to 52 000 (51 folding workgroups and a last arriver), repeated to shake the hand-off."""
+    import torch
+    tdt = torch.float64 if tag == "f64" else torch.float32
+    m, n = grid
+    A = cmi.poisson5pt(m, n, "csr", dtype=tdt)
+    N = A.num_rows
+    plan = A.plan()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    p0 = torch.randn(N, dtype=tdt, device="cuda", generator=g)
+    r0 = torch.randn(N, dtype=tdt, device="cuda", generator=g)
+    x0 = torch.randn(N, dtype=tdt, device="cuda", generator=g)
+    rz = (r0.double() ** 2).sum().reshape(1)
+    ws = cmi.blas_workspace()
+    for rep in range(6 if N > 10**6 else 25):
+        # plain
+        y1, r1, p1, x1 = torch.empty_like(p0), r0.clone(), p0.clone(), x0.clone()
+        yp1, rr1 = torch.zeros(1, dtype=torch.float64, device="cuda"), torch.zeros(1, dtype=torch.float64, device="cuda")
+        h1 = cmi.binding.HostScalar()
+        cmi.spmv_csr_dot(N, N, A.row_offsets, A.column_indices, A.values, p1, y1, p1, yp1, ws, plan=plan)
+        cmi.cg_update(rz, yp1, None, y1, None, r1, rr1, ws, mirror=h1)
+        cmi.cg_direction_x(rr1, rz, yp1, r1, p1, x1)
+        # fold-ahead
+        y2, r2, p2, x2 = torch.empty_like(p0), r0.clone(), p0.clone(), x0.clone()
+        yp2, rr2 = torch.full((1,), 7.0, dtype=torch.float64, device="cuda"), torch.full((1,), 7.0, dtype=torch.float64, device="cuda")
+        h2 = cmi.binding.HostScalar()
+        np_yp = cmi.binding.spmv_csr_dot_partials(plan, A.row_offsets, A.column_indices, A.values, p2, y2, p2, ws)
+        if np_yp == 0:  # more row tiles than the workspace holds partials (f32's small tiles at 10^7 rows): y only, no partials
+            c = plan.config()
+            assert -(-N // c.rows_per_block) > 65536 and torch.equal(y1, y2)
+            return
+        np_rr = cmi.binding.cg_update_fold(rz, yp2, np_yp, y2, r2, ws)
+        assert np_rr > 0
+        cmi.binding.cg_direction_x_fold(rr2, np_rr, rz, yp2, r2, p2, x2, ws, mirror=h2)
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y2) and torch.equal(yp1, yp2), (grid, rep, float(yp1), float(yp2))
+        assert torch.equal(r1, r2) and torch.equal(rr1, rr2), (grid, rep, float(rr1), float(rr2))
+        assert torch.equal(x1, x2) and torch.equal(p1, p2), (grid, rep)
+        assert h1.wait() == h2.wait() == float(rr1)
+        assert math.isfinite(float(yp2)) and math.isfinite(float(rr2))
+        h1.close()
+        h2.close()
+
+
+def test_cg_fold_ahead_on_and_off_give_the_same_solve(cmi, monkeypatch):
+    import torch
+    A = cmi.poisson5pt(300, 217, "csr")
+    N = A.num_rows
+    b = cmi.fill_x(N).cuda()
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CMI_CG_FOLD_AHEAD", flag)
+        x = torch.zeros(N, dtype=torch.float64, device="cuda")
+        mon = cmi.krylov.cg(A, x, b, iteration_limit=80, relative_tolerance=1e-12)
+        out[flag] = (mon.residuals, x)
+    assert out["1"][0] == out["0"][0]            # the same residual history, bit for bit
+    assert torch.equal(out["1"][1], out["0"][1])
