@@ -231,7 +231,8 @@ int cmi_hyb_entries_per_row(int dtype, int64_t num_rows, const int32_t *Ap, int 
 /* and recomputes `row_starts` on the host per call.                               */
 /*   cmi_plan_create reads the index array on the device and SYNCHRONISES `stream`  */
 /*   (one small kernel + a 16-byte read-back); everything after it is asynchronous.  */
-/*   A plan (HYB's aside) owns no device memory and does not keep the pointers: arrays are */
+/*   A plan owns no device memory (except a HYB plan's tile ranges and the opt-in 16-bit column copy of   */
+/*   CMI_CSR_STREAM_C16, both freed by cmi_plan_destroy) and does not keep the pointers: the arrays are   */
 /*   passed again at every multiply; they must be the ones the plan was made for     */
 /*   (same sizes are checked; contents are the caller's promise -- a plan made for    */
 /*   other contents can cost speed or, for COO, give wrong sums: make a new plan      */
