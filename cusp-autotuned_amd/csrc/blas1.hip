@@ -224,6 +224,7 @@ template <typename V> __device__ __forceinline__ void st_policy(V *p, V v, bool 
     else *p = v;
 }
 
+
 template <typename T>
 __global__ void __launch_bounds__(kBlasBlock)
 cg_update_kernel(int64_t n, const double *__restrict__ rz, const double *__restrict__ yp, const T *__restrict__ p,

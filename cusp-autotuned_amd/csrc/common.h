@@ -284,7 +284,7 @@ constexpr int kHybFusedMaxInTile = 4096;
 // spmv_csr16.hip: the plan's 16-bit column copy (built only if every tile qualifies) and the multiply that reads it
 int csr16_build(cmi_plan *p, const int *Ap, const int *Aj, hipStream_t s);
 int csr16_multiply_f64(const cmi_plan *p, const int *Ap, const double *Ax, const double *x, double *y, int accumulate,
-                       hipStream_t s, const double *w, double *dot_partial, int *dot_partials);
+                       hipStream_t s, const double *w, double *dot_partial, int *dot_partials, int cache_policy);
 int csr16_multiply_f32(const cmi_plan *p, const int *Ap, const float *Ax, const float *x, float *y, int accumulate,
-                       hipStream_t s, const float *w, double *dot_partial, int *dot_partials);
+                       hipStream_t s, const float *w, double *dot_partial, int *dot_partials, int cache_policy);
 }

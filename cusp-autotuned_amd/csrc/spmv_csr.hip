@@ -815,7 +815,17 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         select_config(CMI_FORMAT_CSR, dtype, rows, cols, nnz, user, &c);
     hipStream_t s = as_stream(stream);
     const int block = c.block_size;
-    const int pol = c.nontemporal & 3;
+    int pol = c.nontemporal & 3;
+    // The fused <y, w> instance runs inside a solver, between vector kernels whose vectors (p, r, y: 240 MB) would fit the
+    // 256 MiB Infinity Cache if the matrix streams did not push them out: here the once-read index / value streams carry the nt
+    // hint whatever the table says for the stand-alone multiply (where plain loads measured equal or better).  CG iteration on the
+    // headline matrix 263-268 -> 255-257 us, with the 16-bit column copy 248-251 -> 245-248 (profiles/r02_cg_dot_policy.txt;
+    // the y-store hint and load hints in the vector kernels measured no effect: r02_cg_y_store_policy.txt,
+    // r02_cg_vector_load_policy.txt).  $CMI_DOT_POLICY=0..3 overrides (measurements).
+    if (w && dot_partial) {
+        static const int dot_pol = [] { const char *e = std::getenv("CMI_DOT_POLICY"); return e ? std::atoi(e) & 3 : -1; }();
+        pol = dot_pol >= 0 ? dot_pol : (pol | kPolLoadNT);
+    }
     int st = CMI_SUCCESS;
 
     switch (c.kernel) {
@@ -889,8 +899,8 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     case CMI_CSR_STREAM_C16: { // the plan's 16-bit column copy (spmv_csr16.hip); Aj itself is not read
         if (!plan || !plan->csr16_cols) return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_CSR_STREAM_C16 runs through a plan of cmi_plan_create_csr only");
         if (reinterpret_cast<uintptr_t>(Ax) % 16 != 0) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream_c16: values must be 16-byte aligned");
-        if constexpr (std::is_same<T, double>::value) return csr16_multiply_f64(plan, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials);
-        else return csr16_multiply_f32(plan, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials);
+        if constexpr (std::is_same<T, double>::value) return csr16_multiply_f64(plan, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol);
+        else return csr16_multiply_f32(plan, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol);
     }
     case CMI_CSR_STREAM_PIPE: {
         const int rpb = c.rows_per_block;

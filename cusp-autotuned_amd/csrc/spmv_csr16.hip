@@ -197,7 +197,7 @@ csr_stream16_kernel(int64_t num_rows, int64_t num_entries, int num_cols, const i
 
 template <typename T>
 static int csr16_multiply(const cmi_plan *p, const int *Ap, const T *Ax, const T *x, T *y, int accumulate, hipStream_t s,
-                          const T *w, double *dot_partial, int *dot_partials)
+                          const T *w, double *dot_partial, int *dot_partials, int pol)
 {
     const cmi_config &c = p->cfg;
     const int block = c.block_size, ipt = c.items_per_thread, rpb = c.rows_per_block;
@@ -211,7 +211,7 @@ static int csr16_multiply(const cmi_plan *p, const int *Ap, const T *Ax, const T
     if (lds > 160 * 1024) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream_c16: tile does not fit 160 KiB of LDS");
     const bool dot = w && dot_partial && tiles <= kPartialCapacity;
     int st = CMI_SUCCESS;
-    with_policy(c.nontemporal & 3, [&](auto P) {
+    with_policy(pol & 3, [&](auto P) {
         constexpr int POL = decltype(P)::value;
         auto go = [&](auto I) {
             constexpr int IPT = decltype(I)::value;
@@ -232,14 +232,14 @@ static int csr16_multiply(const cmi_plan *p, const int *Ap, const T *Ax, const T
 }
 
 int csr16_multiply_f64(const cmi_plan *p, const int *Ap, const double *Ax, const double *x, double *y, int accumulate,
-                       hipStream_t s, const double *w, double *dot_partial, int *dot_partials)
+                       hipStream_t s, const double *w, double *dot_partial, int *dot_partials, int pol)
 {
-    return csr16_multiply<double>(p, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials);
+    return csr16_multiply<double>(p, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol);
 }
 int csr16_multiply_f32(const cmi_plan *p, const int *Ap, const float *Ax, const float *x, float *y, int accumulate,
-                       hipStream_t s, const float *w, double *dot_partial, int *dot_partials)
+                       hipStream_t s, const float *w, double *dot_partial, int *dot_partials, int pol)
 {
-    return csr16_multiply<float>(p, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials);
+    return csr16_multiply<float>(p, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol);
 }
 
 } // namespace cmi

@@ -100,6 +100,16 @@ template <typename A, typename V> void multiply_dot(const A &a, const V &p, V &y
     cusp::detail::check(cmi_spmv_dia_dot_f64(a.num_rows, a.num_cols, a.values.num_cols, a.values.pitch, a.diagonal_offsets.data(),
                                              cusp::detail::data_of(a.values), p.data(), y.data(), p.data(), yp, ws, cusp::detail::forced_config(), nullptr));
 }
+// HYB whose COO part is empty (the tuned width rule keeps regular matrices entirely in the ELL part): the ELL kernel's fused dot
+template <typename A, typename V> void multiply_dot(const A &a, const V &p, V &y, double *yp, void *ws, cusp::hyb_format)
+{
+    if (a.coo.num_entries == 0 && a.ell.column_indices.pitch == a.ell.values.pitch) {
+        multiply_dot(a.ell, p, y, yp, ws, cusp::ell_format());
+        return;
+    }
+    cusp::multiply(a, p, y);
+    cusp::detail::check(cmi_blas_dot_f64(a.num_rows, y.data(), p.data(), yp, ws, nullptr));
+}
 template <typename A, typename V, typename Format> void multiply_dot(const A &a, const V &p, V &y, double *yp, void *ws, Format)
 {
     cusp::multiply(a, p, y);

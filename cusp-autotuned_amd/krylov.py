@@ -154,7 +154,7 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
     import torch
     from . import binding as B
     from .distributed import ShardedCsr
-    from .matrices import CsrMatrix, DiaMatrix, EllMatrix
+    from .matrices import CsrMatrix, DiaMatrix, EllMatrix, HybMatrix
     dev = x.device
     rr = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(2)]  # <r,r> ping-pong
     yp = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -185,6 +185,9 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
         elif not f64:
             spmv(p, y)
             B.blas_dotd(y, p, yp, ops.ws)
+        elif isinstance(A, HybMatrix) and A.coo.num_entries == 0:   # everything in the ELL part: its fused dot
+            e = A.ell
+            B.spmv_ell_dot(A.num_rows, A.num_cols, e.num_entries_per_row, e.pitch, e.column_indices, e.values, p, y, p, yp, ops.ws)
         elif isinstance(A, EllMatrix):
             B.spmv_ell_dot(A.num_rows, A.num_cols, A.num_entries_per_row, A.pitch, A.column_indices, A.values, p, y, p, yp, ops.ws,
                            row_lengths=A.row_lengths)
