@@ -92,8 +92,9 @@ def _declare(L):
     L.cmi_ipc_close_handle.argtypes = [vp]
     L.cmi_copy_ranges.argtypes = [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), vp]
     L.cmi_spmv_csr_dot_f64.argtypes = [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, cfgp, vp]
-    L.cmi_spmv_ell_dot_f64.argtypes = [i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, cfgp, vp]
-    L.cmi_spmv_dia_dot_f64.argtypes = [i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, cfgp, vp]
+    for suf in ("f64", "f32"):
+        getattr(L, f"cmi_spmv_ell_dot_{suf}").argtypes = [i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, cfgp, vp]
+        getattr(L, f"cmi_spmv_dia_dot_{suf}").argtypes = [i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, cfgp, vp]
     L.cmi_tuning_load.argtypes = [c_char_p]
     L.cmi_tuning_save.argtypes = [c_char_p]
     L.cmi_tuning_set.argtypes = [c_int, c_int, c_double, cfgp]
@@ -158,6 +159,7 @@ def _declare(L):
     L.cmi_plan_create_hyb.argtypes = [c_int, i64, i64, i64, i64, vp, cfgp, cfgp, vp, POINTER(c_void_p)]
     for suf in ("f64", "f32"):
         getattr(L, f"cmi_spmv_hyb_plan_{suf}").argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+        getattr(L, f"cmi_spmv_hyb_dot_plan_{suf}").argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     for suf in ("f64", "f32"):
         getattr(L, f"cmi_spmv_csr_plan_{suf}").argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
         getattr(L, f"cmi_spmv_coo_plan_{suf}").argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
@@ -374,27 +376,29 @@ def spmv_csr_dot(num_rows, num_cols, Ap, Aj, Ax, x, y, w, result, workspace, cfg
 
 
 def spmv_ell_dot(num_rows, num_cols, width, pitch, Aj, Ax, x, y, w, result, workspace, row_lengths=None, cfg=None, stream=None):
-    """ELL: y <- A x and result[0] <- <y, w> in one pass (f64; cmi_spmv_ell_dot_f64)."""
+    """ELL: y <- A x and result[0] <- <y, w> (a double) in one pass (cmi_spmv_ell_dot_{f64,f32})."""
     import torch
-    for t, n in ((Ax, "Ax"), (x, "x"), (y, "y"), (w, "w"), (result, "result")):
-        _need(t, n, torch.float64)
+    for t, n in ((Ax, "Ax"), (x, "x"), (y, "y"), (w, "w")):
+        _need(t, n, y.dtype)
+    _need(result, "result", torch.float64)
     _need(Aj, "Aj", torch.int32)
     if x.numel() != num_cols or y.numel() != num_rows or w.numel() != num_rows or Aj.numel() < width * pitch or Ax.numel() < width * pitch:
         raise ValueError("spmv_ell_dot: array lengths do not match the matrix shape")
-    check(lib().cmi_spmv_ell_dot_f64(num_rows, num_cols, width, pitch, _ptr(Aj), _ptr(Ax), _ptr(row_lengths), _ptr(x), _ptr(y), _ptr(w),
-                                     _ptr(result), _ptr(workspace), _cfg(cfg), _stream(stream)))
+    check(getattr(lib(), "cmi_spmv_ell_dot_" + _suffix(y))(num_rows, num_cols, width, pitch, _ptr(Aj), _ptr(Ax), _ptr(row_lengths), _ptr(x), _ptr(y),
+                                                           _ptr(w), _ptr(result), _ptr(workspace), _cfg(cfg), _stream(stream)))
 
 
 def spmv_dia_dot(num_rows, num_cols, num_diagonals, pitch, offsets, values, x, y, w, result, workspace, cfg=None, stream=None):
-    """DIA: y <- A x and result[0] <- <y, w> in one pass (f64; cmi_spmv_dia_dot_f64)."""
+    """DIA: y <- A x and result[0] <- <y, w> (a double) in one pass (cmi_spmv_dia_dot_{f64,f32})."""
     import torch
-    for t, n in ((values, "values"), (x, "x"), (y, "y"), (w, "w"), (result, "result")):
-        _need(t, n, torch.float64)
+    for t, n in ((values, "values"), (x, "x"), (y, "y"), (w, "w")):
+        _need(t, n, y.dtype)
+    _need(result, "result", torch.float64)
     _need(offsets, "offsets", torch.int32)
     if x.numel() != num_cols or y.numel() != num_rows or w.numel() != num_rows or offsets.numel() != num_diagonals or values.numel() < num_diagonals * pitch:
         raise ValueError("spmv_dia_dot: array lengths do not match the matrix shape")
-    check(lib().cmi_spmv_dia_dot_f64(num_rows, num_cols, num_diagonals, pitch, _ptr(offsets), _ptr(values), _ptr(x), _ptr(y), _ptr(w),
-                                     _ptr(result), _ptr(workspace), _cfg(cfg), _stream(stream)))
+    check(getattr(lib(), "cmi_spmv_dia_dot_" + _suffix(y))(num_rows, num_cols, num_diagonals, pitch, _ptr(offsets), _ptr(values), _ptr(x), _ptr(y),
+                                                           _ptr(w), _ptr(result), _ptr(workspace), _cfg(cfg), _stream(stream)))
 
 
 def spmv_coo(num_rows, num_cols, Ai, Aj, Ax, x, y, accumulate=False, cfg=None, stream=None):
@@ -473,6 +477,17 @@ def spmv_hyb_plan_args(args, x, y, accumulate=False, stream=None):
             or not x.is_contiguous() or not y.is_contiguous():
         raise ValueError("spmv_hyb_plan: x / y must be contiguous device vectors of the matrix's value type and shape")
     check(fn(h, pitch, eAj, eAx, cAi, cAj, cAx, _ptr(x), _ptr(y), int(bool(accumulate)), _stream(stream)))
+
+
+def spmv_hyb_dot_plan_args(args, x, y, w, result, workspace, stream=None):
+    """cmi_spmv_hyb_dot_plan_*: y <- A x and result[0] <- <y, w> (a double), one pass where the plan runs one launch."""
+    import torch
+    fn, h, pitch, eAj, eAx, cAi, cAj, cAx, dt, ncols, nrows = args
+    if x.dtype != dt or y.dtype != dt or w.dtype != dt or x.numel() != ncols or y.numel() != nrows or w.numel() != nrows:
+        raise ValueError("spmv_hyb_dot_plan: x / y / w must be device vectors of the matrix's value type and shape")
+    _need(result, "result", torch.float64)
+    fnd = getattr(lib(), "cmi_spmv_hyb_dot_plan_" + _suffix(y))
+    check(fnd(h, pitch, eAj, eAx, cAi, cAj, cAx, _ptr(x), _ptr(y), _ptr(w), _ptr(result), _ptr(workspace), _stream(stream)))
 
 
 def set_index_compression(on):

@@ -495,13 +495,15 @@ static int spmv_coo(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
 // COO entries of ITS rows -- the plan's tile_start[] says which: entries [tile_start[t], tile_start[t+1]) -- through LDS
 // 256 at a time, marks where each row's run begins and ends, and every lane adds its run to the same accumulator in entry
 // order.  y is written once, with the bits of the host loops.  Bytes: ELL part + 16 per COO entry + 16 per row + 4 per tile.
-template <typename T, int POL, bool ACC>
+// DOT: the workgroup also leaves sum_r y[r] * w[r] over its rows in dot_partial[tile] (the CG step <A p, p>, as csr_stream DOT).
+template <typename T, int POL, bool ACC, bool DOT = false>
 __global__ void __launch_bounds__(kHybTileRows)
 hyb_tile_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict__ eAj, const T *__restrict__ eAx,
                 const int *__restrict__ cAi, const int *__restrict__ cAj, const T *__restrict__ cAx,
                 const int32_t *__restrict__ tile_start, const T *__restrict__ x, T *__restrict__ y, int64_t tiles,
-                int64_t tiles_per_xcd, int swizzle)
+                int64_t tiles_per_xcd, int swizzle, const T *__restrict__ w = nullptr, double *__restrict__ dot_partial = nullptr)
 {
+    __shared__ double dot_slots[DOT ? kHybTileRows / kWave : 1];
     constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
     constexpr int R = kHybTileRows;
     __shared__ T prod[R];
@@ -582,6 +584,10 @@ hyb_tile_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restric
         }
     }
     if (live) st<NTS>(y + row, acc);
+    if constexpr (DOT) {
+        tile_dot_store(live ? (double)acc * (double)w[row] : 0.0, dot_slots, dot_partial + tile);
+        if (tile == 0 && tid == 0) reset_fold_state(dot_partial);
+    }
 }
 
 // tile_start[t] = first COO entry whose row is >= t * kHybTileRows (entries sorted by row), t = 0 .. tiles
@@ -623,8 +629,10 @@ int hyb_tile_starts(int64_t rows, int64_t coo_entries, const int *coo_Ai, int32_
 
 template <typename T>
 static int spmv_hyb_plan(const cmi_plan *plan, int dtype, int64_t pitch, const int *eAj, const T *eAx, const int *cAi,
-                         const int *cAj, const T *cAx, const T *x, T *y, int accumulate, void *stream)
+                         const int *cAj, const T *cAx, const T *x, T *y, int accumulate, void *stream,
+                         const T *wdot = nullptr, double *dot_partial = nullptr, int *dot_partials = nullptr)
 {
+    if (dot_partials) *dot_partials = 0; // > 0: the one-launch kernel left that many partials of <y, wdot>
     if (!plan || plan->format != CMI_FORMAT_HYB || plan->dtype != dtype)
         return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_hyb_plan: null plan, or a plan made for another format or value type");
     const int64_t rows = plan->rows, width = plan->hyb_width, coo = plan->hyb_coo;
@@ -644,6 +652,15 @@ static int spmv_hyb_plan(const cmi_plan *plan, int dtype, int64_t pitch, const i
     const int64_t grid64 = padded_grid(tiles, swz);
     if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_hyb_plan: grid too large");
     hipStream_t s = as_stream(stream);
+    if (wdot && dot_partial && !accumulate && tiles <= kPartialCapacity) {
+        with_policy(plan->cfg.nontemporal & 3, [&](auto P) {
+            constexpr int POL = decltype(P)::value;
+            hipLaunchKernelGGL((hyb_tile_kernel<T, POL, false, true>), dim3((unsigned)grid64), dim3(kHybTileRows), 0, s, rows, (int)width, pitch, eAj, eAx, cAi, cAj, cAx, plan->hyb_tile_start, x, y, tiles, tpx, swz, wdot, dot_partial);
+        });
+        CMI_LAUNCH_CHECK("hyb tile spmv dot");
+        if (dot_partials) *dot_partials = (int)tiles;
+        return CMI_SUCCESS;
+    }
     with_policy(plan->cfg.nontemporal & 3, [&](auto P) {
         constexpr int POL = decltype(P)::value;
         if (accumulate) hipLaunchKernelGGL((hyb_tile_kernel<T, POL, true>), dim3((unsigned)grid64), dim3(kHybTileRows), 0, s, rows, (int)width, pitch, eAj, eAx, cAi, cAj, cAx, plan->hyb_tile_start, x, y, tiles, tpx, swz);
@@ -722,4 +739,31 @@ CMI_API int cmi_spmv_hyb_plan_f32(const cmi_plan *plan, int64_t ell_pitch, const
                                   float *y, int accumulate, void *stream)
 {
     return cmi::spmv_hyb_plan<float>(plan, CMI_F32, ell_pitch, ell_Aj, ell_Ax, coo_Ai, coo_Aj, coo_Ax, x, y, accumulate, stream);
+}
+
+// y <- A x and *dot_dev <- <y, w> (a double) through a HYB plan: in the one-launch kernel's single pass where the plan runs it,
+// else the multiply followed by the library's dot.
+template <typename T>
+static int hyb_dot_plan(const cmi_plan *plan, int dtype, int64_t pitch, const int *eAj, const T *eAx, const int *cAi, const int *cAj,
+                        const T *cAx, const T *x, T *y, const T *w, double *dot_dev, void *workspace, void *stream)
+{
+    if (!plan || (!w && plan->rows > 0) || !dot_dev || !workspace) return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_hyb_dot_plan: null plan, w, result or workspace");
+    int partials = 0;
+    const int st = cmi::spmv_hyb_plan<T>(plan, dtype, pitch, eAj, eAx, cAi, cAj, cAx, x, y, 0, stream, w, (double *)workspace, &partials);
+    if (st) return st;
+    if (partials > 0) return cmi::reduce_partials_f64(partials, (double *)workspace, dot_dev, cmi::as_stream(stream));
+    if constexpr (std::is_same<T, double>::value) return cmi_blas_dot_f64(plan->rows, y, w, dot_dev, workspace, stream);
+    else return cmi_blas_dotd_f32(plan->rows, y, w, dot_dev, workspace, stream);
+}
+CMI_API int cmi_spmv_hyb_dot_plan_f64(const cmi_plan *plan, int64_t ell_pitch, const int32_t *ell_Aj, const double *ell_Ax,
+                                      const int32_t *coo_Ai, const int32_t *coo_Aj, const double *coo_Ax, const double *x,
+                                      double *y, const double *w, double *dot_dev, void *workspace, void *stream)
+{
+    return hyb_dot_plan<double>(plan, CMI_F64, ell_pitch, ell_Aj, ell_Ax, coo_Ai, coo_Aj, coo_Ax, x, y, w, dot_dev, workspace, stream);
+}
+CMI_API int cmi_spmv_hyb_dot_plan_f32(const cmi_plan *plan, int64_t ell_pitch, const int32_t *ell_Aj, const float *ell_Ax,
+                                      const int32_t *coo_Ai, const int32_t *coo_Aj, const float *coo_Ax, const float *x,
+                                      float *y, const float *w, double *dot_dev, void *workspace, void *stream)
+{
+    return hyb_dot_plan<float>(plan, CMI_F32, ell_pitch, ell_Aj, ell_Ax, coo_Ai, coo_Aj, coo_Ax, x, y, w, dot_dev, workspace, stream);
 }

@@ -396,8 +396,8 @@ static int spmv_ell(int dtype, int64_t rows, int64_t cols, int64_t width, int64_
         hipLaunchKernelGGL((ell_row_kernel<T, RPL, ELLR, decltype(P)::value, true>), dim3(grid), dim3(block), 0, s, rows, w, \
                            pitch, Aj, Ax, row_lengths, x, y, accumulate, tiles, tpx, swz, wdot, dot_partial);     \
     })
-    const bool dot = wdot && dot_partial && std::is_same<T, double>::value && tiles <= kPartialCapacity; // one partial per tile
-    if constexpr (std::is_same<T, double>::value) {
+    const bool dot = wdot && dot_partial && tiles <= kPartialCapacity; // one partial per tile (a double, whatever T)
+    {
         if (dot) {
             if (rpl == 1) { if (ellr) CMI_ELL_LAUNCH_DOT(1, true); else CMI_ELL_LAUNCH_DOT(1, false); }
             else          { if (ellr) CMI_ELL_LAUNCH_DOT(2, true); else CMI_ELL_LAUNCH_DOT(2, false); }
@@ -442,10 +442,10 @@ static int spmv_dia(int dtype, int64_t rows, int64_t cols, int64_t ndiag, int64_
     const int64_t grid64 = padded_grid(tiles, swz);
     if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_dia: grid too large");
     const int grid = (int)grid64, nd = (int)ndiag;
-    const bool dot = wdot && dot_partial && std::is_same<T, double>::value && tiles <= kPartialCapacity;
+    const bool dot = wdot && dot_partial && tiles <= kPartialCapacity;
     with_policy(pol, [&](auto P) {
         constexpr int POL = decltype(P)::value;
-        if constexpr (std::is_same<T, double>::value) {
+        {
             if (dot) {
                 if (rpl == 1) hipLaunchKernelGGL((dia_row_kernel<T, POL, true>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate, tiles, tpx, swz, wdot, dot_partial);
                 else          hipLaunchKernelGGL((dia_row2_kernel<T, POL, true>), dim3(grid), dim3(block), 0, s, rows, cols, nd, pitch, offsets, vals, x, y, accumulate, tiles, tpx, swz, wdot, dot_partial);
@@ -500,6 +500,32 @@ CMI_API int cmi_spmv_ell_dot_f64(int64_t num_rows, int64_t num_cols, int64_t num
     if (st) return st;
     if (partials > 0) return cmi::reduce_partials_f64(partials, (double *)workspace, dot_dev, cmi::as_stream(stream));
     return cmi_blas_dot_f64(num_rows, y, w, dot_dev, workspace, stream);
+}
+
+// float matrices: the same, the scalar stays a double (partials are doubles; the fallback is cmi_blas_dotd_f32)
+CMI_API int cmi_spmv_ell_dot_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries_per_row, int64_t pitch,
+                                 const int32_t *Aj, const float *Ax, const int32_t *row_lengths, const float *x,
+                                 float *y, const float *w, double *dot_dev, void *workspace, const cmi_config *cfg, void *stream)
+{
+    if ((!w && num_rows > 0) || !dot_dev || !workspace) return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_ell_dot: null w, result or workspace");
+    int partials = 0;
+    const int st = cmi::spmv_ell<float>(CMI_F32, num_rows, num_cols, num_entries_per_row, pitch, Aj, Ax, row_lengths, x, y, 0, cfg, stream,
+                                        w, (double *)workspace, &partials);
+    if (st) return st;
+    if (partials > 0) return cmi::reduce_partials_f64(partials, (double *)workspace, dot_dev, cmi::as_stream(stream));
+    return cmi_blas_dotd_f32(num_rows, y, w, dot_dev, workspace, stream);
+}
+CMI_API int cmi_spmv_dia_dot_f32(int64_t num_rows, int64_t num_cols, int64_t num_diagonals, int64_t pitch,
+                                 const int32_t *diagonal_offsets, const float *values, const float *x, float *y,
+                                 const float *w, double *dot_dev, void *workspace, const cmi_config *cfg, void *stream)
+{
+    if ((!w && num_rows > 0) || !dot_dev || !workspace) return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_dia_dot: null w, result or workspace");
+    int partials = 0;
+    const int st = cmi::spmv_dia<float>(CMI_F32, num_rows, num_cols, num_diagonals, pitch, diagonal_offsets, values, x, y, 0, cfg, stream,
+                                        w, (double *)workspace, &partials);
+    if (st) return st;
+    if (partials > 0) return cmi::reduce_partials_f64(partials, (double *)workspace, dot_dev, cmi::as_stream(stream));
+    return cmi_blas_dotd_f32(num_rows, y, w, dot_dev, workspace, stream);
 }
 
 CMI_API int cmi_spmv_dia_dot_f64(int64_t num_rows, int64_t num_cols, int64_t num_diagonals, int64_t pitch,

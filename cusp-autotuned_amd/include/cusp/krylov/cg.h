@@ -107,6 +107,11 @@ template <typename A, typename V> void multiply_dot(const A &a, const V &p, V &y
         multiply_dot(a.ell, p, y, yp, ws, cusp::ell_format());
         return;
     }
+    if (const cmi_plan *pl = cusp::detail::plan_of(a, nullptr, 0)) { // one launch through the plan: its fused dot
+        cusp::detail::check(cmi_spmv_hyb_dot_plan_f64(pl, a.ell.column_indices.pitch, cusp::detail::data_of(a.ell.column_indices), cusp::detail::data_of(a.ell.values),
+                                                      a.coo.row_indices.data(), a.coo.column_indices.data(), a.coo.values.data(), p.data(), y.data(), p.data(), yp, ws, nullptr));
+        return;
+    }
     cusp::multiply(a, p, y);
     cusp::detail::check(cmi_blas_dot_f64(a.num_rows, y.data(), p.data(), yp, ws, nullptr));
 }
@@ -190,6 +195,33 @@ template <typename A, typename V> void multiply_dot_f32(const A &a, const V &p, 
 {
     if (p.size() != a.num_cols || y.size() != a.num_rows) throw cusp::invalid_input_exception("cg: vector sizes do not match the matrix");
     multiply_dot(a, p, y, yp, ws, cusp::csr_format()); // CSR fuses the dot for float too (the scalar stays a double)
+}
+template <typename A, typename V> void multiply_dot_f32(const A &a, const V &p, V &y, double *yp, void *ws, cusp::ell_format)
+{
+    cusp::detail::require_int_index<A>();
+    if (p.size() != a.num_cols || y.size() != a.num_rows) throw cusp::invalid_input_exception("cg: vector sizes do not match the matrix");
+    cusp::detail::check(cmi_spmv_ell_dot_f32(a.num_rows, a.num_cols, a.column_indices.num_cols, a.column_indices.pitch, cusp::detail::data_of(a.column_indices),
+                                             cusp::detail::data_of(a.values), cusp::detail::row_lengths_of(a, 0), p.data(), y.data(), p.data(), yp, ws,
+                                             cusp::detail::forced_config(), nullptr));
+}
+template <typename A, typename V> void multiply_dot_f32(const A &a, const V &p, V &y, double *yp, void *ws, cusp::dia_format)
+{
+    cusp::detail::require_int_index<A>();
+    if (p.size() != a.num_cols || y.size() != a.num_rows) throw cusp::invalid_input_exception("cg: vector sizes do not match the matrix");
+    cusp::detail::check(cmi_spmv_dia_dot_f32(a.num_rows, a.num_cols, a.values.num_cols, a.values.pitch, a.diagonal_offsets.data(),
+                                             cusp::detail::data_of(a.values), p.data(), y.data(), p.data(), yp, ws, cusp::detail::forced_config(), nullptr));
+}
+template <typename A, typename V> void multiply_dot_f32(const A &a, const V &p, V &y, double *yp, void *ws, cusp::hyb_format)
+{
+    cusp::detail::require_int_index<A>();
+    if (p.size() != a.num_cols || y.size() != a.num_rows) throw cusp::invalid_input_exception("cg: vector sizes do not match the matrix");
+    if (const cmi_plan *pl = (a.ell.column_indices.pitch == a.ell.values.pitch) ? cusp::detail::plan_of(a, nullptr, 0) : nullptr) {
+        cusp::detail::check(cmi_spmv_hyb_dot_plan_f32(pl, a.ell.column_indices.pitch, cusp::detail::data_of(a.ell.column_indices), cusp::detail::data_of(a.ell.values),
+                                                      a.coo.row_indices.data(), a.coo.column_indices.data(), a.coo.values.data(), p.data(), y.data(), p.data(), yp, ws, nullptr));
+        return;
+    }
+    cusp::multiply(a, p, y);
+    cusp::detail::check(dotd_(y.size(), y.data(), p.data(), yp, ws));
 }
 template <typename A, typename V, typename Format> void multiply_dot_f32(const A &a, const V &p, V &y, double *yp, void *ws, Format)
 {

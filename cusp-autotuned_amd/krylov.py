@@ -176,22 +176,21 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
         return B.spmv_csr_dot_partials(A.plan(), A.row_offsets, A.column_indices, A.values, p, y, p, ops.ws)
 
     def spmv_dot():                              # y <- A p, yp <- <y, p>
-        f64 = p.dtype == torch.float64          # CSR fuses the dot for f64 and f32 (the scalar is a double either way);
-        if isinstance(A, ShardedCsr):            # ELL / DIA for f64; everything else: SpMV, then a dot into a double
+        if isinstance(A, ShardedCsr):            # CSR / ELL / DIA fuse the dot for f64 and f32 (the scalar is a double either way);
+                                                 # everything else: SpMV, then a dot into a double
             A.multiply_dot(y, yp, ops.ws)        # p IS A.x_local
         elif isinstance(A, CsrMatrix) and p.is_cuda:
             B.spmv_csr_dot(A.num_rows, A.num_cols, A.row_offsets, A.column_indices, A.values, p, y, p, yp, ops.ws,
                            plan=A.plan() if A.num_entries > 0 else None)
-        elif not f64:
-            spmv(p, y)
-            B.blas_dotd(y, p, yp, ops.ws)
-        elif isinstance(A, HybMatrix) and A.coo.num_entries == 0:   # everything in the ELL part: its fused dot
+        elif isinstance(A, HybMatrix) and A.coo.num_entries == 0 and p.is_cuda:   # everything in the ELL part: its fused dot
             e = A.ell
             B.spmv_ell_dot(A.num_rows, A.num_cols, e.num_entries_per_row, e.pitch, e.column_indices, e.values, p, y, p, yp, ops.ws)
-        elif isinstance(A, EllMatrix):
+        elif isinstance(A, HybMatrix) and p.is_cuda and A.plan() is not None:   # one launch through the plan: its fused dot
+            B.spmv_hyb_dot_plan_args(A._plan_args, p, y, p, yp, ops.ws)
+        elif isinstance(A, EllMatrix) and p.is_cuda:
             B.spmv_ell_dot(A.num_rows, A.num_cols, A.num_entries_per_row, A.pitch, A.column_indices, A.values, p, y, p, yp, ops.ws,
                            row_lengths=A.row_lengths)
-        elif isinstance(A, DiaMatrix):
+        elif isinstance(A, DiaMatrix) and p.is_cuda:
             B.spmv_dia_dot(A.num_rows, A.num_cols, A.diagonal_offsets.numel(), A.pitch, A.diagonal_offsets, A.values, p, y, p, yp, ops.ws)
         else:
             spmv(p, y)

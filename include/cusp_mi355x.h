@@ -302,6 +302,13 @@ int cmi_spmv_ell_dot_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries
 int cmi_spmv_dia_dot_f64(int64_t num_rows, int64_t num_cols, int64_t num_diagonals, int64_t pitch,
                          const int32_t *diagonal_offsets, const double *values, const double *x, double *y,
                          const double *w, double *dot_dev, void *workspace, const cmi_config *cfg, void *stream);
+/* float matrices: the same one-pass forms; the scalar stays a double in device memory */
+int cmi_spmv_ell_dot_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries_per_row, int64_t pitch,
+                         const int32_t *Aj, const float *Ax, const int32_t *row_lengths, const float *x,
+                         float *y, const float *w, double *dot_dev, void *workspace, const cmi_config *cfg, void *stream);
+int cmi_spmv_dia_dot_f32(int64_t num_rows, int64_t num_cols, int64_t num_diagonals, int64_t pitch,
+                         const int32_t *diagonal_offsets, const float *values, const float *x, float *y,
+                         const float *w, double *dot_dev, void *workspace, const cmi_config *cfg, void *stream);
 /* Row-length profile.  cmi_spmv_csr_* WITHOUT a plan runs the table's row-tile kernel whatever the row    */
 /* lengths (correct for every matrix; a row of 10^5 entries is then summed by one lane).  A plan measures  */
 /* the longest row once and switches to the long-row instance of csr_stream or to CMI_CSR_BALANCED when    */
@@ -394,6 +401,14 @@ int cmi_spmv_hyb_plan_f64(const cmi_plan *plan, int64_t ell_pitch, const int32_t
 int cmi_spmv_hyb_plan_f32(const cmi_plan *plan, int64_t ell_pitch, const int32_t *ell_Aj, const float *ell_Ax,
                           const int32_t *coo_Ai, const int32_t *coo_Aj, const float *coo_Ax, const float *x, float *y,
                           int accumulate, void *stream);
+/* ... and with <y, w> (a double) in the same pass (the CG step <A p, p>): fused where the plan runs one launch, else the       */
+/* multiply followed by the library's dot.                                                                                      */
+int cmi_spmv_hyb_dot_plan_f64(const cmi_plan *plan, int64_t ell_pitch, const int32_t *ell_Aj, const double *ell_Ax,
+                              const int32_t *coo_Ai, const int32_t *coo_Aj, const double *coo_Ax, const double *x, double *y,
+                              const double *w, double *dot_dev, void *workspace, void *stream);
+int cmi_spmv_hyb_dot_plan_f32(const cmi_plan *plan, int64_t ell_pitch, const int32_t *ell_Aj, const float *ell_Ax,
+                              const int32_t *coo_Ai, const int32_t *coo_Aj, const float *coo_Ax, const float *x, float *y,
+                              const float *w, double *dot_dev, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* On-device builders of the benchmark inputs.      */

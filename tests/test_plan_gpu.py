@@ -217,6 +217,26 @@ def test_hyb_plan_one_launch(cmi, torch_cuda, orc, tag, shape):
             assert np.array_equal(ya.cpu().numpy(), want_acc), (shape, force, swz, nt, "acc")
         else:
             assert np.all(np.abs(y.cpu().numpy() - want) <= tol) and np.all(np.abs(ya.cpu().numpy() - want_acc) <= tol), (shape, force, swz, nt)
+    # <y, w> in the same pass (the CG step): fused in the one-launch kernel, a separate dot behind the two launches
+    wv = rng.standard_normal(rows).astype(dtype)
+    res = torch.zeros(1, dtype=torch.float64, device="cuda")
+    for force in ("1", "0"):
+        os.environ["CMI_HYB_ONE_LAUNCH"] = force
+        try:
+            pl = cmi.Plan.hyb(dx.dtype, rows, cols, width, d[2], cfg_ell=cmi.Config(kernel=cmi.ELL_ROW, threads_per_row=1))
+        finally:
+            os.environ.pop("CMI_HYB_ONE_LAUNCH", None)
+        args = cmi.binding.hyb_plan_args(pl, p, *d)
+        y = torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
+        res.fill_(float("nan"))
+        cmi.binding.spmv_hyb_dot_plan_args(args, dx, y, torch.from_numpy(wv).cuda(), res, cmi.blas_workspace())
+        yh = y.cpu().numpy()
+        if pl.info()["storage_order_sums"]:
+            assert np.array_equal(yh, want), (shape, force, "dot: y")
+        else:
+            assert np.all(np.abs(yh - want) <= tol), (shape, force, "dot: y")
+        ref = float(np.dot(yh.astype(np.float64), wv.astype(np.float64)))
+        assert abs(float(res) - ref) <= 1e-12 * float(np.abs(yh.astype(np.float64) * wv).sum()) + 1e-300, (shape, force, float(res), ref)
     # COO part shuffled: the plan sees it, two launches, sums re-associated
     if len(cAi) > 1:
         perm = rng.permutation(len(cAi))

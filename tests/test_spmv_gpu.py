@@ -1267,15 +1267,18 @@ def test_spmv_csr_dot_degenerate(cmi, torch_cuda):
         cmi.spmv_csr_dot(5, 3, Ap, e_i, e_d, torch.ones(3, dtype=torch.float64, device="cuda"), y, w[:4], res, ws)
 
 
-def test_spmv_ell_and_dia_dot(cmi, torch_cuda, orc):
-    """cmi_spmv_{ell,dia}_dot_f64: y bit-identical to the plain multiply (every launch shape, ELLR too), the dot
-    within 1e-12 * sum|y_i w_i| of numpy's, repeatable bit for bit."""
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_spmv_ell_and_dia_dot(cmi, torch_cuda, orc, tag):
+    """cmi_spmv_{ell,dia}_dot_{f64,f32}: y bit-identical to the plain multiply (every launch shape, ELLR too), the dot (a double
+    for both value types) within 1e-12 * sum|y_i w_i| of numpy's double dot of the same y, repeatable bit for bit."""
     torch = torch_cuda
+    dtype = np.float64 if tag == "f64" else np.float32
     m, n = 301, 199
     Ap, Aj, Ax = orc.poisson5pt_csr(m, n)
+    Ax = Ax.astype(dtype)
     N = m * n
     rng = np.random.default_rng(9)
-    x, w = rng.standard_normal(N), rng.standard_normal(N)
+    x, w = rng.standard_normal(N).astype(dtype), rng.standard_normal(N).astype(dtype)
     dx, dw = dev(x, torch), dev(w, torch)
     ws = cmi.blas_workspace()
     res = torch.zeros(1, dtype=torch.float64, device="cuda")
@@ -1286,39 +1289,39 @@ def test_spmv_ell_and_dia_dot(cmi, torch_cuda, orc):
     for rpl, nt, ellr, blk in itertools.product((1, 2), (0, 3), (False, True), (64, 256, 1024)):
         cfg = cmi.Config(kernel=cmi.ELL_ROW, block_size=blk, items_per_thread=rpl, nontemporal=nt,
                          xcd_swizzle=(0, 1, 5, 32)[(rpl + nt + blk // 64) % 4])  # partial index = tile, whatever the dealing
-        y0 = torch.full((N,), 3.0, dtype=torch.float64, device="cuda")
-        y1 = torch.full((N,), -3.0, dtype=torch.float64, device="cuda")
+        y0 = torch.full((N,), 3.0, dtype=dx.dtype, device="cuda")
+        y1 = torch.full((N,), -3.0, dtype=dx.dtype, device="cuda")
         cmi.spmv_ell(N, N, 5, pitch, deAj, deAx, dx, y0, row_lengths=rl if ellr else None, cfg=cfg)
         res.fill_(float("nan"))
         cmi.spmv_ell_dot(N, N, 5, pitch, deAj, deAx, dx, y1, dw, res, ws, row_lengths=rl if ellr else None, cfg=cfg)
         assert torch.equal(y0, y1), (rpl, nt, ellr, blk)
-        yh = host(y1)
-        assert abs(float(res) - float(np.dot(yh, w))) <= 1e-12 * float(np.abs(yh * w).sum()), (rpl, nt, ellr, blk)
+        yh = host(y1).astype(np.float64)
+        assert abs(float(res) - float(np.dot(yh, w.astype(np.float64)))) <= 1e-12 * float(np.abs(yh * w).sum()), (rpl, nt, ellr, blk)
     pd, off, vals = orc.csr_to_dia(N, N, Ap, Aj, Ax)
     doff, dvals = dev(off, torch), dev(vals, torch)
     for rpl, nt, blk in itertools.product((1, 2), (0, 2), (64, 256, 512)):
         cfg = cmi.Config(kernel=cmi.DIA_ROW, block_size=blk, items_per_thread=rpl, nontemporal=nt,
                          xcd_swizzle=(0, 1, 5, 32)[(rpl + nt + blk // 64) % 4])
-        y0 = torch.full((N,), 3.0, dtype=torch.float64, device="cuda")
-        y1 = torch.full((N,), -3.0, dtype=torch.float64, device="cuda")
+        y0 = torch.full((N,), 3.0, dtype=dx.dtype, device="cuda")
+        y1 = torch.full((N,), -3.0, dtype=dx.dtype, device="cuda")
         cmi.spmv_dia(N, N, len(off), pd, doff, dvals, dx, y0, cfg=cfg)
         cmi.spmv_dia_dot(N, N, len(off), pd, doff, dvals, dx, y1, dw, res, ws, cfg=cfg)
         assert torch.equal(y0, y1), (rpl, nt, blk)
-        yh = host(y1)
-        assert abs(float(res) - float(np.dot(yh, w))) <= 1e-12 * float(np.abs(yh * w).sum()), (rpl, nt, blk)
+        yh = host(y1).astype(np.float64)
+        assert abs(float(res) - float(np.dot(yh, w.astype(np.float64)))) <= 1e-12 * float(np.abs(yh * w).sum()), (rpl, nt, blk)
         first = float(res)
         cmi.spmv_dia_dot(N, N, len(off), pd, doff, dvals, dx, y1, dw, res, ws, cfg=cfg)
         assert float(res) == first
     # more workgroups than the workspace holds partials (block 64 on 5M rows): falls back to SpMV + dot
-    big = cmi.poisson5pt(2300, 2300, "dia")
+    big = cmi.poisson5pt(2300, 2300, "dia", dtype=dx.dtype)
     nb = big.num_rows
-    xb = cmi.fill_x(nb).cuda()
-    yb0, yb1 = torch.empty(nb, dtype=torch.float64, device="cuda"), torch.empty(nb, dtype=torch.float64, device="cuda")
+    xb = cmi.fill_x(nb, dx.dtype, "cuda")
+    yb0, yb1 = torch.empty(nb, dtype=dx.dtype, device="cuda"), torch.empty(nb, dtype=dx.dtype, device="cuda")
     cfg = cmi.Config(kernel=cmi.DIA_ROW, block_size=64, items_per_thread=1)
     cmi.multiply(big, xb, yb0, cfg=cfg)
     cmi.spmv_dia_dot(nb, nb, 5, big.pitch, big.diagonal_offsets, big.values, xb, yb1, xb, res, ws, cfg=cfg)
     assert torch.equal(yb0, yb1)
-    assert abs(float(res) - float(torch.dot(yb1, xb))) <= 1e-10 * float((yb1 * xb).abs().sum())
+    assert abs(float(res) - float(torch.dot(yb1.double(), xb.double()))) <= 1e-10 * float((yb1.double() * xb.double()).abs().sum())
 
 
 @pytest.mark.parametrize("tag", ["f64", "f32"])
