@@ -140,7 +140,7 @@ def pmc_traffic(kernel_substr):
     pdir = os.path.join(ROOT, "profiles")
     # the SpMV kernel of each format (not the builders / converters that carry the format's name too)
     names = {"csr": ("csr_stream_kernel", "csr_balanced_kernel", "csr_vector_kernel", "csr_scalar_kernel"), "ell": ("ell_row_kernel",),
-             "dia": ("dia_row_kernel", "dia_row2_kernel"), "coo": ("coo_tile_kernel", "coo_lane4_kernel", "coo_segmented_kernel"), "hyb": ("hyb_tile_kernel",)}[kernel_substr]
+             "dia": ("dia_row_kernel", "dia_row2_kernel"), "coo": ("coo_tile_kernel", "coo_lane4_kernel", "coo_segmented_kernel"), "hyb": ("hyb_tile_kernel",), "csr16": ("csr_stream16_kernel",)}[kernel_substr]
     best, src = None, None
     if os.path.isdir(pdir):
         for f in sorted(os.listdir(pdir)):
@@ -582,6 +582,7 @@ def main():
                        "bytes_read_and_written_per_launch": moved, "moved_gbps": round(moved / (ms16 * 1e-3) / 1e9, 2),
                        "moved_frac_of_peak": round(moved / (ms16 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                        "csr_algorithmic_bytes_over_time_gbps": round(cmi.csr_bytes(A.num_rows, A.num_entries) / (ms16 * 1e-3) / 1e9, 2),
+                       "traffic": pmc_traffic("csr16")[0], "traffic_source": pmc_traffic("csr16")[1],
                        "extra_hbm_bytes_owned_by_the_plan": 2 * A.num_entries + 16 + 4 * tiles16,
                        "y_identical_to_the_plain_kernel": bool(torch.equal(y16, y)),
                        "speedup_over_the_headline_kernel": round(kernel_ms / ms16, 4)}
@@ -660,6 +661,8 @@ def main():
                          "kernel_min_ms": round(kernel_ms_min, 6),
                          "kernel_timing": f"{KERNEL_BATCHES} batches x {per_batch} launches, one HIP event pair per batch on the launch stream",
                          "kernel_avg_over_ms_per_step": round(kernel_ms / ms_per_step, 4),
+                         # the dominant kernel cannot take longer than the step that contains it: checked, not assumed
+                         "kernel_avg_le_step_x1.02": bool(kernel_ms <= ms_per_step * 1.02),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_gflops": round(2.0 * local_nnz / (kernel_ms * 1e-3) / 1e9, 2)},
             "settle_launches": SETTLE,
@@ -679,6 +682,9 @@ def main():
             base, omp = cpu_baseline(cmi, A, x_host, y.cpu().numpy(), args.cpu_seconds)
             line["cpu_baseline"] = base
             line["cpu_baseline_omp"] = omp
+        if not line["roofline"]["kernel_avg_le_step_x1.02"]:
+            print(f"bench.py: WARNING kernel_avg_ms {kernel_ms:.6f} > 1.02 x ms_per_step {ms_per_step:.6f}: the {args.steps} timed steps ran faster "
+                  "than the kernel's average over the 200+ launches behind them (clock / placement drift between the two timed regions)", file=sys.stderr, flush=True)
         print(json.dumps(line), flush=True)
     if dist is not None:
         sh.vec.close()  # barrier + unmap the peers' buffers before anyone frees them
