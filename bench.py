@@ -140,14 +140,15 @@ def pmc_traffic(kernel_substr):
     pdir = os.path.join(ROOT, "profiles")
     # the SpMV kernel of each format (not the builders / converters that carry the format's name too)
     names = {"csr": ("csr_stream_kernel", "csr_balanced_kernel", "csr_vector_kernel", "csr_scalar_kernel"), "ell": ("ell_row_kernel",),
-             "dia": ("dia_row_kernel", "dia_row2_kernel"), "coo": ("coo_tile_kernel", "coo_lane4_kernel", "coo_segmented_kernel"), "hyb": ("hyb_tile_kernel",), "csr16": ("csr_stream16_kernel",)}[kernel_substr]
+             "dia": ("dia_row_kernel", "dia_row2_kernel"), "coo": ("csr_stream_kernel", "csr_balanced_kernel"),  # sorted entries through a plan: the CSR kernels on the plan's row offsets
+             "coo_tile": ("coo_tile_kernel",), "hyb": ("hyb_tile_kernel",), "csr16": ("csr_stream16_kernel",)}[kernel_substr]
     best, src = None, None
     if os.path.isdir(pdir):
         for f in sorted(os.listdir(pdir)):
             if f.endswith(".json") and "pmc" in f and "before" not in f:
                 try:
                     doc = json.load(open(os.path.join(pdir, f)))
-                    if kernel_substr not in doc.get("probe", {}).get("formats", [kernel_substr]):
+                    if kernel_substr.split("_")[0] not in doc.get("probe", {}).get("formats", [kernel_substr]):
                         continue  # (a HYB run also launches ELL / COO kernels: only the run made for this format counts)
                     for k in doc.get("kernels", []):
                         if any(n in k.get("kernel", "") for n in names) and k.get("hbm_bytes_per_launch") and k.get("launches", 0) >= 5:
@@ -632,6 +633,30 @@ def main():
     traffic, traffic_src = pmc_traffic(kname)
     cfg = cmi.tuning_select({"csr": 0, "ell": 1, "dia": 2, "coo": 3, "hyb": 1}[fmt], cmi.F64, local_rows, N_global,
                             local_nnz if fmt in ("csr", "coo") else local_rows * (HYB_WIDTH if fmt == "hyb" else 5))
+    coo_tile = None
+    if fmt == "coo" and world == 1:
+        # what ran above: the matrix's plan found the entries sorted, built the row offsets they imply and multiplies with the CSR
+        # kernel on them (the row indices are not read: 12 instead of 16 bytes per entry) -- `roofline` prices it on COO's 16.
+        # Beside it: the COO format's own kernel for sorted entries (coo_tile: reads the row indices, no plan-owned memory).
+        cfg = Afmt.plan().config()
+        tcfg = cmi.Config(kernel=cmi.COO_TILE, nontemporal=3, xcd_swizzle=32)
+        run_tile = lambda: cmi.spmv_coo(local_rows, N_global, Afmt.row_indices, Afmt.column_indices, Afmt.values, x, y, cfg=tcfg)  # noqa: E731
+        for _ in range(20):
+            run_tile()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * KERNEL_BATCHES)]
+        for bi in range(KERNEL_BATCHES):
+            ev[2 * bi].record()
+            for _ in range(per_batch):
+                run_tile()
+            ev[2 * bi + 1].record()
+        torch.cuda.synchronize()
+        bt = [ev[2 * bi].elapsed_time(ev[2 * bi + 1]) / per_batch for bi in range(KERNEL_BATCHES)]
+        mt = sum(bt) / len(bt)
+        coo_tile = {"kernel_avg_ms": round(mt, 6), "kernel_min_ms": round(min(bt), 6), "achieved_gbps": round(alg_bytes / (mt * 1e-3) / 1e9, 2),
+                    "frac": round(alg_bytes / (mt * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic("coo_tile")[0],
+                    "kernel_config": tcfg.as_dict()}
+        cmi.multiply(Afmt, x, y)
 
     if rank == 0:
         line = {
@@ -678,6 +703,10 @@ def main():
             line["cg"] = cg_leg
         if c16 is not None:
             line["compressed_index_plan"] = c16
+        if coo_tile is not None:
+            line["coo_tile_kernel"] = coo_tile
+            line["roofline"]["note"] = ("sorted COO through its plan = the CSR kernel on plan-built row offsets; algorithmic bytes are COO's "
+                                        "(16 per entry), the kernel reads 12: `traffic` can be below them")
         if world == 1 and not args.no_cpu_baseline and fmt == "csr":
             base, omp = cpu_baseline(cmi, A, x_host, y.cpu().numpy(), args.cpu_seconds)
             line["cpu_baseline"] = base

@@ -163,6 +163,7 @@ def _declare(L):
     for suf in ("f64", "f32"):
         getattr(L, f"cmi_spmv_csr_plan_{suf}").argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
         getattr(L, f"cmi_spmv_coo_plan_{suf}").argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
+        getattr(L, f"cmi_spmv_coo_dot_plan_{suf}").argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         getattr(L, f"cmi_spmv_csr_dot_plan_{suf}").argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.cmi_spmv_csr_dot_f32.argtypes = [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, cfgp, vp]
 
@@ -477,6 +478,21 @@ def spmv_hyb_plan_args(args, x, y, accumulate=False, stream=None):
             or not x.is_contiguous() or not y.is_contiguous():
         raise ValueError("spmv_hyb_plan: x / y must be contiguous device vectors of the matrix's value type and shape")
     check(fn(h, pitch, eAj, eAx, cAi, cAj, cAx, _ptr(x), _ptr(y), int(bool(accumulate)), _stream(stream)))
+
+
+def spmv_coo_dot_plan(plan, Ai, Aj, Ax, x, y, w, result, workspace, stream=None):
+    """cmi_spmv_coo_dot_plan_*: y <- A x and result[0] <- <y, w> (a double); one pass for sorted entries (the plan's row offsets)."""
+    import torch
+    for t, n in ((Ai, "Ai"), (Aj, "Aj")):
+        _need(t, n, torch.int32)
+    for t, n in ((Ax, "Ax"), (x, "x"), (y, "y"), (w, "w")):
+        _need(t, n, y.dtype)
+    _need(result, "result", torch.float64)
+    if (Ai.numel() != plan.num_entries or Aj.numel() != plan.num_entries or Ax.numel() != plan.num_entries
+            or x.numel() != plan.num_cols or y.numel() != plan.num_rows or w.numel() != plan.num_rows):
+        raise ValueError("spmv_coo_dot_plan: array lengths do not match the plan's matrix shape")
+    check(getattr(lib(), "cmi_spmv_coo_dot_plan_" + _suffix(y))(plan.handle, _ptr(Ai), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(y), _ptr(w), _ptr(result),
+                                                                _ptr(workspace), _stream(stream)))
 
 
 def spmv_hyb_dot_plan_args(args, x, y, w, result, workspace, stream=None):

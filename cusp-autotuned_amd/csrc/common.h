@@ -267,6 +267,12 @@ struct cmi_plan {
     int64_t hyb_width = 0, hyb_coo = 0;
     cmi_config hyb_coo_cfg = {};
     int32_t *hyb_tile_start = nullptr; // device, tiles + 1 entries; null: two launches
+    cmi_plan *hyb_coo_plan = nullptr;  // two launches: the COO half's own plan (sorted: row offsets + CSR kernels, accumulating)
+    // COO whose entries are sorted by row (plan.hip): the row offsets the row indices imply (num_rows + 1 ints, built once) and
+    // the CSR plan for them -- the multiply then runs the CSR kernels on (offsets, Aj, Ax) and never reads the row indices:
+    // 12 nnz + 20 N bytes instead of 16 nnz + 16 N, storage-order sums, long rows handled as CSR handles them
+    int32_t *coo_offsets = nullptr;
+    cmi_plan *coo_csr_plan = nullptr;
     // CSR with cfg.kernel == CMI_CSR_STREAM_C16 (spmv_csr16.hip): per-tile smallest column and the 16-bit offsets from it
     int32_t *csr16_base = nullptr;  // device, one per tile of cfg.rows_per_block rows
     uint16_t *csr16_cols = nullptr; // device, nnz (+ padding) entries
@@ -277,9 +283,9 @@ constexpr int kHybTileRows = 256; // rows per workgroup of the one-launch HYB ke
 int hyb_tile_starts(int64_t rows, int64_t coo_entries, const int *coo_Ai, int32_t *tile_start, int *max_in_tile_dev, hipStream_t s);
 // The one-launch kernel walks a tile's COO entries 256 at a time behind its ELL slots: right for a light COO part (the usual
 // HYB: a few entries in some rows), wrong for a heavy one, where the entry-tiled COO kernel in a second launch is faster
-// (tools/hyb_fuse_probe.py, profiles/r02_hyb_one_vs_two_launches.txt: the crossover lies at 3-6 entries per row).  One launch when the COO part averages at most
+// (tools/hyb_fuse_probe.py, profiles/r02_hyb_one_vs_two_launches.txt: the crossover lies at 2.8-3.1 entries per row now that the second launch is the CSR kernel on the COO plan's row offsets).  One launch when the COO part averages at most
 // kHybFusedMaxPerRow entries per row and no tile holds more than kHybFusedMaxInTile; $CMI_HYB_ONE_LAUNCH=0/1 forces it.
-constexpr double kHybFusedMaxPerRow = 4.0;
+constexpr double kHybFusedMaxPerRow = 3.0;
 constexpr int kHybFusedMaxInTile = 4096;
 // spmv_csr16.hip: the plan's 16-bit column copy (built only if every tile qualifies) and the multiply that reads it
 int csr16_build(cmi_plan *p, const int *Ap, const int *Aj, hipStream_t s);

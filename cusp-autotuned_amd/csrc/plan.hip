@@ -9,8 +9,9 @@
 //
 //   CSR : launch shape from the table (or the caller's config), completed; the row-length profile (longest row, entries
 //         in rows of 512+) decides between the row-tile kernel, its long-row instance and the merge-path kernel.
-//   COO : launch shape + "are the entries sorted by row?" -- sorted input runs the tile kernel (plain stores, storage-
-//         order sums), anything else the order-agnostic atomics kernels.
+//   COO : "are the entries sorted by row?" -- sorted input gets the row offsets its row indices imply and runs the CSR
+//         kernels on them (12 instead of 16 bytes per entry); anything else the order-agnostic atomics kernels.  An explicit
+//         CMI_COO_TILE config keeps the COO tile kernel.
 //   ELL / DIA : the resolved launch shape only (nothing to measure).
 //   HYB (cmi_plan_create_hyb) : is the COO part sorted by row?  Then one int per 256 rows -- where that tile's COO entries
 //         begin -- lets ONE kernel finish a row (ELL slots, then its COO entries) instead of two launches over y.
@@ -124,6 +125,20 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
             // (fewer than four entries: the tile kernel's vector loads have nothing to read -- the order-agnostic kernel stays)
             // (a row of more than 1024 entries: the tile kernel would walk its tail serially -- the order-agnostic kernel stays)
             if (sorted && !long_runs && auto_kernel && num_entries >= 4) select_config(CMI_TABLE_COO_SORTED, dtype, num_rows, num_cols, num_entries, cfg, &p->cfg);
+            // Sorted entries and no kernel asked for: the row indices carry no more than row offsets do.  The plan builds the
+            // offsets once (4 bytes per row of HBM it owns) and a CSR plan for them; every multiply then streams 12 bytes per
+            // entry instead of 16 through the CSR kernels -- same products, storage-order sums, rows of any length.
+            // ($CMI_COO_PLAN_OFFSETS=0: keep the COO kernels -- measurements of the tile kernel.)
+            const char *off = std::getenv("CMI_COO_PLAN_OFFSETS");
+            if (sorted && auto_kernel && num_entries >= 4 && num_rows > 0 && num_entries <= INT32_MAX && !(off && off[0] == '0')) {
+                hipError_t e = hipMalloc((void **)&p->coo_offsets, (size_t)(num_rows + 1) * sizeof(int32_t));
+                if (e != hipSuccess) st = hip_fail(e, "cmi_plan_create: COO row offsets");
+                int sorted2 = 0;
+                if (st == CMI_SUCCESS) st = cmi_coo_row_offsets(num_rows, num_entries, index_array, p->coo_offsets, &sorted2, stream);
+                if (st == CMI_SUCCESS && sorted2)
+                    st = plan_create(CMI_FORMAT_CSR, dtype, num_rows, num_cols, num_entries, p->coo_offsets, nullptr, nullptr, stream, &p->coo_csr_plan);
+                if (st == CMI_SUCCESS && p->coo_csr_plan) p->cfg = p->coo_csr_plan->cfg; // what cmi_plan_config reports: the kernel that runs
+            }
             // an explicit CMI_COO_TILE on unsorted entries would add rows up wrongly: refuse it here, where it is known
             if (!sorted && p->cfg.kernel == CMI_COO_TILE) st = fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: CMI_COO_TILE needs row-sorted entries");
         }
@@ -189,6 +204,10 @@ CMI_API int cmi_plan_create_hyb(int dtype, int64_t num_rows, int64_t num_cols, i
                 p->hyb_tile_start = nullptr;
             }
         }
+        // two launches: the COO half multiplies through a COO plan of its own (sorted entries: the CSR kernels on row offsets,
+        // accumulating on top of the ELL half -- per row still the host chain)
+        if (st == CMI_SUCCESS && !p->hyb_tile_start)
+            st = plan_create(CMI_FORMAT_COO, dtype, num_rows, num_cols, coo_entries, coo_row_indices, nullptr, cfg_coo, stream, &p->hyb_coo_plan);
     }
     if (st != CMI_SUCCESS) { (void)cmi_plan_destroy(p); return st; }
     *plan_out = p;
@@ -205,6 +224,9 @@ CMI_API int cmi_plan_hyb_launches(const cmi_plan *plan, int *launches)
 CMI_API int cmi_plan_destroy(cmi_plan *plan)
 {
     if (plan && plan->hyb_tile_start) (void)hipFree(plan->hyb_tile_start);
+    if (plan && plan->hyb_coo_plan) (void)cmi_plan_destroy(plan->hyb_coo_plan);
+    if (plan && plan->coo_csr_plan) (void)cmi_plan_destroy(plan->coo_csr_plan);
+    if (plan && plan->coo_offsets) (void)hipFree(plan->coo_offsets);
     if (plan && plan->csr16_base) (void)hipFree(plan->csr16_base);
     if (plan && plan->csr16_cols) (void)hipFree(plan->csr16_cols);
     delete plan;
@@ -236,10 +258,21 @@ CMI_API int cmi_plan_info(const cmi_plan *plan, int64_t *max_row_length, int64_t
             break;
         case CMI_FORMAT_ELL: exact = ell_lanes_per_row(c, plan->rows, plan->rows > 0 ? plan->nnz / plan->rows : 0) == 1; break;
         case CMI_FORMAT_DIA: exact = 1; break;
-        case CMI_FORMAT_COO: exact = c.kernel == CMI_COO_TILE; break;
+        case CMI_FORMAT_COO:
+            if (plan->coo_csr_plan) { // through the row offsets: the CSR kernel's class
+                int sub = 0;
+                (void)cmi_plan_info(plan->coo_csr_plan, nullptr, nullptr, nullptr, &sub);
+                exact = sub;
+            } else
+                exact = c.kernel == CMI_COO_TILE;
+            break;
         default: // HYB: one launch = one chain per row; two launches: the same chain when the COO half is the tile kernel, else atomics
-            exact = plan->hyb_tile_start != nullptr ||
-                    (ell_lanes_per_row(c, plan->rows, plan->hyb_width) == 1 && (plan->hyb_coo == 0 || plan->hyb_coo_cfg.kernel == CMI_COO_TILE));
+            exact = plan->hyb_tile_start != nullptr;
+            if (!exact && ell_lanes_per_row(c, plan->rows, plan->hyb_width) == 1) {
+                int sub = plan->hyb_coo == 0;
+                if (plan->hyb_coo_plan) (void)cmi_plan_info(plan->hyb_coo_plan, nullptr, nullptr, nullptr, &sub);
+                exact = sub;
+            }
             break;
         }
         *storage_order_sums = exact;

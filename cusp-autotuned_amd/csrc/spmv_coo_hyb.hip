@@ -436,6 +436,10 @@ static int spmv_coo(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     if (rows > INT32_MAX || cols > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_coo: sizes exceed the int32 index type");
     if (rows == 0) return CMI_SUCCESS;
     if (!y || (nnz > 0 && (!Ai || !Aj || !Ax || !x))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_coo: null array");
+    if (plan && plan->coo_csr_plan) { // sorted entries: the plan's row offsets + the CSR kernels (the row indices are not read)
+        if constexpr (std::is_same<T, double>::value) return cmi_spmv_csr_plan_f64(plan->coo_csr_plan, plan->coo_offsets, Aj, Ax, x, y, accumulate, stream);
+        else return cmi_spmv_csr_plan_f32(plan->coo_csr_plan, plan->coo_offsets, Aj, Ax, x, y, accumulate, stream);
+    }
     cmi_config c;
     if (plan) c = plan->cfg;
     else select_config(CMI_FORMAT_COO, dtype, rows, cols, nnz, user, &c);
@@ -641,6 +645,7 @@ static int spmv_hyb_plan(const cmi_plan *plan, int dtype, int64_t pitch, const i
         if constexpr (std::is_same<T, double>::value) st = cmi_spmv_ell_f64(rows, plan->cols, width, pitch, eAj, eAx, nullptr, x, y, accumulate, &plan->cfg, stream);
         else st = cmi_spmv_ell_f32(rows, plan->cols, width, pitch, eAj, eAx, nullptr, x, y, accumulate, &plan->cfg, stream);
         if (st || coo == 0) return st;
+        if (plan->hyb_coo_plan) return spmv_coo<T>(dtype, rows, plan->cols, coo, cAi, cAj, cAx, x, y, 1, nullptr, stream, plan->hyb_coo_plan);
         return spmv_coo<T>(dtype, rows, plan->cols, coo, cAi, cAj, cAx, x, y, 1, &plan->hyb_coo_cfg, stream);
     }
     if (rows == 0) return CMI_SUCCESS;
@@ -698,6 +703,27 @@ CMI_API int cmi_spmv_coo_plan_f32(const cmi_plan *plan, const int32_t *Ai, const
     if (!plan || plan->format != CMI_FORMAT_COO || plan->dtype != CMI_F32)
         return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_coo_plan_f32: null plan, or a plan made for another format or value type");
     return cmi::spmv_coo<float>(CMI_F32, plan->rows, plan->cols, plan->nnz, Ai, Aj, Ax, x, y, accumulate, nullptr, stream, plan);
+}
+
+// y <- A x and *dot_dev <- <y, w> (a double) through a COO plan: sorted entries run the CSR kernel's fused dot on the plan's row
+// offsets; otherwise the multiply followed by the library's dot.
+CMI_API int cmi_spmv_coo_dot_plan_f64(const cmi_plan *plan, const int32_t *Ai, const int32_t *Aj, const double *Ax, const double *x,
+                                      double *y, const double *w, double *dot_dev, void *workspace, void *stream)
+{
+    if (!plan || plan->format != CMI_FORMAT_COO || plan->dtype != CMI_F64)
+        return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_coo_dot_plan_f64: null plan, or a plan made for another format or value type");
+    if (plan->coo_csr_plan) return cmi_spmv_csr_dot_plan_f64(plan->coo_csr_plan, plan->coo_offsets, Aj, Ax, x, y, w, dot_dev, workspace, stream);
+    const int st = cmi_spmv_coo_plan_f64(plan, Ai, Aj, Ax, x, y, 0, stream);
+    return st ? st : cmi_blas_dot_f64(plan->rows, y, w, dot_dev, workspace, stream);
+}
+CMI_API int cmi_spmv_coo_dot_plan_f32(const cmi_plan *plan, const int32_t *Ai, const int32_t *Aj, const float *Ax, const float *x,
+                                      float *y, const float *w, double *dot_dev, void *workspace, void *stream)
+{
+    if (!plan || plan->format != CMI_FORMAT_COO || plan->dtype != CMI_F32)
+        return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_coo_dot_plan_f32: null plan, or a plan made for another format or value type");
+    if (plan->coo_csr_plan) return cmi_spmv_csr_dot_plan_f32(plan->coo_csr_plan, plan->coo_offsets, Aj, Ax, x, y, w, dot_dev, workspace, stream);
+    const int st = cmi_spmv_coo_plan_f32(plan, Ai, Aj, Ax, x, y, 0, stream);
+    return st ? st : cmi_blas_dotd_f32(plan->rows, y, w, dot_dev, workspace, stream);
 }
 
 // HYB = ELL part with the caller's accumulate, then the COO part accumulating on top, same stream.

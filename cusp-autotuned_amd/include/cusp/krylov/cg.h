@@ -100,6 +100,17 @@ template <typename A, typename V> void multiply_dot(const A &a, const V &p, V &y
     cusp::detail::check(cmi_spmv_dia_dot_f64(a.num_rows, a.num_cols, a.values.num_cols, a.values.pitch, a.diagonal_offsets.data(),
                                              cusp::detail::data_of(a.values), p.data(), y.data(), p.data(), yp, ws, cusp::detail::forced_config(), nullptr));
 }
+// COO through its plan: sorted entries run the CSR kernel's fused dot on the plan's row offsets
+template <typename A, typename V> void multiply_dot(const A &a, const V &p, V &y, double *yp, void *ws, cusp::coo_format)
+{
+    cusp::detail::require_int_index<A>();
+    if (const cmi_plan *pl = cusp::detail::plan_of(a, nullptr, 0)) {
+        cusp::detail::check(cmi_spmv_coo_dot_plan_f64(pl, a.row_indices.data(), a.column_indices.data(), a.values.data(), p.data(), y.data(), p.data(), yp, ws, nullptr));
+        return;
+    }
+    cusp::multiply(a, p, y);
+    cusp::detail::check(cmi_blas_dot_f64(a.num_rows, y.data(), p.data(), yp, ws, nullptr));
+}
 // HYB whose COO part is empty (the tuned width rule keeps regular matrices entirely in the ELL part): the ELL kernel's fused dot
 template <typename A, typename V> void multiply_dot(const A &a, const V &p, V &y, double *yp, void *ws, cusp::hyb_format)
 {
@@ -210,6 +221,17 @@ template <typename A, typename V> void multiply_dot_f32(const A &a, const V &p, 
     if (p.size() != a.num_cols || y.size() != a.num_rows) throw cusp::invalid_input_exception("cg: vector sizes do not match the matrix");
     cusp::detail::check(cmi_spmv_dia_dot_f32(a.num_rows, a.num_cols, a.values.num_cols, a.values.pitch, a.diagonal_offsets.data(),
                                              cusp::detail::data_of(a.values), p.data(), y.data(), p.data(), yp, ws, cusp::detail::forced_config(), nullptr));
+}
+template <typename A, typename V> void multiply_dot_f32(const A &a, const V &p, V &y, double *yp, void *ws, cusp::coo_format)
+{
+    cusp::detail::require_int_index<A>();
+    if (p.size() != a.num_cols || y.size() != a.num_rows) throw cusp::invalid_input_exception("cg: vector sizes do not match the matrix");
+    if (const cmi_plan *pl = cusp::detail::plan_of(a, nullptr, 0)) {
+        cusp::detail::check(cmi_spmv_coo_dot_plan_f32(pl, a.row_indices.data(), a.column_indices.data(), a.values.data(), p.data(), y.data(), p.data(), yp, ws, nullptr));
+        return;
+    }
+    cusp::multiply(a, p, y);
+    cusp::detail::check(dotd_(y.size(), y.data(), p.data(), yp, ws));
 }
 template <typename A, typename V> void multiply_dot_f32(const A &a, const V &p, V &y, double *yp, void *ws, cusp::hyb_format)
 {

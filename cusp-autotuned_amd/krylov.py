@@ -154,7 +154,7 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
     import torch
     from . import binding as B
     from .distributed import ShardedCsr
-    from .matrices import CsrMatrix, DiaMatrix, EllMatrix, HybMatrix
+    from .matrices import CooMatrix, CsrMatrix, DiaMatrix, EllMatrix, HybMatrix
     dev = x.device
     rr = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(2)]  # <r,r> ping-pong
     yp = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -182,6 +182,8 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
         elif isinstance(A, CsrMatrix) and p.is_cuda:
             B.spmv_csr_dot(A.num_rows, A.num_cols, A.row_offsets, A.column_indices, A.values, p, y, p, yp, ops.ws,
                            plan=A.plan() if A.num_entries > 0 else None)
+        elif isinstance(A, CooMatrix) and p.is_cuda and A.num_entries > 0:   # sorted entries: the CSR kernel's fused dot on the plan's offsets
+            B.spmv_coo_dot_plan(A.plan(), A.row_indices, A.column_indices, A.values, p, y, p, yp, ops.ws)
         elif isinstance(A, HybMatrix) and A.coo.num_entries == 0 and p.is_cuda:   # everything in the ELL part: its fused dot
             e = A.ell
             B.spmv_ell_dot(A.num_rows, A.num_cols, e.num_entries_per_row, e.pitch, e.column_indices, e.values, p, y, p, yp, ops.ws)

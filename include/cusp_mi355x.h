@@ -205,10 +205,11 @@ int cmi_tuning_select(int format, int dtype, int64_t num_rows, int64_t num_cols,
  *       num_rows * k  +  [the COO part is not empty] * (threshold + relative_speed * coo_entries(k))      (in ELL slots)
  *       -- relative_speed = cost of a COO entry in ELL slots, threshold = fixed cost of the second launch in ELL slots.
  *       The reference's rule is this model's marginal test without the launch term.  Measured on MI355X
- *       (tools/autotune_hyb.py, profiles/r02_autotune_hyb*): while HYB was two launches the launch term decided small
- *       matrices and the fit was (1.3, 5e6); with the one-launch kernel of cmi_spmv_hyb_plan_* the term vanishes and the
- *       shipped pair is (2.0, 0) for f64 and (3.3, 0) for f32 -- geometric-mean regret over the tuning set 1.013 / 1.033
- *       against 1.050 / 1.072 (worst 1.40) for the reference's (3, 4096).                                                */
+ *       (tools/autotune_hyb.py, profiles/r02_autotune_hyb*), once per generation of the kernels behind a HYB multiply:
+ *       two launches with the COO tile kernel (1.3, 5e6); one launch for light COO parts (2.0, 0); and, shipped, heavy COO
+ *       parts through a COO plan's row offsets + the CSR kernel: (1.0, 2e6) for f64, (1.3, 2e6) for f32 -- a COO entry costs
+ *       what an ELL slot costs, irregular matrices get a narrow ELL part; geometric-mean regret over the tuning set 1.11
+ *       against 1.18 for the reference's (3, 4096), every absolute time at or below the earlier generations'.             */
 typedef enum cmi_hyb_rule_kind { CMI_HYB_RULE_REFERENCE = 0, CMI_HYB_RULE_COST = 1 } cmi_hyb_rule_kind;
 int cmi_tuning_hyb_rule(int dtype, int *kind, double *relative_speed, int64_t *threshold);
 int cmi_tuning_set_hyb_rule(int dtype, int kind, double relative_speed, int64_t threshold);
@@ -225,7 +226,10 @@ int cmi_hyb_entries_per_row(int dtype, int64_t num_rows, const int32_t *Ap, int 
 /* caller's config, completed), for CSR the row-length profile (longest row,    */
 /* entries in rows of 512+: picks the long-row instance of csr_stream or the     */
 /* merge-path kernel), for COO whether the entries are sorted by row (then the   */
-/* tile kernel runs: plain stores, no zero fill, no atomics, storage-order sums). */
+/* plan builds the row offsets they imply -- 4 bytes per row that it owns -- and   */
+/* every multiply runs the CSR kernels on them, never reading the row indices:      */
+/* 12 instead of 16 bytes per entry, storage-order sums, no zero fill, no atomics;  */
+/* an explicit CMI_COO_TILE config keeps the COO tile kernel).                      */
 /* The reference has no equivalent object: its KTT path keeps such state in       */
 /* function-local statics keyed by nothing (cuda/ktt/csr_multiply.h:22-29,239-247) */
 /* and recomputes `row_starts` on the host per call.                               */
@@ -258,7 +262,7 @@ int cmi_get_index_compression(void);
 int cmi_plan_create_hyb(int dtype, int64_t num_rows, int64_t num_cols, int64_t ell_entries_per_row, int64_t coo_entries,
                         const int32_t *coo_row_indices, const cmi_config *cfg_ell, const cmi_config *cfg_coo, void *stream,
                         cmi_plan **plan);
-/* How many kernels a multiply through this HYB plan launches: 1 (hyb_tile: COO part sorted and light -- at most 4       */
+/* How many kernels a multiply through this HYB plan launches: 1 (hyb_tile: COO part sorted and light -- at most 3       */
 /* entries per row on average, no 256-row tile holding more than 4096 -- or empty) or 2 (ELL kernel, then a COO kernel        */
 /* accumulating: heavy or unsorted COO parts).  $CMI_HYB_ONE_LAUNCH=0/1 at plan creation overrides the weight rule.           */
 int cmi_plan_hyb_launches(const cmi_plan *plan, int *launches);
@@ -377,6 +381,11 @@ int cmi_spmv_coo_plan_f64(const cmi_plan *plan, const int32_t *Ai, const int32_t
                           const double *x, double *y, int accumulate, void *stream);
 int cmi_spmv_coo_plan_f32(const cmi_plan *plan, const int32_t *Ai, const int32_t *Aj, const float *Ax,
                           const float *x, float *y, int accumulate, void *stream);
+/* ... and with <y, w> (a double) in the same pass where the plan runs the CSR kernel on its row offsets (sorted entries).      */
+int cmi_spmv_coo_dot_plan_f64(const cmi_plan *plan, const int32_t *Ai, const int32_t *Aj, const double *Ax, const double *x,
+                              double *y, const double *w, double *dot_dev, void *workspace, void *stream);
+int cmi_spmv_coo_dot_plan_f32(const cmi_plan *plan, const int32_t *Ai, const int32_t *Aj, const float *Ax, const float *x,
+                              float *y, const float *w, double *dot_dev, void *workspace, void *stream);
 
 /* HYB = ELL part (caller's accumulate) then COO part accumulating on top
  * (generic/multiply/spmv.h:275-290; oracle sequential/multiply/hyb_spmv.h:42-57).

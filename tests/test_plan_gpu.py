@@ -69,17 +69,26 @@ def test_coo_plan_sorted_and_unsorted(cmi, torch_cuda, orc, golden_irregular):
     want = orc.spmv_coo(rows, Ai, Aj, Ax, x)
     dx = dev(x, torch)
     ps = cmi.Plan(cmi.FORMAT_COO, torch.float64, rows, cols, len(Aj), dev(Ai, torch))
-    # sorted entries: the plan runs the table's sorted-COO key (the tile kernel wherever it is the fastest for sorted input)
+    # sorted entries: the plan builds the row offsets the row indices imply and runs what a CSR plan of them runs (the row
+    # indices are never read again: 12 instead of 16 bytes per entry) -- same kernel choice, same result class
     assert ps.info()["coo_sorted"] is True
-    # ... unless a row holds more than one tile of entries (this fixture has a 5000-entry row): the tile kernel would walk that
-    # row's tail serially, so the plan keeps the order-agnostic key
-    key = cmi.FORMAT_COO if (np.diff(Ap) > 1024).any() else cmi.TABLE_COO_SORTED
-    assert ps.config().as_dict() == cmi.tuning_select(key, cmi.F64, rows, cols, len(Aj)).as_dict()
-    Ap_s, Aj_s, Ax_s = orc.poisson5pt_csr(37, 29)   # short rows only: the sorted-COO key
-    Ai_s = orc.csr_row_indices(Ap_s)
-    pss = cmi.Plan(cmi.FORMAT_COO, torch.float64, 37 * 29, 37 * 29, len(Aj_s), dev(Ai_s, torch))
-    assert pss.config().as_dict() == cmi.tuning_select(cmi.TABLE_COO_SORTED, cmi.F64, 37 * 29, 37 * 29, len(Aj_s)).as_dict()
-    assert ps.info()["storage_order_sums"] == (ps.config().kernel == cmi.COO_TILE)
+    pc = cmi.Plan(cmi.FORMAT_CSR, torch.float64, rows, cols, len(Aj), dev(Ap, torch))
+    assert ps.config().as_dict() == pc.config().as_dict()
+    assert ps.info()["storage_order_sums"] == pc.info()["storage_order_sums"]
+    # with $CMI_COO_PLAN_OFFSETS=0 the plan keeps the COO kernels: the table's sorted-COO key (the tile kernel) -- unless a row
+    # holds more than one tile of entries (this fixture has a 5000-entry row: its tail would be walked serially)
+    os.environ["CMI_COO_PLAN_OFFSETS"] = "0"
+    try:
+        pk = cmi.Plan(cmi.FORMAT_COO, torch.float64, rows, cols, len(Aj), dev(Ai, torch))
+        key = cmi.FORMAT_COO if (np.diff(Ap) > 1024).any() else cmi.TABLE_COO_SORTED
+        assert pk.config().as_dict() == cmi.tuning_select(key, cmi.F64, rows, cols, len(Aj)).as_dict()
+        assert pk.info()["storage_order_sums"] == (pk.config().kernel == cmi.COO_TILE)
+        Ap_s, Aj_s, Ax_s = orc.poisson5pt_csr(37, 29)   # short rows only: the sorted-COO key
+        Ai_s = orc.csr_row_indices(Ap_s)
+        pss = cmi.Plan(cmi.FORMAT_COO, torch.float64, 37 * 29, 37 * 29, len(Aj_s), dev(Ai_s, torch))
+        assert pss.config().as_dict() == cmi.tuning_select(cmi.TABLE_COO_SORTED, cmi.F64, 37 * 29, 37 * 29, len(Aj_s)).as_dict()
+    finally:
+        os.environ.pop("CMI_COO_PLAN_OFFSETS", None)
     y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
     cmi.spmv_coo_plan(ps, dev(Ai, torch), dev(Aj, torch), dev(Ax, torch), dx, y)
     bound0 = orc.spmv_csr(Ap, Aj, np.abs(Ax), np.abs(x))
@@ -207,7 +216,7 @@ def test_hyb_plan_one_launch(cmi, torch_cuda, orc, tag, shape):
             assert pl.hyb_launches() == (1 if force == "1" else 2), (shape, force)
         elif len(cAi):  # the weight rule, restated
             per_tile = np.bincount(cAi // 256, minlength=(rows + 255) // 256)
-            assert pl.hyb_launches() == (1 if len(cAi) <= 4.0 * rows and per_tile.max() <= 4096 else 2), (shape, len(cAi), per_tile.max())
+            assert pl.hyb_launches() == (1 if len(cAi) <= 3.0 * rows and per_tile.max() <= 4096 else 2), (shape, len(cAi), per_tile.max())
         y = torch.full((rows,), 10.0, dtype=dx.dtype, device="cuda")
         cmi.spmv_hyb_plan(pl, p, *d, dx, y)
         ya = torch.from_numpy(y0).cuda()

@@ -146,14 +146,14 @@ def run_all_formats(cmi, torch, orc, rows, cols, Ap, Aj, Ax, x, want, want_acc, 
         # row-sorted entries through a plan: the tile kernel, storage-order sums = the host loop's bits
         plan = cmi.Plan(cmi.FORMAT_COO, dx.dtype, rows, cols, len(Aj), dAi)
         assert plan.info()["coo_sorted"] is True
-        assert plan.info()["storage_order_sums"] == (plan.config().kernel == cmi.COO_TILE)
+        coo_exact = plan.info()["storage_order_sums"]  # sorted entries: the plan's row offsets + a CSR kernel (or the COO tile kernel)
         for swz, nt in ((0, 0), (1, 2), (3, 3), (32, 1)):
             y = fresh(acc)
             cmi.spmv_coo(rows, cols, dAi, dAj, dAx, dx, y, accumulate=acc, cfg=cmi.Config(kernel=cmi.COO_TILE, xcd_swizzle=swz, nontemporal=nt))
             assert np.array_equal(host(y), w), f"{label} coo tile x{swz} nt{nt} acc={acc}: not bit-exact"
         y = fresh(acc)
         cmi.spmv_coo_plan(plan, dAi, dAj, dAx, dx, y, accumulate=acc)
-        if plan.config().kernel == cmi.COO_TILE and len(Aj) >= 4:
+        if coo_exact and len(Aj) >= 4:
             assert np.array_equal(host(y), w), f"{label} coo plan acc={acc}: not bit-exact"
         else:
             assert_close(host(y), w, bound, dtype, f"{label} coo plan acc={acc}")
@@ -682,7 +682,7 @@ def test_multiply_inside_hip_graph_capture(cmi, torch_cuda, orc):
     side = torch.cuda.Stream()
     mats["coo planned"] = cmi.convert(A, "coo")
     mats["coo planned"].plan()
-    tile_planned = mats["coo planned"].plan().config().kernel == cmi.COO_TILE
+    tile_planned = mats["coo planned"].plan().info()["storage_order_sums"]  # (through its plan a sorted COO multiply is exact)
     for fmt, M in mats.items():
         y = torch.full((n,), 7.0, dtype=torch.float64, device="cuda")
         side.wait_stream(torch.cuda.current_stream())
