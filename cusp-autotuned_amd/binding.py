@@ -148,6 +148,8 @@ def _declare(L):
     L.cmi_count_zeros_f32.argtypes = [i64, vp, POINTER(c_int64), vp]
     L.cmi_tuning_hyb_rule.argtypes = [c_int, POINTER(c_int), POINTER(c_double), POINTER(c_int64)]
     L.cmi_tuning_set_hyb_rule.argtypes = [c_int, c_int, c_double, i64]
+    L.cmi_tuning_hyb_light_speed.argtypes = [c_int, POINTER(c_double)]
+    L.cmi_tuning_set_hyb_light_speed.argtypes = [c_int, c_double]
     L.cmi_hyb_entries_per_row.argtypes = [c_int, i64, vp, c_int, c_double, i64, POINTER(c_int64), vp]
     L.cmi_plan_create.argtypes = [c_int, c_int, i64, i64, i64, vp, cfgp, vp, POINTER(c_void_p)]
     L.cmi_plan_destroy.argtypes = [vp]
@@ -542,7 +544,7 @@ def tuning_select(fmt, dtype, num_rows, num_cols, num_entries):
     return c
 
 
-HYB_RULE_REFERENCE, HYB_RULE_COST = 0, 1
+HYB_RULE_REFERENCE, HYB_RULE_COST, HYB_RULE_COST2 = 0, 1, 2
 
 
 def count_zeros(values, stream=None):
@@ -558,6 +560,17 @@ def tuning_hyb_rule(dtype):
     k, rs, th = c_int(), c_double(), c_int64()
     check(lib().cmi_tuning_hyb_rule(dtype, byref(k), byref(rs), byref(th)))
     return k.value, rs.value, th.value
+
+
+def tuning_hyb_light_speed(dtype):
+    """HYB_RULE_COST2's fourth parameter: cost of a COO entry (ELL slots) while the COO part is light enough for one launch."""
+    v = c_double()
+    check(lib().cmi_tuning_hyb_light_speed(dtype, byref(v)))
+    return v.value
+
+
+def tuning_set_hyb_light_speed(dtype, light_speed):
+    check(lib().cmi_tuning_set_hyb_light_speed(dtype, float(light_speed)))
 
 
 def tuning_set_hyb_rule(dtype, kind, relative_speed, threshold):

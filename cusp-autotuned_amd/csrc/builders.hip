@@ -709,8 +709,13 @@ CMI_API int cmi_hyb_entries_per_row(int dtype, int64_t num_rows, const int32_t *
         const int st = cmi_tuning_hyb_rule(dtype, &kind, &relative_speed, &threshold);
         if (st) return st;
     }
-    if ((kind != CMI_HYB_RULE_REFERENCE && kind != CMI_HYB_RULE_COST) || !(relative_speed > 0.0) || threshold < 0)
+    if (kind < CMI_HYB_RULE_REFERENCE || kind > CMI_HYB_RULE_COST2 || !(relative_speed > 0.0) || threshold < 0)
         return fail(CMI_ERROR_INVALID_VALUE, "cmi_hyb_entries_per_row: bad rule");
+    double light_speed = relative_speed;
+    if (kind == CMI_HYB_RULE_COST2) {
+        const int st = cmi_tuning_hyb_light_speed(dtype, &light_speed);
+        if (st) return st;
+    }
     hipStream_t s = as_stream(stream);
     unsigned int *dev = nullptr;
     const size_t bytes = (size_t)(kHybCap + 1) * sizeof(unsigned int);
@@ -746,7 +751,10 @@ CMI_API int cmi_hyb_entries_per_row(int dtype, int64_t num_rows, const int32_t *
         for (int k = max_len - 1; k >= 0; k--) {
             longer += hist[k + 1]; // rows of length > k
             coo += (double)longer;
-            const double cost = (double)num_rows * (double)k + (double)threshold + relative_speed * coo;
+            // COST2: while the COO part is light enough for the one-launch kernel (the plan's own limit, kHybFusedMaxPerRow entries
+            // per row) an entry costs light_speed slots and there is no second launch
+            const bool light = kind == CMI_HYB_RULE_COST2 && coo <= kHybFusedMaxPerRow * (double)num_rows;
+            const double cost = (double)num_rows * (double)k + (light ? light_speed * coo : (double)threshold + relative_speed * coo);
             if (cost < best) { best = cost; K = k; } // strict: ties go to the wider ELL part (fewer launches)
         }
     }

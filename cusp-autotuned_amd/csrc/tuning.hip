@@ -30,6 +30,7 @@ struct Table {
     int hyb_kind[2];
     double hyb_relative_speed[2];
     long hyb_threshold[2];
+    double hyb_light_speed[2]; // CMI_HYB_RULE_COST2: cost of a COO entry while the COO part is light (one-launch kernel)
 };
 constexpr double kRefRelativeSpeed = 3.0; // reference csr_to_other.h:248-254
 constexpr long kRefBreakeven = 4096;
@@ -215,9 +216,12 @@ static int load_file(const char *path)
             std::string kind;
             if (find_double(obj, "relative_speed", &rs) && find_int(obj, "threshold", &be) && rs > 0.0 && be >= 0) {
                 g_table.hyb_valid[di] = true;
-                g_table.hyb_kind[di] = (find_str(obj, "kind", &kind) && kind == "cost") ? CMI_HYB_RULE_COST : CMI_HYB_RULE_REFERENCE;
+                const bool has_kind = find_str(obj, "kind", &kind);
+                g_table.hyb_kind[di] = (has_kind && kind == "cost2") ? CMI_HYB_RULE_COST2 : (has_kind && kind == "cost") ? CMI_HYB_RULE_COST : CMI_HYB_RULE_REFERENCE;
                 g_table.hyb_relative_speed[di] = rs;
                 g_table.hyb_threshold[di] = be;
+                double light = 0.0;
+                g_table.hyb_light_speed[di] = (find_double(obj, "light_speed", &light) && light > 0.0) ? light : rs;
             }
         }
     }
@@ -363,8 +367,9 @@ CMI_API int cmi_tuning_save(const char *path)
         bool first_rule = true;
         for (int di = 0; di < 2; di++)
             if (g_table.hyb_valid[di]) {
-                std::fprintf(f, "%s\"%s\": {\"kind\": \"%s\", \"relative_speed\": %.4f, \"threshold\": %ld}", first_rule ? "" : ", ", kDtypeNames[di],
-                             g_table.hyb_kind[di] == CMI_HYB_RULE_COST ? "cost" : "reference", g_table.hyb_relative_speed[di], g_table.hyb_threshold[di]);
+                std::fprintf(f, "%s\"%s\": {\"kind\": \"%s\", \"relative_speed\": %.4f, \"threshold\": %ld, \"light_speed\": %.4f}", first_rule ? "" : ", ",
+                             kDtypeNames[di], g_table.hyb_kind[di] == CMI_HYB_RULE_COST2 ? "cost2" : g_table.hyb_kind[di] == CMI_HYB_RULE_COST ? "cost" : "reference",
+                             g_table.hyb_relative_speed[di], g_table.hyb_threshold[di], g_table.hyb_light_speed[di]);
                 first_rule = false;
             }
         std::fprintf(f, "},\n");
@@ -430,14 +435,40 @@ CMI_API int cmi_tuning_hyb_rule(int dtype, int *kind, double *relative_speed, in
 
 CMI_API int cmi_tuning_set_hyb_rule(int dtype, int kind, double relative_speed, int64_t threshold)
 {
-    if (dtype < 0 || dtype > 1 || (kind != CMI_HYB_RULE_REFERENCE && kind != CMI_HYB_RULE_COST) || !(relative_speed > 0.0) || threshold < 0)
+    if (dtype < 0 || dtype > 1 || kind < CMI_HYB_RULE_REFERENCE || kind > CMI_HYB_RULE_COST2 || !(relative_speed > 0.0) || threshold < 0)
         return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_set_hyb_rule: bad value type, kind, speed or threshold");
     std::lock_guard<std::mutex> lk(g_mu);
     ensure_default_loaded();
+    if (!g_table.hyb_valid[dtype]) g_table.hyb_light_speed[dtype] = relative_speed;
     g_table.hyb_valid[dtype] = true;
     g_table.hyb_kind[dtype] = kind;
     g_table.hyb_relative_speed[dtype] = relative_speed;
     g_table.hyb_threshold[dtype] = (long)threshold;
+    return CMI_SUCCESS;
+}
+
+// the fourth parameter of CMI_HYB_RULE_COST2 (ignored by the other kinds): cost of a COO entry, in ELL slots, while the COO part is
+// light enough for the one-launch kernel
+CMI_API int cmi_tuning_hyb_light_speed(int dtype, double *light_speed)
+{
+    if (dtype < 0 || dtype > 1 || !light_speed) return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_hyb_light_speed: bad argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    ensure_default_loaded();
+    *light_speed = g_table.hyb_valid[dtype] ? g_table.hyb_light_speed[dtype] : kRefRelativeSpeed;
+    return CMI_SUCCESS;
+}
+CMI_API int cmi_tuning_set_hyb_light_speed(int dtype, double light_speed)
+{
+    if (dtype < 0 || dtype > 1 || !(light_speed > 0.0)) return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_set_hyb_light_speed: bad argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    ensure_default_loaded();
+    if (!g_table.hyb_valid[dtype]) { // a light speed alone: the reference's rule stays until a kind is set
+        g_table.hyb_valid[dtype] = true;
+        g_table.hyb_kind[dtype] = CMI_HYB_RULE_REFERENCE;
+        g_table.hyb_relative_speed[dtype] = kRefRelativeSpeed;
+        g_table.hyb_threshold[dtype] = kRefBreakeven;
+    }
+    g_table.hyb_light_speed[dtype] = light_speed;
     return CMI_SUCCESS;
 }
 

@@ -206,11 +206,17 @@ int cmi_tuning_select(int format, int dtype, int64_t num_rows, int64_t num_cols,
  *       -- relative_speed = cost of a COO entry in ELL slots, threshold = fixed cost of the second launch in ELL slots.
  *       The reference's rule is this model's marginal test without the launch term.  Measured on MI355X
  *       (tools/autotune_hyb.py, profiles/r02_autotune_hyb*), once per generation of the kernels behind a HYB multiply:
- *       two launches with the COO tile kernel (1.3, 5e6); one launch for light COO parts (2.0, 0); and, shipped, heavy COO
- *       parts through a COO plan's row offsets + the CSR kernel: (1.0, 2e6) for f64, (1.3, 2e6) for f32 -- a COO entry costs
- *       what an ELL slot costs, irregular matrices get a narrow ELL part; geometric-mean regret over the tuning set 1.11
- *       against 1.18 for the reference's (3, 4096), every absolute time at or below the earlier generations'.             */
-typedef enum cmi_hyb_rule_kind { CMI_HYB_RULE_REFERENCE = 0, CMI_HYB_RULE_COST = 1 } cmi_hyb_rule_kind;
+ *       two launches with the COO tile kernel (1.3, 5e6); one launch for light COO parts (2.0, 0); and heavy COO parts
+ *       through a COO plan's row offsets + the CSR kernel: (1.0, 2e6) for f64, (1.3, 2e6) for f32 -- a COO entry costs what
+ *       an ELL slot costs, irregular matrices get a narrow ELL part; geometric-mean regret over the tuning set 1.11 against
+ *       1.18 for the reference's (3, 4096).  Shipped: CMI_HYB_RULE_COST2 below (1.05).                                      */
+/*   CMI_HYB_RULE_COST2  the cost model with the two regimes a HYB plan has (cmi_plan_hyb_launches): while the COO part is light
+ *       (at most 3 entries per row on average) the multiply is ONE launch and a COO entry costs `light_speed` ELL slots; beyond,
+ *       it is ELL + the CSR kernel on the COO plan's row offsets:  threshold + relative_speed * coo_entries(k).  Offline on the
+ *       sweep log (tools/autotune_hyb.py --refit): geometric-mean regret 1.03 (f64) / 1.06 (f32) against 1.11 for COST.       */
+typedef enum cmi_hyb_rule_kind { CMI_HYB_RULE_REFERENCE = 0, CMI_HYB_RULE_COST = 1, CMI_HYB_RULE_COST2 = 2 } cmi_hyb_rule_kind;
+int cmi_tuning_hyb_light_speed(int dtype, double *light_speed);      /* COST2's fourth parameter (persisted as "light_speed") */
+int cmi_tuning_set_hyb_light_speed(int dtype, double light_speed);
 int cmi_tuning_hyb_rule(int dtype, int *kind, double *relative_speed, int64_t *threshold);
 int cmi_tuning_set_hyb_rule(int dtype, int kind, double relative_speed, int64_t threshold);
 /* The width a rule gives for the CSR matrix with these row offsets: histogram of the row lengths on the device, rule on

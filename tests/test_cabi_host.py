@@ -235,7 +235,7 @@ def test_hyb_rule_and_sorted_coo_key_in_the_table(cmi, tmp_path):
     path = str(tmp_path / "rule.json")
     cmi.tuning_save(path)
     doc = json.load(open(path))
-    assert doc["hyb_rule"] == {"f64": {"kind": "cost", "relative_speed": 1.6, "threshold": 512}}
+    assert doc["hyb_rule"] == {"f64": {"kind": "cost", "relative_speed": 1.6, "threshold": 512, "light_speed": 1.6}}
     assert [e["format"] for e in doc["entries"]] == ["coo_sorted"]
     cmi.tuning_clear()
     assert cmi.tuning_hyb_rule(cmi.F64) == (cmi.HYB_RULE_REFERENCE, 3.0, 4096)
@@ -244,6 +244,17 @@ def test_hyb_rule_and_sorted_coo_key_in_the_table(cmi, tmp_path):
     assert cmi.tuning_hyb_rule(cmi.F32) == (cmi.HYB_RULE_REFERENCE, 3.0, 4096)
     c = cmi.tuning_select(cmi.TABLE_COO_SORTED, cmi.F32, 1000, 1000, 5000)
     assert (c.kernel, c.nontemporal, c.xcd_swizzle) == (cmi.COO_TILE, 3, 64)
+    # the two-regime kind and its fourth parameter survive the file too
+    cmi.tuning_set_hyb_rule(cmi.F32, cmi.HYB_RULE_COST2, 1.1, 2_000_000)
+    cmi.tuning_set_hyb_light_speed(cmi.F32, 3.0)
+    cmi.tuning_save(path)
+    assert json.load(open(path))["hyb_rule"]["f32"] == {"kind": "cost2", "relative_speed": 1.1, "threshold": 2000000, "light_speed": 3.0}
+    cmi.tuning_clear()
+    assert cmi.tuning_hyb_light_speed(cmi.F32) == 3.0                            # no table: the reference's relative speed
+    cmi.tuning_load(path)
+    assert cmi.tuning_hyb_rule(cmi.F32) == (cmi.HYB_RULE_COST2, 1.1, 2_000_000) and cmi.tuning_hyb_light_speed(cmi.F32) == 3.0
+    with pytest.raises(cmi.CmiError):
+        cmi.tuning_set_hyb_light_speed(cmi.F32, 0.0)
     cmi.tuning_clear()
 
 

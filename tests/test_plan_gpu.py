@@ -292,9 +292,23 @@ def test_hyb_width_rule(cmi, torch_cuda, orc, golden_irregular):
         cost = N * ks.astype(np.float64) + np.where(coo > 0, th + rs * coo, 0.0)
         return int(ks[cost == cost.min()].max())            # ties: the wider ELL part
 
+    def cost2_width(Ap, rs, th, light):                     # two regimes: light COO part (<= 3 entries per row) = one launch
+        lens = np.minimum(np.diff(Ap).astype(np.int64), 4096)
+        N, mx = len(lens), int(lens.max())
+        ks = np.arange(mx + 1)
+        coo = np.array([np.maximum(lens - k, 0).sum() for k in ks], dtype=np.float64)
+        cost = N * ks.astype(np.float64) + np.where(coo > 0, np.where(coo <= 3.0 * N, light * coo, th + rs * coo), 0.0)
+        return int(ks[cost == cost.min()].max())
+
+    shipped_rule = {dt: (cmi.tuning_hyb_rule(dt), cmi.tuning_hyb_light_speed(dt)) for dt in (cmi.F64, cmi.F32)}
     for Ap in cases:
         rows = len(Ap) - 1
         dAp = dev(Ap, torch)
+        for rs, th, light in ((1.0, 2_000_000, 3.0), (1.1, 0, 1.5), (2.0, 50_000, 1.0)):
+            cmi.tuning_set_hyb_light_speed(cmi.F64, light)
+            got = cmi.hyb_entries_per_row(cmi.F64, rows, dAp, cmi.HYB_RULE_COST2, rs, th)
+            assert got == cost2_width(Ap, rs, th, light), (rows, rs, th, light, got, cost2_width(Ap, rs, th, light))
+        cmi.tuning_set_hyb_light_speed(cmi.F64, shipped_rule[cmi.F64][1])
         for rs, be in ((3.0, 4096), (3.0, 0), (1.5, 100), (10.0, 1), (1.0, 0)):
             got = cmi.hyb_entries_per_row(cmi.F64, rows, dAp, cmi.HYB_RULE_REFERENCE, rs, be)
             want = min(orc.optimal_entries_per_row(Ap, rs, be), 4096)
@@ -304,9 +318,10 @@ def test_hyb_width_rule(cmi, torch_cuda, orc, golden_irregular):
             assert got == cost_width(Ap, rs, th), (rows, rs, th, got, cost_width(Ap, rs, th))
     # the tuned rule: what the table (or, with none, the reference's constants) says
     kind, rs, th = cmi.tuning_hyb_rule(cmi.F64)
-    assert kind in (cmi.HYB_RULE_REFERENCE, cmi.HYB_RULE_COST) and rs > 0 and th >= 0
+    assert kind in (cmi.HYB_RULE_REFERENCE, cmi.HYB_RULE_COST, cmi.HYB_RULE_COST2) and rs > 0 and th >= 0
     Ap = cases[2]
-    expect = cost_width(Ap, rs, th) if kind == cmi.HYB_RULE_COST else min(orc.optimal_entries_per_row(Ap, rs, th), 4096)
+    expect = (cost2_width(Ap, rs, th, cmi.tuning_hyb_light_speed(cmi.F64)) if kind == cmi.HYB_RULE_COST2 else
+              cost_width(Ap, rs, th) if kind == cmi.HYB_RULE_COST else min(orc.optimal_entries_per_row(Ap, rs, th), 4096))
     assert cmi.hyb_entries_per_row(cmi.F64, len(Ap) - 1, dev(Ap, torch)) == expect
     # set / get / clear
     shipped = os.path.join(os.path.dirname(cmi.lib_path()), "..", "tuned", "gfx950.json")
