@@ -130,7 +130,7 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
             // entry instead of 16 through the CSR kernels -- same products, storage-order sums, rows of any length.
             // ($CMI_COO_PLAN_OFFSETS=0: keep the COO kernels -- measurements of the tile kernel.)
             const char *off = std::getenv("CMI_COO_PLAN_OFFSETS");
-            if (sorted && auto_kernel && num_entries >= 4 && num_rows > 0 && num_entries <= INT32_MAX && !(off && off[0] == '0')) {
+            if (sorted && auto_kernel && num_entries >= 4 && num_rows > 0 && num_entries <= INT32_MAX - 65536 && !(off && off[0] == '0')) {
                 hipError_t e = hipMalloc((void **)&p->coo_offsets, (size_t)(num_rows + 1) * sizeof(int32_t));
                 if (e != hipSuccess) st = hip_fail(e, "cmi_plan_create: COO row offsets");
                 int sorted2 = 0;
@@ -149,7 +149,8 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
 }
 
 // HYB: the ELL part's launch shape, the COO part's order and -- when it is sorted by row -- the per-tile entry ranges the
-// one-launch kernel (spmv_coo_hyb.hip hyb_tile_kernel) reads.  The only plan that owns device memory: one int per 256 rows.
+// one-launch kernel (spmv_coo_hyb.hip hyb_tile_kernel) reads (one int per 256 rows, owned by the plan); a heavy or unsorted COO
+// part gets a COO plan of its own for the second launch.
 CMI_API int cmi_plan_create_hyb(int dtype, int64_t num_rows, int64_t num_cols, int64_t ell_entries_per_row,
                                 int64_t coo_entries, const int32_t *coo_row_indices, const cmi_config *cfg_ell,
                                 const cmi_config *cfg_coo, void *stream, cmi_plan **plan_out)
