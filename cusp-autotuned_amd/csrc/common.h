@@ -260,6 +260,7 @@ struct cmi_plan {
     int format, dtype;
     int64_t rows, cols, nnz;
     cmi_config cfg;        // resolved launch shape (kernel CMI_CSR_BALANCED when the profile switched kernels)
+    bool cfg_explicit = false; // the caller named the kernel (its launch shape is then left as given)
     cmi::row_profile prof; // CSR
     int coo_sorted;        // COO, HYB's COO part: 1 / 0; -1 otherwise
     // HYB (cmi_plan_create_hyb): ELL width, COO entries, the COO part's launch shape for the two-launch path, and -- when the
@@ -290,7 +291,7 @@ constexpr int kHybFusedMaxInTile = 4096;
 // spmv_csr16.hip: the plan's 16-bit column copy (built only if every tile qualifies) and the multiply that reads it
 int csr16_build(cmi_plan *p, const int *Ap, const int *Aj, hipStream_t s);
 int csr16_multiply_f64(const cmi_plan *p, const int *Ap, const double *Ax, const double *x, double *y, int accumulate,
-                       hipStream_t s, const double *w, double *dot_partial, int *dot_partials, int cache_policy);
+                       hipStream_t s, const double *w, double *dot_partial, int *dot_partials, int cache_policy, int xcd_swizzle);
 int csr16_multiply_f32(const cmi_plan *p, const int *Ap, const float *Ax, const float *x, float *y, int accumulate,
-                       hipStream_t s, const float *w, double *dot_partial, int *dot_partials, int cache_policy);
+                       hipStream_t s, const float *w, double *dot_partial, int *dot_partials, int cache_policy, int xcd_swizzle);
 }

@@ -76,6 +76,7 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
     p->nnz = num_entries;
     p->prof = row_profile{};
     p->coo_sorted = -1;
+    p->cfg_explicit = cfg && cfg->kernel != CMI_KERNEL_AUTO && !(cfg->kernel == CMI_CSR_STREAM_C16 && !(cfg->block_size || cfg->rows_per_block || cfg->items_per_thread));
     // CMI_CSR_STREAM_C16 is csr_stream's shape (the caller's launch-shape fields if any, else the table's) + the 16-bit copy
     cmi_config shape;
     bool want16 = false, table_shape = !cfg || cfg->kernel == CMI_KERNEL_AUTO;

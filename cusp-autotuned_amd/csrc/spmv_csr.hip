@@ -772,6 +772,14 @@ static int launch_vector(int tpr, int grid, int block, hipStream_t s, int64_t ro
     return CMI_SUCCESS;
 }
 
+// XCD dealing of the fused SpMV + <y, w> instance when the shape is the table's (see the call site)
+static int dot_swizzle(int table_swizzle, const cmi_plan *plan)
+{
+    static const int env = [] { const char *e = std::getenv("CMI_DOT_SWIZZLE"); return e ? std::atoi(e) : -1; }();
+    if (plan && plan->cfg_explicit) return table_swizzle; // a shape the caller gave the plan: as given
+    return env >= 0 ? env : 0;
+}
+
 template <typename T, bool VEC, int POL, bool DOT = false, bool LONG = false>
 static int launch_stream_ipt(int ipt, int grid, int block, size_t lds, hipStream_t s, int64_t rows, int64_t nnz,
                              const int *Ap, const int *Aj, const T *Ax, const T *x, T *y, int rpb, int64_t tiles,
@@ -870,7 +878,11 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         if (rpb < 1 || rpb > 4 * (block / tpr)) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream: rows_per_block must be in [1, 4*block_size/threads_per_row]");
         const int64_t tiles = ceil_div(rows, rpb);
         const int64_t tpx = ceil_div(tiles, kXcds);
-        const int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
+        int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
+        // ... and its tiles go out in launch order: inside the solve that measured 2.3-3.5 us per iteration better than any chunk
+        // dealing, for every tile shape (tools/cg_dot_shape_probe.py, profiles/r02_cg_dot_shape.txt) -- stand-alone it is the
+        // other way round (section 3.1 of DESIGN.md).  A caller's explicit shape is left alone; $CMI_DOT_SWIZZLE overrides.
+        if (w && dot_partial && (!user || user->kernel == CMI_KERNEL_AUTO)) swz = dot_swizzle(swz, plan);
         const int64_t grid64 = swz == 0 ? tiles : swz == 1 ? tpx * kXcds : ceil_div(tiles, (int64_t)kXcds * swz) * kXcds * swz;
         if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream: grid too large");
         const size_t lds = (size_t)block * ipt * 4 * sizeof(T) + (size_t)(rpb + 1) * sizeof(int);
@@ -899,8 +911,8 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     case CMI_CSR_STREAM_C16: { // the plan's 16-bit column copy (spmv_csr16.hip); Aj itself is not read
         if (!plan || !plan->csr16_cols) return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_CSR_STREAM_C16 runs through a plan of cmi_plan_create_csr only");
         if (reinterpret_cast<uintptr_t>(Ax) % 16 != 0) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream_c16: values must be 16-byte aligned");
-        if constexpr (std::is_same<T, double>::value) return csr16_multiply_f64(plan, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol);
-        else return csr16_multiply_f32(plan, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol);
+        if constexpr (std::is_same<T, double>::value) return csr16_multiply_f64(plan, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol, (w && dot_partial) ? dot_swizzle(c.xcd_swizzle, plan) : c.xcd_swizzle);
+        else return csr16_multiply_f32(plan, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol, (w && dot_partial) ? dot_swizzle(c.xcd_swizzle, plan) : c.xcd_swizzle);
     }
     case CMI_CSR_STREAM_PIPE: {
         const int rpb = c.rows_per_block;

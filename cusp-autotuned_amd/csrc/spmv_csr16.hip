@@ -197,14 +197,14 @@ csr_stream16_kernel(int64_t num_rows, int64_t num_entries, int num_cols, const i
 
 template <typename T>
 static int csr16_multiply(const cmi_plan *p, const int *Ap, const T *Ax, const T *x, T *y, int accumulate, hipStream_t s,
-                          const T *w, double *dot_partial, int *dot_partials, int pol)
+                          const T *w, double *dot_partial, int *dot_partials, int pol, int swizzle)
 {
     const cmi_config &c = p->cfg;
     const int block = c.block_size, ipt = c.items_per_thread, rpb = c.rows_per_block;
     const int64_t rows = p->rows, nnz = p->nnz;
     const int64_t tiles = ceil_div(rows, rpb);
     const int64_t tpx = ceil_div(tiles, kXcds);
-    const int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
+    const int swz = swizzle < 0 ? 0 : swizzle;
     const int64_t grid64 = padded_grid(tiles, swz);
     if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream_c16: grid too large");
     const size_t lds = (size_t)block * ipt * 4 * sizeof(T);
@@ -232,14 +232,14 @@ static int csr16_multiply(const cmi_plan *p, const int *Ap, const T *Ax, const T
 }
 
 int csr16_multiply_f64(const cmi_plan *p, const int *Ap, const double *Ax, const double *x, double *y, int accumulate,
-                       hipStream_t s, const double *w, double *dot_partial, int *dot_partials, int pol)
+                       hipStream_t s, const double *w, double *dot_partial, int *dot_partials, int pol, int swizzle)
 {
-    return csr16_multiply<double>(p, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol);
+    return csr16_multiply<double>(p, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol, swizzle);
 }
 int csr16_multiply_f32(const cmi_plan *p, const int *Ap, const float *Ax, const float *x, float *y, int accumulate,
-                       hipStream_t s, const float *w, double *dot_partial, int *dot_partials, int pol)
+                       hipStream_t s, const float *w, double *dot_partial, int *dot_partials, int pol, int swizzle)
 {
-    return csr16_multiply<float>(p, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol);
+    return csr16_multiply<float>(p, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol, swizzle);
 }
 
 } // namespace cmi
