@@ -50,13 +50,18 @@ def time_us(plan, iters=100, rounds=3):
 base = time_us(A.plan())
 print(f"table plan {A.plan().config()}: {base:.1f} us per iteration (GPU time, 3 kernels + 2 folds)")
 res = []
-for blk, rpb, swz, nt in itertools.product((256, 512), (128, 176, 192, 256, 384), (0, 16, 32, 64), (2,)):
-    if rpb > blk or rpb * 5 + 3 > blk * 4:
+shapes = [(blk, 1, rpb, swz) for blk, rpb, swz in itertools.product((256, 512), (128, 176, 192, 256, 384), (0, 16, 32, 64))]
+shapes += [(blk, ipt, rpb, 0) for blk, ipt, rpb in ((128, 1, 96), (128, 2, 128), (256, 2, 192), (256, 2, 256), (512, 2, 384), (512, 2, 512), (1024, 1, 768), (256, 4, 256))]
+if len(sys.argv) > 1 and sys.argv[1] == "--wide":
+    shapes = [sh for sh in shapes if sh[3] == 0]
+for blk, ipt, rpb, swz in shapes:
+    nt = 2
+    if rpb > blk or rpb * 5 + 3 > blk * ipt * 4:
         continue
-    cfg = cmi.Config(kernel=cmi.CSR_STREAM, block_size=blk, rows_per_block=rpb, items_per_thread=1, nontemporal=nt, xcd_swizzle=swz)
+    cfg = cmi.Config(kernel=cmi.CSR_STREAM, block_size=blk, rows_per_block=rpb, items_per_thread=ipt, nontemporal=nt, xcd_swizzle=swz)
     plan = cmi.Plan(cmi.FORMAT_CSR, torch.float64, N, N, A.num_entries, A.row_offsets, cfg=cfg)
     t = time_us(plan)
-    res.append((t, blk, rpb, swz))
-    print(f"  block {blk} rows/tile {rpb} swizzle {swz}: {t:.1f} us", flush=True)
+    res.append((t, blk, ipt, rpb, swz))
+    print(f"  block {blk} vectors/lane {ipt} rows/tile {rpb} swizzle {swz}: {t:.1f} us", flush=True)
 res.sort()
 print("best:", res[:3], "table:", round(base, 1))
