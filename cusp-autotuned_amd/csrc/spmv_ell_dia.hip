@@ -14,8 +14,16 @@
 // Algorithmic bytes per call (f64):
 //   ELL: width*pitch*(4+8) + 16*num_rows        DIA: ndiag*pitch*8 + 4*ndiag + 16*num_rows
 #include "common.h"
+#include <cstdlib>
 
 namespace cmi {
+
+// $CMI_DOT_SWIZZLE: XCD dealing of the fused <y, w> instances with a table shape (measurements; unset: the table's dealing)
+static int dot_swizzle_env(int table_swizzle)
+{
+    static const int env = [] { const char *e = std::getenv("CMI_DOT_SWIZZLE"); return e ? std::atoi(e) : -1; }();
+    return env >= 0 ? env : table_swizzle;
+}
 
 // ---------------------------------------------------------------------------------------------
 // ELL: one lane per row (RPL rows per lane)
@@ -380,7 +388,8 @@ static int spmv_ell(int dtype, int64_t rows, int64_t cols, int64_t width, int64_
         return CMI_SUCCESS;
     }
     const int64_t tiles = ceil_div(rows, (int64_t)block * rpl); // one-shot grid (see spmv_csr.hip grid_for), padded to chunk rounds
-    const int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
+    int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
+    if (wdot && dot_partial && (!user || user->kernel == CMI_KERNEL_AUTO)) swz = dot_swizzle_env(swz); // (experiment knob: $CMI_DOT_SWIZZLE)
     const int64_t tpx = ceil_div(tiles, kXcds);
     const int64_t grid64 = padded_grid(tiles, swz);
     if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_ell: grid too large");
@@ -437,7 +446,8 @@ static int spmv_dia(int dtype, int64_t rows, int64_t cols, int64_t ndiag, int64_
     if (wdot && dot_partial) // one partial per workgroup: widen the workgroups until they fit the workspace
         while (block < 1024 && ceil_div(rows, (int64_t)block * rpl) > kPartialCapacity) block *= 2;
     const int64_t tiles = ceil_div(rows, (int64_t)block * rpl);
-    const int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
+    int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
+    if (wdot && dot_partial && (!user || user->kernel == CMI_KERNEL_AUTO)) swz = dot_swizzle_env(swz); // (experiment knob: $CMI_DOT_SWIZZLE)
     const int64_t tpx = ceil_div(tiles, kXcds);
     const int64_t grid64 = padded_grid(tiles, swz);
     if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_spmv_dia: grid too large");
