@@ -347,3 +347,36 @@ def test_hyb_width_rule(cmi, torch_cuda, orc, golden_irregular):
             assert torch.allclose(y1, y0, rtol=1e-9, atol=1e-9)
     finally:
         cmi.tuning_load(shipped)   # the rest of the session runs on the shipped table again
+
+
+def test_plans_free_the_device_memory_they_own(cmi, torch_cuda, orc):
+    """COO plans (row offsets + a CSR sub-plan), HYB plans (tile ranges, or a COO plan for the second launch) and 16-bit-column CSR
+    plans own device memory: cmi_plan_destroy gives all of it back (500 create / destroy rounds leave free memory where it was)."""
+    import gc
+    torch = torch_cuda
+    A = cmi.poisson5pt(400, 300, "csr")
+    N, nnz = A.num_rows, A.num_entries
+    C = cmi.convert(A, "coo")
+    H1 = cmi.convert(A, "hyb", num_entries_per_row=4)     # light COO part: one launch (tile ranges)
+    H0 = cmi.convert(A, "hyb", num_entries_per_row=1)     # heavy COO part: two launches (nested COO plan)
+
+    def make_all():
+        ps = [cmi.Plan(cmi.FORMAT_COO, torch.float64, N, N, nnz, C.row_indices),
+              cmi.Plan.hyb(torch.float64, N, N, 4, H1.coo.row_indices),
+              cmi.Plan.hyb(torch.float64, N, N, 1, H0.coo.row_indices),
+              cmi.Plan.csr(torch.float64, N, N, A.row_offsets, A.column_indices, cfg=cmi.Config(kernel=cmi.CSR_STREAM_C16))]
+        assert ps[1].hyb_launches() == 1 and ps[2].hyb_launches() == 2 and ps[3].config().kernel == cmi.CSR_STREAM_C16
+        return ps
+
+    ps = make_all()
+    del ps
+    gc.collect()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(500):
+        ps = make_all()
+        del ps
+    gc.collect()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert abs(free1 - free0) <= 8 << 20, (free0, free1)   # one round owns ~1.2 MB: 500 leaked rounds would be 600 MB
