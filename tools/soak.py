@@ -71,3 +71,46 @@ for dt in (torch.float64, torch.float32):
         hist = hist or h
         assert h == hist, "CG history changed between runs"
     print(f"fused CG {dt}: 5 x 400 iterations, identical residual histories: True")
+
+# round 2's kernels: the 16-bit column plan, HYB in one launch (a real split), sorted COO through its plan's row offsets, ELL with
+# several lanes per row, the fold-ahead CG steps -- thousands of repeats each, results must never change
+p16 = cmi.Plan.csr(torch.float64, n, n, A.row_offsets, A.column_indices, cfg=cmi.Config(kernel=cmi.CSR_STREAM_C16))
+assert p16.config().kernel == cmi.CSR_STREAM_C16
+cmi.multiply(A, x, y0)
+bad = 0
+for _ in range(20):
+    for _ in range(100):
+        cmi.spmv_csr_plan(p16, A.row_offsets, A.column_indices, A.values, x, y)
+    bad += not torch.equal(y, y0)
+print("16-bit column plan: 2000 multiplies, mismatching checks:", bad)
+for name, M in (("hyb K=4 one launch", cmi.convert(A, "hyb", num_entries_per_row=4)), ("hyb K=1 two launches", cmi.convert(A, "hyb", num_entries_per_row=1)),
+                ("coo through its plan", cmi.convert(A, "coo"))):
+    bad = 0
+    for _ in range(20):
+        for _ in range(100):
+            cmi.multiply(M, x, y)
+        bad += not torch.equal(y, y0)
+    print(name + ": 2000 multiplies, mismatching checks:", bad)
+rows_w, width_w = 20000, 256
+g = torch.Generator(device="cuda").manual_seed(1)
+pitch_w = rows_w
+Ajw = torch.randint(0, rows_w, (width_w * pitch_w,), dtype=torch.int32, device="cuda", generator=g)
+Axw = torch.rand(width_w * pitch_w, dtype=torch.float64, device="cuda", generator=g)
+xw = torch.rand(rows_w, dtype=torch.float64, device="cuda", generator=g)
+ya, yb = torch.empty(rows_w, dtype=torch.float64, device="cuda"), torch.empty(rows_w, dtype=torch.float64, device="cuda")
+cmi.spmv_ell(rows_w, rows_w, width_w, pitch_w, Ajw, Axw, xw, ya)
+for _ in range(3000):
+    cmi.spmv_ell(rows_w, rows_w, width_w, pitch_w, Ajw, Axw, xw, yb)
+print("ell lanes per row (auto): 3000 multiplies identical:", bool(torch.equal(ya, yb)))
+import os
+os.environ["CMI_CG_FOLD_AHEAD"] = "1"
+b = cmi.fill_x(n).cuda()
+ref = None
+for rep in range(5):
+    xs0 = torch.zeros(n, dtype=torch.float64, device="cuda")
+    mon = cmi.krylov.cg(A, xs0, b, iteration_limit=200, relative_tolerance=0.0)
+    if ref is None:
+        ref = (mon.residuals, xs0.clone())
+    else:
+        assert mon.residuals == ref[0] and torch.equal(xs0, ref[1]), "fold-ahead CG is not repeatable"
+print("fold-ahead CG: 5 x 200 iterations, identical histories and solutions")
