@@ -115,6 +115,21 @@ template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ double dpp_ta
     const int hi = dpp_take<CTRL, ROW_MASK>(__double2hiint(v), __double2hiint(fill));
     return __hiloint2double(hi, lo);
 }
+template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ float dpp_take(float v, float fill)
+{
+    return __int_as_float(dpp_take<CTRL, ROW_MASK>(__float_as_int(v), __float_as_int(fill)));
+}
+// sum over every aligned group of G lanes (G a power of two, 2..64), left in the group's LAST lane; fixed tree
+template <int G, typename T> __device__ __forceinline__ T group_sum_to_last(T v)
+{
+    if constexpr (G >= 2) v = v + dpp_take<kDppRowShr1>(v, T(0));
+    if constexpr (G >= 4) v = v + dpp_take<kDppRowShr2>(v, T(0));
+    if constexpr (G >= 8) v = v + dpp_take<kDppRowShr4>(v, T(0));
+    if constexpr (G >= 16) v = v + dpp_take<kDppRowShr8>(v, T(0));
+    if constexpr (G >= 32) v = v + dpp_take<kDppRowBcast15, 0xa>(v, T(0));
+    if constexpr (G >= 64) v = v + dpp_take<kDppRowBcast31, 0xc>(v, T(0));
+    return v;
+}
 // inclusive prefix sum over the 64 lanes of the wave
 __device__ __forceinline__ int wave_inclusive_sum(int v)
 {

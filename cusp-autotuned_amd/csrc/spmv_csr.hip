@@ -56,10 +56,10 @@ csr_vector_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__res
         const int s = Ap[row], e = Ap[row + 1];
         T sum = T(0);
         for (int jj = s + lane; jj < e; jj += TPR) sum = sum + ld<NT>(Ax + jj) * x[ld<NT>(Aj + jj)];
-        // butterfly inside the TPR-lane group; every lane of a group runs the same trip count
-#pragma unroll
-        for (int o = TPR / 2; o > 0; o >>= 1) sum = sum + __shfl_down(sum, o, TPR);
-        if (lane == 0) y[row] = accumulate ? y[row] + sum : sum;
+        // the group's lanes are folded on the DPP path (row_shr / row_bcast: VALU moves, no trip through the LDS crossbar as
+        // __shfl_down = ds_bpermute makes); the sum lands in the group's last lane; every lane of a group runs the same trip count
+        sum = group_sum_to_last<TPR>(sum);
+        if (lane == TPR - 1) y[row] = accumulate ? y[row] + sum : sum;
     }
 }
 

@@ -1047,17 +1047,26 @@ def test_full_size_csr_bit_exact_and_formats_agree(cmi, torch_cuda, orc, big):
         cmi.multiply(D, dx, y, cfg=cmi.Config(kernel=cmi.DIA_ROW, items_per_thread=rpl))
         assert np.array_equal(host(y), want)
     del D
+    # sorted COO through its plan (row offsets + the CSR kernel) and HYB through its plan (one launch for the light splits, ELL + the
+    # COO part's plan for the heavy ones): per row the same chain of adds as the CSR loop -- the same bits at full size
     C = cmi.convert(A, "coo")
     y.fill_(10.0)
     cmi.multiply(C, dx, y)
+    assert C.plan().info()["storage_order_sums"] and np.array_equal(host(y), want)
+    y.fill_(10.0)
+    cmi.multiply(C, dx, y, cfg=cmi.Config(kernel=cmi.COO_TILE, nontemporal=3, xcd_swizzle=32))   # the COO format's own kernel
+    assert np.array_equal(host(y), want)
+    y.fill_(10.0)
+    cmi.spmv_coo(N, N, C.row_indices, C.column_indices, C.values, dx, y)                         # plan-less: any order, atomics
     assert np.max(np.abs(host(y) - want)) <= 1e-6 * bound[0]
     del C
-    for w in (3, 4, 5):
+    for w, launches in ((1, 2), (3, 1), (4, 1), (5, 1)):
         H = cmi.convert(A, "hyb", num_entries_per_row=w)
         assert H.coo.num_entries == int(np.maximum(np.diff(big["Ap"]) - w, 0).sum())
         y.fill_(10.0)
         cmi.multiply(H, dx, y)
-        assert np.max(np.abs(host(y) - want)) <= 1e-6 * bound[0]
+        assert H.plan().hyb_launches() == launches, (w, H.plan().hyb_launches())
+        assert H.plan().info()["storage_order_sums"] and np.array_equal(host(y), want), w
         del H
 
 
