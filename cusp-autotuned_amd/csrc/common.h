@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <type_traits>
@@ -214,6 +215,14 @@ typedef float __attribute__((ext_vector_type(4))) float4v;
 // with the nt hint, bit 1 -> y is stored with the nt hint (measured on MI355X: the y store is the
 // expensive 10 % of CSR SpMV's bytes; nt stores cut it by ~40 %, tools/csr_ablate.hip).
 constexpr int kPolLoadNT = 1, kPolStoreNT = 2;
+constexpr int64_t kInfinityCacheBytes = 256ll << 20; // MALL, shared by the 8 XCDs
+constexpr int kPolStrided = 4; // csr_stream only: entry streams requested lane-strided (a dword / a value per lane per instruction), not as 16-byte vectors
+// $CMI_CSR_STRIDED=0/1 overrides the bit (measurements: A/B of the two request shapes through every tool and test)
+inline int csr_lane_strided(int policy_bits)
+{
+    static const int env = [] { const char *e = std::getenv("CMI_CSR_STRIDED"); return e ? std::atoi(e) : -1; }();
+    return env >= 0 ? (env != 0) : ((policy_bits & kPolStrided) != 0);
+}
 
 template <bool NT, typename V> __device__ __forceinline__ V ld(const V *p)
 {

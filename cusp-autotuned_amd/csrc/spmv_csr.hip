@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(1024)
 csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ Ap,
                   const int *__restrict__ Aj, const T *__restrict__ Ax, const T *__restrict__ x,
                   T *__restrict__ y, int rows_per_block, int64_t num_tiles, int64_t tiles_per_xcd,
-                  int swizzle, int accumulate, int tpr, int long_len, const T *__restrict__ w = nullptr,
+                  int swizzle, int accumulate, int tpr, int long_len, int lane_strided, const T *__restrict__ w = nullptr,
                   double *__restrict__ dot_partial = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -104,6 +104,64 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
     // loads the two offsets of its own row, and nothing waits at a barrier before the index / value
     // vectors are requested -- 126.5 us instead of 129.0 on the headline matrix (tools/r2_probe.hip,
     // profiles/r02_probe_timing.txt: csrx flags 1 vs 0), same bits.
+    //
+    // Two request shapes for the entry streams of that path.  LANE-STRIDED (policy bit kPolStrided, round 2): lane l takes entries
+    // l, l + block, l + 2 block, ... counted from the tile's FIRST entry -- every load instruction of a wave is one contiguous
+    // span (256 B of indices, 512 B of f64 values), every line of the streams is requested by exactly one instruction, nothing
+    // of the neighbouring tile is read and no alignment of the arrays is assumed.  The memory system serves that shape 7-9 %
+    // faster than 16-byte vectors per lane whose two value vectors interleave (tools/r2_probe.hip `shape`: 115.9 vs 124.6 us
+    // for the headline matrix's bytes, profiles/r02_probe_load_shape.txt), and the multiply keeps about half of that.  The body is
+    // BRANCH-FREE: a lane past the tile's last entry re-reads the tile's first one and parks a product nobody reads -- with a
+    // predicate per k the compiler waits for each gather before it requests the next (K round trips instead of one; the same
+    // file, `csrd` before / after).  Same products, same order of summation: same bits.
+    if (lane_strided && tpr == 1 && nr <= block) {
+        const int nz0 = Ap[r0], nz1 = Ap[r0 + nr];
+        const int cnt = nz1 - nz0;
+        if (cnt > 0 && cnt <= tile_entries) {
+            int a = Ap[r0 + (tid < nr ? tid : nr)], b = Ap[r0 + (tid + 1 < nr ? tid + 1 : nr)];
+            constexpr int K = IPT * 4;
+            int c[K];
+            T v[K], xv[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int i = k * block + tid;
+                const int e = nz0 + (i < cnt ? i : 0);
+                c[k] = ld<NT>(Aj + e);
+            }
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int i = k * block + tid;
+                v[k] = ld<NT>(Ax + nz0 + (i < cnt ? i : 0));
+            }
+            T wv = T(0);
+            if constexpr (DOT) { if (tid < nr) wv = w[r0 + tid]; } // requested before the barrier
+            // every stream request is out before the first gather address is formed (left alone, the compiler forms the
+            // addresses between the value loads and waits for an index vector with half the requests still unissued) ...
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < K; k++) asm volatile("" : "+v"(c[k]));
+#pragma unroll
+            for (int k = 0; k < K; k++) xv[k] = x[c[k]];
+            // ... and the row's two offsets were requested in front of the streams: not sunk behind the barrier
+            asm volatile("" : "+v"(a), "+v"(b)); // the row's two offsets were requested in front of the streams: not sunk behind the barrier
+#pragma unroll
+            for (int k = 0; k < K; k++) prod[k * block + tid] = v[k] * xv[k];
+            __syncthreads();
+            double d = 0.0;
+            if (tid < nr) {
+                T s = accumulate ? y[r0 + tid] : T(0);
+                if constexpr (IPT == 1) { for (int j = a; j < b; j++) s = s + prod[j - nz0]; }
+                else s = sum_in_order(s, prod + (a - nz0), b - a);
+                st<(POL & kPolStoreNT) != 0>(y + r0 + tid, s);
+                if constexpr (DOT) d = (double)s * (double)wv;
+            }
+            if constexpr (DOT) {
+                tile_dot_store(d, dot_slots, dot_partial + tile);
+                if (tile == 0 && tid == 0) reset_fold_state(dot_partial);
+            }
+            return;
+        }
+    }
     if constexpr (VEC) {
         const int nz0 = Ap[r0], nz1 = Ap[r0 + nr];
         const int fbase = nz0 & ~3;
@@ -783,11 +841,11 @@ static int dot_swizzle(int table_swizzle, const cmi_plan *plan)
 template <typename T, bool VEC, int POL, bool DOT = false, bool LONG = false>
 static int launch_stream_ipt(int ipt, int grid, int block, size_t lds, hipStream_t s, int64_t rows, int64_t nnz,
                              const int *Ap, const int *Aj, const T *Ax, const T *x, T *y, int rpb, int64_t tiles,
-                             int64_t tpx, int swz, int acc, int tpr, int long_len, const T *w = nullptr, double *dot_partial = nullptr)
+                             int64_t tpx, int swz, int acc, int tpr, int long_len, int strided, const T *w = nullptr, double *dot_partial = nullptr)
 {
 #define CMI_STREAM_LAUNCH(IPT)                                                                                              \
     hipLaunchKernelGGL((csr_stream_kernel<T, IPT, VEC, POL, DOT, LONG>), dim3(grid), dim3(block), lds, s, rows, nnz, Ap, Aj, \
-                       Ax, x, y, rpb, tiles, tpx, swz, acc, tpr, long_len, w, dot_partial)
+                       Ax, x, y, rpb, tiles, tpx, swz, acc, tpr, long_len, strided, w, dot_partial)
     switch (ipt) {
     case 1: CMI_STREAM_LAUNCH(1); break;
     case 2: CMI_STREAM_LAUNCH(2); break;
@@ -832,7 +890,9 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     // r02_cg_vector_load_policy.txt).  $CMI_DOT_POLICY=0..3 overrides (measurements).
     if (w && dot_partial) {
         static const int dot_pol = [] { const char *e = std::getenv("CMI_DOT_POLICY"); return e ? std::atoi(e) & 3 : -1; }();
-        pol = dot_pol >= 0 ? dot_pol : (pol | kPolLoadNT);
+        // (only for a matrix that does not itself fit the cache: see select_config's residency rule, tuning.hip)
+        const bool resident = nnz * (int64_t)(sizeof(int) + sizeof(T)) <= kInfinityCacheBytes + kInfinityCacheBytes / 4;
+        pol = dot_pol >= 0 ? dot_pol : resident ? pol : (pol | kPolLoadNT);
     }
     int st = CMI_SUCCESS;
 
@@ -892,8 +952,9 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         // the LONG instance only for a matrix whose plan shows such a row (no plan: the ordinary instance, which sums
         // any row, one lane or lane group at a time -- correct, slow on a long row)
         const bool lng = long_len > 0 && nnz >= long_len && known_max_len >= long_len;
+        const int strided = csr_lane_strided(c.nontemporal);
 #define CMI_STREAM_GO(VEC_, DOT_, LONG_, ...) \
-    launch_stream_ipt<T, VEC_, POL, DOT_, LONG_>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate, tpr, long_len, ##__VA_ARGS__)
+    launch_stream_ipt<T, VEC_, POL, DOT_, LONG_>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate, tpr, long_len, strided, ##__VA_ARGS__)
         with_policy(pol, [&](auto P) {
             constexpr int POL = decltype(P)::value;
             if (dot) {

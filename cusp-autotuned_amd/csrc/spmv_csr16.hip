@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(1024)
 csr_stream16_kernel(int64_t num_rows, int64_t num_entries, int num_cols, const int *__restrict__ Ap,
                     const uint16_t *__restrict__ Aj16, const int32_t *__restrict__ tile_base, const T *__restrict__ Ax,
                     const T *__restrict__ x, T *__restrict__ y, int rows_per_block, int64_t num_tiles, int64_t tiles_per_xcd,
-                    int swizzle, int accumulate, const T *__restrict__ w, double *__restrict__ dot_partial)
+                    int swizzle, int accumulate, int lane_strided, const T *__restrict__ w, double *__restrict__ dot_partial)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double dot_slots[DOT ? 1024 / kWave : 1];
@@ -134,8 +134,39 @@ csr_stream16_kernel(int64_t num_rows, int64_t num_entries, int num_cols, const i
     const int64_t r0 = tile * rows_per_block;
     const int nr = (int)((num_rows - r0) < rows_per_block ? (num_rows - r0) : rows_per_block);
     const int nz0 = Ap[r0], nz1 = Ap[r0 + nr], base = tile_base[tile];
+    int a = Ap[r0 + (tid < nr ? tid : nr)], b = Ap[r0 + (tid + 1 < nr ? tid + 1 : nr)];
+    int origin; // the entry whose product sits in prod[0]
+    if (lane_strided && nz1 > nz0) {
+        // csr_stream's lane-strided request shape (spmv_csr.hip, policy bit kPolStrided): lane l takes entries l, l + block, ... from
+        // the tile's first entry -- 128 B of 16-bit offsets and 512 B of f64 values per wave instruction, every line requested by
+        // one instruction, nothing of the neighbouring tile read (so no clamp: every offset is against THIS tile's base);
+        // branch-free, a lane past the tile's end re-reads its first entry.  Same products, same order: same bits.
+        origin = nz0;
+        const int cnt = nz1 - nz0;
+        constexpr int K = IPT * 4;
+        int c[K];
+        T v[K], xv[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int i = k * block + tid;
+            c[k] = (int)ld<NT>(Aj16 + nz0 + (i < cnt ? i : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int i = k * block + tid;
+            v[k] = ld<NT>(Ax + nz0 + (i < cnt ? i : 0));
+        }
+        __builtin_amdgcn_sched_barrier(0); // every stream request is out before the first gather address is formed
+#pragma unroll
+        for (int k = 0; k < K; k++) asm volatile("" : "+v"(c[k]));
+#pragma unroll
+        for (int k = 0; k < K; k++) xv[k] = x[base + c[k]];
+        asm volatile("" : "+v"(a), "+v"(b)); // the row's two offsets: requested in front of the streams, not sunk behind the barrier
+#pragma unroll
+        for (int k = 0; k < K; k++) prod[k * block + tid] = v[k] * xv[k];
+    } else {
     const int fbase = nz0 & ~3;
-    const int a = Ap[r0 + (tid < nr ? tid : nr)], b = Ap[r0 + (tid + 1 < nr ? tid + 1 : nr)];
+    origin = fbase;
     const int cmax = num_cols - 1;
     int c[IPT][4];
     T v[IPT][4];
@@ -178,14 +209,15 @@ csr_stream16_kernel(int64_t num_rows, int64_t num_entries, int num_cols, const i
             for (int i = 0; i < 4; i++) prod[slot + i] = v[k][i] * xv[i];
         }
     }
+    }
     T wv = T(0);
     if constexpr (DOT) { if (tid < nr) wv = w[r0 + tid]; }
     __syncthreads();
     double d = 0.0;
     if (tid < nr) {
         T s = accumulate ? y[r0 + tid] : T(0);
-        if constexpr (IPT == 1) { for (int j = a; j < b; j++) s = s + prod[j - fbase]; }
-        else s = sum_in_order(s, prod + (a - fbase), b - a);
+        if constexpr (IPT == 1) { for (int j = a; j < b; j++) s = s + prod[j - origin]; }
+        else s = sum_in_order(s, prod + (a - origin), b - a);
         st<(POL & kPolStoreNT) != 0>(y + r0 + tid, s);
         if constexpr (DOT) d = (double)s * (double)wv;
     }
@@ -210,13 +242,14 @@ static int csr16_multiply(const cmi_plan *p, const int *Ap, const T *Ax, const T
     const size_t lds = (size_t)block * ipt * 4 * sizeof(T);
     if (lds > 160 * 1024) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream_c16: tile does not fit 160 KiB of LDS");
     const bool dot = w && dot_partial && tiles <= kPartialCapacity;
+    const int strided = csr_lane_strided(c.nontemporal);
     int st = CMI_SUCCESS;
     with_policy(pol & 3, [&](auto P) {
         constexpr int POL = decltype(P)::value;
         auto go = [&](auto I) {
             constexpr int IPT = decltype(I)::value;
-            if (dot) hipLaunchKernelGGL((csr_stream16_kernel<T, IPT, POL, true>), dim3((unsigned)grid64), dim3(block), lds, s, rows, nnz, (int)p->cols, Ap, p->csr16_cols, p->csr16_base, Ax, x, y, rpb, tiles, tpx, swz, accumulate, w, dot_partial);
-            else     hipLaunchKernelGGL((csr_stream16_kernel<T, IPT, POL, false>), dim3((unsigned)grid64), dim3(block), lds, s, rows, nnz, (int)p->cols, Ap, p->csr16_cols, p->csr16_base, Ax, x, y, rpb, tiles, tpx, swz, accumulate, (const T *)nullptr, (double *)nullptr);
+            if (dot) hipLaunchKernelGGL((csr_stream16_kernel<T, IPT, POL, true>), dim3((unsigned)grid64), dim3(block), lds, s, rows, nnz, (int)p->cols, Ap, p->csr16_cols, p->csr16_base, Ax, x, y, rpb, tiles, tpx, swz, accumulate, strided, w, dot_partial);
+            else     hipLaunchKernelGGL((csr_stream16_kernel<T, IPT, POL, false>), dim3((unsigned)grid64), dim3(block), lds, s, rows, nnz, (int)p->cols, Ap, p->csr16_cols, p->csr16_base, Ax, x, y, rpb, tiles, tpx, swz, accumulate, strided, (const T *)nullptr, (double *)nullptr);
         };
         switch (ipt) {
         case 1: go(std::integral_constant<int, 1>()); break;

@@ -331,6 +331,15 @@ void select_config(int format, int dtype, int64_t rows, int64_t cols, int64_t nn
                 if (want < 1.0) want = 1.0;
                 out->rows_per_block = (int)want;
             }
+            // The table's nt-load bit was measured on matrices far larger than the 256 MiB Infinity Cache, where the once-read
+            // streams only push the vectors out of it.  A matrix whose index and value streams fit there is served from it on every
+            // multiply after the first if they are loaded plainly: thermal2-like (100 MB) 20.0 us against 22.5 with the hint, a
+            // 9-point matrix of 243 MB 42.2 against 48.5; at 430 MB and above the hint wins (profiles/r02_stream_shape_ab.txt,
+            // r02_autotune_csr_short_rows.jsonl.gz).  So the bit is dropped below 1.25x the cache.
+            if (format == CMI_FORMAT_CSR && out->kernel == CMI_CSR_STREAM && (out->nontemporal & kPolLoadNT)) {
+                const int64_t stream_bytes = nnz * (int64_t)(sizeof(int) + (dtype == CMI_F64 ? 8 : 4));
+                if (stream_bytes <= kInfinityCacheBytes + kInfinityCacheBytes / 4) out->nontemporal &= ~kPolLoadNT;
+            }
         } else
             heuristic(format, dtype, mean, out);
         if (user) { // AUTO kernel but explicit launch-shape overrides

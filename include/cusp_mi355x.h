@@ -175,8 +175,15 @@ typedef struct cmi_config {
     int32_t rows_per_block;   /* CSR stream: rows per workgroup tile; 0 = from mean row length     */
     int32_t items_per_thread; /* CSR stream: 16-byte index vectors per lane per pass (1,2,4);
                                  ELL/DIA: rows per lane (1,2); COO: entries per lane; 0 = default   */
-    int32_t nontemporal;      /* cache policy bits: 1 = once-read matrix streams loaded with the nt
-                                 hint, 2 = y stored with the nt hint (3 = both)                     */
+    int32_t nontemporal;      /* memory policy bits: 1 = once-read matrix streams loaded with the nt
+                                 hint, 2 = y stored with the nt hint; 4 (CSR stream, one lane per row)
+                                 = the index / value streams of a tile requested LANE-STRIDED -- lane l
+                                 takes entries l, l + block, ... from the tile's first entry, so each load
+                                 instruction of a wave is one contiguous span -- instead of as 16-byte
+                                 vectors per lane: faster for short rows (about 5 per row: 128 -> 124 us
+                                 on the headline matrix), slower from ~25 per row; same bits either way.
+                                 A table entry's bit 1 is dropped for a CSR matrix whose streams fit the
+                                 256 MiB Infinity Cache (it is then served from there when loaded plainly) */
     int32_t xcd_swizzle;      /* CSR stream, ELL, DIA, COO tile: 0 = tiles (a workgroup's rows / entries) in
                                  launch order, 1 = one contiguous eighth of the tiles per XCD, C >= 2 =
                                  chunks of C tiles dealt round the XCDs (a chunk's x window is fetched into

@@ -168,6 +168,14 @@ def test_tuning_heuristics_and_table_roundtrip(cmi, tmp_path):
     assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 7000).rows_per_block == 128      # 176 * 5/7 = 126 -> 128 (nearest whole y line; fits: 896)
     assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 7990).rows_per_block == 112      # 110 -> 112 (fits: 895)
     assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 4100).rows_per_block == 208      # 215 -> 208 (fits: 853)
+    # ... and its nt-load bit is dropped for a matrix whose index + value streams fit the 256 MiB Infinity Cache (x 1.25): served
+    # from there when loaded plainly.  The other policy bits (2: nt stores of y, 4: lane-strided entry streams) are kept.
+    cmi.tuning_set(cmi.FORMAT_CSR, cmi.F64, 5.0, cmi.Config(kernel=cmi.CSR_STREAM, block_size=256, rows_per_block=176, items_per_thread=1, nontemporal=7))
+    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 1000, 1000, 5000).nontemporal == 6
+    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 5_000_000, 5_000_000, 25_000_000).nontemporal == 6   # 300 MB of streams
+    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, 6_000_000, 6_000_000, 30_000_000).nontemporal == 7   # 360 MB
+    assert cmi.tuning_select(cmi.FORMAT_CSR, cmi.F32, 6_000_000, 6_000_000, 30_000_000).nontemporal != 7   # (another key: f32)
+    cmi.tuning_set(cmi.FORMAT_CSR, cmi.F64, 5.0, cmi.Config(kernel=cmi.CSR_STREAM, block_size=256, rows_per_block=176, items_per_thread=1))
     path2 = str(tmp_path / "means.json")
     cmi.tuning_save(path2)
     assert json.load(open(path2))["entries"][0]["mean"] == 5.0

@@ -60,7 +60,7 @@ def test_c16_poisson_every_shape_bit_exact(cmi, torch_cuda, orc, tag):
     cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
     assert np.array_equal(y.cpu().numpy(), want)
     # explicit shapes: block x vectors per lane x rows per tile x cache policy x XCD dealing
-    for blk, ipt, nt, swz in itertools.product((128, 256, 512), (1, 2, 4), (0, 3), (0, 1, 32)):
+    for blk, ipt, nt, swz in itertools.product((128, 256, 512), (1, 2, 4), (0, 3, 4, 7), (0, 1, 32)):  # (4: lane-strided entry streams)
         fit = (blk * ipt * 4 - 3) // 5
         for rpb in {min(blk, fit), min(blk, max(1, fit // 2)), 1 if blk == 128 and ipt == 1 else min(blk, 64)}:
             cfg = cmi.Config(kernel=cmi.CSR_STREAM_C16, block_size=blk, items_per_thread=ipt, rows_per_block=rpb, nontemporal=nt, xcd_swizzle=swz)

@@ -82,7 +82,10 @@ def csr_variants(cmi, small=False):
     for blk, ipt, rpb, nt, swz in ((256, 1, 0, 0, 1), (256, 1, 0, 1, 0), (256, 2, 0, 0, 1), (256, 4, 0, 0, 0),
                                    (128, 1, 0, 0, 1), (512, 1, 0, 0, 1), (64, 1, 7, 2, 1), (256, 1, 1, 0, 0),
                                    (256, 1, 1024, 3, 1), (128, 2, 512, 1, 1), (1024, 1, 300, 0, 1), (256, 1, 192, 2, 0),
-                                   (256, 1, 192, 2, 16), (128, 1, 5, 0, 3), (256, 2, 0, 2, 64)):
+                                   (256, 1, 192, 2, 16), (128, 1, 5, 0, 3), (256, 2, 0, 2, 64),
+                                   # policy bit 4: the entry streams requested lane-strided (one entry per lane per instruction)
+                                   (256, 1, 0, 4, 1), (256, 1, 0, 7, 64), (256, 2, 0, 6, 0), (256, 4, 0, 7, 16), (128, 1, 5, 5, 3),
+                                   (64, 1, 7, 6, 1), (512, 1, 400, 7, 32), (256, 1, 192, 7, 0), (1024, 2, 300, 4, 0)):
         # threads_per_row = 1: storage order for every row; 0 (the table's value): rows of LONG_ROW entries or more
         # are streamed by the whole workgroup (re-associated), every shorter row stays bit-exact
         out.append((f"stream b{blk} i{ipt} r{rpb} nt{nt} x{swz} strict", True,
@@ -734,11 +737,12 @@ def test_unaligned_views_take_the_scalar_load_paths(cmi, torch_cuda, orc, golden
         dAj.copy_(dev(Aj, torch))
         dAx.copy_(dev(Ax, torch))
         bound = row_abs(orc, Ap, Aj, Ax, x)
-        for ipt, tpr in itertools.product((1, 2, 4), (1, 0)):  # 1: storage order everywhere; 0: the 5000-entry row is streamed
+        # (nontemporal 4: the lane-strided request shape, which assumes no alignment at all)
+        for ipt, tpr, pol in itertools.product((1, 2, 4), (1, 0), (0, 4)):  # 1: storage order everywhere; 0: the 5000-entry row is streamed
             y = torch.full((rows,), 10.0, dtype=torch.float64, device="cuda")
             cmi.spmv_csr(rows, cols, dev(Ap, torch), dAj, dAx, dev(x, torch), y,
-                         cfg=cmi.Config(kernel=cmi.CSR_STREAM, items_per_thread=ipt, threads_per_row=tpr))
-            assert_variant(host(y), want, bound, np.float64, True if tpr == 1 else "short", Ap, f"{shift_i} {shift_v} {ipt} {tpr}")
+                         cfg=cmi.Config(kernel=cmi.CSR_STREAM, items_per_thread=ipt, threads_per_row=tpr, nontemporal=pol))
+            assert_variant(host(y), want, bound, np.float64, True if tpr == 1 else "short", Ap, f"{shift_i} {shift_v} {ipt} {tpr} {pol}")
     # ELL with an odd pitch: the two-rows-per-lane request silently uses one row per lane (same result)
     width = int(np.diff(Ap).max())
     pitch, eAj, eAx = orc.csr_to_ell(Ap, Aj, Ax, width, alignment=1)

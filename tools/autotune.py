@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def csr_space(cmi, mean, quick):
+def csr_space(cmi, mean, quick, stream_only=False):
     out = []
     blocks = (256,) if quick else (128, 256, 512)
     for b in blocks:
@@ -41,9 +41,15 @@ def csr_space(cmi, mean, quick):
     tprs = [t for t in (2, 4, 8, 16, 32, 64) if t <= max(2, 4 * mean) and 4 * t >= mean / 4]
     for t, b, nt in itertools.product(tprs, blocks, (0, 1)):
         out.append(cmi.Config(kernel=cmi.CSR_VECTOR, block_size=b, threads_per_row=t, nontemporal=nt))
+    if stream_only:  # --csr-stream-only: a re-tune of the row-tile kernel alone (the other variants lost by 10 %+ in the full runs)
+        out = []
     if mean <= 100:  # one lane per row (storage order, bit-exact): its LDS reads are batched, so it holds up to ~80/row
-        for b, ipt, nt, swz in itertools.product(blocks, (1, 2, 4), (0, 2) if quick or mean > 12 else (0, 1, 2, 3),
-                                                 (0, 8) if quick else (0, 1, 8, 32, 64)):
+        # policy bits: 1 = nt loads of the streams, 2 = nt stores of y, 4 = entry streams requested lane-strided instead of as
+        # 16-byte vectors (short rows: round 2)
+        pols = (0, 2) if quick else (0, 2, 6, 7) if mean > 12 else (0, 1, 2, 3, 6, 7)
+        for b, ipt, nt, swz in itertools.product(blocks, (1, 2, 4), pols, (0, 8) if quick else (0, 8, 16, 32, 64, 128)):
+            if stream_only and ipt == 4 and mean <= 12:
+                continue
             tile = b * ipt * 4
             base = max(1, int((tile - 3) / max(mean, 0.25)))
             aligned = max(1, base // 16 * 16)
@@ -53,6 +59,8 @@ def csr_space(cmi, mean, quick):
             for rpb in sorted(rpbs):
                 out.append(cmi.Config(kernel=cmi.CSR_STREAM, block_size=b, items_per_thread=ipt, rows_per_block=rpb,
                                       nontemporal=nt, xcd_swizzle=swz))
+    if stream_only:
+        return out
     if mean >= 6:
         # longer rows: the same LDS-staged tile, but a power-of-two group of lanes sums each row
         for b, ipt, tpr, nt, swz in itertools.product(blocks, (1, 2, 4), (2, 4, 8, 16, 32, 64), (0, 2), (0, 8)):
@@ -225,6 +233,9 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--grid", type=int, default=3162)
     ap.add_argument("--skip-synthetic", action="store_true")
+    ap.add_argument("--csr-stream-only", action="store_true", help="CSR: only the row-tile kernel with one lane per row (re-tune of its shapes)")
+    ap.add_argument("--synthetic-rows", type=int, default=1_000_000, help="rows of the seeded synthetic CSR matrices (8e6: their streams no longer fit the 256 MiB Infinity Cache)")
+    ap.add_argument("--csr-max-mean", type=float, default=1e9, help="CSR: skip the tuning matrices with more entries per row than this")
     ap.add_argument("--merge", action="store_true", help="start from the table at --out (tune some formats, keep the others)")
     args = ap.parse_args()
 
@@ -276,7 +287,7 @@ def main():
 
         if "csr" in formats:
             label = f"csr/{tag}/poisson{m}x{n}"
-            best, ms, res = tune_one(cmi, torch, timer, label, csr_space(cmi, 5.0, args.quick),
+            best, ms, res = tune_one(cmi, torch, timer, label, csr_space(cmi, 5.0, args.quick, args.csr_stream_only),
                                      lambda cfg: cmi.multiply(A, dx, y, cfg=cfg),
                                      checker(A, (cmi.CSR_SCALAR, cmi.CSR_STREAM, cmi.CSR_STREAM_PIPE)), args.iters, args.rounds, log,
                                      cmi.csr_bytes(N, A.num_entries, vb))
@@ -332,13 +343,16 @@ def main():
 
         # synthetic CSR matrices for the other mean-row-length buckets
         if "csr" in formats and not args.skip_synthetic:
-            rows = cols = 1_000_000 if not args.quick else 200_000
+            rows = cols = args.synthetic_rows if not args.quick else 200_000
             # FEM-like stencils where a realistic shape exists for the bucket (9-point 2-D: 9/row,
             # 27-point 3-D: ~27/row, an nlpkkt120-like shape), seeded synthetic matrices elsewhere
             cases = [("synthetic", 1.5), ("synthetic", 3.0), ("stencil9", 2000 if not args.quick else 600),
                      ("stencil27", 150 if not args.quick else 60), ("block27x2", 90 if not args.quick else 40),
                      ("block27x3", 70 if not args.quick else 30), ("block27x8", 36 if not args.quick else 20)]
             for kind, param in cases:
+                nominal = param if kind == "synthetic" else {"stencil9": 9, "stencil27": 27, "block27x2": 54, "block27x3": 81, "block27x8": 216}[kind]
+                if nominal > args.csr_max_mean:
+                    continue
                 if kind == "synthetic":
                     mean = param
                     r = rows if mean < 100 else rows // 4
@@ -382,7 +396,7 @@ def main():
                     return bool(np.all(np.abs(got - wants) <= tol * np.maximum(bound, 1e-30))), f"tolerance {tol}"
 
                 label = f"csr/{tag}/{name}"
-                best, ms, res = tune_one(cmi, torch, timer, label, csr_space(cmi, mean, args.quick),
+                best, ms, res = tune_one(cmi, torch, timer, label, csr_space(cmi, mean, args.quick, args.csr_stream_only),
                                          lambda cfg: cmi.multiply(S, dxs, ys, cfg=cfg), check, args.iters, args.rounds,
                                          log, cmi.csr_bytes(r, len(Ax), vb))
                 if best is not None:

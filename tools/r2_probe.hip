@@ -56,6 +56,83 @@ mix_kernel(int64_t N, int64_t nnz, const int *__restrict__ Ap, const int *__rest
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// shape: which LOAD SHAPE over CSR's arrays does the memory system serve fastest?  Same bytes as mix (x from three windows, lane per
+// row; Ap; nt stores of y), no dependences, and the entry streams requested as
+//   0: one 16-byte index vector + two 16-byte value vectors per lane, the value vectors interleaved (csr_stream's shape)
+//   1: two 8-byte index pairs + two 16-byte value pairs per lane, each instruction a contiguous span (halves of the tile)
+//   2: four dwords + four 8-byte values per lane at lane + 256 k (every instruction a contiguous span: ELL's instruction shape)
+//   3: shape 0 with the tile's first entry rounded down to a 128-byte line of the index array
+//   4: shape 0 without the row offsets
+//   5: shape 2, five entries per lane: 256 rows per tile, one row per lane   6: ten per lane: 512 rows, two rows per lane
+//   7: shape 0, two vectors per lane: 352 rows per tile
+// ------------------------------------------------------------------------------------------------------------
+template <int MODE> constexpr int shape_rows() { return MODE == 5 ? 256 : MODE == 6 ? 512 : MODE == 7 ? 352 : 176; }
+template <int MODE, bool NT>
+__global__ void __launch_bounds__(256)
+shape_kernel(int64_t N, int64_t nnz, const int *__restrict__ Ap, const int *__restrict__ Aj, const double *__restrict__ Ax,
+             const double *__restrict__ x, double *__restrict__ y, int64_t tiles, int64_t tpx, int swz, int m)
+{
+    constexpr int R = shape_rows<MODE>();
+    const int64_t tile = tile_of_block(blockIdx.x, tpx, swz);
+    if (tile >= tiles) return;
+    const int tid = threadIdx.x;
+    const int64_t r0 = tile * R;
+    const int nr = (int)((N - r0) < R ? (N - r0) : R);
+    int64_t e0 = (5 * r0) & ~(int64_t)(MODE == 3 ? 31 : 3);
+    if (e0 + 2560 > nnz) e0 = (nnz - 2560) & ~(int64_t)31;
+    const int ne = nr * 5 + 4;
+    double s = 0.0;
+    auto ldi = [&](const int *p) { return NT ? __builtin_nontemporal_load(p) : *p; };
+    auto ldd = [&](const double *p) { return NT ? __builtin_nontemporal_load(p) : *p; };
+    auto ldi2 = [&](const int *p) { const int2v *q = reinterpret_cast<const int2v *>(p); return NT ? __builtin_nontemporal_load(q) : *q; };
+    auto ldi4 = [&](const int *p) { const int4v *q = reinterpret_cast<const int4v *>(p); return NT ? __builtin_nontemporal_load(q) : *q; };
+    auto ldd2 = [&](const double *p) { const double2v *q = reinterpret_cast<const double2v *>(p); return NT ? __builtin_nontemporal_load(q) : *q; };
+    if constexpr (MODE == 0 || MODE == 3 || MODE == 4 || MODE == 7) {
+#pragma unroll
+        for (int k = 0; k < (MODE == 7 ? 2 : 1); k++) {
+            const int e = k * 1024 + tid * 4;
+            if (e < ne) {
+                const int4v c = ldi4(Aj + e0 + e);
+                const double2v a = ldd2(Ax + e0 + e), b = ldd2(Ax + e0 + e + 2);
+                s += (double)(c.x ^ c.y ^ c.z ^ c.w) + a.x + a.y + b.x + b.y;
+            }
+        }
+    } else if constexpr (MODE == 1) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int e = k * 512 + tid * 2;
+            if (e < ne) {
+                const int2v c = ldi2(Aj + e0 + e);
+                const double2v a = ldd2(Ax + e0 + e);
+                s += (double)(c.x ^ c.y) + a.x + a.y;
+            }
+        }
+    } else {
+        constexpr int K = MODE == 2 ? 4 : MODE == 5 ? 5 : 10;
+        int c[K];
+        double a[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int e = k * 256 + tid;
+            c[k] = 0; a[k] = 0.0;
+            if (e < ne) { c[k] = ldi(Aj + e0 + e); a[k] = ldd(Ax + e0 + e); }
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) s += (double)c[k] + a[k];
+    }
+    if constexpr (MODE != 4)
+        for (int i = tid; i <= nr; i += 256) s += (double)Ap[r0 + i];
+    bool stored = false;
+    for (int i = tid; i < nr; i += 256) {
+        const int64_t r = r0 + i, lo = r - m, hi = r + m;
+        const double v = s + x[r] + x[lo < 0 ? 0 : lo] + x[hi >= N ? N - 1 : hi];
+        __builtin_nontemporal_store(v, y + r);
+        stored = true;
+    }
+    if (!stored && s == 123.456) y[0] = s; // keeps the loads of the lanes that own no row
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // csrx: variants of csr_stream's single-pass fast path (one 16-byte index vector per lane, one lane per row)
 //   FLAGS bit 0: row pointers in registers (each lane loads its own two; tile bounds by uniform loads): no LDS
 //                copy of the row pointers, no barrier in front of the streams
@@ -142,6 +219,47 @@ csrx_kernel(int64_t N, int64_t nnz, const int *__restrict__ Ap, const int *__res
         }
     } else {
         if (tid < nr) __builtin_nontemporal_store(s, y + r0 + tid);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// csrd: csr_stream's single-pass path with the entry streams requested in shape 2 / 5 above -- K dwords + K values per lane at
+// lane + BLOCK k from the tile's first entry (no 16-byte alignment, nothing of the previous tile read), products parked at the
+// same LDS index, one lane per row adds in storage order.  Needs rpb <= BLOCK and BLOCK K entries to cover the tile.
+// ------------------------------------------------------------------------------------------------------------
+template <int BLOCK, int K, bool NT>
+__global__ void __launch_bounds__(BLOCK)
+csrd_kernel(int64_t N, const int *Ap /* not restrict: the row's two offsets are requested in front of the streams, not sunk behind the barrier */, const int *__restrict__ Aj, const double *__restrict__ Ax,
+            const double *__restrict__ x, double *__restrict__ y, int rpb, int64_t tiles, int64_t tpx, int swz)
+{
+    __shared__ double prod[BLOCK * K];
+    const int64_t tile = tile_of_block(blockIdx.x, tpx, swz);
+    if (tile >= tiles) return;
+    const int tid = threadIdx.x;
+    const int64_t r0 = tile * rpb;
+    const int nr = (int)((N - r0) < rpb ? (N - r0) : rpb);
+    const int nz0 = Ap[r0], nz1 = Ap[r0 + nr];
+    const int a = Ap[r0 + (tid < nr ? tid : nr)], b = Ap[r0 + (tid + 1 < nr ? tid + 1 : nr)];
+    // branch-free: a lane past the tile's last entry re-reads the tile's first one and parks a product nobody reads -- a
+    // predicate per k would make the compiler wait for each gather before it requests the next (K round trips instead of one)
+    const int cnt = nz1 - nz0;
+    int c[K];
+    double v[K], xv[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int i = k * BLOCK + tid;
+        const int e = nz0 + (i < cnt ? i : 0);
+        c[k] = ld<NT>(Aj + e); v[k] = ld<NT>(Ax + e);
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) xv[k] = x[c[k]];
+#pragma unroll
+    for (int k = 0; k < K; k++) prod[k * BLOCK + tid] = v[k] * xv[k];
+    __syncthreads();
+    if (tid < nr) {
+        double s = 0.0;
+        for (int j = a; j < b; j++) s = s + prod[j - nz0];
+        __builtin_nontemporal_store(s, y + r0 + tid);
     }
 }
 
@@ -323,6 +441,20 @@ int main(int argc, char **argv)
             run(nm, B_csr, true, [&, c] { CM(cmi_spmv_csr_f64(N, N, nnz, Ap, Aj, Ax, x, y, 0, &c, nullptr)); });
         }
     }
+    // ---- csr_stream's two request shapes for the entry streams (policy bit 4 = lane-strided), cache policy x rows per tile x dealing ----
+    for (int nt : {2, 3, 6, 7}) for (int rpb : {176, 192, 204}) for (int swz : {32, 64, 128}) {
+        cmi_config c = {CMI_CSR_STREAM, 256, 0, rpb, 1, nt, swz, 0};
+        char nm[96];
+        snprintf(nm, sizeof nm, "lib shapes csr_stream policy %d rpb %d swz %d", nt, rpb, swz);
+        run(nm, B_csr, true, [&, c] { CM(cmi_spmv_csr_f64(N, N, nnz, Ap, Aj, Ax, x, y, 0, &c, nullptr)); });
+    }
+    for (int nt : {6, 7}) for (int blk : {128, 512}) for (int swz : {32, 64}) {
+        const int rpb = blk == 128 ? 96 : 400;
+        cmi_config c = {CMI_CSR_STREAM, blk, 0, rpb, 1, nt, swz, 0};
+        char nm[96];
+        snprintf(nm, sizeof nm, "lib shapes csr_stream policy %d block %d rpb %d swz %d", nt, blk, rpb, swz);
+        run(nm, B_csr, true, [&, c] { CM(cmi_spmv_csr_f64(N, N, nnz, Ap, Aj, Ax, x, y, 0, &c, nullptr)); });
+    }
     // ---- the merge-path kernel on this regular matrix (why 1.5-1.7x the row-tile kernel?) -------------
     for (int swz : {0, 4, 8, 16}) {
         cmi_config c = {CMI_CSR_BALANCED, 512, 0, 0, 0, 0, swz, 0};
@@ -344,6 +476,20 @@ int main(int argc, char **argv)
         run(nm, B_csr, false, [&, swz] { hipLaunchKernelGGL((mix_kernel<1, true>), dim3((unsigned)grid), dim3(256), 0, 0, N, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, (int)m); });
         snprintf(nm, sizeof nm, "mix x-thrice nt-store swz %d", swz);
         run(nm, B_csr, false, [&, swz] { hipLaunchKernelGGL((mix_kernel<3, true>), dim3((unsigned)grid), dim3(256), 0, 0, N, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, (int)m); });
+    }
+    // ---- shape: load shapes over CSR's arrays (same bytes, no dependences) -------------------------------------------
+    for (int swz : {16, 32, 64}) {
+        char nm[96];
+#define SHAPE(MODE, NT)                                                                                                  \
+    {                                                                                                                    \
+        const int R = shape_rows<MODE>();                                                                                \
+        const int64_t tiles = (N + R - 1) / R, tpx = (tiles + 7) / 8;                                                    \
+        const int64_t grid = ((tiles + 8 * swz - 1) / (8 * swz)) * 8 * swz;                                              \
+        snprintf(nm, sizeof nm, "shape %d nt-load %d rows %d swz %d", MODE, NT, R, swz);                                 \
+        run(nm, B_csr, false, [&, swz] { hipLaunchKernelGGL((shape_kernel<MODE, NT>), dim3((unsigned)grid), dim3(256), 0, 0, N, nnz, Ap, Aj, Ax, x, y, tiles, tpx, swz, (int)m); }); \
+    }
+        SHAPE(0, false) SHAPE(0, true) SHAPE(1, true) SHAPE(2, true) SHAPE(3, true) SHAPE(4, true) SHAPE(5, true) SHAPE(5, false) SHAPE(6, true) SHAPE(7, true)
+#undef SHAPE
     }
     // ---- what does the SpMV pay for running BEHIND vector kernels (the CG iteration) rather than behind itself? ------------
     {
@@ -387,6 +533,22 @@ int main(int argc, char **argv)
             CSRX(0); CSRX(1); CSRX(5); CSRX(9); CSRX(17); CSRX(65); CSRX(129); CSRX(261); CSRX(321);
 #undef CSRX
         }
+    }
+    // ---- csrd: the real multiply with dword-shaped entry streams ------------------------------------------------------
+    for (int swz : {16, 32, 64, 128}) {
+        char nm[96];
+#define CSRD(BLOCK, K, NT, RPB)                                                                                          \
+    {                                                                                                                    \
+        const int rpb = RPB;                                                                                             \
+        const int64_t tiles = (N + rpb - 1) / rpb, tpx = (tiles + 7) / 8;                                                \
+        const int64_t grid = ((tiles + 8 * swz - 1) / (8 * swz)) * 8 * swz;                                              \
+        snprintf(nm, sizeof nm, "csrd block %d k %d nt-load %d rpb %d swz %d", BLOCK, K, NT, rpb, swz);                  \
+        run(nm, B_csr, true, [&, swz] { hipLaunchKernelGGL((csrd_kernel<BLOCK, K, NT>), dim3((unsigned)grid), dim3(BLOCK), 0, 0, N, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz); }); \
+    }
+        CSRD(256, 4, true, 176) CSRD(256, 4, false, 176) CSRD(256, 4, true, 192) CSRD(256, 4, true, 204)
+        CSRD(256, 5, true, 240) CSRD(256, 5, true, 256) CSRD(256, 5, false, 256)
+        CSRD(512, 4, true, 400) CSRD(512, 5, true, 512) CSRD(128, 5, true, 128) CSRD(128, 8, true, 128)
+#undef CSRD
     }
     // ---- ell (library kernel, launch shapes x XCD dealing) -----------------------------------------------------
     {
