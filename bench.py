@@ -139,8 +139,8 @@ def pmc_traffic(kernel_substr):
     figure is a committed measurement of this kernel, not one taken in this run: the line says so (`traffic_source`)."""
     pdir = os.path.join(ROOT, "profiles")
     # the SpMV kernel of each format (not the builders / converters that carry the format's name too)
-    names = {"csr": ("csr_stream_kernel", "csr_balanced_kernel", "csr_vector_kernel", "csr_scalar_kernel"), "ell": ("ell_row_kernel",),
-             "dia": ("dia_row_kernel", "dia_row2_kernel"), "coo": ("csr_stream_kernel", "csr_balanced_kernel"),  # sorted entries through a plan: the CSR kernels on the plan's row offsets
+    names = {"csr": ("csr_wave_kernel", "csr_stream_kernel", "csr_balanced_kernel", "csr_vector_kernel", "csr_scalar_kernel"), "ell": ("ell_row_kernel",),
+             "dia": ("dia_row_kernel", "dia_row2_kernel"), "coo": ("csr_wave_kernel", "csr_stream_kernel", "csr_balanced_kernel"),  # sorted entries through a plan: the CSR kernels on the plan's row offsets
              "coo_tile": ("coo_tile_kernel",), "hyb": ("hyb_tile_kernel",), "csr16": ("csr_stream16_kernel",)}[kernel_substr]
     best, src = None, None
     if os.path.isdir(pdir):
@@ -645,6 +645,11 @@ def main():
     traffic, traffic_src = pmc_traffic(kname)
     cfg = cmi.tuning_select({"csr": 0, "ell": 1, "dia": 2, "coo": 3, "hyb": 1}[fmt], cmi.F64, local_rows, N_global,
                             local_nnz if fmt in ("csr", "coo") else local_rows * (HYB_WIDTH if fmt == "hyb" else 5))
+    if world == 1 and fmt in ("csr", "coo"):  # what actually ran: the matrix's plan may have turned the table entry into another kernel
+        try:                                   # (stencil rows: the wave-tile kernel; skewed rows: the merge-path kernel)
+            cfg = Afmt.plan().config()
+        except Exception:  # noqa: BLE001
+            pass
     coo_tile = None
     if fmt == "coo" and world == 1:
         # what ran above: the matrix's plan found the entries sorted, built the row offsets they imply and multiplies with the CSR

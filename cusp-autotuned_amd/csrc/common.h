@@ -216,6 +216,7 @@ typedef float __attribute__((ext_vector_type(4))) float4v;
 // expensive 10 % of CSR SpMV's bytes; nt stores cut it by ~40 %, tools/csr_ablate.hip).
 constexpr int kPolLoadNT = 1, kPolStoreNT = 2;
 constexpr int64_t kInfinityCacheBytes = 256ll << 20; // MALL, shared by the 8 XCDs
+constexpr int kWaveTileMaxK = 10; // csr_wave: entries per lane (= the longest row of the matrix)
 constexpr int kPolStrided = 4; // csr_stream only: entry streams requested lane-strided (a dword / a value per lane per instruction), not as 16-byte vectors
 // $CMI_CSR_STRIDED=0/1 overrides the bit (measurements: A/B of the two request shapes through every tool and test)
 inline int csr_lane_strided(int policy_bits)

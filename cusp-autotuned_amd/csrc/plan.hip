@@ -38,6 +38,15 @@ CMI_API int cmi_get_index_compression(void) { return compress_default(); }
 static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
                        const int32_t *index_array, const int32_t *csr_columns, const cmi_config *cfg, void *stream, cmi_plan **plan_out);
 
+// csr_wave (CMI_CSR_STREAM_WAVE) instead of csr_stream: the longest row has 2..10 entries and the mean is within 7 % of it
+// ($CMI_CSR_WAVE=0: never -- measurements of csr_stream on stencil matrices)
+static bool wave_tiles_fit(int64_t rows, int64_t nnz, int64_t max_len)
+{
+    static const int env = [] { const char *e = std::getenv("CMI_CSR_WAVE"); return e ? std::atoi(e) : 1; }();
+    if (!env || rows <= 0 || max_len < 2 || max_len > kWaveTileMaxK) return false;
+    return (double)nnz >= 0.93 * (double)max_len * (double)rows;
+}
+
 CMI_API int cmi_plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
                             const int32_t *index_array, const cmi_config *cfg, void *stream, cmi_plan **plan_out)
 {
@@ -115,6 +124,19 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
             }
             st = csr16_build(p, index_array, csr_columns, s); // all tiles qualify -> cfg.kernel = CMI_CSR_STREAM_C16, else unchanged
             if (p->cfg.kernel != CMI_CSR_STREAM_C16) p->cfg.rows_per_block = tuned_rpb; // not granted: csr_stream as tuned
+        }
+        // Rows that all have (nearly) the same short length -- stencils -- take csr_stream's lane-strided body with wave-private
+        // tiles (spmv_csr.hip csr_wave_kernel): 64 rows per wave, as many entries per lane as the longest row has, so every
+        // tile fits and (mean within 7 % of the longest row) at least 93 % of the request lanes carry an entry.  Cache policy and
+        // XCD dealing are the table's csr_stream entry's.  Not for a caller's explicit kernel, not over a granted 16-bit copy.
+        if (st == CMI_SUCCESS && auto_kernel && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
+            wave_tiles_fit(num_rows, num_entries, p->prof.max_len)) {
+            p->cfg.kernel = CMI_CSR_STREAM_WAVE;
+            p->cfg.block_size = 256;
+            p->cfg.rows_per_block = 256;
+            p->cfg.items_per_thread = (int)p->prof.max_len;
+            p->cfg.threads_per_row = 0;
+            p->cfg.nontemporal &= ~kPolStrided; // (the request shape is the kernel's own)
         }
     } else if (format == CMI_FORMAT_COO) {
         int sorted = 1, long_runs = 0;
@@ -255,7 +277,7 @@ CMI_API int cmi_plan_info(const cmi_plan *plan, int64_t *max_row_length, int64_t
         switch (plan->format) {
         case CMI_FORMAT_CSR:
             // scalar / pipe: always; stream: one lane per row and no row long enough for the cooperative path
-            exact = c.kernel == CMI_CSR_SCALAR || c.kernel == CMI_CSR_STREAM_PIPE || c.kernel == CMI_CSR_STREAM_C16 ||
+            exact = c.kernel == CMI_CSR_SCALAR || c.kernel == CMI_CSR_STREAM_PIPE || c.kernel == CMI_CSR_STREAM_C16 || c.kernel == CMI_CSR_STREAM_WAVE ||
                     (c.kernel == CMI_CSR_STREAM && c.threads_per_row <= 1 && (c.threads_per_row == 1 || plan->prof.max_len < 512));
             break;
         case CMI_FORMAT_ELL: exact = ell_lanes_per_row(c, plan->rows, plan->rows > 0 ? plan->nnz / plan->rows : 0) == 1; break;

@@ -400,6 +400,80 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// csr_wave: csr_stream's lane-strided single-pass body with WAVE-PRIVATE tiles (round 2)
+// ---------------------------------------------------------------------------------------------
+// For matrices whose rows all have (nearly) the same short length -- stencils: the plan selects it from the row-length profile
+// (plan.hip wave_tiles_fit).  Each 64-lane wave owns rows_per_wave consecutive rows: lane l requests entries l, l + 64, ...,
+// l + 64 (K - 1) of the wave's tile (K = the longest row, so a tile of 64 rows always fits 64 K slots and every lane of every
+// request carries an entry), gathers x, parks the products in the wave's own LDS region and adds its row in storage order.  No
+// s_barrier: a wave's LDS instructions execute in order, so nothing waits for another wave's loads; every lane owns a row in the
+// sum phase (csr_stream: 192 of 256); the tile bounds are two scalar loads and the row's end is the next lane's start (one
+// row-offset load per lane, wave_shl:1 on the DPP path).  Headline matrix: 124.8 -> 120-121 us (tools/r2_probe.hip csrw / csrw1,
+// profiles/r02_probe_wave_tiles.txt).  Same products, same order of summation as the host loop: bit-exact.
+// A tile that does not fit (an explicit config on an irregular matrix) or holds no entry is summed one lane per row straight
+// from the arrays: correct, slow.
+// LDS: T prod[waves][64 K].
+template <typename T, int K, int POL, bool DOT>
+__global__ void __launch_bounds__(1024)
+csr_wave_kernel(int64_t num_rows, const int *Ap /* not restrict: see the asm below */, const int *__restrict__ Aj,
+                const T *__restrict__ Ax, const T *__restrict__ x, T *__restrict__ y, int rows_per_wave, int64_t num_tiles,
+                int64_t tiles_per_xcd, int swizzle, int accumulate, const T *__restrict__ w, double *__restrict__ dot_partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double dot_slots[DOT ? 1024 / kWave : 1];
+    constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
+    const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle);
+    if (tile >= num_tiles) return; // whole workgroup
+    const int waves = blockDim.x / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x & (kWave - 1); // (scalar: s_loads below)
+    const int64_t r0 = (tile * waves + wave) * (int64_t)rows_per_wave;
+    double d = 0.0;
+    if (r0 < num_rows) {
+        const int nr = (int)((num_rows - r0) < rows_per_wave ? (num_rows - r0) : rows_per_wave);
+        const int nz0 = Ap[r0], nz1 = Ap[r0 + nr];
+        const int cnt = nz1 - nz0;
+        int a = Ap[r0 + (lane < nr ? lane : nr)];
+        T wv = T(0);
+        if constexpr (DOT) { if (lane < nr) wv = w[r0 + lane]; }
+        if (cnt > 0 && cnt <= kWave * K) { // (uniform per wave)
+            T *mine = reinterpret_cast<T *>(smem) + (size_t)wave * kWave * K;
+            int c[K];
+            T v[K], xv[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) { const int i = k * kWave + lane; c[k] = ld<NT>(Aj + nz0 + (i < cnt ? i : 0)); }
+#pragma unroll
+            for (int k = 0; k < K; k++) { const int i = k * kWave + lane; v[k] = ld<NT>(Ax + nz0 + (i < cnt ? i : 0)); }
+            __builtin_amdgcn_sched_barrier(0); // every stream request is out before the first gather address is formed
+#pragma unroll
+            for (int k = 0; k < K; k++) asm volatile("" : "+v"(c[k]));
+#pragma unroll
+            for (int k = 0; k < K; k++) xv[k] = x[c[k]];
+            asm volatile("" : "+v"(a)); // the row offset was requested in front of the streams
+            const int b = __builtin_amdgcn_update_dpp(nz1, a, 0x130 /* wave_shl:1: the next lane's start; lane 63 keeps nz1 */, 0xf, 0xf, false);
+#pragma unroll
+            for (int k = 0; k < K; k++) mine[k * kWave + lane] = v[k] * xv[k];
+            __builtin_amdgcn_wave_barrier(); // (compiler only: the hardware runs a wave's LDS instructions in order)
+            if (lane < nr) {
+                T s = accumulate ? y[r0 + lane] : T(0);
+                for (int j = a; j < b; j++) s = s + mine[j - nz0];
+                st<NTS>(y + r0 + lane, s);
+                if constexpr (DOT) d = (double)s * (double)wv;
+            }
+        } else if (lane < nr) {
+            const int b = Ap[r0 + lane + 1];
+            T s = accumulate ? y[r0 + lane] : T(0);
+            for (int j = a; j < b; j++) s = s + Ax[j] * x[Aj[j]];
+            st<NTS>(y + r0 + lane, s);
+            if constexpr (DOT) d = (double)s * (double)wv;
+        }
+    }
+    if constexpr (DOT) {
+        tile_dot_store(d, dot_slots, dot_partial + tile);
+        if (tile == 0 && threadIdx.x == 0) reset_fold_state(dot_partial);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // csr_stream_pipe: persistent, software-pipelined csr_stream
 // ---------------------------------------------------------------------------------------------
 // The plain csr_stream workgroup pays three DEPENDENT global round trips per tile (row pointers ->
@@ -831,11 +905,11 @@ static int launch_vector(int tpr, int grid, int block, hipStream_t s, int64_t ro
 }
 
 // XCD dealing of the fused SpMV + <y, w> instance when the shape is the table's (see the call site)
-static int dot_swizzle(int table_swizzle, const cmi_plan *plan)
+static int dot_swizzle(int table_swizzle, const cmi_plan *plan, int inside_a_solve = 0)
 {
     static const int env = [] { const char *e = std::getenv("CMI_DOT_SWIZZLE"); return e ? std::atoi(e) : -1; }();
     if (plan && plan->cfg_explicit) return table_swizzle; // a shape the caller gave the plan: as given
-    return env >= 0 ? env : 0;
+    return env >= 0 ? env : inside_a_solve;
 }
 
 template <typename T, bool VEC, int POL, bool DOT = false, bool LONG = false>
@@ -966,6 +1040,45 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         });
 #undef CMI_STREAM_GO
         if (st) return st;
+        if (dot && dot_partials) *dot_partials = (int)tiles;
+        break;
+    }
+    case CMI_CSR_STREAM_WAVE: {
+        const int K = c.items_per_thread;
+        const int waves = block / kWave;
+        if (K < 2 || K > kWaveTileMaxK) return fail(CMI_ERROR_NOT_SUPPORTED, "csr_wave: items_per_thread (entries per lane) must be 2..10");
+        if (c.rows_per_block < waves || c.rows_per_block % waves != 0 || c.rows_per_block / waves > kWave)
+            return fail(CMI_ERROR_INVALID_VALUE, "csr_wave: rows_per_block must be block_size/64 waves x 1..64 rows each");
+        const int rpw = c.rows_per_block / waves;
+        const int64_t tiles = ceil_div(rows, (int64_t)c.rows_per_block);
+        const int64_t tpx = ceil_div(tiles, kXcds);
+        int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
+        // (the wave-tile kernel keeps the table's chunk dealing inside a solve too: 239 against 243.5 us per CG iteration in launch
+        //  order, profiles/r02_cg_wave_dot.txt -- csr_stream's dot instance is the other way round)
+        if (w && dot_partial && (!user || user->kernel == CMI_KERNEL_AUTO)) swz = dot_swizzle(swz, plan, swz);
+        const int64_t grid64 = padded_grid(tiles, swz);
+        if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "csr_wave: grid too large");
+        const size_t lds = (size_t)block * K * sizeof(T);
+        const bool dot = w && dot_partial && tiles <= kPartialCapacity;
+        with_policy(pol, [&](auto P) {
+            constexpr int POL = decltype(P)::value;
+            auto go = [&](auto KK) {
+                constexpr int KC = decltype(KK)::value;
+                if (dot) hipLaunchKernelGGL((csr_wave_kernel<T, KC, POL, true>), dim3((unsigned)grid64), dim3(block), lds, s, rows, Ap, Aj, Ax, x, y, rpw, tiles, tpx, swz, accumulate, w, dot_partial);
+                else     hipLaunchKernelGGL((csr_wave_kernel<T, KC, POL, false>), dim3((unsigned)grid64), dim3(block), lds, s, rows, Ap, Aj, Ax, x, y, rpw, tiles, tpx, swz, accumulate, (const T *)nullptr, (double *)nullptr);
+            };
+            switch (K) {
+            case 2: go(std::integral_constant<int, 2>()); break;
+            case 3: go(std::integral_constant<int, 3>()); break;
+            case 4: go(std::integral_constant<int, 4>()); break;
+            case 5: go(std::integral_constant<int, 5>()); break;
+            case 6: go(std::integral_constant<int, 6>()); break;
+            case 7: go(std::integral_constant<int, 7>()); break;
+            case 8: go(std::integral_constant<int, 8>()); break;
+            case 9: go(std::integral_constant<int, 9>()); break;
+            default: go(std::integral_constant<int, 10>()); break;
+            }
+        });
         if (dot && dot_partials) *dot_partials = (int)tiles;
         break;
     }

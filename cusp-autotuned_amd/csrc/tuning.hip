@@ -108,6 +108,13 @@ static void complete(int format, int dtype, int64_t rows, int64_t nnz, cmi_confi
             while (p < t && p < 64) p <<= 1;
             c->threads_per_row = p;
         }
+        if (c->kernel == CMI_CSR_STREAM_WAVE) { // 64 rows per wave, as many entries per lane as the mean row (rounded up) has
+            if (c->rows_per_block <= 0) c->rows_per_block = c->block_size;
+            if (c->items_per_thread <= 0) {
+                const int k = (int)std::ceil(mean);
+                c->items_per_thread = k < 2 ? 2 : k > kWaveTileMaxK ? kWaveTileMaxK : k;
+            }
+        }
         if (c->kernel == CMI_CSR_STREAM_PIPE) {
             c->items_per_thread = 1;
             if (c->rows_per_block <= 0) {

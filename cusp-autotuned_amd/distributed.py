@@ -356,6 +356,12 @@ class ShardedCsr:
             from . import binding as B
             self._cfg = B.tuning_select(B.FORMAT_CSR, B.F64 if A_local.values.dtype == torch.float64 else B.F32,
                                         A_local.num_rows, A_local.num_cols, A_local.num_entries)
+            # ... or what the block's plan made of the table entry, when that is a row-tile kernel that needs no plan to run
+            # (stencil rows: the wave-tile kernel)
+            if A_local.num_entries > 0 and A_local.values.is_cuda:
+                planned = A_local.plan().config()
+                if planned.kernel in (B.CSR_STREAM, B.CSR_STREAM_WAVE):
+                    self._cfg = planned
 
     def _interior_rows(self):
         """Largest middle block [a, b) of rows whose columns all lie in [lo, hi) (setup-time)."""

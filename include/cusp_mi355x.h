@@ -145,6 +145,14 @@ typedef enum cmi_kernel {
                                instead of 12 nnz + 20 N, same products, same storage-order sums, same bits.  Granted only
                                if EVERY tile spans < 65536 columns and fits one LDS pass; otherwise the plan's config says
                                CMI_CSR_STREAM and nothing is built.  config fields: csr_stream's (0 = the table's)      */
+    CMI_CSR_STREAM_WAVE = 7, /* csr_stream's lane-strided single-pass body with WAVE-PRIVATE tiles, for matrices whose rows all have
+                               (nearly) the same short length (stencils): each 64-lane wave owns rows_per_block / (block_size / 64)
+                               <= 64 consecutive rows, lane l requests entries l, l + 64, ... of the wave's tile, the products are
+                               parked in the wave's own LDS region and every lane adds its row in storage order -- no workgroup
+                               barrier, every lane owns a row.  items_per_thread = entries per lane (2..10): 64 x that many must
+                               hold a wave's tile (a tile that does not fit is summed one lane per row from the arrays: correct,
+                               slow).  Bit-exact.  A CSR plan selects it by itself when the longest row is <= 10 entries and the
+                               mean within 7 % of it ($CMI_CSR_WAVE=0: never); never selected without a plan               */
     /* ELL */
     CMI_ELL_ROW = 10, /* one lane per row            (ref: ell_spmv.h:55-93); threads_per_row 2,4,8,16: that many
                          lanes per row, each summing every 2nd / 4th / ... slot (ref: THREADS_PER_ROW of ktt

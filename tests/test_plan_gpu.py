@@ -31,7 +31,11 @@ def test_plan_lifecycle_and_errors(cmi, torch_cuda, orc):
     info = plan.info()
     assert info == {"max_row_length": 5, "entries_in_long_rows": 0, "coo_sorted": None, "storage_order_sums": True}
     table = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, n, n, len(Aj))
-    assert plan.config().as_dict() == table.as_dict()          # nothing in the profile overrides the table here
+    # the profile (every row 3..5 entries, mean within 7 % of the longest) turns the table's csr_stream entry into the wave-tile
+    # kernel: 64 rows per wave, 5 entries per lane; cache policy and XCD dealing stay the table's
+    c = plan.config()
+    assert (c.kernel, c.block_size, c.rows_per_block, c.items_per_thread) == (cmi.CSR_STREAM_WAVE, 256, 256, 5)
+    assert table.kernel == cmi.CSR_STREAM and (c.nontemporal, c.xcd_swizzle) == (table.nontemporal & 3, table.xcd_swizzle)
     y = torch.full((n,), 10.0, dtype=torch.float64, device="cuda")
     cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dev(x, torch), y)
     assert np.array_equal(y.cpu().numpy(), want)
@@ -380,3 +384,72 @@ def test_plans_free_the_device_memory_they_own(cmi, torch_cuda, orc):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert abs(free1 - free0) <= 8 << 20, (free0, free1)   # one round owns ~1.2 MB: 500 leaked rounds would be 600 MB
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_csr_plan_selects_wave_tiles_for_stencil_rows(cmi, torch_cuda, orc, tag):
+    """Rows that all have (nearly) the same short length: the plan runs CMI_CSR_STREAM_WAVE with as many entries per lane as the
+    longest row has -- bit-exact, also accumulating, through the fused dot, for a sorted COO matrix (row offsets built by its
+    plan) -- and keeps csr_stream where the lengths vary, where a caller names a kernel, and under $CMI_CSR_WAVE=0 (child process)."""
+    torch = torch_cuda
+    dtype = np.float64 if tag == "f64" else np.float32
+    tdt = torch.float64 if tag == "f64" else torch.float32
+    rng = np.random.default_rng(11)
+    for m, n in ((257, 131), (64, 64), (1, 300), (300, 1)):
+        N = m * n
+        Ap, Aj, Ax = orc.poisson5pt_csr(m, n)
+        Ax = (Ax * rng.standard_normal(len(Ax))).astype(dtype)
+        x = rng.standard_normal(N).astype(dtype)
+        y0 = rng.standard_normal(N).astype(dtype)
+        want, want_acc = orc.spmv_csr(Ap, Aj, Ax, x), orc.spmv_csr(Ap, Aj, Ax, x, y0)
+        dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+        plan = cmi.Plan(cmi.FORMAT_CSR, tdt, N, N, len(Aj), dAp)
+        c = plan.config()
+        longest, mean = int(np.diff(Ap).max()), len(Aj) / N
+        if 2 <= longest <= 10 and mean >= 0.93 * longest:
+            assert c.kernel == cmi.CSR_STREAM_WAVE and c.items_per_thread == longest and c.rows_per_block == c.block_size == 256, (m, n, c)
+            assert plan.info()["storage_order_sums"] is True
+        else:
+            assert c.kernel == cmi.CSR_STREAM, (m, n, c)
+        y = torch.full((N,), 9.0, dtype=tdt, device="cuda")
+        cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
+        assert np.array_equal(y.cpu().numpy(), want), (m, n)
+        y = dev(y0, torch)
+        cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y, accumulate=True)
+        assert np.array_equal(y.cpu().numpy(), want_acc), (m, n)
+        w = rng.standard_normal(N).astype(dtype)
+        res = torch.zeros(1, dtype=torch.float64, device="cuda")
+        y = torch.zeros(N, dtype=tdt, device="cuda")
+        cmi.spmv_csr_dot(N, N, dAp, dAj, dAx, dx, y, dev(w, torch), res, cmi.blas_workspace(), plan=plan)
+        assert np.array_equal(y.cpu().numpy(), want), (m, n)
+        ref = float(np.dot(want.astype(np.float64), w.astype(np.float64)))
+        assert abs(float(res) - ref) <= 1e-12 * float(np.abs(want.astype(np.float64) * w).sum()) + (0 if tag == "f64" else 1e-6 * abs(ref)), (m, n)
+        # a caller's kernel is kept
+        explicit = cmi.Plan(cmi.FORMAT_CSR, tdt, N, N, len(Aj), dAp, cmi.Config(kernel=cmi.CSR_STREAM))
+        assert explicit.config().kernel == cmi.CSR_STREAM
+        # sorted COO: the plan's row offsets + the same CSR kernel
+        Ai = orc.csr_row_indices(Ap)
+        cplan = cmi.Plan(cmi.FORMAT_COO, tdt, N, N, len(Aj), dev(Ai, torch))
+        assert cplan.config().kernel == c.kernel
+        y = torch.full((N,), 9.0, dtype=tdt, device="cuda")
+        cmi.spmv_coo_plan(cplan, dev(Ai, torch), dAj, dAx, dx, y)
+        assert np.array_equal(y.cpu().numpy(), want), (m, n)
+    # irregular rows of the same mean: csr_stream
+    lens = rng.integers(0, 11, size=5000)
+    Ap = np.r_[0, np.cumsum(lens)].astype(np.int32)
+    plan = cmi.Plan(cmi.FORMAT_CSR, tdt, 5000, 5000, int(Ap[-1]), dev(Ap, torch))
+    assert plan.config().kernel == cmi.CSR_STREAM
+    # rows longer than 10: csr_stream
+    lens = np.full(4000, 11)
+    Ap = np.r_[0, np.cumsum(lens)].astype(np.int32)
+    assert cmi.Plan(cmi.FORMAT_CSR, tdt, 4000, 4000, int(Ap[-1]), dev(Ap, torch)).config().kernel == cmi.CSR_STREAM
+    if tag == "f64":
+        import subprocess, sys
+        code = ("import numpy as np, torch, cusp_autotuned_amd as cmi\n"
+                "A = cmi.poisson5pt(100, 100, 'csr')\n"
+                "print(A.plan().config().kernel)\n")
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env={**os.environ, "CMI_CSR_WAVE": "0"},
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.strip().splitlines()[-1] == str(cmi.CSR_STREAM)

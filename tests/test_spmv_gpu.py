@@ -103,6 +103,12 @@ def csr_variants(cmi, small=False):
         out.append((f"pipe b{blk} r{rpb} nt{nt} c{chunked} bpc{bpc}", True,
                     cmi.Config(kernel=cmi.CSR_STREAM_PIPE, block_size=blk, rows_per_block=rpb, nontemporal=nt,
                                xcd_swizzle=chunked, blocks_per_cu=bpc)))
+    # wave-private tiles (CMI_CSR_STREAM_WAVE): items_per_thread = entries per lane (64 x that many hold a wave's tile, else the
+    # wave sums its rows one lane per row from the arrays); rows_per_block = waves x rows per wave; storage order either way
+    for blk, k, rpb, nt, swz in ((256, 5, 0, 0, 0), (256, 2, 0, 3, 64), (64, 10, 64, 2, 1), (1024, 4, 16 * 7, 1, 16), (256, 8, 4, 0, 0),
+                                 (128, 3, 128, 3, 32), (512, 0, 0, 2, 8)):
+        out.append((f"wave b{blk} k{k} r{rpb} nt{nt} x{swz}", True,
+                    cmi.Config(kernel=cmi.CSR_STREAM_WAVE, block_size=blk, items_per_thread=k, rows_per_block=rpb, nontemporal=nt, xcd_swizzle=swz)))
     for bpc in (0, 1, 3):  # merge-path split: re-associates (lane groups + atomics on rows that span tiles)
         out.append((f"balanced bpc{bpc}", False, cmi.Config(kernel=cmi.CSR_BALANCED, block_size=256, blocks_per_cu=bpc)))
     return out

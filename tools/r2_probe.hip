@@ -227,7 +227,7 @@ csrx_kernel(int64_t N, int64_t nnz, const int *__restrict__ Ap, const int *__res
 // lane + BLOCK k from the tile's first entry (no 16-byte alignment, nothing of the previous tile read), products parked at the
 // same LDS index, one lane per row adds in storage order.  Needs rpb <= BLOCK and BLOCK K entries to cover the tile.
 // ------------------------------------------------------------------------------------------------------------
-template <int BLOCK, int K, bool NT>
+template <int BLOCK, int K, bool NT, int ABL = 0>
 __global__ void __launch_bounds__(BLOCK)
 csrd_kernel(int64_t N, const int *Ap /* not restrict: the row's two offsets are requested in front of the streams, not sunk behind the barrier */, const int *__restrict__ Aj, const double *__restrict__ Ax,
             const double *__restrict__ x, double *__restrict__ y, int rpb, int64_t tiles, int64_t tpx, int swz)
@@ -251,15 +251,141 @@ csrd_kernel(int64_t N, const int *Ap /* not restrict: the row's two offsets are 
         const int e = nz0 + (i < cnt ? i : 0);
         c[k] = ld<NT>(Aj + e); v[k] = ld<NT>(Ax + e);
     }
+    // ABL (timing only, results wrong): 1 = x read coalesced instead of gathered; 2 = no LDS, no barrier, no row sums; 4 = the row sum
+    // reads its first eight products at once (the real result, bit-exact)
 #pragma unroll
-    for (int k = 0; k < K; k++) xv[k] = x[c[k]];
+    for (int k = 0; k < K; k++) xv[k] = (ABL & 1) ? x[(r0 + ((k * BLOCK + tid) % (nr > 0 ? nr : 1))) + (c[k] & 0)] : x[c[k]];
+    if constexpr (ABL & 2) {
+        double s = (double)(a + b);
+#pragma unroll
+        for (int k = 0; k < K; k++) s += v[k] * xv[k];
+        if (tid < nr) __builtin_nontemporal_store(s, y + r0 + tid);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < K; k++) prod[k * BLOCK + tid] = v[k] * xv[k];
     __syncthreads();
     if (tid < nr) {
         double s = 0.0;
-        for (int j = a; j < b; j++) s = s + prod[j - nz0];
+        if constexpr (ABL & 4) {
+            const int n = b - a, o = a - nz0;
+            double q[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) q[j] = prod[(o + j) < BLOCK * K ? (o + j) : 0];
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (j < n) s = s + q[j];
+            for (int j = a + 8; j < b; j++) s = s + prod[j - nz0];
+        } else {
+            for (int j = a; j < b; j++) s = s + prod[j - nz0];
+        }
         __builtin_nontemporal_store(s, y + r0 + tid);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// csrp: csrd with T consecutive tiles per workgroup, software-pipelined -- the entry streams of tile t + 1 are requested right behind
+// the gathers of tile t and stay in flight through that tile's LDS stores, barrier and row sums (two LDS buffers: one barrier per
+// tile).  Waves return loads in order, so the order inside an iteration is: wait for tile t's indices, gathers(t), requests(t + 1),
+// wait for the gathers only.
+// ------------------------------------------------------------------------------------------------------------
+template <int BLOCK, int K, int T, bool NT>
+__global__ void __launch_bounds__(BLOCK)
+csrp_kernel(int64_t N, const int *Ap, const int *__restrict__ Aj, const double *__restrict__ Ax,
+            const double *__restrict__ x, double *__restrict__ y, int rpb, int64_t stiles, int64_t tpx, int swz)
+{
+    __shared__ double prod[2][BLOCK * K];
+    const int64_t st = tile_of_block(blockIdx.x, tpx, swz);
+    if (st >= stiles) return;
+    const int tid = threadIdx.x;
+    const int64_t R0 = st * (int64_t)T * rpb;
+    int nzb[T + 1];
+#pragma unroll
+    for (int t = 0; t <= T; t++) {
+        const int64_t r = R0 + (int64_t)t * rpb;
+        nzb[t] = Ap[r < N ? r : N];
+    }
+    int c[2][K], a[2], b[2];
+    double v[2][K];
+    auto request = [&](int t, int (&cc)[K], double (&vv)[K], int &aa, int &bb) {
+        int64_t r0 = R0 + (int64_t)t * rpb;
+        r0 = r0 < N ? r0 : N;
+        const int nr = (int)((N - r0) < rpb ? (N - r0) : rpb);
+        aa = Ap[r0 + (tid < nr ? tid : nr)];
+        bb = Ap[r0 + (tid + 1 < nr ? tid + 1 : nr)];
+        const int cnt = nzb[t + 1] - nzb[t];
+#pragma unroll
+        for (int k = 0; k < K; k++) { const int i = k * BLOCK + tid; cc[k] = ld<NT>(Aj + nzb[t] + (i < cnt ? i : 0)); }
+#pragma unroll
+        for (int k = 0; k < K; k++) { const int i = k * BLOCK + tid; vv[k] = ld<NT>(Ax + nzb[t] + (i < cnt ? i : 0)); }
+    };
+    request(0, c[0], v[0], a[0], b[0]);
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        double xv[K];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < K; k++) asm volatile("" : "+v"(c[cur][k]));
+#pragma unroll
+        for (int k = 0; k < K; k++) xv[k] = x[c[cur][k]];
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < T) request(t + 1, c[nxt], v[nxt], a[nxt], b[nxt]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < K; k++) prod[cur][k * BLOCK + tid] = v[cur][k] * xv[k];
+        __syncthreads();
+        int64_t r0 = R0 + (int64_t)t * rpb;
+        const int nr = (int)((N - r0) < rpb ? (N - r0) : rpb); // (<= 0 past the matrix)
+        if (tid < nr) {
+            double s = 0.0;
+            for (int j = a[cur]; j < b[cur]; j++) s = s + prod[cur][j - nzb[t]];
+            __builtin_nontemporal_store(s, y + r0 + tid);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// csrw: csrd with WAVE-PRIVATE tiles -- each wave of the workgroup owns rpw consecutive rows, requests their entries lane-strided
+// (lane + 64 k), parks the products in its own LDS region and sums its rows: no s_barrier (a wave's LDS instructions execute in
+// order), so no wave waits for another wave's loads.
+// ------------------------------------------------------------------------------------------------------------
+template <int K, bool NT, int ONE = 0>
+__global__ void __launch_bounds__(256)
+csrw_kernel(int64_t N, const int *Ap, const int *__restrict__ Aj, const double *__restrict__ Ax,
+            const double *__restrict__ x, double *__restrict__ y, int rpw, int64_t tiles, int64_t tpx, int swz)
+{
+    __shared__ double prod[4][64 * K];
+    const int64_t tile = tile_of_block(blockIdx.x, tpx, swz);
+    if (tile >= tiles) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63; // (scalar: the tile bounds are s_loads)
+    const int64_t r0 = (tile * 4 + wave) * (int64_t)rpw;
+    if (r0 >= N) return;
+    const int nr = (int)((N - r0) < rpw ? (N - r0) : rpw);
+    const int nz0 = Ap[r0], nz1 = Ap[r0 + nr];
+    // ONE: one row-offset load per lane; the row's end is the next lane's start (wave_shl:1 on the DPP path, the last lane takes nz1)
+    int a = Ap[r0 + (lane < nr ? lane : nr)], b = ONE ? 0 : Ap[r0 + (lane + 1 < nr ? lane + 1 : nr)];
+    const int cnt = nz1 - nz0;
+    int c[K];
+    double v[K], xv[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { const int i = k * 64 + lane; c[k] = ld<NT>(Aj + nz0 + (i < cnt ? i : 0)); }
+#pragma unroll
+    for (int k = 0; k < K; k++) { const int i = k * 64 + lane; v[k] = ld<NT>(Ax + nz0 + (i < cnt ? i : 0)); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < K; k++) asm volatile("" : "+v"(c[k]));
+#pragma unroll
+    for (int k = 0; k < K; k++) xv[k] = x[c[k]];
+    asm volatile("" : "+v"(a), "+v"(b));
+    if constexpr (ONE) b = __builtin_amdgcn_update_dpp(nz1, a, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    double *mine = prod[wave];
+#pragma unroll
+    for (int k = 0; k < K; k++) mine[k * 64 + lane] = v[k] * xv[k];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < nr) {
+        double s = 0.0;
+        for (int j = a; j < b; j++) s = s + mine[j - nz0];
+        __builtin_nontemporal_store(s, y + r0 + lane);
     }
 }
 
@@ -545,10 +671,59 @@ int main(int argc, char **argv)
         snprintf(nm, sizeof nm, "csrd block %d k %d nt-load %d rpb %d swz %d", BLOCK, K, NT, rpb, swz);                  \
         run(nm, B_csr, true, [&, swz] { hipLaunchKernelGGL((csrd_kernel<BLOCK, K, NT>), dim3((unsigned)grid), dim3(BLOCK), 0, 0, N, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz); }); \
     }
+#define CSRDA(ABL, RPB)                                                                                                 \
+    {                                                                                                                    \
+        const int rpb = RPB;                                                                                             \
+        const int64_t tiles = (N + rpb - 1) / rpb, tpx = (tiles + 7) / 8;                                                \
+        const int64_t grid = ((tiles + 8 * swz - 1) / (8 * swz)) * 8 * swz;                                              \
+        snprintf(nm, sizeof nm, "csrd ablation %d rpb %d swz %d", ABL, rpb, swz);                                        \
+        run(nm, B_csr, ABL == 0 || ABL == 4, [&, swz] { hipLaunchKernelGGL((csrd_kernel<256, 4, true, ABL>), dim3((unsigned)grid), dim3(256), 0, 0, N, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz); }); \
+    }
+        if (swz == 64) { CSRDA(0, 192) CSRDA(1, 192) CSRDA(2, 192) CSRDA(3, 192) CSRDA(4, 192) CSRDA(0, 204) CSRDA(4, 204) }
+#undef CSRDA
         CSRD(256, 4, true, 176) CSRD(256, 4, false, 176) CSRD(256, 4, true, 192) CSRD(256, 4, true, 204)
         CSRD(256, 5, true, 240) CSRD(256, 5, true, 256) CSRD(256, 5, false, 256)
         CSRD(512, 4, true, 400) CSRD(512, 5, true, 512) CSRD(128, 5, true, 128) CSRD(128, 8, true, 128)
 #undef CSRD
+    }
+    // ---- csrp: csrd, T tiles per workgroup, software-pipelined ---------------------------------------------------------
+    for (int swz : {8, 16, 32, 64}) {
+        char nm[96];
+#define CSRP(BLOCK, K, T, RPB)                                                                                           \
+    {                                                                                                                    \
+        const int rpb = RPB;                                                                                             \
+        const int64_t stiles = (N + (int64_t)rpb * T - 1) / ((int64_t)rpb * T), tpx = (stiles + 7) / 8;                  \
+        const int64_t grid = ((stiles + 8 * swz - 1) / (8 * swz)) * 8 * swz;                                             \
+        snprintf(nm, sizeof nm, "csrp block %d k %d tiles %d rpb %d swz %d", BLOCK, K, T, rpb, swz);                     \
+        run(nm, B_csr, true, [&, swz] { hipLaunchKernelGGL((csrp_kernel<BLOCK, K, T, true>), dim3((unsigned)grid), dim3(BLOCK), 0, 0, N, Ap, Aj, Ax, x, y, rpb, stiles, tpx, swz); }); \
+    }
+        CSRP(256, 4, 1, 192) CSRP(256, 4, 2, 192) CSRP(256, 4, 4, 192) CSRP(256, 4, 8, 192) CSRP(256, 4, 4, 204) CSRP(256, 5, 4, 256)
+        CSRP(128, 4, 4, 96) CSRP(128, 4, 8, 96) CSRP(512, 4, 2, 400) CSRP(512, 4, 4, 400)
+#undef CSRP
+    }
+    // ---- csrw: wave-private tiles, no barrier ---------------------------------------------------------------------------
+    for (int swz : {16, 32, 64, 128}) {
+        char nm[96];
+#define CSRW(K, RPW)                                                                                                     \
+    {                                                                                                                    \
+        const int rpw = RPW;                                                                                             \
+        const int64_t tiles = (N + (int64_t)rpw * 4 - 1) / ((int64_t)rpw * 4), tpx = (tiles + 7) / 8;                    \
+        const int64_t grid = ((tiles + 8 * swz - 1) / (8 * swz)) * 8 * swz;                                              \
+        snprintf(nm, sizeof nm, "csrw k %d rows/wave %d swz %d", K, rpw, swz);                                           \
+        run(nm, B_csr, true, [&, swz] { hipLaunchKernelGGL((csrw_kernel<K, true>), dim3((unsigned)grid), dim3(256), 0, 0, N, Ap, Aj, Ax, x, y, rpw, tiles, tpx, swz); }); \
+    }
+        CSRW(4, 48) CSRW(4, 51) CSRW(5, 64) CSRW(6, 64) CSRW(8, 64) CSRW(3, 38)
+#undef CSRW
+#define CSRW1(K, RPW)                                                                                                    \
+    {                                                                                                                    \
+        const int rpw = RPW;                                                                                             \
+        const int64_t tiles = (N + (int64_t)rpw * 4 - 1) / ((int64_t)rpw * 4), tpx = (tiles + 7) / 8;                    \
+        const int64_t grid = ((tiles + 8 * swz - 1) / (8 * swz)) * 8 * swz;                                              \
+        snprintf(nm, sizeof nm, "csrw1 k %d rows/wave %d swz %d", K, rpw, swz);                                          \
+        run(nm, B_csr, true, [&, swz] { hipLaunchKernelGGL((csrw_kernel<K, true, 1>), dim3((unsigned)grid), dim3(256), 0, 0, N, Ap, Aj, Ax, x, y, rpw, tiles, tpx, swz); }); \
+    }
+        CSRW1(4, 51) CSRW1(5, 64)
+#undef CSRW1
     }
     // ---- ell (library kernel, launch shapes x XCD dealing) -----------------------------------------------------
     {
