@@ -5,6 +5,8 @@
 //   * `mix`: a kernel with csr_stream's ACCESS PATTERN (same tiles, same arrays, same bytes, same dealing) but no
 //     dependent chain, no LDS, no barrier -- what the memory system gives this traffic mix;
 //   * `csrx`: experimental variants of the csr_stream fast path (row pointers in registers, paired 16-byte y stores);
+//   * `shape` / `csrd` / `csrp` / `csrw`: which REQUEST SHAPE over CSR's arrays the memory system serves fastest, and the real multiply
+//     built on the winner: lane-strided streams (branch-free), T pipelined tiles per workgroup, wave-private tiles;
 //   * `diax`: DIA with the x window of the central diagonals staged in LDS, offsets as in the library, XCD chunk dealing.
 // Every result-producing variant is checked bit for bit against the library's csr_scalar (pinned by tests/).
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -Iinclude tools/r2_probe.hip -o tools/bin/r2_probe \
