@@ -1059,6 +1059,7 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         const int64_t grid64 = padded_grid(tiles, swz);
         if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "csr_wave: grid too large");
         const size_t lds = (size_t)block * K * sizeof(T);
+        if (lds > 64 * 1024) return fail(CMI_ERROR_INVALID_VALUE, "csr_wave: block_size x items_per_thread products do not fit 64 KiB of LDS");
         const bool dot = w && dot_partial && tiles <= kPartialCapacity;
         with_policy(pol, [&](auto P) {
             constexpr int POL = decltype(P)::value;
