@@ -141,7 +141,7 @@ def pmc_traffic(kernel_substr):
     # the SpMV kernel of each format (not the builders / converters that carry the format's name too)
     names = {"csr": ("csr_wave_kernel", "csr_stream_kernel", "csr_balanced_kernel", "csr_vector_kernel", "csr_scalar_kernel"), "ell": ("ell_row_kernel",),
              "dia": ("dia_row_kernel", "dia_row2_kernel"), "coo": ("csr_wave_kernel", "csr_stream_kernel", "csr_balanced_kernel"),  # sorted entries through a plan: the CSR kernels on the plan's row offsets
-             "coo_tile": ("coo_tile_kernel",), "hyb": ("hyb_tile_kernel",), "csr16": ("csr_stream16_kernel",)}[kernel_substr]
+             "coo_tile": ("coo_tile_kernel",), "hyb": ("hyb_tile_kernel",), "csr16": ("csr_wave16_kernel", "csr_stream16_kernel")}[kernel_substr]
     best, src = None, None
     if os.path.isdir(pdir):
         for f in sorted(os.listdir(pdir)):

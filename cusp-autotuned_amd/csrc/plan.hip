@@ -122,7 +122,9 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
                 const double mean = (double)num_entries / (double)num_rows;
                 if (up != rpb && up <= p->cfg.block_size && (double)up * mean + 3.0 <= (double)p->cfg.block_size * p->cfg.items_per_thread * 4) p->cfg.rows_per_block = up;
             }
-            st = csr16_build(p, index_array, csr_columns, s); // all tiles qualify -> cfg.kernel = CMI_CSR_STREAM_C16, else unchanged
+            // (stencil-like rows and the table's shape: the copy is tiled for the wave-tile kernel instead -- 64 rows per tile)
+            const int wave_k = table_shape && wave_tiles_fit(num_rows, num_entries, p->prof.max_len) ? (int)p->prof.max_len : 0;
+            st = csr16_build(p, index_array, csr_columns, s, wave_k); // all tiles qualify -> cfg.kernel = CMI_CSR_STREAM_C16, else unchanged
             if (p->cfg.kernel != CMI_CSR_STREAM_C16) p->cfg.rows_per_block = tuned_rpb; // not granted: csr_stream as tuned
         }
         // Rows that all have (nearly) the same short length -- stencils -- take csr_stream's lane-strided body with wave-private

@@ -1086,8 +1086,8 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     case CMI_CSR_STREAM_C16: { // the plan's 16-bit column copy (spmv_csr16.hip); Aj itself is not read
         if (!plan || !plan->csr16_cols) return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_CSR_STREAM_C16 runs through a plan of cmi_plan_create_csr only");
         if (reinterpret_cast<uintptr_t>(Ax) % 16 != 0) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream_c16: values must be 16-byte aligned");
-        if constexpr (std::is_same<T, double>::value) return csr16_multiply_f64(plan, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol, (w && dot_partial) ? dot_swizzle(c.xcd_swizzle, plan) : c.xcd_swizzle);
-        else return csr16_multiply_f32(plan, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol, (w && dot_partial) ? dot_swizzle(c.xcd_swizzle, plan) : c.xcd_swizzle);
+        if constexpr (std::is_same<T, double>::value) return csr16_multiply_f64(plan, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol, (w && dot_partial) ? dot_swizzle(c.xcd_swizzle, plan, plan->csr16_wave_k > 0 ? c.xcd_swizzle : 0) : c.xcd_swizzle);
+        else return csr16_multiply_f32(plan, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol, (w && dot_partial) ? dot_swizzle(c.xcd_swizzle, plan, plan->csr16_wave_k > 0 ? c.xcd_swizzle : 0) : c.xcd_swizzle);
     }
     case CMI_CSR_STREAM_PIPE: {
         const int rpb = c.rows_per_block;

@@ -67,12 +67,15 @@ csr16_encode_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__r
 
 // Tries to give `p` (a CSR plan whose cfg is a completed CMI_CSR_STREAM shape) the 16-bit copy.  On success p->cfg.kernel
 // becomes CMI_CSR_STREAM_C16 and the plan owns csr16_cols / csr16_base; otherwise nothing changes.  Synchronises `s`.
-int csr16_build(cmi_plan *p, const int *Ap, const int *Aj, hipStream_t s)
+// wave_k > 0 (the plan found stencil-like rows, plan.hip wave_tiles_fit): the copy is tiled per wave of the wave-tile kernel instead --
+// 64 rows per tile, wave_k entries per lane -- and p->cfg then reads block_size 256, rows_per_block 64, items_per_thread wave_k.
+int csr16_build(cmi_plan *p, const int *Ap, const int *Aj, hipStream_t s, int wave_k)
 {
     const cmi_config &c = p->cfg;
     const int64_t rows = p->rows, nnz = p->nnz;
     if (c.kernel != CMI_CSR_STREAM || c.threads_per_row > 1 || rows <= 0 || nnz < 4 || nnz > INT32_MAX - 65536) return CMI_SUCCESS;
-    const int rpb = c.rows_per_block, block = c.block_size, ipt = c.items_per_thread;
+    const int rpb = wave_k > 0 ? kWave : c.rows_per_block, block = wave_k > 0 ? kWave : c.block_size, ipt = c.items_per_thread;
+    const int pass_entries = wave_k > 0 ? kWave * wave_k + 3 : block * ipt * 4;
     if (rpb < 1 || rpb > block) return CMI_SUCCESS; // the single-pass kernel gives every row its own lane
     const int64_t tiles = ceil_div(rows, rpb);
     if (tiles > INT32_MAX) return CMI_SUCCESS;
@@ -84,7 +87,7 @@ int csr16_build(cmi_plan *p, const int *Ap, const int *Aj, hipStream_t s)
     if (e == hipSuccess) e = hipMalloc((void **)&flag, sizeof(int));
     if (e == hipSuccess) e = hipMemsetAsync(flag, 0, sizeof(int), s);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(csr16_scan_kernel, dim3((unsigned)tiles), dim3(256), 0, s, rows, Ap, Aj, rpb, block * ipt * 4, base, flag);
+        hipLaunchKernelGGL(csr16_scan_kernel, dim3((unsigned)tiles), dim3(wave_k > 0 ? 64 : 256), 0, s, rows, Ap, Aj, rpb, pass_entries, base, flag);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&host, flag, sizeof(int), hipMemcpyDeviceToHost, s);
@@ -94,7 +97,7 @@ int csr16_build(cmi_plan *p, const int *Ap, const int *Aj, hipStream_t s)
         e = hipMalloc((void **)&cols16, ((size_t)nnz + 8) * sizeof(uint16_t));
         if (e == hipSuccess) e = hipMemsetAsync(cols16, 0, ((size_t)nnz + 8) * sizeof(uint16_t), s);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(csr16_encode_kernel, dim3((unsigned)tiles), dim3(256), 0, s, rows, Ap, Aj, rpb, base, cols16);
+            hipLaunchKernelGGL(csr16_encode_kernel, dim3((unsigned)tiles), dim3(wave_k > 0 ? 64 : 256), 0, s, rows, Ap, Aj, rpb, base, cols16);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -108,7 +111,73 @@ int csr16_build(cmi_plan *p, const int *Ap, const int *Aj, hipStream_t s)
     p->csr16_base = base;
     p->csr16_cols = cols16;
     p->cfg.kernel = CMI_CSR_STREAM_C16;
+    if (wave_k > 0) {
+        p->csr16_wave_k = wave_k;
+        p->cfg.block_size = 256;
+        p->cfg.rows_per_block = kWave;
+        p->cfg.items_per_thread = wave_k;
+        p->cfg.threads_per_row = 0;
+    }
     return CMI_SUCCESS;
+}
+
+// ---- the multiply, wave-tile form ------------------------------------------------------------------------------------------
+// spmv_csr.hip's csr_wave_kernel reading the copy: the wave's tile is the copy's tile (64 rows), every offset is against its base.
+template <typename T, int K, int POL, bool DOT>
+__global__ void __launch_bounds__(1024)
+csr_wave16_kernel(int64_t num_rows, const int *Ap /* not restrict: see the asm below */, const uint16_t *__restrict__ Aj16,
+                  const int32_t *__restrict__ tile_base, const T *__restrict__ Ax, const T *__restrict__ x, T *__restrict__ y,
+                  int64_t num_tiles, int64_t tiles_per_xcd, int swizzle, int accumulate, const T *__restrict__ w,
+                  double *__restrict__ dot_partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double dot_slots[DOT ? 1024 / kWave : 1];
+    constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
+    const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle);
+    if (tile >= num_tiles) return; // whole workgroup
+    const int waves = blockDim.x / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x & (kWave - 1);
+    const int64_t wt = tile * waves + wave;
+    const int64_t r0 = wt * kWave;
+    double d = 0.0;
+    if (r0 < num_rows) {
+        const int nr = (int)((num_rows - r0) < kWave ? (num_rows - r0) : kWave);
+        const int nz0 = Ap[r0], nz1 = Ap[r0 + nr], base = tile_base[wt];
+        const int cnt = nz1 - nz0;
+        int a = Ap[r0 + (lane < nr ? lane : nr)];
+        T wv = T(0);
+        if constexpr (DOT) { if (lane < nr) wv = w[r0 + lane]; }
+        T s = (accumulate && lane < nr) ? y[r0 + lane] : T(0);
+        if (cnt > 0) { // (<= 64 K by the plan's rule, checked when the copy was built)
+            T *mine = reinterpret_cast<T *>(smem) + (size_t)wave * kWave * K;
+            int c[K];
+            T v[K], xv[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) { const int i = k * kWave + lane; c[k] = (int)ld<NT>(Aj16 + nz0 + (i < cnt ? i : 0)); }
+#pragma unroll
+            for (int k = 0; k < K; k++) { const int i = k * kWave + lane; v[k] = ld<NT>(Ax + nz0 + (i < cnt ? i : 0)); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < K; k++) asm volatile("" : "+v"(c[k]));
+#pragma unroll
+            for (int k = 0; k < K; k++) xv[k] = x[base + c[k]];
+            asm volatile("" : "+v"(a));
+            const int b = __builtin_amdgcn_update_dpp(nz1, a, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+#pragma unroll
+            for (int k = 0; k < K; k++) mine[k * kWave + lane] = v[k] * xv[k];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < nr)
+                for (int j = a; j < b; j++) s = s + mine[j - nz0];
+        }
+        if (lane < nr) {
+            st<NTS>(y + r0 + lane, s);
+            if constexpr (DOT) d = (double)s * (double)wv;
+        }
+    }
+    if constexpr (DOT) {
+        tile_dot_store(d, dot_slots, dot_partial + tile);
+        if (tile == 0 && threadIdx.x == 0) reset_fold_state(dot_partial);
+    }
 }
 
 // ---- the multiply ----------------------------------------------------------------------------------------------------
@@ -234,6 +303,38 @@ static int csr16_multiply(const cmi_plan *p, const int *Ap, const T *Ax, const T
     const cmi_config &c = p->cfg;
     const int block = c.block_size, ipt = c.items_per_thread, rpb = c.rows_per_block;
     const int64_t rows = p->rows, nnz = p->nnz;
+    if (p->csr16_wave_k > 0) { // the copy is tiled per wave: the wave-tile kernel, four waves (four tiles of the copy) per workgroup
+        const int K = p->csr16_wave_k, wblock = 256;
+        const int64_t wtiles = ceil_div(rows, (int64_t)wblock);
+        const int64_t wtpx = ceil_div(wtiles, kXcds);
+        const int wswz = swizzle < 0 ? 0 : swizzle;
+        const int64_t wgrid = padded_grid(wtiles, wswz);
+        if (wgrid > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream_c16: grid too large");
+        const size_t wlds = (size_t)wblock * K * sizeof(T);
+        const bool wdot = w && dot_partial && wtiles <= kPartialCapacity;
+        with_policy(pol & 3, [&](auto P) {
+            constexpr int POL = decltype(P)::value;
+            auto go = [&](auto KK) {
+                constexpr int KC = decltype(KK)::value;
+                if (wdot) hipLaunchKernelGGL((csr_wave16_kernel<T, KC, POL, true>), dim3((unsigned)wgrid), dim3(wblock), wlds, s, rows, Ap, p->csr16_cols, p->csr16_base, Ax, x, y, wtiles, wtpx, wswz, accumulate, w, dot_partial);
+                else      hipLaunchKernelGGL((csr_wave16_kernel<T, KC, POL, false>), dim3((unsigned)wgrid), dim3(wblock), wlds, s, rows, Ap, p->csr16_cols, p->csr16_base, Ax, x, y, wtiles, wtpx, wswz, accumulate, (const T *)nullptr, (double *)nullptr);
+            };
+            switch (K) {
+            case 2: go(std::integral_constant<int, 2>()); break;
+            case 3: go(std::integral_constant<int, 3>()); break;
+            case 4: go(std::integral_constant<int, 4>()); break;
+            case 5: go(std::integral_constant<int, 5>()); break;
+            case 6: go(std::integral_constant<int, 6>()); break;
+            case 7: go(std::integral_constant<int, 7>()); break;
+            case 8: go(std::integral_constant<int, 8>()); break;
+            case 9: go(std::integral_constant<int, 9>()); break;
+            default: go(std::integral_constant<int, 10>()); break;
+            }
+        });
+        CMI_LAUNCH_CHECK("csr_wave16 spmv");
+        if (wdot && dot_partials) *dot_partials = (int)wtiles;
+        return CMI_SUCCESS;
+    }
     const int64_t tiles = ceil_div(rows, rpb);
     const int64_t tpx = ceil_div(tiles, kXcds);
     const int swz = swizzle < 0 ? 0 : swizzle;

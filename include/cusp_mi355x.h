@@ -144,7 +144,10 @@ typedef enum cmi_kernel {
                                + uint16 offsets; 2 bytes per entry of extra HBM) -- 10 nnz + 20 N bytes per multiply
                                instead of 12 nnz + 20 N, same products, same storage-order sums, same bits.  Granted only
                                if EVERY tile spans < 65536 columns and fits one LDS pass; otherwise the plan's config says
-                               CMI_CSR_STREAM and nothing is built.  config fields: csr_stream's (0 = the table's)      */
+                               CMI_CSR_STREAM and nothing is built.  config fields: csr_stream's (0 = the table's).  With the
+                               table's shape on stencil-like rows (where a plan would run CMI_CSR_STREAM_WAVE) the copy is tiled
+                               per wave instead -- cmi_plan_config then reads block_size 256, rows_per_block 64 (the copy's
+                               tile), items_per_thread = entries per lane -- and the wave-tile kernel reads it            */
     CMI_CSR_STREAM_WAVE = 7, /* csr_stream's lane-strided single-pass body with WAVE-PRIVATE tiles, for matrices whose rows all have
                                (nearly) the same short length (stencils): each 64-lane wave owns rows_per_block / (block_size / 64)
                                <= 64 consecutive rows, lane l requests entries l, l + 64, ... of the wave's tile, the products are

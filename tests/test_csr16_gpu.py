@@ -53,9 +53,8 @@ def test_c16_poisson_every_shape_bit_exact(cmi, torch_cuda, orc, tag):
     # the table's shape
     plan = cmi.Plan.csr(dx.dtype, N, N, dAp, dAj, cfg=cmi.Config(kernel=cmi.CSR_STREAM_C16))
     assert plan.config().kernel == cmi.CSR_STREAM_C16 and plan.info()["storage_order_sums"] is True
-    c0 = plan.config()  # whole waves of rows when one LDS pass holds them: the fused dot shares the tiling
-    up = -(-c0.rows_per_block // 64) * 64
-    assert c0.rows_per_block % 64 == 0 or up > c0.block_size or up * 5 + 3 > c0.block_size * c0.items_per_thread * 4
+    c0 = plan.config()  # stencil rows + the table's shape: the copy is tiled per wave (64 rows, 5 entries per lane) for the wave-tile kernel
+    assert (c0.block_size, c0.rows_per_block, c0.items_per_thread) == (256, 64, 5)
     y = torch.full((N,), 10.0, dtype=dx.dtype, device="cuda")
     cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
     assert np.array_equal(y.cpu().numpy(), want)

@@ -425,6 +425,21 @@ def test_csr_plan_selects_wave_tiles_for_stencil_rows(cmi, torch_cuda, orc, tag)
         assert np.array_equal(y.cpu().numpy(), want), (m, n)
         ref = float(np.dot(want.astype(np.float64), w.astype(np.float64)))
         assert abs(float(res) - ref) <= 1e-12 * float(np.abs(want.astype(np.float64) * w).sum()) + (0 if tag == "f64" else 1e-6 * abs(ref)), (m, n)
+        # the opt-in 16-bit column copy on such rows is tiled per wave and read by the wave-tile kernel's twin
+        p16 = cmi.Plan.csr(tdt, N, N, dAp, dAj, cfg=cmi.Config(kernel=cmi.CSR_STREAM_C16))
+        c16 = p16.config()
+        assert c16.kernel == cmi.CSR_STREAM_C16
+        if c.kernel == cmi.CSR_STREAM_WAVE:
+            assert (c16.block_size, c16.rows_per_block, c16.items_per_thread) == (256, 64, longest), c16
+        for acc, ref_y in ((False, want), (True, want_acc)):
+            y = dev(y0, torch) if acc else torch.full((N,), 9.0, dtype=tdt, device="cuda")
+            cmi.spmv_csr_plan(p16, dAp, dAj, dAx, dx, y, accumulate=acc)
+            assert np.array_equal(y.cpu().numpy(), ref_y), (m, n, "c16", acc)
+        res.fill_(float("nan"))
+        y = torch.zeros(N, dtype=tdt, device="cuda")
+        cmi.spmv_csr_dot(N, N, dAp, dAj, dAx, dx, y, dev(w, torch), res, cmi.blas_workspace(), plan=p16)
+        assert np.array_equal(y.cpu().numpy(), want), (m, n, "c16 dot")
+        assert abs(float(res) - ref) <= 1e-12 * float(np.abs(want.astype(np.float64) * w).sum()) + (0 if tag == "f64" else 1e-6 * abs(ref)), (m, n, "c16 dot")
         # a caller's kernel is kept
         explicit = cmi.Plan(cmi.FORMAT_CSR, tdt, N, N, len(Aj), dAp, cmi.Config(kernel=cmi.CSR_STREAM))
         assert explicit.config().kernel == cmi.CSR_STREAM
