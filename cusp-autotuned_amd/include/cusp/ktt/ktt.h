@@ -82,6 +82,13 @@ inline std::vector<cmi_config> configuration_space(int format, double mean)
                         out.push_back(make(CMI_CSR_STREAM, b, tpr, 0, ipt, nt, 0, 0));
                         if (!tpr) out.push_back(make(CMI_CSR_STREAM, b, 0, 0, ipt, nt, 64, 0));
                     }
+        if (mean <= 16) // short rows: the entry streams requested lane-strided (policy bit 4), with and without the nt load hint
+            for (int b : blocks)
+                for (int nt : {6, 7}) out.push_back(make(CMI_CSR_STREAM, b, 0, 0, 1, nt, 64, 0));
+        if (mean <= 10) { // (nearly) equal short rows: wave-private tiles, as many entries per lane as the mean row rounded up
+            const int k = mean <= 2 ? 2 : (int)(mean + 0.999);
+            for (int nt : {2, 3}) out.push_back(make(CMI_CSR_STREAM_WAVE, 256, 0, 0, k, nt, 64, 0));
+        }
         for (int tpr : {4, 16, 64}) out.push_back(make(CMI_CSR_VECTOR, 256, tpr, 0, 0, 0, 0, 0));
         out.push_back(make(CMI_CSR_BALANCED, 256, 0, 0, 0, 0, 0, 0)); // merge-path split: wins on skewed row lengths
         if (mean <= 40)
