@@ -1,0 +1,7 @@
+#!/bin/bash
+# session 64: the whole GPU suite on the final tree (cusp::ktt::tune now explores the lane-strided and wave-tile shapes), smoke
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/s64; mkdir -p $O
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; rc=$?; echo "pytest exit $rc"; tail -n 6 $O/pytest_gpu.txt
+[ $rc -eq 0 ] || exit 1
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -n 1 $O/smoke.txt
