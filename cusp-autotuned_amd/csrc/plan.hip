@@ -139,6 +139,12 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
             p->cfg.items_per_thread = (int)p->prof.max_len;
             p->cfg.threads_per_row = 0;
             p->cfg.nontemporal &= ~kPolStrided; // (the request shape is the kernel's own)
+            // every line of its streams is requested exactly once: beyond the Infinity Cache the streaming hint is right whatever
+            // the table's csr_stream entry of this bucket says (its 16-byte-vector shapes measured the other way) -- the top twelve of
+            // 96 swept shapes on the headline matrix all carry it, a tridiagonal matrix of 10^7 rows 91.8 -> 83 us
+            // (profiles/r02_wave_shape_sweep.txt, r02_wave_ab.txt); below it, plain loads keep the matrix resident (tuning.hip)
+            if (num_entries * (int64_t)(sizeof(int) + vbytes) > kInfinityCacheBytes + kInfinityCacheBytes / 4) p->cfg.nontemporal |= kPolLoadNT;
+            p->cfg.nontemporal |= kPolStoreNT;
         }
     } else if (format == CMI_FORMAT_COO) {
         int sorted = 1, long_runs = 0;
