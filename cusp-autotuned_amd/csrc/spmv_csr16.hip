@@ -1,7 +1,6 @@
 // spmv_csr16.hip -- CSR SpMV with the plan's 16-bit copy of the column indices (CMI_CSR_STREAM_C16, opt-in).
 //
-// csr_stream on the headline matrix runs at the rate the memory system delivers (profiles/r02_probe_*: a kernel that only
-// READS the same streams is no faster), so the only way left to make y = A x faster is to move fewer bytes.  Of CSR's
+// Beside the request shape of the streams the other way to make y = A x faster is to move fewer bytes.  Of CSR's
 // 12 nnz + 20 N bytes, 4 nnz are column indices -- and inside one row tile of a banded / FEM-ordered matrix they span a
 // few thousand columns, not 2^31.  A plan created with kernel = CMI_CSR_STREAM_C16 therefore keeps, on the device,
 //     tile_base[t] = smallest column index among the entries of tile t          (4 bytes per tile)
@@ -11,8 +10,9 @@
 // The reference has nothing comparable (its KTT path only re-blocks the same 32-bit arrays, cuda/ktt/kernels/csr_kernel.h).
 //
 // All or nothing, decided by cmi_plan_create: every tile must (a) span fewer than 65536 columns and (b) fit the single
-// LDS pass of csr_stream's fast path (one lane per row).  If any tile does not, the plan keeps CMI_CSR_STREAM and owns
-// nothing.  The kernel below is that fast path and only that.
+// LDS pass of csr_stream's fast path (one lane per row).  If any tile does not, the plan keeps its plain kernel and owns
+// nothing.  Two tilings: csr_stream's (rows_per_block rows per tile; csr_stream16_kernel = that fast path and only that) and, for
+// stencil-like rows, the wave-tile kernel's (64 rows per tile; csr_wave16_kernel).
 #include "common.h"
 
 namespace cmi {
