@@ -302,6 +302,10 @@ struct cmi_plan {
     // CSR with cfg.kernel == CMI_CSR_STREAM_C16 (spmv_csr16.hip): per-tile smallest column and the 16-bit offsets from it
     int32_t *csr16_base = nullptr;  // device, one per tile of cfg.rows_per_block rows
     uint16_t *csr16_cols = nullptr; // device, nnz (+ padding) entries
+    int32_t *wave_row_start = nullptr; // device, wave_tiles + 1 entries: CMI_CSR_STREAM_WAVE on IRREGULAR short rows -- wave tile t owns the rows whose first
+                                       // entry lies in [t wave_q, (t + 1) wave_q) (plan.hip wave_partition); null: 64 rows per wave
+    int64_t wave_tiles = 0;
+    int wave_q = 0;
     int csr16_wave_k = 0;           // > 0: the copy is tiled per WAVE (64 rows; cfg.rows_per_block == 64) and multiplied by the wave-tile kernel with this many entries per lane
 };
 
@@ -315,6 +319,7 @@ int hyb_tile_starts(int64_t rows, int64_t coo_entries, const int *coo_Ai, int32_
 constexpr double kHybFusedMaxPerRow = 3.0;
 constexpr int kHybFusedMaxInTile = 4096;
 // spmv_csr16.hip: the plan's 16-bit column copy (built only if every tile qualifies) and the multiply that reads it
+int wave_partition_build(cmi_plan *p, const int *Ap, int k, hipStream_t s); // spmv_csr.hip
 int csr16_build(cmi_plan *p, const int *Ap, const int *Aj, hipStream_t s, int wave_k = 0);
 int csr16_multiply_f64(const cmi_plan *p, const int *Ap, const double *Ax, const double *x, double *y, int accumulate,
                        hipStream_t s, const double *w, double *dot_partial, int *dot_partials, int cache_policy, int xcd_swizzle);

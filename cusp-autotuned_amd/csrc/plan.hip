@@ -40,11 +40,32 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
 
 // csr_wave (CMI_CSR_STREAM_WAVE) instead of csr_stream: the longest row has 2..10 entries and the mean is within 7 % of it
 // ($CMI_CSR_WAVE=0: never -- measurements of csr_stream on stencil matrices)
-static bool wave_tiles_fit(int64_t rows, int64_t nnz, int64_t max_len)
+static int wave_env()
 {
     static const int env = [] { const char *e = std::getenv("CMI_CSR_WAVE"); return e ? std::atoi(e) : 1; }();
-    if (!env || rows <= 0 || max_len < 2 || max_len > kWaveTileMaxK) return false;
+    return env;
+}
+static bool wave_tiles_fit(int64_t rows, int64_t nnz, int64_t max_len)
+{
+    if (!wave_env() || rows <= 0 || max_len < 2 || max_len > kWaveTileMaxK) return false;
     return (double)nnz >= 0.93 * (double)max_len * (double)rows;
+}
+// ... and csr_wave on a plan-built partition (spmv_csr.hip wave_partition_build) for IRREGULAR short rows: K entries per lane with
+// K = floor(mean + longest / 64), so that a wave tile of Q = 64 K - longest entries holds about Q / mean <= 64 rows; the longest row
+// small enough for the tiles to fill 90 % of the wave's request slots.  OPT-IN: asked for per plan (cfg.kernel = CMI_CSR_STREAM_WAVE
+// with rows_per_block < 0) -- measured against csr_stream it wins on FEM-like rows (thermal2-like 0.98 / 0.93 of its time, f64 / f32)
+// and loses on large matrices with scattered columns (1.04-1.34x; profiles/r02_wavep_ab.txt), so no plan selects it by itself
+// ($CMI_CSR_WAVE=2: every AUTO plan whose rows qualify does -- measurements).
+static int wave_partition_k(int64_t rows, int64_t nnz, const row_profile &prof, bool asked, int asked_k)
+{
+    if (!asked && (wave_env() < 2 || rows < 4096)) return 0;
+    if (rows <= 0 || nnz <= 0 || prof.max_len < 1 || prof.in_long > 0) return 0;
+    const double mean = (double)nnz / (double)rows;
+    if (!asked && mean < 2.5) return 0;
+    int k = asked_k > 0 ? asked_k : (int)std::floor(mean + (double)prof.max_len / 64.0);
+    if (k < 2 && asked_k <= 0) k = 2;
+    if (k < 2 || k > kWaveTileMaxK || (double)prof.max_len > 6.4 * k) return 0;
+    return k;
 }
 
 CMI_API int cmi_plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
@@ -99,6 +120,22 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
         } else if (table_shape && compress_default())
             want16 = true;
     }
+    // CMI_CSR_STREAM_WAVE with rows_per_block < 0: wave tiles on a partition the plan builds (irregular short rows); launch policy from
+    // the table, entries per lane from the caller (items_per_thread) or the rule
+    cmi_config part_shape;
+    bool want_partition = false;
+    int partition_k = 0;
+    if (format == CMI_FORMAT_CSR && cfg && cfg->kernel == CMI_CSR_STREAM_WAVE && cfg->rows_per_block < 0) {
+        want_partition = true;
+        partition_k = cfg->items_per_thread;
+        part_shape = *cfg;
+        part_shape.kernel = CMI_KERNEL_AUTO;
+        part_shape.rows_per_block = 0;
+        part_shape.items_per_thread = 0;
+        part_shape.block_size = 0;
+        cfg = &part_shape;
+        p->cfg_explicit = false;
+    }
     // HYB's table key is its ELL part's (the COO part looks its own shape up per call)
     select_config(format == CMI_FORMAT_HYB ? CMI_FORMAT_ELL : format, dtype, num_rows, num_cols, num_entries, cfg, &p->cfg);
     hipStream_t s = as_stream(stream);
@@ -145,6 +182,21 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
             // (profiles/r02_wave_shape_sweep.txt, r02_wave_ab.txt); below it, plain loads keep the matrix resident (tuning.hip)
             if (num_entries * (int64_t)(sizeof(int) + vbytes) > kInfinityCacheBytes + kInfinityCacheBytes / 4) p->cfg.nontemporal |= kPolLoadNT;
             p->cfg.nontemporal |= kPolStoreNT;
+        } else if (st == CMI_SUCCESS && auto_kernel && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1) {
+            const int k = wave_partition_k(num_rows, num_entries, p->prof, want_partition, partition_k);
+            if (want_partition && k == 0)
+                st = fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: wave tiles on a row partition need 2..10 entries per lane and the longest row <= 6.4 x that");
+            if (k > 0) st = wave_partition_build(p, index_array, k, s);
+            if (st == CMI_SUCCESS && p->wave_row_start) {
+                p->cfg.kernel = CMI_CSR_STREAM_WAVE;
+                p->cfg.block_size = 256;
+                p->cfg.rows_per_block = 0; // (the partition's: about Q / mean rows per wave)
+                p->cfg.items_per_thread = k;
+                p->cfg.threads_per_row = 0;
+                p->cfg.nontemporal &= ~kPolStrided;
+                if (num_entries * (int64_t)(sizeof(int) + vbytes) > kInfinityCacheBytes + kInfinityCacheBytes / 4) p->cfg.nontemporal |= kPolLoadNT;
+                p->cfg.nontemporal |= kPolStoreNT;
+            }
         }
     } else if (format == CMI_FORMAT_COO) {
         int sorted = 1, long_runs = 0;
@@ -259,6 +311,7 @@ CMI_API int cmi_plan_destroy(cmi_plan *plan)
     if (plan && plan->hyb_coo_plan) (void)cmi_plan_destroy(plan->hyb_coo_plan);
     if (plan && plan->coo_csr_plan) (void)cmi_plan_destroy(plan->coo_csr_plan);
     if (plan && plan->coo_offsets) (void)hipFree(plan->coo_offsets);
+    if (plan && plan->wave_row_start) (void)hipFree(plan->wave_row_start);
     if (plan && plan->csr16_base) (void)hipFree(plan->csr16_base);
     if (plan && plan->csr16_cols) (void)hipFree(plan->csr16_cols);
     delete plan;

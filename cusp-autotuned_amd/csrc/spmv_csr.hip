@@ -474,6 +474,98 @@ csr_wave_kernel(int64_t num_rows, const int *Ap /* not restrict: see the asm bel
 }
 
 // ---------------------------------------------------------------------------------------------
+// csr_wave on IRREGULAR short rows: a plan-built partition of the rows into wave tiles
+// ---------------------------------------------------------------------------------------------
+// Wave tile t owns the rows whose FIRST entry lies in [t Q, (t + 1) Q), Q = 64 K - longest row: its entries are at most 64 K (the
+// wave's request slots, filled to Q / 64 K >= 90 %), its rows about Q / mean <= 64 (K is chosen for that, plan.hip) -- more rows
+// than lanes (a stretch of very short or empty rows) take another turn of the row-sum loop.  The partition is one parallel pass
+// over the row offsets (wave_partition_kernel: row r opens every tile between its predecessor's and its own), 4 bytes per tile of
+// plan-owned memory.  Same body as csr_wave_kernel otherwise; same products, storage-order sums: bit-exact.
+__global__ void __launch_bounds__(256)
+wave_partition_kernel(int64_t num_rows, const int *__restrict__ Ap, int q, int64_t tiles, int32_t *__restrict__ start)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > num_rows) return;
+    const int64_t prev = r == 0 ? -1 : (int64_t)(Ap[r - 1] / q);
+    const int64_t mine = r == num_rows ? tiles : (int64_t)(Ap[r] / q); // (the sentinel row closes every remaining tile)
+    for (int64_t t = prev + 1; t <= mine; t++) start[t] = (int32_t)r;
+}
+
+int wave_partition_build(cmi_plan *p, const int *Ap, int k, hipStream_t s)
+{
+    const int64_t rows = p->rows, nnz = p->nnz;
+    const int q = kWave * k - (int)p->prof.max_len;
+    if (q < 1 || rows <= 0 || nnz <= 0) return CMI_SUCCESS;
+    const int64_t tiles = nnz / q + 1;
+    int32_t *start = nullptr;
+    hipError_t e = hipMalloc((void **)&start, (size_t)(tiles + 1) * sizeof(int32_t));
+    if (e != hipSuccess) return hip_fail(e, "cmi_plan_create: wave partition");
+    hipLaunchKernelGGL(wave_partition_kernel, dim3((unsigned)ceil_div(rows + 1, 256)), dim3(256), 0, s, rows, Ap, q, tiles, start);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s); // (the plan is complete when cmi_plan_create returns, like every other plan)
+    if (e != hipSuccess) { (void)hipFree(start); return hip_fail(e, "cmi_plan_create: wave partition"); }
+    p->wave_row_start = start;
+    p->wave_tiles = tiles;
+    p->wave_q = q;
+    return CMI_SUCCESS;
+}
+
+template <typename T, int K, int POL, bool DOT>
+__global__ void __launch_bounds__(256)
+csr_wavep_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, const int *Ap /* not restrict: see the asm below */,
+                 const int *__restrict__ Aj, const T *__restrict__ Ax, const T *__restrict__ x, T *__restrict__ y,
+                 int64_t num_tiles, int64_t tiles_per_xcd, int swizzle, int accumulate, const T *__restrict__ w,
+                 double *__restrict__ dot_partial)
+{
+    __shared__ T prod[4][kWave * K];
+    __shared__ double dot_slots[DOT ? 4 : 1];
+    constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
+    const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle);
+    if (tile >= num_tiles) return; // whole workgroup
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x & (kWave - 1);
+    const int64_t wt = tile * 4 + wave;
+    double d = 0.0;
+    if (wt < wave_tiles) {
+        const int rs = start[wt], re = start[wt + 1];
+        const int nr = re - rs;
+        if (nr > 0) { // (uniform per wave)
+            const int nz0 = Ap[rs], nz1 = Ap[re];
+            const int cnt = nz1 - nz0; // <= 64 K by construction
+            int a = Ap[rs + (lane < nr ? lane : nr)], b = Ap[rs + (lane + 1 < nr ? lane + 1 : nr)];
+            T *mine = prod[wave];
+            if (cnt > 0) {
+                int c[K];
+                T v[K], xv[K];
+#pragma unroll
+                for (int k = 0; k < K; k++) { const int i = k * kWave + lane; c[k] = ld<NT>(Aj + nz0 + (i < cnt ? i : 0)); }
+#pragma unroll
+                for (int k = 0; k < K; k++) { const int i = k * kWave + lane; v[k] = ld<NT>(Ax + nz0 + (i < cnt ? i : 0)); }
+                __builtin_amdgcn_sched_barrier(0); // every stream request is out before the first gather address is formed
+#pragma unroll
+                for (int k = 0; k < K; k++) asm volatile("" : "+v"(c[k]));
+#pragma unroll
+                for (int k = 0; k < K; k++) xv[k] = x[c[k]];
+                asm volatile("" : "+v"(a), "+v"(b)); // the row's two offsets were requested in front of the streams
+#pragma unroll
+                for (int k = 0; k < K; k++) mine[k * kWave + lane] = v[k] * xv[k];
+                __builtin_amdgcn_wave_barrier(); // (compiler only: the hardware runs a wave's LDS instructions in order)
+            }
+            for (int r = lane; r < nr; r += kWave) { // (one turn, except over a stretch of very short rows)
+                if (r >= kWave) { a = Ap[rs + r]; b = Ap[rs + r + 1]; }
+                T sum = accumulate ? y[rs + r] : T(0);
+                for (int j = a; j < b; j++) sum = sum + mine[j - nz0];
+                st<NTS>(y + rs + r, sum);
+                if constexpr (DOT) d += (double)sum * (double)w[rs + r];
+            }
+        }
+    }
+    if constexpr (DOT) {
+        tile_dot_store(d, dot_slots, dot_partial + tile);
+        if (tile == 0 && threadIdx.x == 0) reset_fold_state(dot_partial);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // csr_stream_pipe: persistent, software-pipelined csr_stream
 // ---------------------------------------------------------------------------------------------
 // The plain csr_stream workgroup pays three DEPENDENT global round trips per tile (row pointers ->
@@ -1045,6 +1137,37 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     }
     case CMI_CSR_STREAM_WAVE: {
         const int K = c.items_per_thread;
+        if (plan && plan->wave_row_start) { // irregular short rows: the plan's partition (above)
+            if (K < 2 || K > kWaveTileMaxK) return fail(CMI_ERROR_NOT_SUPPORTED, "csr_wave: items_per_thread (entries per lane) must be 2..10");
+            const int64_t tiles = ceil_div(plan->wave_tiles, (int64_t)4);
+            const int64_t tpx = ceil_div(tiles, kXcds);
+            int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
+            if (w && dot_partial) swz = dot_swizzle(swz, plan, swz);
+            const int64_t grid64 = padded_grid(tiles, swz);
+            if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "csr_wave: grid too large");
+            const bool dot = w && dot_partial && tiles <= kPartialCapacity;
+            with_policy(pol, [&](auto P) {
+                constexpr int POL = decltype(P)::value;
+                auto go = [&](auto KK) {
+                    constexpr int KC = decltype(KK)::value;
+                    if (dot) hipLaunchKernelGGL((csr_wavep_kernel<T, KC, POL, true>), dim3((unsigned)grid64), dim3(256), 0, s, plan->wave_row_start, plan->wave_tiles, Ap, Aj, Ax, x, y, tiles, tpx, swz, accumulate, w, dot_partial);
+                    else     hipLaunchKernelGGL((csr_wavep_kernel<T, KC, POL, false>), dim3((unsigned)grid64), dim3(256), 0, s, plan->wave_row_start, plan->wave_tiles, Ap, Aj, Ax, x, y, tiles, tpx, swz, accumulate, (const T *)nullptr, (double *)nullptr);
+                };
+                switch (K) {
+                case 2: go(std::integral_constant<int, 2>()); break;
+                case 3: go(std::integral_constant<int, 3>()); break;
+                case 4: go(std::integral_constant<int, 4>()); break;
+                case 5: go(std::integral_constant<int, 5>()); break;
+                case 6: go(std::integral_constant<int, 6>()); break;
+                case 7: go(std::integral_constant<int, 7>()); break;
+                case 8: go(std::integral_constant<int, 8>()); break;
+                case 9: go(std::integral_constant<int, 9>()); break;
+                default: go(std::integral_constant<int, 10>()); break;
+                }
+            });
+            if (dot && dot_partials) *dot_partials = (int)tiles;
+            break;
+        }
         const int waves = block / kWave;
         if (K < 2 || K > kWaveTileMaxK) return fail(CMI_ERROR_NOT_SUPPORTED, "csr_wave: items_per_thread (entries per lane) must be 2..10");
         if (c.rows_per_block < waves || c.rows_per_block % waves != 0 || c.rows_per_block / waves > kWave)

@@ -450,15 +450,58 @@ def test_csr_plan_selects_wave_tiles_for_stencil_rows(cmi, torch_cuda, orc, tag)
         y = torch.full((N,), 9.0, dtype=tdt, device="cuda")
         cmi.spmv_coo_plan(cplan, dev(Ai, torch), dAj, dAx, dx, y)
         assert np.array_equal(y.cpu().numpy(), want), (m, n)
-    # irregular rows of the same mean: csr_stream
-    lens = rng.integers(0, 11, size=5000)
-    Ap = np.r_[0, np.cumsum(lens)].astype(np.int32)
-    plan = cmi.Plan(cmi.FORMAT_CSR, tdt, 5000, 5000, int(Ap[-1]), dev(Ap, torch))
-    assert plan.config().kernel == cmi.CSR_STREAM
-    # rows longer than 10: csr_stream
+    # irregular short rows: csr_stream by default; ASKED FOR (kernel CMI_CSR_STREAM_WAVE, rows_per_block < 0) the same kernel runs on a
+    # partition of the rows the plan builds (wave tile = the rows whose first entry falls into one quantum of 64 K - longest entries;
+    # rows_per_block then reads 0) -- with empty rows, a stretch of 300 empty rows (more rows than lanes in one tile: another turn
+    # of the row-sum loop) and a last row that ends exactly at the arrays' end
+    for seed, rows, hi in ((1, 5000, 11), (2, 20000, 7), (3, 4096, 16), (4, 70000, 9)):
+        r2 = np.random.default_rng(seed)
+        lens = r2.integers(0, hi, size=rows)
+        lens[1000:1300] = 0
+        lens[-1] = hi - 1
+        cols = rows + 17
+        Ap = np.r_[0, np.cumsum(lens)].astype(np.int32)
+        nnz = int(Ap[-1])
+        Aj = r2.integers(0, cols, size=nnz).astype(np.int32)  # (unsorted, duplicates allowed)
+        Ax = r2.standard_normal(nnz).astype(dtype)
+        x = r2.standard_normal(cols).astype(dtype)
+        y0 = r2.standard_normal(rows).astype(dtype)
+        want, want_acc = orc.spmv_csr(Ap, Aj, Ax, x), orc.spmv_csr(Ap, Aj, Ax, x, y0)
+        dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+        assert cmi.Plan(cmi.FORMAT_CSR, tdt, rows, cols, nnz, dAp).config().kernel == cmi.CSR_STREAM
+        mean, longest = nnz / rows, int(lens.max())
+        k = max(2, int(np.floor(mean + longest / 64.0)))
+        assert 2 <= k <= 10 and longest <= 6.4 * k
+        plan = cmi.Plan(cmi.FORMAT_CSR, tdt, rows, cols, nnz, dAp, cmi.Config(kernel=cmi.CSR_STREAM_WAVE, rows_per_block=-1))
+        c = plan.config()
+        assert (c.kernel, c.rows_per_block, c.items_per_thread) == (cmi.CSR_STREAM_WAVE, 0, k), (seed, c)
+        assert plan.info()["storage_order_sums"] is True
+        if seed == 2:  # entries per lane given by the caller
+            p8 = cmi.Plan(cmi.FORMAT_CSR, tdt, rows, cols, nnz, dAp, cmi.Config(kernel=cmi.CSR_STREAM_WAVE, rows_per_block=-1, items_per_thread=8))
+            assert p8.config().items_per_thread == 8
+            y = torch.full((rows,), 9.0, dtype=tdt, device="cuda")
+            cmi.spmv_csr_plan(p8, dAp, dAj, dAx, dx, y)
+            assert np.array_equal(y.cpu().numpy(), want), "k 8"
+        y = torch.full((rows,), 9.0, dtype=tdt, device="cuda")
+        cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
+        assert np.array_equal(y.cpu().numpy(), want), seed
+        y = dev(y0, torch)
+        cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y, accumulate=True)
+        assert np.array_equal(y.cpu().numpy(), want_acc), seed
+        w = r2.standard_normal(rows).astype(dtype)
+        res = torch.zeros(1, dtype=torch.float64, device="cuda")
+        y = torch.zeros(rows, dtype=tdt, device="cuda")
+        cmi.spmv_csr_dot(rows, cols, dAp, dAj, dAx, dx, y, dev(w, torch), res, cmi.blas_workspace(), plan=plan)
+        assert np.array_equal(y.cpu().numpy(), want), seed
+        ref = float(np.dot(want.astype(np.float64), w.astype(np.float64)))
+        assert abs(float(res) - ref) <= 1e-12 * float(np.abs(want.astype(np.float64) * w).sum()) + (0 if tag == "f64" else 1e-6 * abs(ref)), seed
+        del plan
+    # rows longer than 10: csr_stream; a partition cannot be asked for either where the rows are too long for it
     lens = np.full(4000, 11)
     Ap = np.r_[0, np.cumsum(lens)].astype(np.int32)
     assert cmi.Plan(cmi.FORMAT_CSR, tdt, 4000, 4000, int(Ap[-1]), dev(Ap, torch)).config().kernel == cmi.CSR_STREAM
+    with pytest.raises(cmi.CmiError):
+        cmi.Plan(cmi.FORMAT_CSR, tdt, 4000, 4000, int(Ap[-1]), dev(Ap, torch), cmi.Config(kernel=cmi.CSR_STREAM_WAVE, rows_per_block=-1))
     if tag == "f64":
         import subprocess, sys
         code = ("import numpy as np, torch, cusp_autotuned_amd as cmi\n"
