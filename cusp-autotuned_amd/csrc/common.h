@@ -302,7 +302,7 @@ struct cmi_plan {
     // CSR with cfg.kernel == CMI_CSR_STREAM_C16 (spmv_csr16.hip): per-tile smallest column and the 16-bit offsets from it
     int32_t *csr16_base = nullptr;  // device, one per tile of cfg.rows_per_block rows
     uint16_t *csr16_cols = nullptr; // device, nnz (+ padding) entries
-    int32_t *wave_row_start = nullptr; // device, wave_tiles + 1 entries: CMI_CSR_STREAM_WAVE on IRREGULAR short rows -- wave tile t owns the rows whose first
+    int32_t *wave_row_start = nullptr; // device, 2 (wave_tiles + 1) entries, (first row, first entry) per tile: CMI_CSR_STREAM_WAVE on IRREGULAR short rows -- wave tile t owns the rows whose first
                                        // entry lies in [t wave_q, (t + 1) wave_q) (plan.hip wave_partition); null: 64 rows per wave
     int64_t wave_tiles = 0;
     int wave_q = 0;

@@ -53,8 +53,8 @@ static bool wave_tiles_fit(int64_t rows, int64_t nnz, int64_t max_len)
 // ... and csr_wave on a plan-built partition (spmv_csr.hip wave_partition_build) for IRREGULAR short rows: K entries per lane with
 // K = floor(mean + longest / 64), so that a wave tile of Q = 64 K - longest entries holds about Q / mean <= 64 rows; the longest row
 // small enough for the tiles to fill 90 % of the wave's request slots.  OPT-IN: asked for per plan (cfg.kernel = CMI_CSR_STREAM_WAVE
-// with rows_per_block < 0) -- measured against csr_stream it wins on FEM-like rows (thermal2-like 0.98 / 0.93 of its time, f64 / f32)
-// and loses on large matrices with scattered columns (1.04-1.34x; profiles/r02_wavep_ab.txt), so no plan selects it by itself
+// with rows_per_block < 0) -- measured against csr_stream it wins on FEM-like rows (thermal2-like 0.94 / 0.90 of its time, f64 / f32)
+// and loses on large matrices with scattered columns (1.02-1.30x; profiles/r02_wavep_ab.txt), so no plan selects it by itself
 // ($CMI_CSR_WAVE=2: every AUTO plan whose rows qualify does -- measurements).
 static int wave_partition_k(int64_t rows, int64_t nnz, const row_profile &prof, bool asked, int asked_k)
 {

@@ -479,7 +479,7 @@ csr_wave_kernel(int64_t num_rows, const int *Ap /* not restrict: see the asm bel
 // Wave tile t owns the rows whose FIRST entry lies in [t Q, (t + 1) Q), Q = 64 K - longest row: its entries are at most 64 K (the
 // wave's request slots, filled to Q / 64 K >= 90 %), its rows about Q / mean <= 64 (K is chosen for that, plan.hip) -- more rows
 // than lanes (a stretch of very short or empty rows) take another turn of the row-sum loop.  The partition is one parallel pass
-// over the row offsets (wave_partition_kernel: row r opens every tile between its predecessor's and its own), 4 bytes per tile of
+// over the row offsets (wave_partition_kernel: row r opens every tile between its predecessor's and its own), 8 bytes per tile of
 // plan-owned memory.  Same body as csr_wave_kernel otherwise; same products, storage-order sums: bit-exact.
 __global__ void __launch_bounds__(256)
 wave_partition_kernel(int64_t num_rows, const int *__restrict__ Ap, int q, int64_t tiles, int32_t *__restrict__ start)
@@ -487,8 +487,10 @@ wave_partition_kernel(int64_t num_rows, const int *__restrict__ Ap, int q, int64
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > num_rows) return;
     const int64_t prev = r == 0 ? -1 : (int64_t)(Ap[r - 1] / q);
-    const int64_t mine = r == num_rows ? tiles : (int64_t)(Ap[r] / q); // (the sentinel row closes every remaining tile)
-    for (int64_t t = prev + 1; t <= mine; t++) start[t] = (int32_t)r;
+    const int e = Ap[r];
+    const int64_t mine = r == num_rows ? tiles : (int64_t)(e / q); // (the sentinel row closes every remaining tile)
+    // (first row, first entry) per tile, interleaved: a wave reads its tile's bounds and its successor's with ONE 16-byte scalar load
+    for (int64_t t = prev + 1; t <= mine; t++) { start[2 * t] = (int32_t)r; start[2 * t + 1] = e; }
 }
 
 int wave_partition_build(cmi_plan *p, const int *Ap, int k, hipStream_t s)
@@ -498,7 +500,7 @@ int wave_partition_build(cmi_plan *p, const int *Ap, int k, hipStream_t s)
     if (q < 1 || rows <= 0 || nnz <= 0) return CMI_SUCCESS;
     const int64_t tiles = nnz / q + 1;
     int32_t *start = nullptr;
-    hipError_t e = hipMalloc((void **)&start, (size_t)(tiles + 1) * sizeof(int32_t));
+    hipError_t e = hipMalloc((void **)&start, (size_t)(tiles + 1) * 2 * sizeof(int32_t));
     if (e != hipSuccess) return hip_fail(e, "cmi_plan_create: wave partition");
     hipLaunchKernelGGL(wave_partition_kernel, dim3((unsigned)ceil_div(rows + 1, 256)), dim3(256), 0, s, rows, Ap, q, tiles, start);
     e = hipGetLastError();
@@ -526,12 +528,13 @@ csr_wavep_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, const in
     const int64_t wt = tile * 4 + wave;
     double d = 0.0;
     if (wt < wave_tiles) {
-        const int rs = start[wt], re = start[wt + 1];
+        const int2v lo = *reinterpret_cast<const int2v *>(start + 2 * wt), hi = *reinterpret_cast<const int2v *>(start + 2 * wt + 2);
+        const int rs = lo.x, nz0 = lo.y, re = hi.x, nz1 = hi.y; // {first row, first entry} of this tile and of the next: one scalar hop
         const int nr = re - rs;
         if (nr > 0) { // (uniform per wave)
-            const int nz0 = Ap[rs], nz1 = Ap[re];
             const int cnt = nz1 - nz0; // <= 64 K by construction
-            int a = Ap[rs + (lane < nr ? lane : nr)], b = Ap[rs + (lane + 1 < nr ? lane + 1 : nr)];
+            const int first_turn_end = Ap[rs + (nr < kWave ? nr : kWave)]; // (scalar) where the 64th row of the tile ends
+            int a = Ap[rs + (lane < nr ? lane : nr)], b = 0;
             T *mine = prod[wave];
             if (cnt > 0) {
                 int c[K];
@@ -545,11 +548,12 @@ csr_wavep_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, const in
                 for (int k = 0; k < K; k++) asm volatile("" : "+v"(c[k]));
 #pragma unroll
                 for (int k = 0; k < K; k++) xv[k] = x[c[k]];
-                asm volatile("" : "+v"(a), "+v"(b)); // the row's two offsets were requested in front of the streams
+                asm volatile("" : "+v"(a)); // the row offset was requested in front of the streams
 #pragma unroll
                 for (int k = 0; k < K; k++) mine[k * kWave + lane] = v[k] * xv[k];
                 __builtin_amdgcn_wave_barrier(); // (compiler only: the hardware runs a wave's LDS instructions in order)
             }
+            b = __builtin_amdgcn_update_dpp(first_turn_end, a, 0x130 /* wave_shl:1: the next lane's start; lane 63 keeps the 64th row's end */, 0xf, 0xf, false);
             for (int r = lane; r < nr; r += kWave) { // (one turn, except over a stretch of very short rows)
                 if (r >= kWave) { a = Ap[rs + r]; b = Ap[rs + r + 1]; }
                 T sum = accumulate ? y[rs + r] : T(0);

@@ -157,10 +157,10 @@ typedef enum cmi_kernel {
                                slow).  Bit-exact.  A CSR plan selects it by itself when the longest row is <= 10 entries and the
                                mean within 7 % of it ($CMI_CSR_WAVE=0: never); never selected without a plan.
                                OPT-IN for irregular short rows: a plan made with this kernel and rows_per_block < 0 builds (and owns,
-                               4 bytes per tile) a partition of the rows into wave tiles -- tile t = the rows whose first entry lies in
+                               8 bytes per tile) a partition of the rows into wave tiles -- tile t = the rows whose first entry lies in
                                [t Q, (t + 1) Q), Q = 64 x items_per_thread - longest row -- and runs the same body on it
                                (items_per_thread 0: floor(mean + longest / 64)); cmi_plan_config then reads rows_per_block 0.  Faster than
-                               csr_stream on FEM-like rows (thermal2-like: 0.93-0.98 of its time), slower on large matrices with
+                               csr_stream on FEM-like rows (thermal2-like: 0.90-0.94 of its time), slower on large matrices with
                                scattered columns: no plan selects it by itself                                         */
     /* ELL */
     CMI_ELL_ROW = 10, /* one lane per row            (ref: ell_spmv.h:55-93); threads_per_row 2,4,8,16: that many
