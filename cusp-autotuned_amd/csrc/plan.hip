@@ -194,8 +194,10 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
                 p->cfg.items_per_thread = k;
                 p->cfg.threads_per_row = 0;
                 p->cfg.nontemporal &= ~kPolStrided;
-                if (num_entries * (int64_t)(sizeof(int) + vbytes) > kInfinityCacheBytes + kInfinityCacheBytes / 4) p->cfg.nontemporal |= kPolLoadNT;
-                p->cfg.nontemporal |= kPolStoreNT;
+                if (!(want_partition && part_shape.nontemporal)) { // (a caller's policy bits are kept as given)
+                    if (num_entries * (int64_t)(sizeof(int) + vbytes) > kInfinityCacheBytes + kInfinityCacheBytes / 4) p->cfg.nontemporal |= kPolLoadNT;
+                    p->cfg.nontemporal |= kPolStoreNT;
+                }
             }
         }
     } else if (format == CMI_FORMAT_COO) {
