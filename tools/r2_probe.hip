@@ -391,6 +391,53 @@ csrw_kernel(int64_t N, const int *Ap, const int *__restrict__ Aj, const double *
     }
 }
 
+// csrw2: csrw with TWO rows per lane (128 rows per wave, 2 K entries per lane): the wave's fixed costs over twice the entries
+template <int K, bool NT>
+__global__ void __launch_bounds__(256)
+csrw2_kernel(int64_t N, const int *Ap, const int *__restrict__ Aj, const double *__restrict__ Ax,
+             const double *__restrict__ x, double *__restrict__ y, int64_t tiles, int64_t tpx, int swz)
+{
+    __shared__ double prod[4][128 * K];
+    const int64_t tile = tile_of_block(blockIdx.x, tpx, swz);
+    if (tile >= tiles) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int64_t r0 = (tile * 4 + wave) * (int64_t)128;
+    if (r0 >= N) return;
+    const int nr = (int)((N - r0) < 128 ? (N - r0) : 128);
+    const int nz0 = Ap[r0], nz1 = Ap[r0 + nr];
+    int a0 = Ap[r0 + (lane < nr ? lane : nr)], a1 = Ap[r0 + (lane + 64 < nr ? lane + 64 : nr)];
+    const int mid = Ap[r0 + (64 < nr ? 64 : nr)];
+    const int cnt = nz1 - nz0;
+    int c[2 * K];
+    double v[2 * K], xv[2 * K];
+#pragma unroll
+    for (int k = 0; k < 2 * K; k++) { const int i = k * 64 + lane; c[k] = ld<NT>(Aj + nz0 + (i < cnt ? i : 0)); }
+#pragma unroll
+    for (int k = 0; k < 2 * K; k++) { const int i = k * 64 + lane; v[k] = ld<NT>(Ax + nz0 + (i < cnt ? i : 0)); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 2 * K; k++) asm volatile("" : "+v"(c[k]));
+#pragma unroll
+    for (int k = 0; k < 2 * K; k++) xv[k] = x[c[k]];
+    asm volatile("" : "+v"(a0), "+v"(a1));
+    const int b0 = __builtin_amdgcn_update_dpp(mid, a0, 0x130, 0xf, 0xf, false);
+    const int b1 = __builtin_amdgcn_update_dpp(nz1, a1, 0x130, 0xf, 0xf, false);
+    double *mine = prod[wave];
+#pragma unroll
+    for (int k = 0; k < 2 * K; k++) mine[k * 64 + lane] = v[k] * xv[k];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < nr) {
+        double s = 0.0;
+        for (int j = a0; j < b0; j++) s = s + mine[j - nz0];
+        __builtin_nontemporal_store(s, y + r0 + lane);
+    }
+    if (lane + 64 < nr) {
+        double s = 0.0;
+        for (int j = a1; j < b1; j++) s = s + mine[j - nz0];
+        __builtin_nontemporal_store(s, y + r0 + 64 + lane);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // diax: DIA, two rows per lane, optional LDS window for the diagonals with |offset| <= H
 // ------------------------------------------------------------------------------------------------------------
@@ -726,6 +773,13 @@ int main(int argc, char **argv)
     }
         CSRW1(4, 51) CSRW1(5, 64)
 #undef CSRW1
+    }
+    for (int swz : {16, 32, 64}) { // csrw2: two rows per lane
+        char nm[96];
+        const int64_t tiles = (N + 511) / 512, tpx = (tiles + 7) / 8;
+        const int64_t grid = ((tiles + 8 * swz - 1) / (8 * swz)) * 8 * swz;
+        snprintf(nm, sizeof nm, "csrw2 k 5 rows/wave 128 swz %d", swz);
+        run(nm, B_csr, true, [&, swz] { hipLaunchKernelGGL((csrw2_kernel<5, true>), dim3((unsigned)grid), dim3(256), 0, 0, N, Ap, Aj, Ax, x, y, tiles, tpx, swz); });
     }
     // ---- ell (library kernel, launch shapes x XCD dealing) -----------------------------------------------------
     {
