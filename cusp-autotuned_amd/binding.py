@@ -14,7 +14,7 @@ FORMAT_CSR, FORMAT_ELL, FORMAT_DIA, FORMAT_COO, FORMAT_HYB = 0, 1, 2, 3, 4
 TABLE_COO_SORTED = 5  # tuning-table key only: the launch shape of a COO multiply whose plan found the entries row-sorted
 F64, F32 = 0, 1
 KERNEL_AUTO = 0
-CSR_SCALAR, CSR_VECTOR, CSR_STREAM, CSR_STREAM_PIPE, CSR_BALANCED, CSR_STREAM_C16, CSR_STREAM_WAVE = 1, 2, 3, 4, 5, 6, 7
+CSR_SCALAR, CSR_VECTOR, CSR_STREAM, CSR_STREAM_PIPE, CSR_BALANCED, CSR_STREAM_C16, CSR_STREAM_WAVE, CSR_STREAM_WAVEV = 1, 2, 3, 4, 5, 6, 7, 8
 ELL_ROW, DIA_ROW, COO_SEGMENTED, COO_LANE4, COO_TILE = 10, 20, 30, 31, 32
 
 
@@ -154,6 +154,7 @@ def _declare(L):
     L.cmi_plan_create.argtypes = [c_int, c_int, i64, i64, i64, vp, cfgp, vp, POINTER(c_void_p)]
     L.cmi_plan_destroy.argtypes = [vp]
     L.cmi_plan_config.argtypes = [vp, cfgp]
+    L.cmi_plan_validate.argtypes = [vp, vp, vp, vp, POINTER(c_int)]
     L.cmi_plan_info.argtypes = [vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int), POINTER(c_int)]
     L.cmi_plan_create_csr.argtypes = [c_int, i64, i64, i64, vp, vp, cfgp, vp, POINTER(c_void_p)]
     L.cmi_set_index_compression.argtypes = [c_int]
@@ -309,6 +310,13 @@ class Plan:
     @property
     def handle(self):
         return self._h
+
+    def validate(self, index_array, column_indices=None, stream=None):
+        """cmi_plan_validate: True while the arrays the plan was made from still hold what they held then (one streaming pass
+        over them + a stream synchronisation); False after an in-place edit -- make a new plan."""
+        ok = c_int(-1)
+        check(lib().cmi_plan_validate(self._h, _ptr(index_array), _ptr(column_indices), _stream(stream), byref(ok)))
+        return bool(ok.value)
 
     def hyb_launches(self):
         """1 = the one-launch HYB kernel (or an empty COO part), 2 = ELL kernel + COO kernel."""

@@ -124,9 +124,35 @@ dot_partial_kernel(int64_t n, const T *__restrict__ x, const T *__restrict__ y, 
 // zeroes it as well, so an uninitialised workspace is fine.
 constexpr int kFoldDirect = 2048; // up to here one workgroup folds the list directly
 
+// Hand-off of one chunk sum to whichever workgroup arrives last (thread 0 of every folding workgroup calls it; returns true in
+// the last arriver).  Default: the memory model's own recipe -- payload store, agent-scope RELEASE fence (buffer_wbl2 sc1, waited
+// for: the inline-asm wait is the one the compiler may not drop, MI355X_MICROARCH.md "Compiler hazard"), relaxed ticket add; the
+// last arriver follows its add with an agent-scope ACQUIRE fence (buffer_inv sc1, waited for before the workgroup barrier that
+// lets its other waves read).  `relaxed` != 0 ($CMI_FOLD_RELAXED=1): the fence-free form of round 2 -- write-through (sc1) payload
+// store drained by s_waitcnt vmcnt(0), relaxed ticket add, sc1 loads by the last arriver -- a form the guide lists as measured-valid
+// on gfx950 (inter-workgroup visibility table, first row) but which the memory model does not order; kept for measurements.
+__device__ __forceinline__ bool fold_handoff(double *folded_slot, double s, unsigned int *ticket, unsigned int groups, int relaxed)
+{
+    __hip_atomic_store(folded_slot, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!relaxed) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = t == groups - 1;
+    if (last && !relaxed) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    return last;
+}
+static int fold_relaxed()
+{
+    static const int env = [] { const char *e = std::getenv("CMI_FOLD_RELAXED"); return (e && e[0] == '1') ? 1 : 0; }();
+    return env;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kBlasBlock)
-dot_fold_final_kernel(int npartial, double *__restrict__ workspace, T *__restrict__ result, double *__restrict__ mirror, int take_sqrt)
+dot_fold_final_kernel(int npartial, double *__restrict__ workspace, T *__restrict__ result, double *__restrict__ mirror, int take_sqrt, int relaxed)
 {
     __shared__ double slots[kBlasBlock / kWave];
     __shared__ int is_last;
@@ -147,19 +173,7 @@ dot_fold_final_kernel(int npartial, double *__restrict__ workspace, T *__restric
 #pragma unroll
     for (int k = 0; k < 4; k++) acc += v[k];
     double s = block_sum(acc, slots);
-    if (threadIdx.x == 0) {
-        // Hand-off of the chunk sums to whichever workgroup arrives last, WITHOUT agent-scope fences (a __threadfence() pair
-        // is buffer_wbl2 + buffer_inv: ~3.5 us each, most of this kernel's 5 us).  The form MI355X_MICROARCH.md lists as
-        // measured-valid (inter-workgroup visibility table, first row): the payload is stored write-through (relaxed
-        // agent-scope atomic store = global_store ... sc1), the storing wave drains it (s_waitcnt vmcnt(0): inline asm, the
-        // compiler may not drop it), ONE lane then adds to the unsharded counter (agent-scope atomic), the workgroup whose
-        // add returned the last ticket reads the payload with sc1 loads (relaxed agent-scope atomic loads) -- its other waves
-        // behind the barrier below.  The grid is at most 64 workgroups: one per CU, the measured configuration.
-        __hip_atomic_store(folded + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int t = __hip_atomic_fetch_add(ticket_of(workspace), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = (t == gridDim.x - 1);
-    }
+    if (threadIdx.x == 0) is_last = fold_handoff(folded + blockIdx.x, s, ticket_of(workspace), gridDim.x, relaxed); // (at most 64 workgroups)
     __syncthreads();
     if (!is_last) return;
     acc = 0.0;
@@ -196,7 +210,7 @@ static void reduce_partials(int npartial, double *workspace, T *result, int take
 {
     if (npartial > kFoldDirect) {
         const int groups = (npartial + kFoldChunk - 1) / kFoldChunk;
-        hipLaunchKernelGGL((dot_fold_final_kernel<T>), dim3(groups), dim3(kBlasBlock), 0, s, npartial, workspace, result, mirror, take_sqrt);
+        hipLaunchKernelGGL((dot_fold_final_kernel<T>), dim3(groups), dim3(kBlasBlock), 0, s, npartial, workspace, result, mirror, take_sqrt, fold_relaxed());
     } else {
         hipLaunchKernelGGL((dot_final_mirror_kernel<T>), dim3(1), dim3(kBlasBlock), 0, s, npartial, (const double *)workspace, result, mirror, take_sqrt);
     }
@@ -332,11 +346,14 @@ cg_direction_kernel(int64_t n, const double *__restrict__ rr_new, const double *
 // IS the flag; "pending" is a NaN payload no sum produces).  Every workgroup requests its vectors first, then one lane polls
 // its slot (sc1 load, sleeping in between; the producer kernel left the slots pending) -- for all but the first ~2000
 // resident workgroups the first poll succeeds, and it replaces the plain load of the scalar the old kernels did anyway.
-// The spin is bounded: if the value never shows up the kernel goes on with a NaN (wrong result, no hang).
+// The spin is bounded: if the value never shows up (the folding workgroups were not resident first, or a second stream used the SAME
+// workspace -- one workspace per stream) the workgroup goes on with the "pending" NaN: r / x / p are poisoned, the next <r, r> is NaN and
+// so is the host mirror -- cusp::krylov::cg's fold-ahead path throws on a NaN residual instead of iterating on (no hang, no silent
+// wrong answer).
 constexpr int kFoldSpinLimit = 1 << 15; // x ~0.5 us of s_sleep
 
 __device__ __forceinline__ double fold_ahead(int npartial, double *area, double *result_out, double *mirror, double *slots_lds,
-                                             double *value_lds)
+                                             double *value_lds, int relaxed)
 {
     const int groups = npartial <= kFoldDirect ? 1 : (npartial + kFoldChunk - 1) / kFoldChunk;
     double *slots = slots_of(area);
@@ -362,12 +379,7 @@ __device__ __forceinline__ double fold_ahead(int npartial, double *area, double 
         double s = block_sum(acc, slots_lds);
         if (groups > 1) {
             __shared__ int is_last;
-            if (threadIdx.x == 0) {
-                __hip_atomic_store(folded + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const unsigned int t = __hip_atomic_fetch_add(ticket_of(area), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                is_last = (t == (unsigned)groups - 1);
-            }
+            if (threadIdx.x == 0) is_last = fold_handoff(folded + blockIdx.x, s, ticket_of(area), (unsigned)groups, relaxed);
             __syncthreads();
             last = is_last != 0;
             if (last) {
@@ -408,7 +420,7 @@ __device__ __forceinline__ double fold_ahead(int npartial, double *area, double 
 template <typename T>
 __global__ void __launch_bounds__(kBlasBlock)
 cg_update_fold_kernel(int64_t n, const double *__restrict__ rz, int npartial_in, double *__restrict__ area_in, double *__restrict__ yp_out,
-                      const T *__restrict__ y, T *__restrict__ r, double *__restrict__ area_out, int vec, int pol)
+                      const T *__restrict__ y, T *__restrict__ r, double *__restrict__ area_out, int vec, int pol, int relaxed)
 {
     typedef typename vec16<T>::type V;
     constexpr int W = vec16<T>::n;
@@ -422,7 +434,7 @@ cg_update_fold_kernel(int64_t n, const double *__restrict__ rz, int npartial_in,
     const bool first = vec && t < nv;
     if (first) { y0 = reinterpret_cast<const V *>(y)[t]; r0 = reinterpret_cast<V *>(r)[t]; }
     const double rzv = *rz;
-    const double ypv = fold_ahead(npartial_in, area_in, yp_out, nullptr, slots, &value);
+    const double ypv = fold_ahead(npartial_in, area_in, yp_out, nullptr, slots, &value, relaxed);
     const T alpha = (T)(rzv / ypv);
     double acc = 0.0;
     if (vec) {
@@ -460,7 +472,7 @@ template <typename T>
 __global__ void __launch_bounds__(kBlasBlock)
 cg_direction_fold_kernel(int64_t n, int npartial_in, double *__restrict__ area_in, double *__restrict__ rr_new_out, double *__restrict__ mirror,
                          const double *__restrict__ rr_old, const double *__restrict__ yp, const T *__restrict__ r, T *__restrict__ p,
-                         T *__restrict__ x, int vec, int pol)
+                         T *__restrict__ x, int vec, int pol, int relaxed)
 {
     typedef typename vec16<T>::type V;
     constexpr int W = vec16<T>::n;
@@ -473,7 +485,7 @@ cg_direction_fold_kernel(int64_t n, int npartial_in, double *__restrict__ area_i
     const bool first = vec && t < nv;
     if (first) { r0 = reinterpret_cast<const V *>(r)[t]; p0 = reinterpret_cast<V *>(p)[t]; x0 = reinterpret_cast<V *>(x)[t]; }
     const double rro = *rr_old, ypv = *yp;
-    const double rrn = fold_ahead(npartial_in, area_in, rr_new_out, mirror, slots, &value);
+    const double rrn = fold_ahead(npartial_in, area_in, rr_new_out, mirror, slots, &value, relaxed);
     const T alpha = (T)(rro / ypv);
     const T beta = (T)(rrn / rro);
     if (vec) {
@@ -633,7 +645,7 @@ int cg_update_fold_impl(int64_t n, const double *rz_dev, double *yp_dev, int npa
     const int vec = aligned16(y) && aligned16(r);
     double *area_in = (double *)workspace, *area_out = (double *)workspace + kFoldArea;
     hipLaunchKernelGGL((cg_update_fold_kernel<T>), dim3(grid), dim3(kBlasBlock), 0, as_stream(stream), n, rz_dev, npartials_yp, area_in, yp_dev,
-                       y, r, area_out, vec, cg_store_policy());
+                       y, r, area_out, vec, cg_store_policy(), fold_relaxed());
     CMI_LAUNCH_CHECK("cg_update_fold");
     *npartials_rr = grid;
     return CMI_SUCCESS;
@@ -653,7 +665,7 @@ int cg_direction_fold_impl(int64_t n, double *rr_new_dev, double *rr_host_mirror
     const int vec = aligned16(r) && aligned16(p) && aligned16(x);
     double *area_in = (double *)workspace + kFoldArea;
     hipLaunchKernelGGL((cg_direction_fold_kernel<T>), dim3(grid), dim3(kBlasBlock), 0, as_stream(stream), n, npartials_rr, area_in, rr_new_dev,
-                       rr_host_mirror, rr_old_dev, yp_dev, r, p, x, vec, cg_store_policy());
+                       rr_host_mirror, rr_old_dev, yp_dev, r, p, x, vec, cg_store_policy(), fold_relaxed());
     CMI_LAUNCH_CHECK("cg_direction_x_fold");
     return CMI_SUCCESS;
 }

@@ -56,7 +56,7 @@ void select_config(int format, int dtype, int64_t num_rows, int64_t num_cols, in
 
 // row-length profile of a CSR matrix (spmv_csr.hip): longest row, entries sitting in rows of kLongRowMin or more
 struct row_profile { int64_t max_len = -1, in_long = 0; }; // max_len < 0: not measured
-int measure_row_lengths(int64_t rows, const int *Ap, hipStream_t s, int64_t *max_len, int64_t *entries_in_long_rows);
+int measure_row_lengths(int64_t rows, const int *Ap, hipStream_t s, int64_t *max_len, int64_t *entries_in_long_rows, int64_t *ends = nullptr); // ends: {Ap[0], Ap[rows]}
 bool prefers_balanced(int64_t rows, int64_t nnz, const row_profile &pr, size_t value_bytes, bool strict_order);
 // are the row indices of a COO matrix non-decreasing and inside [0, rows)?  (spmv_coo_hyb.hip; synchronises the stream)
 int coo_rows_sorted(int64_t rows, int64_t nnz, const int *Ai, hipStream_t s, int *sorted, int *long_runs = nullptr); // long_runs: a row of > 1024 entries
@@ -306,6 +306,10 @@ struct cmi_plan {
                                        // entry lies in [t wave_q, (t + 1) wave_q) (plan.hip wave_partition); null: 64 rows per wave
     int64_t wave_tiles = 0;
     int wave_q = 0;
+    // order-sensitive 64-bit checksums of the arrays the plan was made from (cmi_plan_validate): the index array (CSR row offsets, COO /
+    // HYB-COO row indices) and -- when the plan owns data derived from them (the 16-bit copy) -- the CSR column indices
+    uint64_t fp_index = 0, fp_columns = 0;
+    bool has_fp_index = false, has_fp_columns = false;
     int csr16_wave_k = 0;           // > 0: the copy is tiled per WAVE (64 rows; cfg.rows_per_block == 64) and multiplied by the wave-tile kernel with this many entries per lane
 };
 
@@ -319,7 +323,7 @@ int hyb_tile_starts(int64_t rows, int64_t coo_entries, const int *coo_Ai, int32_
 constexpr double kHybFusedMaxPerRow = 3.0;
 constexpr int kHybFusedMaxInTile = 4096;
 // spmv_csr16.hip: the plan's 16-bit column copy (built only if every tile qualifies) and the multiply that reads it
-int wave_partition_build(cmi_plan *p, const int *Ap, int k, hipStream_t s); // spmv_csr.hip
+int wave_partition_build(cmi_plan *p, const int *Ap, int k, hipStream_t s, int q_override = 0); // spmv_csr.hip (q_override: entries per tile, csr_wavev)
 int csr16_build(cmi_plan *p, const int *Ap, const int *Aj, hipStream_t s, int wave_k = 0);
 int csr16_multiply_f64(const cmi_plan *p, const int *Ap, const double *Ax, const double *x, double *y, int accumulate,
                        hipStream_t s, const double *w, double *dot_partial, int *dot_partials, int cache_policy, int xcd_swizzle);

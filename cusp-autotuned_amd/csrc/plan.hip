@@ -38,6 +38,90 @@ CMI_API int cmi_get_index_compression(void) { return compress_default(); }
 static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
                        const int32_t *index_array, const int32_t *csr_columns, const cmi_config *cfg, void *stream, cmi_plan **plan_out);
 
+// ---- checksum of an index array (cmi_plan_validate) -------------------------------------------------------------------------
+// sum over i of mix(i, a[i]) mod 2^64: position-dependent terms, combined by integer addition -- the same value whatever the
+// launch shape or the order the workgroups finish in.  One pass over the array at streaming speed (10^7 row offsets: ~10 us).
+namespace cmi {
+__device__ __forceinline__ unsigned long long fp_mix(unsigned long long i, int v)
+{
+    unsigned long long h = ((unsigned long long)(unsigned int)v + 0x9E3779B97F4A7C15ull) * ((i << 1) | 1ull);
+    h ^= h >> 29;
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 32;
+    return h;
+}
+__global__ void __launch_bounds__(256) fingerprint_kernel(int64_t n, const int *__restrict__ a, unsigned long long *__restrict__ out)
+{
+    __shared__ unsigned long long slots[256 / kWave];
+    unsigned long long h = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) h += fp_mix((unsigned long long)i, a[i]);
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) h += __shfl_down(h, o);
+    if ((threadIdx.x & (kWave - 1)) == 0) slots[threadIdx.x / kWave] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 256 / kWave; w++) h += slots[w];
+        atomicAdd(out, h);
+    }
+}
+// *fp <- checksum of a[0, n); synchronises the stream (set-up / validation call)
+static int fingerprint(int64_t n, const int *a, hipStream_t s, uint64_t *fp)
+{
+    *fp = 0;
+    if (n <= 0 || !a) return CMI_SUCCESS;
+    unsigned long long *dev = nullptr, host = 0;
+    CMI_HIP(hipMalloc((void **)&dev, sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(dev, 0, sizeof(host), s);
+    if (e == hipSuccess) {
+        int64_t blocks = ceil_div(n, 256 * 8);
+        if (blocks > kCus * 8) blocks = kCus * 8;
+        hipLaunchKernelGGL(fingerprint_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, n, a, dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&host, dev, sizeof(host), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return hip_fail(e, "plan fingerprint");
+    *fp = (uint64_t)host;
+    return CMI_SUCCESS;
+}
+// how many entries of the index array a plan of this format was made from
+static int64_t index_length(const cmi_plan *p)
+{
+    switch (p->format) {
+    case CMI_FORMAT_CSR: return p->rows > 0 ? p->rows + 1 : 0;
+    case CMI_FORMAT_COO: return p->nnz;
+    case CMI_FORMAT_HYB: return p->hyb_coo;
+    default: return 0;
+    }
+}
+} // namespace cmi
+
+// Have the arrays this plan was made from changed?  Recomputes their checksum on the device (one streaming pass; synchronises
+// `stream`) and compares it with the one taken at plan creation.  *valid_host = 1: same contents (up to a 2^-64 collision), 0: the
+// structure was edited in place -- destroy the plan and make a new one.  column_indices: only compared when the plan owns data
+// derived from them (CMI_CSR_STREAM_C16); may be NULL otherwise.  ELL / DIA plans hold nothing derived from the arrays: always valid.
+CMI_API int cmi_plan_validate(const cmi_plan *plan, const int32_t *index_array, const int32_t *column_indices, void *stream, int *valid_host)
+{
+    if (!plan || !valid_host) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_validate: null plan or result");
+    *valid_host = 1;
+    hipStream_t s = as_stream(stream);
+    if (plan->has_fp_index) {
+        if (!index_array) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_validate: the plan was made from an index array; pass it");
+        uint64_t fp = 0;
+        if (int st = fingerprint(index_length(plan), index_array, s, &fp)) return st;
+        if (fp != plan->fp_index) *valid_host = 0;
+    }
+    if (plan->has_fp_columns && *valid_host) {
+        if (!column_indices) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_validate: the plan owns a copy of the column indices; pass them");
+        uint64_t fp = 0;
+        if (int st = fingerprint(plan->nnz, column_indices, s, &fp)) return st;
+        if (fp != plan->fp_columns) *valid_host = 0;
+    }
+    return CMI_SUCCESS;
+}
+
 // csr_wave (CMI_CSR_STREAM_WAVE) instead of csr_stream: the longest row has 2..10 entries and the mean is within 7 % of it
 // ($CMI_CSR_WAVE=0: never -- measurements of csr_stream on stencil matrices)
 static int wave_env()
@@ -66,6 +150,35 @@ static int wave_partition_k(int64_t rows, int64_t nnz, const row_profile &prof, 
     if (k < 2 && asked_k <= 0) k = 2;
     if (k < 2 || k > kWaveTileMaxK || (double)prof.max_len > 6.4 * k) return 0;
     return k;
+}
+
+// csr_wavev (CMI_CSR_STREAM_WAVEV): index vectors per lane V (a wave tile = 256 V slots), or 0 = not for this matrix.  Asked for (a plan
+// made with that kernel): the caller's V or the rule's, refused when the longest row takes more than half of the tile.  AUTO plans:
+// the rule below ($CMI_CSR_WAVEV=0: never; =1: whenever the rows qualify).
+// AUTO plans take csr_wavev when ... (thresholds from tools/pmc_matrix_probe.py --time and tools/wavev_ab.py, profiles/r03_wavev_ab.txt)
+static bool wavev_auto(int64_t rows, int64_t nnz, const row_profile &prof, int v)
+{
+    (void)rows; (void)nnz; (void)prof; (void)v;
+    return false;
+}
+static int wavev_env()
+{
+    static const int env = [] { const char *e = std::getenv("CMI_CSR_WAVEV"); return e ? std::atoi(e) : -1; }();
+    return env;
+}
+static int wavev_vectors(int64_t rows, int64_t nnz, const row_profile &prof, bool asked, int asked_v)
+{
+    if (rows <= 0 || nnz <= 0 || prof.max_len < 1 || prof.in_long > 0) return 0;
+    const double mean = (double)nnz / (double)rows;
+    int v = asked_v;
+    if (v == 0) v = mean >= 20.0 ? 4 : mean >= 8.0 ? 2 : 1;
+    if (v != 1 && v != 2 && v != 4) return 0;
+    while (v < 4 && !asked_v && 2 * (prof.max_len + 3) > 256 * v) v *= 2; // (the rule may widen the tile for a long row)
+    if (2 * (prof.max_len + 3) > 256 * v) return 0;
+    if (asked) return v;
+    if (wavev_env() == 0) return 0;
+    if (wavev_env() == 1) return rows >= 4096 ? v : 0;
+    return wavev_auto(rows, nnz, prof, v) ? v : 0;
 }
 
 CMI_API int cmi_plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
@@ -136,13 +249,37 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
         cfg = &part_shape;
         p->cfg_explicit = false;
     }
+    // CMI_CSR_STREAM_WAVEV: wave-private tiles with the 16-byte-vector body on a partition the plan builds (rows of ~16-250 entries);
+    // cache policy / XCD dealing from the caller's fields if set, else the table's; index vectors per lane from the caller or the rule
+    cmi_config wavev_shape;
+    bool want_wavev = false;
+    int wavev_v = 0;
+    if (format == CMI_FORMAT_CSR && cfg && cfg->kernel == CMI_CSR_STREAM_WAVEV) {
+        want_wavev = true;
+        wavev_v = cfg->items_per_thread;
+        wavev_shape = *cfg;
+        wavev_shape.kernel = CMI_KERNEL_AUTO;
+        wavev_shape.rows_per_block = 0;
+        wavev_shape.items_per_thread = 0;
+        wavev_shape.block_size = 0;
+        wavev_shape.threads_per_row = 0;
+        cfg = &wavev_shape;
+        p->cfg_explicit = false;
+    }
     // HYB's table key is its ELL part's (the COO part looks its own shape up per call)
     select_config(format == CMI_FORMAT_HYB ? CMI_FORMAT_ELL : format, dtype, num_rows, num_cols, num_entries, cfg, &p->cfg);
     hipStream_t s = as_stream(stream);
     const size_t vbytes = dtype == CMI_F64 ? 8 : 4;
     int st = CMI_SUCCESS;
     if (format == CMI_FORMAT_CSR && num_rows > 0 && num_entries > 0) {
-        st = measure_row_lengths(num_rows, index_array, s, &p->prof.max_len, &p->prof.in_long);
+        int64_t ends[2] = {0, num_entries};
+        st = measure_row_lengths(num_rows, index_array, s, &p->prof.max_len, &p->prof.in_long, ends);
+        // the kernels and the plan-owned arrays (wave partition, 16-bit copy) are sized from num_entries: row offsets that do not span
+        // exactly [0, num_entries] are refused here, once, instead of being trusted by every multiply
+        if (st == CMI_SUCCESS && (ends[0] != 0 || ends[1] != num_entries)) {
+            set_error("cmi_plan_create: row offsets run from %lld to %lld, expected 0 to num_entries = %lld", (long long)ends[0], (long long)ends[1], (long long)num_entries);
+            st = CMI_ERROR_INVALID_VALUE;
+        }
         const bool auto_kernel = !cfg || cfg->kernel == CMI_KERNEL_AUTO;
         if (st == CMI_SUCCESS && auto_kernel && prefers_balanced(num_rows, num_entries, p->prof, vbytes, p->cfg.threads_per_row == 1)) {
             p->cfg.kernel = CMI_CSR_BALANCED;
@@ -168,7 +305,7 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
         // tiles (spmv_csr.hip csr_wave_kernel): 64 rows per wave, as many entries per lane as the longest row has, so every
         // tile fits and (mean within 7 % of the longest row) at least 93 % of the request lanes carry an entry.  Cache policy and
         // XCD dealing are the table's csr_stream entry's.  Not for a caller's explicit kernel, not over a granted 16-bit copy.
-        if (st == CMI_SUCCESS && auto_kernel && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
+        if (st == CMI_SUCCESS && auto_kernel && !want_wavev && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
             wave_tiles_fit(num_rows, num_entries, p->prof.max_len)) {
             p->cfg.kernel = CMI_CSR_STREAM_WAVE;
             p->cfg.block_size = 256;
@@ -182,6 +319,24 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
             // (profiles/r02_wave_shape_sweep.txt, r02_wave_ab.txt); below it, plain loads keep the matrix resident (tuning.hip)
             if (num_entries * (int64_t)(sizeof(int) + vbytes) > kInfinityCacheBytes + kInfinityCacheBytes / 4) p->cfg.nontemporal |= kPolLoadNT;
             p->cfg.nontemporal |= kPolStoreNT;
+        } else if (st == CMI_SUCCESS && auto_kernel && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
+                   wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v) > 0) {
+            const int v = wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v);
+            st = wave_partition_build(p, index_array, v, s, 256 * v - (int)p->prof.max_len - 3);
+            if (st == CMI_SUCCESS && p->wave_row_start) {
+                p->cfg.kernel = CMI_CSR_STREAM_WAVEV;
+                p->cfg.block_size = 256;
+                p->cfg.rows_per_block = 0; // (the partition's)
+                p->cfg.items_per_thread = v;
+                p->cfg.threads_per_row = 0;
+                p->cfg.nontemporal &= ~kPolStrided;
+                if (!(want_wavev && wavev_shape.nontemporal)) { // (a caller's policy bits are kept as given)
+                    if (num_entries * (int64_t)(sizeof(int) + vbytes) > kInfinityCacheBytes + kInfinityCacheBytes / 4) p->cfg.nontemporal |= kPolLoadNT;
+                    p->cfg.nontemporal |= kPolStoreNT;
+                }
+            }
+        } else if (st == CMI_SUCCESS && want_wavev) {
+            st = fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: CMI_CSR_STREAM_WAVEV needs items_per_thread 0, 1, 2 or 4, no row of 512+ entries and the longest row at most half of the 256 x items_per_thread slots of a wave tile");
         } else if (st == CMI_SUCCESS && auto_kernel && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1) {
             const int k = wave_partition_k(num_rows, num_entries, p->prof, want_partition, partition_k);
             if (want_partition && k == 0)
@@ -227,6 +382,14 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
             // an explicit CMI_COO_TILE on unsorted entries would add rows up wrongly: refuse it here, where it is known
             if (!sorted && p->cfg.kernel == CMI_COO_TILE) st = fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: CMI_COO_TILE needs row-sorted entries");
         }
+    }
+    if (st == CMI_SUCCESS && indexed && index_array && index_length(p) > 0) {
+        st = fingerprint(index_length(p), index_array, s, &p->fp_index);
+        p->has_fp_index = st == CMI_SUCCESS;
+    }
+    if (st == CMI_SUCCESS && p->csr16_cols && csr_columns) {
+        st = fingerprint(num_entries, csr_columns, s, &p->fp_columns);
+        p->has_fp_columns = st == CMI_SUCCESS;
     }
     if (st != CMI_SUCCESS) { (void)cmi_plan_destroy(p); return st; }
     *plan_out = p;
@@ -294,6 +457,10 @@ CMI_API int cmi_plan_create_hyb(int dtype, int64_t num_rows, int64_t num_cols, i
         // accumulating on top of the ELL half -- per row still the host chain)
         if (st == CMI_SUCCESS && !p->hyb_tile_start)
             st = plan_create(CMI_FORMAT_COO, dtype, num_rows, num_cols, coo_entries, coo_row_indices, nullptr, cfg_coo, stream, &p->hyb_coo_plan);
+        if (st == CMI_SUCCESS) {
+            st = fingerprint(coo_entries, coo_row_indices, s, &p->fp_index);
+            p->has_fp_index = st == CMI_SUCCESS;
+        }
     }
     if (st != CMI_SUCCESS) { (void)cmi_plan_destroy(p); return st; }
     *plan_out = p;
@@ -340,7 +507,7 @@ CMI_API int cmi_plan_info(const cmi_plan *plan, int64_t *max_row_length, int64_t
         switch (plan->format) {
         case CMI_FORMAT_CSR:
             // scalar / pipe: always; stream: one lane per row and no row long enough for the cooperative path
-            exact = c.kernel == CMI_CSR_SCALAR || c.kernel == CMI_CSR_STREAM_PIPE || c.kernel == CMI_CSR_STREAM_C16 || c.kernel == CMI_CSR_STREAM_WAVE ||
+            exact = c.kernel == CMI_CSR_SCALAR || c.kernel == CMI_CSR_STREAM_PIPE || c.kernel == CMI_CSR_STREAM_C16 || c.kernel == CMI_CSR_STREAM_WAVE || c.kernel == CMI_CSR_STREAM_WAVEV ||
                     (c.kernel == CMI_CSR_STREAM && c.threads_per_row <= 1 && (c.threads_per_row == 1 || plan->prof.max_len < 512));
             break;
         case CMI_FORMAT_ELL: exact = ell_lanes_per_row(c, plan->rows, plan->rows > 0 ? plan->nnz / plan->rows : 0) == 1; break;

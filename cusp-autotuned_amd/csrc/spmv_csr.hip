@@ -493,10 +493,10 @@ wave_partition_kernel(int64_t num_rows, const int *__restrict__ Ap, int q, int64
     for (int64_t t = prev + 1; t <= mine; t++) { start[2 * t] = (int32_t)r; start[2 * t + 1] = e; }
 }
 
-int wave_partition_build(cmi_plan *p, const int *Ap, int k, hipStream_t s)
+int wave_partition_build(cmi_plan *p, const int *Ap, int k, hipStream_t s, int q_override)
 {
     const int64_t rows = p->rows, nnz = p->nnz;
-    const int q = kWave * k - (int)p->prof.max_len;
+    const int q = q_override > 0 ? q_override : kWave * k - (int)p->prof.max_len;
     if (q < 1 || rows <= 0 || nnz <= 0) return CMI_SUCCESS;
     const int64_t tiles = nnz / q + 1;
     int32_t *start = nullptr;
@@ -558,6 +558,103 @@ csr_wavep_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, const in
                 if (r >= kWave) { a = Ap[rs + r]; b = Ap[rs + r + 1]; }
                 T sum = accumulate ? y[rs + r] : T(0);
                 for (int j = a; j < b; j++) sum = sum + mine[j - nz0];
+                st<NTS>(y + rs + r, sum);
+                if constexpr (DOT) d += (double)sum * (double)w[rs + r];
+            }
+        }
+    }
+    if constexpr (DOT) {
+        tile_dot_store(d, dot_slots, dot_partial + tile);
+        if (tile == 0 && threadIdx.x == 0) reset_fold_state(dot_partial);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// csr_wavev: wave-private tiles on a plan-built row partition with the 16-BYTE-VECTOR body (round 3) -- rows of ~16-250 entries
+// ---------------------------------------------------------------------------------------------
+// What the counters showed for csr_stream on FEM-like rows (ldoor-like, 45 per row; profiles/r03_long_rows_pmc_csr_stream.json): the
+// bytes are right (1.07 x algorithmic) but a wave spends ~70 % of its life neither issuing nor waiting for an instruction -- it sits
+// at the workgroup barrier while the slowest of eight waves finishes its three dependent round trips, and behind the barrier two of
+// the eight waves own all 80 rows of the tile and add them while the tile's 32 KiB of LDS stay allocated: 19 resident waves per CU
+// where 32 fit.  Here the tile belongs to ONE wave: V index vectors (int4) and their value vectors per lane, requested in one go;
+// the products are parked in the wave's own LDS region (64 V x 4 slots) and the lanes that own a row add it in storage order.  No
+// s_barrier anywhere: a wave starts its sums the moment its own gathers land, every wave owns rows, and the LDS goes back when
+// that wave ends.  Tile t = the rows whose FIRST entry lies in [t Q, (t + 1) Q) with Q = 256 V - longest row - 3 (the 3: the tile's
+// first vector starts at the 16-byte boundary at or below its first entry), so a tile always fits its wave's slots; the partition
+// is wave_partition_kernel's (8 bytes per tile, plan-owned).  Same products, storage-order sums: bit-exact.
+// The last vector of the ARRAYS may reach past num_entries: that one wave sums its rows straight from the arrays.
+template <typename T, int V, int POL, bool DOT>
+__global__ void __launch_bounds__(256)
+csr_wavev_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t num_entries, const int *Ap /* not restrict: see csr_wave */,
+                 const int *__restrict__ Aj, const T *__restrict__ Ax, const T *__restrict__ x, T *__restrict__ y, int64_t num_tiles,
+                 int64_t tiles_per_xcd, int swizzle, int accumulate, const T *__restrict__ w, double *__restrict__ dot_partial)
+{
+    constexpr int SLOTS = kWave * V * 4;
+    __shared__ __attribute__((aligned(16))) T prod[4][SLOTS];
+    __shared__ double dot_slots[DOT ? 4 : 1];
+    constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
+    const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle);
+    if (tile >= num_tiles) return; // whole workgroup
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x & (kWave - 1);
+    const int64_t wt = tile * 4 + wave;
+    double d = 0.0;
+    if (wt < wave_tiles) {
+        const int2v lo = *reinterpret_cast<const int2v *>(start + 2 * wt), hi = *reinterpret_cast<const int2v *>(start + 2 * wt + 2);
+        const int rs = lo.x, nz0 = lo.y, re = hi.x, nz1 = hi.y; // {first row, first entry} of this tile and of the next: one scalar hop
+        const int nr = re - rs;
+        if (nr > 0) { // (uniform per wave)
+            const int fbase = nz0 & ~3;
+            const int first_turn_end = Ap[rs + (nr < kWave ? nr : kWave)]; // (scalar) where the 64th row of the tile ends
+            int a = Ap[rs + (lane < nr ? lane : nr)], b = 0;
+            T *mine = prod[wave];
+            const bool fits = nz1 > nz0 && (int64_t)((nz1 + 3) & ~3) <= num_entries && nz1 - fbase <= SLOTS; // (uniform)
+            if (fits) {
+                const int last = (nz1 - 1) & ~3; // the last vector that holds an entry of the tile; lanes past it re-read it (and park
+                                                 // products in their OWN slots, which nobody reads): no branch between the requests
+                int4v c[V];
+                T v[V][4];
+#pragma unroll
+                for (int k = 0; k < V; k++) {
+                    int e = fbase + (k * kWave + lane) * 4;
+                    e = e < last ? e : last;
+                    c[k] = ld<NT>(reinterpret_cast<const int4v *>(Aj + e));
+                }
+#pragma unroll
+                for (int k = 0; k < V; k++) {
+                    int e = fbase + (k * kWave + lane) * 4;
+                    e = e < last ? e : last;
+                    if constexpr (sizeof(T) == 8) {
+                        const double2v v01 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e));
+                        const double2v v23 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e + 2));
+                        v[k][0] = v01.x; v[k][1] = v01.y; v[k][2] = v23.x; v[k][3] = v23.y;
+                    } else {
+                        const float4v vv = ld<NT>(reinterpret_cast<const float4v *>(Ax + e));
+                        v[k][0] = vv.x; v[k][1] = vv.y; v[k][2] = vv.z; v[k][3] = vv.w;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0); // every stream request is out before the first gather address is formed
+                T xv[V][4];
+#pragma unroll
+                for (int k = 0; k < V; k++) { xv[k][0] = x[c[k].x]; xv[k][1] = x[c[k].y]; xv[k][2] = x[c[k].z]; xv[k][3] = x[c[k].w]; }
+                asm volatile("" : "+v"(a)); // the row offset was requested in front of the streams
+#pragma unroll
+                for (int k = 0; k < V; k++) {
+                    T *dst = mine + (k * kWave + lane) * 4;
+                    if constexpr (sizeof(T) == 8) {
+                        *reinterpret_cast<double2v *>(dst) = double2v{v[k][0] * xv[k][0], v[k][1] * xv[k][1]};
+                        *reinterpret_cast<double2v *>(dst + 2) = double2v{v[k][2] * xv[k][2], v[k][3] * xv[k][3]};
+                    } else {
+                        *reinterpret_cast<float4v *>(dst) = float4v{v[k][0] * xv[k][0], v[k][1] * xv[k][1], v[k][2] * xv[k][2], v[k][3] * xv[k][3]};
+                    }
+                }
+                __builtin_amdgcn_wave_barrier(); // (compiler only: the hardware runs a wave's LDS instructions in order)
+            }
+            b = __builtin_amdgcn_update_dpp(first_turn_end, a, 0x130 /* wave_shl:1: the next lane's start; lane 63 keeps the 64th row's end */, 0xf, 0xf, false);
+            for (int r = lane; r < nr; r += kWave) { // (one turn, except over a stretch of very short rows)
+                if (r >= kWave) { a = Ap[rs + r]; b = Ap[rs + r + 1]; }
+                T sum = accumulate ? y[rs + r] : T(0);
+                if (fits) sum = sum_in_order(sum, mine + (a - fbase), b - a);
+                else for (int j = a; j < b; j++) sum = sum + Ax[j] * x[Aj[j]]; // (the array's last vector, or an empty tile)
                 st<NTS>(y + rs + r, sum);
                 if constexpr (DOT) d += (double)sum * (double)w[rs + r];
             }
@@ -903,9 +1000,11 @@ __global__ void __launch_bounds__(256) zero_fill_kernel(int64_t n, T *__restrict
 // is correct for every matrix.  CMI_CSR_PROFILE=0 turns the whole thing off.
 constexpr int kLongRowMin = 512, kLongRowPerLane = 128; // csr_stream's cooperative long-row path (see the kernel)
 
-// out[0] = longest row, out[1] = entries that sit in rows of kLongRowMin entries or more (two 64-bit words)
+// out[0] = longest row, out[1] = entries that sit in rows of kLongRowMin entries or more, out[2] = Ap[0], out[3] = Ap[num_rows]
+// (64-bit words; the two ends let plan creation refuse row offsets that do not match the caller's num_entries)
 __global__ void __launch_bounds__(256) max_row_length_kernel(int64_t num_rows, const int *__restrict__ Ap, unsigned long long *__restrict__ out)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[2] = (unsigned long long)(long long)Ap[0]; out[3] = (unsigned long long)(long long)Ap[num_rows]; }
     __shared__ int slots[256 / kWave];
     __shared__ unsigned long long lslots[256 / kWave];
     int m = 0;
@@ -931,11 +1030,11 @@ __global__ void __launch_bounds__(256) max_row_length_kernel(int64_t num_rows, c
     }
 }
 
-int measure_row_lengths(int64_t rows, const int *Ap, hipStream_t s, int64_t *max_len, int64_t *entries_in_long_rows)
+int measure_row_lengths(int64_t rows, const int *Ap, hipStream_t s, int64_t *max_len, int64_t *entries_in_long_rows, int64_t *ends)
 {
     unsigned long long *dev = nullptr;
-    CMI_HIP(hipMalloc((void **)&dev, 2 * sizeof(unsigned long long)));
-    unsigned long long host[2] = {0, 0};
+    CMI_HIP(hipMalloc((void **)&dev, 4 * sizeof(unsigned long long)));
+    unsigned long long host[4] = {0, 0, 0, 0};
     hipError_t e = hipMemsetAsync(dev, 0, sizeof(host), s);
     if (e == hipSuccess) {
         int64_t blocks = ceil_div(rows, 256 * 4);
@@ -949,6 +1048,7 @@ int measure_row_lengths(int64_t rows, const int *Ap, hipStream_t s, int64_t *max
     if (e != hipSuccess) return hip_fail(e, "row-length profile");
     *max_len = (int64_t)host[0];
     if (entries_in_long_rows) *entries_in_long_rows = (int64_t)host[1];
+    if (ends) { ends[0] = (int64_t)host[2]; ends[1] = (int64_t)host[3]; }
     return CMI_SUCCESS;
 }
 
@@ -1210,6 +1310,33 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         if (dot && dot_partials) *dot_partials = (int)tiles;
         break;
     }
+    case CMI_CSR_STREAM_WAVEV: { // wave-private tiles, 16-byte-vector body, on the plan's row partition
+        const int V = c.items_per_thread;
+        if (!plan || !plan->wave_row_start || plan->wave_q <= 0) return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_CSR_STREAM_WAVEV runs through a plan (cmi_plan_create) only");
+        if (V != 1 && V != 2 && V != 4) return fail(CMI_ERROR_NOT_SUPPORTED, "csr_wavev: items_per_thread (index vectors per lane) must be 1, 2 or 4");
+        if (reinterpret_cast<uintptr_t>(Aj) % 16 != 0 || reinterpret_cast<uintptr_t>(Ax) % 16 != 0) return fail(CMI_ERROR_INVALID_VALUE, "csr_wavev: Aj and Ax must be 16-byte aligned");
+        const int64_t tiles = ceil_div(plan->wave_tiles, (int64_t)4);
+        const int64_t tpx = ceil_div(tiles, kXcds);
+        int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
+        const int64_t grid64 = padded_grid(tiles, swz);
+        if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "csr_wavev: grid too large");
+        const bool dot = w && dot_partial && tiles <= kPartialCapacity;
+        with_policy(pol, [&](auto P) {
+            constexpr int POL = decltype(P)::value;
+            auto go = [&](auto VV) {
+                constexpr int VC = decltype(VV)::value;
+                if (dot) hipLaunchKernelGGL((csr_wavev_kernel<T, VC, POL, true>), dim3((unsigned)grid64), dim3(256), 0, s, plan->wave_row_start, plan->wave_tiles, nnz, Ap, Aj, Ax, x, y, tiles, tpx, swz, accumulate, w, dot_partial);
+                else     hipLaunchKernelGGL((csr_wavev_kernel<T, VC, POL, false>), dim3((unsigned)grid64), dim3(256), 0, s, plan->wave_row_start, plan->wave_tiles, nnz, Ap, Aj, Ax, x, y, tiles, tpx, swz, accumulate, (const T *)nullptr, (double *)nullptr);
+            };
+            switch (V) {
+            case 1: go(std::integral_constant<int, 1>()); break;
+            case 2: go(std::integral_constant<int, 2>()); break;
+            default: go(std::integral_constant<int, 4>()); break;
+            }
+        });
+        if (dot && dot_partials) *dot_partials = (int)tiles;
+        break;
+    }
     case CMI_CSR_STREAM_C16: { // the plan's 16-bit column copy (spmv_csr16.hip); Aj itself is not read
         if (!plan || !plan->csr16_cols) return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_CSR_STREAM_C16 runs through a plan of cmi_plan_create_csr only");
         if (reinterpret_cast<uintptr_t>(Ax) % 16 != 0) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream_c16: values must be 16-byte aligned");
@@ -1374,5 +1501,5 @@ CMI_API int cmi_csr_max_row_length(int64_t num_rows, const int32_t *Ap, int64_t 
     *max_length_host = 0;
     if (num_rows == 0) return CMI_SUCCESS;
     if (!Ap) return cmi::fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_max_row_length: null row offsets");
-    return cmi::measure_row_lengths(num_rows, Ap, cmi::as_stream(stream), max_length_host, nullptr);
+    return cmi::measure_row_lengths(num_rows, Ap, cmi::as_stream(stream), max_length_host, nullptr, nullptr);
 }

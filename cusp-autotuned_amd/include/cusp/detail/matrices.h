@@ -134,6 +134,8 @@ public:
         row_offsets.resize(rows + 1);
         column_indices.resize(entries);
         values.resize(entries);
+        plan_.reset(); // every writer of structure (convert, gallery, readers, operator=) resizes first: a device array1d keeps its
+                       // buffer when the new size fits, so the plan's (pointer, sizes) key alone would survive a different matrix
     }
     void swap(csr_matrix &o) { Parent::swap(o); row_offsets.swap(o.row_offsets); column_indices.swap(o.column_indices); values.swap(o.values); std::swap(plan_, o.plan_); }
 
@@ -216,6 +218,7 @@ public:
         row_indices.resize(entries);
         column_indices.resize(entries);
         values.resize(entries);
+        plan_.reset(); // as csr_matrix::resize: the cached row offsets of a sorted-COO plan belong to the OLD row indices
     }
     void swap(coo_matrix &o) { Parent::swap(o); row_indices.swap(o.row_indices); column_indices.swap(o.column_indices); values.swap(o.values); std::swap(plan_, o.plan_); }
 

@@ -25,7 +25,8 @@ class _Planned:
     _plan_key = None
 
     def _plan_for(self, fmt_code, index_array, stream, create=True):
-        key = (index_array.data_ptr(), self.num_rows, self.num_cols, self.num_entries, self.values.dtype)
+        # (_version: torch's in-place edit counter -- a .copy_() into the same storage is a different structure)
+        key = (index_array.data_ptr(), index_array._version, self.num_rows, self.num_cols, self.num_entries, self.values.dtype)
         if self._plan_key != key:
             if not create:
                 return None
@@ -55,8 +56,9 @@ class CsrMatrix(_Planned):
         if compress is not None:
             self._compress = bool(compress)  # sticky: later multiplies of this matrix keep the choice
         compress = getattr(self, "_compress", None)
-        key = (self.row_offsets.data_ptr(), self.column_indices.data_ptr(), self.num_rows, self.num_cols, self.num_entries,
-               self.values.dtype, compress if compress is not None else B.get_index_compression())
+        key = (self.row_offsets.data_ptr(), self.row_offsets._version, self.column_indices.data_ptr(), self.column_indices._version,
+               self.num_rows, self.num_cols, self.num_entries, self.values.dtype,
+               compress if compress is not None else B.get_index_compression())
         if self._plan_key != key:
             if not create:
                 return None
@@ -129,8 +131,8 @@ class HybMatrix:
 
     def plan(self, stream=None, create=True):
         e, c = self.ell, self.coo
-        key = (c.row_indices.data_ptr(), c.column_indices.data_ptr(), c.values.data_ptr(), e.column_indices.data_ptr(), e.values.data_ptr(),
-               e.pitch, self.num_rows, self.num_cols, e.num_entries_per_row, c.num_entries, e.values.dtype)
+        key = (c.row_indices.data_ptr(), c.row_indices._version, c.column_indices.data_ptr(), c.values.data_ptr(), e.column_indices.data_ptr(),
+               e.values.data_ptr(), e.pitch, self.num_rows, self.num_cols, e.num_entries_per_row, c.num_entries, e.values.dtype)
         if self._plan_key != key:
             if not create:
                 return None

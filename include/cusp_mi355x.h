@@ -162,6 +162,14 @@ typedef enum cmi_kernel {
                                (items_per_thread 0: floor(mean + longest / 64)); cmi_plan_config then reads rows_per_block 0.  Faster than
                                csr_stream on FEM-like rows (thermal2-like: 0.90-0.94 of its time), slower on large matrices with
                                scattered columns: no plan selects it by itself                                         */
+    CMI_CSR_STREAM_WAVEV = 8, /* plans only (round 3): WAVE-PRIVATE tiles with csr_stream's 16-byte-vector body, for rows of ~16-250 entries
+                               (FEM / KKT matrices).  The plan partitions the rows into wave tiles -- tile t = the rows whose first entry
+                               lies in [t Q, (t + 1) Q), Q = 256 x items_per_thread - longest row - 3; 8 bytes per tile of plan-owned
+                               memory -- and each 64-lane wave streams its tile with items_per_thread (1, 2, 4; 0 = by the mean row
+                               length) int4 index vectors + value vectors per lane, parks the products in its own LDS region and adds
+                               every row in storage order.  No workgroup barrier (csr_stream's waves sit at theirs for most of their
+                               life on such rows: profiles/r03_long_rows_pmc_csr_stream.json), every wave owns rows.  Bit-exact.  Needs
+                               16-byte aligned Aj / Ax, no row of 512+ entries, longest row <= 128 x items_per_thread - 3.           */
     /* ELL */
     CMI_ELL_ROW = 10, /* one lane per row            (ref: ell_spmv.h:55-93); threads_per_row 2,4,8,16: that many
                          lanes per row, each summing every 2nd / 4th / ... slot (ref: THREADS_PER_ROW of ktt
@@ -268,9 +276,17 @@ int cmi_hyb_entries_per_row(int dtype, int64_t num_rows, const int32_t *Ap, int 
 /*   A plan owns no device memory (except a HYB plan's tile ranges and the opt-in 16-bit column copy of   */
 /*   CMI_CSR_STREAM_C16, both freed by cmi_plan_destroy) and does not keep the pointers: the arrays are   */
 /*   passed again at every multiply; they must be the ones the plan was made for     */
-/*   (same sizes are checked; contents are the caller's promise -- a plan made for    */
-/*   other contents can cost speed or, for COO, give wrong sums: make a new plan      */
-/*   when the structure changes).  Thread-safe once created (read-only).              */
+/*   (same sizes are checked; contents are the caller's promise).                     */
+/*   CONTRACT: the index arrays a plan was made from -- CSR row offsets, COO / HYB-COO   */
+/*   row indices, and for a CMI_CSR_STREAM_C16 plan the column indices -- MUST NOT     */
+/*   CHANGE IN PLACE while the plan is used.  A plan caches structure derived from     */
+/*   them (a sorted-COO plan its row offsets, a C16 plan the 16-bit columns, a wave     */
+/*   partition the tile bounds): after an in-place edit the multiplies read that stale  */
+/*   structure and y is WRONG (never a fault: every kernel bounds its LDS tile by what   */
+/*   it reads).  Destroy the plan and make a new one when the structure changes;         */
+/*   cmi_plan_validate (below) tells whether that has happened.  cmi_plan_create also      */
+/*   refuses CSR row offsets that do not run from 0 to num_entries.                        */
+/*   Thread-safe once created (read-only).                                                */
 /* ------------------------------------------------------------------------- */
 typedef struct cmi_plan cmi_plan;
 /* index_array: CSR row offsets (num_rows + 1), COO row indices (num_entries), NULL for ELL / DIA / HYB  */
@@ -297,6 +313,12 @@ int cmi_plan_create_hyb(int dtype, int64_t num_rows, int64_t num_cols, int64_t e
 /* accumulating: heavy or unsorted COO parts).  $CMI_HYB_ONE_LAUNCH=0/1 at plan creation overrides the weight rule.           */
 int cmi_plan_hyb_launches(const cmi_plan *plan, int *launches);
 int cmi_plan_destroy(cmi_plan *plan);
+/* Have the arrays the plan was made from changed since?  One streaming pass over them on the device (an order-sensitive    */
+/* 64-bit checksum, compared with the one taken at creation); SYNCHRONISES `stream`.  *valid_host: 1 same contents, 0 edited  */
+/* in place -> make a new plan.  index_array as for cmi_plan_create (HYB: the COO part's row indices); column_indices only     */
+/* for plans that own a copy derived from them (CMI_CSR_STREAM_C16), NULL otherwise.  ELL / DIA plans are always valid.        */
+int cmi_plan_validate(const cmi_plan *plan, const int32_t *index_array, const int32_t *column_indices, void *stream,
+                      int *valid_host);
 /* The launch shape the plan's multiplies run (SURVEY's cmi_plan_select): kernel CMI_CSR_BALANCED means   */
 /* the profile switched kernels.                                                                            */
 int cmi_plan_config(const cmi_plan *plan, cmi_config *out);

@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Workload for rocprofv3 --pmc passes on the configs[3] matrices (no counter file existed for the
+25-80 entries/row class).  One process, one profiler start-up: per matrix (ldoor / nlpkkt120 / thermal2 stand-ins or the real
+files, tools/suitesparse_like.py) every VARIANT is launched K times back to back; the manifest (stdout, `MANIFEST` lines) lets
+tools/pmc_matrix_table.py map dispatches back to variants.  A calibration kernel of known byte count (axpby, 16 B per lane)
+runs last, as MI355X_MICROARCH.md's HBM section prescribes for FETCH_SIZE / WRITE_SIZE.
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dir>/fetch -- python3 tools/pmc_matrix_probe.py ldoor,nlpkkt120
+    python3 tools/pmc_matrix_probe.py ldoor --time       # no profiler: HIP-event timing of the same variants
+
+Variants (each validated against csr_scalar before it is launched for the counters):
+    plan      the plan's choice (what cusp::multiply runs)
+    stream    csr_stream, the table's shape for this row length (no plan)
+    wavev     CMI_CSR_STREAM_WAVEV through a plan, when the library has it
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import cusp_autotuned_amd as cmi  # noqa: E402
+import suitesparse_like as ssl  # noqa: E402
+
+K = int(os.environ.get("PMC_LAUNCHES", "6"))
+
+
+def cached(name):
+    """full-size stand-in, generated once per box (the passes are separate processes)"""
+    path = f"/tmp/cmi_{name}_1.0.npz"
+    if os.path.exists(path):
+        z = np.load(path)
+        return z["Ap"], z["Aj"], z["Ax"], str(z["src"])
+    Ap, Aj, Ax, src = ssl.load(name, 1.0)
+    np.savez(path, Ap=Ap, Aj=Aj, Ax=Ax, src=src)
+    return Ap, Aj, Ax, src
+
+
+def variants_for(A):
+    out = [("plan", None)]
+    out.append(("stream", "table"))
+    if hasattr(cmi, "CSR_STREAM_WAVEV"):
+        for v in (int(s) for s in os.environ.get("PMC_WAVEV", "2,4").split(",") if s):
+            out.append((f"wavev{v}", cmi.Config(kernel=cmi.CSR_STREAM_WAVEV, items_per_thread=v)))
+    return out
+
+
+def main():
+    names = (sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "ldoor,nlpkkt120").split(",")
+    timing = "--time" in sys.argv
+    lib = cmi.lib()
+    import ctypes
+    for name in names:
+        t0 = time.time()
+        Ap, Aj, Ax, src = cached(name)
+        rows, nnz = len(Ap) - 1, int(Ap[-1])
+        A = cmi.CsrMatrix(rows, rows, nnz, torch.from_numpy(Ap).cuda(), torch.from_numpy(Aj).cuda(), torch.from_numpy(Ax).cuda())
+        x = cmi.fill_x(rows, torch.float64, "cuda")
+        y = torch.empty(rows, dtype=torch.float64, device="cuda")
+        cmi.multiply(A, x, y, cfg=cmi.Config(kernel=cmi.CSR_SCALAR))
+        want = y.clone()
+        alg = cmi.csr_bytes(rows, nnz)
+        print(f"# {name}: {src}; rows {rows} entries {nnz} algorithmic bytes {alg}; set-up {time.time() - t0:.1f} s", flush=True)
+        for label, cfg in variants_for(A):
+            plan = None
+            if isinstance(cfg, cmi.Config):
+                try:
+                    plan = cmi.Plan.csr(torch.float64, rows, rows, A.row_offsets, A.column_indices, cfg=cfg)
+                except Exception as e:  # noqa: BLE001
+                    print(f"# {name} {label}: no plan ({e})")
+                    continue
+
+            def go():
+                if cfg is None:
+                    cmi.multiply(A, x, y)
+                elif cfg == "table":
+                    cmi.spmv_csr(rows, rows, A.row_offsets, A.column_indices, A.values, x, y)
+                else:
+                    cmi.spmv_csr_plan(plan, A.row_offsets, A.column_indices, A.values, x, y)
+            y.fill_(7.0)
+            go()
+            exact = bool(torch.equal(y, want))
+            desc = (A.plan().config() if cfg is None else plan.config() if plan is not None else
+                    cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, rows, rows, nnz))
+            if timing:
+                e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+                cmi.check(lib.cmi_event_create(ctypes.byref(e0)))
+                cmi.check(lib.cmi_event_create(ctypes.byref(e1)))
+                ts = []
+                for _ in range(5):
+                    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                    cmi.check(lib.cmi_event_record(e0, s))
+                    for _ in range(20):
+                        go()
+                    cmi.check(lib.cmi_event_record(e1, s))
+                    ms = ctypes.c_float()
+                    cmi.check(lib.cmi_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+                    ts.append(ms.value / 20 * 1e3)
+                t = float(np.median(ts))
+                print(f"TIME\t{name}:{label}\t{t:.1f} us\t{alg / t / 1e3:.0f} GB/s\tfrac {alg / t / 1e3 / 8000:.3f}\tbit-exact {exact}\t{desc}", flush=True)
+            else:
+                torch.cuda.synchronize()
+                for _ in range(K):
+                    go()
+                torch.cuda.synchronize()
+                print(f"MANIFEST\t{name}:{label}\t{K + 1}\t{alg}\t{exact}\t{desc}", flush=True)
+        del A, x, y, want
+        torch.cuda.empty_cache()
+    n_cal = 1 << 25
+    a = torch.ones(n_cal, dtype=torch.float64, device="cuda")
+    b = torch.ones(n_cal, dtype=torch.float64, device="cuda")
+    c = torch.empty(n_cal, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(6):
+        cmi.blas_axpby(2.0, a, 3.0, b, c)
+    torch.cuda.synchronize()
+    print(json.dumps({"calibration_kernel": "axpby_kernel", "calibration_read_bytes": 16 * n_cal, "calibration_write_bytes": 8 * n_cal}))
+
+
+if __name__ == "__main__":
+    main()
