@@ -348,6 +348,72 @@ CMI_API int cmi_csr_row_indices(int64_t num_rows, const int32_t *Ap, int32_t *Ai
     return CMI_SUCCESS;
 }
 
+// Smallest and largest column index of `num_entries` entries (a row block's gather window: what the sharded operator's exchange
+// plan is made from, cusp/distributed/csr_matrix.h).  Set-up call: allocates 8 bytes of scratch and synchronises the stream.
+// No entries: *min_host = 0, *max_host = -1.
+namespace cmi {
+__global__ void __launch_bounds__(256) column_span_kernel(int64_t n, const int *__restrict__ Aj, int *__restrict__ out)
+{
+    int lo = INT32_MAX, hi = INT32_MIN;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int c = Aj[i];
+        lo = c < lo ? c : lo;
+        hi = c > hi ? c : hi;
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        const int a = __shfl_down(lo, o), b = __shfl_down(hi, o);
+        lo = a < lo ? a : lo;
+        hi = b > hi ? b : hi;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) { atomicMin(out, lo); atomicMax(out + 1, hi); }
+}
+} // namespace cmi
+
+CMI_API int cmi_csr_column_span(int64_t num_entries, const int32_t *Aj, int32_t *min_host, int32_t *max_host, void *stream)
+{
+    if (num_entries < 0 || !min_host || !max_host) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_column_span: bad argument");
+    *min_host = 0;
+    *max_host = -1;
+    if (num_entries == 0) return CMI_SUCCESS;
+    if (!Aj) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_column_span: null column indices");
+    hipStream_t s = as_stream(stream);
+    int *dev = nullptr, host[2] = {INT32_MAX, INT32_MIN};
+    CMI_HIP(hipMalloc((void **)&dev, sizeof(host)));
+    hipError_t e = hipMemcpyAsync(dev, host, sizeof(host), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        int64_t blocks = ceil_div(num_entries, 256 * 8);
+        if (blocks > kCus * 8) blocks = kCus * 8;
+        hipLaunchKernelGGL(column_span_kernel, dim3((unsigned)blocks), dim3(256), 0, s, num_entries, Aj, dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return hip_fail(e, "cmi_csr_column_span");
+    *min_host = host[0];
+    *max_host = host[1];
+    return CMI_SUCCESS;
+}
+
+// Row offsets of a row block cut out of a larger CSR matrix: out[i] = Ap[i] - Ap[0] for i <= num_rows (in place allowed).
+namespace cmi {
+__global__ void __launch_bounds__(256) rebase_offsets_kernel(int64_t n, const int *__restrict__ Ap, int base, int *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = Ap[i] - base;
+}
+} // namespace cmi
+CMI_API int cmi_csr_rebase_offsets(int64_t num_rows, const int32_t *Ap, int32_t base, int32_t *out, void *stream)
+{
+    if (num_rows < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_rebase_offsets: negative size");
+    if (!Ap || !out) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_rebase_offsets: null array");
+    hipLaunchKernelGGL(rebase_offsets_kernel, dim3((unsigned)ceil_div(num_rows + 1, 256)), dim3(256), 0, as_stream(stream), num_rows + 1, Ap, base, out);
+    CMI_LAUNCH_CHECK("rebase_offsets");
+    return CMI_SUCCESS;
+}
+
 // Row offsets of a row-sorted COO matrix: entry e with row r closes the offsets of every row in (row of entry e-1, r]
 // at e; the thread past the last entry closes the rest at num_entries.  Also the order check: *unsorted != 0 afterwards
 // means some row index was smaller than its predecessor (or out of range) and Ap is not to be used.

@@ -27,6 +27,7 @@ CMI_API const char *cmi_status_string(int status)
     case CMI_ERROR_NO_DEVICE: return "CMI_ERROR_NO_DEVICE";
     case CMI_ERROR_ALLOC: return "CMI_ERROR_ALLOC";
     case CMI_ERROR_IO: return "CMI_ERROR_IO";
+    case CMI_ERROR_COMM: return "CMI_ERROR_COMM";
     default: return "CMI_ERROR_UNKNOWN";
     }
 }

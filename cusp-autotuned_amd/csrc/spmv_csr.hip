@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(1024)
 csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ Ap,
                   const int *__restrict__ Aj, const T *__restrict__ Ax, const T *__restrict__ x,
                   T *__restrict__ y, int rows_per_block, int64_t num_tiles, int64_t tiles_per_xcd,
-                  int swizzle, int accumulate, int tpr, int long_len, int lane_strided, const T *__restrict__ w = nullptr,
+                  int swizzle, int accumulate, int tpr, int long_len, int lane_strided, int spread_rows, const T *__restrict__ w = nullptr,
                   double *__restrict__ dot_partial = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -166,7 +166,15 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
         const int nz0 = Ap[r0], nz1 = Ap[r0 + nr];
         const int fbase = nz0 & ~3;
         if (tpr == 1 && nr <= block && nz1 - fbase <= tile_entries && (int64_t)((nz1 + 3) & ~3) <= num_entries) {
-            const int a = Ap[r0 + (tid < nr ? tid : nr)], b = Ap[r0 + (tid + 1 < nr ? tid + 1 : nr)];
+            // Which lane adds which row.  Default: lane r adds row r -- for long rows (80 rows of 45 entries in a 512-lane tile) that is
+            // one and a quarter waves adding serially behind the barrier while the other waves have nothing to do, with up to 32 lanes of
+            // one LDS instruction colliding on banks.  SPREAD (round 3; kernel argument, uniform): the rows are dealt round the WAVES --
+            // wave w adds rows w, w + W, w + 2 W, ... on its lanes 0, 1, 2, ... -- so every SIMD works on the sum phase at once and an LDS
+            // instruction carries nr / W lanes.  Same products, same order per row: same bits.
+            int myrow = tid;
+            if (spread_rows) { const int W = block >> 6; myrow = (tid & (kWave - 1)) * W + (tid >> 6); }
+            const bool has_row = myrow < nr;
+            const int a = Ap[r0 + (has_row ? myrow : nr)], b = Ap[r0 + (has_row ? myrow + 1 : nr)];
             // IPT vectors per lane, all requested before the first product is formed (round 2: the path also serves the
             // longer-row shapes of the table, IPT 2 and 4 -- FEM-like matrices of 27-80 entries per row)
             int4v c[IPT];
@@ -199,14 +207,14 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
                 }
             }
             T wv = T(0);
-            if constexpr (DOT) { if (tid < nr) wv = w[r0 + tid]; } // requested before the barrier
+            if constexpr (DOT) { if (has_row) wv = w[r0 + myrow]; } // requested before the barrier
             __syncthreads();
             double d = 0.0;
-            if (tid < nr) {
-                T s = accumulate ? y[r0 + tid] : T(0);
+            if (has_row) {
+                T s = accumulate ? y[r0 + myrow] : T(0);
                 if constexpr (IPT == 1) { for (int j = a; j < b; j++) s = s + prod[j - fbase]; } // short rows: the plain loop is faster
                 else s = sum_in_order(s, prod + (a - fbase), b - a);
-                st<(POL & kPolStoreNT) != 0>(y + r0 + tid, s);
+                st<(POL & kPolStoreNT) != 0>(y + r0 + myrow, s);
                 if constexpr (DOT) d = (double)s * (double)wv;
             }
             if constexpr (DOT) {
@@ -1111,11 +1119,11 @@ static int dot_swizzle(int table_swizzle, const cmi_plan *plan, int inside_a_sol
 template <typename T, bool VEC, int POL, bool DOT = false, bool LONG = false>
 static int launch_stream_ipt(int ipt, int grid, int block, size_t lds, hipStream_t s, int64_t rows, int64_t nnz,
                              const int *Ap, const int *Aj, const T *Ax, const T *x, T *y, int rpb, int64_t tiles,
-                             int64_t tpx, int swz, int acc, int tpr, int long_len, int strided, const T *w = nullptr, double *dot_partial = nullptr)
+                             int64_t tpx, int swz, int acc, int tpr, int long_len, int strided, int spread, const T *w = nullptr, double *dot_partial = nullptr)
 {
 #define CMI_STREAM_LAUNCH(IPT)                                                                                              \
     hipLaunchKernelGGL((csr_stream_kernel<T, IPT, VEC, POL, DOT, LONG>), dim3(grid), dim3(block), lds, s, rows, nnz, Ap, Aj, \
-                       Ax, x, y, rpb, tiles, tpx, swz, acc, tpr, long_len, strided, w, dot_partial)
+                       Ax, x, y, rpb, tiles, tpx, swz, acc, tpr, long_len, strided, spread, w, dot_partial)
     switch (ipt) {
     case 1: CMI_STREAM_LAUNCH(1); break;
     case 2: CMI_STREAM_LAUNCH(2); break;
@@ -1223,8 +1231,11 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         // any row, one lane or lane group at a time -- correct, slow on a long row)
         const bool lng = long_len > 0 && nnz >= long_len && known_max_len >= long_len;
         const int strided = csr_lane_strided(c.nontemporal);
+        // row sums dealt round the waves when the tile's rows fill at most half of its lanes (long rows); $CMI_CSR_SPREAD=0/1 overrides
+        static const int spread_env = [] { const char *e = std::getenv("CMI_CSR_SPREAD"); return e ? std::atoi(e) : -1; }();
+        const int spread = spread_env >= 0 ? spread_env : (tpr == 1 && 2 * rpb <= block && block >= 128);
 #define CMI_STREAM_GO(VEC_, DOT_, LONG_, ...) \
-    launch_stream_ipt<T, VEC_, POL, DOT_, LONG_>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate, tpr, long_len, strided, ##__VA_ARGS__)
+    launch_stream_ipt<T, VEC_, POL, DOT_, LONG_>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate, tpr, long_len, strided, spread, ##__VA_ARGS__)
         with_policy(pol, [&](auto P) {
             constexpr int POL = decltype(P)::value;
             if (dot) {

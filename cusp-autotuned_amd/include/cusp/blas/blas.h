@@ -108,6 +108,43 @@ template <typename X> typename X::value_type nrm2(const X &x, host_memory)
     return std::sqrt(s);
 }
 
+// ---- sharded vectors (cusp/distributed/vector.h): element-wise work on this rank's slice, reductions all-reduced --------------
+// The slice is an array1d_view in the local space, so the loops / kernels above do the work.  Reductions: the local partial as a
+// DOUBLE (device: left in device memory by the library's deterministic two-stage reduction, all-reduced there by RCCL, then the one
+// 8-byte read the single-GPU routines also make; host: summed in rank order by the star) -- every rank returns the same bits.
+template <typename X, typename Y, typename S, typename L> void axpy(const X &x, Y &y, S a, distributed_memory<L>)
+{ auto xl = x.local(); auto yl = y.local(); axpy(xl, yl, a, L()); }
+template <typename X, typename Y, typename Z, typename S, typename L> void axpby(const X &x, const Y &y, Z &z, S a, S b, distributed_memory<L>)
+{ auto xl = x.local(); auto yl = y.local(); auto zl = z.local(); axpby(xl, yl, zl, a, b, L()); }
+template <typename X, typename Y, typename L> void copy(const X &x, Y &y, distributed_memory<L>)
+{ auto xl = x.local(); auto yl = y.local(); copy(xl, yl, L()); }
+template <typename X, typename S, typename L> void fill(X &x, S v, distributed_memory<L>)
+{ auto xl = x.local(); fill(xl, v, L()); }
+inline int c_dotd(int64_t n, const double *x, const double *y, double *r, void *ws) { return cmi_blas_dot_f64(n, x, y, r, ws, nullptr); }
+inline int c_dotd(int64_t n, const float *x, const float *y, double *r, void *ws) { return cmi_blas_dotd_f32(n, x, y, r, ws, nullptr); }
+template <typename X, typename Y> double dot_all(const X &x, const Y &y, host_memory)
+{
+    double s = 0;
+    for (size_t i = 0; i < x.size(); i++) s += (double)x.data()[i] * (double)y.data()[i];
+    x.comm().allreduce_sum(&s, 1, host_memory());
+    return s;
+}
+template <typename X, typename Y> double dot_all(const X &x, const Y &y, device_memory)
+{
+    require_real<typename X::value_type>();
+    device_workspace &w = workspace();
+    double *res = static_cast<double *>(w.result);
+    cusp::detail::check(c_dotd(x.size(), x.data(), y.data(), res, w.ws));
+    x.comm().allreduce_sum(res, 1, device_memory());
+    double r;
+    cusp::detail::check(cmi_memcpy_d2h(&r, res, sizeof(double), nullptr));
+    return r;
+}
+template <typename X, typename Y, typename L> typename X::value_type dot(const X &x, const Y &y, distributed_memory<L>)
+{ return static_cast<typename X::value_type>(dot_all(x, y, L())); }
+template <typename X, typename L> typename X::value_type nrm2(const X &x, distributed_memory<L>)
+{ return static_cast<typename X::value_type>(std::sqrt(dot_all(x, x, L()))); }
+
 } // namespace detail
 
 template <typename X, typename Y, typename S> void axpy(const X &x, Y &y, S alpha)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CMI_VERSION 200 /* 0.2.0: plans, COO tile kernel, XCD dealing in ELL / DIA / COO, HYB width rule */
+#define CMI_VERSION 300 /* 0.3.0: communicator + collectives (RCCL) behind the boundary, cmi_plan_validate, CMI_CSR_STREAM_WAVEV */
 
 typedef enum cmi_status {
     CMI_SUCCESS = 0,
@@ -41,7 +41,8 @@ typedef enum cmi_status {
     CMI_ERROR_NOT_SUPPORTED = 3, /* config names a kernel variant that does not exist */
     CMI_ERROR_NO_DEVICE = 4,     /* no gfx950 device visible */
     CMI_ERROR_ALLOC = 5,         /* hipMalloc failed: std::bad_alloc */
-    CMI_ERROR_IO = 6             /* tuning table could not be read / written */
+    CMI_ERROR_IO = 6,            /* tuning table could not be read / written */
+    CMI_ERROR_COMM = 7           /* RCCL could not be loaded, or a communicator call failed: cusp::runtime_exception */
 } cmi_status;
 
 /* Human-readable name of a status, and the message of the last failure on this thread. */
@@ -529,6 +530,11 @@ int cmi_csr_to_dia_f64(int64_t num_rows, int64_t num_cols, const int32_t *Ap, co
 int cmi_csr_to_dia_f32(int64_t num_rows, int64_t num_cols, const int32_t *Ap, const int32_t *Aj, const float *Ax,
                        int64_t num_diagonals, int64_t pitch, const int32_t *offsets, int32_t *slot_map,
                        float *values, void *stream);
+/* Set-up helpers of the row-block sharded operator (no reference equivalent): the column window a row block gathers    */
+/* from (smallest / largest column index; no entries: 0, -1; synchronises), and the row offsets of a block cut out of a larger       */
+/* matrix (out[i] = Ap[i] - base for i <= num_rows).                                                                                  */
+int cmi_csr_column_span(int64_t num_entries, const int32_t *Aj, int32_t *min_host, int32_t *max_host, void *stream);
+int cmi_csr_rebase_offsets(int64_t num_rows, const int32_t *Ap, int32_t base, int32_t *out, void *stream);
 /* CSR -> COO row indices (offsets_to_indices, csr_to_other.h:56-70). */
 int cmi_csr_row_indices(int64_t num_rows, const int32_t *Ap, int32_t *Ai, void *stream);
 /* The way back for ROW-SORTED entries (coo -> csr on the device; reference: cusp/system/detail/generic/conversions/
@@ -641,6 +647,58 @@ int cmi_cg_direction_x_fold_f64(int64_t n, double *rr_new_dev, double *rr_host_m
 int cmi_cg_direction_x_fold_f32(int64_t n, double *rr_new_dev, double *rr_host_mirror, int npartials_rr, const double *rr_old_dev,
                                 const double *yp_dev, const float *r, float *p, float *x, void *workspace, void *stream);
 int cmi_blas_dotd_f32(int64_t n, const float *x, const float *y, double *result_dev, void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* Multi-GPU: communicator and collectives of the row-block sharded SpMV / CG */
+/* (cmi_allgather_f64, cmi_allreduce_f64; 8(e): one process per   */
+/* GPU, matrices sharded by row blocks with GLOBAL column indices, an all-gather of x over   */
+/* xGMI before each multiply, all-reduced <.,.> scalars inside cusp::krylov::cg).  The          */
+/* reference has no distributed code (cusp/ktt/detail/ktt.inl:34-35 pins device 0; the caller */
+/* this serves is cusp/krylov/detail/cg.inl:41-107).  Backed by RCCL, bound at run time at the  */
+/* first cmi_comm_* call (librccl.so.1; $CMI_RCCL_LIBRARY overrides): single-GPU users never    */
+/* load it.  One process per GPU: call cmi_set_device first; every rank calls cmi_comm_create     */
+/* with the SAME 128-byte id, which rank 0 makes with cmi_comm_unique_id and hands to the others   */
+/* out of band (the header layer's cusp::distributed::communicator does it over a TCP socket to     */
+/* MASTER_ADDR; a Python host may use any store).  Collectives are ENQUEUED on the caller's stream  */
+/* and return at once; buffers are device memory; every rank must issue the same sequence.           */
+/* ------------------------------------------------------------------------- */
+#define CMI_COMM_ID_BYTES 128
+typedef struct cmi_comm cmi_comm;
+typedef enum cmi_reduce_op { CMI_OP_SUM = 0, CMI_OP_MAX = 1, CMI_OP_MIN = 2 } cmi_reduce_op;
+int cmi_comm_unique_id(void *id_out /* CMI_COMM_ID_BYTES */);
+int cmi_comm_create(const void *unique_id, int rank, int world, cmi_comm **comm); /* collective; synchronises */
+int cmi_comm_destroy(cmi_comm *comm);
+int cmi_comm_rank(const cmi_comm *comm, int *rank, int *world);
+int cmi_comm_library_version(int *version); /* ncclGetVersion of the RCCL that was bound */
+/* recv[r * count, (r + 1) * count) <- rank r's send[0, count): the north-star exchange (ncclAllGather).  In place when      */
+/* send == recv + rank * count: the sharded operator keeps every rank's slice INSIDE the full-length x buffer, so nothing is   */
+/* copied before or after.                                                                                                       */
+int cmi_allgather_f64(cmi_comm *comm, const double *send, double *recv, int64_t count, void *stream);
+int cmi_allgather_f32(cmi_comm *comm, const float *send, float *recv, int64_t count, void *stream);
+/* Row blocks of different lengths (balanced by entries): recv[displs[r], displs[r] + counts[r]) <- rank r's         */
+/* send[0, counts[r]); counts / displs are HOST arrays of `world` element counts.  algorithm 0: one ncclBroadcast per rank in ONE   */
+/* group; 1: direct exchange, a grouped ncclSend / ncclRecv pair per peer -- on the point-to-point xGMI mesh every link then carries */
+/* one peer's piece each way, the fabric's lower bound for an all-gather.  Same result either way.                                    */
+int cmi_allgatherv_f64(cmi_comm *comm, const double *send, double *recv, const int64_t *counts, const int64_t *displs, int algorithm,
+                       void *stream);
+int cmi_allgatherv_f32(cmi_comm *comm, const float *send, float *recv, const int64_t *counts, const int64_t *displs, int algorithm,
+                       void *stream);
+/* Two-sided halo exchange inside ONE full-length buffer indexed by global column (banded matrices: 5-point Poisson needs 2 m     */
+/* values per rank instead of N): for peer i, send x_full[send_lo[i], +send_count[i]) -- part of this rank's slice -- and receive     */
+/* x_full[recv_lo[i], +recv_count[i]); one group = one launch.  HOST arrays of npeers entries.  The one-sided alternative is          */
+/* cmi_ipc_* + cmi_copy_ranges above (a pull over xGMI, no collective).                                                               */
+int cmi_halo_exchange_f64(cmi_comm *comm, double *x_full, int npeers, const int *peers, const int64_t *send_lo, const int64_t *send_count,
+                          const int64_t *recv_lo, const int64_t *recv_count, void *stream);
+int cmi_halo_exchange_f32(cmi_comm *comm, float *x_full, int npeers, const int *peers, const int64_t *send_lo, const int64_t *send_count,
+                          const int64_t *recv_lo, const int64_t *recv_count, void *stream);
+/* recv[i] <- op over the ranks of send[i]; device buffers, in place when send == recv.  CG's <y,p> and <r,r> (cg.inl:83,97): one or */
+/* two doubles that never leave device memory.  Same inputs, same world size -> same bits on every rank and every run.               */
+int cmi_allreduce_f64(cmi_comm *comm, const double *send, double *recv, int64_t count, int op, void *stream);
+/* Every rank has reached this call and everything queued on `stream` before it has completed everywhere.  Synchronises.            */
+int cmi_comm_barrier(cmi_comm *comm, void *stream);
+/* Set-up convenience for small HOST records (IPC handles, column spans, row counts): recv_host[r * bytes, +bytes) <- rank r's          */
+/* send_host[0, bytes); bytes x world <= ~4000.  Synchronises.                                                                      */
+int cmi_comm_allgather_host(cmi_comm *comm, const void *send_host, void *recv_host, size_t bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -119,3 +119,38 @@ def test_reference_examples_run_on_device(cmi, tmp_path):
     assert "Successfully converged after" in outs["Solvers_cg"]
     assert "sparse matrix <" in outs["Gallery_poisson"] and "sparse matrix <" in outs["InputOutput_matrix_market"]
     assert "onverged" in outs["Monitors_monitor"] or "residual" in outs["Monitors_monitor"].lower()
+
+
+# ---- the one-process-per-GPU layer (cusp/distributed/*.h) through C++ only ---------------------------------------------------------
+def _launch(ranks, mode, port, timeout=300):
+    for exe in ("tests/cpp/bin/test_distributed", "tools/bin/cmi_launch"):
+        if not os.path.exists(os.path.join(ROOT, exe)):
+            _build()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([os.path.join(ROOT, "tools", "bin", "cmi_launch"), "-n", str(ranks), "--port", str(port), "--",
+                        os.path.join(CPP, "bin", "test_distributed"), mode], capture_output=True, text=True, timeout=timeout, env=env)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("ranks", [1, 2, 3])
+def test_sharded_operator_and_cg_host_transport(cmi, ranks):
+    """world 1 / 2 / 3 on CPUs: row partitions (equal rows, balanced by entries), exchange plans (all-gather, unequal pieces, halo),
+    cusp::multiply and cusp::krylov::cg on a sharded host_memory operator over the TCP star -- the logic RCCL carries on the GPUs.
+    Every rank's rows have the single-process multiply's bits; CG takes the single-process iteration count."""
+    out = _launch(ranks, "host", 29620 + ranks)
+    lines = [l for l in out.splitlines() if l.startswith("ok ")]
+    assert len(lines) == 6, out
+    if ranks > 1:
+        assert "banded/equal-rows/auto" in out and "mode halo" in out and "mode allgather" in out
+
+
+@pytest.mark.gpu
+def test_sharded_operator_and_cg_through_rccl_one_rank(cmi):
+    """The same program on device_memory with a ONE-rank RCCL communicator (one GPU per box here): cmi_comm_create,
+    cmi_allgather / cmi_allgatherv / cmi_halo_exchange / cmi_allreduce are the calls an 8-GPU node makes; the local SpMV and the
+    fused CG steps are the single-GPU hot path."""
+    out = _launch(1, "device", 29631)
+    assert "RCCL version code" in out
+    assert len([l for l in out.splitlines() if l.startswith("ok ")]) == 6, out

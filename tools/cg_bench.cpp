@@ -1,6 +1,7 @@
 // tools/cg_bench.cpp -- CG iterations/s through the C++ layer (cusp::krylov::cg on device_memory), the
 // caller of the SpMV hot path: poisson5pt(grid, grid), b = deterministic x pattern, fixed iteration count.
 //   [CMI_COMPRESS_INDICES=1] cg_bench [--grid=3162] [--iterations=200] [--format=csr|ell|dia|hyb|coo]
+//   tools/bin/cmi_launch -n 8 -- tools/bin/cg_bench --sharded --grid=10000      (BASELINE.json configs[4]: one process per GPU)
 // Prints the fused device path (default: identity preconditioner, double) and, for comparison, the plain
 // operation-by-operation path (forced by passing an explicit non-identity-typed preconditioner).
 #include <cusp/coo_matrix.h>
@@ -11,8 +12,10 @@
 #include <cusp/gallery/poisson.h>
 #include <cusp/krylov/cg.h>
 #include <cusp/monitor.h>
+#include <cusp/distributed.h>
 
 #include <chrono>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -58,6 +61,81 @@ template <typename Matrix> int run(size_t grid, size_t iters, const char *name)
     return 0;
 }
 
+// BASELINE.json configs[4] through C++ only: poisson5pt(grid, grid) row-block sharded over the ranks of the job (one process per GPU,
+// started by tools/bin/cmi_launch or torchrun --no-python), cusp::multiply = exchange of x + the local hot path, cusp::krylov::cg with
+// all-reduced scalars.  Rank 0 prints: the exchange the operator chose (and the forced all-gather, the north-star exchange, beside
+// it), per-step device times from HIP events -- exchange alone, local SpMV alone, exchange + SpMV -- whole-job GFLOP/s, CG it/s.
+static double timed_us(size_t reps, const std::function<void()> &f)
+{
+    void *e0 = nullptr, *e1 = nullptr;
+    cusp::detail::check(cmi_event_create(&e0));
+    cusp::detail::check(cmi_event_create(&e1));
+    f();
+    cusp::detail::check(cmi_device_synchronize());
+    cusp::detail::check(cmi_event_record(e0, nullptr));
+    for (size_t i = 0; i < reps; i++) f();
+    cusp::detail::check(cmi_event_record(e1, nullptr));
+    float ms = 0;
+    cusp::detail::check(cmi_event_elapsed_ms(e0, e1, &ms));
+    cmi_event_destroy(e0);
+    cmi_event_destroy(e1);
+    return (double)ms * 1e3 / (double)reps;
+}
+
+static int run_sharded(size_t grid, size_t iters)
+{
+    namespace cd = cusp::distributed;
+    auto comm = cd::communicator::from_environment(true);
+    const int rank = comm->rank(), world = comm->size();
+    const size_t N = grid * grid;
+    for (int pass = 0; pass < 2; pass++) {
+        const cd::exchange_mode want = pass == 0 ? cd::exchange_mode::automatic : cd::exchange_mode::allgather;
+        cd::csr_matrix<int, double, cusp::device_memory> A(*comm);
+        cd::poisson5pt(A, grid, grid, want);
+        if (pass == 1 && A.mode() == cd::exchange_mode::allgather && world > 1) { /* automatic already chose it: measured above */ }
+        const char *mode = A.mode() == cd::exchange_mode::halo ? "halo (grouped send/recv)" : "allgather";
+        auto p = A.exchange_slice();
+        auto y = A.make_vector();
+        {
+            cusp::array1d<double, cusp::host_memory> h(A.local_rows());
+            for (size_t i = 0; i < h.size(); i++) h[i] = double((unsigned(A.row_begin() + i) * 2654435761u) % 1000u) / 997.0 - 0.5;
+            auto pv = p.local();
+            cusp::copy_array(h, pv);
+        }
+        const double t_ex = timed_us(50, [&] { A.exchange(); });
+        auto yl = y.local();
+        const double t_mul = timed_us(50, [&] { A.multiply_local(yl); });
+        const double t_both = timed_us(50, [&] { cusp::multiply(A, p, y); });
+        double worst[3] = {t_ex, t_mul, t_both};
+        comm->allreduce_max(worst, 3, cusp::host_memory());
+        const double flops = 2.0 * (double)A.num_entries;
+        if (rank == 0)
+            std::printf("sharded poisson5pt(%zu,%zu): N = %zu, %zu entries, %d rank(s); exchange: %s, %lld values received per rank (all-gather: %lld)\n"
+                        "   per step, slowest rank:  exchange %8.1f us | local SpMV %8.1f us | exchange + SpMV %8.1f us  ->  %8.1f GFLOP/s whole job\n",
+                        grid, grid, N, A.num_entries, world, mode, (long long)A.exchange_values(), (long long)A.allgather_values(), worst[0], worst[1], worst[2],
+                        flops / worst[2] * 1e-3);
+        // CG: b = the x pattern, x0 = 0, fixed iteration count (relative tolerance 0)
+        auto b = A.make_vector(), x = A.make_vector(0.0);
+        cusp::blas::copy(p, b);
+        for (int rep = 0; rep < 2; rep++) {
+            cusp::blas::fill(x, 0.0);
+            cusp::monitor<double> monitor(b, iters, 0.0, 0.0);
+            comm->barrier(cusp::device_memory());
+            const auto t0 = std::chrono::steady_clock::now();
+            cusp::krylov::cg(A, x, b, monitor);
+            cusp::detail::check(cmi_device_synchronize());
+            double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            comm->allreduce_max(&sec, 1, cusp::host_memory());
+            if (rank == 0 && rep == 1)
+                std::printf("   cusp::krylov::cg (fused, sharded): %zu iterations in %8.1f ms = %7.0f it/s, %7.1f us/iteration; final ||r|| = %.6e\n", iters, sec * 1e3,
+                            iters / sec, sec / iters * 1e6, (double)monitor.residual_norm());
+        }
+        if (world == 1 || A.mode() == cd::exchange_mode::allgather) break; // the second pass forces the all-gather beside a chosen halo exchange
+    }
+    comm->barrier(cusp::host_memory());
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     size_t grid = 3162, iters = 200;
@@ -69,8 +147,10 @@ int main(int argc, char **argv)
         if (!std::strncmp(argv[i], "--grid=", 7)) grid = std::strtoul(argv[i] + 7, nullptr, 10);
         if (!std::strncmp(argv[i], "--iterations=", 13)) iters = std::strtoul(argv[i] + 13, nullptr, 10);
         if (!std::strncmp(argv[i], "--format=", 9)) format = argv[i] + 9;
+        if (!std::strcmp(argv[i], "--sharded")) format = "sharded";
     }
     try {
+        if (format == "sharded") return run_sharded(grid, iters);
         if (format == "csr") return run<cusp::csr_matrix<int, double, cusp::device_memory>>(grid, iters, "csr");
         if (format == "ell") return run<cusp::ell_matrix<int, double, cusp::device_memory>>(grid, iters, "ell");
         if (format == "dia") return run<cusp::dia_matrix<int, double, cusp::device_memory>>(grid, iters, "dia");

@@ -58,6 +58,15 @@ def main():
         t0 = time.time()
         Ap, Aj, Ax, src = cached(name)
         rows, nnz = len(Ap) - 1, int(Ap[-1])
+        # PMC_COLS: what the x gathers cost -- the same matrix with every column index replaced by 0 (`zero`: one cache line serves every
+        # gather) or by its row's index (`row`: a gather instruction touches as few lines as y's store does); sums differ, the streams do not
+        cols_mode = os.environ.get("PMC_COLS", "")
+        if cols_mode == "zero":
+            Aj = np.zeros_like(Aj)
+        elif cols_mode == "row":
+            Aj = np.repeat(np.arange(rows, dtype=np.int32), np.diff(Ap))
+        if cols_mode:
+            name = f"{name}[cols={cols_mode}]"
         A = cmi.CsrMatrix(rows, rows, nnz, torch.from_numpy(Ap).cuda(), torch.from_numpy(Aj).cuda(), torch.from_numpy(Ax).cuda())
         x = cmi.fill_x(rows, torch.float64, "cuda")
         y = torch.empty(rows, dtype=torch.float64, device="cuda")
