@@ -25,9 +25,10 @@ from .binding import (  # noqa: F401
     csr_to_ell, csr_to_hyb_coo, csr_row_indices, coo_row_offsets, ell_to_csr, dia_to_csr, hyb_to_csr, ell_row_lengths,
     blas_axpy, blas_axpby, blas_copy, blas_fill, blas_dot, blas_dotd, blas_nrm2, blas_workspace,
     cg_update, cg_direction, cg_direction_x, HostScalar,
+    Comm, OP_SUM, OP_MAX, OP_MIN, csr_column_span,
 )
 from .matrices import (  # noqa: F401
     CsrMatrix, CooMatrix, EllMatrix, DiaMatrix, HybMatrix, multiply, poisson5pt, convert,
     csr_bytes, ell_bytes, dia_bytes, coo_bytes, fill_x,
 )
-from . import distributed, krylov  # noqa: F401,E402
+from . import binding, distributed, krylov  # noqa: F401,E402

@@ -169,6 +169,22 @@ def _declare(L):
         getattr(L, f"cmi_spmv_coo_dot_plan_{suf}").argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         getattr(L, f"cmi_spmv_csr_dot_plan_{suf}").argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.cmi_spmv_csr_dot_f32.argtypes = [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, cfgp, vp]
+    # communicator + collectives (RCCL behind the boundary)
+    L.cmi_comm_unique_id.argtypes = [vp]
+    L.cmi_comm_create.argtypes = [vp, c_int, c_int, POINTER(c_void_p)]
+    L.cmi_comm_destroy.argtypes = [vp]
+    L.cmi_comm_rank.argtypes = [vp, POINTER(c_int), POINTER(c_int)]
+    L.cmi_comm_library_version.argtypes = [POINTER(c_int)]
+    L.cmi_comm_barrier.argtypes = [vp, vp]
+    L.cmi_comm_allgather_host.argtypes = [vp, vp, vp, c_size_t, vp]
+    L.cmi_allreduce_f64.argtypes = [vp, vp, vp, i64, c_int, vp]
+    for suf in ("f64", "f32"):
+        getattr(L, f"cmi_allgather_{suf}").argtypes = [vp, vp, vp, i64, vp]
+        getattr(L, f"cmi_allgatherv_{suf}").argtypes = [vp, vp, vp, POINTER(c_int64), POINTER(c_int64), c_int, vp]
+        getattr(L, f"cmi_halo_exchange_{suf}").argtypes = [vp, vp, c_int, POINTER(c_int), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64),
+                                                          POINTER(c_int64), vp]
+    L.cmi_csr_column_span.argtypes = [i64, vp, POINTER(ctypes.c_int32), POINTER(ctypes.c_int32), vp]
+    L.cmi_csr_rebase_offsets.argtypes = [i64, vp, ctypes.c_int32, vp, vp]
 
 
 def lib():
@@ -882,6 +898,107 @@ def ipc_open(handle):
 
 def ipc_close(ptr):
     check(lib().cmi_ipc_close_handle(ptr))
+
+
+COMM_ID_BYTES = 128
+OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
+
+
+class Comm:
+    """cmi_comm: the RCCL communicator behind the C-ABI (include/cusp_mi355x.h, csrc/comm.hip) -- what the sharded SpMV / CG use for
+    their data path: all-gather of x (equal or unequal pieces), grouped send/recv halo exchange, all-reduce of CG's scalars.  Every
+    call is enqueued on the given (default: torch's current) stream.  The 128-byte unique id comes from rank 0 and reaches the other
+    ranks through `broadcast` (any out-of-band channel: a torch.distributed store here, a TCP socket in the C++ layer)."""
+
+    def __init__(self, rank, world, broadcast=None):
+        ident = ctypes.create_string_buffer(COMM_ID_BYTES)
+        if rank == 0:
+            check(lib().cmi_comm_unique_id(ident))
+        raw = ident.raw
+        if world > 1:
+            if broadcast is None:
+                raise ValueError("Comm: a multi-rank communicator needs a broadcast function for the unique id")
+            raw = broadcast(raw if rank == 0 else None)
+        self._h = c_void_p()
+        self.rank, self.world = rank, world
+        check(lib().cmi_comm_create(ctypes.create_string_buffer(raw, COMM_ID_BYTES), rank, world, byref(self._h)))
+
+    @classmethod
+    def from_torch_distributed(cls, group=None):
+        """One communicator per process group, made collectively: rank 0's id travels through torch.distributed's object broadcast
+        (control plane only -- the data path is then this communicator's)."""
+        import torch.distributed as dist
+        key = id(group) if group is not None else 0
+        if key not in _comms:
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+            def bcast(raw):
+                box = [raw]
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                return box[0]
+            _comms[key] = cls(rank, world, bcast)
+        return _comms[key]
+
+    @property
+    def handle(self):
+        return self._h
+
+    def library_version(self):
+        v = c_int()
+        check(lib().cmi_comm_library_version(byref(v)))
+        return v.value
+
+    def allgather(self, send, recv, count, stream=None):
+        """recv[r*count, +count) <- rank r's send[0, count); in place when send is recv's own slice."""
+        check(getattr(lib(), "cmi_allgather_" + _suffix(recv))(self._h, _ptr(send), _ptr(recv), int(count), _stream(stream)))
+
+    def allgatherv(self, send, recv, counts, displs, algorithm=1, stream=None):
+        c = (c_int64 * self.world)(*[int(v) for v in counts])
+        d = (c_int64 * self.world)(*[int(v) for v in displs])
+        check(getattr(lib(), "cmi_allgatherv_" + _suffix(recv))(self._h, _ptr(send), _ptr(recv), c, d, int(algorithm), _stream(stream)))
+
+    def halo_exchange(self, x_full, peers, send_lo, send_n, recv_lo, recv_n, stream=None):
+        n = len(peers)
+        arr = lambda v: (c_int64 * max(n, 1))(*[int(t) for t in v])  # noqa: E731
+        check(getattr(lib(), "cmi_halo_exchange_" + _suffix(x_full))(self._h, _ptr(x_full), n, (c_int * max(n, 1))(*peers), arr(send_lo), arr(send_n),
+                                                                     arr(recv_lo), arr(recv_n), _stream(stream)))
+
+    def allreduce(self, t, op=OP_SUM, stream=None):
+        """in-place all-reduce of a float64 device tensor (CG's scalars)"""
+        import torch
+        if t.dtype != torch.float64:
+            raise TypeError("Comm.allreduce: float64 tensors only")
+        check(lib().cmi_allreduce_f64(self._h, _ptr(t), _ptr(t), t.numel(), int(op), _stream(stream)))
+
+    def barrier(self, stream=None):
+        check(lib().cmi_comm_barrier(self._h, _stream(stream)))
+
+    def allgather_host(self, record):
+        """bytes -> list of every rank's bytes (small set-up records)"""
+        out = ctypes.create_string_buffer(len(record) * self.world)
+        check(lib().cmi_comm_allgather_host(self._h, record, out, len(record), _stream(None)))
+        return [out.raw[i * len(record):(i + 1) * len(record)] for i in range(self.world)]
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.cmi_comm_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+_comms = {}
+
+
+def csr_column_span(Aj, stream=None):
+    """(smallest, largest) column index on the device; (0, -1) for no entries."""
+    lo, hi = ctypes.c_int32(), ctypes.c_int32()
+    check(lib().cmi_csr_column_span(Aj.numel(), _ptr(Aj), byref(lo), byref(hi), _stream(stream)))
+    return lo.value, hi.value
 
 
 class CopyRanges:

@@ -217,6 +217,7 @@ typedef float __attribute__((ext_vector_type(4))) float4v;
 constexpr int kPolLoadNT = 1, kPolStoreNT = 2;
 constexpr int64_t kInfinityCacheBytes = 256ll << 20; // MALL, shared by the 8 XCDs
 constexpr int kWaveTileMaxK = 10; // csr_wave: entries per lane (= the longest row of the matrix)
+constexpr int kPolPairs = 8;   // csr_stream, f64, single-pass tile path: streams requested as (int2, double2) pairs -- every line requested once (round 3)
 constexpr int kPolStrided = 4; // csr_stream only: entry streams requested lane-strided (a dword / a value per lane per instruction), not as 16-byte vectors
 // $CMI_CSR_STRIDED=0/1 overrides the bit (measurements: A/B of the two request shapes through every tool and test)
 inline int csr_lane_strided(int policy_bits)

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(1024)
 csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__ Ap,
                   const int *__restrict__ Aj, const T *__restrict__ Ax, const T *__restrict__ x,
                   T *__restrict__ y, int rows_per_block, int64_t num_tiles, int64_t tiles_per_xcd,
-                  int swizzle, int accumulate, int tpr, int long_len, int lane_strided, int spread_rows, const T *__restrict__ w = nullptr,
+                  int swizzle, int accumulate, int tpr, int long_len, int lane_strided, int spread_rows, int pairs, const T *__restrict__ w = nullptr,
                   double *__restrict__ dot_partial = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -172,38 +172,73 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
             // wave w adds rows w, w + W, w + 2 W, ... on its lanes 0, 1, 2, ... -- so every SIMD works on the sum phase at once and an LDS
             // instruction carries nr / W lanes.  Same products, same order per row: same bits.
             int myrow = tid;
-            if (spread_rows) { const int W = block >> 6; myrow = (tid & (kWave - 1)) * W + (tid >> 6); }
+            if (spread_rows == 1) { const int W = block >> 6; myrow = (tid & (kWave - 1)) * W + (tid >> 6); }
+            else if (spread_rows == 2) { // (measurement variant: a contiguous chunk of rows per wave -- neighbouring lanes keep neighbouring rows)
+                const int W = block >> 6, chunk = (nr + W - 1) / W, l = tid & (kWave - 1);
+                myrow = l < chunk ? (tid >> 6) * chunk + l : block;
+            }
             const bool has_row = myrow < nr;
             const int a = Ap[r0 + (has_row ? myrow : nr)], b = Ap[r0 + (has_row ? myrow + 1 : nr)];
-            // IPT vectors per lane, all requested before the first product is formed (round 2: the path also serves the
-            // longer-row shapes of the table, IPT 2 and 4 -- FEM-like matrices of 27-80 entries per row)
-            int4v c[IPT];
-            T v[IPT][4];
+            // Request shape of the f64 streams.  16-BYTE VECTORS (rounds 1-2): an int4 of columns and two double2 of values per lane and
+            // vector -- the two value loads of a wave interleave, every 128-byte line of Ax is touched by both instructions.  PAIRS
+            // (round 3, `pairs`, f64 only): an int2 of columns and ONE double2 of values per lane and load, twice as many loads -- every
+            // load instruction covers one contiguous span (512 B of indices, 1 KiB of values) and every line is requested exactly once,
+            // the property of the lane-strided / wave-tile kernels; the products land in LDS 16 bytes per lane, lanes contiguous (no
+            // bank conflict; the vector form's 32-byte lane stride is a 2-way one).  Same products, same slots: same bits.
+            if (sizeof(T) == 8 && pairs) {
+                constexpr int NP = 2 * IPT;
+                int2v c2[NP];
+                double2v v2[NP];
+                const int lastp = (nz1 - 1) & ~1; // lanes past the tile's last pair re-read it and park products in their own (unread) slots
 #pragma unroll
-            for (int k = 0; k < IPT; k++) {
-                const int e = fbase + (k * block + tid) * 4;
-                if (e < nz1) {
-                    c[k] = ld<NT>(reinterpret_cast<const int4v *>(Aj + e));
-                    if constexpr (sizeof(T) == 8) {
-                        const double2v v01 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e));
-                        const double2v v23 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e + 2));
-                        v[k][0] = v01.x; v[k][1] = v01.y; v[k][2] = v23.x; v[k][3] = v23.y;
-                    } else {
-                        const float4v vv = ld<NT>(reinterpret_cast<const float4v *>(Ax + e));
-                        v[k][0] = vv.x; v[k][1] = vv.y; v[k][2] = vv.z; v[k][3] = vv.w;
-                    }
-                } else {
-                    c[k] = int4v{0, 0, 0, 0};
-                    v[k][0] = v[k][1] = v[k][2] = v[k][3] = T(0);
+                for (int k = 0; k < NP; k++) {
+                    int e = fbase + (k * block + tid) * 2;
+                    e = e < lastp ? e : lastp;
+                    c2[k] = ld<NT>(reinterpret_cast<const int2v *>(Aj + e));
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < IPT; k++) {
-                const int slot = (k * block + tid) * 4;
-                if (fbase + slot < nz1) { // (uniform per wave except at the tile's end: the gathers of a wave stay together)
-                    const T x0 = x[c[k].x], x1 = x[c[k].y], x2 = x[c[k].z], x3 = x[c[k].w];
-                    prod[slot + 0] = v[k][0] * x0; prod[slot + 1] = v[k][1] * x1;
-                    prod[slot + 2] = v[k][2] * x2; prod[slot + 3] = v[k][3] * x3;
+                for (int k = 0; k < NP; k++) {
+                    int e = fbase + (k * block + tid) * 2;
+                    e = e < lastp ? e : lastp;
+                    v2[k] = ld<NT>(reinterpret_cast<const double2v *>(Ax + e));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < NP; k++) {
+                    const double x0 = x[c2[k].x], x1 = x[c2[k].y];
+                    *reinterpret_cast<double2v *>(prod + (k * block + tid) * 2) = double2v{v2[k].x * x0, v2[k].y * x1};
+                }
+            } else {
+            // IPT vectors per lane, all requested before the first product is formed (round 2: the path also serves the
+                // longer-row shapes of the table, IPT 2 and 4 -- FEM-like matrices of 27-80 entries per row)
+                int4v c[IPT];
+                T v[IPT][4];
+    #pragma unroll
+                for (int k = 0; k < IPT; k++) {
+                    const int e = fbase + (k * block + tid) * 4;
+                    if (e < nz1) {
+                        c[k] = ld<NT>(reinterpret_cast<const int4v *>(Aj + e));
+                        if constexpr (sizeof(T) == 8) {
+                            const double2v v01 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e));
+                            const double2v v23 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e + 2));
+                            v[k][0] = v01.x; v[k][1] = v01.y; v[k][2] = v23.x; v[k][3] = v23.y;
+                        } else {
+                            const float4v vv = ld<NT>(reinterpret_cast<const float4v *>(Ax + e));
+                            v[k][0] = vv.x; v[k][1] = vv.y; v[k][2] = vv.z; v[k][3] = vv.w;
+                        }
+                    } else {
+                        c[k] = int4v{0, 0, 0, 0};
+                        v[k][0] = v[k][1] = v[k][2] = v[k][3] = T(0);
+                    }
+                }
+    #pragma unroll
+                for (int k = 0; k < IPT; k++) {
+                    const int slot = (k * block + tid) * 4;
+                    if (fbase + slot < nz1) { // (uniform per wave except at the tile's end: the gathers of a wave stay together)
+                        const T x0 = x[c[k].x], x1 = x[c[k].y], x2 = x[c[k].z], x3 = x[c[k].w];
+                        prod[slot + 0] = v[k][0] * x0; prod[slot + 1] = v[k][1] * x1;
+                        prod[slot + 2] = v[k][2] * x2; prod[slot + 3] = v[k][3] * x3;
+                    }
                 }
             }
             T wv = T(0);
@@ -597,7 +632,14 @@ csr_wavev_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t 
                  const int *__restrict__ Aj, const T *__restrict__ Ax, const T *__restrict__ x, T *__restrict__ y, int64_t num_tiles,
                  int64_t tiles_per_xcd, int swizzle, int accumulate, const T *__restrict__ w, double *__restrict__ dot_partial)
 {
-    constexpr int SLOTS = kWave * V * 4;
+    // Request shape: every load instruction of the wave covers ONE contiguous span and every 128-byte line of the streams is requested
+    // by exactly one instruction (csr_stream's f64 body asks for a lane's four values with two 16-byte loads 16 bytes apart: both
+    // instructions touch every line, which is why the nt hint COSTS that body 13-17 %, profiles/r03_long_rows_policy_sweep.txt).
+    //   f64: E = 2 entries per load -- an int2 of columns (512 B per wave instruction) and a double2 of values (1 KiB); 2 V of each
+    //   f32: E = 4 -- an int4 and a float4 (1 KiB each); V of each
+    constexpr int E = sizeof(T) == 8 ? 2 : 4, NL = (V * 4) / E, SLOTS = kWave * V * 4;
+    typedef int __attribute__((ext_vector_type(E))) idx_t;
+    typedef T __attribute__((ext_vector_type(E))) val_t;
     __shared__ __attribute__((aligned(16))) T prod[4][SLOTS];
     __shared__ double dot_slots[DOT ? 4 : 1];
     constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
@@ -611,49 +653,41 @@ csr_wavev_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t 
         const int rs = lo.x, nz0 = lo.y, re = hi.x, nz1 = hi.y; // {first row, first entry} of this tile and of the next: one scalar hop
         const int nr = re - rs;
         if (nr > 0) { // (uniform per wave)
-            const int fbase = nz0 & ~3;
+            const int fbase = nz0 & ~(E - 1);
             const int first_turn_end = Ap[rs + (nr < kWave ? nr : kWave)]; // (scalar) where the 64th row of the tile ends
             int a = Ap[rs + (lane < nr ? lane : nr)], b = 0;
             T *mine = prod[wave];
-            const bool fits = nz1 > nz0 && (int64_t)((nz1 + 3) & ~3) <= num_entries && nz1 - fbase <= SLOTS; // (uniform)
+            const bool fits = nz1 > nz0 && (int64_t)((nz1 + E - 1) & ~(E - 1)) <= num_entries && nz1 - fbase <= SLOTS; // (uniform)
             if (fits) {
-                const int last = (nz1 - 1) & ~3; // the last vector that holds an entry of the tile; lanes past it re-read it (and park
-                                                 // products in their OWN slots, which nobody reads): no branch between the requests
-                int4v c[V];
-                T v[V][4];
+                const int last = (nz1 - 1) & ~(E - 1); // the last load position that holds an entry of the tile; lanes past it re-read it (and
+                                                       // park products in their OWN slots, which nobody reads): no branch between the requests
+                idx_t c[NL];
+                val_t v[NL];
 #pragma unroll
-                for (int k = 0; k < V; k++) {
-                    int e = fbase + (k * kWave + lane) * 4;
+                for (int k = 0; k < NL; k++) {
+                    int e = fbase + (k * kWave + lane) * E;
                     e = e < last ? e : last;
-                    c[k] = ld<NT>(reinterpret_cast<const int4v *>(Aj + e));
+                    c[k] = ld<NT>(reinterpret_cast<const idx_t *>(Aj + e));
                 }
 #pragma unroll
-                for (int k = 0; k < V; k++) {
-                    int e = fbase + (k * kWave + lane) * 4;
+                for (int k = 0; k < NL; k++) {
+                    int e = fbase + (k * kWave + lane) * E;
                     e = e < last ? e : last;
-                    if constexpr (sizeof(T) == 8) {
-                        const double2v v01 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e));
-                        const double2v v23 = ld<NT>(reinterpret_cast<const double2v *>(Ax + e + 2));
-                        v[k][0] = v01.x; v[k][1] = v01.y; v[k][2] = v23.x; v[k][3] = v23.y;
-                    } else {
-                        const float4v vv = ld<NT>(reinterpret_cast<const float4v *>(Ax + e));
-                        v[k][0] = vv.x; v[k][1] = vv.y; v[k][2] = vv.z; v[k][3] = vv.w;
-                    }
+                    v[k] = ld<NT>(reinterpret_cast<const val_t *>(Ax + e));
                 }
                 __builtin_amdgcn_sched_barrier(0); // every stream request is out before the first gather address is formed
-                T xv[V][4];
+                val_t xv[NL];
 #pragma unroll
-                for (int k = 0; k < V; k++) { xv[k][0] = x[c[k].x]; xv[k][1] = x[c[k].y]; xv[k][2] = x[c[k].z]; xv[k][3] = x[c[k].w]; }
+                for (int k = 0; k < NL; k++)
+#pragma unroll
+                    for (int i = 0; i < E; i++) xv[k][i] = x[c[k][i]];
                 asm volatile("" : "+v"(a)); // the row offset was requested in front of the streams
 #pragma unroll
-                for (int k = 0; k < V; k++) {
-                    T *dst = mine + (k * kWave + lane) * 4;
-                    if constexpr (sizeof(T) == 8) {
-                        *reinterpret_cast<double2v *>(dst) = double2v{v[k][0] * xv[k][0], v[k][1] * xv[k][1]};
-                        *reinterpret_cast<double2v *>(dst + 2) = double2v{v[k][2] * xv[k][2], v[k][3] * xv[k][3]};
-                    } else {
-                        *reinterpret_cast<float4v *>(dst) = float4v{v[k][0] * xv[k][0], v[k][1] * xv[k][1], v[k][2] * xv[k][2], v[k][3] * xv[k][3]};
-                    }
+                for (int k = 0; k < NL; k++) {
+                    val_t pr;
+#pragma unroll
+                    for (int i = 0; i < E; i++) pr[i] = v[k][i] * xv[k][i];
+                    *reinterpret_cast<val_t *>(mine + (k * kWave + lane) * E) = pr; // 16 bytes per lane, lanes contiguous: no bank conflict
                 }
                 __builtin_amdgcn_wave_barrier(); // (compiler only: the hardware runs a wave's LDS instructions in order)
             }
@@ -1119,11 +1153,11 @@ static int dot_swizzle(int table_swizzle, const cmi_plan *plan, int inside_a_sol
 template <typename T, bool VEC, int POL, bool DOT = false, bool LONG = false>
 static int launch_stream_ipt(int ipt, int grid, int block, size_t lds, hipStream_t s, int64_t rows, int64_t nnz,
                              const int *Ap, const int *Aj, const T *Ax, const T *x, T *y, int rpb, int64_t tiles,
-                             int64_t tpx, int swz, int acc, int tpr, int long_len, int strided, int spread, const T *w = nullptr, double *dot_partial = nullptr)
+                             int64_t tpx, int swz, int acc, int tpr, int long_len, int strided, int spread, int pairs, const T *w = nullptr, double *dot_partial = nullptr)
 {
 #define CMI_STREAM_LAUNCH(IPT)                                                                                              \
     hipLaunchKernelGGL((csr_stream_kernel<T, IPT, VEC, POL, DOT, LONG>), dim3(grid), dim3(block), lds, s, rows, nnz, Ap, Aj, \
-                       Ax, x, y, rpb, tiles, tpx, swz, acc, tpr, long_len, strided, spread, w, dot_partial)
+                       Ax, x, y, rpb, tiles, tpx, swz, acc, tpr, long_len, strided, spread, pairs, w, dot_partial)
     switch (ipt) {
     case 1: CMI_STREAM_LAUNCH(1); break;
     case 2: CMI_STREAM_LAUNCH(2); break;
@@ -1231,11 +1265,17 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         // any row, one lane or lane group at a time -- correct, slow on a long row)
         const bool lng = long_len > 0 && nnz >= long_len && known_max_len >= long_len;
         const int strided = csr_lane_strided(c.nontemporal);
-        // row sums dealt round the waves when the tile's rows fill at most half of its lanes (long rows); $CMI_CSR_SPREAD=0/1 overrides
-        static const int spread_env = [] { const char *e = std::getenv("CMI_CSR_SPREAD"); return e ? std::atoi(e) : -1; }();
-        const int spread = spread_env >= 0 ? spread_env : (tpr == 1 && 2 * rpb <= block && block >= 128);
+        // row sums dealt round the waves ($CMI_CSR_SPREAD=1: row r -> wave r % W; =2: a contiguous chunk of rows per wave): MEASURED SLOWER on
+        // the long-row matrices it was meant for (ldoor-like 100 -> 110 us, nlpkkt120-like 213 -> 236 / 218 us, profiles/r03_long_rows_experiments.txt)
+        // -- lane r adds row r stays the default; the switch stays for measurements
+        static const int spread_env = [] { const char *e = std::getenv("CMI_CSR_SPREAD"); return e ? std::atoi(e) : 0; }();
+        const int spread = tpr == 1 ? spread_env : 0;
+        // f64 streams requested as (int2, double2) pairs instead of 16-byte vectors in the single-pass tile path: $CMI_CSR_PAIRS=0/1, else the
+        // config's policy bit kPolPairs
+        static const int pairs_env = [] { const char *e = std::getenv("CMI_CSR_PAIRS"); return e ? std::atoi(e) : -1; }();
+        const int pairs = pairs_env >= 0 ? pairs_env : ((c.nontemporal & kPolPairs) != 0);
 #define CMI_STREAM_GO(VEC_, DOT_, LONG_, ...) \
-    launch_stream_ipt<T, VEC_, POL, DOT_, LONG_>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate, tpr, long_len, strided, spread, ##__VA_ARGS__)
+    launch_stream_ipt<T, VEC_, POL, DOT_, LONG_>(ipt, (int)grid64, block, lds, s, rows, nnz, Ap, Aj, Ax, x, y, rpb, tiles, tpx, swz, accumulate, tpr, long_len, strided, spread, pairs, ##__VA_ARGS__)
         with_policy(pol, [&](auto P) {
             constexpr int POL = decltype(P)::value;
             if (dot) {

@@ -69,11 +69,18 @@ class ExchangePlan:
 class ShardedVectorExchange:
     """Owns the full-length x buffer of one rank and fills it before a multiply."""
 
-    def __init__(self, num_cols, rank, world, col_min, col_max, dtype, device, mode="auto", group=None, offsets=None):
+    def __init__(self, num_cols, rank, world, col_min, col_max, dtype, device, mode="auto", group=None, offsets=None, comm=None):
         import torch
         import torch.distributed as dist
         self.dist, self.torch = dist, torch
         self.rank, self.world, self.group = rank, world, group
+        # DATA PATH: the product's communicator (binding.Comm = cmi_comm: RCCL behind the C-ABI) whenever the vectors are in HBM and
+        # the job really has one process per GPU (torch.distributed's "nccl" backend, or a communicator handed in); torch.distributed
+        # then only carries set-up records.  The gloo rehearsals (ranks sharing a GPU, CPU tests) keep the injected host transport.
+        self.comm = comm
+        if comm is None and world > 1 and torch.device(device).type == "cuda" and dist.is_initialized() and dist.get_backend(group) == "nccl":
+            from . import binding as B
+            self.comm = B.Comm.from_torch_distributed(group)
         self.num_cols = num_cols
         self._span = (col_min, col_max)
         # the partition of x (= of the rows): equal counts by default, any monotone cut list on request
@@ -225,7 +232,10 @@ class ShardedVectorExchange:
         if self.x_full.is_cuda:
             self.torch.cuda.current_stream(self.x_full.device).synchronize()
         if self.world > 1:
-            self.dist.barrier(group=self.group)
+            if self.comm is not None:
+                self.comm.barrier()
+            else:
+                self.dist.barrier(group=self.group)
 
     def close(self):
         """Unmap the peers' buffers (collective by convention: call it on every rank before the buffers die)."""
@@ -255,9 +265,13 @@ class ShardedVectorExchange:
     def start(self):
         """Begin filling x_full (asynchronous on the communication stream); returns the work handles.
         x_local must already hold the fresh slice."""
-        if self.world == 1:
+        if self.world == 1 and self.comm is None:
             return []
         dist, plan = self.dist, self.plan
+        if self.comm is not None and plan.mode in ("allgather", "halo"):
+            return self._start_comm()
+        if self.world == 1:
+            return []
         if plan.mode == "peer":
             for c in self._pulls:  # one launch (16 ranges each) on the caller's stream; nothing to wait for
                 c.launch()
@@ -289,6 +303,24 @@ class ShardedVectorExchange:
             if self._gather_in is None:
                 self._gather_in = self.torch.zeros(self.count, dtype=self.x_full.dtype, device=self.x_full.device)
             return self.start()
+
+    def _start_comm(self):
+        """The exchange through the product's communicator (cmi_allgather_* / cmi_allgatherv_* / cmi_halo_exchange_*): enqueued on the
+        compute stream, nothing to wait for on the host."""
+        plan = self.plan
+        if plan.mode == "allgather":
+            if self.uniform:  # in place: this rank's slice already sits at its place in the buffer
+                self.comm.allgather(self.x_full[self.lo:], self.x_full, self.count)
+            else:
+                counts = [b - a for a, b in zip(self.offsets, self.offsets[1:])]
+                self.comm.allgatherv(self.x_full[self.lo:], self.x_full, counts, self.offsets[:-1])
+            return []
+        if getattr(self, "_halo_args", None) is None:
+            peers = [p for p in range(self.world) if p != self.rank and (plan.recv[p][1] > plan.recv[p][0] or plan.send[p][1] > plan.send[p][0])]
+            self._halo_args = (peers, [plan.send[p][0] for p in peers], [plan.send[p][1] - plan.send[p][0] for p in peers],
+                               [plan.recv[p][0] for p in peers], [plan.recv[p][1] - plan.recv[p][0] for p in peers])
+        self.comm.halo_exchange(self.x_full, *self._halo_args)
+        return []
 
     def _unpad_gathered(self):
         item = self.x_full.element_size()
@@ -323,7 +355,7 @@ class ShardedCsr:
     exchange logic without a GPU.)"""
 
     def __init__(self, A_local, num_cols, rank, world, mode="auto", group=None, local_multiply=None,
-                 col_span=None, overlap=True, interior=None, offsets=None):
+                 col_span=None, overlap=True, interior=None, offsets=None, comm=None):
         import torch
         self.A = A_local
         self.rank, self.world = rank, world
@@ -334,7 +366,7 @@ class ShardedCsr:
             else:
                 col_span = (0, -1)
         self.vec = ShardedVectorExchange(num_cols, rank, world, col_span[0], col_span[1], A_local.values.dtype, dev,
-                                         mode=mode, group=group, offsets=offsets)
+                                         mode=mode, group=group, offsets=offsets, comm=comm)
         if A_local.num_rows != self.vec.hi - self.vec.lo:
             raise ValueError(f"rank {rank}: local block has {A_local.num_rows} rows, partition expects "
                              f"{self.vec.hi - self.vec.lo}")
@@ -351,7 +383,7 @@ class ShardedCsr:
         # positions in the shared column/value arrays), so the split needs no copy and no new kernel.
         self.interior = None
         self._cfg = None
-        if overlap and world > 1 and self.vec.plan.mode == "halo" and not self._custom:
+        if overlap and world > 1 and self.vec.plan.mode == "halo" and not self._custom and self.vec.comm is None:
             self.interior = interior if interior is not None else self._interior_rows()
             from . import binding as B
             self._cfg = B.tuning_select(B.FORMAT_CSR, B.F64 if A_local.values.dtype == torch.float64 else B.F32,
@@ -408,7 +440,7 @@ class ShardedCsr:
         rank calls it).  krylov.cg keeps its residual in one so that peers can pull its boundary values."""
         v = self.vec
         return ShardedVectorExchange(v.num_cols, v.rank, v.world, v._span[0], v._span[1], v.x_full.dtype, v.x_full.device,
-                                     mode=v.plan.mode, group=v.group, offsets=v.offsets)
+                                     mode=v.plan.mode, group=v.group, offsets=v.offsets, comm=v.comm)
 
     def halo_ranges(self):
         """[lo, hi) of this rank's slice merged with the ranges it receives: the contiguous pieces of the

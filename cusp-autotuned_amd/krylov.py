@@ -45,19 +45,26 @@ class Monitor:
 class _Ops:
     """dot / norm with the cross-rank reduction folded in."""
 
-    def __init__(self, device, group, world):
+    def __init__(self, device, group, world, comm=None):
         import torch
         from . import binding as B
         self.B, self.torch = B, torch
         self.ws = B.blas_workspace(device)
         self.res = torch.zeros(1, dtype=torch.float64, device=device)
-        self.group, self.world = group, world
+        self.group, self.world, self.comm = group, world, comm
+
+    def reduce(self, t):
+        """sum of a float64 device scalar over the ranks, in place: cmi_allreduce_f64 through the product's communicator when the
+        sharded operator carries one (one process per GPU), torch.distributed in the rehearsals"""
+        if self.comm is not None:
+            self.comm.allreduce(t)
+        elif self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, group=self.group)
 
     def dot(self, x, y):
         self.B.blas_dotd(x, y, self.res, self.ws)  # a double in device memory, f64 or f32 vectors
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.res, group=self.group)
+        self.reduce(self.res)
         return float(self.res.item())
 
     def nrm2(self, x):
@@ -84,7 +91,7 @@ def cg(A, x, b, monitor=None, iteration_limit=500, relative_tolerance=1e-5, abso
     world = A.world if sharded else 1
     n = x.numel()
     dev = x.device
-    ops = _Ops(dev, group, world)
+    ops = _Ops(dev, group, world, comm=A.vec.comm if sharded else None)
     if monitor is None:
         monitor = Monitor(ops.nrm2(b), iteration_limit, relative_tolerance, absolute_tolerance)
 
@@ -161,10 +168,7 @@ def _cg_fused(A, x, b, monitor, ops, spmv, y, r, p, world, group):
     rr_host = B.HostScalar() if dev.type == "cuda" else _SyncScalar()
     mirror = rr_host if world == 1 and dev.type == "cuda" else None  # sharded: <r,r> is all-reduced first
 
-    def reduce_(t):
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(t, group=group)
+    reduce_ = ops.reduce
 
     # fold-ahead (single GPU, CSR through its plan): the partials of <y,p> stay in the workspace and cmi_cg_update_fold_* folds
     # them itself, <r,r> likewise at the front of the direction kernel: three launches per iteration.  Opt-in

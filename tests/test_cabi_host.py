@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol(cmi):
 
 def test_version_and_status_strings(cmi):
     L = cmi.lib()
-    assert cmi.version() == 200
+    assert cmi.version() == 300
+    assert L.cmi_status_string(7) == b"CMI_ERROR_COMM"
     assert L.cmi_status_string(0) == b"CMI_SUCCESS"
     assert L.cmi_status_string(1) == b"CMI_ERROR_INVALID_VALUE"
     assert L.cmi_status_string(99) == b"CMI_ERROR_UNKNOWN"
@@ -54,6 +55,33 @@ def test_argument_validation_fails_before_touching_the_gpu(cmi):
     with pytest.raises(cmi.CmiError) as e:
         cmi.check(L.cmi_blas_axpy_f64(-5, 1.0, None, None, None))
     assert e.value.status == 1
+
+
+def test_communicator_entry_points_validate_before_touching_rccl_or_the_gpu(cmi):
+    """cmi_comm_* / collectives (cmi_allgather_f64, cmi_allreduce_f64): null communicators, bad ranks and bad
+    reduction ops come back as CMI_ERROR_INVALID_VALUE with a message; the unique id is RCCL's 128 bytes (run-time bound:
+    librccl is only loaded by the first call that needs it)."""
+    import ctypes
+    L = cmi.lib()
+    assert L.cmi_comm_create(None, 0, 1, ctypes.byref(ctypes.c_void_p())) == 1
+    ident = ctypes.create_string_buffer(128)
+    assert L.cmi_comm_create(ident, 2, 2, ctypes.byref(ctypes.c_void_p())) == 1 and b"rank" in L.cmi_last_error()
+    assert L.cmi_comm_create(ident, 0, 0, ctypes.byref(ctypes.c_void_p())) == 1
+    assert L.cmi_comm_create(ident, 0, 1, None) == 1
+    assert L.cmi_allgather_f64(None, None, None, 4, None) == 1 and b"communicator" in L.cmi_last_error()
+    assert L.cmi_allgatherv_f32(None, None, None, None, None, 0, None) == 1
+    assert L.cmi_halo_exchange_f64(None, None, 0, None, None, None, None, None, None) == 1
+    assert L.cmi_allreduce_f64(None, None, None, 1, 0, None) == 1
+    assert L.cmi_comm_barrier(None, None) == 1
+    assert L.cmi_comm_allgather_host(None, None, None, 8, None) == 1
+    assert L.cmi_comm_rank(None, None, None) == 1
+    assert L.cmi_comm_destroy(None) == 0
+    assert L.cmi_comm_unique_id(None) == 1
+    assert L.cmi_plan_validate(None, None, None, None, ctypes.byref(ctypes.c_int())) == 1
+    lo, hi = ctypes.c_int32(5), ctypes.c_int32(5)
+    assert L.cmi_csr_column_span(0, None, ctypes.byref(lo), ctypes.byref(hi), None) == 0 and (lo.value, hi.value) == (0, -1)
+    assert L.cmi_csr_column_span(-1, None, ctypes.byref(lo), ctypes.byref(hi), None) == 1
+    assert L.cmi_csr_rebase_offsets(3, None, 0, None, None) == 1
 
 
 def test_argument_validation_of_the_newer_entry_points(cmi):

@@ -213,3 +213,179 @@ def test_fold_handoff_stress(cmi, torch_cuda):
     assert len(set(vals)) == 1, f"the fold returned {len(set(vals))} different values"
     host = float((r.double() * r.double()).sum())
     assert abs(vals[0] - host) <= 1e-10 * host
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[3] at FULL SIZE: nlpkkt120 / ldoor / thermal2 -- the real files when CMI_SUITESPARSE_DIR
+# has them (dimensions from the file), else the seeded stand-ins at scale 1.0 with the collection's published row-length range.
+# The sweep being replaced: performance/csr_vector/csr_vector.cu:41-62,86-110 (THREADS_PER_VECTOR over the testing/UF downloads).
+# ------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["thermal2", "ldoor", "nlpkkt120"])
+def test_configs3_full_size_every_csr_variant(cmi, torch_cuda, orc, name):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import suitesparse_like as ssl
+    torch = torch_cuda
+    Ap, Aj, Ax, source = ssl.load(name, 1.0)
+    st, pub = ssl.stats(Ap, Aj), ssl.PUBLISHED[name]
+    print(f"{name}: {source}: {st}")
+    if source.startswith("seeded"):
+        print(f"{name}: CMI_SUITESPARSE_DIR has no {name}.mtx -- real-file branch SKIPPED, stand-in used (published: {pub})")
+        assert (st["min"], st["max"]) == (pub["min"], pub["max"]), (st, pub)  # the published row-length extremes, exactly
+        assert abs(st["mean"] - pub["mean"]) <= 0.08 * pub["mean"] and abs(st["rows"] - pub["rows"]) <= 0.03 * pub["rows"], (st, pub)
+    rows = cols = st["rows"]
+    nnz = st["entries"]
+    x = orc.fill_x(cols)
+    want = orc.spmv_csr(Ap, Aj, Ax, x, omp=True)                       # the OpenMP oracle: per-row arithmetic = the sequential loop's
+    bound = np.maximum(orc.spmv_csr(Ap, Aj, np.abs(Ax), np.abs(x), omp=True), 1e-300)
+    dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+    y = torch.empty(rows, dtype=torch.float64, device="cuda")
+
+    def check(label, exact):
+        got = y.cpu().numpy()
+        if exact:
+            assert np.array_equal(got, want), f"{name} {label}: not bit-identical to the host loop"
+        else:
+            assert np.all(np.abs(got - want) <= 1e-6 * bound), f"{name} {label}: beyond 1e-6"
+
+    def run(label, cfg, exact):
+        y.fill_(10.0)
+        cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, cfg=cfg)
+        check(label, exact)
+
+    run("csr_scalar", cmi.Config(kernel=cmi.CSR_SCALAR), True)
+    for tpr in (2, 4, 8, 16, 32, 64):                                  # the reference's sweep
+        run(f"csr_vector T={tpr}", cmi.Config(kernel=cmi.CSR_VECTOR, threads_per_row=tpr), False)
+    for tpr, ipt in ((1, 1), (1, 2), (1, 4), (4, 2), (16, 1)):
+        run(f"csr_stream lanes/row={tpr} vectors/lane={ipt}", cmi.Config(kernel=cmi.CSR_STREAM, threads_per_row=tpr, items_per_thread=ipt), tpr == 1)
+    run("csr_stream lane-strided", cmi.Config(kernel=cmi.CSR_STREAM, threads_per_row=1, nontemporal=4 | 2), True)
+    run("csr_balanced", cmi.Config(kernel=cmi.CSR_BALANCED), False)
+    run("table (NULL config)", None, True)
+    # plans: the default, the wave-private vector kernel, the 16-bit column copy where it is granted, sorted COO through its plan
+    plan = cmi.Plan(cmi.FORMAT_CSR, torch.float64, rows, cols, nnz, dAp)
+    assert plan.info()["max_row_length"] == st["max"] and plan.info()["storage_order_sums"]
+    y.fill_(10.0)
+    cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
+    check("plan", True)
+    for v in (0, 2, 4) if name != "thermal2" else (0, 1, 2):
+        pv = cmi.Plan(cmi.FORMAT_CSR, torch.float64, rows, cols, nnz, dAp, cmi.Config(kernel=cmi.CSR_STREAM_WAVEV, items_per_thread=v))
+        assert pv.config().kernel == cmi.CSR_STREAM_WAVEV
+        y.fill_(10.0)
+        cmi.spmv_csr_plan(pv, dAp, dAj, dAx, dx, y)
+        check(f"csr_wavev V={v}", True)
+    if name == "thermal2":
+        pw = cmi.Plan(cmi.FORMAT_CSR, torch.float64, rows, cols, nnz, dAp, cmi.Config(kernel=cmi.CSR_STREAM_WAVE, rows_per_block=-1))
+        y.fill_(10.0)
+        cmi.spmv_csr_plan(pw, dAp, dAj, dAx, dx, y)
+        check("csr_wave on a row partition", True)
+    p16 = cmi.Plan.csr(torch.float64, rows, cols, dAp, dAj, cfg=cmi.Config(kernel=cmi.CSR_STREAM_C16))
+    y.fill_(10.0)
+    cmi.spmv_csr_plan(p16, dAp, dAj, dAx, dx, y)
+    check(f"16-bit column plan (granted: {p16.config().kernel == cmi.CSR_STREAM_C16})", True)
+    dAi = torch.empty(nnz, dtype=torch.int32, device="cuda")
+    cmi.check(cmi.lib().cmi_csr_row_indices(rows, ctypes.c_void_p(dAp.data_ptr()), ctypes.c_void_p(dAi.data_ptr()), None))
+    cplan = cmi.Plan(cmi.FORMAT_COO, torch.float64, rows, cols, nnz, dAi)
+    y.fill_(10.0)
+    cmi.spmv_coo_plan(cplan, dAi, dAj, dAx, dx, y)
+    check("sorted COO through its plan", True)
+    # the containers' own path (cusp::multiply's mirror): plan made at the first multiply
+    A = cmi.CsrMatrix(rows, cols, nnz, dAp, dAj, dAx)
+    y.fill_(10.0)
+    cmi.multiply(A, dx, y)
+    check("multiply(A, x, y)", True)
+
+
+def test_python_comm_one_rank_through_rccl(cmi, torch_cuda, orc):
+    """binding.Comm (cmi_comm: RCCL behind the C-ABI) with ONE rank -- the calls the sharded SpMV / CG make on an 8-GPU node:
+    in-place all-gather, all-gather of unequal pieces (both algorithms), all-reduce, barrier, host records; then a ShardedCsr and
+    krylov.cg carried by that communicator instead of torch.distributed, against the single-GPU results."""
+    torch = torch_cuda
+    comm = cmi.binding.Comm(0, 1)
+    assert comm.library_version() > 20000
+    v = torch.arange(1000, dtype=torch.float64, device="cuda")
+    comm.allgather(v, v, 1000)
+    w = torch.zeros(1000, dtype=torch.float64, device="cuda")
+    comm.allgatherv(v, w, [1000], [0], algorithm=0)
+    comm.allgatherv(v[:500], w[:], [500], [0], algorithm=1)
+    s = torch.tensor([2.5, -1.0], dtype=torch.float64, device="cuda")
+    comm.allreduce(s)
+    comm.allreduce(s, op=cmi.binding.OP_MAX)
+    comm.barrier()
+    assert torch.equal(w, v) and s.tolist() == [2.5, -1.0]
+    assert comm.allgather_host(b"abcdefgh") == [b"abcdefgh"]
+    f = torch.arange(64, dtype=torch.float32, device="cuda")
+    comm.allgather(f, f, 64)
+    comm.halo_exchange(v, [], [], [], [], [])
+    # the sharded operator + CG on that communicator (world 1: the exchange is RCCL's one-rank all-gather)
+    m, n = 97, 83
+    N = m * n
+    A = cmi.poisson5pt(m, n, "csr")
+    sh = cmi.distributed.ShardedCsr(A, N, 0, 1, mode="allgather", comm=comm)
+    assert sh.vec.comm is comm
+    x = cmi.fill_x(N).cuda()
+    sh.x_local.copy_(x)
+    y = torch.empty(N, dtype=torch.float64, device="cuda")
+    sh.multiply(y)
+    Ap, Aj, Ax = orc.poisson5pt_csr(m, n)
+    assert np.array_equal(y.cpu().numpy(), orc.spmv_csr(Ap, Aj, Ax, orc.fill_x(N)))
+    b = torch.ones(N, dtype=torch.float64, device="cuda")
+    x1, x2 = torch.zeros_like(b), torch.zeros_like(b)
+    mon1 = cmi.krylov.cg(sh, x1, b, iteration_limit=400, relative_tolerance=1e-8)
+    mon2 = cmi.krylov.cg(A, x2, b, iteration_limit=400, relative_tolerance=1e-8)
+    assert mon1.iteration_count == mon2.iteration_count and mon1.converged()
+    assert torch.allclose(x1, x2, rtol=0, atol=1e-10)
+    comm.close()
+
+
+def test_every_entry_of_the_shipped_tuning_table_against_the_oracle(cmi, torch_cuda, orc):
+    """the shipped table (cusp-autotuned_amd/tuned/gfx950.json) is loaded as data and EVERY entry -- format x
+    value type x bucket -- is run, as an explicit config, on a matrix of its bucket's width and compared with the oracle (the
+    validation pattern of the reference's testing/ktt.cu:142-202: reference y first, then every configuration against it).
+    One-lane-per-row shapes must have the host loop's bits; lane groups 1e-6 (f64) / 1e-5 (f32) of the row's |a||x| sum."""
+    import json
+    torch = torch_cuda
+    table = json.load(open(os.path.join(os.path.dirname(cmi.lib_path()), "..", "tuned", "gfx950.json")))
+    entries = table["entries"]
+    assert len(entries) >= 80
+    seen = set()
+    for e in entries:
+        fmt, tag, bucket = e["format"], e["dtype"], e["bucket"]
+        seen.add((fmt, tag, bucket))
+        dtype, tdt = (np.float64, torch.float64) if tag == "f64" else (np.float32, torch.float32)
+        width = max(1, int(round(e["mean"])))
+        rows = 6000 if width <= 40 else 2500
+        rng = np.random.default_rng(1000 * bucket + len(fmt))
+        # banded: near diagonals and a few far ones (every format can hold it; DIA needs few distinct offsets)
+        offs = sorted({0} | {(-1) ** k * ((k + 1) // 2) * (1 if k < 4 else 37) for k in range(1, width)})
+        while len(offs) < width:
+            offs.append(max(offs) + 37)
+        r = np.arange(rows, dtype=np.int64)
+        cols2 = r[:, None] + np.array(offs, np.int64)[None, :]
+        mask = (cols2 >= 0) & (cols2 < rows)
+        Ap = np.r_[0, np.cumsum(mask.sum(axis=1))].astype(np.int32)
+        Aj = cols2[mask].astype(np.int32)
+        Ax = rng.standard_normal(len(Aj)).astype(dtype)
+        x = rng.standard_normal(rows).astype(dtype)
+        want = orc.spmv_csr(Ap, Aj, Ax, x)
+        bound = np.maximum(orc.spmv_csr(Ap, Aj, np.abs(Ax), np.abs(x)), 1e-30)
+        cfg = cmi.Config(**{k: e[k] for k in ("kernel", "block_size", "threads_per_row", "rows_per_block", "items_per_thread", "nontemporal", "xcd_swizzle", "blocks_per_cu")})
+        A = cmi.CsrMatrix(rows, rows, len(Aj), dev(Ap, torch), dev(Aj, torch), dev(Ax, torch))
+        M = A if fmt == "csr" else cmi.convert(A, {"coo_sorted": "coo"}.get(fmt, fmt))
+        y = torch.full((rows,), 10.0, dtype=tdt, device="cuda")
+        cmi.multiply(M, dev(x, torch), y, cfg=cfg)
+        got = y.cpu().numpy()
+        exact = (fmt == "csr" and e["kernel"] in (cmi.CSR_SCALAR, cmi.CSR_STREAM, cmi.CSR_STREAM_PIPE) and e["threads_per_row"] <= 1) or \
+                (fmt == "ell" and e["threads_per_row"] == 1) or fmt == "dia" or e["kernel"] == cmi.COO_TILE
+        if exact:
+            assert np.array_equal(got, want), (fmt, tag, bucket, e)
+        else:
+            tol = 1e-6 if tag == "f64" else 1e-5
+            assert np.all(np.abs(got - want) <= tol * bound), (fmt, tag, bucket, e)
+        # and what a NULL config selects for this shape is this entry (the table is what the library consults)
+        sel = cmi.tuning_select({"csr": 0, "ell": 1, "dia": 2, "coo": 3, "coo_sorted": cmi.TABLE_COO_SORTED}[fmt], cmi.F64 if tag == "f64" else cmi.F32,
+                                rows, rows, len(Aj) if fmt in ("csr", "coo", "coo_sorted") else rows * width)
+        assert sel.kernel == e["kernel"] or fmt == "csr", (fmt, tag, bucket, sel, e)
+    assert len(seen) == len(entries), "duplicate (format, dtype, bucket) keys in the shipped table"
+    for fmt in ("csr", "ell", "dia", "coo", "coo_sorted"):
+        for tag in ("f64", "f32"):
+            assert {b for f, t, b in seen if f == fmt and t == tag} == set(range(8)), (fmt, tag)

@@ -83,11 +83,18 @@ def csr_space(cmi, mean, quick, stream_only=False):
     return out
 
 
-def ell_space(cmi, quick):
+def ell_space(cmi, quick, width=0):
     # xcd_swizzle: tiles (one workgroup's rows) dealt to the XCDs in chunks, so that a chunk's x window lands in one L2
-    return [cmi.Config(kernel=cmi.ELL_ROW, block_size=b, items_per_thread=r, nontemporal=nt, xcd_swizzle=swz)
-            for b, r, nt, swz in itertools.product((256,) if quick else (128, 256, 512, 1024), (1, 2), (0, 1, 2, 3),
-                                                   (0, 32) if quick else (0, 8, 16, 32, 64, 128))]
+    out = [cmi.Config(kernel=cmi.ELL_ROW, block_size=b, items_per_thread=r, threads_per_row=1 if width else 0, nontemporal=nt, xcd_swizzle=swz)
+           for b, r, nt, swz in itertools.product((256,) if quick else (128, 256, 512, 1024), (1, 2), (0, 1, 2, 3),
+                                                  (0, 32) if quick else (0, 8, 16, 32, 64, 128))]
+    # per-bucket tuning (round 3): the lanes-per-row axis of the reference's THREADS_PER_ROW (ktt/kernels/ell_kernel.h:102-109) for
+    # wide rows -- 2..16 lanes per row (re-associated sums, <= 1e-6), each lane keeping at least 4 slots
+    for tpr in (2, 4, 8, 16):
+        if width and width >= 4 * tpr:
+            out += [cmi.Config(kernel=cmi.ELL_ROW, block_size=b, items_per_thread=1, threads_per_row=tpr, nontemporal=nt, xcd_swizzle=swz)
+                    for b, nt, swz in itertools.product((256,) if quick else (256, 512), (1, 3), (0, 32))]
+    return out
 
 
 def dia_space(cmi, quick):
@@ -237,6 +244,8 @@ def main():
     ap.add_argument("--synthetic-rows", type=int, default=1_000_000, help="rows of the seeded synthetic CSR matrices (8e6: their streams no longer fit the 256 MiB Infinity Cache)")
     ap.add_argument("--csr-max-mean", type=float, default=1e9, help="CSR: skip the tuning matrices with more entries per row than this")
     ap.add_argument("--merge", action="store_true", help="start from the table at --out (tune some formats, keep the others)")
+    ap.add_argument("--per-bucket", action="store_true", help="ELL / DIA / COO: a tuning matrix per bucket of the table (width 1.2 x 2^b), not the "
+                                                             "headline matrix's shape replicated over all eight")
     args = ap.parse_args()
 
     import torch
@@ -340,6 +349,92 @@ def main():
             print(label, best2, f"{ms2 * 1e3:.1f} us", flush=True)
             del C
         del A
+
+        # ---- per-bucket tuning of ELL / DIA / COO (the table held ONE shape per format replicated over its eight
+        #      buckets).  Bucket b (mean 1.2 x 2^b entries per row) gets a banded matrix of that width -- near diagonals plus far
+        #      ones a thousand rows apart, like a stencil's -- sized for ~600 MB of ELL slots (beyond the Infinity Cache) where the
+        #      row count allows; bucket 2 keeps the headline matrix.  Parameter spaces being replaced: cusp/system/cuda/ktt/
+        #      {ell_multiply.h:20-77, dia_multiply.h:24-55, coo_multiply.h:22-54}; validation as testing/ktt.cu:142-202.
+        if args.per_bucket and any(f in formats for f in ("ell", "dia", "coo")):
+            for b in range(0, 8):
+                if b == 2:
+                    continue  # the headline matrix above
+                width = max(1, int(round(1.2 * 2.0 ** b)))
+                rows_b = int(min(1.0e7, max(2.0e5, 5.0e7 / width))) if not args.quick else 100_000
+                offs = sorted({0} | {(-1) ** k * ((k + 1) // 2) * (1 if k < 4 else 1000) for k in range(1, width)})
+                while len(offs) < width:
+                    offs = sorted(set(offs) | {max(offs) + 1000})
+                r = np.arange(rows_b, dtype=np.int64)
+                cols_b = r[:, None] + np.array(offs, np.int64)[None, :]
+                mask = (cols_b >= 0) & (cols_b < rows_b)
+                Ap_b = np.zeros(rows_b + 1, np.int32)
+                Ap_b[1:] = np.cumsum(mask.sum(axis=1))
+                Aj_b = cols_b[mask].astype(np.int32)
+                Ax_b = np.random.default_rng(100 + b).standard_normal(len(Aj_b)).astype(ndt)
+                S = cmi.CsrMatrix(rows_b, rows_b, len(Aj_b), torch.from_numpy(Ap_b).cuda(), torch.from_numpy(Aj_b).cuda(), torch.from_numpy(Ax_b).cuda())
+                dxs = cmi.fill_x(rows_b, tdt, "cuda")
+                ys = torch.empty(rows_b, dtype=tdt, device="cuda")
+                cmi.multiply(S, dxs, ys, cfg=scalar)
+                wants = ys.cpu().numpy()
+                Sabs = cmi.CsrMatrix(rows_b, rows_b, len(Aj_b), S.row_offsets, S.column_indices, S.values.abs())
+                cmi.multiply(Sabs, dxs.abs(), ys, cfg=scalar)
+                bound_b = np.maximum(ys.cpu().numpy(), 1e-30)
+                del Sabs
+
+                def checker_b(mat, exact_kernels):
+                    def check(cfg):
+                        ys.fill_(10.0)
+                        cmi.multiply(mat, dxs, ys, cfg=cfg)
+                        got = ys.cpu().numpy()
+                        if cfg.kernel in exact_kernels and cfg.threads_per_row <= 1:
+                            return bool(np.array_equal(got, wants)), "bit-exact required"
+                        return bool(np.all(np.abs(got - wants) <= tol * bound_b)), f"tolerance {tol}"
+                    return check
+                mean_b = len(Aj_b) / rows_b
+                name_b = f"banded{width}_rows{rows_b}"
+                print(f"bucket {b}: {name_b}: {len(Aj_b)} entries ({mean_b:.2f}/row)", flush=True)
+                if "ell" in formats:
+                    E = cmi.convert(S, "ell")
+                    label = f"ell/{tag}/{name_b}"
+                    best, ms, res = tune_one(cmi, torch, timer, label, ell_space(cmi, args.quick, width), lambda cfg: cmi.multiply(E, dxs, ys, cfg=cfg),
+                                             checker_b(E, (cmi.ELL_ROW,)), args.iters, args.rounds, log, cmi.ell_bytes(rows_b, E.num_entries_per_row, E.pitch, vb))
+                    if best is not None:
+                        if best.threads_per_row == 1:
+                            best.threads_per_row = 0  # one lane per row won on this (many-row) matrix: the few-row rule stays in force
+                        cmi.tuning_set(cmi.FORMAT_ELL, dcode, mean_b, best)
+                        summary.append((label, best.as_dict(), ms))
+                        print(label, best, f"{ms * 1e3:.1f} us", flush=True)
+                    del E
+                if "dia" in formats:
+                    D = cmi.convert(S, "dia")
+                    label = f"dia/{tag}/{name_b}"
+                    best, ms, res = tune_one(cmi, torch, timer, label, dia_space(cmi, args.quick), lambda cfg: cmi.multiply(D, dxs, ys, cfg=cfg),
+                                             checker_b(D, (cmi.DIA_ROW,)), args.iters, args.rounds, log, cmi.dia_bytes(rows_b, width, D.pitch, vb))
+                    if best is not None:
+                        cmi.tuning_set(cmi.FORMAT_DIA, dcode, mean_b, best)
+                        summary.append((label, best.as_dict(), ms))
+                        print(label, best, f"{ms * 1e3:.1f} us", flush=True)
+                    del D
+                if "coo" in formats:
+                    C = cmi.convert(S, "coo")
+                    space = coo_space(cmi, args.quick)
+                    label = f"coo/{tag}/{name_b}"
+                    best, ms, res = tune_one(cmi, torch, timer, label, [c for c in space if c.kernel != cmi.COO_TILE], lambda cfg: cmi.multiply(C, dxs, ys, cfg=cfg),
+                                             checker_b(C, (cmi.COO_TILE,)), args.iters, args.rounds, log, cmi.coo_bytes(rows_b, len(Aj_b), vb))
+                    if best is not None:
+                        cmi.tuning_set(cmi.FORMAT_COO, dcode, mean_b, best)
+                        summary.append((label, best.as_dict(), ms))
+                        print(label, best, f"{ms * 1e3:.1f} us", flush=True)
+                    label = f"coo_sorted/{tag}/{name_b}"
+                    best2, ms2, res = tune_one(cmi, torch, timer, label, [c for c in space if c.kernel == cmi.COO_TILE] + ([best] if best is not None else []),
+                                               lambda cfg: cmi.multiply(C, dxs, ys, cfg=cfg), checker_b(C, (cmi.COO_TILE,)), args.iters, args.rounds, log,
+                                               cmi.coo_bytes(rows_b, len(Aj_b), vb))
+                    if best2 is not None:
+                        cmi.tuning_set(cmi.TABLE_COO_SORTED, dcode, mean_b, best2)
+                        summary.append((label, best2.as_dict(), ms2))
+                        print(label, best2, f"{ms2 * 1e3:.1f} us", flush=True)
+                    del C
+                del S, dxs, ys
 
         # synthetic CSR matrices for the other mean-row-length buckets
         if "csr" in formats and not args.skip_synthetic:

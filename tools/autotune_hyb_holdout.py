@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""HYB width rule with a HOLD-OUT (the rule was fitted and scored on the same 11 matrices).  Offline, from the
+sweep log of tools/autotune_hyb.py (every (matrix, width K) -> measured time; histograms regenerated from the seeds, no GPU):
+
+  * every split of the matrices into a training set and 3 held-out ones (all C(n, 3) of them): the rule is fitted on the training
+    set only and its regret (time at the rule's K / best time over K) is reported on the held-out matrices -- geometric mean and worst;
+  * two rule forms: CMI_HYB_RULE_COST2 (shipped in round 2) and CMI_HYB_RULE_COST3, which adds what the second launch of a heavy
+    COO part costs PER ROW (it reads and writes y again and walks the COO plan's row offsets: ~20 bytes per row = 1.7 ELL slots)
+    instead of folding that into one constant;
+  * the full-set fit of the better form, matrix by matrix.
+
+    python tools/autotune_hyb_holdout.py profiles/r02_autotune_hyb.jsonl.gz [--patch cusp-autotuned_amd/tuned/gfx950.json]
+"""
+import argparse
+import collections
+import gzip
+import itertools
+import json
+import math
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import autotune_hyb as ah  # noqa: E402
+from autotune_hyb_refit import LIGHT_LIMIT, cost2_rule_width, time_at  # noqa: E402
+
+
+def cost3_rule_width(hist, num_rows, relative_speed, threshold, light_speed, per_row):
+    """cost(k) = rows * k + [COO part empty: 0 | light: light_speed * coo | heavy: threshold + per_row * rows + relative_speed * coo]"""
+    max_len = len(hist) - 1
+    best, K = float(num_rows) * max_len, max_len
+    longer, coo = 0, 0.0
+    for k in range(max_len - 1, -1, -1):
+        longer += int(hist[k + 1])
+        coo += float(longer)
+        light = coo <= LIGHT_LIMIT * num_rows
+        # (also tried: cost(0) = relative_speed * coo -- "no ELL part, no second launch".  Worse on every score: the headline matrix needs
+        #  K = 5 against K = 0, which forces relative_speed up to 1.4 and drags every irregular matrix to a wide ELL part;
+        #  profiles/r03_autotune_hyb_holdout.txt, second block)
+        cost = float(num_rows) * k + (light_speed * coo if light else threshold + per_row * num_rows + relative_speed * coo)
+        if cost < best:
+            best, K = cost, k
+    return K
+
+
+def load(log):
+    opener = gzip.open if log.endswith(".gz") else open
+    times = collections.defaultdict(dict)
+    for line in opener(log, "rt"):
+        r = json.loads(line)
+        if "K" in r and r.get("status") == "Ok":
+            times[(r["dtype"], r["matrix"])][r["K"]] = r["ms"]
+    hists = {}
+    m = 3162
+    lens = np.full(m * m, 5, np.int64)
+    idx = np.arange(m * m)
+    lens -= (idx % m == 0).astype(np.int64) + (idx % m == m - 1) + (idx < m) + (idx >= m * (m - 1))
+    hists["poisson5pt_3162"] = (len(lens), np.bincount(lens))
+    for name, l in ah.distributions(False):
+        hists[name] = (len(l), np.bincount(l))
+    return times, hists
+
+
+def regrets(sweeps, width_of):
+    return [time_at(tk, min(width_of(hist, rows), max(tk))) / min(tk.values()) for _, rows, hist, tk in sweeps]
+
+
+def gm(v):
+    return math.exp(sum(math.log(t) for t in v) / len(v))
+
+
+GRID2 = list(itertools.product((0.8, 1.0, 1.2, 1.4, 1.6), (0, 300_000, 1_000_000, 2_000_000, 5_000_000), (1.0, 1.5, 2.0, 3.0)))
+GRID3 = list(itertools.product((0.8, 1.0, 1.2, 1.4), (0, 300_000, 1_000_000), (1.0, 1.5, 2.0, 3.0), (0.0, 0.5, 1.0, 1.7, 2.5)))
+
+
+def fit(sweeps, form):
+    """width table per parameter tuple is computed once per (matrix, params) by the caller; here: argmin of the geometric-mean regret"""
+    best = None
+    for params in (GRID2 if form == 2 else GRID3):
+        r = gm([sweeps[i][4][form][params] for i in range(len(sweeps))])
+        if best is None or r < best[0]:
+            best = (r, params)
+    return best[1]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("log")
+    ap.add_argument("--holdout", type=int, default=3)
+    ap.add_argument("--patch", default="", help="table file: write the full-set COST3 fit into its hyb_rule")
+    args = ap.parse_args()
+    times, hists = load(args.log)
+    rules = {}
+    for tag in ("f64", "f32"):
+        sweeps = []
+        for (dt, name), tk in times.items():
+            if dt != tag or name not in hists:
+                continue
+            rows, hist = hists[name]
+            tbest = min(tk.values())
+            reg = {2: {p: time_at(tk, min(cost2_rule_width(hist, rows, *p), max(tk))) / tbest for p in GRID2},
+                   3: {p: time_at(tk, min(cost3_rule_width(hist, rows, *p), max(tk))) / tbest for p in GRID3}}
+            sweeps.append((name, rows, hist, tk, reg))
+        n = len(sweeps)
+        print(f"== {tag}: {n} matrices, every split with {args.holdout} held out ({math.comb(n, args.holdout)} splits)")
+        for form in (2, 3):
+            held, train = [], []
+            for out in itertools.combinations(range(n), args.holdout):
+                tr = [sweeps[i] for i in range(n) if i not in out]
+                p = fit(tr, form)
+                held += [sweeps[i][4][form][p] for i in out]
+                train.append(gm([s[4][form][p] for s in tr]))
+            print(f"   COST{form}: hold-out regret geometric mean {gm(held):.4f}, worst {max(held):.3f}, 95th percentile {np.percentile(held, 95):.3f}; "
+                  f"training-set mean {np.mean(train):.4f}")
+        ref = regrets([s[:4] for s in sweeps], lambda h, r: ah.rule_width(h, r, 3.0, 4096))
+        print(f"   reference constants (3.0, 4096), no fit: geometric mean {gm(ref):.4f}, worst {max(ref):.3f}")
+        p3 = fit(sweeps, 3)
+        p2 = fit(sweeps, 2)
+        print(f"   full-set fits: COST2 {p2} -> {gm([s[4][2][p2] for s in sweeps]):.4f} (worst {max(s[4][2][p2] for s in sweeps):.3f});  "
+              f"COST3 (rs, th, light, per_row) {p3} -> {gm([s[4][3][p3] for s in sweeps]):.4f} (worst {max(s[4][3][p3] for s in sweeps):.3f})")
+        for name, rows, hist, tk, reg in sweeps:
+            K = min(cost3_rule_width(hist, rows, *p3), max(tk))
+            kb = min(tk, key=tk.get)
+            print(f"      {name:28s} COST3 K {K:3d} ({time_at(tk, K) * 1e3:7.1f} us)   best K {kb:3d} ({tk[kb] * 1e3:7.1f} us)   regret {reg[3][p3]:.3f}")
+        rules[tag] = {"kind": "cost3", "relative_speed": p3[0], "threshold": p3[1], "light_speed": p3[2], "per_row": p3[3]}
+    print("hyb_rule", json.dumps(rules))
+    if args.patch:
+        doc = json.load(open(args.patch))
+        doc["hyb_rule"] = rules
+        doc["hyb_rule_source"] = ("tools/autotune_hyb.py on MI355X (width sweeps, raw log profiles/r02_autotune_hyb.jsonl.gz); rule form COST3 fitted on the whole "
+                                  "set by tools/autotune_hyb_holdout.py after its hold-out check (every 3-matrix hold-out split: profiles/r03_autotune_hyb_holdout.txt)")
+        with open(args.patch, "w") as f:
+            f.write("{\n")
+            for k, v in doc.items():
+                if k != "entries":
+                    f.write(f"  {json.dumps(k)}: {json.dumps(v)},\n")
+            f.write('  "entries": [\n' + ",\n".join("    " + json.dumps(e) for e in doc["entries"]) + "\n  ]\n}\n")
+        print("patched", args.patch)
+
+
+if __name__ == "__main__":
+    main()

@@ -43,9 +43,19 @@ def cached(name):
 def variants_for(A):
     out = [("plan", None)]
     out.append(("stream", "table"))
+    for spec in (t for t in os.environ.get("PMC_PIPE", "").split(",") if t):  # csr_stream_pipe: block:rows_per_block
+        blk, rpb = (int(v) for v in spec.split(":"))
+        out.append((f"pipe{blk}x{rpb}", ("cfg", cmi.Config(kernel=cmi.CSR_STREAM_PIPE, block_size=blk, rows_per_block=rpb, nontemporal=3))))
+    for spec in (t for t in os.environ.get("PMC_STREAM", "").split(",") if t):  # explicit csr_stream shapes: block:rows_per_block:vectors:policy
+        blk, rpb, ipt, pol = (int(v) for v in spec.split(":"))
+        out.append((f"stream{blk}x{rpb}x{ipt}/pol{pol}", ("cfg", cmi.Config(kernel=cmi.CSR_STREAM, block_size=blk, rows_per_block=rpb, items_per_thread=ipt,
+                                                                              threads_per_row=1, nontemporal=pol))))
     if hasattr(cmi, "CSR_STREAM_WAVEV"):
         for v in (int(s) for s in os.environ.get("PMC_WAVEV", "2,4").split(",") if s):
-            out.append((f"wavev{v}", cmi.Config(kernel=cmi.CSR_STREAM_WAVEV, items_per_thread=v)))
+            for pol in (int(s) for s in os.environ.get("PMC_WAVEV_POL", "0").split(",") if s):  # 0: the plan's own policy choice
+                for swz in (int(s) for s in os.environ.get("PMC_WAVEV_SWZ", "0").split(",") if s):
+                    out.append((f"wavev{v}" + (f"/pol{pol}" if pol else "") + (f"/swz{swz}" if swz else ""),
+                                cmi.Config(kernel=cmi.CSR_STREAM_WAVEV, items_per_thread=v, nontemporal=pol, xcd_swizzle=swz)))
     return out
 
 
@@ -76,6 +86,9 @@ def main():
         print(f"# {name}: {src}; rows {rows} entries {nnz} algorithmic bytes {alg}; set-up {time.time() - t0:.1f} s", flush=True)
         for label, cfg in variants_for(A):
             plan = None
+            explicit = None
+            if isinstance(cfg, tuple):
+                explicit, cfg = cfg[1], "explicit"
             if isinstance(cfg, cmi.Config):
                 try:
                     plan = cmi.Plan.csr(torch.float64, rows, rows, A.row_offsets, A.column_indices, cfg=cfg)
@@ -88,12 +101,14 @@ def main():
                     cmi.multiply(A, x, y)
                 elif cfg == "table":
                     cmi.spmv_csr(rows, rows, A.row_offsets, A.column_indices, A.values, x, y)
+                elif cfg == "explicit":
+                    cmi.spmv_csr(rows, rows, A.row_offsets, A.column_indices, A.values, x, y, cfg=explicit)
                 else:
                     cmi.spmv_csr_plan(plan, A.row_offsets, A.column_indices, A.values, x, y)
             y.fill_(7.0)
             go()
             exact = bool(torch.equal(y, want))
-            desc = (A.plan().config() if cfg is None else plan.config() if plan is not None else
+            desc = (A.plan().config() if cfg is None else explicit if explicit is not None else plan.config() if plan is not None else
                     cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, rows, rows, nnz))
             if timing:
                 e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()

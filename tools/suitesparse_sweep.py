@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--shapes", action="store_true", help="also time explicit csr_stream tile shapes (block, vectors per lane, rows per tile)")
     ap.add_argument("--only", default="", help="comma-separated subset of thermal2,ldoor,nlpkkt120")
+    ap.add_argument("--policies", action="store_true", help="cache policy (nt loads / nt stores) x XCD dealing around the table's csr_stream shape")
     args = ap.parse_args()
     import torch
     import cusp_autotuned_amd as cmi
@@ -84,6 +85,13 @@ def main():
                 for r in sorted({max(16, fit // 16 * 16), max(16, fit // 16 * 16 - 16), max(16, fit // 8 * 8), min(fit, blk)}):
                     cands.append((f"csr_stream block {blk} vectors/lane={ipt} rows/tile={r} (fit {fit})",
                                   cmi.Config(kernel=cmi.CSR_STREAM, block_size=blk, threads_per_row=1, items_per_thread=ipt, rows_per_block=r, nontemporal=2), True))
+        if args.policies:  # the table's shape under every cache policy and a few XCD dealings (the table's entry was tuned on other matrices)
+            t = cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64 if vb == 8 else cmi.F32, rows, rows, nnz)
+            for pol in (0, 1, 2, 3):
+                for swz in (0, 1, 4, 16, 64):
+                    cands.append((f"csr_stream table shape, policy {pol} (1 = nt loads, 2 = nt stores), XCD dealing {swz}",
+                                  cmi.Config(kernel=cmi.CSR_STREAM, block_size=t.block_size, threads_per_row=1, items_per_thread=t.items_per_thread,
+                                             rows_per_block=t.rows_per_block, nontemporal=pol, xcd_swizzle=swz), True))
         plan = A.plan()
         cands.append((f"table (NULL config): {cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64 if vb == 8 else cmi.F32, rows, rows, nnz)}", None, False))
         runs = []
