@@ -155,30 +155,42 @@ static int wave_partition_k(int64_t rows, int64_t nnz, const row_profile &prof, 
 // csr_wavev (CMI_CSR_STREAM_WAVEV): index vectors per lane V (a wave tile = 256 V slots), or 0 = not for this matrix.  Asked for (a plan
 // made with that kernel): the caller's V or the rule's, refused when the longest row takes more than half of the tile.  AUTO plans:
 // the rule below ($CMI_CSR_WAVEV=0: never; =1: whenever the rows qualify).
-// AUTO plans take csr_wavev when ... (thresholds from tools/pmc_matrix_probe.py --time and tools/wavev_ab.py, profiles/r03_wavev_ab.txt)
-static bool wavev_auto(int64_t rows, int64_t nnz, const row_profile &prof, int v)
+// AUTO plans take csr_wavev (V = 4: 1024 request slots per wave) when ALL of (tools/wavev_ab.py, profiles/r03_wavev_ab.txt: 22 matrices,
+// every variant bit-checked, interleaved rounds on one box):
+//   * the index + value streams are beyond 1.25 x the Infinity Cache -- cache-resident matrices lose (305 000 rows of 20: 1.13x; thermal2-like
+//     even) because the partition's extra scalar hop is not hidden by anything there;
+//   * fewer than 44 entries per row on average: 2-60 per row with columns anywhere in a +-2000..5000 band take 0.64-0.84 of csr_stream's
+//     time (the wave keeps 16 gathers per lane in flight where csr_stream keeps 4-8: these matrices are gather-bound, 0.31-0.44 of peak),
+//     27-point-like and nlpkkt120-like rows 0.95-0.97, columns scattered over the whole vector 0.98-1.00 (nothing helps those);
+//     ldoor-like (45.6 per row) is 1.05x against the table's re-tuned csr_stream shape -- hence the bound;
+//   * at least 4096 rows, no row of 512+ entries, the longest row at most half a wave tile (wavev_vectors above).
+// Stencil rows never get here (csr_wave is chosen first).  $CMI_CSR_WAVEV=0: never, =1: whenever the rows qualify.
+static bool wavev_auto(int64_t rows, int64_t nnz, const row_profile &prof, int v, size_t vbytes)
 {
-    (void)rows; (void)nnz; (void)prof; (void)v;
-    return false;
+    (void)prof;
+    if (v != 4 || rows < 4096) return false;
+    const double mean = (double)nnz / (double)rows;
+    if (mean < 2.5 || mean >= 44.0) return false;
+    return nnz * (int64_t)(sizeof(int) + vbytes) > kInfinityCacheBytes + kInfinityCacheBytes / 4;
 }
 static int wavev_env()
 {
     static const int env = [] { const char *e = std::getenv("CMI_CSR_WAVEV"); return e ? std::atoi(e) : -1; }();
     return env;
 }
-static int wavev_vectors(int64_t rows, int64_t nnz, const row_profile &prof, bool asked, int asked_v)
+static int wavev_vectors(int64_t rows, int64_t nnz, const row_profile &prof, bool asked, int asked_v, size_t vbytes)
 {
     if (rows <= 0 || nnz <= 0 || prof.max_len < 1 || prof.in_long > 0) return 0;
     const double mean = (double)nnz / (double)rows;
     int v = asked_v;
-    if (v == 0) v = mean >= 20.0 ? 4 : mean >= 8.0 ? 2 : 1;
+    if (v == 0) v = asked ? (mean >= 20.0 ? 4 : mean >= 8.0 ? 2 : 1) : 4; // (asked for: tile size by row length; AUTO plans: the measured V = 4)
     if (v != 1 && v != 2 && v != 4) return 0;
     while (v < 4 && !asked_v && 2 * (prof.max_len + 3) > 256 * v) v *= 2; // (the rule may widen the tile for a long row)
     if (2 * (prof.max_len + 3) > 256 * v) return 0;
     if (asked) return v;
     if (wavev_env() == 0) return 0;
     if (wavev_env() == 1) return rows >= 4096 ? v : 0;
-    return wavev_auto(rows, nnz, prof, v) ? v : 0;
+    return wavev_auto(rows, nnz, prof, v, vbytes) ? v : 0;
 }
 
 CMI_API int cmi_plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
@@ -320,8 +332,8 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
             if (num_entries * (int64_t)(sizeof(int) + vbytes) > kInfinityCacheBytes + kInfinityCacheBytes / 4) p->cfg.nontemporal |= kPolLoadNT;
             p->cfg.nontemporal |= kPolStoreNT;
         } else if (st == CMI_SUCCESS && auto_kernel && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
-                   wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v) > 0) {
-            const int v = wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v);
+                   wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v, vbytes) > 0) {
+            const int v = wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v, vbytes);
             st = wave_partition_build(p, index_array, v, s, 256 * v - (int)p->prof.max_len - 3);
             if (st == CMI_SUCCESS && p->wave_row_start) {
                 p->cfg.kernel = CMI_CSR_STREAM_WAVEV;

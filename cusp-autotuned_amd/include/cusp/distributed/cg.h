@@ -8,6 +8,12 @@
 //          the all-reduces between its launches --  exchange p | SpMV + local <y,p> | all-reduce | r, local <r,r> | all-reduce |
 //          x, p  -- scalars never leave device memory, ONE host read per iteration (the convergence check, behind the next
 //          iteration's exchange + SpMV, which are queued before the host waits).
+//   fused, one-sided exchange (exchange_mode::peer): p is exchanged ONCE.  Afterwards every rank keeps the p entries of its halo
+//          itself -- p_halo <- r_halo + beta p_halo, the owner's arithmetic with the same all-reduced beta, hence the owner's bits --
+//          and r_halo is PULLED from the owner right behind the all-reduce of <r,r>, which completes only when every rank's update
+//          kernel (the one that wrote that r) has; the owner overwrites r again only behind the next all-reduce of <y,p>, which
+//          needs this rank's contribution, queued behind this pull.  The algorithm's own all-reduces are all the ordering the pulls
+//          need: no collective is added and nothing but 2 x halo values moves per iteration.
 #pragma once
 #include <cmath>
 
@@ -68,9 +74,61 @@ void multiply_dot_local(const csr_matrix<I, V, cusp::device_memory> &A, V *y_loc
                                               A.x_full(), y_local, w_local, yp, ws));
 }
 
+namespace detail {
+inline int cg_direction_(size_t n, const double *rn, const double *ro, const double *r, double *p) { return cmi_cg_direction_f64((int64_t)n, rn, ro, r, p, nullptr); }
+inline int cg_direction_(size_t n, const double *rn, const double *ro, const float *r, float *p) { return cmi_cg_direction_f32((int64_t)n, rn, ro, r, p, nullptr); }
+} // namespace detail
+
+template <typename I, typename V, typename X, typename B, typename Monitor>
+void cg_fused_peer(const csr_matrix<I, V, cusp::device_memory> &A, X &x, const B &b, Monitor &monitor)
+{
+    namespace kd = cusp::krylov::detail;
+    typedef vector<V, cusp::device_memory> vec;
+    communicator &comm = A.comm();
+    const size_t N = A.local_rows();
+    exchange_buffer<V, cusp::device_memory> r_ex;
+    A.make_exchange_buffer(r_ex);                                        // (collective) peers map it: they pull r's boundary values
+    vec y = A.make_vector();
+    vec r(comm, r_ex.data.data() + A.row_begin(), N, A.num_rows, A.row_begin());
+    vec p = A.exchange_slice();
+    V *p_full = const_cast<V *>(A.x_full()), *r_full = r_ex.data.data();
+    const auto halo = A.halo_ranges();
+    cusp::array1d<double, cusp::device_memory> scalars(3);
+    cusp::blas::detail::device_workspace &w = cusp::blas::detail::workspace();
+    double *rr[2] = {scalars.data(), scalars.data() + 1};
+    double *yp = scalars.data() + 2;
+    kd::pinned_scalar rr_host;
+    cusp::multiply(A, x, y);                                             // (fenced exchange: set-up, once)
+    cusp::blas::axpby(b, y, r, V(1), V(-1));
+    A.fence();                                                           // the peers have pulled x out of the buffer p reuses
+    cusp::blas::copy(r, p);
+    cusp::detail::check(kd::dotd_(N, r.data(), r.data(), rr[0], w.ws));
+    comm.allreduce_sum(rr[0], 1, cusp::device_memory());
+    A.pull();                                                            // p's halo, ordered behind every rank's copy by the all-reduce
+    rr_host.fetch(rr[0]);
+    int cur = 0;
+    for (;;) {
+        multiply_dot_local(A, y.data(), p.data(), yp, w.ws);             // halos of p are already in place: no exchange
+        comm.allreduce_sum(yp, 1, cusp::device_memory());
+        if (monitor.finished_norm(static_cast<typename Monitor::Real>(std::sqrt(rr_host.wait())))) break;
+        cusp::detail::check(kd::cg_update_(N, rr[cur], yp, y.data(), r.data(), rr[cur ^ 1], nullptr, w.ws));
+        comm.allreduce_sum(rr[cur ^ 1], 1, cusp::device_memory());
+        rr_host.fetch(rr[cur ^ 1]);
+        r_ex.pull();                                                     // the peers' boundary r
+        for (const auto &h : halo)                                       // halo: p <- r + beta p (the owner's arithmetic)
+            cusp::detail::check(detail::cg_direction_((size_t)h.second, rr[cur ^ 1], rr[cur], r_full + h.first, p_full + h.first));
+        cusp::detail::check(kd::cg_direction_x_(N, rr[cur ^ 1], rr[cur], yp, r.data(), p.data(), x.data()));
+        cur ^= 1;
+        ++monitor;
+    }
+    A.fence();                                                           // nobody is still pulling from r_ex; the discarded SpMV has ended
+    r_ex.close();
+}
+
 template <typename I, typename V, typename X, typename B, typename Monitor>
 void cg_fused(const csr_matrix<I, V, cusp::device_memory> &A, X &x, const B &b, Monitor &monitor)
 {
+    if (A.mode() == exchange_mode::peer) { cg_fused_peer(A, x, b, monitor); return; }
     namespace kd = cusp::krylov::detail;
     typedef vector<V, cusp::device_memory> vec;
     communicator &comm = A.comm();

@@ -13,12 +13,21 @@
 //              (world - 1) / world * N values, bound by the xGMI links.
 //   halo       only the parts of other ranks' slices inside this rank's column window [col_min, col_max] move: one grouped
 //              ncclSend / ncclRecv launch (cmi_halo_exchange_*).  5-point Poisson: 2 m values per rank instead of N.
+//   peer       the halo plan, ONE-SIDED: xGMI is a load / store fabric, so every rank maps its neighbours' exchange buffers once
+//              (cmi_ipc_get_handle / cmi_ipc_open_handle; handles travel over the star) and before a multiply PULLS the ranges it needs
+//              with one small copy kernel on its own stream (cmi_copy_ranges) -- no collective launch at all.  Visibility is at kernel
+//              boundaries: the CALLER orders the peers' producing kernels before the pull.  cusp::multiply does it with two fences per
+//              call (correct, not fast); cusp::krylov::cg needs none inside its loop -- its own all-reduces are the ordering
+//              (cusp/distributed/cg.h).  Verified end to end at set-up (a pull of per-rank signatures); any failure on any rank leaves
+//              the two-sided halo exchange in force.
 //   automatic  halo when the WORST rank's halo volume is less than half of the all-gather's, else allgather (decided alike
-//              on every rank).
-// host_memory operators run the same plans over the TCP star (tests, set-up).
+//              on every rank); the halo one-sided when $CMI_EXCHANGE_PEER is not 0 and every rank could map and verify its peers.
+// host_memory operators run the same plans over the TCP star (tests, set-up; no one-sided mode there).
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstring>
+#include <utility>
 #include <vector>
 
 #include "../blas/blas.h"
@@ -30,7 +39,7 @@
 namespace cusp {
 namespace distributed {
 
-enum class exchange_mode { automatic, allgather, halo };
+enum class exchange_mode { automatic, allgather, halo, peer };
 
 namespace detail {
 inline void column_span(const cusp::csr_matrix<int, double, cusp::device_memory> &a, int &lo, int &hi) { cusp::detail::check(cmi_csr_column_span((int64_t)a.num_entries, a.column_indices.data(), &lo, &hi, nullptr)); }
@@ -47,6 +56,96 @@ inline int halo_call(cmi_comm *c, double *x, int n, const int *peers, const int6
 inline int halo_call(cmi_comm *c, float *x, int n, const int *peers, const int64_t *sl, const int64_t *sc, const int64_t *rl, const int64_t *rc, void *s)
 { return cmi_halo_exchange_f32(c, x, n, peers, sl, sc, rl, rc, s); }
 } // namespace detail
+
+// A full-length vector buffer (indexed by global column) that peers can PULL from: the allocation (its own cmi_malloc, so that its
+// IPC handle maps exactly it), the mapped peers' buffers and the copy ranges of this rank's halo.  host_memory: the plain array.
+template <typename T, typename Local> class exchange_buffer {
+public:
+    cusp::array1d<T, Local> data;
+    bool map_peers(communicator &, const std::vector<int> &, const std::vector<int64_t> &, const std::vector<int64_t> &) { return false; }
+    void pull(void * = nullptr) const {}
+    void close() {}
+};
+template <typename T> class exchange_buffer<T, cusp::device_memory> {
+public:
+    cusp::array1d<T, cusp::device_memory> data;
+    exchange_buffer() {}
+    ~exchange_buffer() { close(); }
+    exchange_buffer(const exchange_buffer &) = delete;
+    exchange_buffer &operator=(const exchange_buffer &) = delete;
+
+    // COLLECTIVE.  Maps every peer this rank receives from and builds the pull; true only if EVERY rank succeeded and a test pull of
+    // per-rank signatures returned the right data (then the buffer is left zeroed).  On false nothing stays mapped.
+    bool map_peers(communicator &comm, const std::vector<int> &peers, const std::vector<int64_t> &recv_lo, const std::vector<int64_t> &recv_n)
+    {
+        const int world = comm.size(), rank = comm.rank();
+        struct record { unsigned char handle[CMI_IPC_HANDLE_BYTES]; int32_t device, ok; } mine;
+        std::memset(&mine, 0, sizeof(mine));
+        mine.ok = cmi_ipc_get_handle(data.data(), mine.handle) == CMI_SUCCESS && cmi_get_device(&mine.device) == CMI_SUCCESS;
+        std::vector<record> all(world);
+        comm.host().allgather(&mine, all.data(), sizeof(record));
+        double good = 1.0;
+        for (int r = 0; r < world; r++) if (!all[r].ok) good = 0.0;
+        src_.clear(); dst_.clear(); bytes_.clear();
+        if (good > 0) {
+            for (size_t i = 0; i < peers.size() && good > 0; i++) {
+                if (recv_n[i] <= 0) continue;
+                const int p = peers[i];
+                int can = 0;
+                if (cmi_device_can_access_peer(mine.device, all[p].device, &can) != CMI_SUCCESS || !can) { good = 0.0; break; }
+                void *ptr = nullptr;
+                if (cmi_ipc_open_handle(all[p].handle, &ptr) != CMI_SUCCESS) { good = 0.0; break; }
+                mapped_.push_back(ptr);
+                // every rank's buffer is indexed by GLOBAL column: the same offset on both sides
+                src_.push_back(static_cast<const char *>(ptr) + (size_t)recv_lo[i] * sizeof(T));
+                dst_.push_back(reinterpret_cast<char *>(data.data()) + (size_t)recv_lo[i] * sizeof(T));
+                bytes_.push_back((int64_t)recv_n[i] * (int64_t)sizeof(T));
+            }
+        }
+        // end-to-end check with a per-rank signature (every collective step runs on every rank, mapped or not)
+        cusp::array1d_view<T, cusp::device_memory> whole(data.data(), data.size());
+        cusp::blas::fill(whole, T(rank + 1));
+        comm.barrier(cusp::device_memory());
+        if (good > 0) {
+            pull();
+            if (cmi_stream_synchronize(nullptr) != CMI_SUCCESS) good = 0.0;
+            for (size_t i = 0; i < peers.size() && good > 0; i++) {
+                if (recv_n[i] <= 0) continue;
+                T first, last;
+                cusp::detail::check(cmi_memcpy_d2h(&first, data.data() + recv_lo[i], sizeof(T), nullptr));
+                cusp::detail::check(cmi_memcpy_d2h(&last, data.data() + recv_lo[i] + recv_n[i] - 1, sizeof(T), nullptr));
+                if (first != T(peers[i] + 1) || last != T(peers[i] + 1)) good = 0.0;
+            }
+        }
+        double bad = 1.0 - good;
+        comm.allreduce_max(&bad, 1, cusp::host_memory());
+        comm.barrier(cusp::device_memory());
+        cusp::blas::fill(whole, T(0));
+        comm.barrier(cusp::device_memory());
+        if (bad > 0) { close(); return false; }
+        return true;
+    }
+    // the pull: one launch per 16 ranges on `stream`; nothing to wait for on the host
+    void pull(void *stream = nullptr) const
+    {
+        for (size_t i = 0; i < src_.size(); i += CMI_MAX_COPY_RANGES) {
+            const int n = (int)std::min<size_t>(CMI_MAX_COPY_RANGES, src_.size() - i);
+            cusp::detail::check(cmi_copy_ranges(n, reinterpret_cast<const void *const *>(src_.data() + i), reinterpret_cast<void *const *>(dst_.data() + i), bytes_.data() + i, stream));
+        }
+    }
+    void close()
+    {
+        for (void *p : mapped_) cmi_ipc_close_handle(p);
+        mapped_.clear(); src_.clear(); dst_.clear(); bytes_.clear();
+    }
+    bool mapped() const { return !src_.empty() || !mapped_.empty(); }
+
+private:
+    std::vector<void *> mapped_;
+    std::vector<const char *> src_;
+    std::vector<char *> dst_;
+    std::vector<int64_t> bytes_;
+};
 
 template <typename IndexType, typename ValueType, typename Local> class csr_matrix {
 public:
@@ -69,7 +168,30 @@ public:
     size_t local_rows() const { return row_end() - row_begin(); }
     exchange_mode mode() const { return mode_; }
     // values this rank receives per exchange, and what the all-gather would receive
-    int64_t exchange_values() const { return mode_ == exchange_mode::halo ? halo_recv_values_ : allgather_values(); }
+    int64_t exchange_values() const { return mode_ == exchange_mode::allgather ? allgather_values() : halo_recv_values_; }
+    const char *mode_name() const { return mode_ == exchange_mode::peer ? "peer (one-sided pull)" : mode_ == exchange_mode::halo ? "halo (grouped send/recv)" : "allgather"; }
+    // the halo this rank keeps of the other ranks' slices: (first global index, length) per peer it receives from
+    std::vector<std::pair<int64_t, int64_t>> halo_ranges() const
+    {
+        std::vector<std::pair<int64_t, int64_t>> out;
+        for (size_t i = 0; i < peers_.size(); i++) if (recv_n_[i] > 0) out.push_back({recv_lo_[i], recv_n_[i]});
+        return out;
+    }
+    // Another full-length buffer with this operator's halo plan and -- in peer mode -- its own mappings of the neighbours' copies
+    // (COLLECTIVE).  cusp::krylov::cg keeps its residual in one so that peers can pull its boundary values.
+    void make_exchange_buffer(exchange_buffer<ValueType, Local> &out) const
+    {
+        out.data.resize(xbuf_.data.size());
+        cusp::array1d_view<ValueType, Local> whole(out.data.data(), out.data.size());
+        cusp::blas::fill(whole, ValueType(0));
+        if (mode_ == exchange_mode::peer && !out.map_peers(*comm_, peers_, recv_lo_, recv_n_))
+            throw cusp::runtime_exception("distributed::csr_matrix: a second exchange buffer could not be mapped by every rank");
+    }
+    // everything queued on this rank's stream has completed AND every rank has reached this point: the epoch boundary the one-sided
+    // pull needs between the peers' producers and itself when the caller's algorithm does not already provide it
+    void fence() const { comm_->barrier(Local()); }
+    // the pull alone (peer mode), no ordering: for callers whose algorithm orders it (cg)
+    void pull(void *stream = nullptr) const { xbuf_.pull(stream); }
     int64_t allgather_values() const { return (int64_t)(comm_->size() - 1) * count_; }
     int64_t halo_values() const { return halo_recv_values_; }
 
@@ -91,8 +213,8 @@ public:
         uniform_ = true;
         for (int r = 0; r <= world; r++) uniform_ = uniform_ && cuts[r] == std::min<int64_t>((int64_t)r * count_, (int64_t)global_rows);
         // the buffer is padded to world * count so that the in-place all-gather of a uniform partition can write straight into it
-        x_full_.resize(std::max<size_t>((size_t)world * (size_t)count_, std::max<size_t>(global_rows, 1)));
-        cusp::array1d_view<ValueType, Local> whole(x_full_.data(), x_full_.size());
+        xbuf_.data.resize(std::max<size_t>((size_t)world * (size_t)count_, std::max<size_t>(global_rows, 1)));
+        cusp::array1d_view<ValueType, Local> whole(xbuf_.data.data(), xbuf_.data.size());
         cusp::blas::fill(whole, ValueType(0));
 
         // every rank learns every rank's column window and entry count (set-up, over the star)
@@ -126,6 +248,16 @@ public:
         if (want == exchange_mode::automatic) mode_ = 2 * worst_halo_values_ < allgather_values() ? exchange_mode::halo : exchange_mode::allgather;
         counts_.resize(world); displs_.resize(world);
         for (int r = 0; r < world; r++) { counts_[r] = cuts[r + 1] - cuts[r]; displs_[r] = cuts[r]; }
+        // the halo one-sided where the buffers are in HBM and every rank can map and verify its neighbours' (collective; any failure
+        // anywhere leaves the two-sided exchange in force -- asked for explicitly, it is an error instead)
+        const char *pe = std::getenv("CMI_EXCHANGE_PEER");
+        const bool try_peer = world > 1 && std::is_same<Local, cusp::device_memory>::value &&
+                              (want == exchange_mode::peer || (want == exchange_mode::automatic && mode_ == exchange_mode::halo && !(pe && pe[0] == '0')));
+        if (mode_ == exchange_mode::peer) mode_ = exchange_mode::halo;
+        if (try_peer) {
+            if (xbuf_.map_peers(*comm_, peers_, recv_lo_, recv_n_)) mode_ = exchange_mode::peer;
+            else if (want == exchange_mode::peer) throw cusp::runtime_exception("distributed::csr_matrix: exchange_mode::peer asked for, but a rank could not map or verify its neighbours' buffers");
+        }
     }
 
     // Every rank holds the WHOLE matrix on the host (tests, MatrixMarket input): take this rank's rows (collective).
@@ -146,10 +278,10 @@ public:
     // call exchange(), and local rows can be multiplied; CG keeps its direction vector p there
     vector_type make_vector() const { return vector_type(*comm_, local_rows(), num_rows, row_begin()); }
     vector_type make_vector(const ValueType &v) const { return vector_type(*comm_, local_rows(), num_rows, row_begin(), v); }
-    vector_type exchange_slice() const { return vector_type(*comm_, const_cast<ValueType *>(x_full_.data()) + row_begin(), local_rows(), num_rows, row_begin()); }
-    const ValueType *x_full() const { return x_full_.data(); }
-    ValueType *x_full() { return x_full_.data(); }
-    cusp::array1d_view<const ValueType, Local> x_view() const { return cusp::array1d_view<const ValueType, Local>(x_full_.data(), num_cols); }
+    vector_type exchange_slice() const { return vector_type(*comm_, const_cast<ValueType *>(xbuf_.data.data()) + row_begin(), local_rows(), num_rows, row_begin()); }
+    const ValueType *x_full() const { return xbuf_.data.data(); }
+    ValueType *x_full() { return xbuf_.data.data(); }
+    cusp::array1d_view<const ValueType, Local> x_view() const { return cusp::array1d_view<const ValueType, Local>(xbuf_.data.data(), num_cols); }
 
     // fill the exchange buffer from every rank's slice (COLLECTIVE; device: enqueued on `stream`, returns at once)
     void exchange(void *stream = nullptr) const { exchange_impl(stream, Local()); }
@@ -166,17 +298,31 @@ private:
     exchange_mode mode_;
     int64_t count_;      // longest slice = the all-gather's padded piece
     bool uniform_;       // cuts[r] == r * count_: the in-place ncclAllGather applies
-    mutable cusp::array1d<ValueType, Local> x_full_;
+    mutable exchange_buffer<ValueType, Local> xbuf_;
     std::vector<int> peers_;
     std::vector<int64_t> send_lo_, send_n_, recv_lo_, recv_n_, counts_, displs_;
     int64_t halo_recv_values_ = 0, worst_halo_values_ = 0;
 
     void exchange_impl(void *stream, cusp::device_memory) const
     {
-        if (comm_->size() == 1 && mode_ == exchange_mode::halo) return;
-        ValueType *buf = x_full_.data();
-        if (mode_ == exchange_mode::halo) {
-            cusp::detail::check(detail::halo_call(comm_->device(), buf, (int)peers_.size(), peers_.data(), send_lo_.data(), send_n_.data(), recv_lo_.data(), recv_n_.data(), stream));
+        if (comm_->size() == 1 && mode_ != exchange_mode::allgather) return;
+        ValueType *buf = xbuf_.data.data();
+        if (mode_ == exchange_mode::peer) { // correct for ANY caller, not fast: the peers' slices are complete before anyone pulls, and nobody
+            fence();                        // overwrites a slice a peer is still pulling from (cg orders its pulls itself and never comes here)
+            xbuf_.pull(stream);
+            fence();
+        } else if (mode_ == exchange_mode::halo) {
+            if (comm_->staged()) { // rehearsal transport (ranks sharing one GPU): through the host
+                const int world = comm_->size();
+                std::vector<size_t> sl(world, 0), sn(world, 0), rl(world, 0), rn(world, 0);
+                for (size_t i = 0; i < peers_.size(); i++) {
+                    const int p = peers_[i];
+                    sl[p] = (size_t)send_lo_[i] * sizeof(ValueType); sn[p] = (size_t)send_n_[i] * sizeof(ValueType);
+                    rl[p] = (size_t)recv_lo_[i] * sizeof(ValueType); rn[p] = (size_t)recv_n_[i] * sizeof(ValueType);
+                }
+                comm_->staged_exchange(buf, xbuf_.data.size(), sl.data(), sn.data(), rl.data(), rn.data(), stream);
+            } else
+                cusp::detail::check(detail::halo_call(comm_->device(), buf, (int)peers_.size(), peers_.data(), send_lo_.data(), send_n_.data(), recv_lo_.data(), recv_n_.data(), stream));
         } else if (uniform_) {
             comm_->allgather(buf + row_begin(), buf, (size_t)count_, cusp::device_memory(), stream); // (a 1-rank world still goes through RCCL)
         } else {
@@ -186,7 +332,7 @@ private:
     void exchange_impl(void *, cusp::host_memory) const
     {
         if (comm_->size() == 1) return;
-        ValueType *buf = x_full_.data();
+        ValueType *buf = xbuf_.data.data();
         if (mode_ == exchange_mode::halo) {
             const int world = comm_->size();
             std::vector<size_t> sl(world, 0), sn(world, 0), rl(world, 0), rn(world, 0);

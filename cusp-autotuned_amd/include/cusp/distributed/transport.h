@@ -99,9 +99,9 @@ public:
         if (rank_ == 0) { for (int r = 1; r < world_; r++) send_all(peers_[r], buf, bytes); }
         else recv_all(root_, buf, bytes);
     }
-    void barrier() { char c = 0; allgather(&c, nullptr, 0); }
+    void barrier() { double token = 0.0; allreduce(&token, 1, 0); } // every rank -> rank 0 -> every rank: nobody leaves before all have arrived
 
-    // recv[r * bytes, +bytes) <- rank r's send (recv may be null when bytes == 0: a barrier)
+    // recv[r * bytes, +bytes) <- rank r's send
     void allgather(const void *send, void *recv, size_t bytes)
     {
         std::vector<size_t> counts(world_, bytes), displs(world_);

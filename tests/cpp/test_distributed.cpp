@@ -5,7 +5,9 @@
 //   host    host_memory operator + vectors over the TCP star: partitions (equal rows / balanced by entries), exchange plans
 //           (all-gather, all-gather of unequal pieces, halo), multiply, plain CG -- the logic RCCL carries on the GPUs, at world 2+
 //           on CPUs.
-//   device  device_memory: the same through cmi_comm / cmi_allgather / cmi_halo_exchange / cmi_allreduce (RCCL).  One rank per GPU.
+//   device  device_memory: the same through cmi_comm / cmi_allgather / cmi_halo_exchange / cmi_allreduce (RCCL).  One rank per GPU --
+//           or, with CMI_COMM_STAGED=1, several ranks SHARING one GPU (collectives staged through the host; the one-sided exchange
+//           and its CG run for real: IPC mappings between processes, cmi_copy_ranges pulls ordered by the algorithm's reductions).
 #include <cusp/csr_matrix.h>
 #include <cusp/distributed.h>
 #include <cusp/gallery/poisson.h>
@@ -72,8 +74,11 @@ template <typename Space> static void run(cd::communicator &comm, const char *sp
                                 {"scattered/by-entries/allgather", false, true, cd::exchange_mode::allgather},
                                 {"banded/equal-rows/auto", true, false, cd::exchange_mode::automatic},
                                 {"banded/by-entries/halo", true, true, cd::exchange_mode::halo},
-                                {"banded/equal-rows/allgather", true, false, cd::exchange_mode::allgather}};
+                                {"banded/equal-rows/allgather", true, false, cd::exchange_mode::allgather},
+                                {"banded/by-entries/peer", true, true, cd::exchange_mode::peer}};
     for (const variant &v : variants) {
+        const bool one_sided = v.mode == cd::exchange_mode::peer;
+        if (one_sided && (!std::is_same<Space, cusp::device_memory>::value || world == 1)) continue; // IPC mappings between processes on GPUs
         const size_t n = 4000 + 37 * (size_t)world + 1; // (not a multiple of the world size: the last slice is short)
         const host_csr G = test_matrix(n, 7u + (v.banded ? 1u : 0u), v.banded);
         const std::vector<int64_t> cuts = v.by_entries ? cd::partition_by_entries(G.row_offsets, world) : cd::partition_rows((int64_t)n, world);
@@ -81,7 +86,9 @@ template <typename Space> static void run(cd::communicator &comm, const char *sp
         A.scatter(G, cuts, v.mode);
         CHECK(A.num_rows == n && A.num_entries == G.num_entries, "%s: global sizes %zu %zu", v.name, A.num_rows, A.num_entries);
         if (v.mode != cd::exchange_mode::automatic) CHECK(A.mode() == v.mode, "%s: mode", v.name);
-        if (world > 1 && v.banded && v.mode == cd::exchange_mode::automatic) CHECK(A.mode() == cd::exchange_mode::halo, "%s: a banded matrix should pick the halo exchange", v.name);
+        if (world > 1 && v.banded && v.mode == cd::exchange_mode::automatic)
+            CHECK(A.mode() == (std::is_same<Space, cusp::device_memory>::value ? cd::exchange_mode::peer : cd::exchange_mode::halo),
+                  "%s: a banded matrix should pick the halo exchange (one-sided on device_memory)", v.name);
         if (world > 1 && !v.banded && v.mode == cd::exchange_mode::automatic) CHECK(A.mode() == cd::exchange_mode::allgather, "%s: scattered columns should pick the all-gather", v.name);
         // x, and the single-process y = G x on the host
         cusp::array1d<double, cusp::host_memory> xg(n), yg(n);
@@ -125,7 +132,7 @@ template <typename Space> static void run(cd::communicator &comm, const char *sp
         for (size_t i = 0; i < sl.size(); i++) err = std::max(err, std::fabs(sl[i] - sg[lo + i]));
         CHECK(err <= 1e-8, "%s: solution differs by %.3e", v.name, err);
         if (rank == 0) std::printf("ok  %-34s [%s, world %d]  mode %s, %lld values per exchange (all-gather %lld), CG %zu iterations\n", v.name, space_name, world,
-                                   A.mode() == cd::exchange_mode::halo ? "halo" : "allgather", (long long)A.exchange_values(), (long long)A.allgather_values(), mon.iteration_count());
+                                   A.mode_name(), (long long)A.exchange_values(), (long long)A.allgather_values(), mon.iteration_count());
     }
     // the gallery builder: every rank its own rows of poisson5pt(m, n); against the host gallery
     {
@@ -152,7 +159,7 @@ template <typename Space> static void run(cd::communicator &comm, const char *sp
         cusp::krylov::cg(G, xg, bg, mon_ref);
         CHECK(mon.converged() && mon.iteration_count() == mon_ref.iteration_count(), "poisson CG: %zu vs %zu iterations", mon.iteration_count(), mon_ref.iteration_count());
         if (rank == 0) std::printf("ok  sharded poisson5pt(%zu,%zu) + cg  [%s, world %d]  mode %s, %zu iterations, ||r|| = %.6e\n", m, nn, space_name, world,
-                                   A.mode() == cd::exchange_mode::halo ? "halo" : "allgather", mon.iteration_count(), (double)mon.residual_norm());
+                                   A.mode_name(), mon.iteration_count(), (double)mon.residual_norm());
     }
 }
 

@@ -122,11 +122,11 @@ def test_reference_examples_run_on_device(cmi, tmp_path):
 
 
 # ---- the one-process-per-GPU layer (cusp/distributed/*.h) through C++ only ---------------------------------------------------------
-def _launch(ranks, mode, port, timeout=300):
+def _launch(ranks, mode, port, timeout=300, extra_env=None):
     for exe in ("tests/cpp/bin/test_distributed", "tools/bin/cmi_launch"):
         if not os.path.exists(os.path.join(ROOT, exe)):
             _build()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     r = subprocess.run([os.path.join(ROOT, "tools", "bin", "cmi_launch"), "-n", str(ranks), "--port", str(port), "--",
                         os.path.join(CPP, "bin", "test_distributed"), mode], capture_output=True, text=True, timeout=timeout, env=env)
     print(r.stdout[-3000:])
@@ -154,3 +154,15 @@ def test_sharded_operator_and_cg_through_rccl_one_rank(cmi):
     out = _launch(1, "device", 29631)
     assert "RCCL version code" in out
     assert len([l for l in out.splitlines() if l.startswith("ok ")]) == 6, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_sharded_operator_ranks_share_one_gpu_one_sided_exchange(cmi, ranks):
+    """2 / 3 ranks on the one GPU of the box (CMI_COMM_STAGED=1: RCCL refuses ranks sharing a device, so the collectives are staged
+    through the host) with the REAL local kernels and the REAL one-sided exchange: IPC mappings between processes, cmi_copy_ranges
+    pulls, and the fused CG whose pulls are ordered by its own reductions.  Every variant of the program incl. exchange_mode::peer."""
+    out = _launch(ranks, "device", 29640 + ranks, extra_env={"CMI_COMM_STAGED": "1"})
+    lines = [l for l in out.splitlines() if l.startswith("ok ")]
+    assert len(lines) == 7, out
+    assert "mode peer" in out and "banded/by-entries/peer" in out
