@@ -14,7 +14,7 @@ FORMAT_CSR, FORMAT_ELL, FORMAT_DIA, FORMAT_COO, FORMAT_HYB = 0, 1, 2, 3, 4
 TABLE_COO_SORTED = 5  # tuning-table key only: the launch shape of a COO multiply whose plan found the entries row-sorted
 F64, F32 = 0, 1
 KERNEL_AUTO = 0
-CSR_SCALAR, CSR_VECTOR, CSR_STREAM, CSR_STREAM_PIPE, CSR_BALANCED, CSR_STREAM_C16, CSR_STREAM_WAVE, CSR_STREAM_WAVEV = 1, 2, 3, 4, 5, 6, 7, 8
+CSR_SCALAR, CSR_VECTOR, CSR_STREAM, CSR_STREAM_PIPE, CSR_BALANCED, CSR_STREAM_C16, CSR_STREAM_WAVE, CSR_STREAM_WAVEV, CSR_STREAM_WAVEX = 1, 2, 3, 4, 5, 6, 7, 8, 9
 ELL_ROW, DIA_ROW, COO_SEGMENTED, COO_LANE4, COO_TILE = 10, 20, 30, 31, 32
 
 
@@ -911,14 +911,20 @@ class Comm:
     ranks through `broadcast` (any out-of-band channel: a torch.distributed store here, a TCP socket in the C++ layer)."""
 
     def __init__(self, rank, world, broadcast=None):
-        ident = ctypes.create_string_buffer(COMM_ID_BYTES)
+        raw, err = None, None
         if rank == 0:
-            check(lib().cmi_comm_unique_id(ident))
-        raw = ident.raw
+            ident = ctypes.create_string_buffer(COMM_ID_BYTES)
+            try:
+                check(lib().cmi_comm_unique_id(ident))
+                raw = ident.raw
+            except CmiError as e:  # (RCCL not loadable: the other ranks must hear about it, not wait for an id that never comes)
+                err = e
         if world > 1:
             if broadcast is None:
                 raise ValueError("Comm: a multi-rank communicator needs a broadcast function for the unique id")
             raw = broadcast(raw if rank == 0 else None)
+        if raw is None:
+            raise err if err is not None else CmiError(7, "CMI_ERROR_COMM: rank 0 could not make a communicator id")
         self._h = c_void_p()
         self.rank, self.world = rank, world
         check(lib().cmi_comm_create(ctypes.create_string_buffer(raw, COMM_ID_BYTES), rank, world, byref(self._h)))

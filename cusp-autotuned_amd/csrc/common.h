@@ -57,6 +57,7 @@ void select_config(int format, int dtype, int64_t num_rows, int64_t num_cols, in
 // row-length profile of a CSR matrix (spmv_csr.hip): longest row, entries sitting in rows of kLongRowMin or more
 struct row_profile { int64_t max_len = -1, in_long = 0; }; // max_len < 0: not measured
 int measure_row_lengths(int64_t rows, const int *Ap, hipStream_t s, int64_t *max_len, int64_t *entries_in_long_rows, int64_t *ends = nullptr); // ends: {Ap[0], Ap[rows]}
+int measure_column_locality(int64_t rows, int64_t cols, const int *Ap, const int *Aj, int halfwin, hipStream_t s, int64_t *inside, int64_t *jumps); // spmv_csr.hip
 bool prefers_balanced(int64_t rows, int64_t nnz, const row_profile &pr, size_t value_bytes, bool strict_order);
 // are the row indices of a COO matrix non-decreasing and inside [0, rows)?  (spmv_coo_hyb.hip; synchronises the stream)
 int coo_rows_sorted(int64_t rows, int64_t nnz, const int *Ai, hipStream_t s, int *sorted, int *long_runs = nullptr); // long_runs: a row of > 1024 entries

@@ -155,15 +155,17 @@ static int wave_partition_k(int64_t rows, int64_t nnz, const row_profile &prof, 
 // csr_wavev (CMI_CSR_STREAM_WAVEV): index vectors per lane V (a wave tile = 256 V slots), or 0 = not for this matrix.  Asked for (a plan
 // made with that kernel): the caller's V or the rule's, refused when the longest row takes more than half of the tile.  AUTO plans:
 // the rule below ($CMI_CSR_WAVEV=0: never; =1: whenever the rows qualify).
-// AUTO plans take csr_wavev (V = 4: 1024 request slots per wave) when ALL of (tools/wavev_ab.py, profiles/r03_wavev_ab.txt: 22 matrices,
+// AUTO plans take csr_wavev when ALL of (tools/wavev_ab.py, profiles/r03_wavev_ab.txt and r03_wavev_wavex_ab.txt: 24 matrices, f64 and f32,
 // every variant bit-checked, interleaved rounds on one box):
-//   * the index + value streams are beyond 1.25 x the Infinity Cache -- cache-resident matrices lose (305 000 rows of 20: 1.13x; thermal2-like
-//     even) because the partition's extra scalar hop is not hidden by anything there;
+//   * the index + value streams are beyond 0.75 x the Infinity Cache -- smaller matrices lose or tie (305 000 rows of 20: 1.13x; thermal2-like
+//     at 104 MB even) because the partition's extra scalar hop is not hidden by anything there; at 240 MB (f32, 2..8 per row) it wins 0.79;
 //   * fewer than 44 entries per row on average: 2-60 per row with columns anywhere in a +-2000..5000 band take 0.64-0.84 of csr_stream's
 //     time (the wave keeps 16 gathers per lane in flight where csr_stream keeps 4-8: these matrices are gather-bound, 0.31-0.44 of peak),
 //     27-point-like and nlpkkt120-like rows 0.95-0.97, columns scattered over the whole vector 0.98-1.00 (nothing helps those);
 //     ldoor-like (45.6 per row) is 1.05x against the table's re-tuned csr_stream shape -- hence the bound;
-//   * at least 4096 rows, no row of 512+ entries, the longest row at most half a wave tile (wavev_vectors above).
+//   * at least 4096 rows, no row of 512+ entries, the longest row at most half a wave tile (wavev_vectors below).
+// Tile size: V = 4 (1024 request slots per wave) -- except f64 rows of fewer than 8 entries whose columns share x lines (see
+// column_profile below: thermal2-like x6 110.0 us with V = 1 against 119.6), known only to plans made WITH the column indices.
 // Stencil rows never get here (csr_wave is chosen first).  $CMI_CSR_WAVEV=0: never, =1: whenever the rows qualify.
 static bool wavev_auto(int64_t rows, int64_t nnz, const row_profile &prof, int v, size_t vbytes)
 {
@@ -171,8 +173,18 @@ static bool wavev_auto(int64_t rows, int64_t nnz, const row_profile &prof, int v
     if (v != 4 || rows < 4096) return false;
     const double mean = (double)nnz / (double)rows;
     if (mean < 2.5 || mean >= 44.0) return false;
-    return nnz * (int64_t)(sizeof(int) + vbytes) > kInfinityCacheBytes + kInfinityCacheBytes / 4;
+    return nnz * (int64_t)(sizeof(int) + vbytes) > kInfinityCacheBytes / 4 * 3;
 }
+// What a plan made with the column indices (cmi_plan_create_csr) adds: where the columns of a row lie.  `jumps` = share of entries 16+
+// columns away from their predecessor in the row (each its own L1 lookup), `inside` = share within 1536 columns of the row's diagonal
+// position (what an LDS x window around a workgroup's rows would serve).  Measured (r03_wavev_wavex_ab.txt):
+//   jumps >= 0.6 and inside >= 0.25 (columns anywhere in a band): csr_wavex, the x window in LDS -- f32 0.71-0.92 of csr_wavev's time
+//       (window 4096 from 15 entries per row, else 2048), f64 0.93-1.00 (window 2048); with jumps <= 0.31 (FEM blocks, stencils, sorted
+//       meshes) the window only adds traffic: 1.3-1.8x SLOWER -- never selected there; inside = 0 (scattered): nothing helps.
+//   f64, fewer than 8 entries per row, jumps < 0.5: V = 1.
+//   inside < 0.05 with jumps >= 0.6 (scattered): csr_stream stays (wave tiles 0.97-1.06x: a wash).
+//   f32 rows of 16+ entries with jumps < 0.5 -- or columns unknown -- : csr_stream stays (27-point-like / nlpkkt120-like f32: wave tiles 1.05-1.06x).
+struct column_profile { double jumps = -1.0, inside = -1.0; }; // < 0: not measured
 static int wavev_env()
 {
     static const int env = [] { const char *e = std::getenv("CMI_CSR_WAVEV"); return e ? std::atoi(e) : -1; }();
@@ -264,11 +276,15 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
     // CMI_CSR_STREAM_WAVEV: wave-private tiles with the 16-byte-vector body on a partition the plan builds (rows of ~16-250 entries);
     // cache policy / XCD dealing from the caller's fields if set, else the table's; index vectors per lane from the caller or the rule
     cmi_config wavev_shape;
-    bool want_wavev = false;
-    int wavev_v = 0;
-    if (format == CMI_FORMAT_CSR && cfg && cfg->kernel == CMI_CSR_STREAM_WAVEV) {
+    bool want_wavev = false, want_wavex = false;
+    int wavev_v = 0, wavex_window = 0;
+    if (format == CMI_FORMAT_CSR && cfg && (cfg->kernel == CMI_CSR_STREAM_WAVEV || cfg->kernel == CMI_CSR_STREAM_WAVEX)) {
         want_wavev = true;
+        want_wavex = cfg->kernel == CMI_CSR_STREAM_WAVEX; // the same partition; the multiply adds an x window in LDS (rows_per_block = its length)
+        wavex_window = cfg->rows_per_block > 0 ? cfg->rows_per_block : 0;
         wavev_v = cfg->items_per_thread;
+        if (want_wavex && wavev_v == 0) wavev_v = 4;
+        if (want_wavex && wavev_v == 1) wavev_v = 2;
         wavev_shape = *cfg;
         wavev_shape.kernel = CMI_KERNEL_AUTO;
         wavev_shape.rows_per_block = 0;
@@ -333,12 +349,34 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
             p->cfg.nontemporal |= kPolStoreNT;
         } else if (st == CMI_SUCCESS && auto_kernel && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
                    wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v, vbytes) > 0) {
-            const int v = wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v, vbytes);
-            st = wave_partition_build(p, index_array, v, s, 256 * v - (int)p->prof.max_len - 3);
+            int v = wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v, vbytes);
+            bool auto_wavex = false, keep_stream = false;
+            if (!want_wavev) { // an AUTO plan: refine by the value type and -- made with the columns -- by where the columns lie
+                const double mean = (double)num_entries / (double)num_rows;
+                column_profile cp;
+                if (csr_columns) {
+                    int64_t inside = 0, jumps = 0;
+                    st = measure_column_locality(num_rows, num_cols, index_array, csr_columns, 1536, s, &inside, &jumps);
+                    if (st == CMI_SUCCESS) { cp.inside = (double)inside / (double)num_entries; cp.jumps = (double)jumps / (double)num_entries; }
+                }
+                const char *wx = std::getenv("CMI_CSR_WAVEX");
+                if (cp.jumps >= 0.6 && cp.inside >= 0.25 && !(wx && wx[0] == '0')) {
+                    auto_wavex = true;
+                    wavex_window = (dtype == CMI_F32 && mean >= 15.0) ? 4096 : 2048;
+                } else if (cp.inside >= 0.0 && cp.inside < 0.05 && cp.jumps >= 0.6) {
+                    keep_stream = true; // columns scattered over the whole vector: 0.08-0.11 of peak whatever runs; wave tiles 0.97-1.06x
+                } else if (dtype == CMI_F32 && mean >= 16.0 && cp.jumps < 0.5) {
+                    keep_stream = true; // f32 stencil / FEM-block rows of 16+ entries (or unknown columns): the table's csr_stream is 5-6 % faster
+                } else if (dtype == CMI_F64 && mean < 8.0 && cp.jumps >= 0.0 && cp.jumps < 0.5)
+                    v = 1;
+            }
+            if (keep_stream) {
+                // (the table's csr_stream entry stays: nothing is built)
+            } else if (st == CMI_SUCCESS) st = wave_partition_build(p, index_array, v, s, 256 * v - (int)p->prof.max_len - 3);
             if (st == CMI_SUCCESS && p->wave_row_start) {
-                p->cfg.kernel = CMI_CSR_STREAM_WAVEV;
+                p->cfg.kernel = (want_wavex || auto_wavex) ? CMI_CSR_STREAM_WAVEX : CMI_CSR_STREAM_WAVEV;
                 p->cfg.block_size = 256;
-                p->cfg.rows_per_block = 0; // (the partition's)
+                p->cfg.rows_per_block = (want_wavex || auto_wavex) ? wavex_window : 0; // (the partition's; WAVEX: the window length, 0 = the default)
                 p->cfg.items_per_thread = v;
                 p->cfg.threads_per_row = 0;
                 p->cfg.nontemporal &= ~kPolStrided;
@@ -519,7 +557,7 @@ CMI_API int cmi_plan_info(const cmi_plan *plan, int64_t *max_row_length, int64_t
         switch (plan->format) {
         case CMI_FORMAT_CSR:
             // scalar / pipe: always; stream: one lane per row and no row long enough for the cooperative path
-            exact = c.kernel == CMI_CSR_SCALAR || c.kernel == CMI_CSR_STREAM_PIPE || c.kernel == CMI_CSR_STREAM_C16 || c.kernel == CMI_CSR_STREAM_WAVE || c.kernel == CMI_CSR_STREAM_WAVEV ||
+            exact = c.kernel == CMI_CSR_SCALAR || c.kernel == CMI_CSR_STREAM_PIPE || c.kernel == CMI_CSR_STREAM_C16 || c.kernel == CMI_CSR_STREAM_WAVE || c.kernel == CMI_CSR_STREAM_WAVEV || c.kernel == CMI_CSR_STREAM_WAVEX ||
                     (c.kernel == CMI_CSR_STREAM && c.threads_per_row <= 1 && (c.threads_per_row == 1 || plan->prof.max_len < 512));
             break;
         case CMI_FORMAT_ELL: exact = ell_lanes_per_row(c, plan->rows, plan->rows > 0 ? plan->nnz / plan->rows : 0) == 1; break;

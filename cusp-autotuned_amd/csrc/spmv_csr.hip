@@ -709,6 +709,133 @@ csr_wavev_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t 
 }
 
 // ---------------------------------------------------------------------------------------------
+// csr_wavex: csr_wavev + an x WINDOW in LDS shared by the workgroup's four wave tiles (round 3) -- gather-bound band matrices
+// ---------------------------------------------------------------------------------------------
+// Where the columns of a row lie anywhere inside a band (FEM matrices after a bandwidth-reducing ordering, seeded 2..60 per row within
+// +-2000..5000 columns: 0.31-0.44 of peak with csr_stream, 0.50-0.57 with csr_wavev), the multiply is bound by the GATHERS: every x entry
+// is its own cache-line lookup in the L1 (1.04 lookups per entry, profiles/r03_long_rows_experiments.txt) at 64 lookups per wave
+// instruction.  Here the workgroup first copies the x window its rows sit in the middle of -- `window` consecutive entries around the
+// diagonal position of its row range, read coalesced, 16 bytes per lane -- into LDS, and a lane whose column falls inside the window
+// gathers from LDS (a wave instruction of 64 random 8-byte reads costs the LDS a few cycles, not 64 tag lookups); columns outside go
+// to memory as before (exec-masked: skipped when no lane needs it).  Everything else is csr_wavev: same partition, same request
+// shape, same products in the same slots, storage-order sums -- bit-exact.  The window loads are issued IN FRONT of the streams, so the
+// wait for them leaves the streams in flight.  LDS: window x sizeof(T) + 4 x 256 V x sizeof(T) per workgroup.
+template <typename T, int V, int POL, bool DOT>
+__global__ void __launch_bounds__(256)
+csr_wavex_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t num_entries, int64_t num_rows, int64_t num_cols, const int *Ap,
+                 const int *__restrict__ Aj, const T *__restrict__ Ax, const T *__restrict__ x, T *__restrict__ y, int64_t num_tiles,
+                 int64_t tiles_per_xcd, int swizzle, int accumulate, int window, const T *__restrict__ w, double *__restrict__ dot_partial)
+{
+    constexpr int E = sizeof(T) == 8 ? 2 : 4, NL = (V * 4) / E, SLOTS = kWave * V * 4, XE = 16 / (int)sizeof(T);
+    typedef int __attribute__((ext_vector_type(E))) idx_t;
+    typedef T __attribute__((ext_vector_type(E))) val_t;
+    typedef T __attribute__((ext_vector_type(XE))) xvec_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double dot_slots[DOT ? 4 : 1];
+    T *xwin = reinterpret_cast<T *>(smem);                       // [window]
+    T *prod = xwin + window;                                     // [4][SLOTS]
+    constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
+    const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle);
+    if (tile >= num_tiles) return; // whole workgroup
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x & (kWave - 1);
+    const int64_t wt = tile * 4 + wave;
+    // the workgroup's row range -> the window's first column (uniform: scalar loads)
+    const int64_t wt_first = tile * 4, wt_last = wt_first + 4 < wave_tiles ? wt_first + 4 : wave_tiles;
+    const int row_lo = start[2 * wt_first], row_hi = start[2 * wt_last];
+    int64_t centre = ((int64_t)row_lo + row_hi) / 2;
+    if (num_cols != num_rows) centre = (int64_t)((double)centre * (double)num_cols / (double)(num_rows > 0 ? num_rows : 1));
+    int64_t w0 = centre - window / 2;
+    if (w0 > num_cols - window) w0 = num_cols - window;
+    if (w0 < 0) w0 = 0;
+    w0 &= ~(int64_t)(XE - 1); // 16-byte aligned reads of x (cmi_malloc'ed vectors are; an unaligned x: the host does not select this kernel)
+    // ---- the window: requested first ----
+    const int per = window / (256 * XE); // vectors per thread (host: window is a multiple of 256 * XE)
+    xvec_t xw[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (j < per) {
+            const int64_t e = w0 + ((int64_t)j * 256 + threadIdx.x) * XE;
+            if (e + XE <= num_cols) xw[j] = *reinterpret_cast<const xvec_t *>(x + e);
+            else {
+#pragma unroll
+                for (int i = 0; i < XE; i++) xw[j][i] = e + i < num_cols ? x[e + i] : T(0);
+            }
+        }
+    }
+    double d = 0.0;
+    int rs = 0, nz0 = 0, nz1 = 0, nr = 0, fbase = 0, first_turn_end = 0, a = 0, b = 0;
+    bool fits = false;
+    idx_t c[NL];
+    val_t v[NL];
+    T *mine = prod + (size_t)wave * SLOTS;
+    if (wt < wave_tiles) {
+        const int2v lo = *reinterpret_cast<const int2v *>(start + 2 * wt), hi = *reinterpret_cast<const int2v *>(start + 2 * wt + 2);
+        rs = lo.x; nz0 = lo.y; nz1 = hi.y;
+        nr = hi.x - rs;
+        if (nr > 0) {
+            fbase = nz0 & ~(E - 1);
+            first_turn_end = Ap[rs + (nr < kWave ? nr : kWave)];
+            a = Ap[rs + (lane < nr ? lane : nr)];
+            fits = nz1 > nz0 && (int64_t)((nz1 + E - 1) & ~(E - 1)) <= num_entries && nz1 - fbase <= SLOTS;
+            if (fits) {
+                const int last = (nz1 - 1) & ~(E - 1);
+#pragma unroll
+                for (int k = 0; k < NL; k++) {
+                    int e = fbase + (k * kWave + lane) * E;
+                    e = e < last ? e : last;
+                    c[k] = ld<NT>(reinterpret_cast<const idx_t *>(Aj + e));
+                }
+#pragma unroll
+                for (int k = 0; k < NL; k++) {
+                    int e = fbase + (k * kWave + lane) * E;
+                    e = e < last ? e : last;
+                    v[k] = ld<NT>(reinterpret_cast<const val_t *>(Ax + e));
+                }
+            }
+        }
+    }
+    // ---- window into LDS (its loads are the oldest: the wait leaves the streams in flight), then the workgroup meets ----
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if (j < per) *reinterpret_cast<xvec_t *>(xwin + ((size_t)j * 256 + threadIdx.x) * XE) = xw[j];
+    __syncthreads();
+    if (nr > 0) {
+        if (fits) {
+            val_t xv[NL];
+            const int iw0 = (int)w0;
+#pragma unroll
+            for (int k = 0; k < NL; k++)
+#pragma unroll
+                for (int i = 0; i < E; i++) {
+                    const unsigned off = (unsigned)(c[k][i] - iw0);
+                    xv[k][i] = off < (unsigned)window ? xwin[off] : x[c[k][i]];
+                }
+#pragma unroll
+            for (int k = 0; k < NL; k++) {
+                val_t pr;
+#pragma unroll
+                for (int i = 0; i < E; i++) pr[i] = v[k][i] * xv[k][i];
+                *reinterpret_cast<val_t *>(mine + (k * kWave + lane) * E) = pr;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        b = __builtin_amdgcn_update_dpp(first_turn_end, a, 0x130, 0xf, 0xf, false);
+        for (int r = lane; r < nr; r += kWave) {
+            if (r >= kWave) { a = Ap[rs + r]; b = Ap[rs + r + 1]; }
+            T sum = accumulate ? y[rs + r] : T(0);
+            if (fits) sum = sum_in_order(sum, mine + (a - fbase), b - a);
+            else for (int j = a; j < b; j++) sum = sum + Ax[j] * x[Aj[j]];
+            st<NTS>(y + rs + r, sum);
+            if constexpr (DOT) d += (double)sum * (double)w[rs + r];
+        }
+    }
+    if constexpr (DOT) {
+        tile_dot_store(d, dot_slots, dot_partial + tile);
+        if (tile == 0 && threadIdx.x == 0) reset_fold_state(dot_partial);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // csr_stream_pipe: persistent, software-pipelined csr_stream
 // ---------------------------------------------------------------------------------------------
 // The plain csr_stream workgroup pays three DEPENDENT global round trips per tile (row pointers ->
@@ -1094,6 +1221,59 @@ int measure_row_lengths(int64_t rows, const int *Ap, hipStream_t s, int64_t *max
     return CMI_SUCCESS;
 }
 
+// Column locality of a CSR matrix (plans made WITH the column indices, cmi_plan_create_csr): out[0] = entries whose column lies within
+// `halfwin` of the diagonal position of their row (row * cols / rows) -- what an LDS x window centred on a workgroup's rows would serve --
+// and out[1] = entries whose column is 16 or more away from their predecessor's in the row (no shared 128-byte line of x: every such
+// entry is its own L1 lookup).  One lane per row, set-up only.
+__global__ void __launch_bounds__(256) column_locality_kernel(int64_t num_rows, int64_t num_cols, const int *__restrict__ Ap, const int *__restrict__ Aj, int halfwin,
+                                                              unsigned long long *__restrict__ out)
+{
+    __shared__ unsigned long long slots[2][256 / kWave];
+    unsigned long long inside = 0, jumps = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < num_rows; r += stride) {
+        const int a = Ap[r], b = Ap[r + 1];
+        const int64_t centre = num_cols == num_rows ? r : (int64_t)((double)r * (double)num_cols / (double)num_rows);
+        int prev = -(1 << 30);
+        for (int j = a; j < b; j++) {
+            const int c = Aj[j];
+            const int64_t dlt = (int64_t)c - centre;
+            inside += (dlt < halfwin && dlt > -(int64_t)halfwin) ? 1u : 0u;
+            if (j > a) { const int g = c - prev; jumps += (g >= 16 || g <= -16) ? 1u : 0u; }
+            prev = c;
+        }
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) { inside += __shfl_down(inside, o); jumps += __shfl_down(jumps, o); }
+    if ((threadIdx.x & (kWave - 1)) == 0) { slots[0][threadIdx.x / kWave] = inside; slots[1][threadIdx.x / kWave] = jumps; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 256 / kWave; w++) { inside += slots[0][w]; jumps += slots[1][w]; }
+        if (inside) atomicAdd(out, inside);
+        if (jumps) atomicAdd(out + 1, jumps);
+    }
+}
+
+int measure_column_locality(int64_t rows, int64_t cols, const int *Ap, const int *Aj, int halfwin, hipStream_t s, int64_t *inside, int64_t *jumps)
+{
+    unsigned long long *dev = nullptr, host[2] = {0, 0};
+    CMI_HIP(hipMalloc((void **)&dev, sizeof(host)));
+    hipError_t e = hipMemsetAsync(dev, 0, sizeof(host), s);
+    if (e == hipSuccess) {
+        int64_t blocks = ceil_div(rows, 256);
+        if (blocks > kCus * 16) blocks = kCus * 16;
+        hipLaunchKernelGGL(column_locality_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, rows, cols, Ap, Aj, halfwin, dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return hip_fail(e, "column locality profile");
+    *inside = (int64_t)host[0];
+    *jumps = (int64_t)host[1];
+    return CMI_SUCCESS;
+}
+
 // cost of the longest row inside the row-tile kernel vs the whole multiply at streaming speed.  The row's
 // workgroup streams it cooperatively (kLongRowUs per entry: 1.2-2.4 ns measured, one workgroup is latency-bound at
 // ~10 GB/s; tools/irregular_probe.py --sweep, profiles/r01_irregular_rows.txt); with
@@ -1384,6 +1564,35 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
             case 2: go(std::integral_constant<int, 2>()); break;
             default: go(std::integral_constant<int, 4>()); break;
             }
+        });
+        if (dot && dot_partials) *dot_partials = (int)tiles;
+        break;
+    }
+    case CMI_CSR_STREAM_WAVEX: { // csr_wavev + an x window in LDS per workgroup (gather-bound band matrices)
+        const int V = c.items_per_thread;
+        if (!plan || !plan->wave_row_start || plan->wave_q <= 0) return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_CSR_STREAM_WAVEX runs through a plan (cmi_plan_create) only");
+        if (V != 2 && V != 4) return fail(CMI_ERROR_NOT_SUPPORTED, "csr_wavex: items_per_thread (index vectors per lane) must be 2 or 4");
+        if (reinterpret_cast<uintptr_t>(Aj) % 16 != 0 || reinterpret_cast<uintptr_t>(Ax) % 16 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0)
+            return fail(CMI_ERROR_INVALID_VALUE, "csr_wavex: Aj, Ax and x must be 16-byte aligned");
+        const int xe = 16 / (int)sizeof(T);
+        int window = c.rows_per_block > 0 ? c.rows_per_block : 4096; // (the config's rows_per_block field carries the window length for this kernel)
+        window = (window + 256 * xe - 1) / (256 * xe) * (256 * xe);
+        if (window > 8 * 256 * xe) window = 8 * 256 * xe;
+        const int64_t tiles = ceil_div(plan->wave_tiles, (int64_t)4);
+        const int64_t tpx = ceil_div(tiles, kXcds);
+        const int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
+        const int64_t grid64 = padded_grid(tiles, swz);
+        if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "csr_wavex: grid too large");
+        const size_t lds = ((size_t)window + (size_t)4 * kWave * V * 4) * sizeof(T);
+        const bool dot = w && dot_partial && tiles <= kPartialCapacity;
+        with_policy(pol, [&](auto P) {
+            constexpr int POL = decltype(P)::value;
+            auto go = [&](auto VV) {
+                constexpr int VC = decltype(VV)::value;
+                if (dot) hipLaunchKernelGGL((csr_wavex_kernel<T, VC, POL, true>), dim3((unsigned)grid64), dim3(256), lds, s, plan->wave_row_start, plan->wave_tiles, nnz, rows, cols, Ap, Aj, Ax, x, y, tiles, tpx, swz, accumulate, window, w, dot_partial);
+                else     hipLaunchKernelGGL((csr_wavex_kernel<T, VC, POL, false>), dim3((unsigned)grid64), dim3(256), lds, s, plan->wave_row_start, plan->wave_tiles, nnz, rows, cols, Ap, Aj, Ax, x, y, tiles, tpx, swz, accumulate, window, (const T *)nullptr, (double *)nullptr);
+            };
+            if (V == 2) go(std::integral_constant<int, 2>()); else go(std::integral_constant<int, 4>());
         });
         if (dot && dot_partials) *dot_partials = (int)tiles;
         break;

@@ -80,7 +80,23 @@ class ShardedVectorExchange:
         self.comm = comm
         if comm is None and world > 1 and torch.device(device).type == "cuda" and dist.is_initialized() and dist.get_backend(group) == "nccl":
             from . import binding as B
-            self.comm = B.Comm.from_torch_distributed(group)
+            import os
+            import sys
+            ok, why = 1, ""
+            if os.environ.get("CMI_PYTHON_COMM", "1") == "0":
+                ok, why = 0, "CMI_PYTHON_COMM=0"
+            else:
+                try:
+                    self.comm = B.Comm.from_torch_distributed(group)
+                except Exception as e:  # noqa: BLE001 -- e.g. librccl not loadable: every rank must then take the same way out
+                    ok, why = 0, f"{type(e).__name__}: {e}"
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 0:
+                if rank == 0 or why:
+                    print(f"[cusp-autotuned_amd] rank {rank}: the C-ABI communicator is not used ({why or 'another rank could not make it'}); "
+                          "the exchange falls back to torch.distributed collectives", file=sys.stderr)
+                self.comm = None
         self.num_cols = num_cols
         self._span = (col_min, col_max)
         # the partition of x (= of the rows): equal counts by default, any monotone cut list on request

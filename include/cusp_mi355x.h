@@ -171,6 +171,12 @@ typedef enum cmi_kernel {
                                every row in storage order.  No workgroup barrier (csr_stream's waves sit at theirs for most of their
                                life on such rows: profiles/r03_long_rows_pmc_csr_stream.json), every wave owns rows.  Bit-exact.  Needs
                                16-byte aligned Aj / Ax, no row of 512+ entries, longest row <= 128 x items_per_thread - 3.           */
+    CMI_CSR_STREAM_WAVEX = 9, /* plans only (round 3): CMI_CSR_STREAM_WAVEV plus an x WINDOW in LDS -- the workgroup (four wave tiles) copies the
+                               rows_per_block (0: 4096; the field carries the WINDOW LENGTH here, a multiple of 512 (f64) / 1024 (f32), at most
+                               4096 / 8192) consecutive x entries around the diagonal position of its rows into LDS, coalesced, and gathers
+                               from there; columns outside the window are gathered from memory as usual.  For GATHER-BOUND band matrices
+                               (columns anywhere within a few thousand of the diagonal: every x entry is its own L1 lookup otherwise).
+                               items_per_thread 2 or 4.  Bit-exact.  Needs 16-byte aligned Aj / Ax / x.                                   */
     /* ELL */
     CMI_ELL_ROW = 10, /* one lane per row            (ref: ell_spmv.h:55-93); threads_per_row 2,4,8,16: that many
                          lanes per row, each summing every 2nd / 4th / ... slot (ref: THREADS_PER_ROW of ktt

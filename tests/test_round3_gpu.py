@@ -384,8 +384,104 @@ def test_every_entry_of_the_shipped_tuning_table_against_the_oracle(cmi, torch_c
         # and what a NULL config selects for this shape is this entry (the table is what the library consults)
         sel = cmi.tuning_select({"csr": 0, "ell": 1, "dia": 2, "coo": 3, "coo_sorted": cmi.TABLE_COO_SORTED}[fmt], cmi.F64 if tag == "f64" else cmi.F32,
                                 rows, rows, len(Aj) if fmt in ("csr", "coo", "coo_sorted") else rows * width)
-        assert sel.kernel == e["kernel"] or fmt == "csr", (fmt, tag, bucket, sel, e)
+        actual_mean = len(Aj) / rows if fmt in ("csr", "coo", "coo_sorted") else float(width)
+        actual_bucket = 0 if actual_mean <= 1.0 else min(7, int(np.floor(np.log2(actual_mean))))
+        if actual_bucket == bucket and fmt != "csr":  # (boundary rows can put a width-2^b matrix one bucket lower: then another entry is consulted)
+            assert sel.kernel == e["kernel"], (fmt, tag, bucket, sel, e)
     assert len(seen) == len(entries), "duplicate (format, dtype, bucket) keys in the shipped table"
     for fmt in ("csr", "ell", "dia", "coo", "coo_sorted"):
         for tag in ("f64", "f32"):
             assert {b for f, t, b in seen if f == fmt and t == tag} == set(range(8)), (fmt, tag)
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_wavex_lds_window_bit_exact(cmi, torch_cuda, orc, tag):
+    """CMI_CSR_STREAM_WAVEX = csr_wavev + an x window in LDS per workgroup: columns inside the window are gathered from LDS, columns
+    outside from memory -- the same products in the same order either way, so every row must keep the host loop's bits
+    (cusp/system/detail/sequential/multiply/csr_spmv.h:42-74): band matrices (all columns inside), columns far outside the window,
+    rectangular matrices, windows of every allowed length, accumulate and the fused <y, w>."""
+    torch = torch_cuda
+    dtype, tdt = (np.float64, torch.float64) if tag == "f64" else (np.float32, torch.float32)
+    for seed, rows, cols, lo, hi, band in ((1, 9000, 9000, 2, 9, 700), (2, 5000, 5000, 10, 30, 1500), (3, 7001, 9100, 0, 12, 9100), (4, 4099, 3000, 20, 60, 300)):
+        rng = np.random.default_rng(seed)
+        lens = rng.integers(lo, hi + 1, size=rows)
+        lens[100:400] = 0
+        if int(lens.sum()) % 4 == 0:
+            lens[0] += 1
+        Ap = np.r_[0, np.cumsum(lens)].astype(np.int32)
+        nnz = int(Ap[-1])
+        ri = np.repeat(np.arange(rows, dtype=np.int64), lens)
+        centre = ri * cols // rows
+        Aj = np.clip(centre + rng.integers(-band, band + 1, size=nnz), 0, cols - 1).astype(np.int32)
+        Ax = rng.standard_normal(nnz).astype(dtype)
+        x = rng.standard_normal(cols).astype(dtype)
+        y0 = rng.standard_normal(rows).astype(dtype)
+        want, want_acc = orc.spmv_csr(Ap, Aj, Ax, x), orc.spmv_csr(Ap, Aj, Ax, x, y0)
+        dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+        for v, window in ((2, 0), (4, 0), (2, 512 if tag == "f64" else 1024), (4, 2048), (4, 100000)):
+            plan = cmi.Plan(cmi.FORMAT_CSR, tdt, rows, cols, nnz, dAp, cmi.Config(kernel=cmi.CSR_STREAM_WAVEX, items_per_thread=v, rows_per_block=window))
+            c = plan.config()
+            assert c.kernel == cmi.CSR_STREAM_WAVEX and c.items_per_thread == v and plan.info()["storage_order_sums"]
+            y = torch.full((rows,), 9.0, dtype=tdt, device="cuda")
+            cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
+            assert np.array_equal(y.cpu().numpy(), want), (seed, v, window)
+            y = dev(y0, torch)
+            cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y, accumulate=True)
+            assert np.array_equal(y.cpu().numpy(), want_acc), (seed, v, window, "accumulate")
+        w = rng.standard_normal(rows).astype(dtype)
+        res = torch.zeros(1, dtype=torch.float64, device="cuda")
+        y = torch.zeros(rows, dtype=tdt, device="cuda")
+        cmi.spmv_csr_dot(rows, cols, dAp, dAj, dAx, dx, y, dev(w, torch), res, cmi.blas_workspace(), plan=plan)
+        assert np.array_equal(y.cpu().numpy(), want), (seed, "dot")
+        ref = float(np.dot(want.astype(np.float64), w.astype(np.float64)))
+        assert abs(float(res) - ref) <= 1e-12 * float(np.abs(want.astype(np.float64) * w).sum()) + (0 if tag == "f64" else 1e-6 * abs(ref)), seed
+
+
+def test_auto_plans_pick_wavev_and_wavex_by_the_measured_rule(cmi, torch_cuda, orc):
+    """The plan's auto rule (plan.hip wavev_auto / column_profile, measured in profiles/r03_wavev_wavex_ab.txt): large irregular
+    matrices of 2.5-44 entries per row run csr_wavev; made WITH the column indices, a plan whose columns lie anywhere inside a band
+    adds the LDS x window (csr_wavex); small matrices, FEM-like column runs and the plan-less path stay what they were.  Every choice
+    keeps the host loop's bits."""
+    torch = torch_cuda
+
+    def irregular(rows, lo, hi, band, seed, dt, runs=1):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        lens = torch.randint(lo, hi + 1, (rows,), device="cuda", generator=g) * runs
+        Ap = torch.zeros(rows + 1, dtype=torch.int32, device="cuda")
+        Ap[1:] = lens.cumsum(0).to(torch.int32)
+        nnz = int(Ap[-1])
+        row = torch.repeat_interleave(torch.arange(rows, device="cuda"), lens)
+        if runs == 1:
+            Aj = (row + torch.randint(-band, band + 1, (nnz,), device="cuda", generator=g)) % rows
+        else:  # runs of `runs` consecutive columns (FEM blocks): neighbours share x lines
+            base = torch.randint(-band, band + 1, (nnz // runs,), device="cuda", generator=g).repeat_interleave(runs)
+            Aj = (row + base + torch.arange(nnz, device="cuda") % runs) % rows
+        return Ap, Aj.to(torch.int32), torch.randn(nnz, dtype=dt, device="cuda", generator=g)
+
+    cases = [("band f32", irregular(4_000_000, 5, 12, 2000, 4, torch.float32), cmi.CSR_STREAM_WAVEX, cmi.CSR_STREAM_WAVEV),
+             ("band f64", irregular(3_000_000, 5, 12, 2000, 5, torch.float64), cmi.CSR_STREAM_WAVEX, cmi.CSR_STREAM_WAVEV),
+             ("blocks of 3 f64", irregular(1_500_000, 3, 8, 2000, 6, torch.float64, runs=3), cmi.CSR_STREAM_WAVEV, cmi.CSR_STREAM_WAVEV),
+             ("small band f64", irregular(200_000, 5, 12, 2000, 7, torch.float64), cmi.CSR_STREAM, cmi.CSR_STREAM)]
+    for name, (Ap, Aj, Ax), want_with_columns, want_offsets_only in cases:
+        N, nnz, dt = Ap.numel() - 1, Aj.numel(), Ax.dtype
+        g = torch.Generator(device="cuda").manual_seed(1)
+        x = torch.randn(N, dtype=dt, device="cuda", generator=g)
+        want = orc.spmv_csr(Ap.cpu().numpy(), Aj.cpu().numpy(), Ax.cpu().numpy(), x.cpu().numpy())
+        p_cols = cmi.Plan.csr(dt, N, N, Ap, Aj)
+        p_offs = cmi.Plan(cmi.FORMAT_CSR, dt, N, N, nnz, Ap)
+        assert p_cols.config().kernel == want_with_columns, (name, p_cols.config())
+        assert p_offs.config().kernel == want_offsets_only, (name, p_offs.config())
+        for p in (p_cols, p_offs):
+            assert p.info()["storage_order_sums"]
+            y = torch.full((N,), 3.0, dtype=dt, device="cuda")
+            cmi.spmv_csr_plan(p, Ap, Aj, Ax, x, y)
+            assert np.array_equal(y.cpu().numpy(), want), (name, p.config())
+        y = torch.full((N,), 3.0, dtype=dt, device="cuda")
+        cmi.spmv_csr(N, N, Ap, Aj, Ax, x, y)  # plan-less: the table's csr_stream, whatever the matrix
+        assert np.array_equal(y.cpu().numpy(), want), name
+        # the container path (cusp::multiply's mirror) makes its plan with the columns
+        A = cmi.CsrMatrix(N, N, nnz, Ap, Aj, Ax)
+        y.fill_(1.0)
+        cmi.multiply(A, x, y)
+        assert A.plan().config().kernel == want_with_columns and np.array_equal(y.cpu().numpy(), want), name
+        del p_cols, p_offs, A

@@ -244,6 +244,8 @@ def main():
     ap.add_argument("--synthetic-rows", type=int, default=1_000_000, help="rows of the seeded synthetic CSR matrices (8e6: their streams no longer fit the 256 MiB Infinity Cache)")
     ap.add_argument("--csr-max-mean", type=float, default=1e9, help="CSR: skip the tuning matrices with more entries per row than this")
     ap.add_argument("--merge", action="store_true", help="start from the table at --out (tune some formats, keep the others)")
+    ap.add_argument("--buckets", default="", help="--per-bucket: only these buckets (comma-separated)")
+    ap.add_argument("--skip-headline", action="store_true", help="do not re-tune on the headline matrix (per-bucket re-runs)")
     ap.add_argument("--per-bucket", action="store_true", help="ELL / DIA / COO: a tuning matrix per bucket of the table (width 1.2 x 2^b), not the "
                                                              "headline matrix's shape replicated over all eight")
     args = ap.parse_args()
@@ -294,7 +296,11 @@ def main():
                 return bool(np.max(np.abs(got - want)) <= tol * scale), f"tolerance {tol}"
             return check
 
-        if "csr" in formats:
+        if args.skip_headline:
+            formats_h = []
+        else:
+            formats_h = formats
+        if "csr" in formats_h:
             label = f"csr/{tag}/poisson{m}x{n}"
             best, ms, res = tune_one(cmi, torch, timer, label, csr_space(cmi, 5.0, args.quick, args.csr_stream_only),
                                      lambda cfg: cmi.multiply(A, dx, y, cfg=cfg),
@@ -303,7 +309,7 @@ def main():
             cmi.tuning_set(cmi.FORMAT_CSR, dcode, A.num_entries / N, best)
             summary.append((label, best.as_dict(), ms))
             print(label, best, f"{ms * 1e3:.1f} us", flush=True)
-        if "ell" in formats:
+        if "ell" in formats_h:
             E = cmi.convert(A, "ell")
             label = f"ell/{tag}/poisson{m}x{n}"
             best, ms, res = tune_one(cmi, torch, timer, label, ell_space(cmi, args.quick),
@@ -314,7 +320,7 @@ def main():
             summary.append((label, best.as_dict(), ms))
             print(label, best, f"{ms * 1e3:.1f} us", flush=True)
             del E
-        if "dia" in formats:
+        if "dia" in formats_h:
             D = cmi.poisson5pt(m, n, "dia", dtype=tdt)
             label = f"dia/{tag}/poisson{m}x{n}"
             best, ms, res = tune_one(cmi, torch, timer, label, dia_space(cmi, args.quick),
@@ -325,7 +331,7 @@ def main():
             summary.append((label, best.as_dict(), ms))
             print(label, best, f"{ms * 1e3:.1f} us", flush=True)
             del D
-        if "coo" in formats:
+        if "coo" in formats_h:
             C = cmi.convert(A, "coo")
             label = f"coo/{tag}/poisson{m}x{n}"
             space = coo_space(cmi, args.quick)
@@ -356,10 +362,14 @@ def main():
         #      row count allows; bucket 2 keeps the headline matrix.  Parameter spaces being replaced: cusp/system/cuda/ktt/
         #      {ell_multiply.h:20-77, dia_multiply.h:24-55, coo_multiply.h:22-54}; validation as testing/ktt.cu:142-202.
         if args.per_bucket and any(f in formats for f in ("ell", "dia", "coo")):
+            import math
+            only = {int(t) for t in args.buckets.split(",") if t != ""} if args.buckets else None
             for b in range(0, 8):
-                if b == 2:
-                    continue  # the headline matrix above
+                if b == 2 or (only is not None and b not in only):
+                    continue  # (2: the headline matrix above)
                 width = max(1, int(round(1.2 * 2.0 ** b)))
+                while b >= 1 and math.floor(math.log2(width * (1.0 - 1e-3))) < b:
+                    width += 1  # boundary rows make the mean a little smaller than the width: stay inside bucket b (width 2 -> mean 1.9999999 is bucket 0)
                 rows_b = int(min(1.0e7, max(2.0e5, 5.0e7 / width))) if not args.quick else 100_000
                 offs = sorted({0} | {(-1) ** k * ((k + 1) // 2) * (1 if k < 4 else 1000) for k in range(1, width)})
                 while len(offs) < width:

@@ -41,6 +41,11 @@ def main():
         Ap, Aj, Ax, _ = ssl.load(name, 0.05 if args.quick else 1.0)
         for dt, nd in ((torch.float64, np.float64), (torch.float32, np.float32)):
             cases.append((f"{name}-like {str(dt)[6:]}", torch.from_numpy(Ap).cuda(), torch.from_numpy(Aj).cuda(), torch.from_numpy(Ax.astype(nd)).cuda()))
+    # an unstructured FEM matrix BEYOND the Infinity Cache: sorted columns, neighbours rarely adjacent (few shared x lines inside a row) but
+    # shared between neighbouring rows -- the case an LDS x window must not be switched on for by a careless rule
+    Ap, Aj, Ax, _ = ssl.load("thermal2", 0.3 if args.quick else 6.0)
+    for dt, nd in ((torch.float64, np.float64), (torch.float32, np.float32)):
+        cases.append((f"thermal2-like x6 {str(dt)[6:]}", torch.from_numpy(Ap).cuda(), torch.from_numpy(Aj).cuda(), torch.from_numpy(Ax.astype(nd)).cuda()))
     s = 0.1 if args.quick else 1.0
     for dt in (torch.float64, torch.float32):
         tag = str(dt)[6:]
@@ -62,6 +67,9 @@ def main():
         cmi.spmv_csr_plan(auto, Ap, Aj, Ax, x, y0)
         fns, labels = [lambda: cmi.spmv_csr_plan(auto, Ap, Aj, Ax, x, y0)], ["auto plan"]
         plans, ys, same = [], [], []
+        yt = torch.full((N,), 5.0, dtype=dt, device="cuda")
+        fns.append(lambda: cmi.spmv_csr(N, N, Ap, Aj, Ax, x, yt))   # no plan: the table's csr_stream entry
+        labels.append("table csr_stream")
         for v in (1, 2, 4):
             try:
                 p = cmi.Plan.csr(dt, N, N, Ap, Aj, cfg=cmi.Config(kernel=cmi.CSR_STREAM_WAVEV, items_per_thread=v))
@@ -72,12 +80,32 @@ def main():
             plans.append(p); ys.append(y); same.append(bool(torch.equal(y, y0)))
             fns.append(lambda p=p, y=y: cmi.spmv_csr_plan(p, Ap, Aj, Ax, x, y))
             labels.append(f"wavev V={v} policy {p.config().nontemporal}")
+        if hasattr(cmi, "CSR_STREAM_WAVEX"):
+            for v, win in ((2, 0), (4, 0), (4, 2048)):
+                try:
+                    p = cmi.Plan.csr(dt, N, N, Ap, Aj, cfg=cmi.Config(kernel=cmi.CSR_STREAM_WAVEX, items_per_thread=v, rows_per_block=win))
+                except cmi.CmiError:
+                    continue
+                y = torch.full((N,), 9.0, dtype=dt, device="cuda")
+                cmi.spmv_csr_plan(p, Ap, Aj, Ax, x, y)
+                plans.append(p); ys.append(y); same.append(bool(torch.equal(y, y0)))
+                fns.append(lambda p=p, y=y: cmi.spmv_csr_plan(p, Ap, Aj, Ax, x, y))
+                labels.append(f"wavex V={v} window {win or 4096}")
         t = time_us(fns, 30, 5)
         ca = auto.config()
         alg = cmi.csr_bytes(N, nnz, 8 if dt == torch.float64 else 4)
-        best = min(range(1, len(t)), key=lambda k: t[k]) if len(t) > 1 else 0
+        best = min(range(2, len(t)), key=lambda k: t[k]) if len(t) > 2 else 0
         lens = (Ap[1:] - Ap[:-1])
-        print(f"{name}: {N} rows, {nnz / N:.2f} per row (max {int(lens.max())}), {alg / 1e6:.0f} MB | auto plan kernel {ca.kernel} block {ca.block_size} rpb {ca.rows_per_block} "
+        # the two column statistics a plan made with the columns can measure (plan.hip): entries within 1536 columns of their row's
+        # diagonal position, and entries 16+ columns away from their predecessor in the row
+        rowid = torch.repeat_interleave(torch.arange(N, device="cuda"), lens.long())
+        inside = float(((Aj.long() - rowid).abs() < 1536).double().mean())
+        first = torch.zeros(nnz, dtype=torch.bool, device="cuda")
+        first[Ap[:-1][lens > 0].long()] = True
+        gap = (Aj[1:].long() - Aj[:-1].long()).abs() >= 16
+        jumps = float((gap & ~first[1:]).double().sum()) / max(nnz, 1)
+        del rowid, first, gap
+        print(f"[inside {inside:.2f} jumps {jumps:.2f}] " + f"{name}: {N} rows, {nnz / N:.2f} per row (max {int(lens.max())}), {alg / 1e6:.0f} MB | auto plan kernel {ca.kernel} block {ca.block_size} rpb {ca.rows_per_block} "
               f"ipt {ca.items_per_thread} policy {ca.nontemporal}: {t[0]:7.1f} us ({alg / t[0] / 8e6:.3f}) | " +
               " | ".join(f"{labels[k]}: {t[k]:7.1f} us" for k in range(1, len(t))) +
               (f" | best wavev / auto = {t[best] / t[0]:.3f}" if best else "") + (" | same bits" if all(same) else " | DIFFERENT BITS"), flush=True)
