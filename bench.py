@@ -425,6 +425,10 @@ def main():
     # Settle phase (disclosed as `settle_launches`, not part of W or K): the device comes out of setup at idle clocks
     # and a 20-step timed region lasts < 3 ms, so the clocks are brought up first.  Then the contract's W warm-up steps.
     SETTLE = 100
+    # launch ledger of the hot path's kernel at N = 1 (phase, launches), in launch order: a rocprofv3 kernel trace of this command can
+    # then be cut into its phases (tools/trace_phases.py) -- the replay legs and the cold leg launch the SAME kernel, so the trace's one
+    # average per kernel name mixes them ("rocprofv3 average duration for that kernel must agree" is checked per phase)
+    ledger = []
     for _ in range(SETTLE):
         step()
     barrier()
@@ -435,6 +439,7 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
+    ledger += [["settle", SETTLE], ["warmup", args.warmup], ["timed_steps", args.steps]]
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -504,6 +509,7 @@ def main():
         for _ in range(per_batch):
             kernel_only()
         cmi.check(lib.cmi_event_record(evs[2 * bi + 1], sptr))
+    ledger += [["roofline_rewarm", 10], ["roofline", KERNEL_BATCHES * per_batch]]
     batch_ms = []
     for bi in range(KERNEL_BATCHES):
         ms = ctypes.c_float()
@@ -571,6 +577,7 @@ def main():
             for _ in range(10):  # re-warm the replay state for the legs below
                 kernel_only()
             torch.cuda.synchronize()
+            ledger += [["cold_first_touch", COLD_SETS], ["roofline_cold", per_cold * KERNEL_BATCHES], ["cold_rewarm", 10]]
         except Exception as e:  # noqa: BLE001 -- a secondary leg
             cold = {"error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -778,6 +785,8 @@ def main():
                          "kernel_gflops": round(2.0 * local_nnz / (kernel_ms * 1e-3) / 1e9, 2)},
             "settle_launches": SETTLE,
         }
+        if world == 1:
+            line["kernel_launch_ledger"] = ledger  # (phase, launches of the hot path's kernel) in launch order; later legs (CG, opt-in plans) follow
         line["roofline"]["protocol"] = ("replay: one (A, x, y) multiplied back to back (the reference's protocol); x and part of the streams are served "
                                         "from the 256 MiB Infinity Cache between launches -- see roofline_cold for the all-from-HBM figure")
         if cold is not None:

@@ -163,6 +163,35 @@ template <typename Space> static void run(cd::communicator &comm, const char *sp
     }
 }
 
+// float operators and vectors: the f32 instances of the sharded multiply and of the (fused, on device) CG -- scalars stay doubles
+template <typename Space> static void run_float(cd::communicator &comm, const char *space_name)
+{
+    const size_t m = 53, nn = 41;
+    cd::csr_matrix<int, float, Space> A(comm);
+    cd::poisson5pt(A, m, nn);
+    cusp::csr_matrix<int, float, cusp::host_memory> G;
+    cusp::gallery::poisson5pt(G, m, nn);
+    cusp::array1d<float, cusp::host_memory> xg(m * nn), yg(m * nn);
+    for (size_t i = 0; i < xg.size(); i++) xg[i] = float((unsigned(i) * 2654435761u) % 1000u) / 997.0f - 0.5f;
+    cusp::multiply(G, xg, yg);
+    auto x = A.make_vector(), y = A.make_vector(7.0f);
+    { cusp::array1d<float, cusp::host_memory> t(xg.begin() + A.row_begin(), xg.begin() + A.row_end()); auto xv = x.local(); cusp::copy_array(t, xv); }
+    cusp::multiply(A, x, y);
+    cusp::array1d<float, cusp::host_memory> got(y.local());
+    bool same = true;
+    for (size_t i = 0; same && i < got.size(); i++) same = got[i] == yg[A.row_begin() + i];
+    CHECK(same, "float sharded multiply differs [%s]", space_name);
+    auto b = A.make_vector(1.0f), sol = A.make_vector(0.0f);
+    cusp::monitor<float> mon(b, 300, 1e-4f);
+    cusp::krylov::cg(A, sol, b, mon);
+    cusp::array1d<float, cusp::host_memory> bg(m * nn, 1.0f), sg(m * nn, 0.0f);
+    cusp::monitor<float> mon_ref(bg, 300, 1e-4f);
+    cusp::krylov::cg(G, sg, bg, mon_ref);
+    const long di = (long)mon.iteration_count() - (long)mon_ref.iteration_count();
+    CHECK(mon.converged() && di >= -2 && di <= 2, "float CG: %zu iterations sharded, %zu single-process", mon.iteration_count(), mon_ref.iteration_count());
+    if (comm.rank() == 0) std::printf("ok  float: sharded poisson5pt(%zu,%zu) multiply + cg [%s, world %d]  mode %s, %zu iterations\n", m, nn, space_name, comm.size(), A.mode_name(), mon.iteration_count());
+}
+
 int main(int argc, char **argv)
 {
     const bool device = argc > 1 && !std::strcmp(argv[1], "device");
@@ -171,11 +200,13 @@ int main(int argc, char **argv)
         g_rank = comm->rank();
         if (device) {
             run<cusp::device_memory>(*comm, "device_memory");
+            run_float<cusp::device_memory>(*comm, "device_memory");
             int v = 0;
             cusp::detail::check(cmi_comm_library_version(&v));
             if (g_rank == 0) std::printf("RCCL version code %d, world %d\n", v, comm->size());
         } else {
             run<cusp::host_memory>(*comm, "host_memory");
+            run_float<cusp::host_memory>(*comm, "host_memory");
         }
         comm->barrier(cusp::host_memory());
     } catch (const std::exception &e) {
