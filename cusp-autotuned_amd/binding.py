@@ -116,6 +116,9 @@ def _declare(L):
     L.cmi_poisson5pt_shard_entries.argtypes = [i64, i64, i64, i64]
     L.cmi_csr_row_indices.argtypes = [i64, vp, vp, vp]
     L.cmi_coo_row_offsets.argtypes = [i64, i64, vp, vp, POINTER(ctypes.c_int), vp]
+    L.cmi_coo_sort_by_row_f64.argtypes = [i64, i64, i64, vp, vp, vp, ctypes.c_int, vp]
+    L.cmi_coo_sort_by_row_f32.argtypes = [i64, i64, i64, vp, vp, vp, ctypes.c_int, vp]
+    L.cmi_coo_is_sorted.argtypes = [i64, i64, vp, vp, ctypes.c_int, POINTER(ctypes.c_int), vp]
     for sfx in ("f64", "f32"):
         getattr(L, "cmi_ell_to_csr_" + sfx).argtypes = [i64, i64, i64, vp, vp, vp, vp, vp, i64, POINTER(c_int64), vp]
         getattr(L, "cmi_dia_to_csr_" + sfx).argtypes = [i64, i64, i64, i64, vp, vp, vp, vp, vp, i64, POINTER(c_int64), vp]
@@ -1053,6 +1056,29 @@ def coo_row_offsets(num_rows, Ai, Ap, stream=None):
     _need(Ap, "Ap", torch.int32)
     ok = ctypes.c_int(0)
     check(lib().cmi_coo_row_offsets(num_rows, Ai.numel(), _ptr(Ai), _ptr(Ap), byref(ok), _stream(stream)))
+    return bool(ok.value)
+
+
+def coo_sort_by_row(num_rows, num_cols, Ai, Aj, Ax, and_column=False, stream=None):
+    """In-place STABLE sort of COO entries by row (and_column: by (row, column)) on the device -- coo_matrix::sort_by_row
+    (cusp/coo_matrix.h:208-212, cusp/sort.h:231,302).  Entries of one row keep their storage order."""
+    import torch
+    _need(Ai, "Ai", torch.int32)
+    _need(Aj, "Aj", torch.int32)
+    if not (Ai.numel() == Aj.numel() == Ax.numel()):
+        raise ValueError("coo_sort_by_row: the three arrays differ in length")
+    fn = getattr(lib(), "cmi_coo_sort_by_row_" + _suffix(Ax))
+    check(fn(num_rows, num_cols, Ai.numel(), _ptr(Ai), _ptr(Aj), _ptr(Ax), 1 if and_column else 0, _stream(stream)))
+
+
+def coo_is_sorted(num_rows, Ai, Aj=None, and_column=False, stream=None):
+    """is_sorted_by_row / is_sorted_by_row_and_column (cusp/coo_matrix.h:218-224) on the device."""
+    import torch
+    _need(Ai, "Ai", torch.int32)
+    if and_column:
+        _need(Aj, "Aj", torch.int32)
+    ok = ctypes.c_int(0)
+    check(lib().cmi_coo_is_sorted(num_rows, Ai.numel(), _ptr(Ai), _ptr(Aj) if Aj is not None else None, 1 if and_column else 0, byref(ok), _stream(stream)))
     return bool(ok.value)
 
 

@@ -626,7 +626,10 @@ csr_wavep_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, const in
 // first vector starts at the 16-byte boundary at or below its first entry), so a tile always fits its wave's slots; the partition
 // is wave_partition_kernel's (8 bytes per tile, plan-owned).  Same products, storage-order sums: bit-exact.
 // The last vector of the ARRAYS may reach past num_entries: that one wave sums its rows straight from the arrays.
-template <typename T, int V, int POL, bool DOT>
+// ABL != 0: ablation instances for measurements only ($CMI_WAVEV_ABLATE, f64 / V = 4; WRONG results by design) --
+//   bit 1: no x gathers (the columns are still loaded);  bit 2: no LDS, no row sums (every lane adds its own products and lanes
+//   < rows store them);  bit 4: products parked in LDS as usual, but a row's lane reads only its first one.
+template <typename T, int V, int POL, bool DOT, int ABL = 0>
 __global__ void __launch_bounds__(256)
 csr_wavev_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t num_entries, const int *Ap /* not restrict: see csr_wave */,
                  const int *__restrict__ Aj, const T *__restrict__ Ax, const T *__restrict__ x, T *__restrict__ y, int64_t num_tiles,
@@ -680,22 +683,35 @@ csr_wavev_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t 
 #pragma unroll
                 for (int k = 0; k < NL; k++)
 #pragma unroll
-                    for (int i = 0; i < E; i++) xv[k][i] = x[c[k][i]];
+                    for (int i = 0; i < E; i++) {
+                        if constexpr ((ABL & 1) != 0) { asm volatile("" ::"v"(c[k][i])); xv[k][i] = T(1); }
+                        else xv[k][i] = x[c[k][i]];
+                    }
                 asm volatile("" : "+v"(a)); // the row offset was requested in front of the streams
+                T lane_sum = T(0);
 #pragma unroll
                 for (int k = 0; k < NL; k++) {
                     val_t pr;
 #pragma unroll
                     for (int i = 0; i < E; i++) pr[i] = v[k][i] * xv[k][i];
-                    *reinterpret_cast<val_t *>(mine + (k * kWave + lane) * E) = pr; // 16 bytes per lane, lanes contiguous: no bank conflict
+                    if constexpr ((ABL & 2) != 0) {
+#pragma unroll
+                        for (int i = 0; i < E; i++) lane_sum = lane_sum + pr[i];
+                    } else
+                        *reinterpret_cast<val_t *>(mine + (k * kWave + lane) * E) = pr; // 16 bytes per lane, lanes contiguous: no bank conflict
                 }
                 __builtin_amdgcn_wave_barrier(); // (compiler only: the hardware runs a wave's LDS instructions in order)
+                if constexpr ((ABL & 2) != 0) {
+                    if (lane < nr) st<NTS>(y + rs + lane, lane_sum);
+                    return;
+                }
             }
             b = __builtin_amdgcn_update_dpp(first_turn_end, a, 0x130 /* wave_shl:1: the next lane's start; lane 63 keeps the 64th row's end */, 0xf, 0xf, false);
             for (int r = lane; r < nr; r += kWave) { // (one turn, except over a stretch of very short rows)
                 if (r >= kWave) { a = Ap[rs + r]; b = Ap[rs + r + 1]; }
                 T sum = accumulate ? y[rs + r] : T(0);
-                if (fits) sum = sum_in_order(sum, mine + (a - fbase), b - a);
+                if constexpr ((ABL & 4) != 0) { if (fits && b > a) sum = sum + mine[a - fbase]; }
+                else if (fits) sum = sum_in_order(sum, mine + (a - fbase), b - a);
                 else for (int j = a; j < b; j++) sum = sum + Ax[j] * x[Aj[j]]; // (the array's last vector, or an empty tile)
                 st<NTS>(y + rs + r, sum);
                 if constexpr (DOT) d += (double)sum * (double)w[rs + r];
@@ -1552,6 +1568,24 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         const int64_t grid64 = padded_grid(tiles, swz);
         if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "csr_wavev: grid too large");
         const bool dot = w && dot_partial && tiles <= kPartialCapacity;
+        if constexpr (sizeof(T) == 8) { // measurements only: ablated instances (wrong results by design), f64 / V = 4 / nt loads and stores
+            static const int ablate = [] { const char *e = std::getenv("CMI_WAVEV_ABLATE"); return e ? std::atoi(e) : 0; }();
+            if (ablate > 0 && ablate < 8 && V == 4 && !dot) {
+                auto run = [&](auto A) {
+                    constexpr int AB = decltype(A)::value;
+                    hipLaunchKernelGGL((csr_wavev_kernel<T, 4, 3, false, AB>), dim3((unsigned)grid64), dim3(256), 0, s, plan->wave_row_start, plan->wave_tiles, nnz, Ap, Aj, Ax, x, y, tiles, tpx, swz, accumulate, (const T *)nullptr, (double *)nullptr);
+                };
+                switch (ablate) {
+                case 1: run(std::integral_constant<int, 1>()); break;
+                case 2: run(std::integral_constant<int, 2>()); break;
+                case 3: run(std::integral_constant<int, 3>()); break;
+                case 4: run(std::integral_constant<int, 4>()); break;
+                case 5: run(std::integral_constant<int, 5>()); break;
+                default: return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_WAVEV_ABLATE: 1..5");
+                }
+                break;
+            }
+        }
         with_policy(pol, [&](auto P) {
             constexpr int POL = decltype(P)::value;
             auto go = [&](auto VV) {

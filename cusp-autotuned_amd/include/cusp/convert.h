@@ -394,7 +394,7 @@ struct device_fast_path<csr_matrix<int, V, device_memory>, coo_matrix<int, V, de
 };
 
 // device COO (row-sorted, the container's contract: cusp/coo_matrix.h:72) -> device CSR: the offsets from the row indices
-// in one pass with the order checked on the way; unsorted entries take the general (host) path, which sorts
+// in one pass with the order checked on the way; unsorted entries are sorted on the device first (a copy)
 template <typename V>
 struct device_fast_path<coo_matrix<int, V, device_memory>, csr_matrix<int, V, device_memory>, coo_format, csr_format> {
     static bool run(const coo_matrix<int, V, device_memory> &s, csr_matrix<int, V, device_memory> &d)
@@ -402,7 +402,17 @@ struct device_fast_path<coo_matrix<int, V, device_memory>, csr_matrix<int, V, de
         array1d<int, device_memory> offsets(s.num_rows + 1);
         int sorted = 0;
         check(cmi_coo_row_offsets(s.num_rows, s.num_entries, s.row_indices.data(), offsets.data(), &sorted, nullptr));
-        if (!sorted) return false;
+        if (!sorted) { // any order: a copy, sorted by row on the device (stable, coo_matrix::sort_by_row), then its offsets
+            coo_matrix<int, V, device_memory> t(s);
+            try { t.sort_by_row(); } catch (const std::exception &) { return false; } // (a row index outside the matrix: the general path's to deal with)
+            check(cmi_coo_row_offsets(t.num_rows, t.num_entries, t.row_indices.data(), offsets.data(), &sorted, nullptr));
+            if (!sorted) return false;
+            d.resize(t.num_rows, t.num_cols, t.num_entries);
+            d.row_offsets = offsets;
+            d.column_indices.swap(t.column_indices);
+            d.values.swap(t.values);
+            return true;
+        }
         d.resize(s.num_rows, s.num_cols, s.num_entries);
         d.row_offsets = offsets;
         d.column_indices = s.column_indices;

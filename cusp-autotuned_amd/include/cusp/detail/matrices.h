@@ -231,8 +231,9 @@ public:
     }
     void invalidate_plan() const { plan_.reset(); }
 
-    // reference cusp/coo_matrix.h: sort_by_row / sort_by_row_and_column / is_sorted_by_row[_and_column]
-    // (set-up operations; done on the host, stable, like the reference's stable_sort_by_key)
+    // reference cusp/coo_matrix.h: sort_by_row / sort_by_row_and_column / is_sorted_by_row[_and_column] (stable, like the
+    // reference's stable_sort_by_key).  device_memory with int indices and float / double values: on the device
+    // (cmi_coo_sort_by_row_*, cmi_coo_is_sorted); everything else: on the host.
     void sort_by_row() { sort_impl(false); }
     void sort_by_row_and_column() { sort_impl(true); }
     bool is_sorted_by_row() const { return sorted_impl(false); }
@@ -240,9 +241,19 @@ public:
 
 private:
     mutable detail::plan_slot plan_;
+    static int device_sort(int64_t r, int64_t c, int64_t n, int *ai, int *aj, double *ax, int ac) { return cmi_coo_sort_by_row_f64(r, c, n, ai, aj, ax, ac, nullptr); }
+    static int device_sort(int64_t r, int64_t c, int64_t n, int *ai, int *aj, float *ax, int ac) { return cmi_coo_sort_by_row_f32(r, c, n, ai, aj, ax, ac, nullptr); }
+    template <typename A, typename B, typename C> static int device_sort(int64_t, int64_t, int64_t, A *, B *, C *, int) { return -1; } // no device sort for these types
+    static const bool on_device = std::is_same<MemorySpace, device_memory>::value && std::is_same<IndexType, int>::value &&
+                                  (std::is_same<ValueType, double>::value || std::is_same<ValueType, float>::value);
     void sort_impl(bool and_column)
     {
         plan_.reset();
+        if (on_device) {
+            detail::check(device_sort((int64_t)this->num_rows, (int64_t)this->num_cols, (int64_t)row_indices.size(), row_indices.data(),
+                                      column_indices.data(), values.data(), and_column ? 1 : 0));
+            return;
+        }
         array1d<IndexType, host_memory> ri(row_indices), ci(column_indices);
         array1d<ValueType, host_memory> va(values);
         std::vector<size_t> perm(ri.size());
@@ -256,8 +267,15 @@ private:
         for (size_t k = 0; k < perm.size(); k++) { ri2[k] = ri[perm[k]]; ci2[k] = ci[perm[k]]; va2[k] = va[perm[k]]; }
         row_indices = ri2; column_indices = ci2; values = va2;
     }
+    static int device_sorted(int64_t r, int64_t n, const int *ai, const int *aj, int ac, int *out) { return cmi_coo_is_sorted(r, n, ai, aj, ac, out, nullptr); }
+    template <typename A> static int device_sorted(int64_t, int64_t, const A *, const A *, int, int *) { return -1; }
     bool sorted_impl(bool and_column) const
     {
+        if (on_device) {
+            int sorted = 0;
+            detail::check(device_sorted((int64_t)this->num_rows, (int64_t)row_indices.size(), row_indices.data(), column_indices.data(), and_column ? 1 : 0, &sorted));
+            return sorted != 0;
+        }
         array1d<IndexType, host_memory> ri(row_indices), ci(column_indices);
         for (size_t k = 1; k < ri.size(); k++) {
             if (ri[k - 1] > ri[k]) return false;

@@ -85,6 +85,22 @@ class CooMatrix(_Planned):
     def plan(self, stream=None, create=True):
         return self._plan_for(B.FORMAT_COO, self.row_indices, stream, create)
 
+    # reference cusp/coo_matrix.h:208-224 (device_memory: cmi_coo_sort_by_row_*, stable; the plan is keyed on the row
+    # indices' in-place version, which the sort bumps below)
+    def sort_by_row(self, stream=None):
+        B.coo_sort_by_row(self.num_rows, self.num_cols, self.row_indices, self.column_indices, self.values, False, stream)
+        self.row_indices.add_(0)  # torch's version counter: the library wrote through the raw pointer
+
+    def sort_by_row_and_column(self, stream=None):
+        B.coo_sort_by_row(self.num_rows, self.num_cols, self.row_indices, self.column_indices, self.values, True, stream)
+        self.row_indices.add_(0)
+
+    def is_sorted_by_row(self, stream=None):
+        return B.coo_is_sorted(self.num_rows, self.row_indices, None, False, stream)
+
+    def is_sorted_by_row_and_column(self, stream=None):
+        return B.coo_is_sorted(self.num_rows, self.row_indices, self.column_indices, True, stream)
+
 
 @dataclass
 class EllMatrix:
@@ -230,7 +246,12 @@ def convert(csr, fmt, num_entries_per_row=None, ell_alignment=32):
         coo = csr
         Ap = torch.empty(coo.num_rows + 1, dtype=torch.int32, device=coo.values.device)
         if not B.coo_row_offsets(coo.num_rows, coo.row_indices, Ap):
-            raise ValueError("convert: the COO entries are not sorted by row (cusp/coo_matrix.h:72 requires it); sort them first")
+            # any order: a copy, sorted by row on the device (stable: coo_matrix::sort_by_row), then its offsets -- what the
+            # reference's coo -> csr does (conversions/coo_to_other.h sorts first)
+            coo = CooMatrix(coo.num_rows, coo.num_cols, coo.num_entries, coo.row_indices.clone(), coo.column_indices.clone(), coo.values.clone())
+            coo.sort_by_row()  # (raises on a row index outside the matrix)
+            if not B.coo_row_offsets(coo.num_rows, coo.row_indices, Ap):
+                raise ValueError("convert: COO row indices outside the matrix")
         return CsrMatrix(coo.num_rows, coo.num_cols, coo.num_entries, Ap, coo.column_indices, coo.values)
     if isinstance(csr, EllMatrix) and fmt == "csr":
         Ap, Aj, Ax = B.ell_to_csr(csr.num_rows, csr.num_entries_per_row, csr.pitch, csr.column_indices, csr.values)

@@ -548,6 +548,23 @@ int cmi_csr_row_indices(int64_t num_rows, const int32_t *Ap, int32_t *Ai, void *
  * in one pass, with the order checked on the way.  *sorted_host == 0 afterwards: the entries were not sorted by row (or a
  * row index was out of range) and Ap is unspecified -- the caller sorts, or converts on the host.  Synchronises the stream. */
 int cmi_coo_row_offsets(int64_t num_rows, int64_t num_entries, const int32_t *Ai, int32_t *Ap, int *sorted_host, void *stream);
+/* The COO container's ordering on the device (reference: cusp/sort.h:231 sort_by_row, :302 sort_by_row_and_column behind
+ * coo_matrix::sort_by_row[_and_column], cusp/coo_matrix.h:208-224; is_sorted_by_row[_and_column]: same lines).  The
+ * reference's device multiply REQUIRES row-sorted entries (cuda/detail/multiply/coo_flat_spmv.h:139-145): a caller with
+ * entries in any order sorts ONCE with this call and then multiplies through a plan (sorted entries -> the CSR kernels on
+ * plan-built row offsets, bit-exact) instead of paying the atomics kernels on every multiply.  In place, STABLE: the
+ * entries of a row keep their storage order (and_column == 0), so the sorted matrix's row sums are the chains the host loop
+ * forms on the unsorted one.  and_column != 0: by (row, column).  Entries already in the order asked for: one checking
+ * pass, nothing moves.  Allocates scratch (about 12 + sizeof(value) bytes per entry; and_column: 20 + ...), synchronises
+ * the stream.  A row index outside [0, num_rows): CMI_ERROR_INVALID_VALUE, arrays untouched.                              */
+int cmi_coo_sort_by_row_f64(int64_t num_rows, int64_t num_cols, int64_t num_entries, int32_t *Ai, int32_t *Aj, double *Ax,
+                            int and_column, void *stream);
+int cmi_coo_sort_by_row_f32(int64_t num_rows, int64_t num_cols, int64_t num_entries, int32_t *Ai, int32_t *Aj, float *Ax,
+                            int and_column, void *stream);
+/* *sorted_host = 1 when the entries are ordered by row (and_column: by (row, column)); Aj may be NULL when and_column == 0.
+ * One pass, synchronises the stream.                                                                                    */
+int cmi_coo_is_sorted(int64_t num_rows, int64_t num_entries, const int32_t *Ai, const int32_t *Aj, int and_column,
+                      int *sorted_host, void *stream);
 /* ELL -> CSR and DIA -> CSR on the device (reference conversions/ell_to_other.h and dia_to_other.h:107-160: the entries
  * with a valid column -- DIA: and a non-zero value -- in row-major order): count per row, exclusive scan, scatter.
  * Two-call protocol: first with Aj == Ax == NULL -- Ap[num_rows + 1] and *num_entries_host are filled, size the arrays --

@@ -93,4 +93,49 @@ void TestKttTune()
 }
 DECLARE_UNITTEST(TestKttTune);
 
+// Entries in any order (the reference's device multiply refuses them, coo_flat_spmv.h:139-145): sort_by_row on the device is
+// stable, so the sorted matrix through its plan has the bits of the host COO loop on the entries as given; coo -> csr of the
+// unsorted device matrix (device sort of a copy) equals the host conversion.
+void TestUnsortedCooSortOnDevice()
+{
+    const size_t rows = 5000, cols = 4000, n = 60000;
+    cusp::coo_matrix<int, double, cusp::host_memory> H(rows, cols, n);
+    unsigned s = 12345u;
+    for (size_t k = 0; k < n; k++) {
+        s = s * 1664525u + 1013904223u; H.row_indices[k] = int((s >> 8) % rows);
+        s = s * 1664525u + 1013904223u; H.column_indices[k] = int((s >> 8) % cols);
+        s = s * 1664525u + 1013904223u; H.values[k] = double(int((s >> 8) % 2001u) - 1000) / 997.0;
+    }
+    cusp::array1d<double, cusp::host_memory> x(cols), y(rows, 0.0);
+    for (size_t i = 0; i < cols; i++) x[i] = double((unsigned(i) * 2654435761u) % 1000u) / 997.0 - 0.5;
+    cusp::multiply(H, x, y); // host loop, storage order
+    cusp::coo_matrix<int, double, cusp::device_memory> D(H);
+    ASSERT_TRUE(!D.is_sorted_by_row());
+    cusp::csr_matrix<int, double, cusp::device_memory> fromUnsorted(D); // device: sort a copy, offsets
+    cusp::csr_matrix<int, double, cusp::host_memory> hostCsr(H);        // host: stable sort, offsets
+    ASSERT_ARRAYS_EQUAL(fromUnsorted.row_offsets, hostCsr.row_offsets);
+    ASSERT_ARRAYS_EQUAL(fromUnsorted.column_indices, hostCsr.column_indices);
+    ASSERT_ARRAYS_EQUAL(fromUnsorted.values, hostCsr.values);
+    ASSERT_TRUE(!D.is_sorted_by_row()); // the source was not touched
+    D.sort_by_row();
+    ASSERT_TRUE(D.is_sorted_by_row());
+    cusp::array1d<double, cusp::device_memory> _x(x), _y(rows, 7.0);
+    cusp::multiply(D, _x, _y);
+    ASSERT_ARRAYS_EQUAL(_y, y);
+    H.sort_by_row();
+    ASSERT_ARRAYS_EQUAL(D.row_indices, H.row_indices);
+    ASSERT_ARRAYS_EQUAL(D.column_indices, H.column_indices);
+    ASSERT_ARRAYS_EQUAL(D.values, H.values);
+    // float instance
+    cusp::coo_matrix<int, float, cusp::host_memory> Hf(H.num_rows, H.num_cols, n);
+    for (size_t k = 0; k < n; k++) { Hf.row_indices[k] = H.row_indices[n - 1 - k]; Hf.column_indices[k] = H.column_indices[n - 1 - k]; Hf.values[k] = float(H.values[n - 1 - k]); }
+    cusp::coo_matrix<int, float, cusp::device_memory> Df(Hf);
+    Df.sort_by_row_and_column();
+    Hf.sort_by_row_and_column();
+    ASSERT_TRUE(Df.is_sorted_by_row_and_column());
+    ASSERT_ARRAYS_EQUAL(Df.column_indices, Hf.column_indices);
+    ASSERT_ARRAYS_EQUAL(Df.values, Hf.values);
+}
+DECLARE_UNITTEST(TestUnsortedCooSortOnDevice);
+
 int main(int argc, char **argv) { return unittest::run_all(argc, argv); }

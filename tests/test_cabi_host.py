@@ -110,6 +110,12 @@ def test_argument_validation_of_the_newer_entry_points(cmi):
     ok = ctypes.c_int(5)
     assert L.cmi_coo_row_offsets(-1, 0, None, None, ctypes.byref(ok), None) == 1 and L.cmi_coo_row_offsets(4, 2, None, None, ctypes.byref(ok), None) == 1
     assert L.cmi_coo_row_offsets(4, 0, None, None, None, None) == 1 and b"cmi_coo_row_offsets" in L.cmi_last_error()
+    # the COO container's device sort (argument checks; nothing touches a GPU)
+    assert L.cmi_coo_sort_by_row_f64(-1, 4, 0, None, None, None, 0, None) == 1 and L.cmi_coo_sort_by_row_f32(4, 4, 3, None, None, None, 1, None) == 1
+    assert b"cmi_coo_sort_by_row" in L.cmi_last_error()
+    assert L.cmi_coo_sort_by_row_f64(4, 4, 0, None, None, None, 0, None) == 0 and L.cmi_coo_sort_by_row_f64(4, 4, 2**31, None, None, None, 0, None) == 1
+    assert L.cmi_coo_is_sorted(4, 0, None, None, 1, ctypes.byref(ok), None) == 0 and ok.value == 1   # no entries: sorted
+    assert L.cmi_coo_is_sorted(4, 3, None, None, 0, ctypes.byref(ok), None) == 1 and L.cmi_coo_is_sorted(4, 0, None, None, 0, None, None) == 1
     assert L.cmi_copy_ranges(17, None, None, None, None) == 1 and b"CMI_MAX_COPY_RANGES" in L.cmi_last_error()
     assert L.cmi_copy_ranges(-1, None, None, None, None) == 1
     assert L.cmi_copy_ranges(0, None, None, None, None) == 0                    # nothing to copy

@@ -485,3 +485,59 @@ def test_auto_plans_pick_wavev_and_wavex_by_the_measured_rule(cmi, torch_cuda, o
         cmi.multiply(A, x, y)
         assert A.plan().config().kernel == want_with_columns and np.array_equal(y.cpu().numpy(), want), name
         del p_cols, p_offs, A
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_device_coo_sort_by_row_is_stable_and_feeds_the_plan_path(cmi, torch_cuda, orc, tag):
+    """coo_matrix::sort_by_row / sort_by_row_and_column / is_sorted_* on the device (reference cusp/coo_matrix.h:208-224,
+    cusp/sort.h:231,302).  Integer work: the sorted arrays must be EXACTLY what a stable host sort gives.  And the point of it:
+    an any-order COO matrix sorted once multiplies through its plan (the CSR kernels on plan-built offsets) with the bits of the
+    reference's host COO loop (sequential/multiply/coo_spmv.h) run on the UNSORTED entries -- the stable sort keeps every row's
+    chain."""
+    torch = torch_cuda
+    dtype = np.float64 if tag == "f64" else np.float32
+    rng = np.random.default_rng(11)
+    for rows, cols, n in ((1, 1, 1), (5, 7, 2), (1000, 900, 37), (70000, 70000, 700001), (30, 50, 4096), (1 << 20, 1 << 20, 3_000_000)):
+        Ai = rng.integers(0, rows, size=n).astype(np.int32)
+        Aj = rng.integers(0, cols, size=n).astype(np.int32)
+        Ax = rng.standard_normal(n).astype(dtype)
+        x = rng.standard_normal(cols).astype(dtype)
+        C = cmi.CooMatrix(rows, cols, n, dev(Ai, torch), dev(Aj, torch), dev(Ax, torch))
+        assert C.is_sorted_by_row() == bool(np.all(Ai[1:] >= Ai[:-1]))
+        C.sort_by_row()
+        order = np.argsort(Ai, kind="stable")
+        assert np.array_equal(C.row_indices.cpu().numpy(), Ai[order]), (rows, n)
+        assert np.array_equal(C.column_indices.cpu().numpy(), Aj[order]) and np.array_equal(C.values.cpu().numpy(), Ax[order])
+        assert C.is_sorted_by_row()
+        # the multiply through the plan on the sorted matrix == the host loop on the entries as they were given
+        want = orc.spmv_coo(rows, Ai, Aj, Ax, x)
+        y = torch.full((rows,), 3.0, dtype=C.values.dtype, device="cuda")
+        cmi.multiply(C, dev(x, torch), y)
+        info = C.plan().info()
+        if n >= 4:
+            assert info["coo_sorted"] == 1
+        if info["storage_order_sums"] or n < 4:        # one lane per row: the host chain, bit for bit
+            assert np.array_equal(y.cpu().numpy(), want), (rows, n)
+        else:                                          # rows of 100+ entries: the table gives a row several lanes (re-associated sums)
+            bound = (1e-6 if tag == "f64" else 1e-5) * orc.spmv_coo(rows, Ai, Aj, np.abs(Ax), np.abs(x))
+            assert np.all(np.abs(y.cpu().numpy() - want) <= bound), (rows, n)
+        # by (row, column): a second call on a fresh copy
+        D = cmi.CooMatrix(rows, cols, n, dev(Ai, torch), dev(Aj, torch), dev(Ax, torch))
+        D.sort_by_row_and_column()
+        order2 = np.lexsort((np.arange(n), Aj, Ai))   # stable in (row, column)
+        assert np.array_equal(D.row_indices.cpu().numpy(), Ai[order2]) and np.array_equal(D.column_indices.cpu().numpy(), Aj[order2])
+        assert np.array_equal(D.values.cpu().numpy(), Ax[order2])
+        assert D.is_sorted_by_row_and_column() and D.is_sorted_by_row()
+        before = D.values.clone()
+        D.sort_by_row_and_column()                    # already in order: nothing moves
+        assert torch.equal(before, D.values)
+    # a row index outside the matrix: refused, arrays untouched
+    Ai = np.array([3, 1, 9, 0], dtype=np.int32)
+    C = cmi.CooMatrix(9, 9, 4, dev(Ai, torch), dev(Ai % 9, torch), dev(np.ones(4, dtype=dtype), torch))
+    with pytest.raises(Exception):
+        C.sort_by_row()
+    assert np.array_equal(C.row_indices.cpu().numpy(), Ai)
+    # empty
+    E = cmi.CooMatrix(4, 4, 0, dev(np.zeros(0, np.int32), torch), dev(np.zeros(0, np.int32), torch), dev(np.zeros(0, dtype), torch))
+    E.sort_by_row()
+    assert E.is_sorted_by_row() and E.is_sorted_by_row_and_column()

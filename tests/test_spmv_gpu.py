@@ -899,9 +899,16 @@ def test_device_coo_to_csr(cmi, torch_cuda, orc, golden_irregular):
         ai = torch.tensor(idx, dtype=torch.int32, device="cuda")
         ap = torch.empty(rws + 1, dtype=torch.int32, device="cuda")
         assert not cmi.coo_row_offsets(rws, ai, ap), (rws, idx)
+    # entries in any order: sorted by row on the device first (a copy; stable), as the reference's coo -> csr sorts first
     perm = np.random.default_rng(3).permutation(len(Aj))
-    with pytest.raises(ValueError):
-        cmi.convert(cmi.CooMatrix(rows, cols, len(Aj), dev(Ai[perm], torch), dev(Aj[perm], torch), dev(Ax[perm], torch)), "csr")
+    U = cmi.CooMatrix(rows, cols, len(Aj), dev(Ai[perm], torch), dev(Aj[perm], torch), dev(Ax[perm], torch))
+    S = cmi.convert(U, "csr")
+    assert np.array_equal(host(S.row_offsets), Ap) and np.array_equal(host(U.row_indices), Ai[perm])   # the source is untouched
+    order = np.argsort(Ai[perm], kind="stable")
+    assert np.array_equal(host(S.column_indices), Aj[perm][order]) and np.array_equal(host(S.values), Ax[perm][order])
+    with pytest.raises(Exception):
+        bad = Ai[perm].copy(); bad[5] = rows
+        cmi.convert(cmi.CooMatrix(rows, cols, len(Aj), dev(bad, torch), dev(Aj[perm], torch), dev(Ax[perm], torch)), "csr")
 
 
 @pytest.mark.parametrize("tag", ["f64", "f32"])
