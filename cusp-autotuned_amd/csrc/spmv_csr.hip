@@ -627,10 +627,13 @@ csr_wavep_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, const in
 // is wave_partition_kernel's (8 bytes per tile, plan-owned).  Same products, storage-order sums: bit-exact.
 // The last vector of the ARRAYS may reach past num_entries: that one wave sums its rows straight from the arrays.
 // ABL != 0: ablation instances for measurements only ($CMI_WAVEV_ABLATE, f64 / V = 4; WRONG results by design) --
-//   bit 1: no x gathers (the columns are still loaded);  bit 2: no LDS, no row sums (every lane adds its own products and lanes
-//   < rows store them);  bit 4: products parked in LDS as usual, but a row's lane reads only its first one.
-template <typename T, int V, int POL, bool DOT, int ABL = 0>
-__global__ void __launch_bounds__(256)
+//   bit 1: no x gathers (the columns are still loaded);  bit 2: no LDS, no row sums (every lane adds its own products, the wave
+//   folds them and lanes < rows store the total);  bit 4: products parked in LDS as usual, but a row's lane reads only its first one.
+//   bit 8 (with bit 2): the LDS ALLOCATION is kept (one store per lane), nothing else of it.
+// WPB: wave tiles per workgroup (4: the shipped shape; 1 / 2: $CMI_WAVEV_WPB, V = 4 -- a workgroup's LDS goes back when its LAST wave ends).
+// LDIV (ablation 10 / 11 only): the kept allocation is 1 / LDIV of the real one.
+template <typename T, int V, int POL, bool DOT, int ABL = 0, int WPB = 4, int LDIV = 1>
+__global__ void __launch_bounds__(kWave * WPB)
 csr_wavev_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t num_entries, const int *Ap /* not restrict: see csr_wave */,
                  const int *__restrict__ Aj, const T *__restrict__ Ax, const T *__restrict__ x, T *__restrict__ y, int64_t num_tiles,
                  int64_t tiles_per_xcd, int swizzle, int accumulate, const T *__restrict__ w, double *__restrict__ dot_partial)
@@ -643,13 +646,13 @@ csr_wavev_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t 
     constexpr int E = sizeof(T) == 8 ? 2 : 4, NL = (V * 4) / E, SLOTS = kWave * V * 4;
     typedef int __attribute__((ext_vector_type(E))) idx_t;
     typedef T __attribute__((ext_vector_type(E))) val_t;
-    __shared__ __attribute__((aligned(16))) T prod[4][SLOTS];
-    __shared__ double dot_slots[DOT ? 4 : 1];
+    __shared__ __attribute__((aligned(16))) T prod[WPB][SLOTS / LDIV];
+    __shared__ double dot_slots[DOT ? WPB : 1];
     constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
     const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle);
     if (tile >= num_tiles) return; // whole workgroup
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x & (kWave - 1);
-    const int64_t wt = tile * 4 + wave;
+    const int64_t wt = tile * WPB + wave;
     double d = 0.0;
     if (wt < wave_tiles) {
         const int2v lo = *reinterpret_cast<const int2v *>(start + 2 * wt), hi = *reinterpret_cast<const int2v *>(start + 2 * wt + 2);
@@ -702,6 +705,11 @@ csr_wavev_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t 
                 }
                 __builtin_amdgcn_wave_barrier(); // (compiler only: the hardware runs a wave's LDS instructions in order)
                 if constexpr ((ABL & 2) != 0) {
+                    if constexpr ((ABL & 8) != 0) *reinterpret_cast<volatile T *>(mine + lane) = lane_sum;
+                    // every lane's products must be NEEDED: without this the compiler masks the loads of the lanes >= nr off (session 22's
+                    // first "no LDS" figures were of a kernel that read a third of the matrix)
+                    lane_sum = (T)wave_sum_to_last((double)lane_sum);
+                    lane_sum = (T)__shfl((double)lane_sum, kWave - 1);
                     if (lane < nr) st<NTS>(y + rs + lane, lane_sum);
                     return;
                 }
@@ -1562,15 +1570,30 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         if (!plan || !plan->wave_row_start || plan->wave_q <= 0) return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_CSR_STREAM_WAVEV runs through a plan (cmi_plan_create) only");
         if (V != 1 && V != 2 && V != 4) return fail(CMI_ERROR_NOT_SUPPORTED, "csr_wavev: items_per_thread (index vectors per lane) must be 1, 2 or 4");
         if (reinterpret_cast<uintptr_t>(Aj) % 16 != 0 || reinterpret_cast<uintptr_t>(Ax) % 16 != 0) return fail(CMI_ERROR_INVALID_VALUE, "csr_wavev: Aj and Ax must be 16-byte aligned");
-        const int64_t tiles = ceil_div(plan->wave_tiles, (int64_t)4);
+        static const int wpb_env = [] { const char *e = std::getenv("CMI_WAVEV_WPB"); const int v = e ? std::atoi(e) : 4; return v == 1 || v == 2 ? v : 4; }();
+        const int wpb = V == 4 ? wpb_env : 4; // wave tiles per workgroup
+        const int64_t tiles = ceil_div(plan->wave_tiles, (int64_t)wpb);
         const int64_t tpx = ceil_div(tiles, kXcds);
         int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
         const int64_t grid64 = padded_grid(tiles, swz);
         if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "csr_wavev: grid too large");
         const bool dot = w && dot_partial && tiles <= kPartialCapacity;
+        if (wpb != 4) {
+            with_policy(pol, [&](auto P) {
+                constexpr int POL = decltype(P)::value;
+                auto go = [&](auto WW) {
+                    constexpr int WC = decltype(WW)::value;
+                    if (dot) hipLaunchKernelGGL((csr_wavev_kernel<T, 4, POL, true, 0, WC>), dim3((unsigned)grid64), dim3(kWave * WC), 0, s, plan->wave_row_start, plan->wave_tiles, nnz, Ap, Aj, Ax, x, y, tiles, tpx, swz, accumulate, w, dot_partial);
+                    else     hipLaunchKernelGGL((csr_wavev_kernel<T, 4, POL, false, 0, WC>), dim3((unsigned)grid64), dim3(kWave * WC), 0, s, plan->wave_row_start, plan->wave_tiles, nnz, Ap, Aj, Ax, x, y, tiles, tpx, swz, accumulate, (const T *)nullptr, (double *)nullptr);
+                };
+                if (wpb == 1) go(std::integral_constant<int, 1>()); else go(std::integral_constant<int, 2>());
+            });
+            if (dot && dot_partials) *dot_partials = (int)tiles;
+            break;
+        }
         if constexpr (sizeof(T) == 8) { // measurements only: ablated instances (wrong results by design), f64 / V = 4 / nt loads and stores
             static const int ablate = [] { const char *e = std::getenv("CMI_WAVEV_ABLATE"); return e ? std::atoi(e) : 0; }();
-            if (ablate > 0 && ablate < 8 && V == 4 && !dot) {
+            if (ablate > 0 && ablate < 16 && V == 4 && !dot) {
                 auto run = [&](auto A) {
                     constexpr int AB = decltype(A)::value;
                     hipLaunchKernelGGL((csr_wavev_kernel<T, 4, 3, false, AB>), dim3((unsigned)grid64), dim3(256), 0, s, plan->wave_row_start, plan->wave_tiles, nnz, Ap, Aj, Ax, x, y, tiles, tpx, swz, accumulate, (const T *)nullptr, (double *)nullptr);
@@ -1581,7 +1604,23 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
                 case 3: run(std::integral_constant<int, 3>()); break;
                 case 4: run(std::integral_constant<int, 4>()); break;
                 case 5: run(std::integral_constant<int, 5>()); break;
-                default: return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_WAVEV_ABLATE: 1..5");
+                case 10: {
+                    static const int ldiv = [] { const char *e = std::getenv("CMI_WAVEV_LDIV"); return e ? std::atoi(e) : 1; }();
+                    auto run_l = [&](auto L) {
+                        constexpr int LD = decltype(L)::value;
+                        hipLaunchKernelGGL((csr_wavev_kernel<T, 4, 3, false, 10, 4, LD>), dim3((unsigned)grid64), dim3(256), 0, s, plan->wave_row_start, plan->wave_tiles, nnz, Ap, Aj, Ax, x, y, tiles, tpx, swz, accumulate, (const T *)nullptr, (double *)nullptr);
+                    };
+                    switch (ldiv) {
+                    case 2: run_l(std::integral_constant<int, 2>()); break;
+                    case 4: run_l(std::integral_constant<int, 4>()); break;
+                    case 8: run_l(std::integral_constant<int, 8>()); break;
+                    case 16: run_l(std::integral_constant<int, 16>()); break;
+                    default: run_l(std::integral_constant<int, 1>()); break;
+                    }
+                    break;
+                }
+                case 11: run(std::integral_constant<int, 11>()); break;
+                default: return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_WAVEV_ABLATE: 1..5, 10, 11");
                 }
                 break;
             }

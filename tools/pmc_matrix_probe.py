@@ -75,6 +75,13 @@ def main():
             Aj = np.zeros_like(Aj)
         elif cols_mode == "row":
             Aj = np.repeat(np.arange(rows, dtype=np.int32), np.diff(Ap))
+        elif cols_mode == "seq":      # entry e gathers x[e mod rows]: a gather instruction's lanes sit in the fewest lines a stride allows
+            Aj = (np.arange(nnz, dtype=np.int64) % rows).astype(np.int32)
+        elif cols_mode.startswith("win"):  # win512: a pseudo-random column inside the 512-column window its row sits in: the lines are cache-resident,
+            w = int(cols_mode[3:] or 512)  # but the lanes of one gather instruction are spread over w / 16 of them
+            e = np.arange(nnz, dtype=np.int64)
+            r = np.repeat(np.arange(rows, dtype=np.int64), np.diff(Ap))
+            Aj = np.minimum((r // w) * w + ((e * 2654435761) >> 7) % w, rows - 1).astype(np.int32)
         if cols_mode:
             name = f"{name}[cols={cols_mode}]"
         A = cmi.CsrMatrix(rows, rows, nnz, torch.from_numpy(Ap).cuda(), torch.from_numpy(Aj).cuda(), torch.from_numpy(Ax).cuda())
