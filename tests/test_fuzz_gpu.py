@@ -104,7 +104,7 @@ def test_csr_every_path_against_the_oracle(cmi, torch_cuda, orc, shape):
     exact = bool(A.plan().info()["storage_order_sums"]) if nnz > 0 and rows > 0 else True
     check(y.cpu().numpy(), want, bound, dtype, exact, "plan: " + what)
     if nnz > 0 and rows > 0:
-        assert A.plan().validate()
+        assert A.plan().validate(A.row_offsets, A.column_indices)
     # plan-less with the table
     y = fresh()
     cmi.spmv_csr(rows, cols, A.row_offsets, A.column_indices, A.values, dx, y, accumulate=accumulate)
