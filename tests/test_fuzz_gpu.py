@@ -1,7 +1,7 @@
 """Property-based parity (-m gpu): hypothesis draws the matrix SHAPE -- sizes down to 0 x n, row-length profiles (uniform, heavy tail, stretches of
 empty rows, one giant row, FEM-like runs), value type, accumulate -- and every way the library can multiply it is compared with the CPU oracle
 (the reference's host loops, oracle/): through the containers' plans (CSR / COO / ELL / HYB), plan-less with the table, and with each explicit CSR
-kernel.  Derandomised (the same examples every run), 40 examples per property.
+kernel.  Derandomised (the same examples every run), 80 examples per property, sizes up to 200 000 rows / columns.
 
 Bars: a plan or kernel that declares storage-order sums (cmi_plan_info) must be BIT-EXACT; every other path |err| <= TOL * sum_j |a_ij x_j|
 (1e-6 f64 / 1e-5 f32) -- the same bars as tests/test_spmv_gpu.py.  What the reference tests with fixed small matrices (testing/multiply.cu:
@@ -16,7 +16,7 @@ from hypothesis import HealthCheck, given, settings, strategies as st  # noqa: E
 pytestmark = pytest.mark.gpu
 
 TOL = {np.dtype(np.float64): 1e-6, np.dtype(np.float32): 1e-5}
-SETTINGS = dict(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+SETTINGS = dict(max_examples=80, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
 
 
 @pytest.fixture(scope="module")
@@ -79,7 +79,7 @@ def check(got, want, bound, dtype, exact, what):
 
 
 shapes = st.tuples(st.sampled_from(["uniform", "tail", "deserts", "giant", "fem", "equal"]),
-                   st.integers(0, 5000), st.integers(1, 5000), st.integers(0, 2**31 - 1), st.sampled_from(["f64", "f32"]), st.booleans())
+                   st.one_of(st.integers(0, 5000), st.integers(5000, 200000)), st.one_of(st.integers(1, 5000), st.integers(5000, 200000)), st.integers(0, 2**31 - 1), st.sampled_from(["f64", "f32"]), st.booleans())
 
 
 @settings(**SETTINGS)
@@ -138,7 +138,7 @@ def test_other_formats_through_their_plans_against_the_oracle(cmi, torch_cuda, o
     torch = torch_cuda
     profile, rows, cols, seed, tag, accumulate = shape
     if profile in ("giant", "tail"):
-        rows = min(rows, 1500)        # (ELL of a giant row: rows x its length in slots)
+        rows, cols = min(rows, 1500), min(cols, 5000)   # (ELL of a giant row: rows x its length in slots)
     dtype = np.float64 if tag == "f64" else np.float32
     Ap, Aj, Ax, x, y0 = make_csr(profile, rows, cols, seed, dtype)
     nnz = len(Aj)
