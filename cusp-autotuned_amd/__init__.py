@@ -22,7 +22,7 @@ from .binding import (  # noqa: F401
     count_zeros, tuning_hyb_rule, tuning_set_hyb_rule, hyb_entries_per_row, HYB_RULE_REFERENCE, HYB_RULE_COST, HYB_RULE_COST2, tuning_hyb_light_speed, tuning_set_hyb_light_speed,
     tuning_select, tuning_set, tuning_load, tuning_save, tuning_clear,
     poisson5pt_num_entries, poisson5pt_shard_entries, poisson5pt_csr, poisson5pt_dia,
-    csr_to_ell, csr_to_hyb_coo, csr_row_indices, coo_row_offsets, coo_sort_by_row, coo_is_sorted, ell_to_csr, dia_to_csr, hyb_to_csr, ell_row_lengths,
+    csr_to_ell, csr_to_hyb_coo, csr_row_indices, coo_row_offsets, coo_sort_by_row, coo_is_sorted, csr_interior_rows, ell_to_csr, dia_to_csr, hyb_to_csr, ell_row_lengths,
     blas_axpy, blas_axpby, blas_copy, blas_fill, blas_dot, blas_dotd, blas_nrm2, blas_workspace,
     cg_update, cg_direction, cg_direction_x, HostScalar,
     Comm, OP_SUM, OP_MAX, OP_MIN, csr_column_span,

@@ -116,6 +116,8 @@ def _declare(L):
     L.cmi_poisson5pt_shard_entries.argtypes = [i64, i64, i64, i64]
     L.cmi_csr_row_indices.argtypes = [i64, vp, vp, vp]
     L.cmi_coo_row_offsets.argtypes = [i64, i64, vp, vp, POINTER(ctypes.c_int), vp]
+    L.cmi_csr_interior_rows.argtypes = [i64, vp, vp, i64, i64, POINTER(c_int64), POINTER(c_int64), vp]
+    L.cmi_stream_wait_event.argtypes = [vp, vp]
     L.cmi_coo_sort_by_row_f64.argtypes = [i64, i64, i64, vp, vp, vp, ctypes.c_int, vp]
     L.cmi_coo_sort_by_row_f32.argtypes = [i64, i64, i64, vp, vp, vp, ctypes.c_int, vp]
     L.cmi_coo_is_sorted.argtypes = [i64, i64, vp, vp, ctypes.c_int, POINTER(ctypes.c_int), vp]
@@ -1057,6 +1059,17 @@ def coo_row_offsets(num_rows, Ai, Ap, stream=None):
     ok = ctypes.c_int(0)
     check(lib().cmi_coo_row_offsets(num_rows, Ai.numel(), _ptr(Ai), _ptr(Ap), byref(ok), _stream(stream)))
     return bool(ok.value)
+
+
+def csr_interior_rows(num_rows, Ap, Aj, col_lo, col_hi, stream=None):
+    """(first, last): rows [first, last) of a row block reference only columns in [col_lo, col_hi) -- the rows a sharded multiply can run
+    while the halo is in flight (cmi_csr_interior_rows)."""
+    import torch
+    _need(Ap, "Ap", torch.int32)
+    _need(Aj, "Aj", torch.int32)
+    a, b = c_int64(0), c_int64(0)
+    check(lib().cmi_csr_interior_rows(num_rows, _ptr(Ap), _ptr(Aj), col_lo, col_hi, byref(a), byref(b), _stream(stream)))
+    return a.value, b.value
 
 
 def coo_sort_by_row(num_rows, num_cols, Ai, Aj, Ax, and_column=False, stream=None):

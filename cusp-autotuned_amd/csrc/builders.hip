@@ -399,6 +399,47 @@ CMI_API int cmi_csr_column_span(int64_t num_entries, const int32_t *Aj, int32_t 
 
 // Row offsets of a row block cut out of a larger CSR matrix: out[i] = Ap[i] - Ap[0] for i <= num_rows (in place allowed).
 namespace cmi {
+// (lane per row: set-up work, once per sharded operator)
+__global__ void __launch_bounds__(256)
+interior_rows_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ Aj, int64_t lo, int64_t hi, int64_t mid, int *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < num_rows; r += stride) {
+        bool outside = false;
+        for (int jj = Ap[r]; jj < Ap[r + 1] && !outside; jj++) outside = Aj[jj] < lo || Aj[jj] >= hi;
+        if (outside) {
+            if (r < mid) atomicMax(out, (int)r); else atomicMin(out + 1, (int)r);
+        }
+    }
+}
+} // namespace cmi
+
+CMI_API int cmi_csr_interior_rows(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, int64_t col_lo, int64_t col_hi, int64_t *first_host,
+                                  int64_t *last_host, void *stream)
+{
+    if (num_rows < 0 || num_rows > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_interior_rows: bad size");
+    if (!first_host || !last_host || (num_rows > 0 && !Ap)) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_interior_rows: null array");
+    *first_host = 0;
+    *last_host = num_rows;
+    if (num_rows == 0) return CMI_SUCCESS;
+    hipStream_t s = as_stream(stream);
+    int *dev = nullptr, host[2] = {-1, (int)num_rows};
+    CMI_HIP(hipMalloc((void **)&dev, sizeof(host)));
+    hipError_t e = hipMemcpyAsync(dev, host, sizeof(host), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(interior_rows_kernel, dim3(grid_1d(num_rows)), dim3(256), 0, s, num_rows, Ap, Aj, col_lo, col_hi, num_rows / 2, dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return hip_fail(e, "cmi_csr_interior_rows");
+    *first_host = (int64_t)host[0] + 1;
+    *last_host = host[1];
+    return CMI_SUCCESS;
+}
+
+namespace cmi {
 __global__ void __launch_bounds__(256) rebase_offsets_kernel(int64_t n, const int *__restrict__ Ap, int base, int *__restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

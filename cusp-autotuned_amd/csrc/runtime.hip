@@ -253,6 +253,14 @@ CMI_API int cmi_event_record(void *event, void *stream)
     CMI_HIP(hipEventRecord((hipEvent_t)event, as_stream(stream)));
     return CMI_SUCCESS;
 }
+// everything enqueued on `stream` after this call waits for `event` (recorded on another stream): the fork / join of the sharded
+// multiply's interior rows on a side stream (cusp/distributed/csr_matrix.h); the host does not block
+CMI_API int cmi_stream_wait_event(void *stream, void *event)
+{
+    if (!event) return fail(CMI_ERROR_INVALID_VALUE, "cmi_stream_wait_event: null event");
+    CMI_HIP(hipStreamWaitEvent(as_stream(stream), (hipEvent_t)event, 0));
+    return CMI_SUCCESS;
+}
 CMI_API int cmi_event_synchronize(void *event)
 {
     CMI_HIP(hipEventSynchronize((hipEvent_t)event));

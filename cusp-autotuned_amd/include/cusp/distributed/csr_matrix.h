@@ -26,7 +26,9 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <utility>
 #include <vector>
 
@@ -258,7 +260,17 @@ public:
             if (xbuf_.map_peers(*comm_, peers_, recv_lo_, recv_n_)) mode_ = exchange_mode::peer;
             else if (want == exchange_mode::peer) throw cusp::runtime_exception("distributed::csr_matrix: exchange_mode::peer asked for, but a rank could not map or verify its neighbours' buffers");
         }
+        setup_overlap(Local());
     }
+
+    // in the two-sided halo mode the rows [interior_first, interior_last) of the block -- those whose columns all lie in this
+    // rank's own slice -- are multiplied on a side stream WHILE the halo is in flight; the boundary rows at the block's two ends follow
+    // on the caller's stream once it has landed.  A row range of a CSR block is itself a CSR matrix (the offsets are absolute positions
+    // in the shared column / value arrays): no copy, same kernels, same bits.  Off: $CMI_EXCHANGE_OVERLAP=0, host_memory, one rank,
+    // the all-gather and the one-sided modes (the pull is one small copy kernel: nothing to hide).
+    bool overlapped() const { return overlap_; }
+    size_t interior_first() const { return (size_t)interior_a_; }
+    size_t interior_last() const { return (size_t)interior_b_; }
 
     // Every rank holds the WHOLE matrix on the host (tests, MatrixMarket input): take this rank's rows (collective).
     template <typename HostCsr> void scatter(const HostCsr &A, const std::vector<int64_t> &row_cuts, exchange_mode want = exchange_mode::automatic)
@@ -293,6 +305,17 @@ public:
         cusp::multiply(local, xv, y_local);
     }
 
+    // exchange() + multiply_local() -- with the interior rows overlapped with the exchange where that is set up (COLLECTIVE)
+    template <typename Y> void exchange_and_multiply(Y &y_local, void *stream = nullptr) const
+    {
+        if (!overlap_) {
+            exchange(stream);
+            multiply_local(y_local);
+            return;
+        }
+        multiply_overlapped(y_local.data(), stream, Local());
+    }
+
 private:
     communicator *comm_;
     exchange_mode mode_;
@@ -302,6 +325,74 @@ private:
     std::vector<int> peers_;
     std::vector<int64_t> send_lo_, send_n_, recv_lo_, recv_n_, counts_, displs_;
     int64_t halo_recv_values_ = 0, worst_halo_values_ = 0;
+    bool overlap_ = false;
+    int64_t interior_a_ = 0, interior_b_ = 0;
+    cmi_config row_cfg_ = cmi_config();
+    bool have_row_cfg_ = false;
+    struct side_resources { // a stream and two events, released with the operator
+        void *stream = nullptr, *ready = nullptr, *done = nullptr;
+        ~side_resources()
+        {
+            if (ready) (void)cmi_event_destroy(ready);
+            if (done) (void)cmi_event_destroy(done);
+            if (stream) (void)cmi_stream_destroy(stream);
+        }
+    };
+    std::shared_ptr<side_resources> side_;
+
+    void setup_overlap(cusp::host_memory) { overlap_ = false; }
+    void setup_overlap(cusp::device_memory)
+    {
+        overlap_ = false;
+        const char *e = std::getenv("CMI_EXCHANGE_OVERLAP");
+        if (comm_->size() == 1 || mode_ != exchange_mode::halo || (e && e[0] == '0') || local.num_rows == 0 || local.num_entries == 0) return;
+        if (!std::is_same<IndexType, int>::value) return;
+        int64_t a = 0, b = 0;
+        cusp::detail::check(cmi_csr_interior_rows((int64_t)local.num_rows, reinterpret_cast<const int *>(local.row_offsets.data()),
+                                                  reinterpret_cast<const int *>(local.column_indices.data()), cuts[comm_->rank()], cuts[comm_->rank() + 1], &a, &b, nullptr));
+        // every rank must take the same path through the collective below (it does not: the schedule is local -- the exchange is the
+        // same call either way), so the decision is this rank's alone
+        if (b - a <= (int64_t)local.num_rows / 2) return;
+        // the launch shape of the WHOLE block (a row range passes the full column / value arrays: its own entry count is not what
+        // the table should see), or what the block's plan made of it when that is a row-tile kernel that runs without a plan
+        const cmi_plan *plan = local.plan();
+        have_row_cfg_ = false;
+        if (plan && cmi_plan_config(plan, &row_cfg_) == CMI_SUCCESS && (row_cfg_.kernel == CMI_CSR_STREAM || row_cfg_.kernel == CMI_CSR_STREAM_WAVE)) have_row_cfg_ = true;
+        if (!have_row_cfg_) {
+            cusp::detail::check(cmi_tuning_select(CMI_FORMAT_CSR, cusp::detail::dtype_code<ValueType>::value, (int64_t)local.num_rows, (int64_t)local.num_cols,
+                                                  (int64_t)local.num_entries, &row_cfg_));
+            have_row_cfg_ = true;
+        }
+        side_ = std::make_shared<side_resources>();
+        cusp::detail::check(cmi_stream_create(&side_->stream));
+        cusp::detail::check(cmi_event_create(&side_->ready));
+        cusp::detail::check(cmi_event_create(&side_->done));
+        interior_a_ = a;
+        interior_b_ = b;
+        overlap_ = true;
+    }
+    static int rows_call(int64_t rows, int64_t cols, int64_t nnz, const int *Ap, const int *Aj, const double *Ax, const double *x, double *y, const cmi_config *c, void *s)
+    { return cmi_spmv_csr_f64(rows, cols, nnz, Ap, Aj, Ax, x, y, 0, c, s); }
+    static int rows_call(int64_t rows, int64_t cols, int64_t nnz, const int *Ap, const int *Aj, const float *Ax, const float *x, float *y, const cmi_config *c, void *s)
+    { return cmi_spmv_csr_f32(rows, cols, nnz, Ap, Aj, Ax, x, y, 0, c, s); }
+    void rows(int64_t a, int64_t b, ValueType *y, void *stream) const // y[a:b] = A[a:b, :] * buffer
+    {
+        if (b <= a) return;
+        cusp::detail::check(rows_call(b - a, (int64_t)local.num_cols, (int64_t)local.num_entries, reinterpret_cast<const int *>(local.row_offsets.data()) + a,
+                                      reinterpret_cast<const int *>(local.column_indices.data()), local.values.data(), xbuf_.data.data(), y + a, &row_cfg_, stream));
+    }
+    void multiply_overlapped(ValueType *, void *, cusp::host_memory) const {}
+    void multiply_overlapped(ValueType *y, void *stream, cusp::device_memory) const
+    {
+        cusp::detail::check(cmi_event_record(side_->ready, stream));           // this rank's slice of x is in the buffer (stream order)
+        cusp::detail::check(cmi_stream_wait_event(side_->stream, side_->ready));
+        rows(interior_a_, interior_b_, y, side_->stream);                        // ... interior rows while ...
+        cusp::detail::check(cmi_event_record(side_->done, side_->stream));
+        exchange(stream);                                                        // ... the halo is in flight
+        rows(0, interior_a_, y, stream);
+        rows(interior_b_, (int64_t)local.num_rows, y, stream);
+        cusp::detail::check(cmi_stream_wait_event(stream, side_->done));         // join: later work on `stream` sees all of y
+    }
 
     void exchange_impl(void *stream, cusp::device_memory) const
     {

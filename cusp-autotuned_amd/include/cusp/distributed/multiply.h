@@ -20,9 +20,8 @@ void multiply(const distributed::csr_matrix<I, V, L> &A, const X &x, Y &y)
         auto dst = slot.local();
         cusp::blas::copy(x.local(), dst);
     }
-    A.exchange();
     auto yl = y.local();
-    A.multiply_local(yl);
+    A.exchange_and_multiply(yl); // (two-sided halo mode on device_memory: interior rows on a side stream while the halo is in flight)
 }
 
 } // namespace cusp

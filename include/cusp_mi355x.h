@@ -100,6 +100,7 @@ int cmi_event_create(void **event);
 int cmi_event_destroy(void *event);
 int cmi_event_record(void *event, void *stream);
 int cmi_event_synchronize(void *event);
+int cmi_stream_wait_event(void *stream, void *event); /* work enqueued on `stream` afterwards waits for `event`; the host does not block */
 int cmi_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
 
 /* ------------------------------------------------------------------------- */
@@ -538,6 +539,13 @@ int cmi_csr_to_dia_f32(int64_t num_rows, int64_t num_cols, const int32_t *Ap, co
                        float *values, void *stream);
 /* Set-up helpers of the row-block sharded operator (no reference equivalent): the column window a row block gathers    */
 /* from (smallest / largest column index; no entries: 0, -1; synchronises), and the row offsets of a block cut out of a larger       */
+/* The rows of a row block that need nothing but the block's OWN slice of x (sharded multiply: they can be multiplied while the
+ * halo is in flight -- SURVEY.md 8(f).4).  Rows whose columns all lie in [col_lo, col_hi) are interior; boundary rows of a banded
+ * block cluster at its two ends, so the answer is ONE range: *first_host = 1 + the last row of the block's first half with a
+ * column outside, *last_host = the first such row of the second half (num_rows if none): rows [first, last) are interior.
+ * One pass over the column indices, synchronises the stream.                                                              */
+int cmi_csr_interior_rows(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, int64_t col_lo, int64_t col_hi,
+                          int64_t *first_host, int64_t *last_host, void *stream);
 /* matrix (out[i] = Ap[i] - base for i <= num_rows).                                                                                  */
 int cmi_csr_column_span(int64_t num_entries, const int32_t *Aj, int32_t *min_host, int32_t *max_host, void *stream);
 int cmi_csr_rebase_offsets(int64_t num_rows, const int32_t *Ap, int32_t base, int32_t *out, void *stream);

@@ -90,6 +90,11 @@ template <typename Space> static void run(cd::communicator &comm, const char *sp
             CHECK(A.mode() == (std::is_same<Space, cusp::device_memory>::value ? cd::exchange_mode::peer : cd::exchange_mode::halo),
                   "%s: a banded matrix should pick the halo exchange (one-sided on device_memory)", v.name);
         if (world > 1 && !v.banded && v.mode == cd::exchange_mode::automatic) CHECK(A.mode() == cd::exchange_mode::allgather, "%s: scattered columns should pick the all-gather", v.name);
+        // two-sided halo mode on device_memory: the interior rows are multiplied on a side stream while the halo is in flight
+        if (world > 1 && v.mode == cd::exchange_mode::halo && std::is_same<Space, cusp::device_memory>::value)
+            CHECK(A.overlapped() && A.interior_last() - A.interior_first() > A.local_rows() / 2 && A.interior_last() - A.interior_first() < A.local_rows(),
+                  "%s: banded block of %zu rows: interior rows [%zu, %zu) overlapped %d", v.name, A.local_rows(), A.interior_first(), A.interior_last(), (int)A.overlapped());
+        if (v.mode != cd::exchange_mode::halo || !std::is_same<Space, cusp::device_memory>::value) CHECK(!A.overlapped(), "%s: overlap outside the two-sided halo mode", v.name);
         // x, and the single-process y = G x on the host
         cusp::array1d<double, cusp::host_memory> xg(n), yg(n);
         for (size_t i = 0; i < n; i++) xg[i] = double((unsigned(i) * 2654435761u) % 1000u) / 997.0 - 0.5;

@@ -110,6 +110,10 @@ def test_argument_validation_of_the_newer_entry_points(cmi):
     ok = ctypes.c_int(5)
     assert L.cmi_coo_row_offsets(-1, 0, None, None, ctypes.byref(ok), None) == 1 and L.cmi_coo_row_offsets(4, 2, None, None, ctypes.byref(ok), None) == 1
     assert L.cmi_coo_row_offsets(4, 0, None, None, None, None) == 1 and b"cmi_coo_row_offsets" in L.cmi_last_error()
+    a64, b64 = ctypes.c_int64(-5), ctypes.c_int64(-5)
+    assert L.cmi_csr_interior_rows(-1, None, None, 0, 4, ctypes.byref(a64), ctypes.byref(b64), None) == 1 and L.cmi_csr_interior_rows(4, None, None, 0, 4, ctypes.byref(a64), ctypes.byref(b64), None) == 1
+    assert L.cmi_csr_interior_rows(0, None, None, 0, 4, ctypes.byref(a64), ctypes.byref(b64), None) == 0 and (a64.value, b64.value) == (0, 0)
+    assert L.cmi_stream_wait_event(None, None) == 1 and b"cmi_stream_wait_event" in L.cmi_last_error()
     # the COO container's device sort (argument checks; nothing touches a GPU)
     assert L.cmi_coo_sort_by_row_f64(-1, 4, 0, None, None, None, 0, None) == 1 and L.cmi_coo_sort_by_row_f32(4, 4, 3, None, None, None, 1, None) == 1
     assert b"cmi_coo_sort_by_row" in L.cmi_last_error()

@@ -541,3 +541,27 @@ def test_device_coo_sort_by_row_is_stable_and_feeds_the_plan_path(cmi, torch_cud
     E = cmi.CooMatrix(4, 4, 0, dev(np.zeros(0, np.int32), torch), dev(np.zeros(0, np.int32), torch), dev(np.zeros(0, dtype), torch))
     E.sort_by_row()
     assert E.is_sorted_by_row() and E.is_sorted_by_row_and_column()
+
+
+def test_interior_rows_of_a_row_block(cmi, torch_cuda):
+    """cmi_csr_interior_rows (the split of a sharded multiply into rows that need only the rank's own slice of x and the boundary rows at
+    the block's two ends) against a numpy restatement: poisson5pt row blocks, a block with no outside column, one with
+    outside columns in the middle (no usable range), empty rows."""
+    torch = torch_cuda
+    m, n = 300, 200
+    for r0, r1 in ((0, 20000), (20000, 41000), (41000, 60000)):
+        A = cmi.poisson5pt(m, n, fmt="csr", dtype=torch.float64, row_begin=r0, row_end=r1)
+        Ap, Aj = A.row_offsets.cpu().numpy(), A.column_indices.cpu().numpy()
+        rows = r1 - r0
+        outside = np.array([np.any((Aj[Ap[i]:Ap[i + 1]] < r0) | (Aj[Ap[i]:Ap[i + 1]] >= r1)) for i in range(rows)])
+        below = np.nonzero(outside[:rows // 2])[0]
+        above = np.nonzero(outside[rows // 2:])[0]
+        want = (int(below[-1]) + 1 if below.size else 0, int(above[0]) + rows // 2 if above.size else rows)
+        assert cmi.csr_interior_rows(rows, A.row_offsets, A.column_indices, r0, r1) == want, (r0, r1)
+        if r0 == 20000:
+            assert want == (m, rows - m)      # one grid line at each end reaches into the neighbours
+    assert cmi.csr_interior_rows(rows, A.row_offsets, A.column_indices, 0, m * n) == (0, rows)          # nothing outside
+    # empty rows and an outside column in the middle of each half
+    Ap = torch.tensor([0, 0, 2, 2, 3, 5, 5, 6], dtype=torch.int32, device="cuda")
+    Aj = torch.tensor([3, 4, 9, 3, 4, 0], dtype=torch.int32, device="cuda")
+    assert cmi.csr_interior_rows(7, Ap, Aj, 1, 8) == (0, 3)   # rows 3 (column 9) and 6 (column 0) reach outside; mid = 3: nothing in the first half, row 3 is the first of the second

@@ -93,7 +93,9 @@ static int run_sharded(size_t grid, size_t iters)
         cd::csr_matrix<int, double, cusp::device_memory> A(*comm);
         cd::poisson5pt(A, grid, grid, want);
         if (pass == 1 && A.mode() == cd::exchange_mode::allgather && world > 1) { /* automatic already chose it: measured above */ }
-        const char *mode = A.mode() == cd::exchange_mode::halo ? "halo (grouped send/recv)" : "allgather";
+        std::string mode_s = A.mode_name();
+        if (A.overlapped()) mode_s += ", interior rows [" + std::to_string(A.interior_first()) + ", " + std::to_string(A.interior_last()) + ") overlapped with it";
+        const char *mode = mode_s.c_str();
         auto p = A.exchange_slice();
         auto y = A.make_vector();
         {
