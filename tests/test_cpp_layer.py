@@ -166,3 +166,13 @@ def test_sharded_operator_ranks_share_one_gpu_one_sided_exchange(cmi, ranks):
     lines = [l for l in out.splitlines() if l.startswith("ok ")]
     assert len(lines) == 8, out
     assert "mode peer" in out and "banded/by-entries/peer" in out
+
+
+def test_host_layers_under_address_and_ub_sanitizers(cmi):
+    """`make -C tests/cpp asan`: test_host and the sharded layer (3 ranks over the TCP star, host_memory) built with
+    -fsanitize=address,undefined -- CPU build only, GPU sanitizers are not available on this pool."""
+    _build()
+    r = subprocess.run(["make", "-C", CPP, "asan"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "runtime error" not in r.stdout + r.stderr and "AddressSanitizer" not in r.stdout + r.stderr
+    assert r.stdout.count("ok  ") >= 7 and ", 0 failed" in r.stdout
