@@ -257,11 +257,27 @@ private:
         array1d<IndexType, host_memory> ri(row_indices), ci(column_indices);
         array1d<ValueType, host_memory> va(values);
         std::vector<size_t> perm(ri.size());
-        std::iota(perm.begin(), perm.end(), size_t(0));
-        std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t b) {
-            if (ri[a] != ri[b]) return ri[a] < ri[b];
-            return and_column && ci[a] < ci[b];
-        });
+        bool in_range = true;
+        for (size_t k = 0; k < ri.size() && in_range; k++) in_range = ri[k] >= IndexType(0) && static_cast<size_t>(ri[k]) < this->num_rows;
+        if (in_range) { // stable counting sort by row (O(n)), then -- by (row, column) -- a stable sort of each row's few entries
+            std::vector<size_t> start(this->num_rows + 1, 0);
+            for (size_t k = 0; k < ri.size(); k++) start[static_cast<size_t>(ri[k]) + 1]++;
+            for (size_t r = 0; r < this->num_rows; r++) start[r + 1] += start[r];
+            std::vector<size_t> next(start.begin(), start.end() - 1);
+            for (size_t k = 0; k < ri.size(); k++) perm[next[static_cast<size_t>(ri[k])]++] = k;
+            if (and_column)
+                for (size_t r = 0; r < this->num_rows; r++) {
+                    auto lo = perm.begin() + static_cast<std::ptrdiff_t>(start[r]), hi = perm.begin() + static_cast<std::ptrdiff_t>(start[r + 1]);
+                    if (hi - lo > 1 && !std::is_sorted(lo, hi, [&](size_t a, size_t b) { return ci[a] < ci[b]; }))
+                        std::stable_sort(lo, hi, [&](size_t a, size_t b) { return ci[a] < ci[b]; });
+                }
+        } else { // (row indices outside the matrix: the comparison sort orders whatever is there)
+            std::iota(perm.begin(), perm.end(), size_t(0));
+            std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t b) {
+                if (ri[a] != ri[b]) return ri[a] < ri[b];
+                return and_column && ci[a] < ci[b];
+            });
+        }
         array1d<IndexType, host_memory> ri2(ri.size()), ci2(ri.size());
         array1d<ValueType, host_memory> va2(ri.size());
         for (size_t k = 0; k < perm.size(); k++) { ri2[k] = ri[perm[k]]; ci2[k] = ci[perm[k]]; va2[k] = va[perm[k]]; }
