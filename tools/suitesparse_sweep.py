@@ -92,6 +92,15 @@ def main():
                     cands.append((f"csr_stream table shape, policy {pol} (1 = nt loads, 2 = nt stores), XCD dealing {swz}",
                                   cmi.Config(kernel=cmi.CSR_STREAM, block_size=t.block_size, threads_per_row=1, items_per_thread=t.items_per_thread,
                                              rows_per_block=t.rows_per_block, nontemporal=pol, xcd_swizzle=swz), True))
+        # round 3: the wave-private vector-body kernels run through plans made for them (a plan refuses a shape whose tile cannot hold the longest row)
+        planned = {}
+        for label, c in ([(f"csr_wavev V={v} (wave-private tiles, one line per load instruction; through a plan)", cmi.Config(kernel=cmi.CSR_STREAM_WAVEV, items_per_thread=v)) for v in (1, 2, 4)]
+                         + [(f"csr_wavex V=4, x window of {w} entries in LDS (through a plan)", cmi.Config(kernel=cmi.CSR_STREAM_WAVEX, items_per_thread=4, rows_per_block=w)) for w in (2048, 4096)]):
+            try:
+                planned[label] = cmi.Plan.csr(tdt, rows, rows, A.row_offsets, A.column_indices, cfg=c)
+                cands.append((label, ("planned", label), True))
+            except Exception as e:  # noqa: BLE001
+                print(f"   (no plan for {label}: {e})")
         plan = A.plan()
         cands.append((f"table (NULL config): {cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64 if vb == 8 else cmi.F32, rows, rows, nnz)}", None, False))
         runs = []
@@ -99,6 +108,8 @@ def main():
             y.fill_(10.0)
             if cfg is None:
                 cmi.spmv_csr(rows, rows, A.row_offsets, A.column_indices, A.values, x, y)
+            elif isinstance(cfg, tuple):
+                cmi.spmv_csr_plan(planned[cfg[1]], A.row_offsets, A.column_indices, A.values, x, y)
             else:
                 cmi.multiply(A, x, y, cfg=cfg)
             ok = bool(torch.equal(y, want)) if exact else bool(((y - want).abs() <= (1e-6 if vb == 8 else 1e-5) * bound).all().item())
@@ -113,6 +124,8 @@ def main():
                     fn = lambda: cmi.multiply(A, x, y)  # noqa: E731
                 elif cfg is None:
                     fn = lambda: cmi.spmv_csr(rows, rows, A.row_offsets, A.column_indices, A.values, x, y)  # noqa: E731
+                elif isinstance(cfg, tuple):
+                    fn = lambda q=planned[cfg[1]]: cmi.spmv_csr_plan(q, A.row_offsets, A.column_indices, A.values, x, y)  # noqa: E731
                 else:
                     fn = lambda c=cfg: cmi.multiply(A, x, y, cfg=c)  # noqa: E731
                 times[label].append(time_us(fn))
