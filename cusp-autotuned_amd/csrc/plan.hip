@@ -347,8 +347,8 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
             // (profiles/r02_wave_shape_sweep.txt, r02_wave_ab.txt); below it, plain loads keep the matrix resident (tuning.hip)
             if (num_entries * (int64_t)(sizeof(int) + vbytes) > kInfinityCacheBytes + kInfinityCacheBytes / 4) p->cfg.nontemporal |= kPolLoadNT;
             p->cfg.nontemporal |= kPolStoreNT;
-        } else if (st == CMI_SUCCESS && auto_kernel && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
-                   wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v, vbytes) > 0) {
+        } else if (st == CMI_SUCCESS && auto_kernel && !want_partition && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
+                   wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v, vbytes) > 0) { // (a caller who asked for csr_wave on a partition gets that)
             int v = wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v, vbytes);
             bool auto_wavex = false, keep_stream = false;
             if (!want_wavev) { // an AUTO plan: refine by the value type and -- made with the columns -- by where the columns lie

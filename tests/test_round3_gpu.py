@@ -476,6 +476,12 @@ def test_auto_plans_pick_wavev_and_wavex_by_the_measured_rule(cmi, torch_cuda, o
             y = torch.full((N,), 3.0, dtype=dt, device="cuda")
             cmi.spmv_csr_plan(p, Ap, Aj, Ax, x, y)
             assert np.array_equal(y.cpu().numpy(), want), (name, p.config())
+        # a caller who ASKS for csr_wave's lane-strided body on a row partition gets that kernel, not the rule's (found in session 30)
+        p_part = cmi.Plan(cmi.FORMAT_CSR, dt, N, N, nnz, Ap, cmi.Config(kernel=cmi.CSR_STREAM_WAVE, rows_per_block=-1, items_per_thread=8))
+        assert p_part.config().kernel == cmi.CSR_STREAM_WAVE and p_part.config().items_per_thread == 8, (name, p_part.config())
+        y = torch.full((N,), 3.0, dtype=dt, device="cuda")
+        cmi.spmv_csr_plan(p_part, Ap, Aj, Ax, x, y)
+        assert np.array_equal(y.cpu().numpy(), want), (name, p_part.config())
         y = torch.full((N,), 3.0, dtype=dt, device="cuda")
         cmi.spmv_csr(N, N, Ap, Aj, Ax, x, y)  # plan-less: the table's csr_stream, whatever the matrix
         assert np.array_equal(y.cpu().numpy(), want), name

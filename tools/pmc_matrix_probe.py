@@ -50,6 +50,9 @@ def variants_for(A):
         blk, rpb, ipt, pol = (int(v) for v in spec.split(":"))
         out.append((f"stream{blk}x{rpb}x{ipt}/pol{pol}", ("cfg", cmi.Config(kernel=cmi.CSR_STREAM, block_size=blk, rows_per_block=rpb, items_per_thread=ipt,
                                                                               threads_per_row=1, nontemporal=pol))))
+    for k in (int(t) for t in os.environ.get("PMC_WAVEP", "").split(",") if t):  # csr_wave's LANE-STRIDED body on a plan-built partition, k entries per lane
+        for pol in (int(s) for s in os.environ.get("PMC_WAVEP_POL", "3").split(",") if s):
+            out.append((f"wavep{k}/pol{pol}", cmi.Config(kernel=cmi.CSR_STREAM_WAVE, rows_per_block=-1, items_per_thread=k, nontemporal=pol)))
     if hasattr(cmi, "CSR_STREAM_WAVEV"):
         for v in (int(s) for s in os.environ.get("PMC_WAVEV", "2,4").split(",") if s):
             for pol in (int(s) for s in os.environ.get("PMC_WAVEV_POL", "0").split(",") if s):  # 0: the plan's own policy choice
