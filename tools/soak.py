@@ -114,3 +114,52 @@ for rep in range(5):
     else:
         assert mon.residuals == ref[0] and torch.equal(xs0, ref[1]), "fold-ahead CG is not repeatable"
 print("fold-ahead CG: 5 x 200 iterations, identical histories and solutions")
+
+# round 3's kernels: wave-private vector-body tiles (csr_wavev V = 1 / 2 / 4) and the LDS x window (csr_wavex) on an irregular band matrix, the
+# fenced fold of the reductions under the fused CG (default path, 5 x 300 iterations), the device COO sort
+os.environ.pop("CMI_CG_FOLD_AHEAD", None)
+g = torch.Generator(device="cuda").manual_seed(3)
+rows_b = 2_000_000
+lens_b = torch.randint(5, 40, (rows_b,), device="cuda", generator=g)
+Apb = torch.zeros(rows_b + 1, dtype=torch.int32, device="cuda")
+Apb[1:] = lens_b.cumsum(0).to(torch.int32)
+nnz_b = int(Apb[-1])
+row_b = torch.repeat_interleave(torch.arange(rows_b, device="cuda"), lens_b)
+Ajb = ((row_b + torch.randint(-2000, 2001, (nnz_b,), device="cuda", generator=g)) % rows_b).to(torch.int32)
+Axb = torch.randn(nnz_b, dtype=torch.float64, device="cuda", generator=g)
+xb = torch.randn(rows_b, dtype=torch.float64, device="cuda", generator=g)
+yref = torch.empty(rows_b, dtype=torch.float64, device="cuda")
+cmi.spmv_csr(rows_b, rows_b, Apb, Ajb, Axb, xb, yref, cfg=cmi.Config(kernel=cmi.CSR_SCALAR))
+yb2 = torch.empty_like(yref)
+for name, cfg in (("csr_wavev V=1", cmi.Config(kernel=cmi.CSR_STREAM_WAVEV, items_per_thread=1)), ("csr_wavev V=2", cmi.Config(kernel=cmi.CSR_STREAM_WAVEV, items_per_thread=2)),
+                  ("csr_wavev V=4", cmi.Config(kernel=cmi.CSR_STREAM_WAVEV, items_per_thread=4)),
+                  ("csr_wavex V=4 window 2048", cmi.Config(kernel=cmi.CSR_STREAM_WAVEX, items_per_thread=4, rows_per_block=2048)), ("auto plan", None)):
+    pl = cmi.Plan.csr(torch.float64, rows_b, rows_b, Apb, Ajb, cfg=cfg)
+    bad = 0
+    for _ in range(20):
+        for _ in range(100):
+            cmi.spmv_csr_plan(pl, Apb, Ajb, Axb, xb, yb2)
+        bad += not torch.equal(yb2, yref)
+    print(f"{name} (plan kernel {pl.config().kernel}): 2000 multiplies of a {rows_b}-row band matrix, checks that differ from csr_scalar's bits: {bad}")
+ref = None
+for rep in range(5):
+    xs0 = torch.zeros(n, dtype=torch.float64, device="cuda")
+    mon = cmi.krylov.cg(A, xs0, b, iteration_limit=300, relative_tolerance=0.0)
+    if ref is None:
+        ref = (mon.residuals, xs0.clone())
+    else:
+        assert mon.residuals == ref[0] and torch.equal(xs0, ref[1]), "fused CG (fenced folds) is not repeatable"
+print("fused CG, fenced folds: 5 x 300 iterations on the headline matrix, identical histories and solutions")
+C = cmi.convert(A, "coo")
+perm = torch.randperm(C.num_entries, device="cuda", generator=g)
+first = None
+for rep in range(5):
+    U = cmi.CooMatrix(C.num_rows, C.num_cols, C.num_entries, C.row_indices[perm].contiguous(), C.column_indices[perm].contiguous(), C.values[perm].contiguous())
+    U.sort_by_row()
+    cur = (U.row_indices.clone(), U.column_indices.clone(), U.values.clone())
+    if first is None:
+        first = cur
+    else:
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(first, cur)), "device COO sort is not repeatable"
+assert torch.equal(first[0], C.row_indices)
+print("device COO sort: 5 x 50 M shuffled entries, identical results, rows as the sorted original's")
