@@ -22,6 +22,7 @@
 #include <cusp/krylov/cg.h>
 #include <cusp/ktt/ktt.h>
 #include <cusp/monitor.h>
+#include <cusp/sort.h>
 #include <cusp/multiply.h>
 
 #include "unittest.h"
@@ -645,6 +646,26 @@ template <typename Space> void TestCooMatrixSorting()
     }
 }
 DECLARE_SPACE_UNITTEST(TestCooMatrixSorting);
+
+// cusp/sort.h:231,302 (the free functions the container's methods call; testing/sort.cu covers the counting sorts, which are not on this path):
+// stable by row -- entries of a row keep their order -- and by (row, column); with and without an execution policy
+template <typename Space> void TestSortByRowFreeFunctions()
+{
+    const int r[9] = {2, 0, 2, 1, 0, 2, 1, 0, 2}, c[9] = {5, 1, 0, 3, 0, 4, 2, 1, 0};
+    cusp::array1d<int, Space> rows(9), cols(9);
+    cusp::array1d<double, Space> vals(9);
+    for (int i = 0; i < 9; i++) { rows[i] = r[i]; cols[i] = c[i]; vals[i] = double(i); }
+    cusp::sort_by_row(rows, cols, vals);
+    const int er[9] = {0, 0, 0, 1, 1, 2, 2, 2, 2}, ec[9] = {1, 0, 1, 3, 2, 5, 0, 4, 0}; const double ev[9] = {1, 4, 7, 3, 6, 0, 2, 5, 8};
+    for (int i = 0; i < 9; i++) { ASSERT_EQUAL(int(rows[i]), er[i]); ASSERT_EQUAL(int(cols[i]), ec[i]); ASSERT_EQUAL(double(vals[i]), ev[i]); }
+    for (int i = 0; i < 9; i++) { rows[i] = r[i]; cols[i] = c[i]; vals[i] = double(i); }
+    cusp::sort_by_row_and_column(cusp::hip::par, rows, cols, vals);
+    const int fr[9] = {0, 0, 0, 1, 1, 2, 2, 2, 2}, fc[9] = {0, 1, 1, 2, 3, 0, 0, 4, 5}; const double fv[9] = {4, 1, 7, 6, 3, 2, 8, 5, 0};
+    for (int i = 0; i < 9; i++) { ASSERT_EQUAL(int(rows[i]), fr[i]); ASSERT_EQUAL(int(cols[i]), fc[i]); ASSERT_EQUAL(double(vals[i]), fv[i]); }
+    cusp::array1d<int, Space> short_cols(3);
+    ASSERT_THROWS(cusp::sort_by_row(rows, short_cols, vals), cusp::invalid_input_exception);
+}
+DECLARE_SPACE_UNITTEST(TestSortByRowFreeFunctions);
 
 // testing/monitor.cu:5-68, statement by statement
 template <typename Space> void TestMonitorSimple()
