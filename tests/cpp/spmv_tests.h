@@ -23,6 +23,7 @@
 #include <cusp/ktt/ktt.h>
 #include <cusp/monitor.h>
 #include <cusp/sort.h>
+#include <cusp/format_utils.h>
 #include <cusp/multiply.h>
 
 #include "unittest.h"
@@ -666,6 +667,30 @@ template <typename Space> void TestSortByRowFreeFunctions()
     ASSERT_THROWS(cusp::sort_by_row(rows, short_cols, vals), cusp::invalid_input_exception);
 }
 DECLARE_SPACE_UNITTEST(TestSortByRowFreeFunctions);
+
+// cusp/format_utils.h:83,133 (testing/format_utils.cu: TestOffsetsToIndices / TestIndicesToOffsets): row offsets <-> row indices, empty rows at both
+// ends and inside; on device_memory through the C-ABI builders
+template <typename Space> void TestOffsetsAndIndices()
+{
+    const int off[8] = {0, 0, 2, 2, 3, 6, 6, 6};
+    cusp::array1d<int, Space> offsets(8), indices, back(8, -1);
+    for (int i = 0; i < 8; i++) offsets[i] = off[i];
+    cusp::offsets_to_indices(offsets, indices);
+    ASSERT_EQUAL(indices.size(), size_t(6));
+    const int want[6] = {1, 1, 3, 4, 4, 4};
+    for (int i = 0; i < 6; i++) ASSERT_EQUAL(int(indices[i]), want[i]);
+    cusp::indices_to_offsets(indices, back);
+    for (int i = 0; i < 8; i++) ASSERT_EQUAL(int(back[i]), off[i]);
+    ASSERT_EQUAL(cusp::compute_max_entries_per_row(offsets), size_t(3));
+    // indices in any order: counted all the same (the reference's host path; device arrays fall back to it)
+    cusp::array1d<int, Space> shuffled(6);
+    const int sh[6] = {4, 1, 4, 3, 1, 4};
+    for (int i = 0; i < 6; i++) shuffled[i] = sh[i];
+    cusp::array1d<int, Space> again(8, -1);
+    cusp::indices_to_offsets(shuffled, again);
+    for (int i = 0; i < 8; i++) ASSERT_EQUAL(int(again[i]), off[i]);
+}
+DECLARE_SPACE_UNITTEST(TestOffsetsAndIndices);
 
 // testing/monitor.cu:5-68, statement by statement
 template <typename Space> void TestMonitorSimple()
