@@ -24,6 +24,7 @@
 #include <cusp/monitor.h>
 #include <cusp/sort.h>
 #include <cusp/format_utils.h>
+#include <cusp/verify.h>
 #include <cusp/multiply.h>
 
 #include "unittest.h"
@@ -691,6 +692,49 @@ template <typename Space> void TestOffsetsAndIndices()
     for (int i = 0; i < 8; i++) ASSERT_EQUAL(int(again[i]), off[i]);
 }
 DECLARE_SPACE_UNITTEST(TestOffsetsAndIndices);
+
+// testing/verify.cu:13-304 (TestIsValidMatrix{Coo,Csr,Dia,Ell,Hyb,Array2d}, TestAssertIsValidMatrix): the same 3 x 3 matrix, the same
+// corruptions, the same verdicts
+template <typename Space> void TestIsValidMatrix()
+{
+    cusp::array2d<float, Space> D(3, 3, 0.0f);
+    D(0, 1) = 1; D(1, 0) = 1; D(1, 2) = 1; D(2, 1) = 1;
+    { cusp::coo_matrix<int, float, Space> M(D); ASSERT_EQUAL(cusp::is_valid_matrix(M), true); }
+    { cusp::coo_matrix<int, float, Space> M(D); M.row_indices[0] = 1; M.row_indices[1] = 0; ASSERT_EQUAL(cusp::is_valid_matrix(M), false); }
+    { cusp::coo_matrix<int, float, Space> M(D); M.column_indices[2] = -1; ASSERT_EQUAL(cusp::is_valid_matrix(M), false); }
+    { cusp::coo_matrix<int, float, Space> M(D); M.column_indices[2] = 4; ASSERT_EQUAL(cusp::is_valid_matrix(M), false); }
+    { cusp::csr_matrix<int, float, Space> M(D); ASSERT_EQUAL(cusp::is_valid_matrix(M), true); }
+    { cusp::csr_matrix<int, float, Space> M(D); M.row_offsets[1] = 1; M.row_offsets[2] = 5; M.row_offsets[3] = 4; ASSERT_EQUAL(cusp::is_valid_matrix(M), false); }
+    { cusp::csr_matrix<int, float, Space> M(D); M.column_indices[2] = -1; ASSERT_EQUAL(cusp::is_valid_matrix(M), false); }
+    { cusp::csr_matrix<int, float, Space> M(D); M.column_indices[2] = 4; ASSERT_EQUAL(cusp::is_valid_matrix(M), false); }
+    { cusp::dia_matrix<int, float, Space> M(D); ASSERT_EQUAL(cusp::is_valid_matrix(M), true); }
+    { cusp::dia_matrix<int, float, Space> M(D); M.values.num_rows = 2; ASSERT_EQUAL(cusp::is_valid_matrix(M), false); }
+    { cusp::ell_matrix<int, float, Space> M(D); ASSERT_EQUAL(cusp::is_valid_matrix(M), true); }
+    { cusp::ell_matrix<int, float, Space> M(D); M.values.num_cols = M.values.num_cols + 1; ASSERT_EQUAL(cusp::is_valid_matrix(M), false); }
+    { cusp::ell_matrix<int, float, Space> M(D); M.column_indices.num_rows = 2; M.values.num_rows = 2; ASSERT_EQUAL(cusp::is_valid_matrix(M), false); }
+    { cusp::ell_matrix<int, float, Space> M(D); M.column_indices(0, 0) = cusp::ell_matrix<int, float, Space>::invalid_index; ASSERT_EQUAL(cusp::is_valid_matrix(M), false); }
+    { cusp::ell_matrix<int, float, Space> M(D); M.column_indices(0, 0) = -2; ASSERT_EQUAL(cusp::is_valid_matrix(M), false); }
+    { cusp::ell_matrix<int, float, Space> M(D); M.column_indices(0, 0) = 3; ASSERT_EQUAL(cusp::is_valid_matrix(M), false); }
+    { cusp::hyb_matrix<int, float, Space> M(D); ASSERT_EQUAL(cusp::is_valid_matrix(M), true); }
+    { cusp::hyb_matrix<int, float, Space> M(D); M.ell.num_rows = 4; ASSERT_EQUAL(cusp::is_valid_matrix(M), false); }
+    { cusp::hyb_matrix<int, float, Space> M(D); M.coo.num_rows = 4; ASSERT_EQUAL(cusp::is_valid_matrix(M), false); }
+    { cusp::hyb_matrix<int, float, Space> M(D); M.num_entries = 5; ASSERT_EQUAL(cusp::is_valid_matrix(M), false); }
+    ASSERT_EQUAL(cusp::is_valid_matrix(D), true);
+    { cusp::array2d<float, Space> E(D); E.num_entries = 8; ASSERT_EQUAL(cusp::is_valid_matrix(E), false); }
+    // assert_is_valid_matrix throws format_exception with the reason; assert_same_dimensions throws invalid_input_exception
+    cusp::csr_matrix<int, float, Space> bad(D);
+    bad.row_offsets[3] = 9;
+    ASSERT_THROWS(cusp::assert_is_valid_matrix(bad), cusp::format_exception);
+    std::ostringstream why;
+    ASSERT_EQUAL(cusp::is_valid_matrix(bad, why), false);
+    ASSERT_TRUE(why.str().find("row_offsets ends at 9") != std::string::npos);
+    cusp::csr_matrix<int, float, Space> good(D);
+    cusp::assert_is_valid_matrix(good);
+    cusp::array1d<float, Space> a3(3), b3(3), c4(4);
+    cusp::assert_same_dimensions(a3, b3);
+    ASSERT_THROWS(cusp::assert_same_dimensions(a3, b3, c4), cusp::invalid_input_exception);
+}
+DECLARE_SPACE_UNITTEST(TestIsValidMatrix);
 
 // testing/monitor.cu:5-68, statement by statement
 template <typename Space> void TestMonitorSimple()
