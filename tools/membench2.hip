@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 typedef float __attribute__((ext_vector_type(4))) f4;
@@ -53,6 +54,60 @@ template <typename V, int U, bool NT> __global__ void __launch_bounds__(256) k_g
         for (int u = 0; u < U; u++) acc += fold(v[u]);
     }
     for (; i < nvec; i += stride) acc += fold(ldv<NT>(a + i));
+    if (acc == 123.456f) *out = acc;
+}
+
+// CSR's two streams (4-byte columns + 8-byte values = 12 bytes per entry) in csr_wave's request shape -- lane-strided: K dword loads + K dwordx2 loads per
+// lane, 64 * K entries per wave -- against the same bytes as 16-byte loads: int4 columns + double2 values, 256 * K entries per wave (K int4 + 2 K double2 per lane)
+typedef int __attribute__((ext_vector_type(4))) i4;
+typedef double __attribute__((ext_vector_type(2))) d2;
+template <int K, bool NT> __global__ void __launch_bounds__(256) k_csr_lane_strided(const int *__restrict__ cols, const double *__restrict__ vals, size_t n, float *out)
+{
+    const int wave = threadIdx.x / 64, lane = threadIdx.x & 63;
+    const size_t base = ((size_t)blockIdx.x * 4 + wave) * (size_t)(64 * K);
+    int c[K]; double v[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { const size_t i = base + (size_t)k * 64 + lane; c[k] = i < n ? ldv<NT>(cols + i) : 0; }
+#pragma unroll
+    for (int k = 0; k < K; k++) { const size_t i = base + (size_t)k * 64 + lane; v[k] = i < n ? ldv<NT>(vals + i) : 0.0; }
+    double acc = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) acc += v[k] * (double)c[k];
+    if (acc == 123.456) *out = (float)acc;
+}
+template <int K, bool NT> __global__ void __launch_bounds__(256) k_csr_vectors(const i4 *__restrict__ cols, const d2 *__restrict__ vals, size_t n4, float *out)
+{
+    const int wave = threadIdx.x / 64, lane = threadIdx.x & 63;
+    const size_t base4 = ((size_t)blockIdx.x * 4 + wave) * (size_t)(64 * K); // in units of 4 entries
+    i4 c[K]; d2 v[2 * K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { const size_t i = base4 + (size_t)k * 64 + lane; c[k] = i < n4 ? ldv<NT>(cols + i) : i4{}; }
+#pragma unroll
+    for (int k = 0; k < 2 * K; k++) { const size_t i = base4 * 2 + (size_t)k * 64 + lane; v[k] = i < 2 * n4 ? ldv<NT>(vals + i) : d2{}; }
+    double acc = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) acc += (double)(c[k].x + c[k].y + c[k].z + c[k].w);
+#pragma unroll
+    for (int k = 0; k < 2 * K; k++) acc += v[k].x + v[k].y;
+    if (acc == 123.456) *out = (float)acc;
+}
+
+// S equal streams read side by side (S separate buffers, the same tile of each by the same wave): what do CONCURRENT streams cost by themselves?
+template <int S, int U, bool NT> __global__ void __launch_bounds__(256) k_streams(const f4 *__restrict__ a, size_t nvec_each, float *out)
+{
+    const int wave = threadIdx.x / 64, lane = threadIdx.x & 63;
+    const size_t base = ((size_t)blockIdx.x * 4 + wave) * (size_t)(64 * U);
+    f4 v[S * U];
+#pragma unroll
+    for (int s = 0; s < S; s++)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t i = base + (size_t)u * 64 + lane;
+            v[s * U + u] = i < nvec_each ? ldv<NT>(a + (size_t)s * nvec_each + i) : f4{};
+        }
+    float acc = 0;
+#pragma unroll
+    for (int k = 0; k < S * U; k++) acc += fold(v[k]);
     if (acc == 123.456f) *out = acc;
 }
 
@@ -115,6 +170,56 @@ int main()
         run_stride<f4, 4, true>("grid-stride 16 B x 4, grid 8192, nt", a, bytes, out, 8192);
         run_stride<f4, 8, true>("grid-stride 16 B x 8, grid 4096, nt", a, bytes, out, 4096);
         CK(hipFree(a));
+    }
+    {
+        const size_t bytes = 1200ull << 20;
+        void *a;
+        CK(hipMalloc(&a, bytes));
+        CK(hipMemset(a, 0, bytes));
+        printf("1200 MiB read as S equal streams side by side (16 B x U per lane and stream, nt)\n");
+        auto st = [&](auto SS, auto UU, const char *name) {
+            constexpr int S = decltype(SS)::value, U = decltype(UU)::value;
+            const size_t nvec_each = bytes / 16 / S, grid = (nvec_each + 256 * U - 1) / (256 * U);
+            const double ms = time_ms([&] { hipLaunchKernelGGL((k_streams<S, U, true>), dim3((unsigned)grid), dim3(256), 0, 0, (const f4 *)a, nvec_each, out); }, 20);
+            printf("  %-58s %7.0f GB/s\n", name, (double)(nvec_each * S * 16) / ms / 1e6);
+        };
+        st(std::integral_constant<int, 1>(), std::integral_constant<int, 4>(), "1 stream, U = 4");
+        st(std::integral_constant<int, 2>(), std::integral_constant<int, 2>(), "2 streams, U = 2");
+        st(std::integral_constant<int, 2>(), std::integral_constant<int, 4>(), "2 streams, U = 4");
+        st(std::integral_constant<int, 3>(), std::integral_constant<int, 2>(), "3 streams, U = 2");
+        st(std::integral_constant<int, 4>(), std::integral_constant<int, 2>(), "4 streams, U = 2");
+        st(std::integral_constant<int, 8>(), std::integral_constant<int, 1>(), "8 streams, U = 1");
+        CK(hipFree(a));
+    }
+    // the headline's streams: 50 M entries = 200 MB of columns + 400 MB of values
+    {
+        const size_t n = 49978572 / 4 * 4;
+        int *cols; double *vals;
+        CK(hipMalloc(&cols, n * 4)); CK(hipMalloc(&vals, n * 8));
+        CK(hipMemset(cols, 0, n * 4)); CK(hipMemset(vals, 0, n * 8));
+        const double bytes = 12.0 * n;
+        printf("CSR streams of the headline matrix (%zu entries, 12 bytes each), replayed\n", n);
+        auto ls = [&](auto KK, auto NN, const char *name) {
+            constexpr int K = decltype(KK)::value; constexpr bool NT = decltype(NN)::value;
+            const size_t grid = (n + 256 * K - 1) / (256 * K);
+            const double ms = time_ms([&] { hipLaunchKernelGGL((k_csr_lane_strided<K, NT>), dim3((unsigned)grid), dim3(256), 0, 0, cols, vals, n, out); }, 20);
+            printf("  %-58s %7.0f GB/s\n", name, bytes / ms / 1e6);
+        };
+        auto vc = [&](auto KK, auto NN, const char *name) {
+            constexpr int K = decltype(KK)::value; constexpr bool NT = decltype(NN)::value;
+            const size_t n4 = n / 4, grid = (n4 + 256 * K - 1) / (256 * K);
+            const double ms = time_ms([&] { hipLaunchKernelGGL((k_csr_vectors<K, NT>), dim3((unsigned)grid), dim3(256), 0, 0, (const i4 *)cols, (const d2 *)vals, n4, out); }, 20);
+            printf("  %-58s %7.0f GB/s\n", name, bytes / ms / 1e6);
+        };
+        ls(std::integral_constant<int, 5>(), std::false_type(), "lane-strided 4 B + 8 B, K = 5 (csr_wave's shape)");
+        ls(std::integral_constant<int, 5>(), std::true_type(), "lane-strided 4 B + 8 B, K = 5, nt");
+        ls(std::integral_constant<int, 10>(), std::true_type(), "lane-strided 4 B + 8 B, K = 10, nt");
+        ls(std::integral_constant<int, 16>(), std::true_type(), "lane-strided 4 B + 8 B, K = 16, nt");
+        vc(std::integral_constant<int, 1>(), std::true_type(), "int4 + 2 x double2 per lane (256 entries per wave), nt");
+        vc(std::integral_constant<int, 2>(), std::true_type(), "2 int4 + 4 double2 per lane (512 entries per wave), nt");
+        vc(std::integral_constant<int, 4>(), std::true_type(), "4 int4 + 8 double2 per lane (1024 entries per wave), nt");
+        vc(std::integral_constant<int, 5>(), std::true_type(), "5 int4 + 10 double2 per lane (1280 entries per wave), nt");
+        vc(std::integral_constant<int, 4>(), std::false_type(), "4 int4 + 8 double2 per lane (1024 entries per wave)");
     }
     return 0;
 }
