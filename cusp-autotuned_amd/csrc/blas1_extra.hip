@@ -1,0 +1,187 @@
+// blas1_extra.hip -- the rest of the reference's BLAS-1 set on device arrays: scal, xmy, axpbypcz, asum (= nrm1), amax (+ nrmmax).
+//
+// Replaces (reference): cusp/blas/blas.h scal / xmy / axpbypcz / nrm1 / nrmmax / amax -> cusp/system/detail/generic/blas.h (Thrust
+// transforms and reductions).  cusp::krylov::cg itself needs none of them (its five routines and their fused forms are in blas1.hip); these
+// are what the OTHER callers of the multiply need around it: a Jacobi-preconditioned cg (xmy), bicgstab / cr (scal, axpbypcz), stopping tests in
+// other norms.  Plain streaming kernels: one pass, nothing cached between calls.  Reductions are deterministic: a fixed grid, a fixed tree per
+// workgroup, the partials combined in index order by one workgroup -- no atomics.  Accumulation in double for both value types.
+#include "common.h"
+
+namespace cmi {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxGrid = 1024; // partials per reduction: doubles [0, kMaxGrid) and int64 [kMaxGrid, 2 kMaxGrid) of the caller's workspace
+
+int grid_for(int64_t n)
+{
+    int64_t b = ceil_div(n, (int64_t)kBlock * 4);
+    if (b > kMaxGrid) b = kMaxGrid;
+    return b < 1 ? 1 : (int)b;
+}
+
+template <typename T> __global__ void __launch_bounds__(kBlock) scal_kernel(int64_t n, T a, T *__restrict__ x)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] = a * x[i];
+}
+template <typename T> __global__ void __launch_bounds__(kBlock) xmy_kernel(int64_t n, const T *x, const T *y, T *z) // z may alias x or y
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) z[i] = x[i] * y[i];
+}
+template <typename T> __global__ void __launch_bounds__(kBlock) axpbypcz_kernel(int64_t n, T a, const T *x, T b, const T *y, T c, const T *z, T *out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // (a x + b y) + c z: the association of the reference's functor (generic/blas.h AXPBYPCZ: alpha * x + beta * y + gamma * z)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = a * x[i] + b * y[i] + c * z[i];
+}
+
+// workgroup tree over LDS, thread 0 gets the result; the same shape whatever the data
+__device__ __forceinline__ double block_add(double v, double *lds)
+{
+    lds[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) lds[threadIdx.x] += lds[threadIdx.x + s];
+        __syncthreads();
+    }
+    return lds[0];
+}
+// (largest |x|, FIRST position holding it): the pair with the larger value wins, equal values: the smaller index
+__device__ __forceinline__ void take_max(double &v, long long &i, double v2, long long i2)
+{
+    if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+}
+__device__ __forceinline__ void block_max(double &v, long long &i, double *lv, long long *li)
+{
+    lv[threadIdx.x] = v;
+    li[threadIdx.x] = i;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            double a = lv[threadIdx.x]; long long ai = li[threadIdx.x];
+            take_max(a, ai, lv[threadIdx.x + s], li[threadIdx.x + s]);
+            lv[threadIdx.x] = a; li[threadIdx.x] = ai;
+        }
+        __syncthreads();
+    }
+    v = lv[0];
+    i = li[0];
+}
+
+template <typename T> __global__ void __launch_bounds__(kBlock) asum_partial_kernel(int64_t n, const T *__restrict__ x, double *__restrict__ partial)
+{
+    __shared__ double lds[kBlock];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += fabs((double)x[i]);
+    const double s = block_add(acc, lds);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+template <typename T> __global__ void __launch_bounds__(kBlock) asum_final_kernel(int npartial, const double *__restrict__ partial, T *__restrict__ result)
+{
+    __shared__ double lds[kBlock];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < npartial; i += kBlock) acc += partial[i];
+    const double s = block_add(acc, lds);
+    if (threadIdx.x == 0) *result = (T)s;
+}
+template <typename T>
+__global__ void __launch_bounds__(kBlock) amax_partial_kernel(int64_t n, const T *__restrict__ x, double *__restrict__ pv, long long *__restrict__ pi)
+{
+    __shared__ double lv[kBlock];
+    __shared__ long long li[kBlock];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double v = -1.0; // below every |x|: an empty or all-NaN range reports (-1 -> 0, position 0)
+    long long at = 0x7fffffffffffffffLL;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) take_max(v, at, fabs((double)x[i]), (long long)i);
+    block_max(v, at, lv, li);
+    if (threadIdx.x == 0) { pv[blockIdx.x] = v; pi[blockIdx.x] = at; }
+}
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+amax_final_kernel(int npartial, const double *__restrict__ pv, const long long *__restrict__ pi, T *__restrict__ value, long long *__restrict__ index)
+{
+    __shared__ double lv[kBlock];
+    __shared__ long long li[kBlock];
+    double v = -1.0;
+    long long at = 0x7fffffffffffffffLL;
+    for (int i = threadIdx.x; i < npartial; i += kBlock) take_max(v, at, pv[i], pi[i]);
+    block_max(v, at, lv, li);
+    if (threadIdx.x == 0) {
+        if (value) *value = (T)(v < 0.0 ? 0.0 : v);
+        if (index) *index = v < 0.0 ? 0 : at;
+    }
+}
+
+template <typename T> int scal_impl(int64_t n, T a, T *x, void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_scal: negative n");
+    if (n == 0) return CMI_SUCCESS;
+    if (!x) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_scal: null array");
+    hipLaunchKernelGGL((scal_kernel<T>), dim3(grid_for(n) * 4), dim3(kBlock), 0, as_stream(stream), n, a, x);
+    CMI_LAUNCH_CHECK("scal");
+    return CMI_SUCCESS;
+}
+template <typename T> int xmy_impl(int64_t n, const T *x, const T *y, T *z, void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_xmy: negative n");
+    if (n == 0) return CMI_SUCCESS;
+    if (!x || !y || !z) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_xmy: null array");
+    hipLaunchKernelGGL((xmy_kernel<T>), dim3(grid_for(n) * 4), dim3(kBlock), 0, as_stream(stream), n, x, y, z);
+    CMI_LAUNCH_CHECK("xmy");
+    return CMI_SUCCESS;
+}
+template <typename T> int axpbypcz_impl(int64_t n, T a, const T *x, T b, const T *y, T c, const T *z, T *out, void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_axpbypcz: negative n");
+    if (n == 0) return CMI_SUCCESS;
+    if (!x || !y || !z || !out) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_axpbypcz: null array");
+    hipLaunchKernelGGL((axpbypcz_kernel<T>), dim3(grid_for(n) * 4), dim3(kBlock), 0, as_stream(stream), n, a, x, b, y, c, z, out);
+    CMI_LAUNCH_CHECK("axpbypcz");
+    return CMI_SUCCESS;
+}
+template <typename T> int asum_impl(int64_t n, const T *x, T *result_dev, void *workspace, void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_asum: negative n");
+    if (!result_dev || !workspace) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_asum: null result or workspace");
+    if (n > 0 && !x) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_asum: null array");
+    const int grid = grid_for(n);
+    hipLaunchKernelGGL((asum_partial_kernel<T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, x, (double *)workspace);
+    hipLaunchKernelGGL((asum_final_kernel<T>), dim3(1), dim3(kBlock), 0, as_stream(stream), grid, (const double *)workspace, result_dev);
+    CMI_LAUNCH_CHECK("asum");
+    return CMI_SUCCESS;
+}
+template <typename T> int amax_impl(int64_t n, const T *x, T *value_dev, int64_t *index_dev, void *workspace, void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_amax: negative n");
+    if ((!value_dev && !index_dev) || !workspace) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_amax: null results or workspace");
+    if (n > 0 && !x) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_amax: null array");
+    const int grid = grid_for(n);
+    double *pv = (double *)workspace;
+    long long *pi = reinterpret_cast<long long *>(pv + kMaxGrid);
+    hipLaunchKernelGGL((amax_partial_kernel<T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, x, pv, pi);
+    hipLaunchKernelGGL((amax_final_kernel<T>), dim3(1), dim3(kBlock), 0, as_stream(stream), grid, (const double *)pv, (const long long *)pi, value_dev, (long long *)index_dev);
+    CMI_LAUNCH_CHECK("amax");
+    return CMI_SUCCESS;
+}
+
+} // namespace
+} // namespace cmi
+
+using namespace cmi;
+CMI_API int cmi_blas_scal_f64(int64_t n, double alpha, double *x, void *stream) { return scal_impl<double>(n, alpha, x, stream); }
+CMI_API int cmi_blas_scal_f32(int64_t n, float alpha, float *x, void *stream) { return scal_impl<float>(n, alpha, x, stream); }
+CMI_API int cmi_blas_xmy_f64(int64_t n, const double *x, const double *y, double *z, void *stream) { return xmy_impl<double>(n, x, y, z, stream); }
+CMI_API int cmi_blas_xmy_f32(int64_t n, const float *x, const float *y, float *z, void *stream) { return xmy_impl<float>(n, x, y, z, stream); }
+CMI_API int cmi_blas_axpbypcz_f64(int64_t n, double alpha, const double *x, double beta, const double *y, double gamma, const double *z, double *out, void *stream)
+{ return axpbypcz_impl<double>(n, alpha, x, beta, y, gamma, z, out, stream); }
+CMI_API int cmi_blas_axpbypcz_f32(int64_t n, float alpha, const float *x, float beta, const float *y, float gamma, const float *z, float *out, void *stream)
+{ return axpbypcz_impl<float>(n, alpha, x, beta, y, gamma, z, out, stream); }
+CMI_API int cmi_blas_asum_f64(int64_t n, const double *x, double *result_dev, void *workspace, void *stream) { return asum_impl<double>(n, x, result_dev, workspace, stream); }
+CMI_API int cmi_blas_asum_f32(int64_t n, const float *x, float *result_dev, void *workspace, void *stream) { return asum_impl<float>(n, x, result_dev, workspace, stream); }
+CMI_API int cmi_blas_amax_f64(int64_t n, const double *x, double *value_dev, int64_t *index_dev, void *workspace, void *stream)
+{ return amax_impl<double>(n, x, value_dev, index_dev, workspace, stream); }
+CMI_API int cmi_blas_amax_f32(int64_t n, const float *x, float *value_dev, int64_t *index_dev, void *workspace, void *stream)
+{ return amax_impl<float>(n, x, value_dev, index_dev, workspace, stream); }

@@ -2,7 +2,7 @@
 // compute_optimal_entries_per_row (cusp/format_utils.h:83,133,276,320).  The general (host) versions live in cusp/convert.h, which the
 // conversions use; here are the device_memory overloads that stay in HBM: CSR row offsets <-> COO row indices through the C-ABI builders
 // (cmi_csr_row_indices; cmi_coo_row_offsets for row-sorted indices, the container's contract -- indices in any order take the host version).
-// extract_diagonal / count_diagonals serve the preconditioners and are not on the multiply path (out of scope).
+// extract_diagonal (host set-up of the Jacobi preconditioner) is below; count_diagonals serves the DIA conversion inside cusp/convert.h.
 #pragma once
 #include "convert.h"
 
@@ -31,6 +31,23 @@ inline void indices_to_offsets(const array1d<int, device_memory> &indices, array
     array1d<int, host_memory> hi(indices), ho(offsets.size());
     indices_to_offsets(hi, ho);
     offsets = ho;
+}
+
+// extract_diagonal(A, output): output[i] = A(i, i) -- 0 where the diagonal entry is not stored, the SUM where it is stored more than once
+// (reference cusp/format_utils.h:184, generic/format_utils.inl extract_diagonal per format).  Set-up work (the Jacobi preconditioner's
+// constructor): on a host copy of the matrix in CSR form, whatever A's format and memory space; `output` may live in either space.
+template <typename MatrixType, typename ArrayType> void extract_diagonal(const MatrixType &A, ArrayType &output)
+{
+    typedef typename MatrixType::index_type I;
+    typedef typename MatrixType::value_type V;
+    detail::host_csr<I, V> H;
+    detail::to_host_csr(A, H, typename MatrixType::format());
+    const size_t n = std::min(A.num_rows, A.num_cols);
+    array1d<typename ArrayType::value_type, host_memory> d(A.num_rows, typename ArrayType::value_type(0));
+    for (size_t i = 0; i < n; i++)
+        for (I jj = H.row_offsets[i]; jj < H.row_offsets[i + 1]; jj++)
+            if (static_cast<size_t>(H.column_indices[jj]) == i) d[i] += H.values[jj];
+    output = d;
 }
 
 } // namespace cusp

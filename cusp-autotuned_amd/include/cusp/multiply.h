@@ -21,6 +21,7 @@
 // user-derived policy reaches a user-provided multiply overload by ADL without being copied
 // (testing/multiply.cu:792-858): see cusp/execution_policy.h.
 #pragma once
+#include <utility>
 #include "array1d.h"
 #include "array2d.h"
 #include "convert.h"
@@ -306,6 +307,16 @@ void multiply(const LinearOperator &A, const Vector1 &x, Vector2 &y)
 {
     typedef typename Vector2::value_type V;
     cusp::multiply(A, x, y, constant_functor<V>(V(0)), multiplies<V>(), plus<V>());
+}
+// an operator WITHOUT a storage format -- cusp::linear_operator's children: identity_operator, precond::diagonal, a user's matrix-free operator --
+// is applied through its own operator()(x, y) (reference cusp/detail/multiply.inl: the unknown_format branch calls A(x, y)).  Excluded:
+// execution policies (the policy-first overloads below) and the sharded operator of cusp/distributed/multiply.h, which has its own overload.
+template <typename LinearOperator, typename Vector1, typename Vector2,
+          typename = typename std::enable_if<!detail::has_format<LinearOperator>::value && !std::is_base_of<cusp::execution_policy<LinearOperator>, LinearOperator>::value>::type,
+          typename = decltype(std::declval<const LinearOperator &>()(std::declval<const Vector1 &>(), std::declval<Vector2 &>()))>
+void multiply(const LinearOperator &A, const Vector1 &x, Vector2 &y)
+{
+    A(x, y);
 }
 // views are cheap handles and are often passed as temporaries
 template <typename LinearOperator, typename Vector1, typename T, typename M, typename = typename std::enable_if<detail::has_format<LinearOperator>::value>::type>

@@ -624,6 +624,21 @@ int cmi_blas_dot_f32(int64_t n, const float *x, const float *y, float *result_de
                      void *stream);
 int cmi_blas_nrm2_f64(int64_t n, const double *x, double *result_dev, void *workspace, void *stream);
 int cmi_blas_nrm2_f32(int64_t n, const float *x, float *result_dev, void *workspace, void *stream);
+/* The rest of the reference's BLAS-1 set (cusp/blas/blas.h scal, xmy, axpbypcz, nrm1, nrmmax, amax -> cusp/system/detail/generic/blas.h)
+ * for the multiply's OTHER callers (a Jacobi-preconditioned cg, bicgstab, cr): x <- alpha x; z <- x .* y (z may alias x or y);
+ * out <- alpha x + beta y + gamma z; *result_dev <- sum |x_i| (nrm1); *value_dev <- max |x_i| (nrmmax) and *index_dev <- the FIRST position
+ * holding it (amax; either pointer may be NULL).  Reductions: deterministic (fixed grid and tree, no atomics), accumulated in double,
+ * result in DEVICE memory, `workspace` as above.  An empty vector: 0 and position 0.                                                   */
+int cmi_blas_scal_f64(int64_t n, double alpha, double *x, void *stream);
+int cmi_blas_scal_f32(int64_t n, float alpha, float *x, void *stream);
+int cmi_blas_xmy_f64(int64_t n, const double *x, const double *y, double *z, void *stream);
+int cmi_blas_xmy_f32(int64_t n, const float *x, const float *y, float *z, void *stream);
+int cmi_blas_axpbypcz_f64(int64_t n, double alpha, const double *x, double beta, const double *y, double gamma, const double *z, double *out, void *stream);
+int cmi_blas_axpbypcz_f32(int64_t n, float alpha, const float *x, float beta, const float *y, float gamma, const float *z, float *out, void *stream);
+int cmi_blas_asum_f64(int64_t n, const double *x, double *result_dev, void *workspace, void *stream);
+int cmi_blas_asum_f32(int64_t n, const float *x, float *result_dev, void *workspace, void *stream);
+int cmi_blas_amax_f64(int64_t n, const double *x, double *value_dev, int64_t *index_dev, void *workspace, void *stream);
+int cmi_blas_amax_f32(int64_t n, const float *x, float *value_dev, int64_t *index_dev, void *workspace, void *stream);
 
 /* Fused steps of unpreconditioned CG (identity M, so z == r), scalars taken from DEVICE memory:
  * replaces dotc -> host -> axpy -> axpy -> copy -> dotc -> host -> axpby of
