@@ -22,6 +22,7 @@
 #include <cusp/krylov/cg.h>
 #include <cusp/krylov/bicgstab.h>
 #include <cusp/krylov/cr.h>
+#include <cusp/krylov/gmres.h>
 #include <cusp/precond/diagonal.h>
 #include <cusp/ktt/ktt.h>
 #include <cusp/monitor.h>
@@ -1278,6 +1279,45 @@ template <typename Space> void TestBicgstab()
     // cg refuses nothing here, but the method is for SPD systems: bicgstab's answer must satisfy the non-symmetric system, checked above
 }
 DECLARE_SPACE_UNITTEST(TestBicgstab);
+
+// testing/gmres.cu:39-61 verbatim protocol (float, restart 20, monitor(b, 20, 1e-4) on poisson5pt(10, 10)); then a non-symmetric system with restarts
+// (restart 5: several outer cycles) and the Jacobi preconditioner
+template <typename Space> void TestGeneralizedMinRes()
+{
+    {
+        cusp::csr_matrix<int, float, Space> A;
+        cusp::gallery::poisson5pt(A, 10, 10);
+        cusp::array1d<float, Space> x(A.num_rows, 0.0f), b(A.num_rows, 1.0f);
+        cusp::monitor<float> monitor(b, 20, 1e-4);
+        cusp::krylov::gmres(A, x, b, 20, monitor);
+        cusp::array1d<float, Space> residual(A.num_rows, 0.0f);
+        cusp::multiply(A, x, residual);
+        cusp::blas::axpby(residual, b, residual, -1.0f, 1.0f);
+        ASSERT_EQUAL(cusp::blas::nrm2(residual) < 1e-4 * cusp::blas::nrm2(b), true);
+    }
+    {
+        cusp::csr_matrix<int, double, cusp::host_memory> H;
+        cusp::gallery::poisson5pt(H, 20, 15);
+        const size_t N = H.num_rows;
+        for (size_t i = 0; i < N; i++)
+            for (int jj = H.row_offsets[i]; jj < H.row_offsets[i + 1]; jj++) {
+                const size_t j = H.column_indices[jj];
+                if (j + 1 == i) H.values[jj] -= 0.8;
+                if (j == i) H.values[jj] += 0.8 + double(i % 5);
+            }
+        cusp::ell_matrix<int, double, Space> A(H);
+        cusp::precond::diagonal<double, Space> M(A);
+        cusp::array1d<double, Space> b(N, 1.0), x(N, 0.0), r(N);
+        cusp::monitor<double> monitor(b, 400, 1e-9);
+        cusp::krylov::gmres(A, x, b, 5, monitor, M);
+        ASSERT_TRUE(monitor.converged());
+        ASSERT_TRUE(monitor.iteration_count() > 5); // more than one cycle
+        cusp::multiply(A, x, r);
+        cusp::blas::axpby(b, r, r, 1.0, -1.0);
+        ASSERT_TRUE(cusp::blas::nrm2(r) <= 1e-6 * cusp::blas::nrm2(b)); // (the monitor watches the PRECONDITIONED residual)
+    }
+}
+DECLARE_SPACE_UNITTEST(TestGeneralizedMinRes);
 
 // ELLR (the fork's container, testing/ktt.cu:26-43 runs its kernels on dia / ell / ellr)
 template <typename Space> void TestEllrMatrix()
