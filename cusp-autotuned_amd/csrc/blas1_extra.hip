@@ -167,10 +167,102 @@ template <typename T> int amax_impl(int64_t n, const T *x, T *value_dev, int64_t
     return CMI_SUCCESS;
 }
 
+// ---- Jacobi-preconditioned CG: the two vector passes of an iteration with z = D^-1 r never stored ---------------------------------------------
+// (reference cusp/krylov/detail/cg.inl:83-103 with M = cusp::precond::diagonal: axpy, axpy, xmy, dotc, axpby = 5 passes and 2 host reads between
+// two multiplies).  Here, as for the unpreconditioned solve (blas1.hip cg_update / cg_direction_x), the scalars stay in DEVICE memory:
+//   update:     alpha = <r,z> / <y,p>;  r <- r - alpha y;  partials of <r, D^-1 r> and of <r, r>   -> *rz_new, *rr (+ the host's pinned mirror)
+//   direction:  beta = <r,z>_new / <r,z>_old;  x <- x + alpha p;  p <- D^-1 r + beta p
+// 8 + 1 vector passes (dinv is read twice) and ONE host read per iteration.  Deterministic two-stage reductions in double.
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+pcg_update_kernel(int64_t n, const double *__restrict__ rz, const double *__restrict__ yp, const T *__restrict__ y, T *__restrict__ r, const T *__restrict__ dinv,
+                  double *__restrict__ part_rz, double *__restrict__ part_rr)
+{
+    __shared__ double lds[kBlock];
+    const T alpha = (T)(*rz / *yp);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double a_rz = 0.0, a_rr = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T ri = r[i] - alpha * y[i];
+        r[i] = ri;
+        a_rz += (double)ri * (double)(dinv[i] * ri);
+        a_rr += (double)ri * (double)ri;
+    }
+    const double s1 = block_add(a_rz, lds);
+    __syncthreads();
+    const double s2 = block_add(a_rr, lds);
+    if (threadIdx.x == 0) { part_rz[blockIdx.x] = s1; part_rr[blockIdx.x] = s2; }
+}
+__global__ void __launch_bounds__(kBlock)
+pcg_final_kernel(int npartial, const double *__restrict__ part_rz, const double *__restrict__ part_rr, double *__restrict__ rz_new, double *__restrict__ rr,
+                 double *__restrict__ rr_mirror)
+{
+    __shared__ double lds[kBlock];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < npartial; i += kBlock) { a += part_rz[i]; b += part_rr[i]; }
+    const double s1 = block_add(a, lds);
+    __syncthreads();
+    const double s2 = block_add(b, lds);
+    if (threadIdx.x == 0) {
+        *rz_new = s1;
+        *rr = s2;
+        if (rr_mirror) *rr_mirror = s2;
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+pcg_direction_kernel(int64_t n, const double *__restrict__ rz_new, const double *__restrict__ rz_old, const double *__restrict__ yp, const T *__restrict__ r,
+                     const T *__restrict__ dinv, T *__restrict__ p, T *__restrict__ x)
+{
+    const T alpha = (T)(*rz_old / *yp), beta = (T)(*rz_new / *rz_old);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T pi = p[i];
+        x[i] = x[i] + alpha * pi;
+        p[i] = dinv[i] * r[i] + beta * pi;
+    }
+}
+
+template <typename T>
+int pcg_update_impl(int64_t n, const double *rz, const double *yp, const T *y, T *r, const T *dinv, double *rz_new, double *rr, double *rr_mirror, void *workspace,
+                    void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_pcg_update_jacobi: negative n");
+    if (!rz || !yp || !rz_new || !rr || !workspace || (n > 0 && (!y || !r || !dinv))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_pcg_update_jacobi: null argument");
+    const int grid = grid_for(n);
+    double *part = (double *)workspace;
+    hipLaunchKernelGGL((pcg_update_kernel<T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, rz, yp, y, r, dinv, part, part + kMaxGrid);
+    hipLaunchKernelGGL(pcg_final_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), grid, (const double *)part, (const double *)(part + kMaxGrid), rz_new, rr, rr_mirror);
+    CMI_LAUNCH_CHECK("pcg_update_jacobi");
+    return CMI_SUCCESS;
+}
+template <typename T>
+int pcg_direction_impl(int64_t n, const double *rz_new, const double *rz_old, const double *yp, const T *r, const T *dinv, T *p, T *x, void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_pcg_direction_x_jacobi: negative n");
+    if (!rz_new || !rz_old || !yp || (n > 0 && (!r || !dinv || !p || !x))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_pcg_direction_x_jacobi: null argument");
+    if (n == 0) return CMI_SUCCESS;
+    hipLaunchKernelGGL((pcg_direction_kernel<T>), dim3(grid_for(n) * 4), dim3(kBlock), 0, as_stream(stream), n, rz_new, rz_old, yp, r, dinv, p, x);
+    CMI_LAUNCH_CHECK("pcg_direction_x_jacobi");
+    return CMI_SUCCESS;
+}
+
 } // namespace
 } // namespace cmi
 
 using namespace cmi;
+CMI_API int cmi_pcg_update_jacobi_f64(int64_t n, const double *rz_dev, const double *yp_dev, const double *y, double *r, const double *dinv, double *rz_new_dev,
+                                      double *rr_dev, double *rr_host_mirror, void *workspace, void *stream)
+{ return pcg_update_impl<double>(n, rz_dev, yp_dev, y, r, dinv, rz_new_dev, rr_dev, rr_host_mirror, workspace, stream); }
+CMI_API int cmi_pcg_update_jacobi_f32(int64_t n, const double *rz_dev, const double *yp_dev, const float *y, float *r, const float *dinv, double *rz_new_dev,
+                                      double *rr_dev, double *rr_host_mirror, void *workspace, void *stream)
+{ return pcg_update_impl<float>(n, rz_dev, yp_dev, y, r, dinv, rz_new_dev, rr_dev, rr_host_mirror, workspace, stream); }
+CMI_API int cmi_pcg_direction_x_jacobi_f64(int64_t n, const double *rz_new_dev, const double *rz_old_dev, const double *yp_dev, const double *r, const double *dinv,
+                                           double *p, double *x, void *stream)
+{ return pcg_direction_impl<double>(n, rz_new_dev, rz_old_dev, yp_dev, r, dinv, p, x, stream); }
+CMI_API int cmi_pcg_direction_x_jacobi_f32(int64_t n, const double *rz_new_dev, const double *rz_old_dev, const double *yp_dev, const float *r, const float *dinv,
+                                           float *p, float *x, void *stream)
+{ return pcg_direction_impl<float>(n, rz_new_dev, rz_old_dev, yp_dev, r, dinv, p, x, stream); }
 CMI_API int cmi_blas_scal_f64(int64_t n, double alpha, double *x, void *stream) { return scal_impl<double>(n, alpha, x, stream); }
 CMI_API int cmi_blas_scal_f32(int64_t n, float alpha, float *x, void *stream) { return scal_impl<float>(n, alpha, x, stream); }
 CMI_API int cmi_blas_xmy_f64(int64_t n, const double *x, const double *y, double *z, void *stream) { return xmy_impl<double>(n, x, y, z, stream); }

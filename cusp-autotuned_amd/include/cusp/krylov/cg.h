@@ -16,6 +16,7 @@
 #include "../multiply.h"
 
 namespace cusp {
+namespace precond { template <typename ValueType, typename MemorySpace> class diagonal; }
 namespace krylov {
 
 namespace detail {
@@ -304,6 +305,57 @@ void cg_fused_device(const LinearOperator &A, VectorType1 &x, const VectorType2 
     cusp::detail::check(cmi_device_synchronize()); // the discarded SpMV must not outlive y
 }
 
+// M = cusp::precond::diagonal on device_memory: the same schedule with z = D^-1 r never stored (cmi_pcg_update_jacobi_* / cmi_pcg_direction_x_jacobi_*):
+// SpMV + <y,p>, the update with BOTH <r,z> (for alpha / beta) and <r,r> (for the monitor, as the reference's monitor.finished(r)), the direction
+// pass -- one host read per iteration behind the next, speculative multiply.
+inline int pcg_update_(size_t n, const double *rz, const double *yp, const double *y, double *r, const double *d, double *rz_new, double *rr, double *mirror, void *ws)
+{ return cmi_pcg_update_jacobi_f64(n, rz, yp, y, r, d, rz_new, rr, mirror, ws, nullptr); }
+inline int pcg_update_(size_t n, const double *rz, const double *yp, const float *y, float *r, const float *d, double *rz_new, double *rr, double *mirror, void *ws)
+{ return cmi_pcg_update_jacobi_f32(n, rz, yp, y, r, d, rz_new, rr, mirror, ws, nullptr); }
+inline int pcg_direction_(size_t n, const double *rz_new, const double *rz_old, const double *yp, const double *r, const double *d, double *p, double *x)
+{ return cmi_pcg_direction_x_jacobi_f64(n, rz_new, rz_old, yp, r, d, p, x, nullptr); }
+inline int pcg_direction_(size_t n, const double *rz_new, const double *rz_old, const double *yp, const float *r, const float *d, float *p, float *x)
+{ return cmi_pcg_direction_x_jacobi_f32(n, rz_new, rz_old, yp, r, d, p, x, nullptr); }
+
+template <typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor, typename Diagonal>
+void cg_fused_jacobi_device(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &monitor, const Diagonal &M)
+{
+    typedef typename LinearOperator::value_type T;
+    const size_t N = A.num_rows;
+    const T *dinv = M.reciprocals().data();
+    cusp::array1d<T, cusp::device_memory> y(N), r(N), p(N);
+    cusp::array1d<double, cusp::device_memory> scalars(4); // <r,z>[0], <r,z>[1], <y,p>, <r,r>
+    cusp::blas::detail::device_workspace &w = cusp::blas::detail::workspace();
+    double *rz[2] = {scalars.data(), scalars.data() + 1};
+    double *yp = scalars.data() + 2, *rr = scalars.data() + 3;
+    pinned_scalar rr_host;
+    cusp::multiply(A, x, y);
+    cusp::blas::axpby(b, y, r, T(1), T(-1));
+    cusp::blas::xmy(M.reciprocals(), r, p);                           // p <- z = D^-1 r
+    cusp::detail::check(dotd_(N, r.data(), p.data(), rz[0], w.ws));   // <r, z>
+    cusp::detail::check(dotd_(N, r.data(), r.data(), rr, w.ws));
+    rr_host.fetch(rr);
+    int cur = 0;
+    for (;;) {
+        multiply_dot_any(A, p, y, yp, w.ws, std::is_same<T, double>()); // the hot path, speculative: y <- A p, *yp <- <y, p>
+        if (monitor.finished_norm(static_cast<typename Monitor::Real>(std::sqrt(rr_host.wait())))) break; // the one host read
+        cusp::detail::check(pcg_update_(N, rz[cur], yp, y.data(), r.data(), dinv, rz[cur ^ 1], rr, rr_host.host, w.ws));
+        rr_host.record();
+        cusp::detail::check(pcg_direction_(N, rz[cur ^ 1], rz[cur], yp, r.data(), dinv, p.data(), x.data()));
+        cur ^= 1;
+        ++monitor;
+    }
+    cusp::detail::check(cmi_device_synchronize()); // the discarded SpMV must not outlive y
+}
+
+template <typename A, typename X, typename M, typename Mon> struct use_fused_jacobi {
+    typedef typename A::value_type T;
+    static const bool value = std::is_same<typename A::memory_space, cusp::device_memory>::value &&
+                              (std::is_same<T, double>::value || std::is_same<T, float>::value) && std::is_same<typename X::value_type, T>::value &&
+                              std::is_same<typename std::remove_const<M>::type, cusp::precond::diagonal<T, cusp::device_memory>>::value &&
+                              decltype(has_finished_norm(static_cast<Mon *>(nullptr)))::value;
+};
+
 template <typename A, typename X, typename M, typename Mon> struct use_fused {
     typedef typename A::value_type T;
     static const bool value = std::is_same<typename A::memory_space, cusp::device_memory>::value &&
@@ -321,9 +373,21 @@ void cg_select(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Mo
     cg_fused_device(A, x, b, monitor);
 }
 template <typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor, typename Preconditioner>
-void cg_select(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &monitor, Preconditioner &M, std::false_type)
+void cg_select_plain(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &monitor, Preconditioner &M, std::true_type) // Jacobi, device
+{
+    const char *e = std::getenv("CMI_CG_FUSED_JACOBI");
+    if (e && e[0] == '0') { cg_plain(A, x, b, monitor, M); return; } // (measurements: the operation-by-operation path)
+    cg_fused_jacobi_device(A, x, b, monitor, M);
+}
+template <typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor, typename Preconditioner>
+void cg_select_plain(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &monitor, Preconditioner &M, std::false_type)
 {
     cg_plain(A, x, b, monitor, M);
+}
+template <typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor, typename Preconditioner>
+void cg_select(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &monitor, Preconditioner &M, std::false_type)
+{
+    cg_select_plain(A, x, b, monitor, M, std::integral_constant<bool, use_fused_jacobi<LinearOperator, VectorType1, Preconditioner, Monitor>::value>());
 }
 
 } // namespace detail

@@ -23,6 +23,8 @@ public:
         for (size_t i = 0; i < d.size(); i++) d[i] = ValueType(1) / d[i]; // (a zero on the diagonal gives inf, as in the reference)
         diagonal_reciprocals = d;
     }
+    // 1 / a_ii (what cusp::krylov::cg's fused Jacobi path on device_memory reads instead of storing z = D^-1 r)
+    const cusp::array1d<ValueType, MemorySpace> &reciprocals() const { return diagonal_reciprocals; }
     template <typename VectorType1, typename VectorType2> void operator()(const VectorType1 &x, VectorType2 &y) const
     {
         cusp::blas::xmy(diagonal_reciprocals, x, y);

@@ -639,6 +639,20 @@ int cmi_blas_asum_f64(int64_t n, const double *x, double *result_dev, void *work
 int cmi_blas_asum_f32(int64_t n, const float *x, float *result_dev, void *workspace, void *stream);
 int cmi_blas_amax_f64(int64_t n, const double *x, double *value_dev, int64_t *index_dev, void *workspace, void *stream);
 int cmi_blas_amax_f32(int64_t n, const float *x, float *value_dev, int64_t *index_dev, void *workspace, void *stream);
+/* Jacobi-preconditioned CG's two vector passes with the scalars in device memory (the twin of cmi_cg_update_* / cmi_cg_direction_x_* for
+ * M = cusp::precond::diagonal; reference cusp/krylov/detail/cg.inl:83-103 with that M: 5 passes and 2 host reads).  dinv = 1 / diag(A).
+ *   update:     alpha = *rz_dev / *yp_dev;  r <- r - alpha y;  *rz_new_dev <- <r, dinv .* r>;  *rr_dev <- <r, r> (also written to
+ *               rr_host_mirror when that is not NULL: page-locked memory the device can write, for the monitor)
+ *   direction:  alpha = *rz_old_dev / *yp_dev;  beta = *rz_new_dev / *rz_old_dev;  x <- x + alpha p;  p <- dinv .* r + beta p
+ * Deterministic two-stage reductions in double; `workspace`: cmi_blas_workspace_bytes().                                                 */
+int cmi_pcg_update_jacobi_f64(int64_t n, const double *rz_dev, const double *yp_dev, const double *y, double *r, const double *dinv, double *rz_new_dev,
+                              double *rr_dev, double *rr_host_mirror, void *workspace, void *stream);
+int cmi_pcg_update_jacobi_f32(int64_t n, const double *rz_dev, const double *yp_dev, const float *y, float *r, const float *dinv, double *rz_new_dev,
+                              double *rr_dev, double *rr_host_mirror, void *workspace, void *stream);
+int cmi_pcg_direction_x_jacobi_f64(int64_t n, const double *rz_new_dev, const double *rz_old_dev, const double *yp_dev, const double *r, const double *dinv,
+                                   double *p, double *x, void *stream);
+int cmi_pcg_direction_x_jacobi_f32(int64_t n, const double *rz_new_dev, const double *rz_old_dev, const double *yp_dev, const float *r, const float *dinv,
+                                   float *p, float *x, void *stream);
 
 /* Fused steps of unpreconditioned CG (identity M, so z == r), scalars taken from DEVICE memory:
  * replaces dotc -> host -> axpy -> axpy -> copy -> dotc -> host -> axpby of

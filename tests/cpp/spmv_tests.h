@@ -8,6 +8,7 @@
 //   testing/cg.cu:46-99                  CG on poisson5pt(10,10) and the zero-residual start
 //   testing/multiply.cu:792-858          user execution policy reaches a user overload
 #pragma once
+#include <cstdlib>
 #include <cusp/array1d.h>
 #include <cusp/array2d.h>
 #include <cusp/coo_matrix.h>
@@ -1211,6 +1212,32 @@ template <typename Space> void TestPreconditionedCg()
     cusp::multiply(A, x1, r);
     cusp::blas::axpby(b, r, r, 1.0, -1.0);
     ASSERT_TRUE(cusp::blas::nrm2(r) <= 1e-9 * cusp::blas::nrm2(b));
+    // device_memory runs the FUSED Jacobi iteration (cmi_pcg_*_jacobi_*); $CMI_CG_FUSED_JACOBI=0 forces the operation-by-operation path: the
+    // same method, so the same iteration count to within rounding and the same solution
+    setenv("CMI_CG_FUSED_JACOBI", "0", 1);
+    cusp::array1d<double, Space> x2(N, 0.0);
+    cusp::monitor<double> generic(b, 20000, 1e-10);
+    cusp::krylov::cg(A, x2, b, generic, M);
+    unsetenv("CMI_CG_FUSED_JACOBI");
+    ASSERT_TRUE(generic.converged());
+    const long long d = (long long)generic.iteration_count() - (long long)jacobi.iteration_count();
+    ASSERT_TRUE(d >= -3 && d <= 3);
+    cusp::blas::axpy(x1, x2, -1.0);
+    ASSERT_TRUE(cusp::blas::nrmmax(x2) <= 1e-8 * cusp::blas::nrmmax(x1));
+    // float instance
+    cusp::csr_matrix<int, float, cusp::host_memory> Hf;
+    cusp::gallery::poisson5pt(Hf, 20, 20);
+    for (size_t i = 0; i < Hf.num_rows; i++)
+        for (int jj = Hf.row_offsets[i]; jj < Hf.row_offsets[i + 1]; jj++) Hf.values[jj] = Hf.values[jj] * float(1 + i % 4) * float(1 + Hf.column_indices[jj] % 4);
+    cusp::csr_matrix<int, float, Space> Af(Hf);
+    cusp::precond::diagonal<float, Space> Mf(Af);
+    cusp::array1d<float, Space> bf(Af.num_rows, 1.0f), xf(Af.num_rows, 0.0f), rf(Af.num_rows);
+    cusp::monitor<float> mf(bf, 2000, 1e-5);
+    cusp::krylov::cg(Af, xf, bf, mf, Mf);
+    ASSERT_TRUE(mf.converged());
+    cusp::multiply(Af, xf, rf);
+    cusp::blas::axpby(bf, rf, rf, 1.0f, -1.0f);
+    ASSERT_TRUE(cusp::blas::nrm2(rf) <= 1e-4f * cusp::blas::nrm2(bf));
 }
 DECLARE_SPACE_UNITTEST(TestPreconditionedCg);
 

@@ -1,6 +1,7 @@
 // tools/cg_bench.cpp -- CG iterations/s through the C++ layer (cusp::krylov::cg on device_memory), the
 // caller of the SpMV hot path: poisson5pt(grid, grid), b = deterministic x pattern, fixed iteration count.
 //   [CMI_COMPRESS_INDICES=1] cg_bench [--grid=3162] [--iterations=200] [--format=csr|ell|dia|hyb|coo]
+//   cg_bench --solvers [--grid=3162] [--iterations=100]     the multiply's other callers: Jacobi-preconditioned cg, cr, bicgstab, gmres(20)
 //   tools/bin/cmi_launch -n 8 -- tools/bin/cg_bench --sharded --grid=10000      (BASELINE.json configs[4]: one process per GPU)
 // Prints the fused device path (default: identity preconditioner, double) and, for comparison, the plain
 // operation-by-operation path (forced by passing an explicit non-identity-typed preconditioner).
@@ -11,6 +12,10 @@
 #include <cusp/hyb_matrix.h>
 #include <cusp/gallery/poisson.h>
 #include <cusp/krylov/cg.h>
+#include <cusp/krylov/bicgstab.h>
+#include <cusp/krylov/cr.h>
+#include <cusp/krylov/gmres.h>
+#include <cusp/precond/diagonal.h>
 #include <cusp/monitor.h>
 #include <cusp/distributed.h>
 
@@ -58,6 +63,46 @@ template <typename Matrix> int run(size_t grid, size_t iters, const char *name)
                         "final ||r|| = %.6e\n", fused ? "fused" : "plain", iters, sec * 1e3, iters / sec, sec / iters * 1e6, (sec2 - sec) / iters * 1e6, res);
         }
     }
+    return 0;
+}
+
+// The multiply's OTHER callers on the same matrix (--solvers): Jacobi-preconditioned cg (generic path: precond::diagonal = one xmy kernel), cr, bicgstab,
+// gmres(20) -- operation by operation through cusp::multiply (A's plan) and cusp::blas; a fixed iteration count (relative tolerance 0)
+template <typename F> static void time_solver(const char *name, size_t iters, size_t multiplies_per_iteration, F solve)
+{
+    auto timed = [&](size_t k) {
+        cusp::detail::check(cmi_device_synchronize());
+        const auto t0 = std::chrono::steady_clock::now();
+        solve(k);
+        cusp::detail::check(cmi_device_synchronize());
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    };
+    timed(iters / 4 + 1); // warm-up: plans, workspaces
+    const double t1 = timed(iters), t2 = timed(2 * iters);
+    // the marginal iteration: work-vector allocation and release (bicgstab: 8 vectors, gmres(20): 23), r = b - A x and the monitor's ||b|| are in both solves
+    std::printf("%-34s %7.1f us per marginal iteration (%zu multiplies of A each); a whole %zu-iteration solve %8.1f ms\n", name, (t2 - t1) / iters * 1e6,
+                multiplies_per_iteration, iters, t1 * 1e3);
+}
+static int run_solvers(size_t grid, size_t iters)
+{
+    typedef cusp::csr_matrix<int, double, cusp::device_memory> Matrix;
+    typedef cusp::array1d<double, cusp::device_memory> Vector;
+    Matrix A;
+    cusp::gallery::poisson5pt(A, grid, grid);
+    const size_t N = A.num_rows;
+    cusp::array1d<double, cusp::host_memory> hb(N);
+    for (size_t i = 0; i < N; i++) hb[i] = double((unsigned(i) * 2654435761u) % 1000u) / 997.0 - 0.5;
+    Vector b(hb);
+    cusp::precond::diagonal<double, cusp::device_memory> M(A);
+    std::printf("poisson5pt(%zu,%zu) CSR fp64 on the device, fixed iteration counts\n", grid, grid);
+    time_solver("cg (fused, identity M)", iters, 1, [&](size_t k) { Vector x(N, 0.0); cusp::monitor<double> m(b, k, 0.0, 0.0); cusp::krylov::cg(A, x, b, m); });
+    time_solver("cg + precond::diagonal (fused)", iters, 1, [&](size_t k) { Vector x(N, 0.0); cusp::monitor<double> m(b, k, 0.0, 0.0); cusp::krylov::cg(A, x, b, m, M); });
+    setenv("CMI_CG_FUSED_JACOBI", "0", 1);
+    time_solver("cg + precond::diagonal (generic)", iters, 1, [&](size_t k) { Vector x(N, 0.0); cusp::monitor<double> m(b, k, 0.0, 0.0); cusp::krylov::cg(A, x, b, m, M); });
+    unsetenv("CMI_CG_FUSED_JACOBI");
+    time_solver("cr", iters, 2, [&](size_t k) { Vector x(N, 0.0); cusp::monitor<double> m(b, k, 0.0, 0.0); cusp::krylov::cr(A, x, b, m); });
+    time_solver("bicgstab", iters, 2, [&](size_t k) { Vector x(N, 0.0); cusp::monitor<double> m(b, k, 0.0, 0.0); cusp::krylov::bicgstab(A, x, b, m); });
+    time_solver("gmres(20)", iters, 1, [&](size_t k) { Vector x(N, 0.0); cusp::monitor<double> m(b, k, 0.0, 0.0); cusp::krylov::gmres(A, x, b, 20, m); });
     return 0;
 }
 
@@ -150,9 +195,11 @@ int main(int argc, char **argv)
         if (!std::strncmp(argv[i], "--iterations=", 13)) iters = std::strtoul(argv[i] + 13, nullptr, 10);
         if (!std::strncmp(argv[i], "--format=", 9)) format = argv[i] + 9;
         if (!std::strcmp(argv[i], "--sharded")) format = "sharded";
+        if (!std::strcmp(argv[i], "--solvers")) format = "solvers";
     }
     try {
         if (format == "sharded") return run_sharded(grid, iters);
+        if (format == "solvers") return run_solvers(grid, iters);
         if (format == "csr") return run<cusp::csr_matrix<int, double, cusp::device_memory>>(grid, iters, "csr");
         if (format == "ell") return run<cusp::ell_matrix<int, double, cusp::device_memory>>(grid, iters, "ell");
         if (format == "dia") return run<cusp::dia_matrix<int, double, cusp::device_memory>>(grid, iters, "dia");
