@@ -23,7 +23,10 @@ void bicgstab(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Mon
     typedef typename LinearOperator::memory_space MemorySpace;
     if (A.num_rows != A.num_cols) throw cusp::invalid_input_exception("bicgstab: the operator must be square");
     const size_t N = A.num_rows;
-    cusp::array1d<ValueType, MemorySpace> p(N), r(N), r_star(N), s(N), Mp(N), AMp(N), Ms(N), AMs(N);
+    // M = identity_operator (the default): M p IS p and M s IS s -- the two copies per iteration the reference makes are skipped (aliases below)
+    const bool plain = detail::is_identity<Preconditioner>::value;
+    cusp::array1d<ValueType, MemorySpace> p(N), r(N), r_star(N), s(N), Mp_own(plain ? 0 : N), AMp(N), Ms_own(plain ? 0 : N), AMs(N);
+    cusp::array1d<ValueType, MemorySpace> &Mp = plain ? p : Mp_own, &Ms = plain ? s : Ms_own;
 
     cusp::multiply(A, x, r);
     cusp::blas::axpby(b, r, r, ValueType(1), ValueType(-1)); // r <- b - A x
@@ -32,7 +35,7 @@ void bicgstab(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Mon
     ValueType rho = cusp::blas::dotc(r_star, r);
 
     while (!monitor.finished(r)) {
-        detail::apply(M, p, Mp, 0);
+        if (!plain) detail::apply(M, p, Mp, 0);
         cusp::multiply(A, Mp, AMp);
         const ValueType alpha = rho / cusp::blas::dotc(r_star, AMp);
         cusp::blas::axpby(r, AMp, s, ValueType(1), -alpha);  // s <- r - alpha A M p
@@ -40,7 +43,7 @@ void bicgstab(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Mon
             cusp::blas::axpby(x, Mp, x, ValueType(1), alpha);
             break;
         }
-        detail::apply(M, s, Ms, 0);
+        if (!plain) detail::apply(M, s, Ms, 0);
         cusp::multiply(A, Ms, AMs);
         const ValueType omega = cusp::blas::dotc(AMs, s) / cusp::blas::dotc(AMs, AMs);
         cusp::blas::axpbypcz(x, Mp, Ms, x, ValueType(1), alpha, omega);     // x <- x + alpha M p + omega M s

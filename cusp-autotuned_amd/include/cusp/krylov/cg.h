@@ -22,6 +22,10 @@ namespace krylov {
 namespace detail {
 // the overloads without a policy must not swallow cg(policy, A, x, b[, monitor]) calls
 template <typename T> struct is_policy : std::is_base_of<cusp::execution_policy<T>, T> {};
+// (the solvers skip the copy an identity preconditioner would make)
+template <typename M> struct is_identity : std::false_type {};
+template <typename V, typename S, typename I> struct is_identity<cusp::identity_operator<V, S, I>> : std::true_type {};
+template <typename V, typename S, typename I> struct is_identity<const cusp::identity_operator<V, S, I>> : std::true_type {};
 template <typename T> using not_policy = typename std::enable_if<!is_policy<T>::value>::type;
 
 // z <- M r for a matrix-like preconditioner or a linear operator with operator()

@@ -20,11 +20,13 @@ void cr(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &
     typedef typename LinearOperator::memory_space MemorySpace;
     if (A.num_rows != A.num_cols) throw cusp::invalid_input_exception("cr: the operator must be square");
     const size_t N = A.num_rows, recompute_r = 8; // (cr.inl:50: how often the residual is rebuilt from b - A x)
-    cusp::array1d<ValueType, MemorySpace> y(N), z(N), r(N), p(N), Az(N), Ax(N);
+    const bool plain = detail::is_identity<Preconditioner>::value; // M = identity_operator: z IS r (no copy per iteration)
+    cusp::array1d<ValueType, MemorySpace> y(N), z_own(plain ? 0 : N), r(N), p(N), Az(N), Ax(N);
+    cusp::array1d<ValueType, MemorySpace> &z = plain ? r : z_own;
 
     cusp::multiply(A, x, Ax);
     cusp::blas::axpby(b, Ax, r, ValueType(1), ValueType(-1)); // r <- b - A x
-    detail::apply(M, r, z, 0);                                // z <- M r
+    if (!plain) detail::apply(M, r, z, 0);                    // z <- M r
     cusp::blas::copy(z, p);
     cusp::multiply(A, p, y);                                  // y <- A p
     cusp::multiply(A, z, Az);
@@ -40,7 +42,7 @@ void cr(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, Monitor &
             cusp::multiply(A, x, Ax);
             cusp::blas::axpby(b, Ax, r, ValueType(1), ValueType(-1));
         }
-        detail::apply(M, r, z, 0);
+        if (!plain) detail::apply(M, r, z, 0);
         cusp::multiply(A, z, Az);
         const ValueType rz_old = rz;
         rz = cusp::blas::dotc(r, Az);

@@ -46,6 +46,7 @@ void gmres(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, const 
     if (restart == 0) throw cusp::invalid_input_exception("gmres: restart must be positive");
     const size_t N = A.num_rows;
     const int R = static_cast<int>(restart);
+    const bool plain = detail::is_identity<Preconditioner>::value;
     cusp::array1d<ValueType, MemorySpace> w(N), t(N);
     std::vector<cusp::array1d<ValueType, MemorySpace>> V(R + 1, cusp::array1d<ValueType, MemorySpace>(N, ValueType(0))); // the Krylov basis
     std::vector<ValueType> H((size_t)(R + 1) * R, ValueType(0)), s(R + 1), cs(R), sn(R);                               // H(k, i) = H[k + i (R + 1)]
@@ -56,11 +57,10 @@ void gmres(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, const 
     do {
         cusp::multiply(A, x, w);
         cusp::blas::axpy(b, w, ValueType(-1));            // w <- A x - b
-        detail::apply(M, w, t, 0);                        // (the reference applies M in place; operators here take distinct arguments)
+        if (plain) t.swap(w); else detail::apply(M, w, t, 0); // t <- M (A x - b)   (operators here take distinct arguments)
         const ValueType beta = cusp::blas::nrm2(t);
         cusp::blas::scal(t, ValueType(-1.0 / beta));      // the first basis vector: M (b - A x) / beta
-        cusp::blas::copy(t, w);
-        cusp::blas::copy(w, V[0]);
+        cusp::blas::copy(t, V[0]);
         std::fill(s.begin(), s.end(), ValueType(0));
         s[0] = beta;
         i = -1;
@@ -69,8 +69,8 @@ void gmres(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, const 
         do {
             ++i;
             ++monitor;
-            cusp::multiply(A, w, t);                      // (the hot path)
-            detail::apply(M, t, w, 0);                    // w <- M A v_i
+            if (plain) cusp::multiply(A, V[i], w);        // (the hot path) M = identity_operator: w <- A v_i directly
+            else { cusp::multiply(A, V[i], t); detail::apply(M, t, w, 0); } // w <- M A v_i
             for (int k = 0; k <= i; k++) {                // modified Gram-Schmidt
                 h(k, i) = cusp::blas::dotc(V[k], w);
                 cusp::blas::axpy(V[k], w, -h(k, i));
