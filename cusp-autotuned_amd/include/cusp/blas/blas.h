@@ -20,13 +20,13 @@ namespace detail {
 
 struct device_workspace { // lazily allocated per thread, freed at exit: no allocation per call
     void *ws;
-    void *result; // 8 bytes: holds a double or a float scalar
+    void *result; // 16 bytes: a double or a float scalar, and behind it the position amax reports
     device_workspace() : ws(nullptr), result(nullptr) {}
     ~device_workspace() { if (ws) cmi_free(ws); if (result) cmi_free(result); }
     void ensure()
     {
         if (!ws) cusp::detail::check(cmi_malloc(&ws, cmi_blas_workspace_bytes()));
-        if (!result) cusp::detail::check(cmi_malloc(&result, sizeof(double)));
+        if (!result) cusp::detail::check(cmi_malloc(&result, 2 * sizeof(double)));
     }
 };
 inline device_workspace &workspace()
@@ -158,8 +158,7 @@ template <typename X> void max_abs(const X &x, typename X::value_type &value, si
     typedef typename X::value_type V;
     require_real<V>();
     device_workspace &w = workspace();
-    // the position goes behind the fold areas' first doubles in the workspace: 8 bytes at its very end are never touched by the reduction
-    int64_t *pos = reinterpret_cast<int64_t *>(static_cast<char *>(w.ws) + cmi_blas_workspace_bytes() - sizeof(int64_t));
+    int64_t *pos = reinterpret_cast<int64_t *>(static_cast<char *>(w.result) + sizeof(double));
     cusp::detail::check(c_amax(x.size(), x.data(), static_cast<V *>(w.result), pos, w.ws));
     int64_t p = 0;
     cusp::detail::check(cmi_memcpy_d2h(&value, w.result, sizeof(V), nullptr));
