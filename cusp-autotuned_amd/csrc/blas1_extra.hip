@@ -247,10 +247,152 @@ int pcg_direction_impl(int64_t n, const double *rz_new, const double *rz_old, co
     return CMI_SUCCESS;
 }
 
+// ---- BiCGstab (identity preconditioner): the three vector passes of an iteration with the scalars in DEVICE memory ----------------------------
+// (reference cusp/krylov/detail/bicgstab.inl:78-125: axpby, [copy,] dotc, dotc, axpbypcz, axpby, dotc, axpbypcz + two monitor norms = ~9 passes
+// and 6 host reads around its two multiplies).  Here: the multiplies carry <r*, A p> and <A s, s> (cmi_spmv_*_dot_*), and
+//   s-pass:   alpha = rho / <r*, A p>;  s <- r - alpha A p;  *ss <- <s, s>                                          (+ host mirror: the early exit)
+//   xr-pass:  omega = <A s, s> / <A s, A s>;  x <- x + alpha p + omega s;  r <- s - omega A s;  *rho_new <- <r*, r>;  *rr <- <r, r> (+ mirror)
+//   p-pass:   beta = (rho_new / rho) (alpha / omega);  p <- r + beta (p - omega A p)
+// Two host reads per iteration (||s||, ||r||), deterministic two-stage reductions in double.
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+bicg_s_kernel(int64_t n, const double *__restrict__ rho, const double *__restrict__ d1, const T *__restrict__ r, const T *__restrict__ AMp, T *__restrict__ s,
+              double *__restrict__ part)
+{
+    __shared__ double lds[kBlock];
+    const T alpha = (T)(*rho / *d1);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T si = r[i] - alpha * AMp[i];
+        s[i] = si;
+        acc += (double)si * (double)si;
+    }
+    const double t = block_add(acc, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(kBlock) sum1_final_kernel(int npartial, const double *__restrict__ part, double *__restrict__ out, double *__restrict__ mirror)
+{
+    __shared__ double lds[kBlock];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < npartial; i += kBlock) a += part[i];
+    const double t = block_add(a, lds);
+    if (threadIdx.x == 0) { *out = t; if (mirror) *mirror = t; }
+}
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+bicg_xr_kernel(int64_t n, const double *__restrict__ rho, const double *__restrict__ d1, const double *__restrict__ d2, const double *__restrict__ d3,
+               const T *__restrict__ p, const T *__restrict__ s, const T *__restrict__ AMs, const T *__restrict__ r_star, T *__restrict__ x, T *__restrict__ r,
+               double *__restrict__ part_rho, double *__restrict__ part_rr)
+{
+    __shared__ double lds[kBlock];
+    const T alpha = (T)(*rho / *d1), omega = (T)(*d2 / *d3);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double a1 = 0.0, a2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T si = s[i];
+        x[i] = x[i] + alpha * p[i] + omega * si;
+        const T ri = si - omega * AMs[i];
+        r[i] = ri;
+        a1 += (double)r_star[i] * (double)ri;
+        a2 += (double)ri * (double)ri;
+    }
+    const double t1 = block_add(a1, lds);
+    __syncthreads();
+    const double t2 = block_add(a2, lds);
+    if (threadIdx.x == 0) { part_rho[blockIdx.x] = t1; part_rr[blockIdx.x] = t2; }
+}
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+bicg_p_kernel(int64_t n, const double *__restrict__ rho_new, const double *__restrict__ rho, const double *__restrict__ d1, const double *__restrict__ d2,
+              const double *__restrict__ d3, const T *__restrict__ r, const T *__restrict__ AMp, T *__restrict__ p)
+{
+    const double alpha = *rho / *d1, omega = *d2 / *d3;
+    const T beta = (T)((*rho_new / *rho) * (alpha / omega)), bo = (T)(-(double)beta * omega);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = r[i] + beta * p[i] + bo * AMp[i];
+}
+template <typename T>
+__global__ void __launch_bounds__(kBlock) axpy_ratio_kernel(int64_t n, const double *__restrict__ num, const double *__restrict__ den, const T *__restrict__ x, T *__restrict__ y)
+{
+    const T a = (T)(*num / *den);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = y[i] + a * x[i];
+}
+
+template <typename T>
+int bicg_s_impl(int64_t n, const double *rho, const double *d1, const T *r, const T *AMp, T *s, double *ss, double *ss_mirror, void *workspace, void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_bicgstab_s: negative n");
+    if (!rho || !d1 || !ss || !workspace || (n > 0 && (!r || !AMp || !s))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_bicgstab_s: null argument");
+    const int grid = grid_for(n);
+    hipLaunchKernelGGL((bicg_s_kernel<T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, rho, d1, r, AMp, s, (double *)workspace);
+    hipLaunchKernelGGL(sum1_final_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), grid, (const double *)workspace, ss, ss_mirror);
+    CMI_LAUNCH_CHECK("bicgstab_s");
+    return CMI_SUCCESS;
+}
+template <typename T>
+int bicg_xr_impl(int64_t n, const double *rho, const double *d1, const double *d2, const double *d3, const T *p, const T *s, const T *AMs, const T *r_star, T *x, T *r,
+                 double *rho_new, double *rr, double *rr_mirror, void *workspace, void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_bicgstab_xr: negative n");
+    if (!rho || !d1 || !d2 || !d3 || !rho_new || !rr || !workspace || (n > 0 && (!p || !s || !AMs || !r_star || !x || !r)))
+        return fail(CMI_ERROR_INVALID_VALUE, "cmi_bicgstab_xr: null argument");
+    const int grid = grid_for(n);
+    double *part = (double *)workspace;
+    hipLaunchKernelGGL((bicg_xr_kernel<T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, rho, d1, d2, d3, p, s, AMs, r_star, x, r, part, part + kMaxGrid);
+    hipLaunchKernelGGL(pcg_final_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), grid, (const double *)part, (const double *)(part + kMaxGrid), rho_new, rr, rr_mirror);
+    CMI_LAUNCH_CHECK("bicgstab_xr");
+    return CMI_SUCCESS;
+}
+template <typename T>
+int bicg_p_impl(int64_t n, const double *rho_new, const double *rho, const double *d1, const double *d2, const double *d3, const T *r, const T *AMp, T *p, void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_bicgstab_p: negative n");
+    if (!rho_new || !rho || !d1 || !d2 || !d3 || (n > 0 && (!r || !AMp || !p))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_bicgstab_p: null argument");
+    if (n == 0) return CMI_SUCCESS;
+    hipLaunchKernelGGL((bicg_p_kernel<T>), dim3(grid_for(n) * 4), dim3(kBlock), 0, as_stream(stream), n, rho_new, rho, d1, d2, d3, r, AMp, p);
+    CMI_LAUNCH_CHECK("bicgstab_p");
+    return CMI_SUCCESS;
+}
+template <typename T> int axpy_ratio_impl(int64_t n, const double *num, const double *den, const T *x, T *y, void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_axpy_ratio: negative n");
+    if (!num || !den || (n > 0 && (!x || !y))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_axpy_ratio: null argument");
+    if (n == 0) return CMI_SUCCESS;
+    hipLaunchKernelGGL((axpy_ratio_kernel<T>), dim3(grid_for(n) * 4), dim3(kBlock), 0, as_stream(stream), n, num, den, x, y);
+    CMI_LAUNCH_CHECK("axpy_ratio");
+    return CMI_SUCCESS;
+}
+
 } // namespace
 } // namespace cmi
 
 using namespace cmi;
+CMI_API int cmi_bicgstab_s_f64(int64_t n, const double *rho_dev, const double *d1_dev, const double *r, const double *AMp, double *s, double *ss_dev, double *ss_host_mirror,
+                               void *workspace, void *stream)
+{ return bicg_s_impl<double>(n, rho_dev, d1_dev, r, AMp, s, ss_dev, ss_host_mirror, workspace, stream); }
+CMI_API int cmi_bicgstab_s_f32(int64_t n, const double *rho_dev, const double *d1_dev, const float *r, const float *AMp, float *s, double *ss_dev, double *ss_host_mirror,
+                               void *workspace, void *stream)
+{ return bicg_s_impl<float>(n, rho_dev, d1_dev, r, AMp, s, ss_dev, ss_host_mirror, workspace, stream); }
+CMI_API int cmi_bicgstab_xr_f64(int64_t n, const double *rho_dev, const double *d1_dev, const double *d2_dev, const double *d3_dev, const double *p, const double *s,
+                                const double *AMs, const double *r_star, double *x, double *r, double *rho_new_dev, double *rr_dev, double *rr_host_mirror, void *workspace,
+                                void *stream)
+{ return bicg_xr_impl<double>(n, rho_dev, d1_dev, d2_dev, d3_dev, p, s, AMs, r_star, x, r, rho_new_dev, rr_dev, rr_host_mirror, workspace, stream); }
+CMI_API int cmi_bicgstab_xr_f32(int64_t n, const double *rho_dev, const double *d1_dev, const double *d2_dev, const double *d3_dev, const float *p, const float *s,
+                                const float *AMs, const float *r_star, float *x, float *r, double *rho_new_dev, double *rr_dev, double *rr_host_mirror, void *workspace,
+                                void *stream)
+{ return bicg_xr_impl<float>(n, rho_dev, d1_dev, d2_dev, d3_dev, p, s, AMs, r_star, x, r, rho_new_dev, rr_dev, rr_host_mirror, workspace, stream); }
+CMI_API int cmi_bicgstab_p_f64(int64_t n, const double *rho_new_dev, const double *rho_dev, const double *d1_dev, const double *d2_dev, const double *d3_dev, const double *r,
+                               const double *AMp, double *p, void *stream)
+{ return bicg_p_impl<double>(n, rho_new_dev, rho_dev, d1_dev, d2_dev, d3_dev, r, AMp, p, stream); }
+CMI_API int cmi_bicgstab_p_f32(int64_t n, const double *rho_new_dev, const double *rho_dev, const double *d1_dev, const double *d2_dev, const double *d3_dev, const float *r,
+                               const float *AMp, float *p, void *stream)
+{ return bicg_p_impl<float>(n, rho_new_dev, rho_dev, d1_dev, d2_dev, d3_dev, r, AMp, p, stream); }
+CMI_API int cmi_blas_axpy_ratio_f64(int64_t n, const double *num_dev, const double *den_dev, const double *x, double *y, void *stream)
+{ return axpy_ratio_impl<double>(n, num_dev, den_dev, x, y, stream); }
+CMI_API int cmi_blas_axpy_ratio_f32(int64_t n, const double *num_dev, const double *den_dev, const float *x, float *y, void *stream)
+{ return axpy_ratio_impl<float>(n, num_dev, den_dev, x, y, stream); }
 CMI_API int cmi_pcg_update_jacobi_f64(int64_t n, const double *rz_dev, const double *yp_dev, const double *y, double *r, const double *dinv, double *rz_new_dev,
                                       double *rr_dev, double *rr_host_mirror, void *workspace, void *stream)
 { return pcg_update_impl<double>(n, rz_dev, yp_dev, y, r, dinv, rz_new_dev, rr_dev, rr_host_mirror, workspace, stream); }

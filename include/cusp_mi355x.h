@@ -653,6 +653,28 @@ int cmi_pcg_direction_x_jacobi_f64(int64_t n, const double *rz_new_dev, const do
                                    double *p, double *x, void *stream);
 int cmi_pcg_direction_x_jacobi_f32(int64_t n, const double *rz_new_dev, const double *rz_old_dev, const double *yp_dev, const float *r, const float *dinv,
                                    float *p, float *x, void *stream);
+/* BiCGstab's three vector passes with the scalars in device memory (reference cusp/krylov/detail/bicgstab.inl:78-125, identity preconditioner:
+ * ~9 passes and 6 host reads around its two multiplies).  rho = <r*, r>, d1 = <r*, A p>, d2 = <A s, s>, d3 = <A s, A s> are device doubles:
+ *   s:   alpha = rho / d1;  s <- r - alpha A p;  *ss_dev <- <s, s>  (+ host mirror when not NULL)
+ *   xr:  omega = d2 / d3;  x <- x + alpha p + omega s;  r <- s - omega A s;  *rho_new_dev <- <r*, r>;  *rr_dev <- <r, r>  (+ host mirror)
+ *   p:   beta = (rho_new / rho) (alpha / omega);  p <- r + beta (p - omega A p)
+ * cmi_blas_axpy_ratio_*: y <- y + (*num_dev / *den_dev) x  (the half step x <- x + alpha p of the early exit).                                */
+int cmi_bicgstab_s_f64(int64_t n, const double *rho_dev, const double *d1_dev, const double *r, const double *AMp, double *s, double *ss_dev, double *ss_host_mirror,
+                       void *workspace, void *stream);
+int cmi_bicgstab_s_f32(int64_t n, const double *rho_dev, const double *d1_dev, const float *r, const float *AMp, float *s, double *ss_dev, double *ss_host_mirror,
+                       void *workspace, void *stream);
+int cmi_bicgstab_xr_f64(int64_t n, const double *rho_dev, const double *d1_dev, const double *d2_dev, const double *d3_dev, const double *p, const double *s,
+                        const double *AMs, const double *r_star, double *x, double *r, double *rho_new_dev, double *rr_dev, double *rr_host_mirror, void *workspace,
+                        void *stream);
+int cmi_bicgstab_xr_f32(int64_t n, const double *rho_dev, const double *d1_dev, const double *d2_dev, const double *d3_dev, const float *p, const float *s,
+                        const float *AMs, const float *r_star, float *x, float *r, double *rho_new_dev, double *rr_dev, double *rr_host_mirror, void *workspace,
+                        void *stream);
+int cmi_bicgstab_p_f64(int64_t n, const double *rho_new_dev, const double *rho_dev, const double *d1_dev, const double *d2_dev, const double *d3_dev, const double *r,
+                       const double *AMp, double *p, void *stream);
+int cmi_bicgstab_p_f32(int64_t n, const double *rho_new_dev, const double *rho_dev, const double *d1_dev, const double *d2_dev, const double *d3_dev, const float *r,
+                       const float *AMp, float *p, void *stream);
+int cmi_blas_axpy_ratio_f64(int64_t n, const double *num_dev, const double *den_dev, const double *x, double *y, void *stream);
+int cmi_blas_axpy_ratio_f32(int64_t n, const double *num_dev, const double *den_dev, const float *x, float *y, void *stream);
 
 /* Fused steps of unpreconditioned CG (identity M, so z == r), scalars taken from DEVICE memory:
  * replaces dotc -> host -> axpy -> axpy -> copy -> dotc -> host -> axpby of

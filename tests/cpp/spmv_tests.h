@@ -1295,6 +1295,37 @@ template <typename Space> void TestBicgstab()
     cusp::multiply(A, x, r);
     cusp::blas::axpby(b, r, r, 1.0, -1.0);
     ASSERT_TRUE(cusp::blas::nrm2(r) <= 1e-8 * cusp::blas::nrm2(b));
+    // device_memory ran the FUSED iteration (cmi_bicgstab_*); $CMI_BICGSTAB_FUSED=0 forces the operation-by-operation path: same method, same count
+    // to within rounding, same solution; a float instance through the fused path as well
+    setenv("CMI_BICGSTAB_FUSED", "0", 1);
+    cusp::array1d<double, Space> xg(N, 0.0);
+    cusp::monitor<double> generic(b, 500, 1e-9);
+    cusp::krylov::bicgstab(A, xg, b, generic);
+    unsetenv("CMI_BICGSTAB_FUSED");
+    ASSERT_TRUE(generic.converged());
+    const long long dit = (long long)generic.iteration_count() - (long long)monitor.iteration_count();
+    ASSERT_TRUE(dit >= -3 && dit <= 3);
+    cusp::blas::axpy(x, xg, -1.0);
+    ASSERT_TRUE(cusp::blas::nrmmax(xg) <= 1e-6);
+    {
+        cusp::csr_matrix<int, float, cusp::host_memory> Hf(H.num_rows, H.num_cols, H.num_entries);
+        for (size_t i = 0; i <= N; i++) Hf.row_offsets[i] = H.row_offsets[i];
+        for (size_t k = 0; k < H.num_entries; k++) { Hf.column_indices[k] = H.column_indices[k]; Hf.values[k] = float(H.values[k]); }
+        cusp::csr_matrix<int, float, Space> Af(Hf);
+        cusp::array1d<float, Space> bf(N, 1.0f), xf(N, 0.0f), rf(N);
+        cusp::monitor<float> mf(bf, 500, 1e-4);
+        cusp::krylov::bicgstab(Af, xf, bf, mf);
+        ASSERT_TRUE(mf.converged());
+        cusp::multiply(Af, xf, rf);
+        cusp::blas::axpby(bf, rf, rf, 1.0f, -1.0f);
+        ASSERT_TRUE(cusp::blas::nrm2(rf) <= 1e-3f * cusp::blas::nrm2(bf));
+        // the zero-residual start: no iteration, x untouched
+        cusp::array1d<float, Space> x1(N, 1.0f), b1(N);
+        cusp::multiply(Af, x1, b1);
+        cusp::monitor<float> m0(b1, 20, 0.0f);
+        cusp::krylov::bicgstab(Af, x1, b1, m0);
+        ASSERT_EQUAL(m0.iteration_count(), size_t(0));
+    }
     cusp::hyb_matrix<int, double, Space> Hy(H);
     cusp::precond::diagonal<double, Space> M(A);
     cusp::array1d<double, Space> x2(N, 0.0);
