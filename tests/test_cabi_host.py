@@ -114,6 +114,17 @@ def test_argument_validation_of_the_newer_entry_points(cmi):
     assert L.cmi_csr_interior_rows(-1, None, None, 0, 4, ctypes.byref(a64), ctypes.byref(b64), None) == 1 and L.cmi_csr_interior_rows(4, None, None, 0, 4, ctypes.byref(a64), ctypes.byref(b64), None) == 1
     assert L.cmi_csr_interior_rows(0, None, None, 0, 4, ctypes.byref(a64), ctypes.byref(b64), None) == 0 and (a64.value, b64.value) == (0, 0)
     assert L.cmi_stream_wait_event(None, None) == 1 and b"cmi_stream_wait_event" in L.cmi_last_error()
+    # the rest of BLAS-1 and the fused Jacobi-cg / bicgstab passes (argument checks; nothing touches a GPU)
+    for suf in ("f64", "f32"):
+        assert getattr(L, "cmi_blas_scal_" + suf)(-1, 1, None, None) == 1 and getattr(L, "cmi_blas_scal_" + suf)(0, 1, None, None) == 0
+        assert getattr(L, "cmi_blas_xmy_" + suf)(4, None, None, None, None) == 1 and getattr(L, "cmi_blas_xmy_" + suf)(0, None, None, None, None) == 0
+        assert getattr(L, "cmi_blas_asum_" + suf)(4, None, None, None, None) == 1 and getattr(L, "cmi_blas_amax_" + suf)(4, None, None, None, None, None) == 1
+        assert getattr(L, "cmi_pcg_update_jacobi_" + suf)(4, None, None, None, None, None, None, None, None, None, None) == 1
+        assert getattr(L, "cmi_pcg_direction_x_jacobi_" + suf)(-1, None, None, None, None, None, None, None, None) == 1
+        assert getattr(L, "cmi_bicgstab_s_" + suf)(4, None, None, None, None, None, None, None, None, None) == 1
+        assert getattr(L, "cmi_bicgstab_p_" + suf)(4, None, None, None, None, None, None, None, None, None) == 1
+        assert getattr(L, "cmi_blas_axpy_ratio_" + suf)(4, None, None, None, None, None) == 1
+    assert b"cmi_blas_axpy_ratio" in L.cmi_last_error()
     # the COO container's device sort (argument checks; nothing touches a GPU)
     assert L.cmi_coo_sort_by_row_f64(-1, 4, 0, None, None, None, 0, None) == 1 and L.cmi_coo_sort_by_row_f32(4, 4, 3, None, None, None, 1, None) == 1
     assert b"cmi_coo_sort_by_row" in L.cmi_last_error()
