@@ -320,6 +320,36 @@ __global__ void __launch_bounds__(kBlock) axpy_ratio_kernel(int64_t n, const dou
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = y[i] + a * x[i];
 }
 
+// ---- GMRES's modified Gram-Schmidt as a chain of fused steps with the coefficients in device memory ---------------------------------------------
+// (reference gmres.inl:145-152: per basis vector one dotc -- a host read -- and one axpy).  One step here: w <- w - (*h) v;  *out <- <w, u>  -- the
+// axpy of vector k and the dot with vector k + 1 (u = V[k + 1]) in ONE pass, or the norm's square (u = w) behind the last axpy; h == NULL: the dot alone.
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+axpy_dot_kernel(int64_t n, const double *__restrict__ h, const T *__restrict__ v, T *w, const T *u, double *__restrict__ part, int u_is_w)
+{
+    __shared__ double lds[kBlock];
+    const T a = h ? (T)(*h) : T(0);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        T wi = w[i];
+        if (h) { wi = wi - a * v[i]; w[i] = wi; }
+        acc += (double)wi * (double)(u_is_w ? wi : u[i]);
+    }
+    const double t = block_add(acc, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+template <typename T> int axpy_dot_impl(int64_t n, const double *h, const T *v, T *w, const T *u, double *out, void *workspace, void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_axpy_dot: negative n");
+    if (!out || !workspace || (n > 0 && (!w || !u || (h && !v)))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_axpy_dot: null argument");
+    const int grid = grid_for(n);
+    hipLaunchKernelGGL((axpy_dot_kernel<T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, h, v, w, u, (double *)workspace, (int)(u == w));
+    hipLaunchKernelGGL(sum1_final_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), grid, (const double *)workspace, out, (double *)nullptr);
+    CMI_LAUNCH_CHECK("axpy_dot");
+    return CMI_SUCCESS;
+}
+
 template <typename T>
 int bicg_s_impl(int64_t n, const double *rho, const double *d1, const T *r, const T *AMp, T *s, double *ss, double *ss_mirror, void *workspace, void *stream)
 {
@@ -389,6 +419,10 @@ CMI_API int cmi_bicgstab_p_f64(int64_t n, const double *rho_new_dev, const doubl
 CMI_API int cmi_bicgstab_p_f32(int64_t n, const double *rho_new_dev, const double *rho_dev, const double *d1_dev, const double *d2_dev, const double *d3_dev, const float *r,
                                const float *AMp, float *p, void *stream)
 { return bicg_p_impl<float>(n, rho_new_dev, rho_dev, d1_dev, d2_dev, d3_dev, r, AMp, p, stream); }
+CMI_API int cmi_blas_axpy_dot_f64(int64_t n, const double *h_dev, const double *v, double *w, const double *u, double *out_dev, void *workspace, void *stream)
+{ return axpy_dot_impl<double>(n, h_dev, v, w, u, out_dev, workspace, stream); }
+CMI_API int cmi_blas_axpy_dot_f32(int64_t n, const double *h_dev, const float *v, float *w, const float *u, double *out_dev, void *workspace, void *stream)
+{ return axpy_dot_impl<float>(n, h_dev, v, w, u, out_dev, workspace, stream); }
 CMI_API int cmi_blas_axpy_ratio_f64(int64_t n, const double *num_dev, const double *den_dev, const double *x, double *y, void *stream)
 { return axpy_ratio_impl<double>(n, num_dev, den_dev, x, y, stream); }
 CMI_API int cmi_blas_axpy_ratio_f32(int64_t n, const double *num_dev, const double *den_dev, const float *x, float *y, void *stream)

@@ -34,6 +34,37 @@ template <typename V> void make_rotation(V dx, V dy, V &cs, V &sn) // the rotati
     sn = (dx / std::abs(dx)) * dy / norm;
 }
 
+// Modified Gram-Schmidt of w against V[0..i]: hcol[k] <- <V[k], w> with w <- w - hcol[k] V[k] applied before the next dot; hcol[i + 1] <- ||w||.
+// Any memory space: one dotc + one axpy per vector (gmres.inl:145-152: i + 2 host reads).  device_memory, float / double: a chain of fused steps
+// (cmi_blas_axpy_dot_*: the axpy of vector k and the dot with vector k + 1 in one pass, coefficients in device memory) and ONE read of the column.
+template <typename Vec, typename ValueType, typename Space> void orthogonalize(const std::vector<Vec> &V, int i, Vec &w, ValueType *hcol, Space)
+{
+    for (int k = 0; k <= i; k++) {
+        hcol[k] = cusp::blas::dotc(V[k], w);
+        cusp::blas::axpy(V[k], w, -hcol[k]);
+    }
+    hcol[i + 1] = cusp::blas::nrm2(w);
+}
+inline int axpy_dot_(size_t n, const double *h, const double *v, double *w, const double *u, double *out, void *ws) { return cmi_blas_axpy_dot_f64(n, h, v, w, u, out, ws, nullptr); }
+inline int axpy_dot_(size_t n, const double *h, const float *v, float *w, const float *u, double *out, void *ws) { return cmi_blas_axpy_dot_f32(n, h, v, w, u, out, ws, nullptr); }
+template <typename ValueType> struct mgs_on_device : std::integral_constant<bool, std::is_same<ValueType, double>::value || std::is_same<ValueType, float>::value> {};
+template <typename Vec, typename ValueType>
+typename std::enable_if<mgs_on_device<ValueType>::value>::type orthogonalize(const std::vector<Vec> &V, int i, Vec &w, ValueType *hcol, cusp::device_memory)
+{
+    static thread_local cusp::array1d<double, cusp::device_memory> coeff;
+    if (coeff.size() < static_cast<size_t>(i + 2)) coeff.resize(static_cast<size_t>(i + 2) + 32);
+    cusp::blas::detail::device_workspace &ws = cusp::blas::detail::workspace();
+    const size_t n = w.size();
+    double *c = coeff.data();
+    cusp::detail::check(axpy_dot_(n, nullptr, w.data(), w.data(), V[0].data(), c, ws.ws));                                   // <V[0], w>
+    for (int k = 0; k < i; k++) cusp::detail::check(axpy_dot_(n, c + k, V[k].data(), w.data(), V[k + 1].data(), c + k + 1, ws.ws)); // w -= h_k V[k]; <V[k+1], w>
+    cusp::detail::check(axpy_dot_(n, c + i, V[i].data(), w.data(), w.data(), c + i + 1, ws.ws));                             // w -= h_i V[i]; <w, w>
+    std::vector<double> host(static_cast<size_t>(i + 2));
+    cusp::detail::check(cmi_memcpy_d2h(host.data(), c, host.size() * sizeof(double), nullptr));
+    for (int k = 0; k <= i; k++) hcol[k] = static_cast<ValueType>(host[k]);
+    hcol[i + 1] = static_cast<ValueType>(std::sqrt(host[i + 1]));
+}
+
 } // namespace detail
 
 template <typename LinearOperator, typename VectorType1, typename VectorType2, typename Monitor, typename Preconditioner,
@@ -71,11 +102,7 @@ void gmres(const LinearOperator &A, VectorType1 &x, const VectorType2 &b, const 
             ++monitor;
             if (plain) cusp::multiply(A, V[i], w);        // (the hot path) M = identity_operator: w <- A v_i directly
             else { cusp::multiply(A, V[i], t); detail::apply(M, t, w, 0); } // w <- M A v_i
-            for (int k = 0; k <= i; k++) {                // modified Gram-Schmidt
-                h(k, i) = cusp::blas::dotc(V[k], w);
-                cusp::blas::axpy(V[k], w, -h(k, i));
-            }
-            h(i + 1, i) = cusp::blas::nrm2(w);
+            detail::orthogonalize(V, i, w, &h(0, i), MemorySpace()); // modified Gram-Schmidt: h(0..i, i) and h(i + 1, i) = ||w||
             cusp::blas::scal(w, ValueType(1.0) / h(i + 1, i));
             cusp::blas::copy(w, V[i + 1]);
             for (int k = 0; k < i; k++) detail::apply_rotation(h(k, i), h(k + 1, i), cs[k], sn[k]);

@@ -673,6 +673,11 @@ int cmi_bicgstab_p_f64(int64_t n, const double *rho_new_dev, const double *rho_d
                        const double *AMp, double *p, void *stream);
 int cmi_bicgstab_p_f32(int64_t n, const double *rho_new_dev, const double *rho_dev, const double *d1_dev, const double *d2_dev, const double *d3_dev, const float *r,
                        const float *AMp, float *p, void *stream);
+/* One step of GMRES's modified Gram-Schmidt with the coefficient in device memory (reference gmres.inl:145-152: a dotc -- a host read -- and an
+ * axpy per basis vector): w <- w - (*h_dev) v, then *out_dev <- <w, u> in the same pass (u = the next basis vector, or u = w: the norm's square
+ * behind the last axpy).  h_dev == NULL: the dot alone.  Deterministic two-stage reduction in double.                                        */
+int cmi_blas_axpy_dot_f64(int64_t n, const double *h_dev, const double *v, double *w, const double *u, double *out_dev, void *workspace, void *stream);
+int cmi_blas_axpy_dot_f32(int64_t n, const double *h_dev, const float *v, float *w, const float *u, double *out_dev, void *workspace, void *stream);
 int cmi_blas_axpy_ratio_f64(int64_t n, const double *num_dev, const double *den_dev, const double *x, double *y, void *stream);
 int cmi_blas_axpy_ratio_f32(int64_t n, const double *num_dev, const double *den_dev, const float *x, float *y, void *stream);
 
