@@ -23,6 +23,8 @@
 #include <cusp/krylov/cg.h>
 #include <cusp/krylov/bicgstab.h>
 #include <cusp/krylov/cr.h>
+#include <cusp/krylov/bicg.h>
+#include <cusp/transpose.h>
 #include <cusp/krylov/gmres.h>
 #include <cusp/precond/diagonal.h>
 #include <cusp/ktt/ktt.h>
@@ -1376,6 +1378,73 @@ template <typename Space> void TestGeneralizedMinRes()
     }
 }
 DECLARE_SPACE_UNITTEST(TestGeneralizedMinRes);
+
+// cusp/transpose.h (testing/transpose.cu: every format against the dense transpose) and testing/bicg.cu:50-101 (verbatim protocol: A = A^T there) plus a
+// NON-symmetric system with A^T from cusp::transpose
+template <typename Space> void TestTransposeAndBicg()
+{
+    cusp::array2d<float, cusp::host_memory> D(3, 4, 0.0f);
+    D(0, 0) = 10; D(0, 2) = 20; D(1, 3) = 30; D(2, 0) = 40; D(2, 1) = 50; D(2, 3) = 60;
+    cusp::csr_matrix<int, float, cusp::host_memory> H(D);
+    {
+        cusp::csr_matrix<int, float, Space> A(H), At;
+        cusp::transpose(A, At);
+        ASSERT_EQUAL(At.num_rows, size_t(4)); ASSERT_EQUAL(At.num_cols, size_t(3)); ASSERT_EQUAL(At.num_entries, size_t(6));
+        cusp::array2d<float, cusp::host_memory> T(At);
+        for (size_t i = 0; i < 3; i++) for (size_t j = 0; j < 4; j++) ASSERT_EQUAL(float(T(j, i)), float(D(i, j)));
+        cusp::coo_matrix<int, float, Space> C(A), Ct;
+        cusp::transpose(C, Ct);
+        ASSERT_TRUE(Ct.is_sorted_by_row_and_column());
+        cusp::ell_matrix<int, float, Space> E(A), Et;
+        cusp::transpose(E, Et);
+        cusp::array2d<float, cusp::host_memory> T2(Et);
+        for (size_t i = 0; i < 3; i++) for (size_t j = 0; j < 4; j++) ASSERT_EQUAL(float(T2(j, i)), float(D(i, j)));
+    }
+    {
+        cusp::csr_matrix<int, float, Space> A;
+        cusp::gallery::poisson5pt(A, 10, 10);
+        cusp::array1d<float, Space> x(A.num_rows, 0.0f), b(A.num_rows, 1.0f);
+        cusp::monitor<float> monitor(b, 20, 1e-4);
+        cusp::krylov::bicg(A, A, x, b, monitor);
+        cusp::array1d<float, Space> residual(A.num_rows, 0.0f);
+        cusp::multiply(A, x, residual);
+        cusp::blas::axpby(residual, b, residual, -1.0f, 1.0f);
+        ASSERT_EQUAL(cusp::blas::nrm2(residual) < 1e-4 * cusp::blas::nrm2(b), true);
+        cusp::array1d<float, Space> x1(A.num_rows, 1.0f), b1(A.num_rows);
+        cusp::multiply(A, x1, b1);
+        cusp::monitor<float> m0(b1, 20, 0.0f);
+        cusp::krylov::bicg(A, A, x1, b1, m0);
+        ASSERT_EQUAL(m0.converged(), true); ASSERT_EQUAL(m0.iteration_count(), size_t(0));
+    }
+    {
+        cusp::csr_matrix<int, double, cusp::host_memory> G;
+        cusp::gallery::poisson5pt(G, 25, 16);
+        const size_t N = G.num_rows;
+        for (size_t i = 0; i < N; i++)
+            for (int jj = G.row_offsets[i]; jj < G.row_offsets[i + 1]; jj++) {
+                const size_t j = G.column_indices[jj];
+                if (j + 1 == i) G.values[jj] -= 0.6;
+                if (j == i) G.values[jj] += 0.6;
+            }
+        cusp::csr_matrix<int, double, Space> A(G), At;
+        cusp::transpose(A, At);
+        cusp::array1d<double, Space> b(N, 1.0), x(N, 0.0), r(N);
+        cusp::monitor<double> monitor(b, 1000, 1e-9);
+        cusp::krylov::bicg(A, At, x, b, monitor);
+        ASSERT_TRUE(monitor.converged());
+        cusp::multiply(A, x, r);
+        cusp::blas::axpby(b, r, r, 1.0, -1.0);
+        ASSERT_TRUE(cusp::blas::nrm2(r) <= 1e-8 * cusp::blas::nrm2(b));
+        cusp::precond::diagonal<double, Space> M(A), Mt(At);
+        cusp::array1d<double, Space> x2(N, 0.0);
+        cusp::monitor<double> monitor2(b, 1000, 1e-9);
+        cusp::krylov::bicg(A, At, x2, b, monitor2, M, Mt);
+        ASSERT_TRUE(monitor2.converged());
+        cusp::blas::axpy(x, x2, -1.0);
+        ASSERT_TRUE(cusp::blas::nrmmax(x2) <= 1e-6);
+    }
+}
+DECLARE_SPACE_UNITTEST(TestTransposeAndBicg);
 
 // ELLR (the fork's container, testing/ktt.cu:26-43 runs its kernels on dia / ell / ellr)
 template <typename Space> void TestEllrMatrix()
