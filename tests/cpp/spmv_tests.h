@@ -9,6 +9,7 @@
 //   testing/multiply.cu:792-858          user execution policy reaches a user overload
 #pragma once
 #include <cstdlib>
+#include <map>
 #include <cusp/array1d.h>
 #include <cusp/array2d.h>
 #include <cusp/coo_matrix.h>
@@ -1445,6 +1446,80 @@ template <typename Space> void TestTransposeAndBicg()
     }
 }
 DECLARE_SPACE_UNITTEST(TestTransposeAndBicg);
+
+// every solver on the same seeded, irregular, strictly diagonally dominant systems (rows of 2..12 scattered off-diagonal entries): the non-symmetric one
+// through bicgstab / gmres / bicg, its symmetric part (SPD) through cg / cr / Jacobi-cg as well -- in four storage formats -- must all find the solution
+// a host cg / bicgstab finds, to the tolerance asked for
+template <typename Space> void TestSolversAgreeOnRandomSystems()
+{
+    const size_t N = 3000;
+    unsigned s = 2024u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) & 0xffffu; };
+    std::vector<std::vector<std::pair<int, double>>> rows(N);
+    for (size_t i = 0; i < N; i++) {
+        const int k = 2 + int(rnd() % 11);
+        for (int e = 0; e < k; e++) {
+            const int j = int(rnd() % N);
+            if (size_t(j) != i) rows[i].push_back({j, double(int(rnd() % 2001) - 1000) / 1000.0});
+        }
+    }
+    auto build = [&](bool symmetric) {
+        std::vector<std::map<int, double>> m(N);
+        for (size_t i = 0; i < N; i++)
+            for (auto &e : rows[i]) {
+                if (symmetric) { m[i][e.first] += 0.5 * e.second; m[e.first][int(i)] += 0.5 * e.second; }
+                else m[i][e.first] += e.second;
+            }
+        size_t nnz = 0;
+        for (size_t i = 0; i < N; i++) { double a = 0; for (auto &e : m[i]) a += std::fabs(e.second); m[i][int(i)] = a + 1.0; nnz += m[i].size(); }
+        cusp::csr_matrix<int, double, cusp::host_memory> H(N, N, nnz);
+        size_t p = 0;
+        for (size_t i = 0; i < N; i++) { H.row_offsets[i] = int(p); for (auto &e : m[i]) { H.column_indices[p] = e.first; H.values[p] = e.second; p++; } }
+        H.row_offsets[N] = int(p);
+        return H;
+    };
+    cusp::array1d<double, cusp::host_memory> hb(N);
+    for (size_t i = 0; i < N; i++) hb[i] = double(int(rnd() % 201) - 100) / 50.0;
+    const double tol = 1e-10;
+    auto close_to = [&](const cusp::array1d<double, Space> &x, const cusp::array1d<double, cusp::host_memory> &ref) {
+        cusp::array1d<double, cusp::host_memory> h(x);
+        double worst = 0, scale = 0;
+        for (size_t i = 0; i < N; i++) { worst = std::max(worst, std::fabs(h[i] - ref[i])); scale = std::max(scale, std::fabs(ref[i])); }
+        return worst <= 1e-7 * scale;
+    };
+    { // SPD
+        const auto H = build(true);
+        cusp::array1d<double, cusp::host_memory> ref(N, 0.0);
+        { cusp::monitor<double> m(hb, 5000, tol); cusp::krylov::cg(H, ref, hb, m); ASSERT_TRUE(m.converged()); }
+        cusp::array1d<double, Space> b(hb);
+        cusp::csr_matrix<int, double, Space> A(H);
+        cusp::ell_matrix<int, double, Space> E(H);
+        cusp::hyb_matrix<int, double, Space> Y(H);
+        cusp::coo_matrix<int, double, Space> C(H);
+        cusp::precond::diagonal<double, Space> M(A);
+        { cusp::array1d<double, Space> x(N, 0.0); cusp::monitor<double> m(b, 5000, tol); cusp::krylov::cg(A, x, b, m); ASSERT_TRUE(m.converged() && close_to(x, ref)); }
+        { cusp::array1d<double, Space> x(N, 0.0); cusp::monitor<double> m(b, 5000, tol); cusp::krylov::cg(E, x, b, m, M); ASSERT_TRUE(m.converged() && close_to(x, ref)); }
+        { cusp::array1d<double, Space> x(N, 0.0); cusp::monitor<double> m(b, 5000, tol); cusp::krylov::cr(Y, x, b, m); ASSERT_TRUE(m.converged() && close_to(x, ref)); }
+        { cusp::array1d<double, Space> x(N, 0.0); cusp::monitor<double> m(b, 5000, tol); cusp::krylov::bicgstab(C, x, b, m); ASSERT_TRUE(m.converged() && close_to(x, ref)); }
+        { cusp::array1d<double, Space> x(N, 0.0); cusp::monitor<double> m(b, 5000, tol); cusp::krylov::gmres(A, x, b, 30, m); ASSERT_TRUE(m.converged() && close_to(x, ref)); }
+    }
+    { // non-symmetric
+        const auto H = build(false);
+        cusp::array1d<double, cusp::host_memory> ref(N, 0.0);
+        { cusp::monitor<double> m(hb, 5000, tol); cusp::krylov::bicgstab(H, ref, hb, m); ASSERT_TRUE(m.converged()); }
+        cusp::array1d<double, Space> b(hb);
+        cusp::csr_matrix<int, double, Space> A(H), At;
+        cusp::transpose(A, At);
+        cusp::ell_matrix<int, double, Space> E(H);
+        cusp::hyb_matrix<int, double, Space> Y(H);
+        cusp::precond::diagonal<double, Space> M(A);
+        { cusp::array1d<double, Space> x(N, 0.0); cusp::monitor<double> m(b, 5000, tol); cusp::krylov::bicgstab(A, x, b, m); ASSERT_TRUE(m.converged() && close_to(x, ref)); }
+        { cusp::array1d<double, Space> x(N, 0.0); cusp::monitor<double> m(b, 5000, tol); cusp::krylov::bicgstab(E, x, b, m, M); ASSERT_TRUE(m.converged() && close_to(x, ref)); }
+        { cusp::array1d<double, Space> x(N, 0.0); cusp::monitor<double> m(b, 5000, tol); cusp::krylov::gmres(Y, x, b, 25, m, M); ASSERT_TRUE(m.converged() && close_to(x, ref)); }
+        { cusp::array1d<double, Space> x(N, 0.0); cusp::monitor<double> m(b, 5000, tol); cusp::krylov::bicg(A, At, x, b, m); ASSERT_TRUE(m.converged() && close_to(x, ref)); }
+    }
+}
+DECLARE_SPACE_UNITTEST(TestSolversAgreeOnRandomSystems);
 
 // ELLR (the fork's container, testing/ktt.cu:26-43 runs its kernels on dia / ell / ellr)
 template <typename Space> void TestEllrMatrix()
