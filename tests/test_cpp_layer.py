@@ -76,8 +76,10 @@ def test_reference_style_benchmark_driver(cmi, tmp_path):
 
 # ---- the reference's own example programs, compiled unchanged against this layer (oracle/_ref/examples) ----
 EXAMPLES = os.path.join(ROOT, "oracle", "_ref", "examples")
-HOST_EXAMPLES = ["Algorithms_multiply", "MatrixFormats_coo", "MatrixFormats_csr", "MatrixFormats_dia", "MatrixFormats_ell", "MatrixFormats_hyb"]
-DEVICE_EXAMPLES = ["Solvers_cg", "Gallery_poisson", "Monitors_monitor", "Monitors_verbose_monitor", "InputOutput_matrix_market"]
+HOST_EXAMPLES = ["Algorithms_multiply", "MatrixFormats_coo", "MatrixFormats_csr", "MatrixFormats_dia", "MatrixFormats_ell", "MatrixFormats_hyb",
+                 "Algorithms_transpose", "Algorithms_blas"]
+DEVICE_EXAMPLES = ["Solvers_cg", "Gallery_poisson", "Monitors_monitor", "Monitors_verbose_monitor", "InputOutput_matrix_market",
+                   "Solvers_bicgstab", "Solvers_cr", "Preconditioners_diagonal"]
 
 
 def _examples_ready():
@@ -100,6 +102,13 @@ def test_reference_examples_build_unchanged_and_host_ones_run(cmi):
         if e == "Algorithms_multiply":  # dense 2x2 times [10, 20]: y = [50, 140] (examples/Algorithms/multiply.cu)
             assert r.stdout.split() == ["array1d", "<2>", "(50)", "(140)"], r.stdout
             continue
+        if e == "Algorithms_transpose":  # a 2 x 3 array2d and its transpose (examples/Algorithms/transpose.cu)
+            assert r.stdout.split() == ["array2d", "<2,", "3>", "(10)", "(20)", "(30)", "(40)", "(50)", "(60)",
+                                        "array2d", "<3,", "2>", "(10)", "(40)", "(20)", "(50)", "(30)", "(60)"], r.stdout
+            continue
+        if e == "Algorithms_blas":  # examples/Algorithms/blas.cu: axpy, xmy results and four norms of z
+            assert "|z|_1 = 15" in r.stdout and "max(|z_i|) = 12" in r.stdout and r.stdout.count("array1d <2>") == 2, r.stdout
+            continue
         assert first == ("sparse matrix <3, 4> with 8 entries" if e.endswith("hyb") else "sparse matrix <4, 3> with 6 entries"), (e, first)
     coo = subprocess.run([os.path.join(EXAMPLES, "MatrixFormats_coo")], capture_output=True, text=True).stdout.splitlines()
     assert coo[1].split() == ["0", "0", "(10)"] and coo[6].split() == ["3", "2", "(60)"]
@@ -112,11 +121,16 @@ def test_reference_examples_run_on_device(cmi, tmp_path):
     if not all(os.path.exists(os.path.join(EXAMPLES, e)) for e in DEVICE_EXAMPLES):
         pytest.skip("no prebuilt oracle/_ref/examples (they are built where /root/reference exists)")
     outs = {}
+    import shutil
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "ref_data", "examples", "Preconditioners_A.mtx"), os.path.join(str(tmp_path), "A.mtx"))  # (the example reads ./A.mtx)
     for e in DEVICE_EXAMPLES:
         r = subprocess.run([os.path.join(EXAMPLES, e)], capture_output=True, text=True, timeout=120, cwd=tmp_path)
         assert r.returncode == 0, e + r.stdout[-500:] + r.stderr[-500:]
         outs[e] = r.stdout
     assert "Successfully converged after" in outs["Solvers_cg"]
+    assert "Successfully converged after" in outs["Solvers_bicgstab"] and "Successfully converged after" in outs["Solvers_cr"]
+    # examples/Preconditioners/diagonal.cu: the same 25 x 25 system without and with M = D^-1; both converge
+    assert outs["Preconditioners_diagonal"].count("Successfully converged after") == 2, outs["Preconditioners_diagonal"][-600:]
     assert "sparse matrix <" in outs["Gallery_poisson"] and "sparse matrix <" in outs["InputOutput_matrix_market"]
     assert "onverged" in outs["Monitors_monitor"] or "residual" in outs["Monitors_monitor"].lower()
 
