@@ -320,6 +320,75 @@ __global__ void __launch_bounds__(kBlock) axpy_ratio_kernel(int64_t n, const dou
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = y[i] + a * x[i];
 }
 
+__global__ void sum1_final_kernel(int npartial, const double *__restrict__ part, double *__restrict__ out, double *__restrict__ mirror);
+
+// ---- conjugate residuals (identity preconditioner): the two vector passes of an iteration with the scalars in DEVICE memory ----------------
+// (reference cusp/krylov/detail/cr.inl:83-124: dotc, axpy, axpy, [copy,] dotc, axpby, axpby + the monitor's norm = 7 passes and 3 host reads around
+// its multiply).  rz = <r, A r>, yy = <A p, A p> are device doubles; the multiply carries <A r, r> (cmi_spmv_*_dot_*):
+//   xr-pass:  alpha = rz / yy;  x <- x + alpha p;  r <- r - alpha y   (y = A p);  *rr <- <r, r>  (+ host mirror)
+//             -- with update_r == 0 only x moves (every 8th iteration the caller rebuilds r = b - A x itself, cr.inl:96-107)
+//   py-pass:  beta = rz_new / rz;  p <- r + beta p;  y <- A r + beta y;  *yy_new <- <y, y>
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+cr_xr_kernel(int64_t n, const double *__restrict__ rz, const double *__restrict__ yy, const T *__restrict__ p, const T *__restrict__ y, T *__restrict__ x, T *__restrict__ r,
+             int update_r, double *__restrict__ part)
+{
+    __shared__ double lds[kBlock];
+    const T alpha = (T)(*rz / *yy);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        x[i] = x[i] + alpha * p[i];
+        if (update_r) {
+            const T ri = r[i] - alpha * y[i];
+            r[i] = ri;
+            acc += (double)ri * (double)ri;
+        }
+    }
+    const double t = block_add(acc, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+cr_py_kernel(int64_t n, const double *__restrict__ rz_new, const double *__restrict__ rz, const T *__restrict__ r, const T *__restrict__ Ar, T *__restrict__ p, T *__restrict__ y,
+             double *__restrict__ part)
+{
+    __shared__ double lds[kBlock];
+    const T beta = (T)(*rz_new / *rz);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        p[i] = r[i] + beta * p[i];
+        const T yi = Ar[i] + beta * y[i];
+        y[i] = yi;
+        acc += (double)yi * (double)yi;
+    }
+    const double t = block_add(acc, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+template <typename T>
+int cr_xr_impl(int64_t n, const double *rz, const double *yy, const T *p, const T *y, T *x, T *r, int update_r, double *rr, double *rr_mirror, void *workspace, void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cr_xr: negative n");
+    if (!rz || !yy || !workspace || (update_r && !rr) || (n > 0 && (!p || !y || !x || !r))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cr_xr: null argument");
+    const int grid = grid_for(n);
+    hipLaunchKernelGGL((cr_xr_kernel<T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, rz, yy, p, y, x, r, update_r, (double *)workspace);
+    if (update_r) hipLaunchKernelGGL(sum1_final_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), grid, (const double *)workspace, rr, rr_mirror);
+    CMI_LAUNCH_CHECK("cr_xr");
+    return CMI_SUCCESS;
+}
+template <typename T>
+int cr_py_impl(int64_t n, const double *rz_new, const double *rz, const T *r, const T *Ar, T *p, T *y, double *yy_new, void *workspace, void *stream)
+{
+    if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cr_py: negative n");
+    if (!rz_new || !rz || !yy_new || !workspace || (n > 0 && (!r || !Ar || !p || !y))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cr_py: null argument");
+    const int grid = grid_for(n);
+    hipLaunchKernelGGL((cr_py_kernel<T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, rz_new, rz, r, Ar, p, y, (double *)workspace);
+    hipLaunchKernelGGL(sum1_final_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), grid, (const double *)workspace, yy_new, (double *)nullptr);
+    CMI_LAUNCH_CHECK("cr_py");
+    return CMI_SUCCESS;
+}
+
 // ---- GMRES's modified Gram-Schmidt as a chain of fused steps with the coefficients in device memory ---------------------------------------------
 // (reference gmres.inl:145-152: per basis vector one dotc -- a host read -- and one axpy).  One step here: w <- w - (*h) v;  *out <- <w, u>  -- the
 // axpy of vector k and the dot with vector k + 1 (u = V[k + 1]) in ONE pass, or the norm's square (u = w) behind the last axpy; h == NULL: the dot alone.
@@ -419,6 +488,18 @@ CMI_API int cmi_bicgstab_p_f64(int64_t n, const double *rho_new_dev, const doubl
 CMI_API int cmi_bicgstab_p_f32(int64_t n, const double *rho_new_dev, const double *rho_dev, const double *d1_dev, const double *d2_dev, const double *d3_dev, const float *r,
                                const float *AMp, float *p, void *stream)
 { return bicg_p_impl<float>(n, rho_new_dev, rho_dev, d1_dev, d2_dev, d3_dev, r, AMp, p, stream); }
+CMI_API int cmi_cr_xr_f64(int64_t n, const double *rz_dev, const double *yy_dev, const double *p, const double *y, double *x, double *r, int update_r, double *rr_dev,
+                          double *rr_host_mirror, void *workspace, void *stream)
+{ return cr_xr_impl<double>(n, rz_dev, yy_dev, p, y, x, r, update_r, rr_dev, rr_host_mirror, workspace, stream); }
+CMI_API int cmi_cr_xr_f32(int64_t n, const double *rz_dev, const double *yy_dev, const float *p, const float *y, float *x, float *r, int update_r, double *rr_dev,
+                          double *rr_host_mirror, void *workspace, void *stream)
+{ return cr_xr_impl<float>(n, rz_dev, yy_dev, p, y, x, r, update_r, rr_dev, rr_host_mirror, workspace, stream); }
+CMI_API int cmi_cr_py_f64(int64_t n, const double *rz_new_dev, const double *rz_dev, const double *r, const double *Ar, double *p, double *y, double *yy_new_dev, void *workspace,
+                          void *stream)
+{ return cr_py_impl<double>(n, rz_new_dev, rz_dev, r, Ar, p, y, yy_new_dev, workspace, stream); }
+CMI_API int cmi_cr_py_f32(int64_t n, const double *rz_new_dev, const double *rz_dev, const float *r, const float *Ar, float *p, float *y, double *yy_new_dev, void *workspace,
+                          void *stream)
+{ return cr_py_impl<float>(n, rz_new_dev, rz_dev, r, Ar, p, y, yy_new_dev, workspace, stream); }
 CMI_API int cmi_blas_axpy_dot_f64(int64_t n, const double *h_dev, const double *v, double *w, const double *u, double *out_dev, void *workspace, void *stream)
 { return axpy_dot_impl<double>(n, h_dev, v, w, u, out_dev, workspace, stream); }
 CMI_API int cmi_blas_axpy_dot_f32(int64_t n, const double *h_dev, const float *v, float *w, const float *u, double *out_dev, void *workspace, void *stream)

@@ -673,6 +673,18 @@ int cmi_bicgstab_p_f64(int64_t n, const double *rho_new_dev, const double *rho_d
                        const double *AMp, double *p, void *stream);
 int cmi_bicgstab_p_f32(int64_t n, const double *rho_new_dev, const double *rho_dev, const double *d1_dev, const double *d2_dev, const double *d3_dev, const float *r,
                        const float *AMp, float *p, void *stream);
+/* Conjugate residuals' two vector passes with the scalars in device memory (reference cusp/krylov/detail/cr.inl:83-124, identity preconditioner:
+ * 7 passes and 3 host reads around its multiply).  rz = <r, A r>, yy = <A p, A p> are device doubles:
+ *   xr:  alpha = rz / yy;  x <- x + alpha p;  update_r != 0: r <- r - alpha y (y = A p) and *rr_dev <- <r, r> (+ host mirror)
+ *   py:  beta = rz_new / rz;  p <- r + beta p;  y <- A r + beta y;  *yy_new_dev <- <y, y>                                                   */
+int cmi_cr_xr_f64(int64_t n, const double *rz_dev, const double *yy_dev, const double *p, const double *y, double *x, double *r, int update_r, double *rr_dev,
+                  double *rr_host_mirror, void *workspace, void *stream);
+int cmi_cr_xr_f32(int64_t n, const double *rz_dev, const double *yy_dev, const float *p, const float *y, float *x, float *r, int update_r, double *rr_dev,
+                  double *rr_host_mirror, void *workspace, void *stream);
+int cmi_cr_py_f64(int64_t n, const double *rz_new_dev, const double *rz_dev, const double *r, const double *Ar, double *p, double *y, double *yy_new_dev, void *workspace,
+                  void *stream);
+int cmi_cr_py_f32(int64_t n, const double *rz_new_dev, const double *rz_dev, const float *r, const float *Ar, float *p, float *y, double *yy_new_dev, void *workspace,
+                  void *stream);
 /* One step of GMRES's modified Gram-Schmidt with the coefficient in device memory (reference gmres.inl:145-152: a dotc -- a host read -- and an
  * axpy per basis vector): w <- w - (*h_dev) v, then *out_dev <- <w, u> in the same pass (u = the next basis vector, or u = w: the norm's square
  * behind the last axpy).  h_dev == NULL: the dot alone.  Deterministic two-stage reduction in double.                                        */

@@ -1277,6 +1277,40 @@ template <typename Space> void TestConjugateResidual()
 }
 DECLARE_SPACE_UNITTEST(TestConjugateResidual);
 
+// cr on device_memory runs a FUSED iteration (cmi_cr_*); $CMI_CR_FUSED=0 forces the operation-by-operation path: the same method -- incl. the residual
+// rebuilt every 8th iteration -- so the same iteration count to within rounding and the same solution (double and float)
+template <typename Space> void TestConjugateResidualFusedAgainstGeneric()
+{
+    cusp::csr_matrix<int, double, Space> A;
+    cusp::gallery::poisson5pt(A, 60, 45);
+    const size_t N = A.num_rows;
+    cusp::array1d<double, Space> b(N, 1.0), x1(N, 0.0), x2(N, 0.0), r(N);
+    cusp::monitor<double> m1(b, 2000, 1e-10), m2(b, 2000, 1e-10);
+    cusp::krylov::cr(A, x1, b, m1);
+    setenv("CMI_CR_FUSED", "0", 1);
+    cusp::krylov::cr(A, x2, b, m2);
+    unsetenv("CMI_CR_FUSED");
+    ASSERT_TRUE(m1.converged() && m2.converged());
+    ASSERT_TRUE(m1.iteration_count() > 20); // (the every-8th-iteration branch was taken several times)
+    const long long d = (long long)m1.iteration_count() - (long long)m2.iteration_count();
+    ASSERT_TRUE(d >= -3 && d <= 3);
+    cusp::multiply(A, x1, r);
+    cusp::blas::axpby(b, r, r, 1.0, -1.0);
+    ASSERT_TRUE(cusp::blas::nrm2(r) <= 1e-9 * cusp::blas::nrm2(b));
+    cusp::blas::axpy(x1, x2, -1.0);
+    ASSERT_TRUE(cusp::blas::nrmmax(x2) <= 1e-7 * cusp::blas::nrmmax(x1));
+    cusp::ell_matrix<int, float, Space> Ef;
+    cusp::gallery::poisson5pt(Ef, 30, 20);
+    cusp::array1d<float, Space> bf(Ef.num_rows, 1.0f), xf(Ef.num_rows, 0.0f), rf(Ef.num_rows);
+    cusp::monitor<float> mf(bf, 500, 1e-5);
+    cusp::krylov::cr(Ef, xf, bf, mf);
+    ASSERT_TRUE(mf.converged());
+    cusp::multiply(Ef, xf, rf);
+    cusp::blas::axpby(bf, rf, rf, 1.0f, -1.0f);
+    ASSERT_TRUE(cusp::blas::nrm2(rf) <= 1e-4f * cusp::blas::nrm2(bf));
+}
+DECLARE_SPACE_UNITTEST(TestConjugateResidualFusedAgainstGeneric);
+
 // bicgstab (no test file in the reference's testing/; examples/Solvers/bicgstab.cu protocol): a NON-symmetric matrix -- 5-point diffusion plus an
 // upwind convection term -- with and without the Jacobi preconditioner; the residual is checked from scratch; every format multiplies the same way
 template <typename Space> void TestBicgstab()

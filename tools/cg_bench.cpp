@@ -100,7 +100,10 @@ static int run_solvers(size_t grid, size_t iters)
     setenv("CMI_CG_FUSED_JACOBI", "0", 1);
     time_solver("cg + precond::diagonal (generic)", iters, 1, [&](size_t k) { Vector x(N, 0.0); cusp::monitor<double> m(b, k, 0.0, 0.0); cusp::krylov::cg(A, x, b, m, M); });
     unsetenv("CMI_CG_FUSED_JACOBI");
-    time_solver("cr", iters, 2, [&](size_t k) { Vector x(N, 0.0); cusp::monitor<double> m(b, k, 0.0, 0.0); cusp::krylov::cr(A, x, b, m); });
+    time_solver("cr (fused)", iters, 1, [&](size_t k) { Vector x(N, 0.0); cusp::monitor<double> m(b, k, 0.0, 0.0); cusp::krylov::cr(A, x, b, m); });
+    setenv("CMI_CR_FUSED", "0", 1);
+    time_solver("cr (generic)", iters, 1, [&](size_t k) { Vector x(N, 0.0); cusp::monitor<double> m(b, k, 0.0, 0.0); cusp::krylov::cr(A, x, b, m); });
+    unsetenv("CMI_CR_FUSED");
     time_solver("bicgstab (fused)", iters, 2, [&](size_t k) { Vector x(N, 0.0); cusp::monitor<double> m(b, k, 0.0, 0.0); cusp::krylov::bicgstab(A, x, b, m); });
     setenv("CMI_BICGSTAB_FUSED", "0", 1);
     time_solver("bicgstab (generic)", iters, 2, [&](size_t k) { Vector x(N, 0.0); cusp::monitor<double> m(b, k, 0.0, 0.0); cusp::krylov::bicgstab(A, x, b, m); });
