@@ -124,7 +124,10 @@ def test_argument_validation_of_the_newer_entry_points(cmi):
         assert getattr(L, "cmi_bicgstab_s_" + suf)(4, None, None, None, None, None, None, None, None, None) == 1
         assert getattr(L, "cmi_bicgstab_p_" + suf)(4, None, None, None, None, None, None, None, None, None) == 1
         assert getattr(L, "cmi_blas_axpy_ratio_" + suf)(4, None, None, None, None, None) == 1
-    assert b"cmi_blas_axpy_ratio" in L.cmi_last_error()
+        assert getattr(L, "cmi_cr_xr_" + suf)(4, None, None, None, None, None, None, 1, None, None, None, None) == 1
+        assert getattr(L, "cmi_cr_py_" + suf)(-1, None, None, None, None, None, None, None, None, None) == 1
+        assert getattr(L, "cmi_blas_axpy_dot_" + suf)(4, None, None, None, None, None, None, None) == 1
+    assert b"cmi_blas_axpy_dot" in L.cmi_last_error()
     # the COO container's device sort (argument checks; nothing touches a GPU)
     assert L.cmi_coo_sort_by_row_f64(-1, 4, 0, None, None, None, 0, None) == 1 and L.cmi_coo_sort_by_row_f32(4, 4, 3, None, None, None, 1, None) == 1
     assert b"cmi_coo_sort_by_row" in L.cmi_last_error()
