@@ -336,7 +336,7 @@ def test_reference_data_files_all_formats(cmi, torch_cuda, orc):
     from conftest import coo_to_csr, read_mtx, reference_data_files
     torch = torch_cuda
     files = reference_data_files()
-    assert len(files) == 19
+    assert len(files) == 20  # testing/data (19) + examples/Preconditioners/A.mtx
     for path in files:
         rows, cols, I, J, V = read_mtx(path)
         for dtype in (np.float64, np.float32):
