@@ -178,6 +178,12 @@ template <typename X, typename Y, typename L> void copy(const X &x, Y &y, distri
 { auto xl = x.local(); auto yl = y.local(); copy(xl, yl, L()); }
 template <typename X, typename S, typename L> void fill(X &x, S v, distributed_memory<L>)
 { auto xl = x.local(); fill(xl, v, L()); }
+template <typename X, typename S, typename L> void scal(X &x, S a, distributed_memory<L>)
+{ auto xl = x.local(); scal(xl, a, L()); }
+template <typename X, typename Y, typename Z, typename L> void xmy(const X &x, const Y &y, Z &z, distributed_memory<L>)
+{ auto xl = x.local(); auto yl = y.local(); auto zl = z.local(); xmy(xl, yl, zl, L()); }
+template <typename X, typename Y, typename Z, typename O, typename S, typename L> void axpbypcz(const X &x, const Y &y, const Z &z, O &out, S a, S b, S c, distributed_memory<L>)
+{ auto xl = x.local(); auto yl = y.local(); auto zl = z.local(); auto ol = out.local(); axpbypcz(xl, yl, zl, ol, a, b, c, L()); }
 inline int c_dotd(int64_t n, const double *x, const double *y, double *r, void *ws) { return cmi_blas_dot_f64(n, x, y, r, ws, nullptr); }
 inline int c_dotd(int64_t n, const float *x, const float *y, double *r, void *ws) { return cmi_blas_dotd_f32(n, x, y, r, ws, nullptr); }
 template <typename X, typename Y> double dot_all(const X &x, const Y &y, host_memory)

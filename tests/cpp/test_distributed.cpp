@@ -10,6 +10,7 @@
 //           and its CG run for real: IPC mappings between processes, cmi_copy_ranges pulls ordered by the algorithm's reductions).
 #include <cusp/csr_matrix.h>
 #include <cusp/distributed.h>
+#include <cusp/krylov/bicgstab.h>
 #include <cusp/gallery/poisson.h>
 
 #include <cmath>
@@ -138,6 +139,36 @@ template <typename Space> static void run(cd::communicator &comm, const char *sp
         CHECK(err <= 1e-8, "%s: solution differs by %.3e", v.name, err);
         if (rank == 0) std::printf("ok  %-34s [%s, world %d]  mode %s, %lld values per exchange (all-gather %lld), CG %zu iterations\n", v.name, space_name, world,
                                    A.mode_name(), (long long)A.exchange_values(), (long long)A.allgather_values(), mon.iteration_count());
+    }
+    // bicgstab on a sharded NON-symmetric operator (cusp/distributed/bicgstab.h): the banded matrix with its strictly-upper entries scaled by 0.4 (still
+    // strictly diagonally dominant); the single-process host solve is the reference: same iteration count to within rounding, same solution
+    {
+        const size_t n = 3000 + 13 * (size_t)world;
+        host_csr G = test_matrix(n, 21u, true);
+        for (size_t i = 0; i < n; i++)
+            for (int jj = G.row_offsets[i]; jj < G.row_offsets[i + 1]; jj++)
+                if ((size_t)G.column_indices[jj] > i) G.values[jj] *= 0.4;
+        const std::vector<int64_t> cuts = cd::partition_by_entries(G.row_offsets, world);
+        dist_csr A(comm);
+        A.scatter(G, cuts, cd::exchange_mode::automatic);
+        cusp::array1d<double, cusp::host_memory> bg(n), sg(n, 0.0);
+        for (size_t i = 0; i < n; i++) bg[i] = 1.0 + double(i % 5);
+        cusp::monitor<double> mon_ref(bg, 300, 1e-10);
+        cusp::krylov::bicgstab(G, sg, bg, mon_ref);
+        const size_t lo = A.row_begin(), hi = A.row_end();
+        dist_vec bl = A.make_vector(), sol = A.make_vector(0.0);
+        { cusp::array1d<double, cusp::host_memory> t(bg.begin() + lo, bg.begin() + hi); auto bv = bl.local(); cusp::copy_array(t, bv); }
+        cusp::monitor<double> mon(bl, 300, 1e-10);
+        cusp::krylov::bicgstab(A, sol, bl, mon);
+        CHECK(mon.converged() && mon_ref.converged(), "sharded bicgstab did not converge (%zu / %zu iterations)", mon.iteration_count(), mon_ref.iteration_count());
+        const long long d = (long long)mon.iteration_count() - (long long)mon_ref.iteration_count();
+        CHECK(d >= -2 && d <= 2, "sharded bicgstab: %zu iterations, single-process %zu", mon.iteration_count(), mon_ref.iteration_count());
+        cusp::array1d<double, cusp::host_memory> sl(sol.local());
+        double err = 0;
+        for (size_t i = 0; i < sl.size(); i++) err = std::max(err, std::fabs(sl[i] - sg[lo + i]));
+        CHECK(err <= 1e-8, "sharded bicgstab: solution differs by %.3e", err);
+        if (rank == 0) std::printf("ok  sharded bicgstab, non-symmetric banded [%s, world %d]  mode %s, %zu iterations (single process %zu)\n", space_name, world, A.mode_name(),
+                                   mon.iteration_count(), mon_ref.iteration_count());
     }
     // the gallery builder: every rank its own rows of poisson5pt(m, n); against the host gallery
     {
