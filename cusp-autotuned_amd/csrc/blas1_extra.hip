@@ -322,6 +322,31 @@ __global__ void __launch_bounds__(kBlock) axpy_ratio_kernel(int64_t n, const dou
 
 __global__ void sum1_final_kernel(int npartial, const double *__restrict__ part, double *__restrict__ out, double *__restrict__ mirror);
 
+// ---- the main diagonal of a CSR matrix (the Jacobi preconditioner's set-up on the device) ---------------------------------------------------------
+// diag[i] <- the sum of row i's entries whose column is i (0 when none is stored), or its reciprocal (reference cusp/format_utils.h:184 extract_diagonal +
+// precond/detail/diagonal.inl: a Thrust transform with reciprocal_functor).  Lane per row: set-up work, one pass over the column indices.
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+csr_diagonal_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ Aj, const T *__restrict__ Ax, T *__restrict__ diag, int reciprocal)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < num_rows; r += stride) {
+        T d = T(0);
+        for (int jj = Ap[r]; jj < Ap[r + 1]; jj++)
+            if ((int64_t)Aj[jj] == r) d += Ax[jj];
+        diag[r] = reciprocal ? T(1) / d : d;
+    }
+}
+template <typename T> int csr_diagonal_impl(int64_t num_rows, const int *Ap, const int *Aj, const T *Ax, T *diag, int reciprocal, void *stream)
+{
+    if (num_rows < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_diagonal: negative size");
+    if (num_rows == 0) return CMI_SUCCESS;
+    if (!Ap || !diag) return fail(CMI_ERROR_INVALID_VALUE, "cmi_csr_diagonal: null array");
+    hipLaunchKernelGGL((csr_diagonal_kernel<T>), dim3(grid_for(num_rows) * 4), dim3(kBlock), 0, as_stream(stream), num_rows, Ap, Aj, Ax, diag, reciprocal);
+    CMI_LAUNCH_CHECK("csr_diagonal");
+    return CMI_SUCCESS;
+}
+
 // ---- conjugate residuals (identity preconditioner): the two vector passes of an iteration with the scalars in DEVICE memory ----------------
 // (reference cusp/krylov/detail/cr.inl:83-124: dotc, axpy, axpy, [copy,] dotc, axpby, axpby + the monitor's norm = 7 passes and 3 host reads around
 // its multiply).  rz = <r, A r>, yy = <A p, A p> are device doubles; the multiply carries <A r, r> (cmi_spmv_*_dot_*):
@@ -488,6 +513,10 @@ CMI_API int cmi_bicgstab_p_f64(int64_t n, const double *rho_new_dev, const doubl
 CMI_API int cmi_bicgstab_p_f32(int64_t n, const double *rho_new_dev, const double *rho_dev, const double *d1_dev, const double *d2_dev, const double *d3_dev, const float *r,
                                const float *AMp, float *p, void *stream)
 { return bicg_p_impl<float>(n, rho_new_dev, rho_dev, d1_dev, d2_dev, d3_dev, r, AMp, p, stream); }
+CMI_API int cmi_csr_diagonal_f64(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, const double *Ax, double *diag, int reciprocal, void *stream)
+{ return csr_diagonal_impl<double>(num_rows, Ap, Aj, Ax, diag, reciprocal, stream); }
+CMI_API int cmi_csr_diagonal_f32(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, const float *Ax, float *diag, int reciprocal, void *stream)
+{ return csr_diagonal_impl<float>(num_rows, Ap, Aj, Ax, diag, reciprocal, stream); }
 CMI_API int cmi_cr_xr_f64(int64_t n, const double *rz_dev, const double *yy_dev, const double *p, const double *y, double *x, double *r, int update_r, double *rr_dev,
                           double *rr_host_mirror, void *workspace, void *stream)
 { return cr_xr_impl<double>(n, rz_dev, yy_dev, p, y, x, r, update_r, rr_dev, rr_host_mirror, workspace, stream); }

@@ -673,6 +673,10 @@ int cmi_bicgstab_p_f64(int64_t n, const double *rho_new_dev, const double *rho_d
                        const double *AMp, double *p, void *stream);
 int cmi_bicgstab_p_f32(int64_t n, const double *rho_new_dev, const double *rho_dev, const double *d1_dev, const double *d2_dev, const double *d3_dev, const float *r,
                        const float *AMp, float *p, void *stream);
+/* diag[i] <- the sum of row i's entries in column i (0 when none is stored); reciprocal != 0: 1 / that -- the Jacobi preconditioner's set-up on the
+ * device (reference cusp/format_utils.h:184 extract_diagonal, precond/detail/diagonal.inl).  One pass over the column indices, no synchronisation.  */
+int cmi_csr_diagonal_f64(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, const double *Ax, double *diag, int reciprocal, void *stream);
+int cmi_csr_diagonal_f32(int64_t num_rows, const int32_t *Ap, const int32_t *Aj, const float *Ax, float *diag, int reciprocal, void *stream);
 /* Conjugate residuals' two vector passes with the scalars in device memory (reference cusp/krylov/detail/cr.inl:83-124, identity preconditioner:
  * 7 passes and 3 host reads around its multiply).  rz = <r, A r>, yy = <A p, A p> are device doubles:
  *   xr:  alpha = rz / yy;  x <- x + alpha p;  update_r != 0: r <- r - alpha y (y = A p) and *rr_dev <- <r, r> (+ host mirror)

@@ -124,6 +124,7 @@ def test_argument_validation_of_the_newer_entry_points(cmi):
         assert getattr(L, "cmi_bicgstab_s_" + suf)(4, None, None, None, None, None, None, None, None, None) == 1
         assert getattr(L, "cmi_bicgstab_p_" + suf)(4, None, None, None, None, None, None, None, None, None) == 1
         assert getattr(L, "cmi_blas_axpy_ratio_" + suf)(4, None, None, None, None, None) == 1
+        assert getattr(L, "cmi_csr_diagonal_" + suf)(-1, None, None, None, None, 1, None) == 1 and getattr(L, "cmi_csr_diagonal_" + suf)(0, None, None, None, None, 1, None) == 0
         assert getattr(L, "cmi_cr_xr_" + suf)(4, None, None, None, None, None, None, 1, None, None, None, None) == 1
         assert getattr(L, "cmi_cr_py_" + suf)(-1, None, None, None, None, None, None, None, None, None) == 1
         assert getattr(L, "cmi_blas_axpy_dot_" + suf)(4, None, None, None, None, None, None, None) == 1
