@@ -7,6 +7,8 @@
 // workgroup, the partials combined in index order by one workgroup -- no atomics.  Accumulation in double for both value types.
 #include "common.h"
 
+#include <initializer_list>
+
 namespace cmi {
 namespace {
 
@@ -48,6 +50,23 @@ __device__ __forceinline__ double block_add(double v, double *lds)
     }
     return lds[0];
 }
+// 16 bytes of T, and the element type a streaming pass runs on: E = T (any n, any alignment) or E = wide<T>::type (n a multiple of its width and every
+// pointer 16-byte aligned: 16-byte loads and stores -- the scalar form of these passes reads at 5.3-6.2 TB/s, the wide form at 6.3-6.9)
+template <typename T> struct wide;
+template <> struct wide<double> { typedef double __attribute__((ext_vector_type(2))) type; static constexpr int n = 2; };
+template <> struct wide<float> { typedef float __attribute__((ext_vector_type(4))) type; static constexpr int n = 4; };
+__device__ __forceinline__ double dot_acc(double a, double b) { return a * b; }
+__device__ __forceinline__ double dot_acc(float a, float b) { return (double)a * (double)b; }
+__device__ __forceinline__ double dot_acc(wide<double>::type a, wide<double>::type b) { return a.x * b.x + a.y * b.y; }
+__device__ __forceinline__ double dot_acc(wide<float>::type a, wide<float>::type b)
+{ return (double)a.x * (double)b.x + (double)a.y * (double)b.y + (double)a.z * (double)b.z + (double)a.w * (double)b.w; }
+template <typename T> bool can_widen(int64_t n, std::initializer_list<const void *> ptrs)
+{
+    if (n % wide<T>::n != 0) return false;
+    for (const void *q : ptrs) if (reinterpret_cast<uintptr_t>(q) % 16 != 0) return false;
+    return true;
+}
+
 // (largest |x|, FIRST position holding it): the pair with the larger value wins, equal values: the smaller index
 __device__ __forceinline__ void take_max(double &v, long long &i, double v2, long long i2)
 {
@@ -173,9 +192,9 @@ template <typename T> int amax_impl(int64_t n, const T *x, T *value_dev, int64_t
 //   update:     alpha = <r,z> / <y,p>;  r <- r - alpha y;  partials of <r, D^-1 r> and of <r, r>   -> *rz_new, *rr (+ the host's pinned mirror)
 //   direction:  beta = <r,z>_new / <r,z>_old;  x <- x + alpha p;  p <- D^-1 r + beta p
 // 8 + 1 vector passes (dinv is read twice) and ONE host read per iteration.  Deterministic two-stage reductions in double.
-template <typename T>
+template <typename T, typename E>
 __global__ void __launch_bounds__(kBlock)
-pcg_update_kernel(int64_t n, const double *__restrict__ rz, const double *__restrict__ yp, const T *__restrict__ y, T *__restrict__ r, const T *__restrict__ dinv,
+pcg_update_kernel(int64_t n, const double *__restrict__ rz, const double *__restrict__ yp, const E *__restrict__ y, E *__restrict__ r, const E *__restrict__ dinv,
                   double *__restrict__ part_rz, double *__restrict__ part_rr)
 {
     __shared__ double lds[kBlock];
@@ -183,10 +202,10 @@ pcg_update_kernel(int64_t n, const double *__restrict__ rz, const double *__rest
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     double a_rz = 0.0, a_rr = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const T ri = r[i] - alpha * y[i];
+        const E ri = r[i] - alpha * y[i];
         r[i] = ri;
-        a_rz += (double)ri * (double)(dinv[i] * ri);
-        a_rr += (double)ri * (double)ri;
+        a_rz += dot_acc(ri, dinv[i] * ri);
+        a_rr += dot_acc(ri, ri);
     }
     const double s1 = block_add(a_rz, lds);
     __syncthreads();
@@ -209,15 +228,15 @@ pcg_final_kernel(int npartial, const double *__restrict__ part_rz, const double 
         if (rr_mirror) *rr_mirror = s2;
     }
 }
-template <typename T>
+template <typename T, typename E>
 __global__ void __launch_bounds__(kBlock)
-pcg_direction_kernel(int64_t n, const double *__restrict__ rz_new, const double *__restrict__ rz_old, const double *__restrict__ yp, const T *__restrict__ r,
-                     const T *__restrict__ dinv, T *__restrict__ p, T *__restrict__ x)
+pcg_direction_kernel(int64_t n, const double *__restrict__ rz_new, const double *__restrict__ rz_old, const double *__restrict__ yp, const E *__restrict__ r,
+                     const E *__restrict__ dinv, E *__restrict__ p, E *__restrict__ x)
 {
     const T alpha = (T)(*rz_old / *yp), beta = (T)(*rz_new / *rz_old);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const T pi = p[i];
+        const E pi = p[i];
         x[i] = x[i] + alpha * pi;
         p[i] = dinv[i] * r[i] + beta * pi;
     }
@@ -229,9 +248,12 @@ int pcg_update_impl(int64_t n, const double *rz, const double *yp, const T *y, T
 {
     if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_pcg_update_jacobi: negative n");
     if (!rz || !yp || !rz_new || !rr || !workspace || (n > 0 && (!y || !r || !dinv))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_pcg_update_jacobi: null argument");
-    const int grid = grid_for(n);
+    typedef typename wide<T>::type V;
+    const bool w = can_widen<T>(n, {y, r, dinv});
+    const int grid = grid_for(w ? n / wide<T>::n : n);
     double *part = (double *)workspace;
-    hipLaunchKernelGGL((pcg_update_kernel<T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, rz, yp, y, r, dinv, part, part + kMaxGrid);
+    if (w) hipLaunchKernelGGL((pcg_update_kernel<T, V>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n / wide<T>::n, rz, yp, (const V *)y, (V *)r, (const V *)dinv, part, part + kMaxGrid);
+    else hipLaunchKernelGGL((pcg_update_kernel<T, T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, rz, yp, y, r, dinv, part, part + kMaxGrid);
     hipLaunchKernelGGL(pcg_final_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), grid, (const double *)part, (const double *)(part + kMaxGrid), rz_new, rr, rr_mirror);
     CMI_LAUNCH_CHECK("pcg_update_jacobi");
     return CMI_SUCCESS;
@@ -242,7 +264,10 @@ int pcg_direction_impl(int64_t n, const double *rz_new, const double *rz_old, co
     if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_pcg_direction_x_jacobi: negative n");
     if (!rz_new || !rz_old || !yp || (n > 0 && (!r || !dinv || !p || !x))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_pcg_direction_x_jacobi: null argument");
     if (n == 0) return CMI_SUCCESS;
-    hipLaunchKernelGGL((pcg_direction_kernel<T>), dim3(grid_for(n) * 4), dim3(kBlock), 0, as_stream(stream), n, rz_new, rz_old, yp, r, dinv, p, x);
+    typedef typename wide<T>::type V;
+    if (can_widen<T>(n, {r, dinv, p, x}))
+        hipLaunchKernelGGL((pcg_direction_kernel<T, V>), dim3(grid_for(n / wide<T>::n) * 4), dim3(kBlock), 0, as_stream(stream), n / wide<T>::n, rz_new, rz_old, yp, (const V *)r, (const V *)dinv, (V *)p, (V *)x);
+    else hipLaunchKernelGGL((pcg_direction_kernel<T, T>), dim3(grid_for(n) * 4), dim3(kBlock), 0, as_stream(stream), n, rz_new, rz_old, yp, r, dinv, p, x);
     CMI_LAUNCH_CHECK("pcg_direction_x_jacobi");
     return CMI_SUCCESS;
 }
@@ -254,9 +279,9 @@ int pcg_direction_impl(int64_t n, const double *rz_new, const double *rz_old, co
 //   xr-pass:  omega = <A s, s> / <A s, A s>;  x <- x + alpha p + omega s;  r <- s - omega A s;  *rho_new <- <r*, r>;  *rr <- <r, r> (+ mirror)
 //   p-pass:   beta = (rho_new / rho) (alpha / omega);  p <- r + beta (p - omega A p)
 // Two host reads per iteration (||s||, ||r||), deterministic two-stage reductions in double.
-template <typename T>
+template <typename T, typename E>
 __global__ void __launch_bounds__(kBlock)
-bicg_s_kernel(int64_t n, const double *__restrict__ rho, const double *__restrict__ d1, const T *__restrict__ r, const T *__restrict__ AMp, T *__restrict__ s,
+bicg_s_kernel(int64_t n, const double *__restrict__ rho, const double *__restrict__ d1, const E *__restrict__ r, const E *__restrict__ AMp, E *__restrict__ s,
               double *__restrict__ part)
 {
     __shared__ double lds[kBlock];
@@ -264,9 +289,9 @@ bicg_s_kernel(int64_t n, const double *__restrict__ rho, const double *__restric
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const T si = r[i] - alpha * AMp[i];
+        const E si = r[i] - alpha * AMp[i];
         s[i] = si;
-        acc += (double)si * (double)si;
+        acc += dot_acc(si, si);
     }
     const double t = block_add(acc, lds);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
@@ -279,10 +304,10 @@ __global__ void __launch_bounds__(kBlock) sum1_final_kernel(int npartial, const 
     const double t = block_add(a, lds);
     if (threadIdx.x == 0) { *out = t; if (mirror) *mirror = t; }
 }
-template <typename T>
+template <typename T, typename E>
 __global__ void __launch_bounds__(kBlock)
 bicg_xr_kernel(int64_t n, const double *__restrict__ rho, const double *__restrict__ d1, const double *__restrict__ d2, const double *__restrict__ d3,
-               const T *__restrict__ p, const T *__restrict__ s, const T *__restrict__ AMs, const T *__restrict__ r_star, T *__restrict__ x, T *__restrict__ r,
+               const E *__restrict__ p, const E *__restrict__ s, const E *__restrict__ AMs, const E *__restrict__ r_star, E *__restrict__ x, E *__restrict__ r,
                double *__restrict__ part_rho, double *__restrict__ part_rr)
 {
     __shared__ double lds[kBlock];
@@ -290,22 +315,22 @@ bicg_xr_kernel(int64_t n, const double *__restrict__ rho, const double *__restri
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     double a1 = 0.0, a2 = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const T si = s[i];
+        const E si = s[i];
         x[i] = x[i] + alpha * p[i] + omega * si;
-        const T ri = si - omega * AMs[i];
+        const E ri = si - omega * AMs[i];
         r[i] = ri;
-        a1 += (double)r_star[i] * (double)ri;
-        a2 += (double)ri * (double)ri;
+        a1 += dot_acc(r_star[i], ri);
+        a2 += dot_acc(ri, ri);
     }
     const double t1 = block_add(a1, lds);
     __syncthreads();
     const double t2 = block_add(a2, lds);
     if (threadIdx.x == 0) { part_rho[blockIdx.x] = t1; part_rr[blockIdx.x] = t2; }
 }
-template <typename T>
+template <typename T, typename E>
 __global__ void __launch_bounds__(kBlock)
 bicg_p_kernel(int64_t n, const double *__restrict__ rho_new, const double *__restrict__ rho, const double *__restrict__ d1, const double *__restrict__ d2,
-              const double *__restrict__ d3, const T *__restrict__ r, const T *__restrict__ AMp, T *__restrict__ p)
+              const double *__restrict__ d3, const E *__restrict__ r, const E *__restrict__ AMp, E *__restrict__ p)
 {
     const double alpha = *rho / *d1, omega = *d2 / *d3;
     const T beta = (T)((*rho_new / *rho) * (alpha / omega)), bo = (T)(-(double)beta * omega);
@@ -353,9 +378,9 @@ template <typename T> int csr_diagonal_impl(int64_t num_rows, const int *Ap, con
 //   xr-pass:  alpha = rz / yy;  x <- x + alpha p;  r <- r - alpha y   (y = A p);  *rr <- <r, r>  (+ host mirror)
 //             -- with update_r == 0 only x moves (every 8th iteration the caller rebuilds r = b - A x itself, cr.inl:96-107)
 //   py-pass:  beta = rz_new / rz;  p <- r + beta p;  y <- A r + beta y;  *yy_new <- <y, y>
-template <typename T>
+template <typename T, typename E>
 __global__ void __launch_bounds__(kBlock)
-cr_xr_kernel(int64_t n, const double *__restrict__ rz, const double *__restrict__ yy, const T *__restrict__ p, const T *__restrict__ y, T *__restrict__ x, T *__restrict__ r,
+cr_xr_kernel(int64_t n, const double *__restrict__ rz, const double *__restrict__ yy, const E *__restrict__ p, const E *__restrict__ y, E *__restrict__ x, E *__restrict__ r,
              int update_r, double *__restrict__ part)
 {
     __shared__ double lds[kBlock];
@@ -365,17 +390,17 @@ cr_xr_kernel(int64_t n, const double *__restrict__ rz, const double *__restrict_
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         x[i] = x[i] + alpha * p[i];
         if (update_r) {
-            const T ri = r[i] - alpha * y[i];
+            const E ri = r[i] - alpha * y[i];
             r[i] = ri;
-            acc += (double)ri * (double)ri;
+            acc += dot_acc(ri, ri);
         }
     }
     const double t = block_add(acc, lds);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
-template <typename T>
+template <typename T, typename E>
 __global__ void __launch_bounds__(kBlock)
-cr_py_kernel(int64_t n, const double *__restrict__ rz_new, const double *__restrict__ rz, const T *__restrict__ r, const T *__restrict__ Ar, T *__restrict__ p, T *__restrict__ y,
+cr_py_kernel(int64_t n, const double *__restrict__ rz_new, const double *__restrict__ rz, const E *__restrict__ r, const E *__restrict__ Ar, E *__restrict__ p, E *__restrict__ y,
              double *__restrict__ part)
 {
     __shared__ double lds[kBlock];
@@ -384,9 +409,9 @@ cr_py_kernel(int64_t n, const double *__restrict__ rz_new, const double *__restr
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         p[i] = r[i] + beta * p[i];
-        const T yi = Ar[i] + beta * y[i];
+        const E yi = Ar[i] + beta * y[i];
         y[i] = yi;
-        acc += (double)yi * (double)yi;
+        acc += dot_acc(yi, yi);
     }
     const double t = block_add(acc, lds);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
@@ -396,8 +421,11 @@ int cr_xr_impl(int64_t n, const double *rz, const double *yy, const T *p, const 
 {
     if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cr_xr: negative n");
     if (!rz || !yy || !workspace || (update_r && !rr) || (n > 0 && (!p || !y || !x || !r))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cr_xr: null argument");
-    const int grid = grid_for(n);
-    hipLaunchKernelGGL((cr_xr_kernel<T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, rz, yy, p, y, x, r, update_r, (double *)workspace);
+    typedef typename wide<T>::type V;
+    const bool w = can_widen<T>(n, {p, y, x, r});
+    const int grid = grid_for(w ? n / wide<T>::n : n);
+    if (w) hipLaunchKernelGGL((cr_xr_kernel<T, V>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n / wide<T>::n, rz, yy, (const V *)p, (const V *)y, (V *)x, (V *)r, update_r, (double *)workspace);
+    else hipLaunchKernelGGL((cr_xr_kernel<T, T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, rz, yy, p, y, x, r, update_r, (double *)workspace);
     if (update_r) hipLaunchKernelGGL(sum1_final_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), grid, (const double *)workspace, rr, rr_mirror);
     CMI_LAUNCH_CHECK("cr_xr");
     return CMI_SUCCESS;
@@ -407,8 +435,11 @@ int cr_py_impl(int64_t n, const double *rz_new, const double *rz, const T *r, co
 {
     if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cr_py: negative n");
     if (!rz_new || !rz || !yy_new || !workspace || (n > 0 && (!r || !Ar || !p || !y))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_cr_py: null argument");
-    const int grid = grid_for(n);
-    hipLaunchKernelGGL((cr_py_kernel<T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, rz_new, rz, r, Ar, p, y, (double *)workspace);
+    typedef typename wide<T>::type V;
+    const bool w = can_widen<T>(n, {r, Ar, p, y});
+    const int grid = grid_for(w ? n / wide<T>::n : n);
+    if (w) hipLaunchKernelGGL((cr_py_kernel<T, V>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n / wide<T>::n, rz_new, rz, (const V *)r, (const V *)Ar, (V *)p, (V *)y, (double *)workspace);
+    else hipLaunchKernelGGL((cr_py_kernel<T, T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, rz_new, rz, r, Ar, p, y, (double *)workspace);
     hipLaunchKernelGGL(sum1_final_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), grid, (const double *)workspace, yy_new, (double *)nullptr);
     CMI_LAUNCH_CHECK("cr_py");
     return CMI_SUCCESS;
@@ -417,28 +448,51 @@ int cr_py_impl(int64_t n, const double *rz_new, const double *rz, const T *r, co
 // ---- GMRES's modified Gram-Schmidt as a chain of fused steps with the coefficients in device memory ---------------------------------------------
 // (reference gmres.inl:145-152: per basis vector one dotc -- a host read -- and one axpy).  One step here: w <- w - (*h) v;  *out <- <w, u>  -- the
 // axpy of vector k and the dot with vector k + 1 (u = V[k + 1]) in ONE pass, or the norm's square (u = w) behind the last axpy; h == NULL: the dot alone.
+// vec != 0: every pointer is 16-byte aligned -- 16-byte loads and stores over the first n / W * W elements, the last few one by one
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-axpy_dot_kernel(int64_t n, const double *__restrict__ h, const T *__restrict__ v, T *w, const T *u, double *__restrict__ part, int u_is_w)
+axpy_dot_kernel(int64_t n, const double *__restrict__ h, const T *__restrict__ v, T *w, const T *u, double *__restrict__ part, int u_is_w, int vec)
 {
+    typedef typename wide<T>::type V;
+    constexpr int W = wide<T>::n;
     __shared__ double lds[kBlock];
     const T a = h ? (T)(*h) : T(0);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t nv = vec ? n / W : 0;
+    for (int64_t i = t; i < nv; i += stride) {
+        V wi = reinterpret_cast<const V *>(w)[i];
+        if (h) {
+            const V vi = reinterpret_cast<const V *>(v)[i];
+#pragma unroll
+            for (int k = 0; k < W; k++) wi[k] = wi[k] - a * vi[k];
+            reinterpret_cast<V *>(w)[i] = wi;
+        }
+        if (u_is_w) {
+#pragma unroll
+            for (int k = 0; k < W; k++) acc += (double)wi[k] * (double)wi[k];
+        } else {
+            const V ui = reinterpret_cast<const V *>(u)[i];
+#pragma unroll
+            for (int k = 0; k < W; k++) acc += (double)wi[k] * (double)ui[k];
+        }
+    }
+    for (int64_t i = nv * W + t; i < n; i += stride) {
         T wi = w[i];
         if (h) { wi = wi - a * v[i]; w[i] = wi; }
         acc += (double)wi * (double)(u_is_w ? wi : u[i]);
     }
-    const double t = block_add(acc, lds);
-    if (threadIdx.x == 0) part[blockIdx.x] = t;
+    const double s = block_add(acc, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 template <typename T> int axpy_dot_impl(int64_t n, const double *h, const T *v, T *w, const T *u, double *out, void *workspace, void *stream)
 {
     if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_axpy_dot: negative n");
     if (!out || !workspace || (n > 0 && (!w || !u || (h && !v)))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_blas_axpy_dot: null argument");
     const int grid = grid_for(n);
-    hipLaunchKernelGGL((axpy_dot_kernel<T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, h, v, w, u, (double *)workspace, (int)(u == w));
+    auto aligned = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    const int vec = aligned(w) && aligned(u) && (!h || aligned(v));
+    hipLaunchKernelGGL((axpy_dot_kernel<T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, h, v, w, u, (double *)workspace, (int)(u == w), vec);
     hipLaunchKernelGGL(sum1_final_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), grid, (const double *)workspace, out, (double *)nullptr);
     CMI_LAUNCH_CHECK("axpy_dot");
     return CMI_SUCCESS;
@@ -449,8 +503,11 @@ int bicg_s_impl(int64_t n, const double *rho, const double *d1, const T *r, cons
 {
     if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_bicgstab_s: negative n");
     if (!rho || !d1 || !ss || !workspace || (n > 0 && (!r || !AMp || !s))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_bicgstab_s: null argument");
-    const int grid = grid_for(n);
-    hipLaunchKernelGGL((bicg_s_kernel<T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, rho, d1, r, AMp, s, (double *)workspace);
+    typedef typename wide<T>::type V;
+    const bool w = can_widen<T>(n, {r, AMp, s});
+    const int grid = grid_for(w ? n / wide<T>::n : n);
+    if (w) hipLaunchKernelGGL((bicg_s_kernel<T, V>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n / wide<T>::n, rho, d1, (const V *)r, (const V *)AMp, (V *)s, (double *)workspace);
+    else hipLaunchKernelGGL((bicg_s_kernel<T, T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, rho, d1, r, AMp, s, (double *)workspace);
     hipLaunchKernelGGL(sum1_final_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), grid, (const double *)workspace, ss, ss_mirror);
     CMI_LAUNCH_CHECK("bicgstab_s");
     return CMI_SUCCESS;
@@ -462,9 +519,12 @@ int bicg_xr_impl(int64_t n, const double *rho, const double *d1, const double *d
     if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_bicgstab_xr: negative n");
     if (!rho || !d1 || !d2 || !d3 || !rho_new || !rr || !workspace || (n > 0 && (!p || !s || !AMs || !r_star || !x || !r)))
         return fail(CMI_ERROR_INVALID_VALUE, "cmi_bicgstab_xr: null argument");
-    const int grid = grid_for(n);
+    typedef typename wide<T>::type V;
+    const bool w = can_widen<T>(n, {p, s, AMs, r_star, x, r});
+    const int grid = grid_for(w ? n / wide<T>::n : n);
     double *part = (double *)workspace;
-    hipLaunchKernelGGL((bicg_xr_kernel<T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, rho, d1, d2, d3, p, s, AMs, r_star, x, r, part, part + kMaxGrid);
+    if (w) hipLaunchKernelGGL((bicg_xr_kernel<T, V>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n / wide<T>::n, rho, d1, d2, d3, (const V *)p, (const V *)s, (const V *)AMs, (const V *)r_star, (V *)x, (V *)r, part, part + kMaxGrid);
+    else hipLaunchKernelGGL((bicg_xr_kernel<T, T>), dim3(grid), dim3(kBlock), 0, as_stream(stream), n, rho, d1, d2, d3, p, s, AMs, r_star, x, r, part, part + kMaxGrid);
     hipLaunchKernelGGL(pcg_final_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), grid, (const double *)part, (const double *)(part + kMaxGrid), rho_new, rr, rr_mirror);
     CMI_LAUNCH_CHECK("bicgstab_xr");
     return CMI_SUCCESS;
@@ -475,7 +535,10 @@ int bicg_p_impl(int64_t n, const double *rho_new, const double *rho, const doubl
     if (n < 0) return fail(CMI_ERROR_INVALID_VALUE, "cmi_bicgstab_p: negative n");
     if (!rho_new || !rho || !d1 || !d2 || !d3 || (n > 0 && (!r || !AMp || !p))) return fail(CMI_ERROR_INVALID_VALUE, "cmi_bicgstab_p: null argument");
     if (n == 0) return CMI_SUCCESS;
-    hipLaunchKernelGGL((bicg_p_kernel<T>), dim3(grid_for(n) * 4), dim3(kBlock), 0, as_stream(stream), n, rho_new, rho, d1, d2, d3, r, AMp, p);
+    typedef typename wide<T>::type V;
+    if (can_widen<T>(n, {r, AMp, p}))
+        hipLaunchKernelGGL((bicg_p_kernel<T, V>), dim3(grid_for(n / wide<T>::n) * 4), dim3(kBlock), 0, as_stream(stream), n / wide<T>::n, rho_new, rho, d1, d2, d3, (const V *)r, (const V *)AMp, (V *)p);
+    else hipLaunchKernelGGL((bicg_p_kernel<T, T>), dim3(grid_for(n) * 4), dim3(kBlock), 0, as_stream(stream), n, rho_new, rho, d1, d2, d3, r, AMp, p);
     CMI_LAUNCH_CHECK("bicgstab_p");
     return CMI_SUCCESS;
 }
