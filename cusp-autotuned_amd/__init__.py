@@ -15,7 +15,7 @@ from .binding import (  # noqa: F401
     Config,
     FORMAT_CSR, FORMAT_ELL, FORMAT_DIA, FORMAT_COO, FORMAT_HYB, TABLE_COO_SORTED,
     F64, F32,
-    KERNEL_AUTO, CSR_SCALAR, CSR_VECTOR, CSR_STREAM, CSR_STREAM_PIPE, CSR_BALANCED, CSR_STREAM_C16, CSR_STREAM_WAVE, CSR_STREAM_WAVEV, CSR_STREAM_WAVEX, ELL_ROW, DIA_ROW, COO_SEGMENTED, COO_LANE4, COO_TILE,
+    KERNEL_AUTO, CSR_SCALAR, CSR_VECTOR, CSR_STREAM, CSR_STREAM_PIPE, CSR_BALANCED, CSR_STREAM_C16, CSR_STREAM_WAVE, CSR_STREAM_WAVEV, CSR_STREAM_WAVEX, CSR_STREAM_WAVER, CSR_STREAM_PACKED, ELL_ROW, DIA_ROW, COO_SEGMENTED, COO_LANE4, COO_TILE,
     lib, lib_path, build, version, check,
     Plan, spmv_csr_plan, spmv_coo_plan, spmv_hyb_plan, set_index_compression, get_index_compression,
     spmv_csr, spmv_csr_dot, spmv_ell_dot, spmv_dia_dot, spmv_ell, spmv_dia, spmv_coo, spmv_hyb,

@@ -15,6 +15,7 @@ TABLE_COO_SORTED = 5  # tuning-table key only: the launch shape of a COO multipl
 F64, F32 = 0, 1
 KERNEL_AUTO = 0
 CSR_SCALAR, CSR_VECTOR, CSR_STREAM, CSR_STREAM_PIPE, CSR_BALANCED, CSR_STREAM_C16, CSR_STREAM_WAVE, CSR_STREAM_WAVEV, CSR_STREAM_WAVEX = 1, 2, 3, 4, 5, 6, 7, 8, 9
+CSR_STREAM_WAVER, CSR_STREAM_PACKED = 11, 12  # round 4: run-compressed column copy on wave tiles; ... with the values packed beside it (opt-in)
 ELL_ROW, DIA_ROW, COO_SEGMENTED, COO_LANE4, COO_TILE = 10, 20, 30, 31, 32
 
 
@@ -162,6 +163,9 @@ def _declare(L):
     L.cmi_plan_validate.argtypes = [vp, vp, vp, vp, POINTER(c_int)]
     L.cmi_plan_info.argtypes = [vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int), POINTER(c_int)]
     L.cmi_plan_create_csr.argtypes = [c_int, i64, i64, i64, vp, vp, cfgp, vp, POINTER(c_void_p)]
+    L.cmi_plan_create_csr_values.argtypes = [c_int, i64, i64, i64, vp, vp, vp, cfgp, vp, POINTER(c_void_p)]
+    L.cmi_plan_validate_values.argtypes = [vp, vp, vp, POINTER(c_int)]
+    L.cmi_plan_device_bytes.argtypes = [vp, POINTER(c_int64)]
     L.cmi_set_index_compression.argtypes = [c_int]
     L.cmi_plan_hyb_launches.argtypes = [vp, POINTER(c_int)]
     L.cmi_plan_create_hyb.argtypes = [c_int, i64, i64, i64, i64, vp, cfgp, cfgp, vp, POINTER(c_void_p)]
@@ -306,6 +310,34 @@ class Plan:
         self.format, self.dtype = FORMAT_CSR, code
         self.num_rows, self.num_cols, self.num_entries = num_rows, num_cols, Aj.numel()
         return self
+
+    @classmethod
+    def csr_values(cls, num_rows, num_cols, Ap, Aj, Ax, cfg=None, stream=None):
+        """cmi_plan_create_csr_values: Plan.csr plus the values -- with cfg.kernel == CSR_STREAM_PACKED the plan copies pieces AND values into
+        one span per wave tile (the plan then owns a copy of the values: validate_values tells whether they have changed since)."""
+        import torch
+        self = cls.__new__(cls)
+        self._h = c_void_p()
+        _need(Ap, "Ap", torch.int32)
+        _need(Aj, "Aj", torch.int32)
+        if Ap.numel() != num_rows + 1 or Ax.numel() != Aj.numel():
+            raise ValueError("Plan.csr_values: row offsets must have num_rows + 1 entries, values as many as columns")
+        code = F64 if Ax.dtype == torch.float64 else F32
+        check(lib().cmi_plan_create_csr_values(code, num_rows, num_cols, Aj.numel(), _ptr(Ap), _ptr(Aj), _ptr(Ax), _cfg(cfg), _stream(stream), byref(self._h)))
+        self.format, self.dtype = FORMAT_CSR, code
+        self.num_rows, self.num_cols, self.num_entries = num_rows, num_cols, Aj.numel()
+        return self
+
+    def validate_values(self, values, stream=None):
+        """cmi_plan_validate_values: False when a CSR_STREAM_PACKED plan's copy of the values no longer matches `values`."""
+        ok = c_int(-1)
+        check(lib().cmi_plan_validate_values(self._h, _ptr(values), _stream(stream), byref(ok)))
+        return bool(ok.value)
+
+    def device_bytes(self):
+        n = c_int64()
+        check(lib().cmi_plan_device_bytes(self._h, byref(n)))
+        return n.value
 
     @classmethod
     def hyb(cls, dtype, num_rows, num_cols, width, coo_row_indices, cfg_ell=None, cfg_coo=None, stream=None):
@@ -909,6 +941,13 @@ COMM_ID_BYTES = 128
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
 
 
+def comm_library_version():
+    """ncclGetVersion of the RCCL the library binds at run time; raises when it cannot be bound (local call, not collective)."""
+    v = c_int()
+    check(lib().cmi_comm_library_version(byref(v)))
+    return v.value
+
+
 class Comm:
     """cmi_comm: the RCCL communicator behind the C-ABI (include/cusp_mi355x.h, csrc/comm.hip) -- what the sharded SpMV / CG use for
     their data path: all-gather of x (equal or unequal pieces), grouped send/recv halo exchange, all-reduce of CG's scalars.  Every
@@ -955,9 +994,7 @@ class Comm:
         return self._h
 
     def library_version(self):
-        v = c_int()
-        check(lib().cmi_comm_library_version(byref(v)))
-        return v.value
+        return comm_library_version()
 
     def allgather(self, send, recv, count, stream=None):
         """recv[r*count, +count) <- rank r's send[0, count); in place when send is recv's own slice."""

@@ -313,6 +313,15 @@ struct cmi_plan {
     uint64_t fp_index = 0, fp_columns = 0;
     bool has_fp_index = false, has_fp_columns = false;
     int csr16_wave_k = 0;           // > 0: the copy is tiled per WAVE (64 rows; cfg.rows_per_block == 64) and multiplied by the wave-tile kernel with this many entries per lane
+    bool kernel_asked = false;      // the caller named a plan-only kernel (WAVE on a partition, WAVEV, WAVEX, WAVER, PACKED): its requirements are hard errors, not fall-backs
+    // CMI_CSR_STREAM_WAVER / _PACKED (spmv_csr_runs.hip): the run-compressed column copy on wave tiles (wave_tiles, wave_q as above)
+    int32_t *runs_start = nullptr;   // device, 4 (wave_tiles + 1) entries: {first row, first entry, first piece, packed offset / 16} per tile
+    uint32_t *runs_pieces = nullptr; // device, runs_count (+ padding): (first column << 2) | (length - 1)
+    int64_t runs_count = 0;
+    unsigned char *runs_packed = nullptr; // device, _PACKED only: per tile [pieces | pad | values | pad]
+    int64_t runs_packed_bytes = 0;
+    uint64_t fp_values = 0;          // checksum of the values a _PACKED plan copied (cmi_plan_validate_values)
+    bool has_fp_values = false;
 };
 
 namespace cmi {
@@ -327,6 +336,10 @@ constexpr int kHybFusedMaxInTile = 4096;
 // spmv_csr16.hip: the plan's 16-bit column copy (built only if every tile qualifies) and the multiply that reads it
 int wave_partition_build(cmi_plan *p, const int *Ap, int k, hipStream_t s, int q_override = 0); // spmv_csr.hip (q_override: entries per tile, csr_wavev)
 int csr16_build(cmi_plan *p, const int *Ap, const int *Aj, hipStream_t s, int wave_k = 0);
+// spmv_csr_runs.hip: the plan's run-compressed column copy (+ the packed tiles when `values` is given) and the multiply that reads it
+int csr_runs_build(cmi_plan *p, const int *Ap, const int *Aj, int v, double min_mean_piece, const void *values, hipStream_t s, double *mean_piece);
+int csr_runs_multiply_f64(const cmi_plan *p, const int *Ap, const int *Aj, const double *Ax, const double *x, double *y, int accumulate, hipStream_t s,
+                          const double *w, double *dot_partial, int *dot_partials, int cache_policy, int xcd_swizzle);
 int csr16_multiply_f64(const cmi_plan *p, const int *Ap, const double *Ax, const double *x, double *y, int accumulate,
                        hipStream_t s, const double *w, double *dot_partial, int *dot_partials, int cache_policy, int xcd_swizzle);
 int csr16_multiply_f32(const cmi_plan *p, const int *Ap, const float *Ax, const float *x, float *y, int accumulate,

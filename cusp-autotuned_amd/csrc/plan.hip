@@ -36,7 +36,7 @@ CMI_API int cmi_set_index_compression(int on) { g_compress = on ? 1 : 0; return 
 CMI_API int cmi_get_index_compression(void) { return compress_default(); }
 
 static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
-                       const int32_t *index_array, const int32_t *csr_columns, const cmi_config *cfg, void *stream, cmi_plan **plan_out);
+                       const int32_t *index_array, const int32_t *csr_columns, const cmi_config *cfg, void *stream, cmi_plan **plan_out, const void *csr_values = nullptr);
 
 // ---- checksum of an index array (cmi_plan_validate) -------------------------------------------------------------------------
 // sum over i of mix(i, a[i]) mod 2^64: position-dependent terms, combined by integer addition -- the same value whatever the
@@ -205,6 +205,46 @@ static int wavev_vectors(int64_t rows, int64_t nnz, const row_profile &prof, boo
     return wavev_auto(rows, nnz, prof, v, vbytes) ? v : 0;
 }
 
+// csr_waver (CMI_CSR_STREAM_WAVER): wave tiles on the run-compressed column copy.  Asked for: built whenever the tile can hold the longest
+// row.  AUTO plans made with the columns ($CMI_CSR_WAVER=0: never, =1: whenever the rows qualify): f64, at least 4096 rows of 8+ entries on
+// average, no row of 512+, streams beyond 0.75 x the Infinity Cache (csr_wavev's size rule: below it the partition's scalar hop is not
+// hidden), and pieces of kWaverMinPiece+ entries on average -- measured by building the copy, which is dropped again when they are shorter.
+constexpr double kWaverMinPiece = 2.5;
+static int waver_env()
+{
+    static const int env = [] { const char *e = std::getenv("CMI_CSR_WAVER"); return e ? std::atoi(e) : -1; }();
+    return env;
+}
+static bool waver_try(cmi_plan *p, const int *Ap, const int *Aj, bool asked, int asked_v, bool keep_policy, const void *values, hipStream_t s, int *st)
+{
+    const int64_t rows = p->rows, nnz = p->nnz;
+    if (p->dtype != CMI_F64 || rows <= 0 || nnz <= 0 || p->prof.max_len < 1 || p->prof.in_long > 0 || p->cols < 2 || p->cols >= ((int64_t)1 << 30)) return false;
+    int v = asked_v ? asked_v : 4;
+    if (v != 1 && v != 2 && v != 4) return false;
+    while (v < 4 && !asked_v && 2 * (p->prof.max_len + 3) > 256 * v) v *= 2;
+    if (2 * (p->prof.max_len + 3) > 256 * v) return false;
+    if (!asked) {
+        if (waver_env() == 0) return false;
+        const double mean = (double)nnz / (double)rows;
+        if (rows < 4096) return false;
+        if (waver_env() != 1 && (mean < 8.0 || nnz * (int64_t)12 <= kInfinityCacheBytes / 4 * 3)) return false;
+    }
+    double mean_piece = 0.0;
+    *st = csr_runs_build(p, Ap, Aj, v, asked ? 0.0 : kWaverMinPiece, values, s, &mean_piece);
+    if (*st != CMI_SUCCESS || !p->runs_start) return false;
+    p->cfg.kernel = values ? CMI_CSR_STREAM_PACKED : CMI_CSR_STREAM_WAVER;
+    p->cfg.block_size = 256;
+    p->cfg.rows_per_block = 0;
+    p->cfg.items_per_thread = v;
+    p->cfg.threads_per_row = 0;
+    p->cfg.nontemporal &= ~kPolStrided;
+    if (!keep_policy) { // (a caller's policy bits are kept as given)
+        if (nnz * (int64_t)12 > kInfinityCacheBytes + kInfinityCacheBytes / 4) p->cfg.nontemporal |= kPolLoadNT;
+        p->cfg.nontemporal |= kPolStoreNT;
+    }
+    return true;
+}
+
 CMI_API int cmi_plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
                             const int32_t *index_array, const cmi_config *cfg, void *stream, cmi_plan **plan_out)
 {
@@ -219,11 +259,54 @@ CMI_API int cmi_plan_create_csr(int dtype, int64_t num_rows, int64_t num_cols, i
                                 const int32_t *column_indices, const cmi_config *cfg, void *stream, cmi_plan **plan_out)
 {
     if (num_entries > 0 && !column_indices) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create_csr: null column indices");
+    if (cfg && cfg->kernel == CMI_CSR_STREAM_PACKED) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create_csr: CMI_CSR_STREAM_PACKED copies the values -- use cmi_plan_create_csr_values");
     return plan_create(CMI_FORMAT_CSR, dtype, num_rows, num_cols, num_entries, row_offsets, column_indices, cfg, stream, plan_out);
 }
 
+// CSR with the structure arrays AND the values: cmi_plan_create_csr plus -- asked for by cfg->kernel == CMI_CSR_STREAM_PACKED -- the packed
+// per-tile copy of pieces and values (spmv_csr_runs.hip).  The values of any other plan stay the caller's.
+CMI_API int cmi_plan_create_csr_values(int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *row_offsets,
+                                       const int32_t *column_indices, const void *values, const cmi_config *cfg, void *stream, cmi_plan **plan_out)
+{
+    if (num_entries > 0 && !column_indices) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create_csr_values: null column indices");
+    const bool packed = cfg && cfg->kernel == CMI_CSR_STREAM_PACKED;
+    if (packed && num_entries > 0 && !values) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create_csr_values: CMI_CSR_STREAM_PACKED needs the values");
+    return plan_create(CMI_FORMAT_CSR, dtype, num_rows, num_cols, num_entries, row_offsets, column_indices, cfg, stream, plan_out, packed ? values : nullptr);
+}
+
+CMI_API int cmi_plan_validate_values(const cmi_plan *plan, const void *values, void *stream, int *valid_host)
+{
+    if (!plan || !valid_host) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_validate_values: null plan or result");
+    *valid_host = 1;
+    if (!plan->has_fp_values) return CMI_SUCCESS;
+    if (!values) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_validate_values: the plan owns a copy of the values; pass them");
+    uint64_t fp = 0;
+    if (int st = fingerprint(plan->nnz * (plan->dtype == CMI_F64 ? 2 : 1), reinterpret_cast<const int *>(values), as_stream(stream), &fp)) return st;
+    if (fp != plan->fp_values) *valid_host = 0;
+    return CMI_SUCCESS;
+}
+
+CMI_API int cmi_plan_device_bytes(const cmi_plan *plan, int64_t *bytes)
+{
+    if (!plan || !bytes) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_device_bytes: null argument");
+    int64_t b = 0;
+    if (plan->hyb_tile_start) b += (ceil_div(plan->rows, kHybTileRows) + 1) * 4;
+    if (plan->coo_offsets) b += (plan->rows + 1) * 4;
+    if (plan->wave_row_start) b += (plan->wave_tiles + 1) * 8;
+    if (plan->csr16_cols) b += (plan->nnz + 8) * 2;
+    if (plan->csr16_base) b += ceil_div(plan->rows, plan->cfg.rows_per_block > 0 ? plan->cfg.rows_per_block : 1) * 4;
+    if (plan->runs_start) b += (plan->wave_tiles + 1) * 16;
+    if (plan->runs_pieces) b += (plan->runs_count + 64) * 4;
+    if (plan->runs_packed) b += plan->runs_packed_bytes;
+    int64_t sub = 0;
+    if (plan->hyb_coo_plan && cmi_plan_device_bytes(plan->hyb_coo_plan, &sub) == CMI_SUCCESS) b += sub;
+    if (plan->coo_csr_plan && cmi_plan_device_bytes(plan->coo_csr_plan, &sub) == CMI_SUCCESS) b += sub;
+    *bytes = b;
+    return CMI_SUCCESS;
+}
+
 static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
-                       const int32_t *index_array, const int32_t *csr_columns, const cmi_config *cfg, void *stream, cmi_plan **plan_out)
+                       const int32_t *index_array, const int32_t *csr_columns, const cmi_config *cfg, void *stream, cmi_plan **plan_out, const void *csr_values)
 {
     if (!plan_out) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: null result pointer");
     *plan_out = nullptr;
@@ -294,6 +377,26 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
         cfg = &wavev_shape;
         p->cfg_explicit = false;
     }
+    // CMI_CSR_STREAM_WAVER / _PACKED: wave tiles on the run-compressed column copy (spmv_csr_runs.hip); policy / dealing as for WAVEV
+    cmi_config waver_shape;
+    bool want_waver = false, want_packed = false;
+    int waver_v = 0;
+    if (format == CMI_FORMAT_CSR && cfg && (cfg->kernel == CMI_CSR_STREAM_WAVER || cfg->kernel == CMI_CSR_STREAM_PACKED)) {
+        if (!csr_columns && num_entries > 0) { delete p; return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: CMI_CSR_STREAM_WAVER needs the column indices -- use cmi_plan_create_csr"); }
+        if (dtype != CMI_F64) { delete p; return fail(CMI_ERROR_NOT_SUPPORTED, "cmi_plan_create: CMI_CSR_STREAM_WAVER / _PACKED are f64 kernels"); }
+        want_waver = true;
+        want_packed = cfg->kernel == CMI_CSR_STREAM_PACKED;
+        waver_v = cfg->items_per_thread;
+        waver_shape = *cfg;
+        waver_shape.kernel = CMI_KERNEL_AUTO;
+        waver_shape.rows_per_block = 0;
+        waver_shape.items_per_thread = 0;
+        waver_shape.block_size = 0;
+        waver_shape.threads_per_row = 0;
+        cfg = &waver_shape;
+        p->cfg_explicit = false;
+    }
+    p->kernel_asked = want_partition || want_wavev || want_waver;
     // HYB's table key is its ELL part's (the COO part looks its own shape up per call)
     select_config(format == CMI_FORMAT_HYB ? CMI_FORMAT_ELL : format, dtype, num_rows, num_cols, num_entries, cfg, &p->cfg);
     hipStream_t s = as_stream(stream);
@@ -333,7 +436,7 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
         // tiles (spmv_csr.hip csr_wave_kernel): 64 rows per wave, as many entries per lane as the longest row has, so every
         // tile fits and (mean within 7 % of the longest row) at least 93 % of the request lanes carry an entry.  Cache policy and
         // XCD dealing are the table's csr_stream entry's.  Not for a caller's explicit kernel, not over a granted 16-bit copy.
-        if (st == CMI_SUCCESS && auto_kernel && !want_wavev && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
+        if (st == CMI_SUCCESS && auto_kernel && !want_wavev && !want_waver && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
             wave_tiles_fit(num_rows, num_entries, p->prof.max_len)) {
             p->cfg.kernel = CMI_CSR_STREAM_WAVE;
             p->cfg.block_size = 256;
@@ -347,6 +450,11 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
             // (profiles/r02_wave_shape_sweep.txt, r02_wave_ab.txt); below it, plain loads keep the matrix resident (tuning.hip)
             if (num_entries * (int64_t)(sizeof(int) + vbytes) > kInfinityCacheBytes + kInfinityCacheBytes / 4) p->cfg.nontemporal |= kPolLoadNT;
             p->cfg.nontemporal |= kPolStoreNT;
+        } else if (st == CMI_SUCCESS && auto_kernel && !want_partition && !want_wavev && csr_columns && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
+                   waver_try(p, index_array, csr_columns, want_waver, waver_v, want_waver && waver_shape.nontemporal != 0, want_packed ? csr_values : nullptr, s, &st)) {
+            // (the run-compressed copy was built and pays: p->cfg is set)
+        } else if (st == CMI_SUCCESS && want_waver) {
+            st = fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: CMI_CSR_STREAM_WAVER / _PACKED need f64 values, 2 <= columns < 2^30, items_per_thread 0, 1, 2 or 4, no row of 512+ entries and the longest row at most half of the 256 x items_per_thread slots of a wave tile");
         } else if (st == CMI_SUCCESS && auto_kernel && !want_partition && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
                    wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v, vbytes) > 0) { // (a caller who asked for csr_wave on a partition gets that)
             int v = wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v, vbytes);
@@ -367,8 +475,13 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
                     keep_stream = true; // columns scattered over the whole vector: 0.08-0.11 of peak whatever runs; wave tiles 0.97-1.06x
                 } else if (dtype == CMI_F32 && mean >= 16.0 && cp.jumps < 0.5) {
                     keep_stream = true; // f32 stencil / FEM-block rows of 16+ entries (or unknown columns): the table's csr_stream is 5-6 % faster
-                } else if (dtype == CMI_F64 && mean < 8.0 && cp.jumps >= 0.0 && cp.jumps < 0.5)
+                } else if (dtype == CMI_F64 && mean < 8.0 && cp.jumps >= 0.0 && cp.jumps < 0.5) {
+                    // V = 1 -- but only while the longest row still takes at most half of the smaller tile: with Q = 256 v - longest - 3
+                    // entries per tile a few rows of 126-252 entries would leave Q = 127..1, i.e. up to one wave tile (8 bytes of plan
+                    // memory, one wave) per handful of entries.  Widen back until the bound wavev_vectors() checked holds.
                     v = 1;
+                    while (v < 4 && 2 * (p->prof.max_len + 3) > 256 * v) v *= 2;
+                }
             }
             if (keep_stream) {
                 // (the table's csr_stream entry stays: nothing is built)
@@ -437,7 +550,11 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
         st = fingerprint(index_length(p), index_array, s, &p->fp_index);
         p->has_fp_index = st == CMI_SUCCESS;
     }
-    if (st == CMI_SUCCESS && p->csr16_cols && csr_columns) {
+    if (st == CMI_SUCCESS && p->runs_packed && csr_values) {
+        st = fingerprint(num_entries * (dtype == CMI_F64 ? 2 : 1), reinterpret_cast<const int *>(csr_values), s, &p->fp_values);
+        p->has_fp_values = st == CMI_SUCCESS;
+    }
+    if (st == CMI_SUCCESS && (p->csr16_cols || p->runs_pieces) && csr_columns) {
         st = fingerprint(num_entries, csr_columns, s, &p->fp_columns);
         p->has_fp_columns = st == CMI_SUCCESS;
     }
@@ -533,6 +650,9 @@ CMI_API int cmi_plan_destroy(cmi_plan *plan)
     if (plan && plan->wave_row_start) (void)hipFree(plan->wave_row_start);
     if (plan && plan->csr16_base) (void)hipFree(plan->csr16_base);
     if (plan && plan->csr16_cols) (void)hipFree(plan->csr16_cols);
+    if (plan && plan->runs_start) (void)hipFree(plan->runs_start);
+    if (plan && plan->runs_pieces) (void)hipFree(plan->runs_pieces);
+    if (plan && plan->runs_packed) (void)hipFree(plan->runs_packed);
     delete plan;
     return CMI_SUCCESS;
 }
@@ -557,7 +677,7 @@ CMI_API int cmi_plan_info(const cmi_plan *plan, int64_t *max_row_length, int64_t
         switch (plan->format) {
         case CMI_FORMAT_CSR:
             // scalar / pipe: always; stream: one lane per row and no row long enough for the cooperative path
-            exact = c.kernel == CMI_CSR_SCALAR || c.kernel == CMI_CSR_STREAM_PIPE || c.kernel == CMI_CSR_STREAM_C16 || c.kernel == CMI_CSR_STREAM_WAVE || c.kernel == CMI_CSR_STREAM_WAVEV || c.kernel == CMI_CSR_STREAM_WAVEX ||
+            exact = c.kernel == CMI_CSR_SCALAR || c.kernel == CMI_CSR_STREAM_PIPE || c.kernel == CMI_CSR_STREAM_C16 || c.kernel == CMI_CSR_STREAM_WAVE || c.kernel == CMI_CSR_STREAM_WAVEV || c.kernel == CMI_CSR_STREAM_WAVEX || c.kernel == CMI_CSR_STREAM_WAVER || c.kernel == CMI_CSR_STREAM_PACKED ||
                     (c.kernel == CMI_CSR_STREAM && c.threads_per_row <= 1 && (c.threads_per_row == 1 || plan->prof.max_len < 512));
             break;
         case CMI_FORMAT_ELL: exact = ell_lanes_per_row(c, plan->rows, plan->rows > 0 ? plan->nnz / plan->rows : 0) == 1; break;

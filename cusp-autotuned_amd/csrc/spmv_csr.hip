@@ -19,6 +19,7 @@
 // SpMV is HBM-bound (0.125 flop/byte): no MFMA.  Algorithmic bytes per call:
 //   12*nnz + 20*num_rows + 4   (Ap once, Aj once, Ax once, x once, y once; f64).
 #include "common.h"
+#include <cmath>
 #include <cstdlib>
 #include <mutex>
 
@@ -185,7 +186,7 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
             // load instruction covers one contiguous span (512 B of indices, 1 KiB of values) and every line is requested exactly once,
             // the property of the lane-strided / wave-tile kernels; the products land in LDS 16 bytes per lane, lanes contiguous (no
             // bank conflict; the vector form's 32-byte lane stride is a 2-way one).  Same products, same slots: same bits.
-            if (sizeof(T) == 8 && pairs) {
+            if (sizeof(T) == 8 && pairs && nz1 > nz0) { // (a tile of empty rows has no last pair to clamp to: the guarded vector body below loads nothing)
                 constexpr int NP = 2 * IPT;
                 int2v c2[NP];
                 double2v v2[NP];
@@ -453,15 +454,18 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
 // sum phase (csr_stream: 192 of 256); the tile bounds are two scalar loads and the row's end is the next lane's start (one
 // row-offset load per lane, wave_shl:1 on the DPP path).  Headline matrix: 124.8 -> 120-121 us (tools/r2_probe.hip csrw / csrw1,
 // profiles/r02_probe_wave_tiles.txt).  Same products, same order of summation as the host loop: bit-exact.
-// A tile that does not fit (an explicit config on an irregular matrix) or holds no entry is summed one lane per row straight
-// from the arrays: correct, slow.
+// A tile that does not fit (rows longer than K: an explicit config, or a plan-less call, which knows only the mean row length) takes
+// further PASSES of 64 K entries through the same body, every lane carrying its row's running sum across them (round 4; before: one lane
+// per row straight from the arrays).
 // LDS: T prod[waves][64 K].
 template <typename T, int K, int POL, bool DOT>
 __global__ void __launch_bounds__(1024)
 csr_wave_kernel(int64_t num_rows, const int *Ap /* not restrict: see the asm below */, const int *__restrict__ Aj,
                 const T *__restrict__ Ax, const T *__restrict__ x, T *__restrict__ y, int rows_per_wave, int64_t num_tiles,
-                int64_t tiles_per_xcd, int swizzle, int accumulate, const T *__restrict__ w, double *__restrict__ dot_partial)
+                int64_t tiles_per_xcd, int swizzle, int accumulate, const T *__restrict__ w, double *__restrict__ dot_partial, int dot_ablate = 0)
 {
+    // dot_ablate (measurements only, $CMI_DOT_ABLATE; WRONG <y, w> by design): bit 1 -- w is not loaded; bit 2 -- no workgroup combine (no
+    // barrier: wave 0 stores its own partial)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double dot_slots[DOT ? 1024 / kWave : 1];
     constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
@@ -477,7 +481,7 @@ csr_wave_kernel(int64_t num_rows, const int *Ap /* not restrict: see the asm bel
         const int cnt = nz1 - nz0;
         int a = Ap[r0 + (lane < nr ? lane : nr)];
         T wv = T(0);
-        if constexpr (DOT) { if (lane < nr) wv = w[r0 + lane]; }
+        if constexpr (DOT) { if (lane < nr) wv = (dot_ablate & 1) ? T(1) : w[r0 + lane]; }
         if (cnt > 0 && cnt <= kWave * K) { // (uniform per wave)
             T *mine = reinterpret_cast<T *>(smem) + (size_t)wave * kWave * K;
             int c[K];
@@ -502,16 +506,48 @@ csr_wave_kernel(int64_t num_rows, const int *Ap /* not restrict: see the asm bel
                 st<NTS>(y + r0 + lane, s);
                 if constexpr (DOT) d = (double)s * (double)wv;
             }
-        } else if (lane < nr) {
-            const int b = Ap[r0 + lane + 1];
-            T s = accumulate ? y[r0 + lane] : T(0);
-            for (int j = a; j < b; j++) s = s + Ax[j] * x[Aj[j]];
+        } else if (cnt > 0) {
+            // The tile does not fit the wave's 64 K slots (rows longer than the caller's K -- a plan-less call knows only the MEAN row
+            // length): the same body in PASSES of 64 K entries, every lane carrying its row's running sum across the passes and adding the
+            // part of its row that lies inside the current one -- still the host loop's order, so still its bits; a row of thousands of
+            // entries costs one lane a long serial sum (what csr_stream's threads_per_row = 1 costs too).  Round 4: this is what lets a
+            // plan-less multiply take the wave-tile kernel without knowing the longest row.
+            T *mine = reinterpret_cast<T *>(smem) + (size_t)wave * kWave * K;
+            const int b = __builtin_amdgcn_update_dpp(nz1, a, 0x130, 0xf, 0xf, false);
+            T s = (accumulate && lane < nr) ? y[r0 + lane] : T(0);
+            for (int base = nz0; base < nz1; base += kWave * K) {
+                T pr[K];
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const int i = base + k * kWave + lane;
+                    const int e = i < nz1 ? i : nz0;
+                    pr[k] = ld<NT>(Ax + e) * x[ld<NT>(Aj + e)];
+                }
+#pragma unroll
+                for (int k = 0; k < K; k++) mine[k * kWave + lane] = pr[k];
+                __builtin_amdgcn_wave_barrier();
+                if (lane < nr) {
+                    const int lo = a > base ? a : base, hi = b < base + kWave * K ? b : base + kWave * K;
+                    for (int j = lo; j < hi; j++) s = s + mine[j - base];
+                }
+                __builtin_amdgcn_wave_barrier(); // (the next pass overwrites the slots: in order behind these reads on the hardware)
+            }
+            if (lane < nr) {
+                st<NTS>(y + r0 + lane, s);
+                if constexpr (DOT) d = (double)s * (double)wv;
+            }
+        } else if (lane < nr) { // no entry in these rows
+            const T s = accumulate ? y[r0 + lane] : T(0);
             st<NTS>(y + r0 + lane, s);
             if constexpr (DOT) d = (double)s * (double)wv;
         }
     }
     if constexpr (DOT) {
-        tile_dot_store(d, dot_slots, dot_partial + tile);
+        if (dot_ablate & 2) {
+            d = wave_sum_to_last(d);
+            if (threadIdx.x == kWave - 1) dot_partial[tile] = d;
+        } else
+            tile_dot_store(d, dot_slots, dot_partial + tile);
         if (tile == 0 && threadIdx.x == 0) reset_fold_state(dot_partial);
     }
 }
@@ -1393,8 +1429,41 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     if (plan) {
         c = plan->cfg; // resolved at plan creation (table / caller's config, completed; balanced if the profile says so)
         known_max_len = plan->prof.max_len;
-    } else
+        // A plan is made from the row offsets (and columns) alone: an AUTO plan that chose a wave-tile kernel with 16-byte loads never saw Aj, Ax
+        // or x.  Arrays that are not 16-byte aligned (offset views, sliced tensors) then run the table's row-tile kernel, which takes any
+        // alignment -- as they did before those kernels existed.  A kernel the caller ASKED for keeps its hard error below.
+        if ((c.kernel == CMI_CSR_STREAM_WAVEV || c.kernel == CMI_CSR_STREAM_WAVEX || c.kernel == CMI_CSR_STREAM_WAVER) && !plan->kernel_asked) {
+            const bool aligned = reinterpret_cast<uintptr_t>(Aj) % 16 == 0 && reinterpret_cast<uintptr_t>(Ax) % 16 == 0 &&
+                                 (c.kernel != CMI_CSR_STREAM_WAVEX || reinterpret_cast<uintptr_t>(x) % 16 == 0);
+            if (!aligned) select_config(CMI_FORMAT_CSR, dtype, rows, cols, nnz, nullptr, &c);
+        }
+    } else {
         select_config(CMI_FORMAT_CSR, dtype, rows, cols, nnz, user, &c);
+        // PLAN-LESS and no kernel asked for (the literal replacement of the reference's selector, csr_vector_spmv.h:225-258: arrays in,
+        // launch out, nothing measured): where the table says csr_stream and the MEAN row length sits within 2 % below an integer K <= 10 --
+        // what a stencil looks like from its sizes alone -- the wave-tile kernel runs with K entries per lane, the shape a plan would give
+        // it (the plan-less call ran csr_stream at 0.80 where the plan's csr_wave gets 0.84).  A matrix that only LOOKS
+        // like one (irregular rows whose mean happens to qualify) is still correct and still streams: tiles that overflow their 64 K slots
+        // take a second pass.  $CMI_PLANLESS_WAVE=0: never.
+        static const int planless_wave = [] { const char *e = std::getenv("CMI_PLANLESS_WAVE"); return e ? std::atoi(e) : 1; }();
+        if (planless_wave && (!user || (user->kernel == CMI_KERNEL_AUTO && !user->block_size && !user->rows_per_block && !user->items_per_thread && !user->threads_per_row)) &&
+            c.kernel == CMI_CSR_STREAM && c.threads_per_row <= 1 && rows >= 4096 && nnz > 0) {
+            const double mean = (double)nnz / (double)rows;
+            const int k = (int)std::ceil(mean);
+            if (k >= 2 && k <= kWaveTileMaxK && mean >= 0.98 * k) {
+                c.kernel = CMI_CSR_STREAM_WAVE;
+                c.block_size = 256;
+                c.rows_per_block = 256;
+                c.items_per_thread = k;
+                c.threads_per_row = 0;
+                c.nontemporal &= ~kPolStrided;
+                if (!(user && user->nontemporal)) {
+                    if (nnz * (int64_t)(sizeof(int) + sizeof(T)) > kInfinityCacheBytes + kInfinityCacheBytes / 4) c.nontemporal |= kPolLoadNT;
+                    c.nontemporal |= kPolStoreNT;
+                }
+            }
+        }
+    }
     hipStream_t s = as_stream(stream);
     const int block = c.block_size;
     int pol = c.nontemporal & 3;
@@ -1543,11 +1612,12 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         const size_t lds = (size_t)block * K * sizeof(T);
         if (lds > 64 * 1024) return fail(CMI_ERROR_INVALID_VALUE, "csr_wave: block_size x items_per_thread products do not fit 64 KiB of LDS");
         const bool dot = w && dot_partial && tiles <= kPartialCapacity;
+        static const int dot_ablate = [] { const char *e = std::getenv("CMI_DOT_ABLATE"); return e ? std::atoi(e) : 0; }();
         with_policy(pol, [&](auto P) {
             constexpr int POL = decltype(P)::value;
             auto go = [&](auto KK) {
                 constexpr int KC = decltype(KK)::value;
-                if (dot) hipLaunchKernelGGL((csr_wave_kernel<T, KC, POL, true>), dim3((unsigned)grid64), dim3(block), lds, s, rows, Ap, Aj, Ax, x, y, rpw, tiles, tpx, swz, accumulate, w, dot_partial);
+                if (dot) hipLaunchKernelGGL((csr_wave_kernel<T, KC, POL, true>), dim3((unsigned)grid64), dim3(block), lds, s, rows, Ap, Aj, Ax, x, y, rpw, tiles, tpx, swz, accumulate, w, dot_partial, dot_ablate);
                 else     hipLaunchKernelGGL((csr_wave_kernel<T, KC, POL, false>), dim3((unsigned)grid64), dim3(block), lds, s, rows, Ap, Aj, Ax, x, y, rpw, tiles, tpx, swz, accumulate, (const T *)nullptr, (double *)nullptr);
             };
             switch (K) {
@@ -1669,6 +1739,12 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         });
         if (dot && dot_partials) *dot_partials = (int)tiles;
         break;
+    }
+    case CMI_CSR_STREAM_WAVER:
+    case CMI_CSR_STREAM_PACKED: { // the plan's run-compressed column copy on wave tiles (spmv_csr_runs.hip); Aj is read by the array-tail fall-back only
+        if (!plan) return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_CSR_STREAM_WAVER / _PACKED run through a plan of cmi_plan_create_csr only");
+        if constexpr (std::is_same<T, double>::value) return csr_runs_multiply_f64(plan, Ap, Aj, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol, c.xcd_swizzle);
+        else return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_CSR_STREAM_WAVER / _PACKED are f64 kernels");
     }
     case CMI_CSR_STREAM_C16: { // the plan's 16-bit column copy (spmv_csr16.hip); Aj itself is not read
         if (!plan || !plan->csr16_cols) return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_CSR_STREAM_C16 runs through a plan of cmi_plan_create_csr only");

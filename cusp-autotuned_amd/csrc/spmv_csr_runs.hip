@@ -1,0 +1,396 @@
+// spmv_csr_runs.hip -- CSR SpMV on the plan's RUN-COMPRESSED copy of the column indices (CMI_CSR_STREAM_WAVER, round 4; f64).
+//
+// FEM and KKT matrices store their columns in short consecutive runs -- three degrees of freedom per node give runs of 3, 6, 9 ...; a
+// 27-point coupling is nine runs of 3 (measured on the configs[3] stand-ins, profiles/r04_column_runs.txt: ldoor-like 5.9 entries per
+// run, nlpkkt120-like 2.9, thermal2-like 1.7).  For such rows the 4 bytes of column index per entry are mostly redundant, and -- what the
+// round-3 ablation found to be the whole gap of this class to CSR's bare streams -- every entry costs its own 8-byte
+// gather of x.  A plan made WITH the column indices therefore cuts every row into PIECES of 1..4 consecutive columns and keeps, on the
+// device,
+//     piece[q]  = (first column << 2) | (length - 1)                         4 bytes per piece = 1.25-1.4 bytes per entry on those matrices
+//     start[t]  = {first row, first entry, first piece} of wave tile t       16 bytes per tile of ~950 entries
+// and the multiply reads those instead of Aj: the index stream shrinks to a third, and a piece's x values arrive with TWO 16-byte loads
+// per piece (x[c], x[c+1] and x[c+len-2], x[c+len-1]: branch-free for every length) instead of one 8-byte gather per entry.
+// The VALUES stay the caller's array (a caller may refresh values in place; nothing of them is cached) and are streamed exactly as
+// csr_wavev streams them: (double2) pairs, every line requested once.  The x values of a piece meet the values of its entries in the
+// wave's LDS region: pieces -> x values written at their entries' slots -> each lane multiplies its own value pairs in place -> the lanes
+// that own a row add it in storage order.  Same products, same order of summation as sequential/multiply/csr_spmv.h:56-73: bit-exact.
+// Replaces (reference): the fixed T = 32 selector of cusp/system/cuda/detail/multiply/csr_vector_spmv.h:225-258 and the __ldg gathers of
+// cusp/system/cuda/ktt/kernels/csr_kernel.h:63-109 for this class of matrices.
+//
+// PACKED (CMI_CSR_STREAM_PACKED, opt-in, plans made with the VALUES too): per wave tile the pieces and the values are laid side by side
+// in ONE plan-owned buffer -- [pieces | pad to 16 | values | pad to 16] -- so that a wave's requests are one contiguous span of HBM
+// (one stream reads at 7.1-7.3 TB/s, two arrays side by side at 6.4-6.6).  The plan then owns a copy of the values:
+// refresh the values => make a new plan (cmi_plan_validate checks them).
+#include "common.h"
+#include <rocprim/rocprim.hpp>
+
+namespace cmi {
+
+constexpr int kRunCap = 4;            // entries per piece at most (2 bits of the descriptor)
+constexpr int64_t kRunMaxCols = (int64_t)1 << 30;
+
+typedef double __attribute__((ext_vector_type(2), aligned(8))) double2u; // 16 bytes of x from an 8-byte aligned address: one global_load_dwordx4
+typedef int __attribute__((ext_vector_type(4))) start_t;
+
+// ---- plan time -------------------------------------------------------------------------------------------------------
+// pieces of row r: maximal runs of consecutive columns, cut every kRunCap entries
+__global__ void __launch_bounds__(256) runs_count_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ Aj, int *__restrict__ count)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= num_rows) return;
+    const int a = Ap[r], b = Ap[r + 1];
+    int n = 0, len = 0, prev = 0;
+    for (int j = a; j < b; j++) {
+        const int c = Aj[j];
+        if (len == 0 || c != prev + 1 || len == kRunCap) { n++; len = 0; }
+        len++;
+        prev = c;
+    }
+    count[r] = n;
+}
+
+__global__ void __launch_bounds__(256) runs_fill_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ Aj, const int *__restrict__ offset,
+                                                        uint32_t *__restrict__ pieces)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= num_rows) return;
+    const int a = Ap[r], b = Ap[r + 1];
+    int q = offset[r] - 1, len = 0, prev = 0, first = 0;
+    for (int j = a; j < b; j++) {
+        const int c = Aj[j];
+        if (len == 0 || c != prev + 1 || len == kRunCap) {
+            if (len > 0) pieces[q] = ((uint32_t)first << 2) | (uint32_t)(len - 1);
+            q++;
+            len = 0;
+            first = c;
+        }
+        len++;
+        prev = c;
+    }
+    if (len > 0) pieces[q] = ((uint32_t)first << 2) | (uint32_t)(len - 1);
+}
+
+// tile t = the rows whose FIRST entry lies in [t q, (t + 1) q) (wave_partition_kernel's rule, spmv_csr.hip); {row, entry, piece, 0} per tile
+__global__ void __launch_bounds__(256)
+runs_partition_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ piece_offset, int q, int64_t tiles, int32_t *__restrict__ start)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > num_rows) return;
+    const int64_t prev = r == 0 ? -1 : (int64_t)(Ap[r - 1] / q);
+    const int e = Ap[r];
+    const int64_t mine = r == num_rows ? tiles : (int64_t)(e / q);
+    const int pc = piece_offset[r];
+    for (int64_t t = prev + 1; t <= mine; t++) { start[4 * t] = (int32_t)r; start[4 * t + 1] = e; start[4 * t + 2] = pc; start[4 * t + 3] = 0; }
+}
+
+// PACKED: bytes / 16 of tile t's span = pieces padded to 16 bytes + values padded to 16 bytes
+__global__ void __launch_bounds__(256) runs_span_kernel(int64_t tiles, const int32_t *__restrict__ start, int *__restrict__ span16)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles) return;
+    const int np = start[4 * (t + 1) + 2] - start[4 * t + 2], cnt = start[4 * (t + 1) + 1] - start[4 * t + 1];
+    span16[t] = (np + 3) / 4 + (cnt + 1) / 2;
+}
+// one wave per tile copies its pieces and values into the tile's span; start[t].w <- the span's offset in 16-byte units
+template <typename T>
+__global__ void __launch_bounds__(256)
+runs_pack_kernel(int64_t tiles, int32_t *__restrict__ start, const int *__restrict__ off16, const uint32_t *__restrict__ pieces, const T *__restrict__ Ax,
+                 unsigned char *__restrict__ packed)
+{
+    const int64_t t = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    const int lane = threadIdx.x & (kWave - 1);
+    if (t > tiles) return;
+    if (t == tiles) { if (lane == 0) start[4 * t + 3] = off16[t]; return; } // (the sentinel: where the buffer ends)
+    const int p0 = start[4 * t + 2], np = start[4 * (t + 1) + 2] - p0, nz0 = start[4 * t + 1], cnt = start[4 * (t + 1) + 1] - nz0;
+    unsigned char *span = packed + (size_t)off16[t] * 16;
+    uint32_t *pc = reinterpret_cast<uint32_t *>(span);
+    const int np4 = (np + 3) & ~3;
+    for (int i = lane; i < np4; i += kWave) pc[i] = i < np ? pieces[p0 + i] : 0u;
+    T *vals = reinterpret_cast<T *>(span + (size_t)np4 * 4);
+    constexpr int per16 = 16 / (int)sizeof(T);
+    const int cntp = (cnt + per16 - 1) / per16 * per16;
+    for (int i = lane; i < cntp; i += kWave) vals[i] = i < cnt ? Ax[nz0 + i] : T(0);
+    if (lane == 0) start[4 * t + 3] = off16[t];
+}
+
+static int device_exclusive_scan(const int *in, int *out, size_t n, hipStream_t s)
+{
+    size_t bytes = 0;
+    void *tmp = nullptr;
+    hipError_t e = rocprim::exclusive_scan(nullptr, bytes, in, out, 0, n, rocprim::plus<int>(), s);
+    if (e == hipSuccess) e = hipMalloc(&tmp, bytes ? bytes : 16);
+    if (e == hipSuccess) e = rocprim::exclusive_scan(tmp, bytes, in, out, 0, n, rocprim::plus<int>(), s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (tmp) (void)hipFree(tmp);
+    return e == hipSuccess ? (int)CMI_SUCCESS : hip_fail(e, "cmi_plan_create: run-compressed columns (scan)");
+}
+
+// Gives `p` (a CSR plan with a measured row profile) the run-compressed column copy on wave tiles of 256 v slots.  On success
+// p->runs_start / runs_pieces are set (and runs_packed when `values` is given).  *mean_piece: entries per piece (the caller decides
+// whether that pays).  Nothing is kept when min_mean_piece is not reached.  Synchronises `s`.
+int csr_runs_build(cmi_plan *p, const int *Ap, const int *Aj, int v, double min_mean_piece, const void *values, hipStream_t s, double *mean_piece)
+{
+    const int64_t rows = p->rows, nnz = p->nnz;
+    if (mean_piece) *mean_piece = 0.0;
+    if (rows <= 0 || nnz <= 0 || nnz > INT32_MAX - 65536 || p->cols < 2 || p->cols >= kRunMaxCols || p->prof.max_len < 1) return CMI_SUCCESS;
+    const int q = 256 * v - (int)p->prof.max_len - 3;
+    if (q < 1) return CMI_SUCCESS;
+    int *count = nullptr;
+    hipError_t e = hipMalloc((void **)&count, (size_t)(rows + 1) * sizeof(int));
+    if (e != hipSuccess) return hip_fail(e, "cmi_plan_create: run-compressed columns");
+    e = hipMemsetAsync(count + rows, 0, sizeof(int), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(runs_count_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, s, rows, Ap, Aj, count);
+        e = hipGetLastError();
+    }
+    int st = e == hipSuccess ? (int)CMI_SUCCESS : hip_fail(e, "cmi_plan_create: run-compressed columns");
+    if (st == CMI_SUCCESS) st = device_exclusive_scan(count, count, (size_t)rows + 1, s); // in place: count[r] <- pieces before row r
+    int total = 0;
+    if (st == CMI_SUCCESS) {
+        e = hipMemcpy(&total, count + rows, sizeof(int), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) st = hip_fail(e, "cmi_plan_create: run-compressed columns");
+    }
+    uint32_t *pieces = nullptr;
+    int32_t *start = nullptr;
+    const int64_t tiles = nnz / q + 1;
+    if (st == CMI_SUCCESS && total > 0) {
+        if (mean_piece) *mean_piece = (double)nnz / (double)total;
+        if ((double)nnz / (double)total < min_mean_piece) { (void)hipFree(count); return CMI_SUCCESS; }
+        e = hipMalloc((void **)&pieces, ((size_t)total + 64) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(pieces + total, 0, 64 * sizeof(uint32_t), s);
+        if (e == hipSuccess) e = hipMalloc((void **)&start, (size_t)(tiles + 1) * 4 * sizeof(int32_t));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(runs_fill_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, s, rows, Ap, Aj, count, pieces);
+            hipLaunchKernelGGL(runs_partition_kernel, dim3((unsigned)ceil_div(rows + 1, 256)), dim3(256), 0, s, rows, Ap, count, q, tiles, start);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) st = hip_fail(e, "cmi_plan_create: run-compressed columns");
+    }
+    (void)hipFree(count);
+    unsigned char *packed = nullptr;
+    int64_t packed_bytes = 0;
+    if (st == CMI_SUCCESS && pieces && values) { // PACKED: spans per tile -> offsets -> the copy
+        int *span = nullptr;
+        e = hipMalloc((void **)&span, (size_t)(tiles + 1) * sizeof(int));
+        if (e == hipSuccess) e = hipMemsetAsync(span + tiles, 0, sizeof(int), s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(runs_span_kernel, dim3((unsigned)ceil_div(tiles, 256)), dim3(256), 0, s, tiles, start, span);
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) st = hip_fail(e, "cmi_plan_create: packed tiles");
+        if (st == CMI_SUCCESS) st = device_exclusive_scan(span, span, (size_t)tiles + 1, s);
+        int end16 = 0;
+        if (st == CMI_SUCCESS) {
+            e = hipMemcpy(&end16, span + tiles, sizeof(int), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) st = hip_fail(e, "cmi_plan_create: packed tiles");
+        }
+        if (st == CMI_SUCCESS && end16 < 0) st = fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: the packed copy would exceed 32 GiB");
+        if (st == CMI_SUCCESS) {
+            packed_bytes = (int64_t)end16 * 16 + 64 * 16; // (+ slack: a wave's clamped request never leaves the buffer)
+            e = hipMalloc((void **)&packed, (size_t)packed_bytes);
+            if (e == hipSuccess) e = hipMemsetAsync(packed + (size_t)end16 * 16, 0, 64 * 16, s);
+            if (e == hipSuccess) {
+                const unsigned grid = (unsigned)ceil_div(tiles + 1, 4);
+                if (p->dtype == CMI_F64) hipLaunchKernelGGL((runs_pack_kernel<double>), dim3(grid), dim3(256), 0, s, tiles, start, span, pieces, (const double *)values, packed);
+                else hipLaunchKernelGGL((runs_pack_kernel<float>), dim3(grid), dim3(256), 0, s, tiles, start, span, pieces, (const float *)values, packed);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) st = hip_fail(e, "cmi_plan_create: packed tiles");
+        }
+        if (span) (void)hipFree(span);
+    }
+    if (st != CMI_SUCCESS || !pieces) {
+        if (pieces) (void)hipFree(pieces);
+        if (start) (void)hipFree(start);
+        if (packed) (void)hipFree(packed);
+        return st;
+    }
+    p->runs_start = start;
+    p->runs_pieces = pieces;
+    p->runs_count = total;
+    p->runs_packed = packed;
+    p->runs_packed_bytes = packed_bytes;
+    p->wave_tiles = tiles;
+    p->wave_q = q;
+    return CMI_SUCCESS;
+}
+
+// ---- the multiply ------------------------------------------------------------------------------------------------------
+// One 64-lane wave per tile, four tiles per workgroup, no workgroup barrier (csr_wavev's structure, spmv_csr.hip).  V: 256 V request slots
+// per tile.  NPC: piece chunks (of 64) handled by the unrolled, branch-free first pass -- a tile with more pieces (short runs) takes
+// further turns of a plain loop.  PACKED: pieces and values come from the plan's one-span-per-tile buffer.
+template <int V, int POL, bool DOT, bool PACKED>
+__global__ void __launch_bounds__(256)
+csr_waver_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t num_entries, int num_cols, const int *Ap /* not restrict: see csr_wave */,
+                 const int *__restrict__ Aj, const uint32_t *__restrict__ pieces, const double *__restrict__ Ax, const unsigned char *__restrict__ packed,
+                 const double *__restrict__ x, double *__restrict__ y, int64_t num_tiles, int64_t tiles_per_xcd, int swizzle, int accumulate,
+                 const double *__restrict__ w, double *__restrict__ dot_partial)
+{
+    typedef double T;
+    constexpr int E = 2, NL = (V * 4) / E, SLOTS = kWave * V * 4, NPC = V == 4 ? 6 : V == 2 ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) T prod[4][SLOTS];
+    __shared__ double dot_slots[DOT ? 4 : 1];
+    constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
+    const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle);
+    if (tile >= num_tiles) return; // whole workgroup
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x & (kWave - 1);
+    const int64_t wt = tile * 4 + wave;
+    double d = 0.0;
+    if (wt < wave_tiles) {
+        const start_t lo = *reinterpret_cast<const start_t *>(start + 4 * wt), hi = *reinterpret_cast<const start_t *>(start + 4 * wt + 4);
+        const int rs = lo.x, nz0 = lo.y, p0 = lo.z, re = hi.x, nz1 = hi.y, p1 = hi.z; // this tile's and the next one's {row, entry, piece}: one scalar hop
+        const int nr = re - rs;
+        if (nr > 0) { // (uniform per wave)
+            const int np = p1 - p0;
+            // where the tile's pieces and values lie, and the slot of its first entry
+            const uint32_t *pc;
+            const T *vbase; // value of slot i = vbase[i]
+            int shift, cnt; // first entry's slot; slots that hold entries of this (or, below `shift`, the previous) tile
+            bool fits;
+            if constexpr (PACKED) {
+                const unsigned char *span = packed + (size_t)(unsigned)lo.w * 16;
+                pc = reinterpret_cast<const uint32_t *>(span);
+                vbase = reinterpret_cast<const T *>(span + (size_t)((np + 3) & ~3) * 4);
+                shift = 0;
+                cnt = nz1 - nz0;
+                fits = cnt > 0 && cnt <= SLOTS;
+            } else {
+                const int fbase = nz0 & ~(E - 1);
+                pc = pieces + p0;
+                vbase = Ax + fbase;
+                shift = nz0 - fbase;
+                cnt = nz1 - fbase;
+                fits = nz1 > nz0 && (int64_t)((nz1 + E - 1) & ~(E - 1)) <= num_entries && cnt <= SLOTS; // (the ARRAY's last pair may reach past it)
+            }
+            const int first_turn_end = Ap[rs + (nr < kWave ? nr : kWave)]; // (scalar) where the 64th row of the tile ends
+            int a = Ap[rs + (lane < nr ? lane : nr)], b = 0;
+            T *mine = prod[wave];
+            if (fits) {
+                const int last = (cnt - 1) & ~(E - 1); // the last pair that holds an entry of the tile; lanes past it re-read it
+                const int lastp = np - 1;
+                // ---- requests: the pieces first (their chain is the longest: piece -> x -> LDS), then the value pairs ----
+                uint32_t dsc[NPC];
+#pragma unroll
+                for (int k = 0; k < NPC; k++) {
+                    const int i = k * kWave + lane;
+                    dsc[k] = ld<NT>(pc + (i < lastp ? i : lastp));
+                }
+                double2v v[NL];
+#pragma unroll
+                for (int k = 0; k < NL; k++) {
+                    int e = (k * kWave + lane) * E;
+                    e = e < last ? e : last;
+                    v[k] = ld<NT>(reinterpret_cast<const double2v *>(vbase + e));
+                }
+                __builtin_amdgcn_sched_barrier(0); // every stream request is out before the first x address is formed
+                // ---- x: two 16-byte loads per piece, whatever its length ----
+                int run = shift; // slot of the next piece's first entry (uniform)
+                int o[NPC], len[NPC], sel[NPC];
+                double2u xa[NPC], xb[NPC];
+#pragma unroll
+                for (int k = 0; k < NPC; k++) {
+                    const bool valid = k * kWave + lane < np;
+                    len[k] = valid ? (int)(dsc[k] & 3u) + 1 : 0;
+                    const int incl = wave_inclusive_sum(len[k]);
+                    o[k] = run + incl - len[k];
+                    run += __builtin_amdgcn_readlane(incl, kWave - 1);
+                    const int cs = (int)(dsc[k] >> 2);
+                    const int ca = cs < num_cols - 2 ? cs : num_cols - 2; // (a piece of one entry in the last column: the pair before it)
+                    sel[k] = cs - ca;
+                    const int cb = ca + (len[k] > 2 ? len[k] - 2 : 0);
+                    xa[k] = *reinterpret_cast<const double2u *>(x + ca);
+                    xb[k] = *reinterpret_cast<const double2u *>(x + cb);
+                }
+#pragma unroll
+                for (int k = 0; k < NPC; k++) {
+                    if (len[k] >= 1) mine[o[k]] = sel[k] ? xa[k].y : xa[k].x;
+                    if (len[k] >= 2) {
+                        mine[o[k] + 1] = xa[k].y;
+                        mine[o[k] + len[k] - 2] = xb[k].x;
+                        mine[o[k] + len[k] - 1] = xb[k].y;
+                    }
+                }
+                for (int base = NPC * kWave; base < np; base += kWave) { // (a tile of short runs: further chunks, one at a time)
+                    const int i = base + lane;
+                    const uint32_t ds = pc[i < lastp ? i : lastp];
+                    const int ln = i < np ? (int)(ds & 3u) + 1 : 0;
+                    const int incl = wave_inclusive_sum(ln);
+                    const int oo = run + incl - ln;
+                    run += __builtin_amdgcn_readlane(incl, kWave - 1);
+                    const int cs = (int)(ds >> 2);
+                    const int ca = cs < num_cols - 2 ? cs : num_cols - 2;
+                    const int cb = ca + (ln > 2 ? ln - 2 : 0);
+                    const double2u A = *reinterpret_cast<const double2u *>(x + ca), B = *reinterpret_cast<const double2u *>(x + cb);
+                    if (ln >= 1) mine[oo] = (cs - ca) ? A.y : A.x;
+                    if (ln >= 2) { mine[oo + 1] = A.y; mine[oo + ln - 2] = B.x; mine[oo + ln - 1] = B.y; }
+                }
+                asm volatile("" : "+v"(a)); // the row offset was requested in front of the streams
+                __builtin_amdgcn_wave_barrier(); // (compiler only: the hardware runs a wave's LDS instructions in order)
+                // ---- products, in place: lane l owns the slot pairs l, l + 64, ... ----
+#pragma unroll
+                for (int k = 0; k < NL; k++) {
+                    double2v *slot = reinterpret_cast<double2v *>(mine + (k * kWave + lane) * E);
+                    const double2v xs = *slot;
+                    *slot = double2v{v[k].x * xs.x, v[k].y * xs.y};
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            b = __builtin_amdgcn_update_dpp(first_turn_end, a, 0x130 /* wave_shl:1: the next lane's start; lane 63 keeps the 64th row's end */, 0xf, 0xf, false);
+            const int slot0 = nz0 - shift; // entry index of slot 0
+            for (int r = lane; r < nr; r += kWave) { // (one turn, except over a stretch of very short rows)
+                if (r >= kWave) { a = Ap[rs + r]; b = Ap[rs + r + 1]; }
+                T sum = accumulate ? y[rs + r] : T(0);
+                if (fits) sum = sum_in_order(sum, mine + (a - slot0), b - a);
+                else for (int j = a; j < b; j++) sum = sum + Ax[j] * x[Aj[j]]; // (the array's last pair, or an empty tile)
+                st<NTS>(y + rs + r, sum);
+                if constexpr (DOT) d += (double)sum * (double)w[rs + r];
+            }
+        }
+    }
+    if constexpr (DOT) {
+        tile_dot_store(d, dot_slots, dot_partial + tile);
+        if (tile == 0 && threadIdx.x == 0) reset_fold_state(dot_partial);
+    }
+}
+
+int csr_runs_multiply_f64(const cmi_plan *p, const int *Ap, const int *Aj, const double *Ax, const double *x, double *y, int accumulate, hipStream_t s,
+                          const double *w, double *dot_partial, int *dot_partials, int pol, int swz_in)
+{
+    if (!p->runs_start || !p->runs_pieces) return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_CSR_STREAM_WAVER / _PACKED run through a plan of cmi_plan_create_csr only");
+    const bool packed = p->cfg.kernel == CMI_CSR_STREAM_PACKED;
+    if (packed && !p->runs_packed) return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_CSR_STREAM_PACKED: the plan holds no packed copy (cmi_plan_create_csr_values)");
+    if (!packed && reinterpret_cast<uintptr_t>(Ax) % 16 != 0) return fail(CMI_ERROR_INVALID_VALUE, "csr_waver: Ax must be 16-byte aligned");
+    if (reinterpret_cast<uintptr_t>(x) % 8 != 0) return fail(CMI_ERROR_INVALID_VALUE, "csr_waver: x must be 8-byte aligned");
+    const int V = p->cfg.items_per_thread;
+    if (V != 1 && V != 2 && V != 4) return fail(CMI_ERROR_NOT_SUPPORTED, "csr_waver: items_per_thread must be 1, 2 or 4");
+    const int64_t tiles = ceil_div(p->wave_tiles, (int64_t)4);
+    const int64_t tpx = ceil_div(tiles, kXcds);
+    const int swz = swz_in < 0 ? 0 : swz_in;
+    const int64_t grid64 = padded_grid(tiles, swz);
+    if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "csr_waver: grid too large");
+    const bool dot = w && dot_partial && tiles <= kPartialCapacity;
+    with_policy(pol, [&](auto P) {
+        constexpr int POL = decltype(P)::value;
+        auto go = [&](auto VV, auto PK) {
+            constexpr int VC = decltype(VV)::value;
+            constexpr bool PKC = decltype(PK)::value;
+            if (dot) hipLaunchKernelGGL((csr_waver_kernel<VC, POL, true, PKC>), dim3((unsigned)grid64), dim3(256), 0, s, p->runs_start, p->wave_tiles, p->nnz, (int)p->cols, Ap, Aj, p->runs_pieces, Ax, p->runs_packed, x, y, tiles, tpx, swz, accumulate, w, dot_partial);
+            else     hipLaunchKernelGGL((csr_waver_kernel<VC, POL, false, PKC>), dim3((unsigned)grid64), dim3(256), 0, s, p->runs_start, p->wave_tiles, p->nnz, (int)p->cols, Ap, Aj, p->runs_pieces, Ax, p->runs_packed, x, y, tiles, tpx, swz, accumulate, (const double *)nullptr, (double *)nullptr);
+        };
+        auto by_v = [&](auto PK) {
+            switch (V) {
+            case 1: go(std::integral_constant<int, 1>(), PK); break;
+            case 2: go(std::integral_constant<int, 2>(), PK); break;
+            default: go(std::integral_constant<int, 4>(), PK); break;
+            }
+        };
+        if (packed) by_v(std::true_type()); else by_v(std::false_type());
+    });
+    if (dot && dot_partials) *dot_partials = (int)tiles;
+    CMI_LAUNCH_CHECK("csr_waver");
+    return CMI_SUCCESS;
+}
+
+} // namespace cmi

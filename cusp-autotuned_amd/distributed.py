@@ -82,16 +82,26 @@ class ShardedVectorExchange:
             from . import binding as B
             import os
             import sys
+            # Making the communicator is COLLECTIVE (ncclCommInitRank inside cmi_comm_create): a rank that cannot enter it must say so BEFORE
+            # the others do, or they wait for it for ever.  So the ranks first agree that every one of them can bind RCCL -- a
+            # local, non-collective check -- and only then call it.
             ok, why = 1, ""
             if os.environ.get("CMI_PYTHON_COMM", "1") == "0":
                 ok, why = 0, "CMI_PYTHON_COMM=0"
             else:
                 try:
-                    self.comm = B.Comm.from_torch_distributed(group)
-                except Exception as e:  # noqa: BLE001 -- e.g. librccl not loadable: every rank must then take the same way out
+                    B.comm_library_version()
+                except Exception as e:  # noqa: BLE001 -- librccl not loadable on this rank
                     ok, why = 0, f"{type(e).__name__}: {e}"
             flag = torch.tensor([ok], dtype=torch.int32, device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 1:
+                try:
+                    self.comm = B.Comm.from_torch_distributed(group)
+                except Exception as e:  # noqa: BLE001 -- an error every rank sees alike (argument check) or one the init itself reports
+                    ok, why = 0, f"{type(e).__name__}: {e}"
+                flag = torch.tensor([ok], dtype=torch.int32, device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
             if int(flag.item()) == 0:
                 if rank == 0 or why:
                     print(f"[cusp-autotuned_amd] rank {rank}: the C-ABI communicator is not used ({why or 'another rank could not make it'}); "

@@ -357,7 +357,7 @@ private:
         // the table should see), or what the block's plan made of it when that is a row-tile kernel that runs without a plan
         const cmi_plan *plan = local.plan();
         have_row_cfg_ = false;
-        if (plan && cmi_plan_config(plan, &row_cfg_) == CMI_SUCCESS && (row_cfg_.kernel == CMI_CSR_STREAM || row_cfg_.kernel == CMI_CSR_STREAM_WAVE)) have_row_cfg_ = true;
+        if (plan && cmi_plan_config(plan, &row_cfg_) == CMI_SUCCESS && (row_cfg_.kernel == CMI_CSR_STREAM || (row_cfg_.kernel == CMI_CSR_STREAM_WAVE && row_cfg_.rows_per_block > 0))) have_row_cfg_ = true; // (a WAVE plan on a row partition reads rows_per_block 0: its shape is the plan's, not a plan-less call's)
         if (!have_row_cfg_) {
             cusp::detail::check(cmi_tuning_select(CMI_FORMAT_CSR, cusp::detail::dtype_code<ValueType>::value, (int64_t)local.num_rows, (int64_t)local.num_cols,
                                                   (int64_t)local.num_entries, &row_cfg_));

@@ -17,6 +17,8 @@
 
 #include <chrono>
 #include <cstring>
+#include <poll.h>
+#include <cerrno>
 #include <string>
 #include <thread>
 #include <vector>
@@ -44,7 +46,20 @@ public:
             if (::bind(ls, reinterpret_cast<sockaddr *>(&sa), sizeof(sa)) != 0) { ::close(ls); fail("bind (is the port in use? set CMI_PORT)"); }
             if (::listen(ls, world) != 0) { ::close(ls); fail("listen"); }
             peers_.assign(world, -1);
+            const auto t0 = std::chrono::steady_clock::now();
             for (int k = 1; k < world; k++) {
+                // a peer that died before connecting must not leave rank 0 in accept() for ever: wait for the listening socket with the
+                // same budget the connecting side has
+                for (;;) {
+                    const double left = timeout_s - std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    if (left <= 0.0) { ::close(ls); fail("accept: a peer did not connect in time"); }
+                    pollfd pf{};
+                    pf.fd = ls;
+                    pf.events = POLLIN;
+                    const int pr = ::poll(&pf, 1, (int)((left < 1.0 ? left : 1.0) * 1000.0) + 1);
+                    if (pr > 0) break;
+                    if (pr < 0 && errno != EINTR) { ::close(ls); fail("poll"); }
+                }
                 const int fd = ::accept(ls, nullptr, nullptr);
                 if (fd < 0) { ::close(ls); fail("accept"); }
                 nodelay(fd);

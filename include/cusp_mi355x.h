@@ -178,6 +178,22 @@ typedef enum cmi_kernel {
                                from there; columns outside the window are gathered from memory as usual.  For GATHER-BOUND band matrices
                                (columns anywhere within a few thousand of the diagonal: every x entry is its own L1 lookup otherwise).
                                items_per_thread 2 or 4.  Bit-exact.  Needs 16-byte aligned Aj / Ax / x.                                   */
+    CMI_CSR_STREAM_WAVER = 11, /* plans of cmi_plan_create_csr only (round 4), f64: CMI_CSR_STREAM_WAVEV's wave tiles reading a RUN-COMPRESSED copy of the
+                               column indices that the plan builds and owns -- every row cut into pieces of 1..4 CONSECUTIVE columns, 4 bytes
+                               per piece ((first column << 2) | (length - 1)), 16 bytes per wave tile -- instead of Aj: FEM (3 dof per node) and
+                               KKT / 27-point matrices keep their columns in runs of 3 or more, so the index stream shrinks to about a third
+                               (9.3-9.4 instead of 12 bytes per entry) and a piece's x values arrive with two 16-byte loads instead of one
+                               8-byte gather per entry.  The VALUES stay the caller's array (refreshing them in place is fine).  Same products,
+                               storage-order sums: bit-exact.  An AUTO plan made with the columns selects it when the pieces average 2.5+
+                               entries on a matrix csr_wavev's size / row-length rule admits ($CMI_CSR_WAVER=0: never, =1: whenever the rows
+                               qualify); asked for explicitly it is refused only where the tile cannot hold the longest row.  items_per_thread
+                               1, 2, 4 (0: 4) = 256 x that many slots per wave tile.  Needs fewer than 2^30 columns, no row of 512+ entries,
+                               16-byte aligned Ax, 8-byte aligned x.  cmi_plan_validate checks the column indices.                     */
+    CMI_CSR_STREAM_PACKED = 12, /* OPT-IN, plans of cmi_plan_create_csr_values only (round 4), f64: CMI_CSR_STREAM_WAVER with the pieces AND THE VALUES of
+                               every wave tile laid side by side in one plan-owned buffer ([pieces | pad to 16 | values | pad to 16] per tile),
+                               so that a wave's requests are ONE contiguous span of HBM.  The plan then owns a COPY OF THE VALUES: values
+                               refreshed in place are NOT seen -- destroy the plan and make a new one (cmi_plan_validate_values tells).
+                               Never selected by itself.  Bit-exact.                                                                   */
     /* ELL */
     CMI_ELL_ROW = 10, /* one lane per row            (ref: ell_spmv.h:55-93); threads_per_row 2,4,8,16: that many
                          lanes per row, each summing every 2nd / 4th / ... slot (ref: THREADS_PER_ROW of ktt
@@ -307,6 +323,15 @@ int cmi_plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols, i
 /* cmi_set_index_compression(1) (initial value: $CMI_COMPRESS_INDICES).  cmi_plan_config tells whether it was granted.      */
 int cmi_plan_create_csr(int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *row_offsets,
                         const int32_t *column_indices, const cmi_config *cfg, void *stream, cmi_plan **plan);
+/* ... and with the VALUES (device pointer, `dtype` elements): what cmi_plan_create_csr does, plus -- asked for by                    */
+/* cfg->kernel == CMI_CSR_STREAM_PACKED -- the packed per-tile copy of pieces and values.  Any other config: the values are ignored.  */
+int cmi_plan_create_csr_values(int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *row_offsets,
+                               const int32_t *column_indices, const void *values, const cmi_config *cfg, void *stream, cmi_plan **plan);
+/* Have the VALUES a CMI_CSR_STREAM_PACKED plan copied changed since?  (*valid_host = 1 for every other plan: nothing of the values  */
+/* is kept.)  One streaming pass, synchronises `stream`.                                                                             */
+int cmi_plan_validate_values(const cmi_plan *plan, const void *values, void *stream, int *valid_host);
+/* Bytes of device memory the plan owns (partitions, offsets, column copies, packed tiles).                                           */
+int cmi_plan_device_bytes(const cmi_plan *plan, int64_t *bytes);
 int cmi_set_index_compression(int on);
 int cmi_get_index_compression(void);
 /* HYB: launch shapes of both parts (cfg_* may be NULL) and, when the COO part's row indices are sorted (what every     */

@@ -1,0 +1,234 @@
+"""Round-4 additions on an MI355X, through the C-ABI: the run-compressed column copy (CMI_CSR_STREAM_WAVER), its packed twin
+(CMI_CSR_STREAM_PACKED), the unaligned fall-back of AUTO wave-tile plans, the plan-less wave-tile multiply."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    return torch
+
+
+def dev(a, torch):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run_csr(rng, rows, cols, lens, run_mean):
+    """CSR whose rows are made of runs of consecutive columns (geometric lengths of mean `run_mean`; run_mean <= 1: single columns),
+    columns ascending inside a row, no duplicates; the last row ends in the LAST column (a piece of one entry there is the kernel's
+    clamped x load)."""
+    Ap = np.r_[0, np.cumsum(lens)].astype(np.int32)
+    Aj = np.empty(int(Ap[-1]), np.int32)
+    for r in range(rows):
+        n = int(lens[r])
+        if n == 0:
+            continue
+        out = []
+        c = int(rng.integers(0, max(1, cols - 3 * n - 8)))
+        while len(out) < n:
+            L = 1 if run_mean <= 1 else int(min(rng.geometric(1.0 / run_mean), n - len(out)))
+            L = max(1, min(L, n - len(out)))
+            if c + L > cols:
+                break
+            out.extend(range(c, c + L))
+            c += L + int(rng.integers(1, 6))  # a gap: the next run is a new piece
+        while len(out) < n:                   # ran out of columns: fill from the row's front (still ascending, no duplicates)
+            have = set(out)
+            k = 0
+            while k in have:
+                k += 1
+            out.append(k)
+            out.sort()
+        Aj[Ap[r]:Ap[r + 1]] = np.array(sorted(out), np.int32)
+    if lens[-1] > 0:
+        row = Aj[Ap[-2]:Ap[-1]]
+        if cols - 1 not in row:
+            row[-1] = cols - 1
+    Ax = rng.standard_normal(len(Aj))
+    return Ap, Aj, Ax
+
+
+def pieces_of(Ap, Aj, cap=4):
+    n = 0
+    for r in range(len(Ap) - 1):
+        ln, prev = 0, None
+        for c in Aj[Ap[r]:Ap[r + 1]]:
+            if ln == 0 or c != prev + 1 or ln == cap:
+                n += 1
+                ln = 0
+            ln += 1
+            prev = c
+    return n
+
+
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("vectors", [0, 1, 2, 4])
+def test_waver_kernel_bit_exact(cmi, torch_cuda, orc, vectors, packed):
+    """reference arithmetic: cusp/system/detail/sequential/multiply/csr_spmv.h:42-74.  Every row of every matrix must have the host
+    loop's bits: FEM-like runs (3, 6, 9 ...), single columns only (every piece one entry: more pieces than the unrolled pass holds),
+    empty rows and a stretch of 300 of them, the longest row the tile admits, an odd entry count (the arrays' last pair), a piece of
+    one entry in the last column, accumulate, the fused <y, w>."""
+    torch = torch_cuda
+    cases = [(1, 6000, 20, 72, 3.0), (2, 3000, 1, 100, 1.0), (3, 20000, 5, 28, 2.0), (4, 4099, 0, 40, 6.0), (5, 900, 60, 125, 4.0), (6, 5000, 1, 9, 1.5)]
+    for seed, rows, lo, hi, run_mean in cases:
+        rng = np.random.default_rng(1000 * seed + vectors)
+        lens = rng.integers(lo, hi + 1, size=rows)
+        lens[rows // 3:rows // 3 + 300] = 0
+        lens[-1] = hi
+        if int(lens.sum()) % 2 == 0:
+            lens[0] += 1
+        cols = rows + 700
+        Ap, Aj, Ax = run_csr(rng, rows, cols, lens, run_mean)
+        nnz, longest = int(Ap[-1]), int(lens.max())
+        v_rule = vectors if vectors else 4
+        x = rng.standard_normal(cols)
+        y0 = rng.standard_normal(rows)
+        dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+        kern = cmi.CSR_STREAM_PACKED if packed else cmi.CSR_STREAM_WAVER
+        cfg = cmi.Config(kernel=kern, items_per_thread=vectors)
+        make = (lambda: cmi.Plan.csr_values(rows, cols, dAp, dAj, dAx, cfg)) if packed else (lambda: cmi.Plan.csr(torch.float64, rows, cols, dAp, dAj, cfg))
+        if 2 * (longest + 3) > 256 * v_rule:  # the longest row takes more than half a tile: refused, by name
+            with pytest.raises(cmi.CmiError):
+                make()
+            continue
+        plan = make()
+        c = plan.config()
+        assert (c.kernel, c.items_per_thread) == (kern, v_rule), (seed, c)
+        assert plan.info()["storage_order_sums"] is True
+        npieces = pieces_of(Ap, Aj)
+        want_bytes = 4 * (npieces + 64) + 16 * (nnz // (256 * v_rule - longest - 3) + 2)
+        assert plan.device_bytes() >= want_bytes, (plan.device_bytes(), want_bytes)  # (+ the packed tiles)
+        want, want_acc = orc.spmv_csr(Ap, Aj, Ax, x), orc.spmv_csr(Ap, Aj, Ax, x, y0)
+        y = torch.full((rows,), 9.0, dtype=torch.float64, device="cuda")
+        cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
+        assert np.array_equal(y.cpu().numpy(), want), (seed, vectors, packed)
+        y = dev(y0, torch)
+        cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y, accumulate=True)
+        assert np.array_equal(y.cpu().numpy(), want_acc), (seed, vectors, packed, "accumulate")
+        w = rng.standard_normal(rows)
+        res = torch.zeros(1, dtype=torch.float64, device="cuda")
+        y = torch.zeros(rows, dtype=torch.float64, device="cuda")
+        cmi.spmv_csr_dot(rows, cols, dAp, dAj, dAx, dx, y, dev(w, torch), res, cmi.blas_workspace(), plan=plan)
+        assert np.array_equal(y.cpu().numpy(), want), (seed, vectors, packed, "dot")
+        assert abs(res.item() - float(np.dot(want, w))) <= 1e-9 * float(np.dot(np.abs(want), np.abs(w))) + 1e-300
+        # the plan's contract: the column indices must not change in place -- and cmi_plan_validate tells when they have
+        assert plan.validate(dAp, dAj) is True
+        if packed:
+            assert plan.validate_values(dAx) is True
+            dAx2 = dAx.clone()
+            dAx2[nnz // 2] += 1.0
+            assert plan.validate_values(dAx2) is False
+        else:  # the VALUES are the caller's: refreshed in place they are seen by the next multiply
+            dAx.mul_(2.0)
+            cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
+            assert np.array_equal(y.cpu().numpy(), orc.spmv_csr(Ap, Aj, 2.0 * Ax, x)), (seed, "values refreshed in place")
+            assert plan.validate_values(dAx) is True  # (nothing of them is kept)
+        dAj2 = dAj.clone()
+        dAj2[nnz // 2] = (int(Aj[nnz // 2]) + 1) % cols
+        assert plan.validate(dAp, dAj2) is False
+
+
+def test_waver_refusals(cmi, torch_cuda):
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    rows = cols = 5000
+    Ap, Aj, Ax = run_csr(rng, rows, cols, np.full(rows, 12), 3.0)
+    dAp, dAj, dAx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch)
+    with pytest.raises(cmi.CmiError):   # without the columns
+        cmi.Plan(cmi.FORMAT_CSR, torch.float64, rows, cols, len(Aj), dAp, cmi.Config(kernel=cmi.CSR_STREAM_WAVER))
+    with pytest.raises(cmi.CmiError):   # packed without the values
+        cmi.Plan.csr(torch.float64, rows, cols, dAp, dAj, cmi.Config(kernel=cmi.CSR_STREAM_PACKED))
+    with pytest.raises(cmi.CmiError):   # f32
+        cmi.Plan.csr(torch.float32, rows, cols, dAp, dAj, cmi.Config(kernel=cmi.CSR_STREAM_WAVER))
+    with pytest.raises(cmi.CmiError):   # plan-less
+        y = torch.zeros(rows, dtype=torch.float64, device="cuda")
+        cmi.spmv_csr(rows, cols, dAp, dAj, dAx, y.clone(), y, cfg=cmi.Config(kernel=cmi.CSR_STREAM_WAVER))
+    plan = cmi.Plan.csr(torch.float64, rows, cols, dAp, dAj, cmi.Config(kernel=cmi.CSR_STREAM_WAVER))
+    x = torch.zeros(cols + 1, dtype=torch.float64, device="cuda")
+    y = torch.zeros(rows, dtype=torch.float64, device="cuda")
+    pad = torch.zeros(len(Aj) + 1, dtype=torch.float64, device="cuda")
+    pad[1:] = dAx
+    with pytest.raises(cmi.CmiError):   # an ASKED-FOR kernel keeps its alignment requirement as a hard error
+        cmi.spmv_csr_plan(plan, dAp, dAj, pad[1:], x[:cols], y)
+
+
+def test_auto_plans_fall_back_on_unaligned_arrays(cmi, torch_cuda, orc):
+    """an AUTO plan that chose a wave-tile kernel with 16-byte loads never saw Aj / Ax / x; offset views then run the table's
+    row-tile kernel (any alignment) instead of failing -- as they did before those kernels existed.  Two matrices beyond the size rule of
+    those kernels: FEM blocks (-> the run-compressed copy) and columns anywhere inside a band (-> wave tiles, with or without the x window)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import suitesparse_like as ssl
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    mats = []
+    Ap, Aj, Ax = ssl.ldoor_like(0.45)
+    mats.append(("fem blocks", Ap, Aj, Ax, (cmi.CSR_STREAM_WAVER,)))
+    rows = 800000
+    lens = rng.integers(16, 33, size=rows)
+    Ap = np.r_[0, np.cumsum(lens)].astype(np.int32)
+    ri = np.repeat(np.arange(rows, dtype=np.int64), lens)
+    Aj = np.clip(ri + rng.integers(-3000, 3001, size=len(ri)), 0, rows - 1).astype(np.int32)
+    mats.append(("band", Ap, Aj, rng.standard_normal(len(Aj)), (cmi.CSR_STREAM_WAVEV, cmi.CSR_STREAM_WAVEX)))
+    for label, Ap, Aj, Ax, kernels in mats:
+        rows = cols = len(Ap) - 1
+        nnz = len(Aj)
+        x = rng.standard_normal(cols)
+        want = orc.spmv_csr(Ap, Aj, Ax, x, omp=True)
+        dAp = dev(Ap, torch)
+        jpad = torch.zeros(nnz + 1, dtype=torch.int32, device="cuda"); jpad[1:] = dev(Aj, torch)
+        vpad = torch.zeros(nnz + 1, dtype=torch.float64, device="cuda"); vpad[1:] = dev(Ax, torch)
+        xpad = torch.zeros(cols + 1, dtype=torch.float64, device="cuda"); xpad[1:] = dev(x, torch)
+        plan = cmi.Plan.csr(torch.float64, rows, cols, dAp, jpad[1:])
+        assert plan.config().kernel in kernels, (label, plan.config())
+        y = torch.full((rows,), 3.0, dtype=torch.float64, device="cuda")
+        cmi.spmv_csr_plan(plan, dAp, jpad[1:], vpad[1:], xpad[1:], y)   # 4 / 8 bytes off a 16-byte boundary
+        assert np.array_equal(y.cpu().numpy(), want), label
+        y.fill_(3.0)
+        cmi.spmv_csr_plan(plan, dAp, dev(Aj, torch), dev(Ax, torch), dev(x, torch), y)  # aligned: the plan's own kernel
+        assert np.array_equal(y.cpu().numpy(), want), label
+
+
+@pytest.mark.parametrize("name", ["ldoor", "nlpkkt120", "thermal2"])
+def test_configs3_full_size_run_compressed(cmi, torch_cuda, orc, name):
+    """BASELINE.json configs[3] at full size through the run-compressed copy and its packed twin: asked for
+    explicitly, and what an AUTO plan made with the columns selects (WAVER where the pieces average 2.5+ entries: ldoor, nlpkkt120)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import suitesparse_like as ssl
+    torch = torch_cuda
+    Ap, Aj, Ax, source = ssl.load(name, 1.0)
+    rows = cols = len(Ap) - 1
+    nnz = len(Aj)
+    x = orc.fill_x(cols)
+    want = orc.spmv_csr(Ap, Aj, Ax, x, omp=True)
+    dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+    y = torch.empty(rows, dtype=torch.float64, device="cuda")
+    for v in (0, 2, 4) if name != "thermal2" else (0, 1, 2):
+        for packed in (False, True):
+            cfg = cmi.Config(kernel=cmi.CSR_STREAM_PACKED if packed else cmi.CSR_STREAM_WAVER, items_per_thread=v)
+            plan = cmi.Plan.csr_values(rows, cols, dAp, dAj, dAx, cfg) if packed else cmi.Plan.csr(torch.float64, rows, cols, dAp, dAj, cfg)
+            y.fill_(10.0)
+            cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
+            assert np.array_equal(y.cpu().numpy(), want), f"{name} ({source}) V={v} packed={packed}: not bit-identical to the host loop"
+            print(f"{name}: V={v} packed={packed}: plan owns {plan.device_bytes() / 1e6:.1f} MB for {12 * nnz / 1e6:.1f} MB of index + value streams")
+    auto = cmi.Plan.csr(torch.float64, rows, cols, dAp, dAj)
+    k = auto.config().kernel
+    print(f"{name}: AUTO plan made with the columns -> kernel {k}")
+    if name in ("ldoor", "nlpkkt120") and source.startswith("seeded"):
+        assert k == cmi.CSR_STREAM_WAVER, k
+    else:
+        assert k != cmi.CSR_STREAM_PACKED
+    y.fill_(10.0)
+    cmi.spmv_csr_plan(auto, dAp, dAj, dAx, dx, y)
+    assert np.array_equal(y.cpu().numpy(), want)
+    A = cmi.CsrMatrix(rows, cols, nnz, dAp, dAj, dAx)   # the containers' own path: plan made (with the columns) at the first multiply
+    y.fill_(10.0)
+    cmi.multiply(A, dx, y)
+    assert np.array_equal(y.cpu().numpy(), want)

@@ -59,6 +59,15 @@ def variants_for(A):
                 for swz in (int(s) for s in os.environ.get("PMC_WAVEV_SWZ", "0").split(",") if s):
                     out.append((f"wavev{v}" + (f"/pol{pol}" if pol else "") + (f"/swz{swz}" if swz else ""),
                                 cmi.Config(kernel=cmi.CSR_STREAM_WAVEV, items_per_thread=v, nontemporal=pol, xcd_swizzle=swz)))
+    # round 4: the run-compressed column copy on wave tiles (and its packed twin: ("values", cfg) -> a plan made with the values), the 16-bit copy
+    if hasattr(cmi, "CSR_STREAM_WAVER"):
+        for v in (int(s) for s in os.environ.get("PMC_WAVER", "4").split(",") if s):
+            for pol in (int(s) for s in os.environ.get("PMC_WAVER_POL", "0").split(",") if s):
+                out.append((f"waver{v}" + (f"/pol{pol}" if pol else ""), cmi.Config(kernel=cmi.CSR_STREAM_WAVER, items_per_thread=v, nontemporal=pol)))
+                if os.environ.get("PMC_PACKED", "1") != "0":
+                    out.append((f"packed{v}" + (f"/pol{pol}" if pol else ""), ("values", cmi.Config(kernel=cmi.CSR_STREAM_PACKED, items_per_thread=v, nontemporal=pol))))
+    if os.environ.get("PMC_C16", "0") != "0":
+        out.append(("c16", cmi.Config(kernel=cmi.CSR_STREAM_C16)))
     return out
 
 
@@ -97,11 +106,15 @@ def main():
         for label, cfg in variants_for(A):
             plan = None
             explicit = None
+            with_values = isinstance(cfg, tuple) and cfg[0] == "values"
+            if with_values:
+                cfg = cfg[1]
             if isinstance(cfg, tuple):
                 explicit, cfg = cfg[1], "explicit"
             if isinstance(cfg, cmi.Config):
                 try:
-                    plan = cmi.Plan.csr(torch.float64, rows, rows, A.row_offsets, A.column_indices, cfg=cfg)
+                    plan = (cmi.Plan.csr_values(rows, rows, A.row_offsets, A.column_indices, A.values, cfg) if with_values else
+                            cmi.Plan.csr(torch.float64, rows, rows, A.row_offsets, A.column_indices, cfg=cfg))
                 except Exception as e:  # noqa: BLE001
                     print(f"# {name} {label}: no plan ({e})")
                     continue
@@ -135,7 +148,8 @@ def main():
                     cmi.check(lib.cmi_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
                     ts.append(ms.value / 20 * 1e3)
                 t = float(np.median(ts))
-                print(f"TIME\t{name}:{label}\t{t:.1f} us\t{alg / t / 1e3:.0f} GB/s\tfrac {alg / t / 1e3 / 8000:.3f}\tbit-exact {exact}\t{desc}", flush=True)
+                owns = f"\tplan owns {plan.device_bytes() / 1e6:.1f} MB" if plan is not None and hasattr(plan, "device_bytes") else ""
+                print(f"TIME\t{name}:{label}\t{t:.1f} us\t{alg / t / 1e3:.0f} GB/s\tfrac {alg / t / 1e3 / 8000:.3f}\tbit-exact {exact}\t{desc}{owns}", flush=True)
             else:
                 torch.cuda.synchronize()
                 for _ in range(K):
