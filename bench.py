@@ -631,60 +631,115 @@ def main():
         except Exception as e:  # noqa: BLE001 -- a secondary leg
             cg_leg = {"error": f"{type(e).__name__}: {e}"[:300]}
 
-    # ---- opt-in: the plan's 16-bit column copy (CMI_CSR_STREAM_C16, csrc/spmv_csr16.hip) -- NOT the headline: `value` and
-    #      `roofline` above are the plain kernel reading the caller's 32-bit arrays.  Reported beside them because it is the one
-    #      way left to make this multiply faster: same products, same sums, same bits, 10 instead of 12 bytes per entry read.
-    c16 = None
+    # ---- opt-in plans: the 16-bit column copy (CMI_CSR_STREAM_C16, csrc/spmv_csr16.hip) and the PACKED wave tiles (CMI_CSR_STREAM_PACKED: per
+    #      tile of 64 rows one contiguous span [row starts | 16-bit columns | values]) -- NOT the headline: `value` and
+    #      `roofline` above are the plain kernel reading the caller's 32-bit arrays.  Reported beside them, replayed AND cold (the headline's
+    #      two protocols), because moving fewer bytes / one stream instead of four is the one way left to make this multiply faster: same
+    #      products, same sums, same bits.
+    def opt_in_leg(kind):
+        """kind "c16" | "packed": (dict) replay + cold timing of the headline matrix through that plan"""
+        def make(Ap_, Aj_, Ax_):
+            if kind == "c16":
+                return cmi.Plan.csr(torch.float64, A.num_rows, A.num_cols, Ap_, Aj_, cfg=cmi.Config(kernel=cmi.CSR_STREAM_C16))
+            return cmi.Plan.csr_values(A.num_rows, A.num_cols, Ap_, Aj_, Ax_, cfg=cmi.Config(kernel=cmi.CSR_STREAM_PACKED))
+        want_kernel = cmi.CSR_STREAM_C16 if kind == "c16" else cmi.CSR_STREAM_PACKED
+        pl = make(A.row_offsets, A.column_indices, A.values)
+        pc = pl.config()
+        if pc.kernel != want_kernel:
+            return {"granted": False, "why": "a row tile spans 65536+ columns or does not fit one LDS pass"}, None
+        yk = torch.full_like(y, -1.0)
+        run = lambda: cmi.spmv_csr_plan(pl, A.row_offsets, A.column_indices, A.values, x, yk)  # noqa: E731
+        for _ in range(20):
+            run()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * KERNEL_BATCHES)]
+        for bi in range(KERNEL_BATCHES):
+            ev[2 * bi].record()
+            for _ in range(per_batch):
+                run()
+            ev[2 * bi + 1].record()
+        torch.cuda.synchronize()
+        bb = [ev[2 * bi].elapsed_time(ev[2 * bi + 1]) / per_batch for bi in range(KERNEL_BATCHES)]
+        ms = sum(bb) / len(bb)
+        cmi.multiply(A, x, y)
+        wtiles = -(-A.num_rows // pc.rows_per_block)
+        if kind == "c16":
+            moved = 10 * A.num_entries + 20 * A.num_rows + 4 + 4 * wtiles
+            owned = 2 * A.num_entries + 16 + 4 * wtiles
+        else:
+            owned = pl.device_bytes()
+            moved = owned + 16 * A.num_rows  # the packed tiles + x once + y once
+        out = {"granted": True, "kernel_config": pc.as_dict(), "kernel_avg_ms": round(ms, 6), "kernel_min_ms": round(min(bb), 6),
+               "gflops": round(2.0 * A.num_entries / (ms * 1e-3) / 1e9, 2),
+               "bytes_read_and_written_per_launch": moved, "moved_gbps": round(moved / (ms * 1e-3) / 1e9, 2),
+               "moved_frac_of_peak": round(moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+               "csr_algorithmic_bytes_over_time_gbps": round(cmi.csr_bytes(A.num_rows, A.num_entries) / (ms * 1e-3) / 1e9, 2),
+               "hbm_bytes_owned_by_the_plan": owned,
+               "y_identical_to_the_plain_kernel": bool(torch.equal(yk, y)),
+               "speedup_over_the_headline_kernel": round(kernel_ms / ms, 4)}
+        if kind == "c16":
+            out["traffic"], out["traffic_source"] = pmc_traffic("csr16")
+        # cold: COLD_SETS distinct (A, x, y, plan) sets round-robin, as roofline_cold does for the headline kernel
+        if os.environ.get("CMI_BENCH_COLD", "1") != "0":
+            sets = [(A.row_offsets, A.column_indices, A.values, x, yk, pl)]
+            for _ in range(COLD_SETS - 1):
+                a2, j2, v2 = A.row_offsets.clone(), A.column_indices.clone(), A.values.clone()
+                sets.append((a2, j2, v2, x.clone(), torch.empty_like(y), make(a2, j2, v2)))
+            for a2, j2, v2, x2, y2, p2 in sets:
+                cmi.spmv_csr_plan(p2, a2, j2, v2, x2, y2)
+            same = all(bool(torch.equal(t[4], y)) for t in sets)
+            per_cold = -(-per_batch // COLD_SETS) * COLD_SETS
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * KERNEL_BATCHES)]
+            torch.cuda.synchronize()
+            for bi in range(KERNEL_BATCHES):
+                ev[2 * bi].record()
+                for i in range(per_cold):
+                    a2, j2, v2, x2, y2, p2 = sets[i % COLD_SETS]
+                    cmi.spmv_csr_plan(p2, a2, j2, v2, x2, y2)
+                ev[2 * bi + 1].record()
+            torch.cuda.synchronize()
+            cb2 = [ev[2 * bi].elapsed_time(ev[2 * bi + 1]) / per_cold for bi in range(KERNEL_BATCHES)]
+            cms = sum(cb2) / len(cb2)
+            out["cold"] = {"kernel_avg_ms": round(cms, 6), "kernel_min_ms": round(min(cb2), 6), "sets": COLD_SETS,
+                           "moved_frac_of_peak": round(moved / (cms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                           "csr_algorithmic_bytes_over_time_gbps": round(cmi.csr_bytes(A.num_rows, A.num_entries) / (cms * 1e-3) / 1e9, 2),
+                           "speedup_over_the_headline_kernel_cold": None if not cold or "error" in cold else round(cold["kernel_avg_ms"] / cms, 4),
+                           "results_identical_across_sets": same}
+            del sets
+            torch.cuda.empty_cache()
+        del yk
+        return out, pl
+
+    c16 = packed = None
     if fmt == "csr" and world == 1:
         try:
-            p16 = cmi.Plan.csr(torch.float64, A.num_rows, A.num_cols, A.row_offsets, A.column_indices, cfg=cmi.Config(kernel=cmi.CSR_STREAM_C16))
-            pc = p16.config()
-            if pc.kernel != cmi.CSR_STREAM_C16:
-                c16 = {"granted": False, "why": "a row tile spans 65536+ columns or does not fit one LDS pass"}
-            else:
-                y16 = torch.full_like(y, -1.0)
-                run16 = lambda: cmi.spmv_csr_plan(p16, A.row_offsets, A.column_indices, A.values, x, y16)  # noqa: E731
-                for _ in range(20):
-                    run16()
+            c16, p16 = opt_in_leg("c16")
+            if c16.get("granted") and args.cg_iterations > 0:
+                A.plan(compress=True)
+                b_vec = torch.from_numpy(x_host).to(dev)
+                x_sol = torch.zeros(rows_per_rank, dtype=torch.float64, device=dev)
+                cmi.krylov.cg(A, x_sol.clone(), b_vec, iteration_limit=3, relative_tolerance=0.0)
                 torch.cuda.synchronize()
-                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * KERNEL_BATCHES)]
-                for bi in range(KERNEL_BATCHES):
-                    ev[2 * bi].record()
-                    for _ in range(per_batch):
-                        run16()
-                    ev[2 * bi + 1].record()
+                t0 = time.perf_counter()
+                mon = cmi.krylov.cg(A, x_sol, b_vec, iteration_limit=args.cg_iterations, relative_tolerance=0.0)
                 torch.cuda.synchronize()
-                b16 = [ev[2 * bi].elapsed_time(ev[2 * bi + 1]) / per_batch for bi in range(KERNEL_BATCHES)]
-                ms16 = sum(b16) / len(b16)
-                cmi.multiply(A, x, y)
-                tiles16 = -(-A.num_rows // pc.rows_per_block)
-                moved = 10 * A.num_entries + 20 * A.num_rows + 4 + 4 * tiles16
-                c16 = {"granted": True, "kernel_config": pc.as_dict(), "kernel_avg_ms": round(ms16, 6), "kernel_min_ms": round(min(b16), 6),
-                       "gflops": round(2.0 * A.num_entries / (ms16 * 1e-3) / 1e9, 2),
-                       "bytes_read_and_written_per_launch": moved, "moved_gbps": round(moved / (ms16 * 1e-3) / 1e9, 2),
-                       "moved_frac_of_peak": round(moved / (ms16 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                       "csr_algorithmic_bytes_over_time_gbps": round(cmi.csr_bytes(A.num_rows, A.num_entries) / (ms16 * 1e-3) / 1e9, 2),
-                       "traffic": pmc_traffic("csr16")[0], "traffic_source": pmc_traffic("csr16")[1],
-                       "extra_hbm_bytes_owned_by_the_plan": 2 * A.num_entries + 16 + 4 * tiles16,
-                       "y_identical_to_the_plain_kernel": bool(torch.equal(y16, y)),
-                       "speedup_over_the_headline_kernel": round(kernel_ms / ms16, 4)}
-                if args.cg_iterations > 0:
-                    A.plan(compress=True)
-                    b_vec = torch.from_numpy(x_host).to(dev)
-                    x_sol = torch.zeros(rows_per_rank, dtype=torch.float64, device=dev)
-                    cmi.krylov.cg(A, x_sol.clone(), b_vec, iteration_limit=3, relative_tolerance=0.0)
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    mon = cmi.krylov.cg(A, x_sol, b_vec, iteration_limit=args.cg_iterations, relative_tolerance=0.0)
-                    torch.cuda.synchronize()
-                    cg_s = time.perf_counter() - t0
-                    c16["cg_us_per_iteration"] = round(cg_s / max(mon.iteration_count, 1) * 1e6, 2)
-                    c16["cg_final_residual_norm"] = mon.residuals[-1]
-                    A.plan(compress=False)
-                del y16
+                cg_s = time.perf_counter() - t0
+                c16["cg_us_per_iteration"] = round(cg_s / max(mon.iteration_count, 1) * 1e6, 2)
+                c16["cg_final_residual_norm"] = mon.residuals[-1]
+                A.plan(compress=False)
             del p16
         except Exception as e:  # noqa: BLE001 -- a secondary leg
             c16 = {"error": f"{type(e).__name__}: {e}"[:300]}
+        try:
+            packed, ppk = opt_in_leg("packed")
+            if packed.get("granted") and c16 and c16.get("granted"):
+                packed["speedup_over_the_16_bit_plan"] = round(c16["kernel_avg_ms"] / packed["kernel_avg_ms"], 4)
+                if "cold" in packed and "cold" in c16:
+                    packed["cold"]["speedup_over_the_16_bit_plan_cold"] = round(c16["cold"]["kernel_avg_ms"] / packed["cold"]["kernel_avg_ms"], 4)
+            del ppk
+        except Exception as e:  # noqa: BLE001 -- a secondary leg
+            packed = {"error": f"{type(e).__name__}: {e}"[:300]}
+        cmi.multiply(A, x, y)
 
     # ---- N>1: BASELINE.json configs[4]'s literal shape -- poisson5pt(10000, 10000), 1e8 rows, row-block sharded over the
     #      N ranks, inside cusp::krylov::cg -- as a secondary leg (the headline stays weak-scaled: 3162^2 rows per GPU) ----
@@ -812,6 +867,8 @@ def main():
             line["cg"] = cg_leg
         if c16 is not None:
             line["compressed_index_plan"] = c16
+        if packed is not None:
+            line["packed_tile_plan"] = packed
         if coo_tile is not None:
             line["coo_tile_kernel"] = coo_tile
             line["roofline"]["note"] = ("sorted COO through its plan = the CSR kernel on plan-built row offsets (built once, 4 bytes per row owned by the plan); "

@@ -318,8 +318,11 @@ struct cmi_plan {
     int32_t *runs_start = nullptr;   // device, 4 (wave_tiles + 1) entries: {first row, first entry, first piece, packed offset / 16} per tile
     uint32_t *runs_pieces = nullptr; // device, runs_count (+ padding): (first column << 2) | (length - 1)
     int64_t runs_count = 0;
+    int runs_cap = 4;                // entries per piece at most (3 where that costs no more pieces: no LDS bank conflict between pieces)
     unsigned char *runs_packed = nullptr; // device, _PACKED only: per tile [pieces | pad | values | pad]
     int64_t runs_packed_bytes = 0;
+    unsigned char *csr16_packed = nullptr; // device, _PACKED on stencil-like rows (spmv_csr16.hip): fixed-stride wave tiles [head | row starts | 16-bit columns | values]
+    int64_t csr16_packed_bytes = 0;
     uint64_t fp_values = 0;          // checksum of the values a _PACKED plan copied (cmi_plan_validate_values)
     bool has_fp_values = false;
 };
@@ -340,6 +343,7 @@ int csr16_build(cmi_plan *p, const int *Ap, const int *Aj, hipStream_t s, int wa
 int csr_runs_build(cmi_plan *p, const int *Ap, const int *Aj, int v, double min_mean_piece, const void *values, hipStream_t s, double *mean_piece);
 int csr_runs_multiply_f64(const cmi_plan *p, const int *Ap, const int *Aj, const double *Ax, const double *x, double *y, int accumulate, hipStream_t s,
                           const double *w, double *dot_partial, int *dot_partials, int cache_policy, int xcd_swizzle);
+int csr16_pack(cmi_plan *p, const int *Ap, const void *values, hipStream_t s); // the wave-tiled 16-bit copy + the values -> packed wave tiles (CMI_CSR_STREAM_PACKED)
 int csr16_multiply_f64(const cmi_plan *p, const int *Ap, const double *Ax, const double *x, double *y, int accumulate,
                        hipStream_t s, const double *w, double *dot_partial, int *dot_partials, int cache_policy, int xcd_swizzle);
 int csr16_multiply_f32(const cmi_plan *p, const int *Ap, const float *Ax, const float *x, float *y, int accumulate,

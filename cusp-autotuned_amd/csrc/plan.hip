@@ -245,6 +245,22 @@ static bool waver_try(cmi_plan *p, const int *Ap, const int *Aj, bool asked, int
     return true;
 }
 
+// CMI_CSR_STREAM_PACKED on stencil-like rows: the wave-tiled 16-bit copy, then everything a wave needs packed into one span per tile
+static bool packed16_try(cmi_plan *p, const int *Ap, const int *Aj, const void *values, bool keep_policy, hipStream_t s, int *st)
+{
+    const cmi_config before = p->cfg;
+    *st = csr16_build(p, Ap, Aj, s, (int)p->prof.max_len); // granted only if every tile of 64 rows spans fewer than 65536 columns
+    if (*st == CMI_SUCCESS && p->cfg.kernel == CMI_CSR_STREAM_C16 && p->csr16_wave_k > 0) *st = csr16_pack(p, Ap, values, s);
+    if (*st != CMI_SUCCESS || !p->csr16_packed) { if (*st == CMI_SUCCESS) p->cfg = before; return false; }
+    p->cfg.nontemporal &= ~kPolStrided;
+    if (!keep_policy) {
+        const int64_t vb = p->dtype == CMI_F64 ? 8 : 4;
+        if (p->nnz * (2 + vb) > kInfinityCacheBytes + kInfinityCacheBytes / 4) p->cfg.nontemporal |= kPolLoadNT;
+        p->cfg.nontemporal |= kPolStoreNT;
+    }
+    return true;
+}
+
 CMI_API int cmi_plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
                             const int32_t *index_array, const cmi_config *cfg, void *stream, cmi_plan **plan_out)
 {
@@ -298,6 +314,7 @@ CMI_API int cmi_plan_device_bytes(const cmi_plan *plan, int64_t *bytes)
     if (plan->runs_start) b += (plan->wave_tiles + 1) * 16;
     if (plan->runs_pieces) b += (plan->runs_count + 64) * 4;
     if (plan->runs_packed) b += plan->runs_packed_bytes;
+    if (plan->csr16_packed) b += plan->csr16_packed_bytes;
     int64_t sub = 0;
     if (plan->hyb_coo_plan && cmi_plan_device_bytes(plan->hyb_coo_plan, &sub) == CMI_SUCCESS) b += sub;
     if (plan->coo_csr_plan && cmi_plan_device_bytes(plan->coo_csr_plan, &sub) == CMI_SUCCESS) b += sub;
@@ -383,9 +400,9 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
     int waver_v = 0;
     if (format == CMI_FORMAT_CSR && cfg && (cfg->kernel == CMI_CSR_STREAM_WAVER || cfg->kernel == CMI_CSR_STREAM_PACKED)) {
         if (!csr_columns && num_entries > 0) { delete p; return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: CMI_CSR_STREAM_WAVER needs the column indices -- use cmi_plan_create_csr"); }
-        if (dtype != CMI_F64) { delete p; return fail(CMI_ERROR_NOT_SUPPORTED, "cmi_plan_create: CMI_CSR_STREAM_WAVER / _PACKED are f64 kernels"); }
         want_waver = true;
         want_packed = cfg->kernel == CMI_CSR_STREAM_PACKED;
+        if (dtype != CMI_F64 && !want_packed) { delete p; return fail(CMI_ERROR_NOT_SUPPORTED, "cmi_plan_create: CMI_CSR_STREAM_WAVER is an f64 kernel"); }
         waver_v = cfg->items_per_thread;
         waver_shape = *cfg;
         waver_shape.kernel = CMI_KERNEL_AUTO;
@@ -450,6 +467,9 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
             // (profiles/r02_wave_shape_sweep.txt, r02_wave_ab.txt); below it, plain loads keep the matrix resident (tuning.hip)
             if (num_entries * (int64_t)(sizeof(int) + vbytes) > kInfinityCacheBytes + kInfinityCacheBytes / 4) p->cfg.nontemporal |= kPolLoadNT;
             p->cfg.nontemporal |= kPolStoreNT;
+        } else if (st == CMI_SUCCESS && want_packed && csr_values && csr_columns && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
+                   wave_tiles_fit(num_rows, num_entries, p->prof.max_len) && packed16_try(p, index_array, csr_columns, csr_values, waver_shape.nontemporal != 0, s, &st)) {
+            // (stencil-like rows: packed wave tiles of the 16-bit copy, spmv_csr16.hip; p->cfg is set)
         } else if (st == CMI_SUCCESS && auto_kernel && !want_partition && !want_wavev && csr_columns && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
                    waver_try(p, index_array, csr_columns, want_waver, waver_v, want_waver && waver_shape.nontemporal != 0, want_packed ? csr_values : nullptr, s, &st)) {
             // (the run-compressed copy was built and pays: p->cfg is set)
@@ -550,11 +570,11 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
         st = fingerprint(index_length(p), index_array, s, &p->fp_index);
         p->has_fp_index = st == CMI_SUCCESS;
     }
-    if (st == CMI_SUCCESS && p->runs_packed && csr_values) {
+    if (st == CMI_SUCCESS && (p->runs_packed || p->csr16_packed) && csr_values) {
         st = fingerprint(num_entries * (dtype == CMI_F64 ? 2 : 1), reinterpret_cast<const int *>(csr_values), s, &p->fp_values);
         p->has_fp_values = st == CMI_SUCCESS;
     }
-    if (st == CMI_SUCCESS && (p->csr16_cols || p->runs_pieces) && csr_columns) {
+    if (st == CMI_SUCCESS && (p->csr16_cols || p->runs_pieces || p->csr16_packed) && csr_columns) {
         st = fingerprint(num_entries, csr_columns, s, &p->fp_columns);
         p->has_fp_columns = st == CMI_SUCCESS;
     }
@@ -653,6 +673,7 @@ CMI_API int cmi_plan_destroy(cmi_plan *plan)
     if (plan && plan->runs_start) (void)hipFree(plan->runs_start);
     if (plan && plan->runs_pieces) (void)hipFree(plan->runs_pieces);
     if (plan && plan->runs_packed) (void)hipFree(plan->runs_packed);
+    if (plan && plan->csr16_packed) (void)hipFree(plan->csr16_packed);
     delete plan;
     return CMI_SUCCESS;
 }

@@ -1743,6 +1743,11 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     case CMI_CSR_STREAM_WAVER:
     case CMI_CSR_STREAM_PACKED: { // the plan's run-compressed column copy on wave tiles (spmv_csr_runs.hip); Aj is read by the array-tail fall-back only
         if (!plan) return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_CSR_STREAM_WAVER / _PACKED run through a plan of cmi_plan_create_csr only");
+        if (plan->csr16_packed) { // stencil-like rows: packed wave tiles of the 16-bit copy (spmv_csr16.hip); neither Ap nor Aj nor Ax is read
+            const int swz16 = (w && dot_partial) ? dot_swizzle(c.xcd_swizzle, plan, c.xcd_swizzle) : c.xcd_swizzle;
+            if constexpr (std::is_same<T, double>::value) return csr16_multiply_f64(plan, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol, swz16);
+            else return csr16_multiply_f32(plan, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol, swz16);
+        }
         if constexpr (std::is_same<T, double>::value) return csr_runs_multiply_f64(plan, Ap, Aj, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol, c.xcd_swizzle);
         else return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_CSR_STREAM_WAVER / _PACKED are f64 kernels");
     }

@@ -121,6 +121,133 @@ int csr16_build(cmi_plan *p, const int *Ap, const int *Aj, hipStream_t s, int wa
     return CMI_SUCCESS;
 }
 
+// ---- PACKED wave tiles (CMI_CSR_STREAM_PACKED on stencil-like rows, round 4) ------------------------------------------------------
+// DESIGN.md 9.5 / VERDICT r3 next 3: one stream reads at 7.1-7.3 TB/s, CSR's arrays side by side at 6.4-6.6 -- so lay everything a wave
+// needs for its tile of 64 rows in ONE contiguous, line-aligned span of a plan-owned buffer, tiles at a fixed stride:
+//     [ 0,  16)  int32 base (smallest column of the tile), int32 cnt (entries of the tile), 8 bytes of padding
+//     [16, 144)  64 x uint16: first entry of row l inside the tile (rows past the matrix: cnt)
+//     [144, 256) padding
+//     [256, 256 + 128 K)          64 K x uint16 column offsets from base, entry order (K = entries per lane = the longest row)
+//     [256 + 128 K, 256 + 640 K)  64 K x f64 values (f32: 256 K bytes)
+// K = 5, f64: 3456 bytes = 27 lines per tile, against 3460 through the 16-bit copy's four arrays (Ap, base, Aj16, Ax).  The multiply reads
+// neither Ap nor Aj nor Ax.  The plan OWNS A COPY OF THE VALUES: refresh them => new plan (cmi_plan_validate_values).
+constexpr int kPackHead = 256;
+inline int64_t pack16_span(int k, size_t vbytes) { return kPackHead + (int64_t)kWave * k * (2 + (int64_t)vbytes); }
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+csr16_pack_kernel(int64_t num_rows, int64_t wtiles, int k, const int *__restrict__ Ap, const uint16_t *__restrict__ Aj16, const int32_t *__restrict__ tile_base,
+                  const T *__restrict__ Ax, unsigned char *__restrict__ packed)
+{
+    const int64_t wt = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    const int lane = threadIdx.x & (kWave - 1);
+    if (wt >= wtiles) return;
+    const int64_t span_bytes = kPackHead + (int64_t)kWave * k * (2 + (int64_t)sizeof(T));
+    unsigned char *span = packed + wt * span_bytes;
+    const int64_t r0 = wt * kWave;
+    const int nr = (int)((num_rows - r0) < kWave ? (num_rows - r0) : kWave);
+    const int nz0 = Ap[r0], cnt = Ap[r0 + nr] - nz0;
+    if (lane == 0) { reinterpret_cast<int32_t *>(span)[0] = tile_base[wt]; reinterpret_cast<int32_t *>(span)[1] = cnt; reinterpret_cast<int32_t *>(span)[2] = 0; reinterpret_cast<int32_t *>(span)[3] = 0; }
+    reinterpret_cast<uint16_t *>(span + 16)[lane] = (uint16_t)(lane < nr ? Ap[r0 + lane] - nz0 : cnt);
+    for (int i = lane; i < (kPackHead - 144) / 2; i += kWave) reinterpret_cast<uint16_t *>(span + 144)[i] = 0;
+    uint16_t *cols = reinterpret_cast<uint16_t *>(span + kPackHead);
+    T *vals = reinterpret_cast<T *>(span + kPackHead + (size_t)kWave * k * 2);
+    for (int i = lane; i < kWave * k; i += kWave) {
+        cols[i] = i < cnt ? Aj16[nz0 + i] : (uint16_t)0;
+        vals[i] = i < cnt ? Ax[nz0 + i] : T(0);
+    }
+}
+
+// after csr16_build(..., wave_k) granted the wave-tiled 16-bit copy: assemble the packed tiles from it and the values; the 16-bit
+// arrays are released (the packed buffer holds what the multiply needs).  Synchronises `s`.
+int csr16_pack(cmi_plan *p, const int *Ap, const void *values, hipStream_t s)
+{
+    if (!p->csr16_cols || !p->csr16_base || p->csr16_wave_k <= 0 || !values) return CMI_SUCCESS;
+    const int k = p->csr16_wave_k;
+    const size_t vbytes = p->dtype == CMI_F64 ? 8 : 4;
+    const int64_t wtiles = ceil_div(p->rows, (int64_t)kWave);
+    const int64_t bytes = wtiles * pack16_span(k, vbytes);
+    unsigned char *buf = nullptr;
+    hipError_t e = hipMalloc((void **)&buf, (size_t)bytes);
+    if (e == hipSuccess) {
+        const unsigned grid = (unsigned)ceil_div(wtiles, 4);
+        if (p->dtype == CMI_F64) hipLaunchKernelGGL((csr16_pack_kernel<double>), dim3(grid), dim3(256), 0, s, p->rows, wtiles, k, Ap, p->csr16_cols, p->csr16_base, (const double *)values, buf);
+        else hipLaunchKernelGGL((csr16_pack_kernel<float>), dim3(grid), dim3(256), 0, s, p->rows, wtiles, k, Ap, p->csr16_cols, p->csr16_base, (const float *)values, buf);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { if (buf) (void)hipFree(buf); return hip_fail(e, "cmi_plan_create: packed wave tiles"); }
+    (void)hipFree(p->csr16_cols);
+    (void)hipFree(p->csr16_base);
+    p->csr16_cols = nullptr;
+    p->csr16_base = nullptr;
+    p->csr16_packed = buf;
+    p->csr16_packed_bytes = bytes;
+    p->cfg.kernel = CMI_CSR_STREAM_PACKED;
+    return CMI_SUCCESS;
+}
+
+// the multiply on packed wave tiles: csr_wave16_kernel's body with every request of a wave inside its tile's span
+template <typename T, int K, int POL, bool DOT>
+__global__ void __launch_bounds__(1024)
+csr_wave16p_kernel(int64_t num_rows, const unsigned char *__restrict__ packed, const T *__restrict__ x, T *__restrict__ y, int64_t num_tiles,
+                   int64_t tiles_per_xcd, int swizzle, int accumulate, const T *__restrict__ w, double *__restrict__ dot_partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double dot_slots[DOT ? 1024 / kWave : 1];
+    constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
+    constexpr int64_t SPAN = kPackHead + (int64_t)kWave * K * (2 + (int64_t)sizeof(T));
+    const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle);
+    if (tile >= num_tiles) return; // whole workgroup
+    const int waves = blockDim.x / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x & (kWave - 1);
+    const int64_t wt = tile * waves + wave;
+    const int64_t r0 = wt * kWave;
+    double d = 0.0;
+    if (r0 < num_rows) {
+        const int nr = (int)((num_rows - r0) < kWave ? (num_rows - r0) : kWave);
+        const unsigned char *span = packed + wt * SPAN;
+        const int2v head = *reinterpret_cast<const int2v *>(span); // (scalar)
+        const int base = head.x, cnt = head.y;
+        int a = (int)ld<NT>(reinterpret_cast<const uint16_t *>(span + 16) + lane);
+        const uint16_t *cols = reinterpret_cast<const uint16_t *>(span + kPackHead);
+        const T *vals = reinterpret_cast<const T *>(span + kPackHead + (size_t)kWave * K * 2);
+        T wv = T(0);
+        if constexpr (DOT) { if (lane < nr) wv = w[r0 + lane]; }
+        T s = (accumulate && lane < nr) ? y[r0 + lane] : T(0);
+        if (cnt > 0) {
+            T *mine = reinterpret_cast<T *>(smem) + (size_t)wave * kWave * K;
+            int c[K];
+            T v[K], xv[K];
+            // (every slot of the span holds something -- padding slots a zero offset and a zero value -- so nothing is clamped)
+#pragma unroll
+            for (int k = 0; k < K; k++) c[k] = (int)ld<NT>(cols + k * kWave + lane);
+#pragma unroll
+            for (int k = 0; k < K; k++) v[k] = ld<NT>(vals + k * kWave + lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < K; k++) asm volatile("" : "+v"(c[k]));
+#pragma unroll
+            for (int k = 0; k < K; k++) xv[k] = x[base + c[k]];
+            asm volatile("" : "+v"(a));
+            const int b = __builtin_amdgcn_update_dpp(cnt, a, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+#pragma unroll
+            for (int k = 0; k < K; k++) mine[k * kWave + lane] = v[k] * xv[k];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < nr)
+                for (int j = a; j < b; j++) s = s + mine[j];
+        }
+        if (lane < nr) {
+            st<NTS>(y + r0 + lane, s);
+            if constexpr (DOT) d = (double)s * (double)wv;
+        }
+    }
+    if constexpr (DOT) {
+        tile_dot_store(d, dot_slots, dot_partial + tile);
+        if (tile == 0 && threadIdx.x == 0) reset_fold_state(dot_partial);
+    }
+}
+
 // ---- the multiply, wave-tile form ------------------------------------------------------------------------------------------
 // spmv_csr.hip's csr_wave_kernel reading the copy: the wave's tile is the copy's tile (64 rows), every offset is against its base.
 template <typename T, int K, int POL, bool DOT>
@@ -303,6 +430,38 @@ static int csr16_multiply(const cmi_plan *p, const int *Ap, const T *Ax, const T
     const cmi_config &c = p->cfg;
     const int block = c.block_size, ipt = c.items_per_thread, rpb = c.rows_per_block;
     const int64_t rows = p->rows, nnz = p->nnz;
+    if (p->csr16_packed) { // CMI_CSR_STREAM_PACKED on stencil-like rows: packed wave tiles (above); Ap / Ax are not read
+        const int K = p->csr16_wave_k, wblock = 256;
+        const int64_t wtiles = ceil_div(rows, (int64_t)wblock);
+        const int64_t wtpx = ceil_div(wtiles, kXcds);
+        const int wswz = swizzle < 0 ? 0 : swizzle;
+        const int64_t wgrid = padded_grid(wtiles, wswz);
+        if (wgrid > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "csr_stream_packed: grid too large");
+        const size_t wlds = (size_t)wblock * K * sizeof(T);
+        const bool wdot = w && dot_partial && wtiles <= kPartialCapacity;
+        with_policy(pol & 3, [&](auto P) {
+            constexpr int POL = decltype(P)::value;
+            auto go = [&](auto KK) {
+                constexpr int KC = decltype(KK)::value;
+                if (wdot) hipLaunchKernelGGL((csr_wave16p_kernel<T, KC, POL, true>), dim3((unsigned)wgrid), dim3(wblock), wlds, s, rows, p->csr16_packed, x, y, wtiles, wtpx, wswz, accumulate, w, dot_partial);
+                else      hipLaunchKernelGGL((csr_wave16p_kernel<T, KC, POL, false>), dim3((unsigned)wgrid), dim3(wblock), wlds, s, rows, p->csr16_packed, x, y, wtiles, wtpx, wswz, accumulate, (const T *)nullptr, (double *)nullptr);
+            };
+            switch (K) {
+            case 2: go(std::integral_constant<int, 2>()); break;
+            case 3: go(std::integral_constant<int, 3>()); break;
+            case 4: go(std::integral_constant<int, 4>()); break;
+            case 5: go(std::integral_constant<int, 5>()); break;
+            case 6: go(std::integral_constant<int, 6>()); break;
+            case 7: go(std::integral_constant<int, 7>()); break;
+            case 8: go(std::integral_constant<int, 8>()); break;
+            case 9: go(std::integral_constant<int, 9>()); break;
+            default: go(std::integral_constant<int, 10>()); break;
+            }
+        });
+        CMI_LAUNCH_CHECK("csr_wave16p spmv");
+        if (wdot && dot_partials) *dot_partials = (int)wtiles;
+        return CMI_SUCCESS;
+    }
     if (p->csr16_wave_k > 0) { // the copy is tiled per wave: the wave-tile kernel, four waves (four tiles of the copy) per workgroup
         const int K = p->csr16_wave_k, wblock = 256;
         const int64_t wtiles = ceil_div(rows, (int64_t)wblock);

@@ -34,22 +34,35 @@ typedef int __attribute__((ext_vector_type(4))) start_t;
 
 // ---- plan time -------------------------------------------------------------------------------------------------------
 // pieces of row r: maximal runs of consecutive columns, cut every kRunCap entries
-__global__ void __launch_bounds__(256) runs_count_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ Aj, int *__restrict__ count)
+// (cap: 3 or 4 entries per piece at most; count3: optional total for cap 3 beside the per-row counts for `cap`)
+__global__ void __launch_bounds__(256) runs_count_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ Aj, int cap, int *__restrict__ count,
+                                                         unsigned long long *__restrict__ totals)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= num_rows) return;
-    const int a = Ap[r], b = Ap[r + 1];
-    int n = 0, len = 0, prev = 0;
-    for (int j = a; j < b; j++) {
-        const int c = Aj[j];
-        if (len == 0 || c != prev + 1 || len == kRunCap) { n++; len = 0; }
-        len++;
-        prev = c;
+    int n = 0, n3 = 0;
+    if (r < num_rows) {
+        const int a = Ap[r], b = Ap[r + 1];
+        int len = 0, len3 = 0, prev = 0;
+        for (int j = a; j < b; j++) {
+            const int c = Aj[j];
+            const bool brk = j == a || c != prev + 1;
+            if (brk || len == cap) { n++; len = 0; }
+            if (brk || len3 == 3) { n3++; len3 = 0; }
+            len++;
+            len3++;
+            prev = c;
+        }
+        if (count) count[r] = n;
     }
-    count[r] = n;
+    if (totals) { // (first pass only: how many pieces would cap 4 / cap 3 give?)
+        unsigned long long t4 = (unsigned long long)n, t3 = (unsigned long long)n3;
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) { t4 += __shfl_down(t4, o); t3 += __shfl_down(t3, o); }
+        if ((threadIdx.x & (kWave - 1)) == 0) { if (t4) atomicAdd(totals, t4); if (t3) atomicAdd(totals + 1, t3); }
+    }
 }
 
-__global__ void __launch_bounds__(256) runs_fill_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ Aj, const int *__restrict__ offset,
+__global__ void __launch_bounds__(256) runs_fill_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ Aj, const int *__restrict__ offset, int cap,
                                                         uint32_t *__restrict__ pieces)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -58,7 +71,7 @@ __global__ void __launch_bounds__(256) runs_fill_kernel(int64_t num_rows, const 
     int q = offset[r] - 1, len = 0, prev = 0, first = 0;
     for (int j = a; j < b; j++) {
         const int c = Aj[j];
-        if (len == 0 || c != prev + 1 || len == kRunCap) {
+        if (len == 0 || c != prev + 1 || len == cap) {
             if (len > 0) pieces[q] = ((uint32_t)first << 2) | (uint32_t)(len - 1);
             q++;
             len = 0;
@@ -136,13 +149,30 @@ int csr_runs_build(cmi_plan *p, const int *Ap, const int *Aj, int v, double min_
     const int q = 256 * v - (int)p->prof.max_len - 3;
     if (q < 1) return CMI_SUCCESS;
     int *count = nullptr;
+    unsigned long long *totals = nullptr, host_totals[2] = {0, 0};
     hipError_t e = hipMalloc((void **)&count, (size_t)(rows + 1) * sizeof(int));
     if (e != hipSuccess) return hip_fail(e, "cmi_plan_create: run-compressed columns");
-    e = hipMemsetAsync(count + rows, 0, sizeof(int), s);
+    e = hipMalloc((void **)&totals, sizeof(host_totals));
+    if (e == hipSuccess) e = hipMemsetAsync(totals, 0, sizeof(host_totals), s);
+    if (e == hipSuccess) e = hipMemsetAsync(count + rows, 0, sizeof(int), s);
+    // Pieces of at most 4 or at most 3 entries?  Three degrees of freedom per node give runs of 3, 6, 9 ...: cut at 4 they become 4 + 2,
+    // 4 + 4 + 1 -- no fewer pieces than cut at 3, and the pieces of 4 park their x values 32 bytes apart in LDS (a 4-way bank conflict
+    // where pieces of 3 have none; profiles/r04_long_rows_pmc.json: LDS index unit 71 % busy on ldoor-like).  Cap 3 when it costs at most
+    // 3 % more pieces than cap 4 ($CMI_WAVER_CAP=3 / 4 forces).
+    static const int cap_env = [] { const char *ev = std::getenv("CMI_WAVER_CAP"); return ev ? std::atoi(ev) : 0; }();
+    int cap = kRunCap;
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(runs_count_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, s, rows, Ap, Aj, count);
+        hipLaunchKernelGGL(runs_count_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, s, rows, Ap, Aj, kRunCap, count, totals);
         e = hipGetLastError();
     }
+    if (e == hipSuccess) e = hipMemcpyAsync(host_totals, totals, sizeof(host_totals), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess && (cap_env == 3 || (cap_env != 4 && (double)host_totals[1] <= 1.03 * (double)host_totals[0]))) {
+        cap = 3;
+        hipLaunchKernelGGL(runs_count_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, s, rows, Ap, Aj, 3, count, (unsigned long long *)nullptr);
+        e = hipGetLastError();
+    }
+    if (totals) (void)hipFree(totals);
     int st = e == hipSuccess ? (int)CMI_SUCCESS : hip_fail(e, "cmi_plan_create: run-compressed columns");
     if (st == CMI_SUCCESS) st = device_exclusive_scan(count, count, (size_t)rows + 1, s); // in place: count[r] <- pieces before row r
     int total = 0;
@@ -160,7 +190,7 @@ int csr_runs_build(cmi_plan *p, const int *Ap, const int *Aj, int v, double min_
         if (e == hipSuccess) e = hipMemsetAsync(pieces + total, 0, 64 * sizeof(uint32_t), s);
         if (e == hipSuccess) e = hipMalloc((void **)&start, (size_t)(tiles + 1) * 4 * sizeof(int32_t));
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(runs_fill_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, s, rows, Ap, Aj, count, pieces);
+            hipLaunchKernelGGL(runs_fill_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, s, rows, Ap, Aj, count, cap, pieces);
             hipLaunchKernelGGL(runs_partition_kernel, dim3((unsigned)ceil_div(rows + 1, 256)), dim3(256), 0, s, rows, Ap, count, q, tiles, start);
             e = hipGetLastError();
         }
@@ -210,6 +240,7 @@ int csr_runs_build(cmi_plan *p, const int *Ap, const int *Aj, int v, double min_
     p->runs_start = start;
     p->runs_pieces = pieces;
     p->runs_count = total;
+    p->runs_cap = cap;
     p->runs_packed = packed;
     p->runs_packed_bytes = packed_bytes;
     p->wave_tiles = tiles;
@@ -303,14 +334,14 @@ csr_waver_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t 
                     xa[k] = *reinterpret_cast<const double2u *>(x + ca);
                     xb[k] = *reinterpret_cast<const double2u *>(x + cb);
                 }
+                // x values into the slots of their entries: a piece of 2+ stores its first PAIR with one LDS instruction (ds_write2_b64), a
+                // piece of 3 or 4 its last pair with another (a piece of 3 rewrites its middle value with itself), a piece of 1 its one value
+                // (the branch is skipped where no lane of the chunk holds one: FEM / 27-point rows)
 #pragma unroll
                 for (int k = 0; k < NPC; k++) {
-                    if (len[k] >= 1) mine[o[k]] = sel[k] ? xa[k].y : xa[k].x;
-                    if (len[k] >= 2) {
-                        mine[o[k] + 1] = xa[k].y;
-                        mine[o[k] + len[k] - 2] = xb[k].x;
-                        mine[o[k] + len[k] - 1] = xb[k].y;
-                    }
+                    if (len[k] >= 2) *reinterpret_cast<double2u *>(mine + o[k]) = xa[k];
+                    if (len[k] >= 3) *reinterpret_cast<double2u *>(mine + o[k] + len[k] - 2) = xb[k];
+                    if (len[k] == 1) mine[o[k]] = sel[k] ? xa[k].y : xa[k].x;
                 }
                 for (int base = NPC * kWave; base < np; base += kWave) { // (a tile of short runs: further chunks, one at a time)
                     const int i = base + lane;
@@ -323,8 +354,9 @@ csr_waver_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t 
                     const int ca = cs < num_cols - 2 ? cs : num_cols - 2;
                     const int cb = ca + (ln > 2 ? ln - 2 : 0);
                     const double2u A = *reinterpret_cast<const double2u *>(x + ca), B = *reinterpret_cast<const double2u *>(x + cb);
-                    if (ln >= 1) mine[oo] = (cs - ca) ? A.y : A.x;
-                    if (ln >= 2) { mine[oo + 1] = A.y; mine[oo + ln - 2] = B.x; mine[oo + ln - 1] = B.y; }
+                    if (ln >= 2) *reinterpret_cast<double2u *>(mine + oo) = A;
+                    if (ln >= 3) *reinterpret_cast<double2u *>(mine + oo + ln - 2) = B;
+                    if (ln == 1) mine[oo] = (cs - ca) ? A.y : A.x;
                 }
                 asm volatile("" : "+v"(a)); // the row offset was requested in front of the streams
                 __builtin_amdgcn_wave_barrier(); // (compiler only: the hardware runs a wave's LDS instructions in order)

@@ -232,3 +232,122 @@ def test_configs3_full_size_run_compressed(cmi, torch_cuda, orc, name):
     y.fill_(10.0)
     cmi.multiply(A, dx, y)
     assert np.array_equal(y.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_packed_wave_tiles_on_stencils(cmi, torch_cuda, orc, tag):
+    """CMI_CSR_STREAM_PACKED on stencil-like rows: per wave tile of 64 rows ONE contiguous span [head | row starts |
+    16-bit column offsets | values]; the multiply reads neither Ap nor Aj nor Ax.  Bit-exact against the host loop
+    (sequential/multiply/csr_spmv.h:42-74) on 5-point Poisson grids (row counts that are and are not multiples of 64 / 256), accumulate,
+    fused <y, w>; the plan owns a copy of the values: refreshed values are NOT seen and cmi_plan_validate_values says so."""
+    torch = torch_cuda
+    dtype, tdt = (np.float64, torch.float64) if tag == "f64" else (np.float32, torch.float32)
+    for m, n in ((64, 48), (100, 100), (333, 77), (512, 512)):
+        Ap, Aj, Ax = orc.poisson5pt_csr(m, n)
+        Ax = (Ax * np.linspace(0.5, 1.5, len(Ax))).astype(dtype)  # (values that differ entry by entry)
+        rows = cols = m * n
+        x = orc.fill_x(cols).astype(dtype)
+        y0 = np.linspace(-1.0, 1.0, rows).astype(dtype)
+        dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+        plan = cmi.Plan.csr_values(rows, cols, dAp, dAj, dAx, cmi.Config(kernel=cmi.CSR_STREAM_PACKED))
+        c = plan.config()
+        assert (c.kernel, c.items_per_thread, c.rows_per_block) == (cmi.CSR_STREAM_PACKED, 5, 64), c
+        vb = 8 if tag == "f64" else 4
+        assert plan.device_bytes() == -(-rows // 64) * (256 + 64 * 5 * (2 + vb)), plan.device_bytes()
+        assert plan.info()["storage_order_sums"] is True
+        want, want_acc = orc.spmv_csr(Ap, Aj, Ax, x), orc.spmv_csr(Ap, Aj, Ax, x, y0)
+        y = torch.full((rows,), 9.0, dtype=tdt, device="cuda")
+        cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
+        assert np.array_equal(y.cpu().numpy(), want), (m, n)
+        y = dev(y0, torch)
+        cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y, accumulate=True)
+        assert np.array_equal(y.cpu().numpy(), want_acc), (m, n, "accumulate")
+        w = np.cos(np.arange(rows)).astype(dtype)
+        res = torch.zeros(1, dtype=torch.float64, device="cuda")
+        y = torch.zeros(rows, dtype=tdt, device="cuda")
+        cmi.spmv_csr_dot(rows, cols, dAp, dAj, dAx, dx, y, dev(w, torch), res, cmi.blas_workspace(), plan=plan)
+        assert np.array_equal(y.cpu().numpy(), want), (m, n, "dot")
+        ref = float(np.dot(want.astype(np.float64), w.astype(np.float64)))
+        assert abs(res.item() - ref) <= 1e-9 * float(np.dot(np.abs(want).astype(np.float64), np.abs(w).astype(np.float64))) + 1e-300
+        assert plan.validate(dAp, dAj) and plan.validate_values(dAx)
+        keep = dAx.clone()
+        dAx.mul_(2.0)                                   # refreshed in place: the plan's copy is stale, and says so
+        assert plan.validate_values(dAx) is False
+        cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)   # (still the OLD values: the documented contract of this opt-in)
+        assert np.array_equal(y.cpu().numpy(), want)
+        dAx.copy_(keep)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The REAL-FILE branch of configs[3] without the real files (VERDICT r3 next 6): a symmetric `coordinate real` MatrixMarket file of
+# 10^6+ stored entries, named thermal2.mtx, dropped where CMI_SUITESPARSE_DIR points.  Both readers run: the C++ layer's
+# (cusp/io/matrix_market.h, replacing /root/reference's cusp/io/detail/matrix_market.inl:160-300 -- symmetric expansion, sort by row and
+# column) through tools/bin/spmv_bench, and the test path's (tools/suitesparse_like.py::load) through the every-CSR-variant body.
+# ------------------------------------------------------------------------------------------------------------------------------------
+def test_configs3_real_file_branch_on_a_written_mtx(cmi, torch_cuda, orc, tmp_path, monkeypatch):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import suitesparse_like as ssl
+    import test_round3_gpu as r3
+    from conftest import coo_to_csr
+    Ap, Aj, Ax = ssl.thermal2_like(0.33)                       # symmetric PATTERN (every edge both ways + the diagonal)
+    rows = len(Ap) - 1
+    ri = np.repeat(np.arange(rows, dtype=np.int64), np.diff(Ap))
+    low = ri >= Aj                                             # the stored half: lower triangle incl. the diagonal
+    I, J, V = ri[low], Aj[low].astype(np.int64), Ax[low]
+    assert len(I) >= 10 ** 6, len(I)
+    path = tmp_path / "thermal2.mtx"
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real symmetric\n% written by tests/test_round4_gpu.py: the real-file branch of configs[3]\n")
+        f.write(f"{rows} {rows} {len(I)}\n")
+        np.savetxt(f, np.column_stack([I + 1, J + 1, V]), fmt="%d %d %.17g")
+    off = I != J                                               # what the file MEANS: both triangles, sorted by row and column
+    eAp, eAj, eAx = coo_to_csr(rows, np.concatenate([I, J[off]]), np.concatenate([J, I[off]]), np.concatenate([V, V[off]]))
+    monkeypatch.setenv("CMI_SUITESPARSE_DIR", str(tmp_path))
+    gAp, gAj, gAx, source = ssl.load("thermal2", 1.0)
+    assert source.startswith("file "), source
+    assert np.array_equal(gAp, eAp) and np.array_equal(gAj, eAj) and np.array_equal(gAx, eAx)   # %.17g: the values round-trip exactly
+    r3.test_configs3_full_size_every_csr_variant(cmi, torch_cuda, orc, "thermal2")            # its load() now takes the file
+    # the product's own reader: header-only C++ layer -> device containers -> every format's multiply against the host multiply
+    exe = os.path.join(root, "tools", "bin", "spmv_bench")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(root, "tests", "cpp"), exe], check=True, capture_output=True)
+    r = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    print(r.stdout[-1500:])
+    assert r.returncode == 0, r.stderr[-500:]
+    assert f"with shape ({rows},{rows}) and {len(eAj)} entries" in r.stdout, r.stdout[:600]
+    assert "RESULT MISMATCH" not in r.stdout
+    assert sum(1 for k in ("coo ", "csr ", "ell ", "hyb ") if f"\t{k}:" in r.stdout and "GFLOP/s" in r.stdout) == 4, r.stdout
+
+
+def test_bench_under_torchrun_n1_agrees_with_the_plain_run(torch_cuda):
+    """the driver's SCALE run starts `bench.py --gpus 1` under torch.distributed.run; its N = 1 value must be the
+    plain run's.  The launcher is started as a CHILD (nothing of it touches the GPU before its own child does); both runs use the driver's
+    flags but 200 timed steps (a 24 ms region: the 20-step region of 2.4 ms wanders by +-1.5 % by itself).  3 % band."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    flags = ["--gpus", "1", "--steps", "200", "--warmup", "5", "--no-cpu-baseline", "--cg-iterations", "0"]
+    env = dict(os.environ, CMI_BENCH_COLD="0")
+
+    def line_of(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    plain = line_of([sys.executable, os.path.join(root, "bench.py")] + flags)
+    launched = line_of([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py")] + flags)
+    for d in (plain, launched):
+        assert d["n_gpus"] == 1 and d["metric"] == "spmv_gflops_fp64_poisson5pt" and d["roofline"]["frac"] > 0.6, d
+    a, b = plain["roofline"]["kernel_avg_ms"], launched["roofline"]["kernel_avg_ms"]
+    assert abs(a - b) <= 0.03 * a, (a, b)
+    assert abs(plain["value"] - launched["value"]) <= 0.03 * plain["value"], (plain["value"], launched["value"])
+    print(f"plain {plain['value']:.1f} GFLOP/s kernel {a * 1e3:.2f} us | under torch.distributed.run {launched['value']:.1f} GFLOP/s kernel {b * 1e3:.2f} us")

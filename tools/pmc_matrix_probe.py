@@ -68,6 +68,8 @@ def variants_for(A):
                     out.append((f"packed{v}" + (f"/pol{pol}" if pol else ""), ("values", cmi.Config(kernel=cmi.CSR_STREAM_PACKED, items_per_thread=v, nontemporal=pol))))
     if os.environ.get("PMC_C16", "0") != "0":
         out.append(("c16", cmi.Config(kernel=cmi.CSR_STREAM_C16)))
+    if os.environ.get("PMC_PLAN_AGAIN", "0") != "0":
+        out.append(("plan-again", None))
     return out
 
 
@@ -138,7 +140,15 @@ def main():
                 cmi.check(lib.cmi_event_create(ctypes.byref(e0)))
                 cmi.check(lib.cmi_event_create(ctypes.byref(e1)))
                 ts = []
-                for _ in range(5):
+                # settle: the first variant of a matrix used to be timed while the clocks were still coming up behind the set-up (r3: `plan` 95.3 us
+                # against `stream` 89.5 us with the SAME printed config; r4 session 2: 88.4 against 77.7) -- every variant now runs SETTLE
+                # untimed launches first
+                t_settle = time.time()
+                while time.time() - t_settle < float(os.environ.get("PMC_SETTLE_S", "0.05")):  # (by time: 60 launches of a 80 us kernel were not enough)
+                    for _ in range(20):
+                        go()
+                    torch.cuda.synchronize()
+                for _ in range(7):
                     s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
                     cmi.check(lib.cmi_event_record(e0, s))
                     for _ in range(20):
