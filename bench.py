@@ -148,7 +148,8 @@ def pmc_traffic(kernel_substr):
     # the SpMV kernel of each format (not the builders / converters that carry the format's name too)
     names = {"csr": ("csr_wave_kernel", "csr_stream_kernel", "csr_balanced_kernel", "csr_vector_kernel", "csr_scalar_kernel"), "ell": ("ell_row_kernel",),
              "dia": ("dia_row_kernel", "dia_row2_kernel"), "coo": ("csr_wave_kernel", "csr_stream_kernel", "csr_balanced_kernel"),  # sorted entries through a plan: the CSR kernels on the plan's row offsets
-             "coo_tile": ("coo_tile_kernel",), "hyb": ("hyb_tile_kernel",), "csr16": ("csr_wave16_kernel", "csr_stream16_kernel")}[kernel_substr]
+             "coo_tile": ("coo_tile_kernel",), "hyb": ("hyb_tile_kernel",), "csr16": ("csr_wave16_kernel", "csr_stream16_kernel"),
+             "csr16p": ("csr_wave16p_kernel",)}[kernel_substr]
     best, src = None, None
     if os.path.isdir(pdir):
         for f in sorted(os.listdir(pdir)):
@@ -410,11 +411,21 @@ def main():
             raise SystemExit(f"parity gate failed: sharded y differs from the stencil's closed form with every exchange {rejected}")
         del want
         step = lambda: sh.multiply(y)  # noqa: E731
+        # per rank: the data path's communicator as the LIBRARY reports it (cmi_comm_rank: ncclCommCount of the RCCL communicator behind
+        # the C-ABI) and the exchange that carries `value` -- so that the N > 1 line itself shows N ranks talking through RCCL
+        me = {"rank": rank, "device": torch.cuda.current_device(), "exchange": sh.vec.plan.mode, "data_path": "torch.distributed", "comm_world": None}
+        if sh.vec.comm is not None:
+            r_, w_ = ctypes.c_int(-1), ctypes.c_int(-1)
+            cmi.check(cmi.lib().cmi_comm_rank(sh.vec.comm.handle, ctypes.byref(r_), ctypes.byref(w_)))
+            me.update(data_path="cmi_comm (RCCL behind the C-ABI)", comm_rank=r_.value, comm_world=w_.value, rccl_version=sh.vec.comm.library_version())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, me)
         p = sh.vec.plan
         exchange_info = {"mode": p.mode, "values_received_per_rank": p.allgather_values if p.mode == "allgather" else p.recv_values,
                          "allgather_values": p.allgather_values, "validated_against": "stencil closed form (bit-exact)",
                          "rejected_exchanges": rejected,
-                         "peer_probe_in_child_process": None if peer_probe is None else {"ok": peer_probe[0], "note": peer_probe[1]}}
+                         "peer_probe_in_child_process": None if peer_probe is None else {"ok": peer_probe[0], "note": peer_probe[1]},
+                         "ranks": per_rank}
 
     def barrier():
         if dist is not None:
@@ -490,7 +501,7 @@ def main():
     # >= 200 launches whatever --steps says, as KERNEL_BATCHES batches of launches each bracketed by its own event pair
     # (a batch, not a single launch: an event pair around one launch also times the ~2 us launch gap).  Reported:
     # the mean over all batches (= the average launch duration, what roofline.achieved is computed from), the median
-    # batch and the fastest batch.  Launch-to-launch spread on this pool is 130-161 us (profiles/r01_bench_kernel_stats.csv),
+    # batch and the fastest batch.  Launch-to-launch spread on this pool is 130-161 us (archive/profiles/r01_bench_kernel_stats.csv),
     # so 20 launches after a cold start -- round 1's protocol -- could land 5 % off the average.
     KERNEL_BATCHES = 10
     per_batch = max(20, -(-max(args.steps, 200) // KERNEL_BATCHES))
@@ -677,8 +688,7 @@ def main():
                "hbm_bytes_owned_by_the_plan": owned,
                "y_identical_to_the_plain_kernel": bool(torch.equal(yk, y)),
                "speedup_over_the_headline_kernel": round(kernel_ms / ms, 4)}
-        if kind == "c16":
-            out["traffic"], out["traffic_source"] = pmc_traffic("csr16")
+        out["traffic"], out["traffic_source"] = pmc_traffic("csr16" if kind == "c16" else "csr16p")
         # cold: COLD_SETS distinct (A, x, y, plan) sets round-robin, as roofline_cold does for the headline kernel
         if os.environ.get("CMI_BENCH_COLD", "1") != "0":
             sets = [(A.row_offsets, A.column_indices, A.values, x, yk, pl)]

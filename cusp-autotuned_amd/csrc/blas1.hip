@@ -267,8 +267,8 @@ cg_update_kernel(int64_t n, const double *__restrict__ rz, const double *__restr
             for (int k = 0; k < W; k++) rv[k] = (-alpha) * yv[k] + rv[k];       // r <- r - alpha y   (:89)
             // (r is read again by the direction kernel right behind this one: plain store.  x is not read before the matrix
             // streams of the next SpMV have flushed every cache: nt -- stored plainly it is written back DURING that SpMV, which
-            // then runs ~6 us longer: tools/r2_probe.hip "ctx:" lines, profiles/r02_probe_ctx.txt.  p is gathered by that SpMV:
-            // plain; with the nt hint on p the SpMV lost 5 us, profiles/r02_cg_store_policy.txt)
+            // then runs ~6 us longer: archive/tools/r2_probe.hip "ctx:" lines, archive/profiles/r02_probe_ctx.txt.  p is gathered by that SpMV:
+            // plain; with the nt hint on p the SpMV lost 5 us, archive/profiles/r02_cg_store_policy.txt)
             st_policy(reinterpret_cast<V *>(r) + i, rv, (pol & 4) != 0);
 #pragma unroll
             for (int k = 0; k < W; k++) acc += (double)rv[k] * (double)rv[k];   // <r, r>             (:97, z == r)

@@ -62,7 +62,7 @@ bool prefers_balanced(int64_t rows, int64_t nnz, const row_profile &pr, size_t v
 // are the row indices of a COO matrix non-decreasing and inside [0, rows)?  (spmv_coo_hyb.hip; synchronises the stream)
 int coo_rows_sorted(int64_t rows, int64_t nnz, const int *Ai, hipStream_t s, int *sorted, int *long_runs = nullptr); // long_runs: a row of > 1024 entries
 // ELL lanes per row (spmv_ell_dia.hip): 1 = the row kernel (storage-order sums), 2..16 = the slices kernel.  Auto rule,
-// from tools/ell_wide_probe.py (profiles/r02_ell_wide_lanes_f64.txt): every lane keeps >= kEllSliceMinSlots slots
+// from tools/ell_wide_probe.py (archive/profiles/r02_ell_wide_lanes_f64.txt): every lane keeps >= kEllSliceMinSlots slots
 // (lanes = width / 16 rounded down to a power of two, at most 16); two lanes only pay below kEllSliceMaxRows2 rows
 // (one lane per row no longer fills 256 CUs x 8 waves x 64 lanes), four or more up to kEllSliceMaxRows.
 constexpr int64_t kEllSliceMaxRows2 = 131072, kEllSliceMaxRows = 524288;
@@ -102,8 +102,8 @@ __device__ __forceinline__ void reset_fold_state(double *area)
 // ---- cross-lane steps on the DPP path (gfx9 family: row_shr, row_bcast:15/31, wave_shr:1) -----------------------------
 // `__shfl_*` compiles to ds_bpermute_b32: a trip through the LDS crossbar per step, and a wave-wide reduction or scan is
 // six DEPENDENT steps -- ~1500 cycles at the very end of a workgroup's life, i.e. residency: the fused <y, w> of
-// csr_stream cost 10-15 us of 128 on the headline matrix with it (tools/r2_probe.hip: csrx flags 5/9/17 against 1,
-// profiles/r02_probe_timing_session5.txt).  DPP moves ride on the VALU.  All deterministic: a fixed tree.
+// csr_stream cost 10-15 us of 128 on the headline matrix with it (archive/tools/r2_probe.hip: csrx flags 5/9/17 against 1,
+// archive/profiles/r02_probe_timing_session5.txt).  DPP moves ride on the VALU.  All deterministic: a fixed tree.
 constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118, kDppRowBcast15 = 0x142,
               kDppRowBcast31 = 0x143, kDppWaveShr1 = 0x138;
 // value of the source lane selected by CTRL, `fill` where there is none (or the row is masked off)
@@ -332,7 +332,7 @@ constexpr int kHybTileRows = 256; // rows per workgroup of the one-launch HYB ke
 int hyb_tile_starts(int64_t rows, int64_t coo_entries, const int *coo_Ai, int32_t *tile_start, int *max_in_tile_dev, hipStream_t s);
 // The one-launch kernel walks a tile's COO entries 256 at a time behind its ELL slots: right for a light COO part (the usual
 // HYB: a few entries in some rows), wrong for a heavy one, where the entry-tiled COO kernel in a second launch is faster
-// (tools/hyb_fuse_probe.py, profiles/r02_hyb_one_vs_two_launches.txt: the crossover lies at 2.8-3.1 entries per row now that the second launch is the CSR kernel on the COO plan's row offsets).  One launch when the COO part averages at most
+// (tools/hyb_fuse_probe.py, archive/profiles/r02_hyb_one_vs_two_launches.txt: the crossover lies at 2.8-3.1 entries per row now that the second launch is the CSR kernel on the COO plan's row offsets).  One launch when the COO part averages at most
 // kHybFusedMaxPerRow entries per row and no tile holds more than kHybFusedMaxInTile; $CMI_HYB_ONE_LAUNCH=0/1 forces it.
 constexpr double kHybFusedMaxPerRow = 3.0;
 constexpr int kHybFusedMaxInTile = 4096;
@@ -340,7 +340,7 @@ constexpr int kHybFusedMaxInTile = 4096;
 int wave_partition_build(cmi_plan *p, const int *Ap, int k, hipStream_t s, int q_override = 0); // spmv_csr.hip (q_override: entries per tile, csr_wavev)
 int csr16_build(cmi_plan *p, const int *Ap, const int *Aj, hipStream_t s, int wave_k = 0);
 // spmv_csr_runs.hip: the plan's run-compressed column copy (+ the packed tiles when `values` is given) and the multiply that reads it
-int csr_runs_build(cmi_plan *p, const int *Ap, const int *Aj, int v, double min_mean_piece, const void *values, hipStream_t s, double *mean_piece);
+int csr_runs_build(cmi_plan *p, const int *Ap, const int *Aj, int v, double min_mean_piece, const void *values, hipStream_t s, double *mean_piece, int cap = 0);
 int csr_runs_multiply_f64(const cmi_plan *p, const int *Ap, const int *Aj, const double *Ax, const double *x, double *y, int accumulate, hipStream_t s,
                           const double *w, double *dot_partial, int *dot_partials, int cache_policy, int xcd_swizzle);
 int csr16_pack(cmi_plan *p, const int *Ap, const void *values, hipStream_t s); // the wave-tiled 16-bit copy + the values -> packed wave tiles (CMI_CSR_STREAM_PACKED)

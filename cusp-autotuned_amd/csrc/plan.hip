@@ -138,7 +138,7 @@ static bool wave_tiles_fit(int64_t rows, int64_t nnz, int64_t max_len)
 // K = floor(mean + longest / 64), so that a wave tile of Q = 64 K - longest entries holds about Q / mean <= 64 rows; the longest row
 // small enough for the tiles to fill 90 % of the wave's request slots.  OPT-IN: asked for per plan (cfg.kernel = CMI_CSR_STREAM_WAVE
 // with rows_per_block < 0) -- measured against csr_stream it wins on FEM-like rows (thermal2-like 0.94 / 0.90 of its time, f64 / f32)
-// and loses on large matrices with scattered columns (1.02-1.30x; profiles/r02_wavep_ab.txt), so no plan selects it by itself
+// and loses on large matrices with scattered columns (1.02-1.30x; archive/profiles/r02_wavep_ab.txt), so no plan selects it by itself
 // ($CMI_CSR_WAVE=2: every AUTO plan whose rows qualify does -- measurements).
 static int wave_partition_k(int64_t rows, int64_t nnz, const row_profile &prof, bool asked, int asked_k)
 {
@@ -215,7 +215,7 @@ static int waver_env()
     static const int env = [] { const char *e = std::getenv("CMI_CSR_WAVER"); return e ? std::atoi(e) : -1; }();
     return env;
 }
-static bool waver_try(cmi_plan *p, const int *Ap, const int *Aj, bool asked, int asked_v, bool keep_policy, const void *values, hipStream_t s, int *st)
+static bool waver_try(cmi_plan *p, const int *Ap, const int *Aj, bool asked, int asked_v, int asked_cap, bool keep_policy, const void *values, hipStream_t s, int *st)
 {
     const int64_t rows = p->rows, nnz = p->nnz;
     if (p->dtype != CMI_F64 || rows <= 0 || nnz <= 0 || p->prof.max_len < 1 || p->prof.in_long > 0 || p->cols < 2 || p->cols >= ((int64_t)1 << 30)) return false;
@@ -230,7 +230,7 @@ static bool waver_try(cmi_plan *p, const int *Ap, const int *Aj, bool asked, int
         if (waver_env() != 1 && (mean < 8.0 || nnz * (int64_t)12 <= kInfinityCacheBytes / 4 * 3)) return false;
     }
     double mean_piece = 0.0;
-    *st = csr_runs_build(p, Ap, Aj, v, asked ? 0.0 : kWaverMinPiece, values, s, &mean_piece);
+    *st = csr_runs_build(p, Ap, Aj, v, asked ? 0.0 : kWaverMinPiece, values, s, &mean_piece, asked ? asked_cap : 0);
     if (*st != CMI_SUCCESS || !p->runs_start) return false;
     p->cfg.kernel = values ? CMI_CSR_STREAM_PACKED : CMI_CSR_STREAM_WAVER;
     p->cfg.block_size = 256;
@@ -397,13 +397,14 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
     // CMI_CSR_STREAM_WAVER / _PACKED: wave tiles on the run-compressed column copy (spmv_csr_runs.hip); policy / dealing as for WAVEV
     cmi_config waver_shape;
     bool want_waver = false, want_packed = false;
-    int waver_v = 0;
+    int waver_v = 0, waver_cap = 0;
     if (format == CMI_FORMAT_CSR && cfg && (cfg->kernel == CMI_CSR_STREAM_WAVER || cfg->kernel == CMI_CSR_STREAM_PACKED)) {
         if (!csr_columns && num_entries > 0) { delete p; return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: CMI_CSR_STREAM_WAVER needs the column indices -- use cmi_plan_create_csr"); }
         want_waver = true;
         want_packed = cfg->kernel == CMI_CSR_STREAM_PACKED;
         if (dtype != CMI_F64 && !want_packed) { delete p; return fail(CMI_ERROR_NOT_SUPPORTED, "cmi_plan_create: CMI_CSR_STREAM_WAVER is an f64 kernel"); }
         waver_v = cfg->items_per_thread;
+        waver_cap = cfg->threads_per_row; // (this kernel's use of the field: entries per piece at most, 0 = the rule, 3 or 4)
         waver_shape = *cfg;
         waver_shape.kernel = CMI_KERNEL_AUTO;
         waver_shape.rows_per_block = 0;
@@ -464,14 +465,14 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
             // every line of its streams is requested exactly once: beyond the Infinity Cache the streaming hint is right whatever
             // the table's csr_stream entry of this bucket says (its 16-byte-vector shapes measured the other way) -- the top twelve of
             // 96 swept shapes on the headline matrix all carry it, a tridiagonal matrix of 10^7 rows 91.8 -> 83 us
-            // (profiles/r02_wave_shape_sweep.txt, r02_wave_ab.txt); below it, plain loads keep the matrix resident (tuning.hip)
+            // (archive/profiles/r02_wave_shape_sweep.txt, r02_wave_ab.txt); below it, plain loads keep the matrix resident (tuning.hip)
             if (num_entries * (int64_t)(sizeof(int) + vbytes) > kInfinityCacheBytes + kInfinityCacheBytes / 4) p->cfg.nontemporal |= kPolLoadNT;
             p->cfg.nontemporal |= kPolStoreNT;
         } else if (st == CMI_SUCCESS && want_packed && csr_values && csr_columns && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
                    wave_tiles_fit(num_rows, num_entries, p->prof.max_len) && packed16_try(p, index_array, csr_columns, csr_values, waver_shape.nontemporal != 0, s, &st)) {
             // (stencil-like rows: packed wave tiles of the 16-bit copy, spmv_csr16.hip; p->cfg is set)
         } else if (st == CMI_SUCCESS && auto_kernel && !want_partition && !want_wavev && csr_columns && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
-                   waver_try(p, index_array, csr_columns, want_waver, waver_v, want_waver && waver_shape.nontemporal != 0, want_packed ? csr_values : nullptr, s, &st)) {
+                   waver_try(p, index_array, csr_columns, want_waver, waver_v, waver_cap, want_waver && waver_shape.nontemporal != 0, want_packed ? csr_values : nullptr, s, &st)) {
             // (the run-compressed copy was built and pays: p->cfg is set)
         } else if (st == CMI_SUCCESS && want_waver) {
             st = fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: CMI_CSR_STREAM_WAVER / _PACKED need f64 values, 2 <= columns < 2^30, items_per_thread 0, 1, 2 or 4, no row of 512+ entries and the longest row at most half of the 256 x items_per_thread slots of a wave tile");

@@ -205,7 +205,7 @@ coo_lane4_kernel(int64_t num_entries, const int *__restrict__ Ai, const int *__r
 // ---------------------------------------------------------------------------------------------
 // The order-agnostic kernels above pay for not knowing the order: y is zero-filled first (80 MB on the headline
 // matrix) and every run end is a read-modify-write at the memory side -- 1.10 GB moved for 0.96 GB of compulsory bytes
-// (profiles/r02_formats_pmc_before.json).  The reference's contract for coo_matrix IS sorted entries
+// (archive/profiles/r02_formats_pmc_before.json).  The reference's contract for coo_matrix IS sorted entries
 // (cusp/coo_matrix.h:72); a plan (plan.hip) checks that once, and then this kernel runs: csr_stream's single-pass tile
 // with the row pointers built on the fly from the row indices.
 //

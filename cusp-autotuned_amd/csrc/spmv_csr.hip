@@ -103,15 +103,15 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
     // loop peeled away (measured 3-4 % faster on the 5-point Poisson matrix, same arithmetic).
     // Row pointers stay in REGISTERS here: the tile bounds come from two uniform (scalar) loads, each lane
     // loads the two offsets of its own row, and nothing waits at a barrier before the index / value
-    // vectors are requested -- 126.5 us instead of 129.0 on the headline matrix (tools/r2_probe.hip,
-    // profiles/r02_probe_timing.txt: csrx flags 1 vs 0), same bits.
+    // vectors are requested -- 126.5 us instead of 129.0 on the headline matrix (archive/tools/r2_probe.hip,
+    // archive/profiles/r02_probe_timing.txt: csrx flags 1 vs 0), same bits.
     //
     // Two request shapes for the entry streams of that path.  LANE-STRIDED (policy bit kPolStrided, round 2): lane l takes entries
     // l, l + block, l + 2 block, ... counted from the tile's FIRST entry -- every load instruction of a wave is one contiguous
     // span (256 B of indices, 512 B of f64 values), every line of the streams is requested by exactly one instruction, nothing
     // of the neighbouring tile is read and no alignment of the arrays is assumed.  The memory system serves that shape 7-9 %
-    // faster than 16-byte vectors per lane whose two value vectors interleave (tools/r2_probe.hip `shape`: 115.9 vs 124.6 us
-    // for the headline matrix's bytes, profiles/r02_probe_load_shape.txt), and the multiply keeps about half of that.  The body is
+    // faster than 16-byte vectors per lane whose two value vectors interleave (archive/tools/r2_probe.hip `shape`: 115.9 vs 124.6 us
+    // for the headline matrix's bytes, archive/profiles/r02_probe_load_shape.txt), and the multiply keeps about half of that.  The body is
     // BRANCH-FREE: a lane past the tile's last entry re-reads the tile's first one and parks a product nobody reads -- with a
     // predicate per k the compiler waits for each gather before it requests the next (K round trips instead of one; the same
     // file, `csrd` before / after).  Same products, same order of summation: same bits.
@@ -452,8 +452,8 @@ csr_stream_kernel(int64_t num_rows, int64_t num_entries, const int *__restrict__
 // request carries an entry), gathers x, parks the products in the wave's own LDS region and adds its row in storage order.  No
 // s_barrier: a wave's LDS instructions execute in order, so nothing waits for another wave's loads; every lane owns a row in the
 // sum phase (csr_stream: 192 of 256); the tile bounds are two scalar loads and the row's end is the next lane's start (one
-// row-offset load per lane, wave_shl:1 on the DPP path).  Headline matrix: 124.8 -> 120-121 us (tools/r2_probe.hip csrw / csrw1,
-// profiles/r02_probe_wave_tiles.txt).  Same products, same order of summation as the host loop: bit-exact.
+// row-offset load per lane, wave_shl:1 on the DPP path).  Headline matrix: 124.8 -> 120-121 us (archive/tools/r2_probe.hip csrw / csrw1,
+// archive/profiles/r02_probe_wave_tiles.txt).  Same products, same order of summation as the host loop: bit-exact.
 // A tile that does not fit (rows longer than K: an explicit config, or a plan-less call, which knows only the mean row length) takes
 // further PASSES of 64 K entries through the same body, every lane carrying its row's running sum across them (round 4; before: one lane
 // per row straight from the arrays).
@@ -1336,7 +1336,7 @@ int measure_column_locality(int64_t rows, int64_t cols, const int *Ap, const int
 
 // cost of the longest row inside the row-tile kernel vs the whole multiply at streaming speed.  The row's
 // workgroup streams it cooperatively (kLongRowUs per entry: 1.2-2.4 ns measured, one workgroup is latency-bound at
-// ~10 GB/s; tools/irregular_probe.py --sweep, profiles/r01_irregular_rows.txt); with
+// ~10 GB/s; tools/irregular_probe.py --sweep, archive/profiles/r01_irregular_rows.txt); with
 // threads_per_row == 1 asked for, one lane adds it in storage order (kSerialRowUs per entry).
 constexpr double kLongRowUs = 0.002, kSerialRowUs = 0.012;
 bool prefers_balanced(int64_t rows, int64_t nnz, const row_profile &pr, size_t value_bytes, bool strict_order)
@@ -1440,17 +1440,19 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     } else {
         select_config(CMI_FORMAT_CSR, dtype, rows, cols, nnz, user, &c);
         // PLAN-LESS and no kernel asked for (the literal replacement of the reference's selector, csr_vector_spmv.h:225-258: arrays in,
-        // launch out, nothing measured): where the table says csr_stream and the MEAN row length sits within 2 % below an integer K <= 10 --
-        // what a stencil looks like from its sizes alone -- the wave-tile kernel runs with K entries per lane, the shape a plan would give
-        // it (the plan-less call ran csr_stream at 0.80 where the plan's csr_wave gets 0.84).  A matrix that only LOOKS
-        // like one (irregular rows whose mean happens to qualify) is still correct and still streams: tiles that overflow their 64 K slots
-        // take a second pass.  $CMI_PLANLESS_WAVE=0: never.
+        // launch out, nothing measured): where the table says csr_stream and the MEAN row length sits within 0.5 % below an integer K <= 10
+        // -- what a stencil of 10^5+ rows looks like from its sizes alone -- the wave-tile kernel runs with K entries per lane, the shape a
+        // plan would give it (the plan-less call ran csr_stream at 0.80 where the plan's csr_wave gets 0.84).  Measured,
+        // tools/planless_wave_probe.py, profiles/r04_planless_wave_rule.txt: 5- / 7- / 9-point stencils 0.96-0.99 of the table kernel's time,
+        // a tridiagonal matrix 0.90.  A matrix that only LOOKS like one (random row lengths 1..9 whose mean happens to be 4.99) is still
+        // correct and still streams -- tiles that overflow their 64 K slots take a second pass -- at 1.01-1.09 of the table kernel's time:
+        // the price of a false positive, which the 0.5 % window makes rare.  $CMI_PLANLESS_WAVE=0: never.
         static const int planless_wave = [] { const char *e = std::getenv("CMI_PLANLESS_WAVE"); return e ? std::atoi(e) : 1; }();
         if (planless_wave && (!user || (user->kernel == CMI_KERNEL_AUTO && !user->block_size && !user->rows_per_block && !user->items_per_thread && !user->threads_per_row)) &&
             c.kernel == CMI_CSR_STREAM && c.threads_per_row <= 1 && rows >= 4096 && nnz > 0) {
             const double mean = (double)nnz / (double)rows;
             const int k = (int)std::ceil(mean);
-            if (k >= 2 && k <= kWaveTileMaxK && mean >= 0.98 * k) {
+            if (k >= 2 && k <= kWaveTileMaxK && mean >= 0.995 * k) {
                 c.kernel = CMI_CSR_STREAM_WAVE;
                 c.block_size = 256;
                 c.rows_per_block = 256;
@@ -1470,7 +1472,7 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
     // The fused <y, w> instance runs inside a solver, between vector kernels whose vectors (p, r, y: 240 MB) would fit the
     // 256 MiB Infinity Cache if the matrix streams did not push them out: here the once-read index / value streams carry the nt
     // hint whatever the table says for the stand-alone multiply (where plain loads measured equal or better).  CG iteration on the
-    // headline matrix 263-268 -> 255-257 us, with the 16-bit column copy 248-251 -> 245-248 (profiles/r02_cg_dot_policy.txt;
+    // headline matrix 263-268 -> 255-257 us, with the 16-bit column copy 248-251 -> 245-248 (archive/profiles/r02_cg_dot_policy.txt;
     // the y-store hint and load hints in the vector kernels measured no effect: r02_cg_y_store_policy.txt,
     // r02_cg_vector_load_policy.txt).  $CMI_DOT_POLICY=0..3 overrides (measurements).
     if (w && dot_partial) {
@@ -1501,8 +1503,8 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         int rpb = c.rows_per_block;
         const int ipt = c.items_per_thread;
         // The fused <y, w> instance wants whole waves of rows: with the table's 176 rows per tile (2.75 waves) the dot costs
-        // +9.3 us on the headline matrix, with 192 (3 waves) +3.7 us (tools/r2_probe.hip csrx flags 5 vs 1 at rpb 176 / 192,
-        // profiles/r02_probe_dot_ablation.txt).  So a table-chosen shape (not a caller's explicit one) is rounded up to the
+        // +9.3 us on the headline matrix, with 192 (3 waves) +3.7 us (archive/tools/r2_probe.hip csrx flags 5 vs 1 at rpb 176 / 192,
+        // archive/profiles/r02_probe_dot_ablation.txt).  So a table-chosen shape (not a caller's explicit one) is rounded up to the
         // next multiple of 64 rows when the tile's single LDS pass still holds them.
         if (w && dot_partial && (!user || user->kernel == CMI_KERNEL_AUTO || user->rows_per_block == 0) && c.threads_per_row <= 1 && rows > 0) {
             const int up = (rpb + kWave - 1) / kWave * kWave;
@@ -1525,7 +1527,7 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         const int64_t tpx = ceil_div(tiles, kXcds);
         int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
         // ... and its tiles go out in launch order: inside the solve that measured 2.3-3.5 us per iteration better than any chunk
-        // dealing, for every tile shape (tools/cg_dot_shape_probe.py, profiles/r02_cg_dot_shape.txt) -- stand-alone it is the
+        // dealing, for every tile shape (tools/cg_dot_shape_probe.py, archive/profiles/r02_cg_dot_shape.txt) -- stand-alone it is the
         // other way round (section 3.1 of DESIGN.md).  A caller's explicit shape is left alone; $CMI_DOT_SWIZZLE overrides.
         if (w && dot_partial && (!user || user->kernel == CMI_KERNEL_AUTO)) swz = dot_swizzle(swz, plan);
         const int64_t grid64 = swz == 0 ? tiles : swz == 1 ? tpx * kXcds : ceil_div(tiles, (int64_t)kXcds * swz) * kXcds * swz;
@@ -1605,7 +1607,7 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
         const int64_t tpx = ceil_div(tiles, kXcds);
         int swz = c.xcd_swizzle < 0 ? 0 : c.xcd_swizzle;
         // (the wave-tile kernel keeps the table's chunk dealing inside a solve too: 239 against 243.5 us per CG iteration in launch
-        //  order, profiles/r02_cg_wave_dot.txt -- csr_stream's dot instance is the other way round)
+        //  order, archive/profiles/r02_cg_wave_dot.txt -- csr_stream's dot instance is the other way round)
         if (w && dot_partial && (!user || user->kernel == CMI_KERNEL_AUTO)) swz = dot_swizzle(swz, plan, swz);
         const int64_t grid64 = padded_grid(tiles, swz);
         if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "csr_wave: grid too large");

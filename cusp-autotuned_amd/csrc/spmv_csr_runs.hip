@@ -141,7 +141,7 @@ static int device_exclusive_scan(const int *in, int *out, size_t n, hipStream_t 
 // Gives `p` (a CSR plan with a measured row profile) the run-compressed column copy on wave tiles of 256 v slots.  On success
 // p->runs_start / runs_pieces are set (and runs_packed when `values` is given).  *mean_piece: entries per piece (the caller decides
 // whether that pays).  Nothing is kept when min_mean_piece is not reached.  Synchronises `s`.
-int csr_runs_build(cmi_plan *p, const int *Ap, const int *Aj, int v, double min_mean_piece, const void *values, hipStream_t s, double *mean_piece)
+int csr_runs_build(cmi_plan *p, const int *Ap, const int *Aj, int v, double min_mean_piece, const void *values, hipStream_t s, double *mean_piece, int cap_asked)
 {
     const int64_t rows = p->rows, nnz = p->nnz;
     if (mean_piece) *mean_piece = 0.0;
@@ -159,7 +159,8 @@ int csr_runs_build(cmi_plan *p, const int *Ap, const int *Aj, int v, double min_
     // 4 + 4 + 1 -- no fewer pieces than cut at 3, and the pieces of 4 park their x values 32 bytes apart in LDS (a 4-way bank conflict
     // where pieces of 3 have none; profiles/r04_long_rows_pmc.json: LDS index unit 71 % busy on ldoor-like).  Cap 3 when it costs at most
     // 3 % more pieces than cap 4 ($CMI_WAVER_CAP=3 / 4 forces).
-    static const int cap_env = [] { const char *ev = std::getenv("CMI_WAVER_CAP"); return ev ? std::atoi(ev) : 0; }();
+    static const int cap_env_ = [] { const char *ev = std::getenv("CMI_WAVER_CAP"); return ev ? std::atoi(ev) : 0; }();
+    const int cap_env = (cap_asked == 3 || cap_asked == 4) ? cap_asked : cap_env_; // (a plan that asks: config.threads_per_row)
     int cap = kRunCap;
     if (e == hipSuccess) {
         hipLaunchKernelGGL(runs_count_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, s, rows, Ap, Aj, kRunCap, count, totals);

@@ -49,7 +49,7 @@ ell_row_kernel(int64_t num_rows, int width, int64_t pitch, const int *__restrict
     // A tile = the blockDim.x * RPL consecutive rows of one workgroup (one-shot grid).  Tiles are dealt to the XCDs in
     // chunks (`swizzle`: common.h tile_of_block) so that the x window a chunk gathers -- its rows +- the matrix
     // bandwidth -- is fetched into ONE L2; in launch order x is fetched ~2.5x on the headline matrix
-    // (profiles/r02_formats_pmc.json).  The grid is padded to whole chunk rounds: a workgroup whose tile lies past the
+    // (archive/profiles/r02_formats_pmc.json).  The grid is padded to whole chunk rounds: a workgroup whose tile lies past the
     // end leaves as a whole.
     const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle);
     if (tile >= tiles) return;
@@ -225,7 +225,7 @@ dia_row_kernel(int64_t num_rows, int64_t num_cols, int num_diagonals, int64_t pi
     __shared__ int soff[kDiaChunk];
     __shared__ double dot_slots[DOT ? 1024 / kWave : 1];
     // tiles (one workgroup's rows) dealt to the XCDs in chunks: see ell_row_kernel.  Measured on the headline matrix
-    // (tools/r2_probe.hip, profiles/r02_probe_*): launch order 98-101 us with x fetched 2.9x (651 MB read), chunks of 32
+    // (archive/tools/r2_probe.hip, archive/profiles/r02_probe_*): launch order 98-101 us with x fetched 2.9x (651 MB read), chunks of 32
     // tiles 85 us with 498 MB read (compulsory: 480 MB).
     const int64_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, swizzle);
     if (tile >= tiles) return;

@@ -74,7 +74,7 @@ static void heuristic(int format, int dtype, double mean, cmi_config *c)
         else if (mean <= 96.0) { c->items_per_thread = 2; c->threads_per_row = 0; }
         else { c->items_per_thread = 2; c->threads_per_row = 32; }
         break;
-    // measured (tools/r2_probe.hip, profiles/r02_probe_timing_session2.txt): nt policy, tiles dealt to the XCDs in chunks
+    // measured (archive/tools/r2_probe.hip, archive/profiles/r02_probe_timing_session2.txt): nt policy, tiles dealt to the XCDs in chunks
     case CMI_FORMAT_ELL: c->kernel = CMI_ELL_ROW; c->items_per_thread = 1; c->nontemporal = 3; c->xcd_swizzle = 64; break;
     case CMI_FORMAT_DIA: c->kernel = CMI_DIA_ROW; c->items_per_thread = 2; c->block_size = 512; c->nontemporal = 3; c->xcd_swizzle = 32; break;
     case CMI_FORMAT_COO: c->kernel = CMI_COO_LANE4; c->items_per_thread = 4; break;
@@ -341,7 +341,7 @@ void select_config(int format, int dtype, int64_t rows, int64_t cols, int64_t nn
             // The table's nt-load bit was measured on matrices far larger than the 256 MiB Infinity Cache, where the once-read
             // streams only push the vectors out of it.  A matrix whose index and value streams fit there is served from it on every
             // multiply after the first if they are loaded plainly: thermal2-like (100 MB) 20.0 us against 22.5 with the hint, a
-            // 9-point matrix of 243 MB 42.2 against 48.5; at 430 MB and above the hint wins (profiles/r02_stream_shape_ab.txt,
+            // 9-point matrix of 243 MB 42.2 against 48.5; at 430 MB and above the hint wins (archive/profiles/r02_stream_shape_ab.txt,
             // r02_autotune_csr_short_rows.jsonl.gz).  So the bit is dropped below 1.25x the cache.
             if (format == CMI_FORMAT_CSR && out->kernel == CMI_CSR_STREAM && (out->nontemporal & kPolLoadNT)) {
                 const int64_t stream_bytes = nnz * (int64_t)(sizeof(int) + (dtype == CMI_F64 ? 8 : 4));

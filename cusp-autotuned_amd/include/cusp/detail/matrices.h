@@ -43,8 +43,9 @@ public:
 // launch shape, the CSR row-length profile, COO row-sortedness.  Owned by the CONTAINER (views have none and multiply
 // through the plan-less entry points); made at the first cusp::multiply -- that one call synchronises the stream -- or
 // ahead of time by A.plan(); re-made when the index array or the sizes change; `invalidate_plan()` after editing the
-// structure in place.  The reference has no such object (its KTT path recomputes `row_starts` on the host per call,
-// cusp/system/cuda/ktt/csr_multiply.h:239-247).
+// structure -- row offsets OR column indices: a CSR plan is made from both and may hold a copy derived from the columns (the
+// run-compressed pieces of CMI_CSR_STREAM_WAVER, round 4) -- in place.  Values are never cached: refresh them freely.  The reference
+// has no such object (its KTT path recomputes `row_starts` on the host per call, cusp/system/cuda/ktt/csr_multiply.h:239-247).
 struct plan_slot {
     std::shared_ptr<cmi_plan> plan;
     const void *index_ptr = nullptr, *columns_ptr = nullptr;

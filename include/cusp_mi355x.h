@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CMI_VERSION 300 /* 0.3.0: communicator + collectives (RCCL) behind the boundary, cmi_plan_validate, CMI_CSR_STREAM_WAVEV */
+#define CMI_VERSION 400 /* 0.4.0: run-compressed column copy (CMI_CSR_STREAM_WAVER), packed tiles (CMI_CSR_STREAM_PACKED), plan-less wave tiles; 0.3.0: communicator + collectives (RCCL) behind the boundary, cmi_plan_validate, CMI_CSR_STREAM_WAVEV */
 
 typedef enum cmi_status {
     CMI_SUCCESS = 0,
@@ -187,7 +187,9 @@ typedef enum cmi_kernel {
                                storage-order sums: bit-exact.  An AUTO plan made with the columns selects it when the pieces average 2.5+
                                entries on a matrix csr_wavev's size / row-length rule admits ($CMI_CSR_WAVER=0: never, =1: whenever the rows
                                qualify); asked for explicitly it is refused only where the tile cannot hold the longest row.  items_per_thread
-                               1, 2, 4 (0: 4) = 256 x that many slots per wave tile.  Needs fewer than 2^30 columns, no row of 512+ entries,
+                               1, 2, 4 (0: 4) = 256 x that many slots per wave tile; threads_per_row = entries per piece at most, 3 or 4
+                               (0: 3 where that costs at most 3 % more pieces than 4 -- pieces of three leave no LDS bank conflict between
+                               them -- else 4).  Needs fewer than 2^30 columns, no row of 512+ entries,
                                16-byte aligned Ax, 8-byte aligned x.  cmi_plan_validate checks the column indices.                     */
     CMI_CSR_STREAM_PACKED = 12, /* OPT-IN, plans of cmi_plan_create_csr_values only (round 4), f64: CMI_CSR_STREAM_WAVER with the pieces AND THE VALUES of
                                every wave tile laid side by side in one plan-owned buffer ([pieces | pad to 16 | values | pad to 16] per tile),
@@ -261,7 +263,7 @@ int cmi_tuning_select(int format, int dtype, int64_t num_rows, int64_t num_cols,
  *       num_rows * k  +  [the COO part is not empty] * (threshold + relative_speed * coo_entries(k))      (in ELL slots)
  *       -- relative_speed = cost of a COO entry in ELL slots, threshold = fixed cost of the second launch in ELL slots.
  *       The reference's rule is this model's marginal test without the launch term.  Measured on MI355X
- *       (tools/autotune_hyb.py, profiles/r02_autotune_hyb*), once per generation of the kernels behind a HYB multiply:
+ *       (tools/autotune_hyb.py, archive/profiles/r02_autotune_hyb*), once per generation of the kernels behind a HYB multiply:
  *       two launches with the COO tile kernel (1.3, 5e6); one launch for light COO parts (2.0, 0); and heavy COO parts
  *       through a COO plan's row offsets + the CSR kernel: (1.0, 2e6) for f64, (1.3, 2e6) for f32 -- a COO entry costs what
  *       an ELL slot costs, irregular matrices get a narrow ELL part; geometric-mean regret over the tuning set 1.11 against
@@ -269,7 +271,14 @@ int cmi_tuning_select(int format, int dtype, int64_t num_rows, int64_t num_cols,
 /*   CMI_HYB_RULE_COST2  the cost model with the two regimes a HYB plan has (cmi_plan_hyb_launches): while the COO part is light
  *       (at most 3 entries per row on average) the multiply is ONE launch and a COO entry costs `light_speed` ELL slots; beyond,
  *       it is ELL + the CSR kernel on the COO plan's row offsets:  threshold + relative_speed * coo_entries(k).  Offline on the
- *       sweep log (tools/autotune_hyb.py --refit): geometric-mean regret 1.03 (f64) / 1.06 (f32) against 1.11 for COST.       */
+ *       sweep log (tools/autotune_hyb.py --refit): geometric-mean regret 1.03 (f64) / 1.06 (f32) against 1.11 for COST.
+ *       THIS is the shipped rule (tuned/gfx950.json "hyb_rule"; the COST3 form printed by tools/autotune_hyb_holdout.py is an experiment
+ *       of that tool, no better on its hold-out, and not a rule kind of the library).
+ *       LIMIT OF THE RULE FORM: the width is a function of the row-length HISTOGRAM alone.  Held out (every 3-of-11 split,
+ *       profiles/r03_autotune_hyb_holdout.txt) the regret is 1.09 in the geometric mean and up to 1.48 on one matrix; on the full fit
+ *       f32 rows of uniform length 1..16 stay at 1.36 (the rule keeps one ELL slot where none is best).  No constants of this form close
+ *       those cases -- what they miss (how the COO part's columns gather) is not in a histogram.  A caller who knows the matrix passes the
+ *       width (cusp::hyb_matrix's num_entries_per_row / cmi_csr_to_hyb's width argument); the rule is the default, not a bound.          */
 typedef enum cmi_hyb_rule_kind { CMI_HYB_RULE_REFERENCE = 0, CMI_HYB_RULE_COST = 1, CMI_HYB_RULE_COST2 = 2 } cmi_hyb_rule_kind;
 int cmi_tuning_hyb_light_speed(int dtype, double *light_speed);      /* COST2's fourth parameter (persisted as "light_speed") */
 int cmi_tuning_set_hyb_light_speed(int dtype, double light_speed);
@@ -297,15 +306,16 @@ int cmi_hyb_entries_per_row(int dtype, int64_t num_rows, const int32_t *Ap, int 
 /* and recomputes `row_starts` on the host per call.                               */
 /*   cmi_plan_create reads the index array on the device and SYNCHRONISES `stream`  */
 /*   (one small kernel + a 16-byte read-back); everything after it is asynchronous.  */
-/*   A plan owns no device memory (except a HYB plan's tile ranges and the opt-in 16-bit column copy of   */
-/*   CMI_CSR_STREAM_C16, both freed by cmi_plan_destroy) and does not keep the pointers: the arrays are   */
+/*   A plan owns little device memory -- a HYB plan's tile ranges, a wave partition, a sorted-COO plan's row offsets, the       */
+/*   run-compressed / 16-bit column copies, the opt-in packed tiles: cmi_plan_device_bytes; all freed by cmi_plan_destroy -- and */
+/*   does not keep the pointers: the arrays are   */
 /*   passed again at every multiply; they must be the ones the plan was made for     */
 /*   (same sizes are checked; contents are the caller's promise).                     */
 /*   CONTRACT: the index arrays a plan was made from -- CSR row offsets, COO / HYB-COO   */
-/*   row indices, and for a CMI_CSR_STREAM_C16 plan the column indices -- MUST NOT     */
+/*   row indices, and for a plan made by cmi_plan_create_csr* the column indices --  MUST NOT     */
 /*   CHANGE IN PLACE while the plan is used.  A plan caches structure derived from     */
-/*   them (a sorted-COO plan its row offsets, a C16 plan the 16-bit columns, a wave     */
-/*   partition the tile bounds): after an in-place edit the multiplies read that stale  */
+/*   them (a sorted-COO plan its row offsets, a C16 plan the 16-bit columns, a WAVER plan the pieces of   */
+/*   consecutive columns, a wave partition the tile bounds): after an in-place edit the multiplies read that stale  */
 /*   structure and y is WRONG (never a fault: every kernel bounds its LDS tile by what   */
 /*   it reads).  Destroy the plan and make a new one when the structure changes;         */
 /*   cmi_plan_validate (below) tells whether that has happened.  cmi_plan_create also      */
@@ -349,7 +359,7 @@ int cmi_plan_destroy(cmi_plan *plan);
 /* Have the arrays the plan was made from changed since?  One streaming pass over them on the device (an order-sensitive    */
 /* 64-bit checksum, compared with the one taken at creation); SYNCHRONISES `stream`.  *valid_host: 1 same contents, 0 edited  */
 /* in place -> make a new plan.  index_array as for cmi_plan_create (HYB: the COO part's row indices); column_indices only     */
-/* for plans that own a copy derived from them (CMI_CSR_STREAM_C16), NULL otherwise.  ELL / DIA plans are always valid.        */
+/* for plans that own a copy derived from them (CMI_CSR_STREAM_C16, _WAVER, _PACKED), NULL otherwise.  ELL / DIA plans: always valid. */
 int cmi_plan_validate(const cmi_plan *plan, const int32_t *index_array, const int32_t *column_indices, void *stream,
                       int *valid_host);
 /* The launch shape the plan's multiplies run (SURVEY's cmi_plan_select): kernel CMI_CSR_BALANCED means   */

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(cmi):
 
 def test_version_and_status_strings(cmi):
     L = cmi.lib()
-    assert cmi.version() == 300
+    assert cmi.version() == 400
     assert L.cmi_status_string(7) == b"CMI_ERROR_COMM"
     assert L.cmi_status_string(0) == b"CMI_SUCCESS"
     assert L.cmi_status_string(1) == b"CMI_ERROR_INVALID_VALUE"

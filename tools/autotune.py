@@ -349,8 +349,8 @@ def main():
             best2, ms2, res = tune_one(cmi, torch, timer, label, [c for c in space if c.kernel == cmi.COO_TILE] + [best],
                                        lambda cfg: cmi.multiply(C, dx, y, cfg=cfg), checker(C, (cmi.COO_TILE,)),
                                        args.iters, args.rounds, log, cmi.coo_bytes(N, A.num_entries, vb))
-            for b in range(0, 8):
-                cmi.tuning_set(cmi.TABLE_COO_SORTED, dcode, 2.0 ** b * 1.2, best2)
+            # (round 4: measured and logged, no longer written to the table -- sorted COO multiplies through its plan's row offsets + the
+            #  CSR kernels; CMI_COO_TILE stays an explicit-config kernel with its built-in shape)
             summary.append((label, best2.as_dict(), ms2))
             print(label, best2, f"{ms2 * 1e3:.1f} us", flush=True)
             del C
@@ -440,7 +440,7 @@ def main():
                                                lambda cfg: cmi.multiply(C, dxs, ys, cfg=cfg), checker_b(C, (cmi.COO_TILE,)), args.iters, args.rounds, log,
                                                cmi.coo_bytes(rows_b, len(Aj_b), vb))
                     if best2 is not None:
-                        cmi.tuning_set(cmi.TABLE_COO_SORTED, dcode, mean_b, best2)
+                        pass  # (round 4: coo_sorted keys retired from the table, see above)
                         summary.append((label, best2.as_dict(), ms2))
                         print(label, best2, f"{ms2 * 1e3:.1f} us", flush=True)
                     del C

@@ -9,7 +9,7 @@ sweep log of tools/autotune_hyb.py (every (matrix, width K) -> measured time; hi
     instead of folding that into one constant;
   * the full-set fit of the better form, matrix by matrix.
 
-    python tools/autotune_hyb_holdout.py profiles/r02_autotune_hyb.jsonl.gz [--patch cusp-autotuned_amd/tuned/gfx950.json]
+    python tools/autotune_hyb_holdout.py archive/profiles/r02_autotune_hyb.jsonl.gz [--patch cusp-autotuned_amd/tuned/gfx950.json]
 """
 import argparse
 import collections
@@ -125,11 +125,16 @@ def main():
             kb = min(tk, key=tk.get)
             print(f"      {name:28s} COST3 K {K:3d} ({time_at(tk, K) * 1e3:7.1f} us)   best K {kb:3d} ({tk[kb] * 1e3:7.1f} us)   regret {reg[3][p3]:.3f}")
         rules[tag] = {"kind": "cost3", "relative_speed": p3[0], "threshold": p3[1], "light_speed": p3[2], "per_row": p3[3]}
-    print("hyb_rule", json.dumps(rules))
+    # COST3 is an EXPERIMENT of this tool (a per-row term on top of COST2): its hold-out regret is no better than COST2's (f32: worse), the
+    # library has no such rule kind and the shipped table carries COST2 (cusp-autotuned_amd/tuned/gfx950.json "hyb_rule", cusp_mi355x.h
+    # CMI_HYB_RULE_COST2).  Printed for the record only -- never written to the table (round 4: --patch refuses).
+    print("experiment only, NOT the product's rule (the table ships cost2): cost3 full-set fit", json.dumps(rules))
     if args.patch:
+        raise SystemExit("--patch: the COST3 form is not a rule kind of the library (cmi_hyb_rule_kind); the shipped rule is COST2, fitted by tools/autotune_hyb_refit.py")
+    if False:
         doc = json.load(open(args.patch))
         doc["hyb_rule"] = rules
-        doc["hyb_rule_source"] = ("tools/autotune_hyb.py on MI355X (width sweeps, raw log profiles/r02_autotune_hyb.jsonl.gz); rule form COST3 fitted on the whole "
+        doc["hyb_rule_source"] = ("tools/autotune_hyb.py on MI355X (width sweeps, raw log archive/profiles/r02_autotune_hyb.jsonl.gz); rule form COST3 fitted on the whole "
                                   "set by tools/autotune_hyb_holdout.py after its hold-out check (every 3-matrix hold-out split: profiles/r03_autotune_hyb_holdout.txt)")
         with open(args.patch, "w") as f:
             f.write("{\n")

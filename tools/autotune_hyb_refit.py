@@ -4,7 +4,7 @@ tuning matrices' row-length histograms (seeded, numpy only -- no GPU), fits the 
 cost model CMI_HYB_RULE_COST2 (one launch while the COO part averages <= 3 entries per row: `light_speed` slots per COO entry;
 beyond: threshold + relative_speed per entry), prints the ranking and patches `hyb_rule` in the table.
 
-    python tools/autotune_hyb_refit.py profiles/r02_autotune_hyb.jsonl.gz [--out cusp-autotuned_amd/tuned/gfx950.json] [--dry-run]
+    python tools/autotune_hyb_refit.py archive/profiles/r02_autotune_hyb.jsonl.gz [--out cusp-autotuned_amd/tuned/gfx950.json] [--dry-run]
 """
 import argparse
 import collections

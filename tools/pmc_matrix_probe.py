@@ -29,13 +29,16 @@ import suitesparse_like as ssl  # noqa: E402
 K = int(os.environ.get("PMC_LAUNCHES", "6"))
 
 
+SCALE = float(os.environ.get("PMC_SCALE", "1.0"))  # stand-in size (1.0: the published one)
+
+
 def cached(name):
-    """full-size stand-in, generated once per box (the passes are separate processes)"""
-    path = f"/tmp/cmi_{name}_1.0.npz"
+    """stand-in at SCALE, generated once per box (the passes are separate processes)"""
+    path = f"/tmp/cmi_{name}_{SCALE}.npz"
     if os.path.exists(path):
         z = np.load(path)
         return z["Ap"], z["Aj"], z["Ax"], str(z["src"])
-    Ap, Aj, Ax, src = ssl.load(name, 1.0)
+    Ap, Aj, Ax, src = ssl.load(name, SCALE)
     np.savez(path, Ap=Ap, Aj=Aj, Ax=Ax, src=src)
     return Ap, Aj, Ax, src
 
@@ -63,7 +66,9 @@ def variants_for(A):
     if hasattr(cmi, "CSR_STREAM_WAVER"):
         for v in (int(s) for s in os.environ.get("PMC_WAVER", "4").split(",") if s):
             for pol in (int(s) for s in os.environ.get("PMC_WAVER_POL", "0").split(",") if s):
-                out.append((f"waver{v}" + (f"/pol{pol}" if pol else ""), cmi.Config(kernel=cmi.CSR_STREAM_WAVER, items_per_thread=v, nontemporal=pol)))
+                for cap in (int(s) for s in os.environ.get("PMC_WAVER_CAP", "0").split(",") if s):  # 0: the rule; 3 / 4: entries per piece at most
+                    out.append((f"waver{v}" + (f"/pol{pol}" if pol else "") + (f"/cap{cap}" if cap else ""),
+                                cmi.Config(kernel=cmi.CSR_STREAM_WAVER, items_per_thread=v, nontemporal=pol, threads_per_row=cap)))
                 if os.environ.get("PMC_PACKED", "1") != "0":
                     out.append((f"packed{v}" + (f"/pol{pol}" if pol else ""), ("values", cmi.Config(kernel=cmi.CSR_STREAM_PACKED, items_per_thread=v, nontemporal=pol))))
     if os.environ.get("PMC_C16", "0") != "0":

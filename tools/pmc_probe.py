@@ -29,14 +29,22 @@ for fmt in fmts:
     if fmt == "csr16":  # the opt-in plan with the 16-bit column copy (CMI_CSR_STREAM_C16): same matrix, same arrays
         Afmt = cmi.CsrMatrix(N, N, A.num_entries, A.row_offsets, A.column_indices, A.values)
         assert Afmt.plan(compress=True).config().kernel == cmi.CSR_STREAM_C16
+    elif fmt == "csr16p":  # round 4: the opt-in PACKED wave tiles (CMI_CSR_STREAM_PACKED): one span per tile of 64 rows
+        pk = cmi.Plan.csr_values(N, N, A.row_offsets, A.column_indices, A.values, cmi.Config(kernel=cmi.CSR_STREAM_PACKED))
+        assert pk.config().kernel == cmi.CSR_STREAM_PACKED
+        packed_bytes = pk.device_bytes()
+        Afmt = None  # (multiplied through the plan below: the containers do not make packed plans by themselves)
     else:
         Afmt = A if fmt == "csr" else (cmi.poisson5pt(M, M, "dia") if fmt == "dia" else
                                        cmi.convert(A, fmt, num_entries_per_row=4 if fmt == "hyb" else None))
     torch.cuda.synchronize()
     for _ in range(10):
-        cmi.multiply(Afmt, x, y)
+        if fmt == "csr16p":
+            cmi.spmv_csr_plan(pk, A.row_offsets, A.column_indices, A.values, x, y)
+        else:
+            cmi.multiply(Afmt, x, y)
     torch.cuda.synchronize()
-    alg[fmt] = {"csr": cmi.csr_bytes(N, A.num_entries), "csr16": cmi.csr_bytes(N, A.num_entries) - 2 * A.num_entries, "ell": cmi.ell_bytes(N, 5, 9998272), "dia": cmi.dia_bytes(N, 5, N),
+    alg[fmt] = {"csr": cmi.csr_bytes(N, A.num_entries), "csr16p": (packed_bytes + 16 * N) if fmt == "csr16p" else 0, "csr16": cmi.csr_bytes(N, A.num_entries) - 2 * A.num_entries, "ell": cmi.ell_bytes(N, 5, 9998272), "dia": cmi.dia_bytes(N, 5, N),
                 "coo": cmi.coo_bytes(N, A.num_entries),
                 "hyb": cmi.ell_bytes(N, 4, 9998272) + 16 * (A.num_entries - 4 * N if fmt != "hyb" else Afmt.coo.num_entries)}[fmt]
     del Afmt

@@ -8,7 +8,7 @@ bit to the reference host loop by tests/) and timed with HIP events in interleav
   csr_scalar | csr_vector T = 2..64 (the reference's sweep; its own selector's T marked) | csr_stream with 1 / T lanes per row |
   the tuning table's choice (NULL config) | the plan's choice
 
-    python tools/suitesparse_sweep.py [--scale 1.0] [--dtype f64] > profiles/r02_suitesparse_like_sweep.txt
+    python tools/suitesparse_sweep.py [--scale 1.0] [--dtype f64] > archive/profiles/r02_suitesparse_like_sweep.txt
 """
 import argparse
 import ctypes
