@@ -190,6 +190,18 @@ static int wavev_env()
     static const int env = [] { const char *e = std::getenv("CMI_CSR_WAVEV"); return e ? std::atoi(e) : -1; }();
     return env;
 }
+// Round 4: f64 rows of fewer than 8 entries whose columns share x lines take wave tiles with V = 1 BELOW the size gate
+// too -- thermal2-like at 0.3 x / 1 x its size: 9.7 against 10.4 us, 20.8 against 21.8 (3 x: 63.6 against 70.6, already admitted),
+// profiles/r04_size_gates_scale_sweep.txt, r04_thermal2_wave_tiles_v1.txt; V = 2 / 4 lose there.  From 200 000 rows; the column profile
+// (jumps < 0.5) is checked by the caller, so only plans made WITH the columns qualify.
+static bool short_f64_rows(int64_t rows, int64_t nnz, const row_profile &prof, int dtype, bool have_columns)
+{
+    if (!have_columns || dtype != CMI_F64 || rows < 200000 || nnz <= 0 || prof.max_len < 1 || prof.in_long > 0) return false;
+    static const int env = [] { const char *e = std::getenv("CMI_CSR_WAVEV"); return e ? std::atoi(e) : -1; }();
+    if (env == 0) return false;
+    const double mean = (double)nnz / (double)rows;
+    return mean >= 2.5 && mean < 8.0 && 2 * (prof.max_len + 3) <= 256;
+}
 static int wavev_vectors(int64_t rows, int64_t nnz, const row_profile &prof, bool asked, int asked_v, size_t vbytes)
 {
     if (rows <= 0 || nnz <= 0 || prof.max_len < 1 || prof.in_long > 0) return 0;
@@ -207,8 +219,8 @@ static int wavev_vectors(int64_t rows, int64_t nnz, const row_profile &prof, boo
 
 // csr_waver (CMI_CSR_STREAM_WAVER): wave tiles on the run-compressed column copy.  Asked for: built whenever the tile can hold the longest
 // row.  AUTO plans made with the columns ($CMI_CSR_WAVER=0: never, =1: whenever the rows qualify): f64, at least 4096 rows of 8+ entries on
-// average, no row of 512+, streams beyond 0.75 x the Infinity Cache (csr_wavev's size rule: below it the partition's scalar hop is not
-// hidden), and pieces of kWaverMinPiece+ entries on average -- measured by building the copy, which is dropped again when they are shorter.
+// average, no row of 512+, 10 M+ entries (below: the partition's scalar hop is not hidden), and pieces of kWaverMinPiece+ entries on
+// average -- measured by building the copy, which is dropped again when they are shorter.
 constexpr double kWaverMinPiece = 2.5;
 static int waver_env()
 {
@@ -227,7 +239,9 @@ static bool waver_try(cmi_plan *p, const int *Ap, const int *Aj, bool asked, int
         if (waver_env() == 0) return false;
         const double mean = (double)nnz / (double)rows;
         if (rows < 4096) return false;
-        if (waver_env() != 1 && (mean < 8.0 || nnz * (int64_t)12 <= kInfinityCacheBytes / 4 * 3)) return false;
+        // (size gate, profiles/r04_size_gates_scale_sweep.txt: at 10.8-10.9 M entries -- 130 MB of streams -- it takes 0.85-0.95 of the table
+        //  kernel's time, at 5 M entries 1.13-1.22: smaller matrices keep csr_stream)
+        if (waver_env() != 1 && (mean < 8.0 || nnz < (int64_t)10000000)) return false;
     }
     double mean_piece = 0.0;
     *st = csr_runs_build(p, Ap, Aj, v, asked ? 0.0 : kWaverMinPiece, values, s, &mean_piece, asked ? asked_cap : 0);
@@ -477,8 +491,13 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
         } else if (st == CMI_SUCCESS && want_waver) {
             st = fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: CMI_CSR_STREAM_WAVER / _PACKED need f64 values, 2 <= columns < 2^30, items_per_thread 0, 1, 2 or 4, no row of 512+ entries and the longest row at most half of the 256 x items_per_thread slots of a wave tile");
         } else if (st == CMI_SUCCESS && auto_kernel && !want_partition && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
-                   wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v, vbytes) > 0) { // (a caller who asked for csr_wave on a partition gets that)
+                   (wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v, vbytes) > 0 ||
+                    short_f64_rows(num_rows, num_entries, p->prof, dtype, csr_columns != nullptr && !want_wavev))) { // (a caller who asked for csr_wave on a partition gets that)
             int v = wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v, vbytes);
+            // v == 0 here: only the short-row rule of round 4 admitted this (cache-resident) matrix -- it runs wave tiles with V = 1 if its
+            // columns share x lines, else nothing changes
+            const bool short_only = v == 0;
+            if (short_only) v = 1;
             bool auto_wavex = false, keep_stream = false;
             if (!want_wavev) { // an AUTO plan: refine by the value type and -- made with the columns -- by where the columns lie
                 const double mean = (double)num_entries / (double)num_rows;
@@ -489,7 +508,9 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
                     if (st == CMI_SUCCESS) { cp.inside = (double)inside / (double)num_entries; cp.jumps = (double)jumps / (double)num_entries; }
                 }
                 const char *wx = std::getenv("CMI_CSR_WAVEX");
-                if (cp.jumps >= 0.6 && cp.inside >= 0.25 && !(wx && wx[0] == '0')) {
+                if (short_only) {
+                    if (!(cp.jumps >= 0.0 && cp.jumps < 0.5)) keep_stream = true;
+                } else if (cp.jumps >= 0.6 && cp.inside >= 0.25 && !(wx && wx[0] == '0')) {
                     auto_wavex = true;
                     wavex_window = (dtype == CMI_F32 && mean >= 15.0) ? 4096 : 2048;
                 } else if (cp.inside >= 0.0 && cp.inside < 0.05 && cp.jumps >= 0.6) {

@@ -253,13 +253,19 @@ int csr_runs_build(cmi_plan *p, const int *Ap, const int *Aj, int v, double min_
 // One 64-lane wave per tile, four tiles per workgroup, no workgroup barrier (csr_wavev's structure, spmv_csr.hip).  V: 256 V request slots
 // per tile.  NPC: piece chunks (of 64) handled by the unrolled, branch-free first pass -- a tile with more pieces (short runs) takes
 // further turns of a plain loop.  PACKED: pieces and values come from the plan's one-span-per-tile buffer.
+// (Tried and dropped, round 4 session 7: loading the VALUES per piece too and parking products -- no product stage -- was 11-13 % SLOWER,
+// 83.0 / 196 us against 73.6 / 178: the value loads of a wave instruction then overlap instead of tiling the stream.  The ablations of the
+// same session put the product stage at 1 % and the row sums at 4 % of this kernel: what is left is the load phase, at 6.7 TB/s of
+// counted traffic.  profiles/r04_waver_ablation_and_piece_values.txt.)
 template <int V, int POL, bool DOT, bool PACKED>
 __global__ void __launch_bounds__(256)
 csr_waver_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t num_entries, int num_cols, const int *Ap /* not restrict: see csr_wave */,
                  const int *__restrict__ Aj, const uint32_t *__restrict__ pieces, const double *__restrict__ Ax, const unsigned char *__restrict__ packed,
                  const double *__restrict__ x, double *__restrict__ y, int64_t num_tiles, int64_t tiles_per_xcd, int swizzle, int accumulate,
-                 const double *__restrict__ w, double *__restrict__ dot_partial)
+                 const double *__restrict__ w, double *__restrict__ dot_partial, int ablate = 0)
 {
+    // ablate (measurements only, $CMI_WAVER_ABLATE; WRONG results by design): bit 1 -- no product stage (the rows sum the parked x values; the
+    // value loads stay needed: added to lane 0's row); bit 2 -- a row's lane reads only its first slot (no sum phase)
     typedef double T;
     constexpr int E = 2, NL = (V * 4) / E, SLOTS = kWave * V * 4, NPC = V == 4 ? 6 : V == 2 ? 3 : 2;
     __shared__ __attribute__((aligned(16))) T prod[4][SLOTS];
@@ -362,11 +368,18 @@ csr_waver_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t 
                 asm volatile("" : "+v"(a)); // the row offset was requested in front of the streams
                 __builtin_amdgcn_wave_barrier(); // (compiler only: the hardware runs a wave's LDS instructions in order)
                 // ---- products, in place: lane l owns the slot pairs l, l + 64, ... ----
+                if (ablate & 1) { // (uniform) the values must stay NEEDED, or the compiler drops their loads
+                    T keep = T(0);
 #pragma unroll
-                for (int k = 0; k < NL; k++) {
-                    double2v *slot = reinterpret_cast<double2v *>(mine + (k * kWave + lane) * E);
-                    const double2v xs = *slot;
-                    *slot = double2v{v[k].x * xs.x, v[k].y * xs.y};
+                    for (int k = 0; k < NL; k++) keep = keep + v[k].x + v[k].y;
+                    if (keep == T(12345.678)) mine[0] = keep;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NL; k++) {
+                        double2v *slot = reinterpret_cast<double2v *>(mine + (k * kWave + lane) * E);
+                        const double2v xs = *slot;
+                        *slot = double2v{v[k].x * xs.x, v[k].y * xs.y};
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -375,7 +388,8 @@ csr_waver_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t 
             for (int r = lane; r < nr; r += kWave) { // (one turn, except over a stretch of very short rows)
                 if (r >= kWave) { a = Ap[rs + r]; b = Ap[rs + r + 1]; }
                 T sum = accumulate ? y[rs + r] : T(0);
-                if (fits) sum = sum_in_order(sum, mine + (a - slot0), b - a);
+                if (fits && (ablate & 2)) { if (b > a) sum = sum + mine[a - slot0]; }
+                else if (fits) sum = sum_in_order(sum, mine + (a - slot0), b - a);
                 else for (int j = a; j < b; j++) sum = sum + Ax[j] * x[Aj[j]]; // (the array's last pair, or an empty tile)
                 st<NTS>(y + rs + r, sum);
                 if constexpr (DOT) d += (double)sum * (double)w[rs + r];
@@ -404,13 +418,14 @@ int csr_runs_multiply_f64(const cmi_plan *p, const int *Ap, const int *Aj, const
     const int64_t grid64 = padded_grid(tiles, swz);
     if (grid64 > INT32_MAX) return fail(CMI_ERROR_INVALID_VALUE, "csr_waver: grid too large");
     const bool dot = w && dot_partial && tiles <= kPartialCapacity;
+    static const int ablate = [] { const char *e = std::getenv("CMI_WAVER_ABLATE"); return e ? std::atoi(e) : 0; }();
     with_policy(pol, [&](auto P) {
         constexpr int POL = decltype(P)::value;
         auto go = [&](auto VV, auto PK) {
             constexpr int VC = decltype(VV)::value;
             constexpr bool PKC = decltype(PK)::value;
             if (dot) hipLaunchKernelGGL((csr_waver_kernel<VC, POL, true, PKC>), dim3((unsigned)grid64), dim3(256), 0, s, p->runs_start, p->wave_tiles, p->nnz, (int)p->cols, Ap, Aj, p->runs_pieces, Ax, p->runs_packed, x, y, tiles, tpx, swz, accumulate, w, dot_partial);
-            else     hipLaunchKernelGGL((csr_waver_kernel<VC, POL, false, PKC>), dim3((unsigned)grid64), dim3(256), 0, s, p->runs_start, p->wave_tiles, p->nnz, (int)p->cols, Ap, Aj, p->runs_pieces, Ax, p->runs_packed, x, y, tiles, tpx, swz, accumulate, (const double *)nullptr, (double *)nullptr);
+            else     hipLaunchKernelGGL((csr_waver_kernel<VC, POL, false, PKC>), dim3((unsigned)grid64), dim3(256), 0, s, p->runs_start, p->wave_tiles, p->nnz, (int)p->cols, Ap, Aj, p->runs_pieces, Ax, p->runs_packed, x, y, tiles, tpx, swz, accumulate, (const double *)nullptr, (double *)nullptr, ablate);
         };
         auto by_v = [&](auto PK) {
             switch (V) {

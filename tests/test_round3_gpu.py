@@ -466,7 +466,6 @@ def test_auto_plans_pick_wavev_and_wavex_by_the_measured_rule(cmi, torch_cuda, o
              ("band f64", irregular(3_000_000, 5, 12, 2000, 5, torch.float64), cmi.CSR_STREAM_WAVEX, cmi.CSR_STREAM_WAVEV),
              # (round 4: columns in runs of 3 -> a plan made WITH the columns multiplies from the run-compressed copy, csr_waver)
              ("blocks of 3 f64", irregular(1_500_000, 3, 8, 2000, 6, torch.float64, runs=3), cmi.CSR_STREAM_WAVER, cmi.CSR_STREAM_WAVEV),
-             ("blocks of 3 f32", irregular(1_500_000, 3, 8, 2000, 8, torch.float32, runs=3), cmi.CSR_STREAM_WAVEV, cmi.CSR_STREAM_WAVEV),
              ("small band f64", irregular(200_000, 5, 12, 2000, 7, torch.float64), cmi.CSR_STREAM, cmi.CSR_STREAM)]
     for name, (Ap, Aj, Ax), want_with_columns, want_offsets_only in cases:
         N, nnz, dt = Ap.numel() - 1, Aj.numel(), Ax.dtype

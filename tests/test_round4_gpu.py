@@ -223,6 +223,8 @@ def test_configs3_full_size_run_compressed(cmi, torch_cuda, orc, name):
     print(f"{name}: AUTO plan made with the columns -> kernel {k}")
     if name in ("ldoor", "nlpkkt120") and source.startswith("seeded"):
         assert k == cmi.CSR_STREAM_WAVER, k
+    elif source.startswith("seeded"):  # thermal2-like: f64 rows of ~7 entries whose columns share x lines -> wave tiles with V = 1 (round 4 rule)
+        assert (k, auto.config().items_per_thread) == (cmi.CSR_STREAM_WAVEV, 1), auto.config()
     else:
         assert k != cmi.CSR_STREAM_PACKED
     y.fill_(10.0)
