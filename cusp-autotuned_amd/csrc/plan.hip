@@ -487,7 +487,8 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
             // (stencil-like rows: packed wave tiles of the 16-bit copy, spmv_csr16.hip; p->cfg is set)
         } else if (st == CMI_SUCCESS && auto_kernel && !want_partition && !want_wavev && csr_columns && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
                    waver_try(p, index_array, csr_columns, want_waver, waver_v, waver_cap, want_waver && waver_shape.nontemporal != 0, want_packed ? csr_values : nullptr, s, &st)) {
-            // (the run-compressed copy was built and pays: p->cfg is set)
+            // (the run-compressed copy was built and pays: p->cfg is set; a caller's XCD dealing is kept as given)
+            if (want_waver && waver_shape.xcd_swizzle != 0) p->cfg.xcd_swizzle = waver_shape.xcd_swizzle < 0 ? 0 : waver_shape.xcd_swizzle;
         } else if (st == CMI_SUCCESS && want_waver) {
             st = fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: CMI_CSR_STREAM_WAVER / _PACKED need f64 values, 2 <= columns < 2^30, items_per_thread 0, 1, 2 or 4, no row of 512+ entries and the longest row at most half of the 256 x items_per_thread slots of a wave tile");
         } else if (st == CMI_SUCCESS && auto_kernel && !want_partition && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&

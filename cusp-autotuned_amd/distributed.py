@@ -381,7 +381,10 @@ class ShardedCsr:
     exchange logic without a GPU.)"""
 
     def __init__(self, A_local, num_cols, rank, world, mode="auto", group=None, local_multiply=None,
-                 col_span=None, overlap=True, interior=None, offsets=None, comm=None):
+                 col_span=None, overlap=True, interior=None, offsets=None, comm=None, local_format=None):
+        """local_format ("ell" | "dia" | "coo" | "hyb", round 4): the partition, the column window and the exchange are derived from
+        the CSR block as always -- they are properties of its entries -- and the block is then converted ONCE into that format; the
+        multiply is exchange + the format's single-GPU multiply on the rectangular block (cusp/distributed/matrix.h is the C++ twin)."""
         import torch
         self.A = A_local
         self.rank, self.world = rank, world
@@ -420,6 +423,14 @@ class ShardedCsr:
                 planned = A_local.plan().config()
                 if planned.kernel in (B.CSR_STREAM, B.CSR_STREAM_WAVE):
                     self._cfg = planned
+
+        if local_format not in (None, "csr"):
+            from .matrices import convert
+            self.A = convert(A_local, local_format)  # rows x num_cols in the format, global column indices
+            self.interior = None                      # (the interior / boundary split is a row range of CSR arrays)
+            self.local_format = local_format
+        else:
+            self.local_format = "csr"
 
     def _interior_rows(self):
         """Largest middle block [a, b) of rows whose columns all lie in [lo, hi) (setup-time)."""
@@ -486,7 +497,7 @@ class ShardedCsr:
         overlapped (interior / boundary) schedule keeps its three launches and adds a dot."""
         from . import binding as B
         A = self.A
-        if (self.interior is None or not exchange) and not self._custom and self.vec.x_full.is_cuda:
+        if (self.interior is None or not exchange) and not self._custom and self.vec.x_full.is_cuda and self.local_format == "csr":
             if exchange:
                 self.vec.exchange()
             B.spmv_csr_dot(A.num_rows, A.num_cols, A.row_offsets, A.column_indices, A.values, self.x_view, y_local,

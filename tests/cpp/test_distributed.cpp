@@ -199,6 +199,54 @@ template <typename Space> static void run(cd::communicator &comm, const char *sp
     }
 }
 
+// the other formats (cusp/distributed/matrix.h, round 4): the CSR operator's partition + exchange with the rank's block converted into ELL /
+// DIA / COO / HYB -- multiply against the single-process host result (one chain per row in every one of these paths: the host loop's bits
+// on host_memory; on device_memory the formats' own parity classes), CG against the single-process solve
+template <typename Space> static void run_formats(cd::communicator &comm, const char *space_name)
+{
+    const int world = comm.size(), rank = comm.rank();
+    const size_t n = 3000 + 29 * (size_t)world + 1;
+    const host_csr G = test_matrix(n, 11u, true); // banded: a handful of diagonals (DIA holds it), a halo exchange
+    const std::vector<int64_t> cuts = cd::partition_by_entries(G.row_offsets, world);
+    cd::csr_matrix<int, double, Space> A(comm);
+    A.scatter(G, cuts, cd::exchange_mode::automatic);
+    cusp::array1d<double, cusp::host_memory> xg(n), yg(n);
+    for (size_t i = 0; i < n; i++) xg[i] = double((unsigned(i) * 2654435761u) % 1000u) / 997.0 - 0.5;
+    cusp::multiply(G, xg, yg);
+    const size_t lo = A.row_begin(), hi = A.row_end();
+    cusp::array1d<double, cusp::host_memory> bg(n), sg(n, 0.0);
+    for (size_t i = 0; i < n; i++) bg[i] = 1.0 + double(i % 7);
+    cusp::monitor<double> mon_ref(bg, 200, 1e-10);
+    cusp::krylov::cg(G, sg, bg, mon_ref);
+    auto check = [&](const char *name, const auto &E) {
+        CHECK(E.num_rows == n && E.local_rows() == hi - lo && E.local.num_rows == hi - lo && E.local.num_cols == n, "%s: block shape", name);
+        auto x = E.make_vector(), y = E.make_vector(9.0);
+        { cusp::array1d<double, cusp::host_memory> t(xg.begin() + lo, xg.begin() + hi); auto xv = x.local(); cusp::copy_array(t, xv); }
+        cusp::multiply(E, x, y);
+        cusp::array1d<double, cusp::host_memory> got(y.local());
+        double worst = 0, scale = 0;
+        bool same = got.size() == hi - lo;
+        for (size_t i = 0; i < got.size(); i++) { same = same && got[i] == yg[lo + i]; worst = std::max(worst, std::fabs(got[i] - yg[lo + i])); scale = std::max(scale, std::fabs(yg[lo + i])); }
+        if (std::is_same<Space, cusp::host_memory>::value) CHECK(same, "%s [%s]: sharded multiply differs from the single-process result", name, space_name);
+        else CHECK(worst <= 1e-12 * scale, "%s [%s]: sharded multiply off by %.3e", name, space_name, worst);
+        auto bl = E.make_vector(), sol = E.make_vector(0.0);
+        { cusp::array1d<double, cusp::host_memory> t(bg.begin() + lo, bg.begin() + hi); auto bv = bl.local(); cusp::copy_array(t, bv); }
+        cusp::monitor<double> mon(bl, 200, 1e-10);
+        cusp::krylov::cg(E, sol, bl, mon);
+        const long long d = (long long)mon.iteration_count() - (long long)mon_ref.iteration_count();
+        CHECK(mon.converged() && d >= -1 && d <= 1, "%s [%s]: CG %zu iterations sharded, %zu single-process", name, space_name, mon.iteration_count(), mon_ref.iteration_count());
+        cusp::array1d<double, cusp::host_memory> sl(sol.local());
+        double err = 0;
+        for (size_t i = 0; i < sl.size(); i++) err = std::max(err, std::fabs(sl[i] - sg[lo + i]));
+        CHECK(err <= 1e-8, "%s: solution differs by %.3e", name, err);
+        if (rank == 0) std::printf("ok  sharded %-4s [%s, world %d]  mode %s, multiply %s, CG %zu iterations\n", name, space_name, world, E.mode_name(), same ? "bit-identical" : "within 1e-12", mon.iteration_count());
+    };
+    { cd::ell_matrix<int, double, Space> E(A); check("ell", E); }
+    { cd::coo_matrix<int, double, Space> E(A); check("coo", E); }
+    { cd::dia_matrix<int, double, Space> E(A); check("dia", E); }
+    { cd::hyb_matrix<int, double, Space> E(A); check("hyb", E); }
+}
+
 // float operators and vectors: the f32 instances of the sharded multiply and of the (fused, on device) CG -- scalars stay doubles
 template <typename Space> static void run_float(cd::communicator &comm, const char *space_name)
 {
@@ -236,12 +284,14 @@ int main(int argc, char **argv)
         g_rank = comm->rank();
         if (device) {
             run<cusp::device_memory>(*comm, "device_memory");
+            run_formats<cusp::device_memory>(*comm, "device_memory");
             run_float<cusp::device_memory>(*comm, "device_memory");
             int v = 0;
             cusp::detail::check(cmi_comm_library_version(&v));
             if (g_rank == 0) std::printf("RCCL version code %d, world %d\n", v, comm->size());
         } else {
             run<cusp::host_memory>(*comm, "host_memory");
+            run_formats<cusp::host_memory>(*comm, "host_memory");
             run_float<cusp::host_memory>(*comm, "host_memory");
         }
         comm->barrier(cusp::host_memory());

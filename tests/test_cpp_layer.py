@@ -156,7 +156,9 @@ def test_sharded_operator_and_cg_host_transport(cmi, ranks):
     Every rank's rows have the single-process multiply's bits; CG takes the single-process iteration count."""
     out = _launch(ranks, "host", 29620 + ranks)
     lines = [l for l in out.splitlines() if l.startswith("ok ")]
-    assert len(lines) == 8 and "sharded bicgstab" in out, out
+    assert len(lines) == 12 and "sharded bicgstab" in out, out
+    for fmt in ("ell", "coo", "dia", "hyb"):  # round 4: the sharded operator in the other formats (cusp/distributed/matrix.h)
+        assert any(l.startswith(f"ok  sharded {fmt}") and "multiply bit-identical" in l for l in lines), (fmt, out)
     if ranks > 1:
         assert "banded/equal-rows/auto" in out and "mode halo" in out and "mode allgather" in out
 
@@ -168,7 +170,10 @@ def test_sharded_operator_and_cg_through_rccl_one_rank(cmi):
     fused CG steps are the single-GPU hot path."""
     out = _launch(1, "device", 29631)
     assert "RCCL version code" in out
-    assert len([l for l in out.splitlines() if l.startswith("ok ")]) == 8 and "sharded bicgstab" in out, out
+    lines = [l for l in out.splitlines() if l.startswith("ok ")]
+    assert len(lines) == 12 and "sharded bicgstab" in out, out
+    for fmt in ("ell", "coo", "dia", "hyb"):
+        assert any(l.startswith(f"ok  sharded {fmt}") for l in lines), (fmt, out)
 
 
 @pytest.mark.gpu
@@ -179,7 +184,9 @@ def test_sharded_operator_ranks_share_one_gpu_one_sided_exchange(cmi, ranks):
     pulls, and the fused CG whose pulls are ordered by its own reductions.  Every variant of the program incl. exchange_mode::peer."""
     out = _launch(ranks, "device", 29640 + ranks, extra_env={"CMI_COMM_STAGED": "1"})
     lines = [l for l in out.splitlines() if l.startswith("ok ")]
-    assert len(lines) == 9 and "sharded bicgstab" in out, out
+    assert len(lines) == 13 and "sharded bicgstab" in out, out
+    for fmt in ("ell", "coo", "dia", "hyb"):  # (through the CSR operator's one-sided exchange)
+        assert any(l.startswith(f"ok  sharded {fmt}") and "mode peer" in l for l in lines), (fmt, out)
     assert "mode peer" in out and "banded/by-entries/peer" in out
 
 

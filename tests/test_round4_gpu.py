@@ -353,3 +353,91 @@ def test_bench_under_torchrun_n1_agrees_with_the_plain_run(torch_cuda):
     assert abs(a - b) <= 0.03 * a, (a, b)
     assert abs(plain["value"] - launched["value"]) <= 0.03 * plain["value"], (plain["value"], launched["value"])
     print(f"plain {plain['value']:.1f} GFLOP/s kernel {a * 1e3:.2f} us | under torch.distributed.run {launched['value']:.1f} GFLOP/s kernel {b * 1e3:.2f} us")
+
+
+@pytest.mark.parametrize("fmt", ["ell", "dia", "coo", "hyb"])
+def test_sharded_operator_in_the_other_formats_one_rank_through_rccl(cmi, torch_cuda, orc, fmt):
+    """VERDICT r3 missing 6: row-block sharding for every container the hot path serves.  ShardedCsr(local_format=...) keeps the CSR
+    block's partition and exchange and converts the block once; the multiply is exchange + the format's single-GPU multiply on the
+    rectangular block.  Here with one rank through the C-ABI communicator (RCCL), against the oracle's host loops, and inside krylov.cg
+    against the CSR operator's solve.  (World 2-3: tests/cpp/test_distributed.cpp run_formats, host_memory and ranks sharing the GPU.)"""
+    torch = torch_cuda
+    comm = cmi.binding.Comm(0, 1)
+    m, n = 97, 83
+    N = m * n
+    A = cmi.poisson5pt(m, n, "csr")
+    sh = cmi.distributed.ShardedCsr(A, N, 0, 1, mode="allgather", comm=comm, local_format=fmt)
+    assert sh.local_format == fmt and type(sh.A).__name__.lower().startswith(fmt)
+    x = cmi.fill_x(N).cuda()
+    sh.x_local.copy_(x)
+    y = torch.full((N,), 7.0, dtype=torch.float64, device="cuda")
+    sh.multiply(y)
+    Ap, Aj, Ax = orc.poisson5pt_csr(m, n)
+    want = orc.spmv_csr(Ap, Aj, Ax, orc.fill_x(N))
+    assert np.array_equal(y.cpu().numpy(), want), fmt   # one chain per row in each of these formats' default paths: the host loop's bits
+    b = torch.ones(N, dtype=torch.float64, device="cuda")
+    x1, x2 = torch.zeros_like(b), torch.zeros_like(b)
+    mon1 = cmi.krylov.cg(sh, x1, b, iteration_limit=400, relative_tolerance=1e-8)
+    mon2 = cmi.krylov.cg(A, x2, b, iteration_limit=400, relative_tolerance=1e-8)
+    assert mon1.converged() and abs(mon1.iteration_count - mon2.iteration_count) <= 1
+    assert torch.allclose(x1, x2, rtol=0, atol=1e-9)
+    sh.vec.close()
+    comm.close()
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_wave_tiles_that_overflow_take_further_passes(cmi, torch_cuda, orc, tag):
+    """csr_wave with K entries per lane on rows LONGER than K (round 4: an explicit config on an irregular matrix, or the plan-less rule on a
+    matrix that only looks like a stencil): a tile whose entries do not fit its 64 K slots runs the same body in passes of 64 K entries, every
+    lane carrying its row's running sum across them -- the host loop's order (sequential/multiply/csr_spmv.h:56-73), so its bits.  Rows of
+    2000 entries among rows of 1..9, empty rows, accumulate, the fused <y, w>; then the plan-less NULL-config call on a matrix whose sizes
+    satisfy the stencil rule (mean 4.99) although its rows are 1..9 long."""
+    torch = torch_cuda
+    dtype, tdt = (np.float64, torch.float64) if tag == "f64" else (np.float32, torch.float32)
+    rng = np.random.default_rng(77)
+    rows = 20011
+    lens = rng.integers(0, 10, size=rows)
+    lens[[5, 4000, 4001, rows - 1]] = 2000
+    lens[100:400] = 0
+    cols = rows
+    Ap = np.r_[0, np.cumsum(lens)].astype(np.int32)
+    Aj = rng.integers(0, cols, size=int(Ap[-1])).astype(np.int32)
+    Ax = rng.standard_normal(len(Aj)).astype(dtype)
+    x = rng.standard_normal(cols).astype(dtype)
+    y0 = rng.standard_normal(rows).astype(dtype)
+    want, want_acc = orc.spmv_csr(Ap, Aj, Ax, x), orc.spmv_csr(Ap, Aj, Ax, x, y0)
+    dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+    for k in (2, 5, 10):
+        cfg = cmi.Config(kernel=cmi.CSR_STREAM_WAVE, block_size=256, rows_per_block=256, items_per_thread=k, nontemporal=3)
+        y = torch.full((rows,), 9.0, dtype=tdt, device="cuda")
+        cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, cfg=cfg)
+        assert np.array_equal(y.cpu().numpy(), want), (tag, k)
+        y = dev(y0, torch)
+        cmi.spmv_csr(rows, cols, dAp, dAj, dAx, dx, y, accumulate=True, cfg=cfg)
+        assert np.array_equal(y.cpu().numpy(), want_acc), (tag, k, "accumulate")
+        w = rng.standard_normal(rows).astype(dtype)
+        res = torch.zeros(1, dtype=torch.float64, device="cuda")
+        y = torch.zeros(rows, dtype=tdt, device="cuda")
+        cmi.spmv_csr_dot(rows, cols, dAp, dAj, dAx, dx, y, dev(w, torch), res, cmi.blas_workspace(), cfg=cfg)
+        assert np.array_equal(y.cpu().numpy(), want), (tag, k, "dot")
+        ref = float(np.dot(want.astype(np.float64), w.astype(np.float64)))
+        assert abs(res.item() - ref) <= 1e-9 * float(np.dot(np.abs(want).astype(np.float64), np.abs(w).astype(np.float64))) + 1e-300
+    # the plan-less rule: sizes say "stencil of 5" (mean within 0.5 % below 5), rows say otherwise
+    rows2 = 200000
+    lens2 = rng.integers(1, 10, size=rows2)
+    target = int(4.99 * rows2)
+    while lens2.sum() > target:
+        i = rng.integers(0, rows2)
+        if lens2[i] > 1:
+            lens2[i] -= 1
+    while lens2.sum() < target:
+        i = rng.integers(0, rows2)
+        if lens2[i] < 9:
+            lens2[i] += 1
+    Ap2 = np.r_[0, np.cumsum(lens2)].astype(np.int32)
+    Aj2 = rng.integers(0, rows2, size=int(Ap2[-1])).astype(np.int32)
+    Ax2 = rng.standard_normal(len(Aj2)).astype(dtype)
+    x2 = rng.standard_normal(rows2).astype(dtype)
+    y = torch.full((rows2,), 9.0, dtype=tdt, device="cuda")
+    cmi.spmv_csr(rows2, rows2, dev(Ap2, torch), dev(Aj2, torch), dev(Ax2, torch), dev(x2, torch), y)   # NULL config, no plan
+    assert np.array_equal(y.cpu().numpy(), orc.spmv_csr(Ap2, Aj2, Ax2, x2)), tag

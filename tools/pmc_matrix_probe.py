@@ -67,8 +67,9 @@ def variants_for(A):
         for v in (int(s) for s in os.environ.get("PMC_WAVER", "4").split(",") if s):
             for pol in (int(s) for s in os.environ.get("PMC_WAVER_POL", "0").split(",") if s):
                 for cap in (int(s) for s in os.environ.get("PMC_WAVER_CAP", "0").split(",") if s):  # 0: the rule; 3 / 4: entries per piece at most
-                    out.append((f"waver{v}" + (f"/pol{pol}" if pol else "") + (f"/cap{cap}" if cap else ""),
-                                cmi.Config(kernel=cmi.CSR_STREAM_WAVER, items_per_thread=v, nontemporal=pol, threads_per_row=cap)))
+                    for swz in (int(s) for s in os.environ.get("PMC_WAVER_SWZ", "0").split(",") if s):  # 0: the table's XCD dealing; -1: launch order; C: chunks of C tiles
+                        out.append((f"waver{v}" + (f"/pol{pol}" if pol else "") + (f"/cap{cap}" if cap else "") + (f"/swz{swz}" if swz else ""),
+                                    cmi.Config(kernel=cmi.CSR_STREAM_WAVER, items_per_thread=v, nontemporal=pol, threads_per_row=cap, xcd_swizzle=swz)))
                 if os.environ.get("PMC_PACKED", "1") != "0":
                     out.append((f"packed{v}" + (f"/pol{pol}" if pol else ""), ("values", cmi.Config(kernel=cmi.CSR_STREAM_PACKED, items_per_thread=v, nontemporal=pol))))
     if os.environ.get("PMC_C16", "0") != "0":
