@@ -343,6 +343,8 @@ int csr16_build(cmi_plan *p, const int *Ap, const int *Aj, hipStream_t s, int wa
 int csr_runs_build(cmi_plan *p, const int *Ap, const int *Aj, int v, double min_mean_piece, const void *values, hipStream_t s, double *mean_piece, int cap = 0);
 int csr_runs_multiply_f64(const cmi_plan *p, const int *Ap, const int *Aj, const double *Ax, const double *x, double *y, int accumulate, hipStream_t s,
                           const double *w, double *dot_partial, int *dot_partials, int cache_policy, int xcd_swizzle);
+int csr_runs_multiply_f32(const cmi_plan *p, const int *Ap, const int *Aj, const float *Ax, const float *x, float *y, int accumulate, hipStream_t s,
+                          const float *w, double *dot_partial, int *dot_partials, int cache_policy, int xcd_swizzle);
 int csr16_pack(cmi_plan *p, const int *Ap, const void *values, hipStream_t s); // the wave-tiled 16-bit copy + the values -> packed wave tiles (CMI_CSR_STREAM_PACKED)
 int csr16_multiply_f64(const cmi_plan *p, const int *Ap, const double *Ax, const double *x, double *y, int accumulate,
                        hipStream_t s, const double *w, double *dot_partial, int *dot_partials, int cache_policy, int xcd_swizzle);

@@ -230,7 +230,9 @@ static int waver_env()
 static bool waver_try(cmi_plan *p, const int *Ap, const int *Aj, bool asked, int asked_v, int asked_cap, bool keep_policy, const void *values, hipStream_t s, int *st)
 {
     const int64_t rows = p->rows, nnz = p->nnz;
-    if (p->dtype != CMI_F64 || rows <= 0 || nnz <= 0 || p->prof.max_len < 1 || p->prof.in_long > 0 || p->cols < 2 || p->cols >= ((int64_t)1 << 30)) return false;
+    if (rows <= 0 || nnz <= 0 || p->prof.max_len < 1 || p->prof.in_long > 0 || p->cols < (p->dtype == CMI_F64 ? 2 : 4) || p->cols >= ((int64_t)1 << 30)) return false;
+    // (f32, session 10 of round 4: ldoor-like 49.8 us against csr_stream's 70.9, nlpkkt120-like 101.3 against 156.8 -- the index stream is half of
+    //  an f32 matrix's bytes, so compressing it pays more than for f64; same rule, profiles/r04_waver_f32_time.txt)
     int v = asked_v ? asked_v : 4;
     if (v != 1 && v != 2 && v != 4) return false;
     while (v < 4 && !asked_v && 2 * (p->prof.max_len + 3) > 256 * v) v *= 2;
@@ -252,8 +254,9 @@ static bool waver_try(cmi_plan *p, const int *Ap, const int *Aj, bool asked, int
     p->cfg.items_per_thread = v;
     p->cfg.threads_per_row = 0;
     p->cfg.nontemporal &= ~kPolStrided;
+    p->cfg.xcd_swizzle = 16; // chunks of 16 workgroups (64 wave tiles) per XCD: 0.99 of launch order's time on both configs[3] matrices, twice (profiles/r04_waver_xcd_dealing.txt)
     if (!keep_policy) { // (a caller's policy bits are kept as given)
-        if (nnz * (int64_t)12 > kInfinityCacheBytes + kInfinityCacheBytes / 4) p->cfg.nontemporal |= kPolLoadNT;
+        if (nnz * (int64_t)(p->dtype == CMI_F64 ? 12 : 8) > kInfinityCacheBytes + kInfinityCacheBytes / 4) p->cfg.nontemporal |= kPolLoadNT;
         p->cfg.nontemporal |= kPolStoreNT;
     }
     return true;
@@ -416,7 +419,6 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
         if (!csr_columns && num_entries > 0) { delete p; return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: CMI_CSR_STREAM_WAVER needs the column indices -- use cmi_plan_create_csr"); }
         want_waver = true;
         want_packed = cfg->kernel == CMI_CSR_STREAM_PACKED;
-        if (dtype != CMI_F64 && !want_packed) { delete p; return fail(CMI_ERROR_NOT_SUPPORTED, "cmi_plan_create: CMI_CSR_STREAM_WAVER is an f64 kernel"); }
         waver_v = cfg->items_per_thread;
         waver_cap = cfg->threads_per_row; // (this kernel's use of the field: entries per piece at most, 0 = the rule, 3 or 4)
         waver_shape = *cfg;

@@ -1751,7 +1751,7 @@ static int spmv_csr(int dtype, int64_t rows, int64_t cols, int64_t nnz, const in
             else return csr16_multiply_f32(plan, Ap, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol, swz16);
         }
         if constexpr (std::is_same<T, double>::value) return csr_runs_multiply_f64(plan, Ap, Aj, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol, c.xcd_swizzle);
-        else return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_CSR_STREAM_WAVER / _PACKED are f64 kernels");
+        else return csr_runs_multiply_f32(plan, Ap, Aj, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol, c.xcd_swizzle);
     }
     case CMI_CSR_STREAM_C16: { // the plan's 16-bit column copy (spmv_csr16.hip); Aj itself is not read
         if (!plan || !plan->csr16_cols) return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_CSR_STREAM_C16 runs through a plan of cmi_plan_create_csr only");

@@ -30,7 +30,47 @@ constexpr int kRunCap = 4;            // entries per piece at most (2 bits of th
 constexpr int64_t kRunMaxCols = (int64_t)1 << 30;
 
 typedef double __attribute__((ext_vector_type(2), aligned(8))) double2u; // 16 bytes of x from an 8-byte aligned address: one global_load_dwordx4
+typedef float __attribute__((ext_vector_type(2), aligned(4))) float2u;   // (f32: a pair of x values / of LDS slots at any 4-byte boundary)
+typedef float __attribute__((ext_vector_type(4), aligned(4))) float4u;   // f32: the four x values a piece can span, one 16-byte load
 typedef int __attribute__((ext_vector_type(4))) start_t;
+template <typename T> struct pair_of;
+template <> struct pair_of<double> { typedef double2u type; };
+template <> struct pair_of<float> { typedef float2u type; };
+// element i (0..3) of a 4-vector, i known at run time only (selects, no scratch)
+__device__ __forceinline__ float pick4(const float4u &a, int i) { return i == 0 ? a.x : i == 1 ? a.y : i == 2 ? a.z : a.w; }
+
+// The x values of ONE piece (first column cs, len entries, 1 <= len <= 4), as what the LDS stores need: the first pair, the last pair
+// (pieces of 3 and 4) and the single value (pieces of 1).  f64: two 16-byte loads, x[c], x[c+1] and x[c+len-2], x[c+len-1] (a piece of
+// one entry in the LAST column loads the pair before it and takes its second element).  f32: ONE 16-byte load of x[c .. c+3] -- clamped
+// to the last four columns, the piece's values picked out by the shift.  Branch-free; issues the loads and returns raw registers.
+template <typename T> struct piece_x;
+template <> struct piece_x<double> {
+    double2u a, b;
+    int sel;
+    __device__ __forceinline__ void load(const double *x, int cs, int len, int num_cols)
+    {
+        const int ca = cs < num_cols - 2 ? cs : num_cols - 2;
+        sel = cs - ca;
+        a = *reinterpret_cast<const double2u *>(x + ca);
+        b = *reinterpret_cast<const double2u *>(x + ca + (len > 2 ? len - 2 : 0));
+    }
+    __device__ __forceinline__ double2u first(int) const { return a; }
+    __device__ __forceinline__ double2u last(int) const { return b; }
+    __device__ __forceinline__ double single() const { return sel ? a.y : a.x; }
+};
+template <> struct piece_x<float> {
+    float4u q;
+    int sh;
+    __device__ __forceinline__ void load(const float *x, int cs, int, int num_cols)
+    {
+        const int ca = cs < num_cols - 4 ? cs : num_cols - 4;
+        sh = cs - ca;
+        q = *reinterpret_cast<const float4u *>(x + ca);
+    }
+    __device__ __forceinline__ float2u first(int) const { return float2u{pick4(q, sh), pick4(q, sh + 1)}; }
+    __device__ __forceinline__ float2u last(int len) const { return float2u{pick4(q, sh + len - 2), pick4(q, sh + len - 1)}; }
+    __device__ __forceinline__ float single() const { return pick4(q, sh); }
+};
 
 // ---- plan time -------------------------------------------------------------------------------------------------------
 // pieces of row r: maximal runs of consecutive columns, cut every kRunCap entries
@@ -97,12 +137,12 @@ runs_partition_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *_
 }
 
 // PACKED: bytes / 16 of tile t's span = pieces padded to 16 bytes + values padded to 16 bytes
-__global__ void __launch_bounds__(256) runs_span_kernel(int64_t tiles, const int32_t *__restrict__ start, int *__restrict__ span16)
+__global__ void __launch_bounds__(256) runs_span_kernel(int64_t tiles, const int32_t *__restrict__ start, int per16, int *__restrict__ span16)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tiles) return;
     const int np = start[4 * (t + 1) + 2] - start[4 * t + 2], cnt = start[4 * (t + 1) + 1] - start[4 * t + 1];
-    span16[t] = (np + 3) / 4 + (cnt + 1) / 2;
+    span16[t] = (np + 3) / 4 + (cnt + per16 - 1) / per16; // (per16: values per 16 bytes -- 2 for f64, 4 for f32)
 }
 // one wave per tile copies its pieces and values into the tile's span; start[t].w <- the span's offset in 16-byte units
 template <typename T>
@@ -145,7 +185,7 @@ int csr_runs_build(cmi_plan *p, const int *Ap, const int *Aj, int v, double min_
 {
     const int64_t rows = p->rows, nnz = p->nnz;
     if (mean_piece) *mean_piece = 0.0;
-    if (rows <= 0 || nnz <= 0 || nnz > INT32_MAX - 65536 || p->cols < 2 || p->cols >= kRunMaxCols || p->prof.max_len < 1) return CMI_SUCCESS;
+    if (rows <= 0 || nnz <= 0 || nnz > INT32_MAX - 65536 || p->cols < (p->dtype == CMI_F64 ? 2 : 4) || p->cols >= kRunMaxCols || p->prof.max_len < 1) return CMI_SUCCESS;
     const int q = 256 * v - (int)p->prof.max_len - 3;
     if (q < 1) return CMI_SUCCESS;
     int *count = nullptr;
@@ -206,7 +246,7 @@ int csr_runs_build(cmi_plan *p, const int *Ap, const int *Aj, int v, double min_
         e = hipMalloc((void **)&span, (size_t)(tiles + 1) * sizeof(int));
         if (e == hipSuccess) e = hipMemsetAsync(span + tiles, 0, sizeof(int), s);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(runs_span_kernel, dim3((unsigned)ceil_div(tiles, 256)), dim3(256), 0, s, tiles, start, span);
+            hipLaunchKernelGGL(runs_span_kernel, dim3((unsigned)ceil_div(tiles, 256)), dim3(256), 0, s, tiles, start, p->dtype == CMI_F64 ? 2 : 4, span);
             e = hipGetLastError();
         }
         if (e != hipSuccess) st = hip_fail(e, "cmi_plan_create: packed tiles");
@@ -257,17 +297,19 @@ int csr_runs_build(cmi_plan *p, const int *Ap, const int *Aj, int v, double min_
 // 83.0 / 196 us against 73.6 / 178: the value loads of a wave instruction then overlap instead of tiling the stream.  The ablations of the
 // same session put the product stage at 1 % and the row sums at 4 % of this kernel: what is left is the load phase, at 6.7 TB/s of
 // counted traffic.  profiles/r04_waver_ablation_and_piece_values.txt.)
-template <int V, int POL, bool DOT, bool PACKED>
+template <typename T, int V, int POL, bool DOT, bool PACKED>
 __global__ void __launch_bounds__(256)
 csr_waver_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t num_entries, int num_cols, const int *Ap /* not restrict: see csr_wave */,
-                 const int *__restrict__ Aj, const uint32_t *__restrict__ pieces, const double *__restrict__ Ax, const unsigned char *__restrict__ packed,
-                 const double *__restrict__ x, double *__restrict__ y, int64_t num_tiles, int64_t tiles_per_xcd, int swizzle, int accumulate,
-                 const double *__restrict__ w, double *__restrict__ dot_partial, int ablate = 0)
+                 const int *__restrict__ Aj, const uint32_t *__restrict__ pieces, const T *__restrict__ Ax, const unsigned char *__restrict__ packed,
+                 const T *__restrict__ x, T *__restrict__ y, int64_t num_tiles, int64_t tiles_per_xcd, int swizzle, int accumulate,
+                 const T *__restrict__ w, double *__restrict__ dot_partial, int ablate = 0)
 {
     // ablate (measurements only, $CMI_WAVER_ABLATE; WRONG results by design): bit 1 -- no product stage (the rows sum the parked x values; the
     // value loads stay needed: added to lane 0's row); bit 2 -- a row's lane reads only its first slot (no sum phase)
-    typedef double T;
-    constexpr int E = 2, NL = (V * 4) / E, SLOTS = kWave * V * 4, NPC = V == 4 ? 6 : V == 2 ? 3 : 2;
+    // f64: E = 2 values per 16-byte load, 2 V loads per lane; f32: E = 4, V loads per lane -- 256 V slots per tile either way
+    constexpr int E = 16 / (int)sizeof(T), NL = (V * 4) / E, SLOTS = kWave * V * 4, NPC = V == 4 ? 6 : V == 2 ? 3 : 2;
+    typedef T __attribute__((ext_vector_type(E))) val_t;
+    typedef typename pair_of<T>::type pair_t;
     __shared__ __attribute__((aligned(16))) T prod[4][SLOTS];
     __shared__ double dot_slots[DOT ? 4 : 1];
     constexpr bool NT = (POL & kPolLoadNT) != 0, NTS = (POL & kPolStoreNT) != 0;
@@ -315,18 +357,18 @@ csr_waver_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t 
                     const int i = k * kWave + lane;
                     dsc[k] = ld<NT>(pc + (i < lastp ? i : lastp));
                 }
-                double2v v[NL];
+                val_t v[NL];
 #pragma unroll
                 for (int k = 0; k < NL; k++) {
                     int e = (k * kWave + lane) * E;
                     e = e < last ? e : last;
-                    v[k] = ld<NT>(reinterpret_cast<const double2v *>(vbase + e));
+                    v[k] = ld<NT>(reinterpret_cast<const val_t *>(vbase + e));
                 }
                 __builtin_amdgcn_sched_barrier(0); // every stream request is out before the first x address is formed
                 // ---- x: two 16-byte loads per piece, whatever its length ----
                 int run = shift; // slot of the next piece's first entry (uniform)
-                int o[NPC], len[NPC], sel[NPC];
-                double2u xa[NPC], xb[NPC];
+                int o[NPC], len[NPC];
+                piece_x<T> px[NPC];
 #pragma unroll
                 for (int k = 0; k < NPC; k++) {
                     const bool valid = k * kWave + lane < np;
@@ -334,21 +376,16 @@ csr_waver_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t 
                     const int incl = wave_inclusive_sum(len[k]);
                     o[k] = run + incl - len[k];
                     run += __builtin_amdgcn_readlane(incl, kWave - 1);
-                    const int cs = (int)(dsc[k] >> 2);
-                    const int ca = cs < num_cols - 2 ? cs : num_cols - 2; // (a piece of one entry in the last column: the pair before it)
-                    sel[k] = cs - ca;
-                    const int cb = ca + (len[k] > 2 ? len[k] - 2 : 0);
-                    xa[k] = *reinterpret_cast<const double2u *>(x + ca);
-                    xb[k] = *reinterpret_cast<const double2u *>(x + cb);
+                    px[k].load(x, (int)(dsc[k] >> 2), len[k], num_cols);
                 }
                 // x values into the slots of their entries: a piece of 2+ stores its first PAIR with one LDS instruction (ds_write2_b64), a
                 // piece of 3 or 4 its last pair with another (a piece of 3 rewrites its middle value with itself), a piece of 1 its one value
                 // (the branch is skipped where no lane of the chunk holds one: FEM / 27-point rows)
 #pragma unroll
                 for (int k = 0; k < NPC; k++) {
-                    if (len[k] >= 2) *reinterpret_cast<double2u *>(mine + o[k]) = xa[k];
-                    if (len[k] >= 3) *reinterpret_cast<double2u *>(mine + o[k] + len[k] - 2) = xb[k];
-                    if (len[k] == 1) mine[o[k]] = sel[k] ? xa[k].y : xa[k].x;
+                    if (len[k] >= 2) *reinterpret_cast<pair_t *>(mine + o[k]) = px[k].first(len[k]);
+                    if (len[k] >= 3) *reinterpret_cast<pair_t *>(mine + o[k] + len[k] - 2) = px[k].last(len[k]);
+                    if (len[k] == 1) mine[o[k]] = px[k].single();
                 }
                 for (int base = NPC * kWave; base < np; base += kWave) { // (a tile of short runs: further chunks, one at a time)
                     const int i = base + lane;
@@ -357,13 +394,11 @@ csr_waver_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t 
                     const int incl = wave_inclusive_sum(ln);
                     const int oo = run + incl - ln;
                     run += __builtin_amdgcn_readlane(incl, kWave - 1);
-                    const int cs = (int)(ds >> 2);
-                    const int ca = cs < num_cols - 2 ? cs : num_cols - 2;
-                    const int cb = ca + (ln > 2 ? ln - 2 : 0);
-                    const double2u A = *reinterpret_cast<const double2u *>(x + ca), B = *reinterpret_cast<const double2u *>(x + cb);
-                    if (ln >= 2) *reinterpret_cast<double2u *>(mine + oo) = A;
-                    if (ln >= 3) *reinterpret_cast<double2u *>(mine + oo + ln - 2) = B;
-                    if (ln == 1) mine[oo] = (cs - ca) ? A.y : A.x;
+                    piece_x<T> one;
+                    one.load(x, (int)(ds >> 2), ln, num_cols);
+                    if (ln >= 2) *reinterpret_cast<pair_t *>(mine + oo) = one.first(ln);
+                    if (ln >= 3) *reinterpret_cast<pair_t *>(mine + oo + ln - 2) = one.last(ln);
+                    if (ln == 1) mine[oo] = one.single();
                 }
                 asm volatile("" : "+v"(a)); // the row offset was requested in front of the streams
                 __builtin_amdgcn_wave_barrier(); // (compiler only: the hardware runs a wave's LDS instructions in order)
@@ -371,14 +406,19 @@ csr_waver_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t 
                 if (ablate & 1) { // (uniform) the values must stay NEEDED, or the compiler drops their loads
                     T keep = T(0);
 #pragma unroll
-                    for (int k = 0; k < NL; k++) keep = keep + v[k].x + v[k].y;
+                    for (int k = 0; k < NL; k++)
+#pragma unroll
+                        for (int i = 0; i < E; i++) keep = keep + v[k][i];
                     if (keep == T(12345.678)) mine[0] = keep;
                 } else {
 #pragma unroll
                     for (int k = 0; k < NL; k++) {
-                        double2v *slot = reinterpret_cast<double2v *>(mine + (k * kWave + lane) * E);
-                        const double2v xs = *slot;
-                        *slot = double2v{v[k].x * xs.x, v[k].y * xs.y};
+                        val_t *slot = reinterpret_cast<val_t *>(mine + (k * kWave + lane) * E);
+                        const val_t xs = *slot;
+                        val_t pr;
+#pragma unroll
+                        for (int i = 0; i < E; i++) pr[i] = v[k][i] * xs[i];
+                        *slot = pr;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -402,14 +442,15 @@ csr_waver_kernel(const int32_t *__restrict__ start, int64_t wave_tiles, int64_t 
     }
 }
 
-int csr_runs_multiply_f64(const cmi_plan *p, const int *Ap, const int *Aj, const double *Ax, const double *x, double *y, int accumulate, hipStream_t s,
-                          const double *w, double *dot_partial, int *dot_partials, int pol, int swz_in)
+template <typename T>
+static int csr_runs_multiply(const cmi_plan *p, const int *Ap, const int *Aj, const T *Ax, const T *x, T *y, int accumulate, hipStream_t s,
+                             const T *w, double *dot_partial, int *dot_partials, int pol, int swz_in)
 {
     if (!p->runs_start || !p->runs_pieces) return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_CSR_STREAM_WAVER / _PACKED run through a plan of cmi_plan_create_csr only");
     const bool packed = p->cfg.kernel == CMI_CSR_STREAM_PACKED;
     if (packed && !p->runs_packed) return fail(CMI_ERROR_NOT_SUPPORTED, "CMI_CSR_STREAM_PACKED: the plan holds no packed copy (cmi_plan_create_csr_values)");
     if (!packed && reinterpret_cast<uintptr_t>(Ax) % 16 != 0) return fail(CMI_ERROR_INVALID_VALUE, "csr_waver: Ax must be 16-byte aligned");
-    if (reinterpret_cast<uintptr_t>(x) % 8 != 0) return fail(CMI_ERROR_INVALID_VALUE, "csr_waver: x must be 8-byte aligned");
+    if (reinterpret_cast<uintptr_t>(x) % sizeof(T) != 0) return fail(CMI_ERROR_INVALID_VALUE, "csr_waver: x must be aligned to its element size");
     const int V = p->cfg.items_per_thread;
     if (V != 1 && V != 2 && V != 4) return fail(CMI_ERROR_NOT_SUPPORTED, "csr_waver: items_per_thread must be 1, 2 or 4");
     const int64_t tiles = ceil_div(p->wave_tiles, (int64_t)4);
@@ -424,8 +465,8 @@ int csr_runs_multiply_f64(const cmi_plan *p, const int *Ap, const int *Aj, const
         auto go = [&](auto VV, auto PK) {
             constexpr int VC = decltype(VV)::value;
             constexpr bool PKC = decltype(PK)::value;
-            if (dot) hipLaunchKernelGGL((csr_waver_kernel<VC, POL, true, PKC>), dim3((unsigned)grid64), dim3(256), 0, s, p->runs_start, p->wave_tiles, p->nnz, (int)p->cols, Ap, Aj, p->runs_pieces, Ax, p->runs_packed, x, y, tiles, tpx, swz, accumulate, w, dot_partial);
-            else     hipLaunchKernelGGL((csr_waver_kernel<VC, POL, false, PKC>), dim3((unsigned)grid64), dim3(256), 0, s, p->runs_start, p->wave_tiles, p->nnz, (int)p->cols, Ap, Aj, p->runs_pieces, Ax, p->runs_packed, x, y, tiles, tpx, swz, accumulate, (const double *)nullptr, (double *)nullptr, ablate);
+            if (dot) hipLaunchKernelGGL((csr_waver_kernel<T, VC, POL, true, PKC>), dim3((unsigned)grid64), dim3(256), 0, s, p->runs_start, p->wave_tiles, p->nnz, (int)p->cols, Ap, Aj, p->runs_pieces, Ax, p->runs_packed, x, y, tiles, tpx, swz, accumulate, w, dot_partial);
+            else     hipLaunchKernelGGL((csr_waver_kernel<T, VC, POL, false, PKC>), dim3((unsigned)grid64), dim3(256), 0, s, p->runs_start, p->wave_tiles, p->nnz, (int)p->cols, Ap, Aj, p->runs_pieces, Ax, p->runs_packed, x, y, tiles, tpx, swz, accumulate, (const T *)nullptr, (double *)nullptr, ablate);
         };
         auto by_v = [&](auto PK) {
             switch (V) {
@@ -439,6 +480,17 @@ int csr_runs_multiply_f64(const cmi_plan *p, const int *Ap, const int *Aj, const
     if (dot && dot_partials) *dot_partials = (int)tiles;
     CMI_LAUNCH_CHECK("csr_waver");
     return CMI_SUCCESS;
+}
+
+int csr_runs_multiply_f64(const cmi_plan *p, const int *Ap, const int *Aj, const double *Ax, const double *x, double *y, int accumulate, hipStream_t s,
+                          const double *w, double *dot_partial, int *dot_partials, int pol, int swz)
+{
+    return csr_runs_multiply<double>(p, Ap, Aj, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol, swz);
+}
+int csr_runs_multiply_f32(const cmi_plan *p, const int *Ap, const int *Aj, const float *Ax, const float *x, float *y, int accumulate, hipStream_t s,
+                          const float *w, double *dot_partial, int *dot_partials, int pol, int swz)
+{
+    return csr_runs_multiply<float>(p, Ap, Aj, Ax, x, y, accumulate, s, w, dot_partial, dot_partials, pol, swz);
 }
 
 } // namespace cmi

@@ -178,20 +178,20 @@ typedef enum cmi_kernel {
                                from there; columns outside the window are gathered from memory as usual.  For GATHER-BOUND band matrices
                                (columns anywhere within a few thousand of the diagonal: every x entry is its own L1 lookup otherwise).
                                items_per_thread 2 or 4.  Bit-exact.  Needs 16-byte aligned Aj / Ax / x.                                   */
-    CMI_CSR_STREAM_WAVER = 11, /* plans of cmi_plan_create_csr only (round 4), f64: CMI_CSR_STREAM_WAVEV's wave tiles reading a RUN-COMPRESSED copy of the
+    CMI_CSR_STREAM_WAVER = 11, /* plans of cmi_plan_create_csr only (round 4), f64 and f32: CMI_CSR_STREAM_WAVEV's wave tiles reading a RUN-COMPRESSED copy of the
                                column indices that the plan builds and owns -- every row cut into pieces of 1..4 CONSECUTIVE columns, 4 bytes
                                per piece ((first column << 2) | (length - 1)), 16 bytes per wave tile -- instead of Aj: FEM (3 dof per node) and
                                KKT / 27-point matrices keep their columns in runs of 3 or more, so the index stream shrinks to about a third
-                               (9.3-9.4 instead of 12 bytes per entry) and a piece's x values arrive with two 16-byte loads instead of one
-                               8-byte gather per entry.  The VALUES stay the caller's array (refreshing them in place is fine).  Same products,
+                               (f64: 9.3-9.4 instead of 12 bytes per entry; f32: 5.3-5.4 instead of 8) and a piece's x values arrive with two
+                               16-byte loads (f32: one) instead of one gather per entry.  The VALUES stay the caller's array (refreshing them in place is fine).  Same products,
                                storage-order sums: bit-exact.  An AUTO plan made with the columns selects it when the pieces average 2.5+
                                entries on a matrix csr_wavev's size / row-length rule admits ($CMI_CSR_WAVER=0: never, =1: whenever the rows
                                qualify); asked for explicitly it is refused only where the tile cannot hold the longest row.  items_per_thread
                                1, 2, 4 (0: 4) = 256 x that many slots per wave tile; threads_per_row = entries per piece at most, 3 or 4
                                (0: 3 where that costs at most 3 % more pieces than 4 -- pieces of three leave no LDS bank conflict between
-                               them -- else 4).  Needs fewer than 2^30 columns, no row of 512+ entries,
-                               16-byte aligned Ax, 8-byte aligned x.  cmi_plan_validate checks the column indices.                     */
-    CMI_CSR_STREAM_PACKED = 12, /* OPT-IN, plans of cmi_plan_create_csr_values only (round 4), f64: CMI_CSR_STREAM_WAVER with the pieces AND THE VALUES of
+                               them -- else 4).  Needs fewer than 2^30 columns (f32: at least 4), no row of 512+ entries,
+                               16-byte aligned Ax.  cmi_plan_validate checks the column indices.                     */
+    CMI_CSR_STREAM_PACKED = 12, /* OPT-IN, plans of cmi_plan_create_csr_values only (round 4): CMI_CSR_STREAM_WAVER with the pieces AND THE VALUES of
                                every wave tile laid side by side in one plan-owned buffer ([pieces | pad to 16 | values | pad to 16] per tile),
                                so that a wave's requests are ONE contiguous span of HBM.  The plan then owns a COPY OF THE VALUES: values
                                refreshed in place are NOT seen -- destroy the plan and make a new one (cmi_plan_validate_values tells).

@@ -67,14 +67,16 @@ def pieces_of(Ap, Aj, cap=4):
     return n
 
 
+@pytest.mark.parametrize("tag", ["f64", "f32"])
 @pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("vectors", [0, 1, 2, 4])
-def test_waver_kernel_bit_exact(cmi, torch_cuda, orc, vectors, packed):
+def test_waver_kernel_bit_exact(cmi, torch_cuda, orc, vectors, packed, tag):
     """reference arithmetic: cusp/system/detail/sequential/multiply/csr_spmv.h:42-74.  Every row of every matrix must have the host
     loop's bits: FEM-like runs (3, 6, 9 ...), single columns only (every piece one entry: more pieces than the unrolled pass holds),
     empty rows and a stretch of 300 of them, the longest row the tile admits, an odd entry count (the arrays' last pair), a piece of
     one entry in the last column, accumulate, the fused <y, w>."""
     torch = torch_cuda
+    dtype, tdt = (np.float64, torch.float64) if tag == "f64" else (np.float32, torch.float32)
     cases = [(1, 6000, 20, 72, 3.0), (2, 3000, 1, 100, 1.0), (3, 20000, 5, 28, 2.0), (4, 4099, 0, 40, 6.0), (5, 900, 60, 125, 4.0), (6, 5000, 1, 9, 1.5)]
     for seed, rows, lo, hi, run_mean in cases:
         rng = np.random.default_rng(1000 * seed + vectors)
@@ -85,14 +87,15 @@ def test_waver_kernel_bit_exact(cmi, torch_cuda, orc, vectors, packed):
             lens[0] += 1
         cols = rows + 700
         Ap, Aj, Ax = run_csr(rng, rows, cols, lens, run_mean)
+        Ax = Ax.astype(dtype)
         nnz, longest = int(Ap[-1]), int(lens.max())
         v_rule = vectors if vectors else 4
-        x = rng.standard_normal(cols)
-        y0 = rng.standard_normal(rows)
+        x = rng.standard_normal(cols).astype(dtype)
+        y0 = rng.standard_normal(rows).astype(dtype)
         dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
         kern = cmi.CSR_STREAM_PACKED if packed else cmi.CSR_STREAM_WAVER
         cfg = cmi.Config(kernel=kern, items_per_thread=vectors)
-        make = (lambda: cmi.Plan.csr_values(rows, cols, dAp, dAj, dAx, cfg)) if packed else (lambda: cmi.Plan.csr(torch.float64, rows, cols, dAp, dAj, cfg))
+        make = (lambda: cmi.Plan.csr_values(rows, cols, dAp, dAj, dAx, cfg)) if packed else (lambda: cmi.Plan.csr(tdt, rows, cols, dAp, dAj, cfg))
         if 2 * (longest + 3) > 256 * v_rule:  # the longest row takes more than half a tile: refused, by name
             with pytest.raises(cmi.CmiError):
                 make()
@@ -105,18 +108,19 @@ def test_waver_kernel_bit_exact(cmi, torch_cuda, orc, vectors, packed):
         want_bytes = 4 * (npieces + 64) + 16 * (nnz // (256 * v_rule - longest - 3) + 2)
         assert plan.device_bytes() >= want_bytes, (plan.device_bytes(), want_bytes)  # (+ the packed tiles)
         want, want_acc = orc.spmv_csr(Ap, Aj, Ax, x), orc.spmv_csr(Ap, Aj, Ax, x, y0)
-        y = torch.full((rows,), 9.0, dtype=torch.float64, device="cuda")
+        y = torch.full((rows,), 9.0, dtype=tdt, device="cuda")
         cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
-        assert np.array_equal(y.cpu().numpy(), want), (seed, vectors, packed)
+        assert np.array_equal(y.cpu().numpy(), want), (seed, vectors, packed, tag)
         y = dev(y0, torch)
         cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y, accumulate=True)
-        assert np.array_equal(y.cpu().numpy(), want_acc), (seed, vectors, packed, "accumulate")
-        w = rng.standard_normal(rows)
+        assert np.array_equal(y.cpu().numpy(), want_acc), (seed, vectors, packed, tag, "accumulate")
+        w = rng.standard_normal(rows).astype(dtype)
         res = torch.zeros(1, dtype=torch.float64, device="cuda")
-        y = torch.zeros(rows, dtype=torch.float64, device="cuda")
+        y = torch.zeros(rows, dtype=tdt, device="cuda")
         cmi.spmv_csr_dot(rows, cols, dAp, dAj, dAx, dx, y, dev(w, torch), res, cmi.blas_workspace(), plan=plan)
-        assert np.array_equal(y.cpu().numpy(), want), (seed, vectors, packed, "dot")
-        assert abs(res.item() - float(np.dot(want, w))) <= 1e-9 * float(np.dot(np.abs(want), np.abs(w))) + 1e-300
+        assert np.array_equal(y.cpu().numpy(), want), (seed, vectors, packed, tag, "dot")
+        ref64 = float(np.dot(want.astype(np.float64), w.astype(np.float64)))
+        assert abs(res.item() - ref64) <= 1e-9 * float(np.dot(np.abs(want).astype(np.float64), np.abs(w).astype(np.float64))) + 1e-300
         # the plan's contract: the column indices must not change in place -- and cmi_plan_validate tells when they have
         assert plan.validate(dAp, dAj) is True
         if packed:
@@ -127,7 +131,7 @@ def test_waver_kernel_bit_exact(cmi, torch_cuda, orc, vectors, packed):
         else:  # the VALUES are the caller's: refreshed in place they are seen by the next multiply
             dAx.mul_(2.0)
             cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
-            assert np.array_equal(y.cpu().numpy(), orc.spmv_csr(Ap, Aj, 2.0 * Ax, x)), (seed, "values refreshed in place")
+            assert np.array_equal(y.cpu().numpy(), orc.spmv_csr(Ap, Aj, (2.0 * Ax).astype(dtype), x)), (seed, "values refreshed in place")
             assert plan.validate_values(dAx) is True  # (nothing of them is kept)
         dAj2 = dAj.clone()
         dAj2[nnz // 2] = (int(Aj[nnz // 2]) + 1) % cols
@@ -144,8 +148,9 @@ def test_waver_refusals(cmi, torch_cuda):
         cmi.Plan(cmi.FORMAT_CSR, torch.float64, rows, cols, len(Aj), dAp, cmi.Config(kernel=cmi.CSR_STREAM_WAVER))
     with pytest.raises(cmi.CmiError):   # packed without the values
         cmi.Plan.csr(torch.float64, rows, cols, dAp, dAj, cmi.Config(kernel=cmi.CSR_STREAM_PACKED))
-    with pytest.raises(cmi.CmiError):   # f32
-        cmi.Plan.csr(torch.float32, rows, cols, dAp, dAj, cmi.Config(kernel=cmi.CSR_STREAM_WAVER))
+    # (f32 is served since session 9 of round 4: one 16-byte x load per piece; AUTO: the same size / piece-length rule as f64 -- this matrix is too small)
+    assert cmi.Plan.csr(torch.float32, rows, cols, dAp, dAj, cmi.Config(kernel=cmi.CSR_STREAM_WAVER)).config().kernel == cmi.CSR_STREAM_WAVER
+    assert cmi.Plan.csr(torch.float32, rows, cols, dAp, dAj).config().kernel != cmi.CSR_STREAM_WAVER
     with pytest.raises(cmi.CmiError):   # plan-less
         y = torch.zeros(rows, dtype=torch.float64, device="cuda")
         cmi.spmv_csr(rows, cols, dAp, dAj, dAx, y.clone(), y, cfg=cmi.Config(kernel=cmi.CSR_STREAM_WAVER))
@@ -234,6 +239,16 @@ def test_configs3_full_size_run_compressed(cmi, torch_cuda, orc, name):
     y.fill_(10.0)
     cmi.multiply(A, dx, y)
     assert np.array_equal(y.cpu().numpy(), want)
+    # f32 values of the same matrix: the AUTO plan takes the run-compressed copy too (ldoor, nlpkkt120), the host loop's f32 bits
+    Ax32, x32 = Ax.astype(np.float32), x.astype(np.float32)
+    want32 = orc.spmv_csr(Ap, Aj, Ax32, x32, omp=True)
+    dAx32, dx32 = dev(Ax32, torch), dev(x32, torch)
+    auto32 = cmi.Plan.csr(torch.float32, rows, cols, dAp, dAj)
+    if name in ("ldoor", "nlpkkt120") and source.startswith("seeded"):
+        assert auto32.config().kernel == cmi.CSR_STREAM_WAVER, auto32.config()
+    y32 = torch.full((rows,), 10.0, dtype=torch.float32, device="cuda")
+    cmi.spmv_csr_plan(auto32, dAp, dAj, dAx32, dx32, y32)
+    assert np.array_equal(y32.cpu().numpy(), want32), (name, "f32", auto32.config())
 
 
 @pytest.mark.parametrize("tag", ["f64", "f32"])

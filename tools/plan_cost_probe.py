@@ -60,3 +60,31 @@ for name, make, mult in rows:
         mult = lambda p=p: cmi.spmv_csr_plan(p, A.row_offsets, A.column_indices, A.values, x, y)  # noqa: E731
     m = mult_us(mult)
     print(f"  {name:42s} {t:9.0f} us to create   {m:7.1f} us per multiply   = {t / m:5.1f} multiplies")
+
+# round 4: the plans that own a copy derived from the columns / the values, on the matrices they are made for
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import numpy as np  # noqa: E402
+import suitesparse_like as ssl  # noqa: E402
+
+p = cmi.Plan.csr_values(N, N, A.row_offsets, A.column_indices, A.values, cmi.Config(kernel=cmi.CSR_STREAM_PACKED))
+t = wall_us(lambda: cmi.Plan.csr_values(N, N, A.row_offsets, A.column_indices, A.values, cmi.Config(kernel=cmi.CSR_STREAM_PACKED)))
+m = mult_us(lambda: cmi.spmv_csr_plan(p, A.row_offsets, A.column_indices, A.values, x, y))
+print(f"  {'CSR packed wave tiles (16-bit copy + pack)':42s} {t:9.0f} us to create   {m:7.1f} us per multiply   = {t / m:5.1f} multiplies   (owns {p.device_bytes() / 1e6:.0f} MB)")
+del p, A, C, H, H1
+torch.cuda.empty_cache()
+for name in ("ldoor", "nlpkkt120"):
+    Ap, Aj, Ax = ssl.GENERATORS[name](1.0)
+    rows_, nnz_ = len(Ap) - 1, len(Aj)
+    dAp, dAj, dAx = (torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (Ap, Aj, Ax))
+    xx = cmi.fill_x(rows_, device="cuda")
+    yy = torch.empty(rows_, dtype=torch.float64, device="cuda")
+    for label, make in (("AUTO with the columns (csr_waver)", lambda: cmi.Plan.csr(torch.float64, rows_, rows_, dAp, dAj)),
+                        ("row offsets only (csr_stream / csr_wavev)", lambda: cmi.Plan(cmi.FORMAT_CSR, torch.float64, rows_, rows_, nnz_, dAp)),
+                        ("packed run-compressed tiles", lambda: cmi.Plan.csr_values(rows_, rows_, dAp, dAj, dAx, cmi.Config(kernel=cmi.CSR_STREAM_PACKED)))):
+        p = make()
+        t = wall_us(make, reps=5)
+        m = mult_us(lambda: cmi.spmv_csr_plan(p, dAp, dAj, dAx, xx, yy), iters=100)
+        print(f"  {name + '-like: ' + label:58s} {t:9.0f} us to create   {m:7.1f} us per multiply   = {t / m:5.1f} multiplies   (kernel {p.config().kernel}, owns {p.device_bytes() / 1e6:.1f} MB)")
+        del p
+    del dAp, dAj, dAx, xx, yy
+    torch.cuda.empty_cache()

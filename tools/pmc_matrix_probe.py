@@ -30,6 +30,8 @@ K = int(os.environ.get("PMC_LAUNCHES", "6"))
 
 
 SCALE = float(os.environ.get("PMC_SCALE", "1.0"))  # stand-in size (1.0: the published one)
+DT = torch.float32 if os.environ.get("PMC_DTYPE", "f64") == "f32" else torch.float64  # value type of the matrices
+VB = 4 if DT == torch.float32 else 8
 
 
 def cached(name):
@@ -104,12 +106,12 @@ def main():
             Aj = np.minimum((r // w) * w + ((e * 2654435761) >> 7) % w, rows - 1).astype(np.int32)
         if cols_mode:
             name = f"{name}[cols={cols_mode}]"
-        A = cmi.CsrMatrix(rows, rows, nnz, torch.from_numpy(Ap).cuda(), torch.from_numpy(Aj).cuda(), torch.from_numpy(Ax).cuda())
-        x = cmi.fill_x(rows, torch.float64, "cuda")
-        y = torch.empty(rows, dtype=torch.float64, device="cuda")
+        A = cmi.CsrMatrix(rows, rows, nnz, torch.from_numpy(Ap).cuda(), torch.from_numpy(Aj).cuda(), torch.from_numpy(Ax).cuda().to(DT))
+        x = cmi.fill_x(rows, DT, "cuda")
+        y = torch.empty(rows, dtype=DT, device="cuda")
         cmi.multiply(A, x, y, cfg=cmi.Config(kernel=cmi.CSR_SCALAR))
         want = y.clone()
-        alg = cmi.csr_bytes(rows, nnz)
+        alg = cmi.csr_bytes(rows, nnz, VB)
         print(f"# {name}: {src}; rows {rows} entries {nnz} algorithmic bytes {alg}; set-up {time.time() - t0:.1f} s", flush=True)
         for label, cfg in variants_for(A):
             plan = None
@@ -122,7 +124,7 @@ def main():
             if isinstance(cfg, cmi.Config):
                 try:
                     plan = (cmi.Plan.csr_values(rows, rows, A.row_offsets, A.column_indices, A.values, cfg) if with_values else
-                            cmi.Plan.csr(torch.float64, rows, rows, A.row_offsets, A.column_indices, cfg=cfg))
+                            cmi.Plan.csr(DT, rows, rows, A.row_offsets, A.column_indices, cfg=cfg))
                 except Exception as e:  # noqa: BLE001
                     print(f"# {name} {label}: no plan ({e})")
                     continue
@@ -140,7 +142,7 @@ def main():
             go()
             exact = bool(torch.equal(y, want))
             desc = (A.plan().config() if cfg is None else explicit if explicit is not None else plan.config() if plan is not None else
-                    cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64, rows, rows, nnz))
+                    cmi.tuning_select(cmi.FORMAT_CSR, cmi.F64 if VB == 8 else cmi.F32, rows, rows, nnz))
             if timing:
                 e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
                 cmi.check(lib.cmi_event_create(ctypes.byref(e0)))
