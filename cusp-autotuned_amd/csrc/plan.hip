@@ -243,7 +243,8 @@ static bool waver_try(cmi_plan *p, const int *Ap, const int *Aj, bool asked, int
         if (rows < 4096) return false;
         // (size gate, profiles/r04_size_gates_scale_sweep.txt: at 10.8-10.9 M entries -- 130 MB of streams -- it takes 0.85-0.95 of the table
         //  kernel's time, at 5 M entries 1.13-1.22: smaller matrices keep csr_stream)
-        if (waver_env() != 1 && (mean < 8.0 || nnz < (int64_t)10000000)) return false;
+        //  f32 (r04_waver_f32_time.txt, f32 scale sweep): still 0.92 of the table kernel's time at 5.2 M entries -- gate at 5 M
+        if (waver_env() != 1 && (mean < 8.0 || nnz < (int64_t)(p->dtype == CMI_F64 ? 10000000 : 5000000))) return false;
     }
     double mean_piece = 0.0;
     *st = csr_runs_build(p, Ap, Aj, v, asked ? 0.0 : kWaverMinPiece, values, s, &mean_piece, asked ? asked_cap : 0);

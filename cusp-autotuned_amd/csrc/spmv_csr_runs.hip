@@ -73,54 +73,63 @@ template <> struct piece_x<float> {
 };
 
 // ---- plan time -------------------------------------------------------------------------------------------------------
-// pieces of row r: maximal runs of consecutive columns, cut every kRunCap entries
-// (cap: 3 or 4 entries per piece at most; count3: optional total for cap 3 beside the per-row counts for `cap`)
-__global__ void __launch_bounds__(256) runs_count_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ Aj, int cap, int *__restrict__ count,
-                                                         unsigned long long *__restrict__ totals)
+// pieces of row r: maximal runs of consecutive columns, cut every `cap` entries.  One lane walks one row -- but over a copy of the block's
+// columns in LDS: a workgroup owns `rpb` consecutive rows and first reads their entries [Ap[r0], Ap[r0 + nr]) COALESCED (a lane walking its
+// row through global memory touches a line per step, 64 different lines per wave instruction: the first version of these kernels took
+// 0.7-1.5 ms per pass on the configs[3] matrices, profiles/r04_plan_cost.txt; staged: one streaming read of Aj per pass).  A block whose rows
+// hold more than kRunsTile entries (rows far longer than the mean) walks global memory as before: correct, slower.
+constexpr int kRunsTile = 12288; // entries staged per workgroup (48 KiB of LDS)
+
+// FILL == false: count4[r] / count3[r] <- pieces of row r cut at 4 / at 3 (one walk counts both), totals[0 / 1] += their sums.
+// FILL == true: pieces[offset[r] ...] <- the row's pieces cut at `cap`.
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+runs_tile_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ Aj, int rpb, int cap, int *__restrict__ count4, int *__restrict__ count3,
+                 unsigned long long *__restrict__ totals, const int *__restrict__ offset, uint32_t *__restrict__ pieces)
 {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int n = 0, n3 = 0;
-    if (r < num_rows) {
+    __shared__ int cols[kRunsTile];
+    const int64_t r0 = (int64_t)blockIdx.x * rpb;
+    if (r0 >= num_rows) return;
+    const int nr = (int)((num_rows - r0) < rpb ? (num_rows - r0) : rpb);
+    const int nz0 = Ap[r0], nz1 = Ap[r0 + nr];
+    const bool staged = nz1 - nz0 <= kRunsTile; // (uniform)
+    if (staged) {
+        for (int i = threadIdx.x; i < nz1 - nz0; i += blockDim.x) cols[i] = Aj[nz0 + i];
+        __syncthreads();
+    }
+    int n4 = 0, n3 = 0;
+    if ((int)threadIdx.x < nr) {
+        const int64_t r = r0 + threadIdx.x;
         const int a = Ap[r], b = Ap[r + 1];
-        int len = 0, len3 = 0, prev = 0;
+        int len4 = 0, len3 = 0, prev = 0, first = 0, lenc = 0, q = FILL ? offset[r] - 1 : 0;
         for (int j = a; j < b; j++) {
-            const int c = Aj[j];
+            const int c = staged ? cols[j - nz0] : Aj[j];
             const bool brk = j == a || c != prev + 1;
-            if (brk || len == cap) { n++; len = 0; }
-            if (brk || len3 == 3) { n3++; len3 = 0; }
-            len++;
-            len3++;
+            if constexpr (FILL) {
+                if (brk || lenc == cap) {
+                    if (lenc > 0) pieces[q] = ((uint32_t)first << 2) | (uint32_t)(lenc - 1);
+                    q++;
+                    lenc = 0;
+                    first = c;
+                }
+                lenc++;
+            } else {
+                if (brk || len4 == 4) { n4++; len4 = 0; }
+                if (brk || len3 == 3) { n3++; len3 = 0; }
+                len4++;
+                len3++;
+            }
             prev = c;
         }
-        if (count) count[r] = n;
+        if constexpr (FILL) { if (lenc > 0) pieces[q] = ((uint32_t)first << 2) | (uint32_t)(lenc - 1); }
+        else { count4[r] = n4; count3[r] = n3; }
     }
-    if (totals) { // (first pass only: how many pieces would cap 4 / cap 3 give?)
-        unsigned long long t4 = (unsigned long long)n, t3 = (unsigned long long)n3;
+    if constexpr (!FILL) {
+        unsigned long long t4 = (unsigned long long)n4, t3 = (unsigned long long)n3;
 #pragma unroll
         for (int o = kWave / 2; o > 0; o >>= 1) { t4 += __shfl_down(t4, o); t3 += __shfl_down(t3, o); }
         if ((threadIdx.x & (kWave - 1)) == 0) { if (t4) atomicAdd(totals, t4); if (t3) atomicAdd(totals + 1, t3); }
     }
-}
-
-__global__ void __launch_bounds__(256) runs_fill_kernel(int64_t num_rows, const int *__restrict__ Ap, const int *__restrict__ Aj, const int *__restrict__ offset, int cap,
-                                                        uint32_t *__restrict__ pieces)
-{
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= num_rows) return;
-    const int a = Ap[r], b = Ap[r + 1];
-    int q = offset[r] - 1, len = 0, prev = 0, first = 0;
-    for (int j = a; j < b; j++) {
-        const int c = Aj[j];
-        if (len == 0 || c != prev + 1 || len == cap) {
-            if (len > 0) pieces[q] = ((uint32_t)first << 2) | (uint32_t)(len - 1);
-            q++;
-            len = 0;
-            first = c;
-        }
-        len++;
-        prev = c;
-    }
-    if (len > 0) pieces[q] = ((uint32_t)first << 2) | (uint32_t)(len - 1);
 }
 
 // tile t = the rows whose FIRST entry lies in [t q, (t + 1) q) (wave_partition_kernel's rule, spmv_csr.hip); {row, entry, piece, 0} per tile
@@ -188,39 +197,39 @@ int csr_runs_build(cmi_plan *p, const int *Ap, const int *Aj, int v, double min_
     if (rows <= 0 || nnz <= 0 || nnz > INT32_MAX - 65536 || p->cols < (p->dtype == CMI_F64 ? 2 : 4) || p->cols >= kRunMaxCols || p->prof.max_len < 1) return CMI_SUCCESS;
     const int q = 256 * v - (int)p->prof.max_len - 3;
     if (q < 1) return CMI_SUCCESS;
-    int *count = nullptr;
+    int *count = nullptr, *count3 = nullptr;
     unsigned long long *totals = nullptr, host_totals[2] = {0, 0};
-    hipError_t e = hipMalloc((void **)&count, (size_t)(rows + 1) * sizeof(int));
+    hipError_t e = hipMalloc((void **)&count, (size_t)(rows + 1) * 2 * sizeof(int)); // [rows + 1] cut at 4, then [rows + 1] cut at 3
     if (e != hipSuccess) return hip_fail(e, "cmi_plan_create: run-compressed columns");
+    count3 = count + rows + 1;
     e = hipMalloc((void **)&totals, sizeof(host_totals));
     if (e == hipSuccess) e = hipMemsetAsync(totals, 0, sizeof(host_totals), s);
     if (e == hipSuccess) e = hipMemsetAsync(count + rows, 0, sizeof(int), s);
+    if (e == hipSuccess) e = hipMemsetAsync(count3 + rows, 0, sizeof(int), s);
+    // rows per workgroup of the tile kernels: as many as keep the block's entries inside the LDS tile at the MEAN row length (with a
+    // quarter of slack), at most one per lane
+    int rpb = (int)((double)kRunsTile * 0.75 / ((double)nnz / (double)rows));
+    rpb = rpb > 256 ? 256 : rpb < 1 ? 1 : rpb;
+    const unsigned tgrid = (unsigned)ceil_div(rows, rpb);
     // Pieces of at most 4 or at most 3 entries?  Three degrees of freedom per node give runs of 3, 6, 9 ...: cut at 4 they become 4 + 2,
     // 4 + 4 + 1 -- no fewer pieces than cut at 3, and the pieces of 4 park their x values 32 bytes apart in LDS (a 4-way bank conflict
     // where pieces of 3 have none; profiles/r04_long_rows_pmc.json: LDS index unit 71 % busy on ldoor-like).  Cap 3 when it costs at most
-    // 3 % more pieces than cap 4 ($CMI_WAVER_CAP=3 / 4 forces).
+    // 3 % more pieces than cap 4 ($CMI_WAVER_CAP=3 / 4 forces).  One walk counts both.
     static const int cap_env_ = [] { const char *ev = std::getenv("CMI_WAVER_CAP"); return ev ? std::atoi(ev) : 0; }();
     const int cap_env = (cap_asked == 3 || cap_asked == 4) ? cap_asked : cap_env_; // (a plan that asks: config.threads_per_row)
     int cap = kRunCap;
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(runs_count_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, s, rows, Ap, Aj, kRunCap, count, totals);
+        hipLaunchKernelGGL((runs_tile_kernel<false>), dim3(tgrid), dim3(256), 0, s, rows, Ap, Aj, rpb, kRunCap, count, count3, totals, (const int *)nullptr, (uint32_t *)nullptr);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(host_totals, totals, sizeof(host_totals), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e == hipSuccess && (cap_env == 3 || (cap_env != 4 && (double)host_totals[1] <= 1.03 * (double)host_totals[0]))) {
-        cap = 3;
-        hipLaunchKernelGGL(runs_count_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, s, rows, Ap, Aj, 3, count, (unsigned long long *)nullptr);
-        e = hipGetLastError();
-    }
+    if (e == hipSuccess && (cap_env == 3 || (cap_env != 4 && (double)host_totals[1] <= 1.03 * (double)host_totals[0]))) cap = 3;
     if (totals) (void)hipFree(totals);
+    int *chosen = cap == 3 ? count3 : count; // the per-row counts that are scanned, in place, into piece offsets
     int st = e == hipSuccess ? (int)CMI_SUCCESS : hip_fail(e, "cmi_plan_create: run-compressed columns");
-    if (st == CMI_SUCCESS) st = device_exclusive_scan(count, count, (size_t)rows + 1, s); // in place: count[r] <- pieces before row r
-    int total = 0;
-    if (st == CMI_SUCCESS) {
-        e = hipMemcpy(&total, count + rows, sizeof(int), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) st = hip_fail(e, "cmi_plan_create: run-compressed columns");
-    }
+    if (st == CMI_SUCCESS) st = device_exclusive_scan(chosen, chosen, (size_t)rows + 1, s); // chosen[r] <- pieces before row r
+    const int total = (int)(cap == 3 ? host_totals[1] : host_totals[0]); // (= chosen[rows]: the totals were summed by the same walk)
     uint32_t *pieces = nullptr;
     int32_t *start = nullptr;
     const int64_t tiles = nnz / q + 1;
@@ -231,8 +240,8 @@ int csr_runs_build(cmi_plan *p, const int *Ap, const int *Aj, int v, double min_
         if (e == hipSuccess) e = hipMemsetAsync(pieces + total, 0, 64 * sizeof(uint32_t), s);
         if (e == hipSuccess) e = hipMalloc((void **)&start, (size_t)(tiles + 1) * 4 * sizeof(int32_t));
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(runs_fill_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, s, rows, Ap, Aj, count, cap, pieces);
-            hipLaunchKernelGGL(runs_partition_kernel, dim3((unsigned)ceil_div(rows + 1, 256)), dim3(256), 0, s, rows, Ap, count, q, tiles, start);
+            hipLaunchKernelGGL((runs_tile_kernel<true>), dim3(tgrid), dim3(256), 0, s, rows, Ap, Aj, rpb, cap, (int *)nullptr, (int *)nullptr, (unsigned long long *)nullptr, (const int *)chosen, pieces);
+            hipLaunchKernelGGL(runs_partition_kernel, dim3((unsigned)ceil_div(rows + 1, 256)), dim3(256), 0, s, rows, Ap, (const int *)chosen, q, tiles, start);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(s);
