@@ -163,6 +163,7 @@ def _declare(L):
     L.cmi_plan_validate.argtypes = [vp, vp, vp, vp, POINTER(c_int)]
     L.cmi_plan_info.argtypes = [vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int), POINTER(c_int)]
     L.cmi_plan_create_csr.argtypes = [c_int, i64, i64, i64, vp, vp, cfgp, vp, POINTER(c_void_p)]
+    L.cmi_plan_create_coo.argtypes = [c_int, i64, i64, i64, vp, vp, cfgp, vp, POINTER(c_void_p)]
     L.cmi_plan_create_csr_values.argtypes = [c_int, i64, i64, i64, vp, vp, vp, cfgp, vp, POINTER(c_void_p)]
     L.cmi_plan_validate_values.argtypes = [vp, vp, vp, POINTER(c_int)]
     L.cmi_plan_device_bytes.argtypes = [vp, POINTER(c_int64)]
@@ -308,6 +309,23 @@ class Plan:
         code = F64 if dtype in (F64, torch.float64) else F32
         check(lib().cmi_plan_create_csr(code, num_rows, num_cols, Aj.numel(), _ptr(Ap), _ptr(Aj), _cfg(cfg), _stream(stream), byref(self._h)))
         self.format, self.dtype = FORMAT_CSR, code
+        self.num_rows, self.num_cols, self.num_entries = num_rows, num_cols, Aj.numel()
+        return self
+
+    @classmethod
+    def coo(cls, dtype, num_rows, num_cols, Ai, Aj, cfg=None, stream=None):
+        """cmi_plan_create_coo: a COO plan made from both index arrays -- sorted entries get a CSR sub-plan made with the columns (the
+        run-compressed copy where the columns come in runs)."""
+        import torch
+        self = cls.__new__(cls)
+        self._h = c_void_p()
+        _need(Ai, "Ai", torch.int32)
+        _need(Aj, "Aj", torch.int32)
+        if Ai.numel() != Aj.numel():
+            raise ValueError("Plan.coo: row and column indices must have the same length")
+        code = F64 if dtype in (F64, torch.float64) else F32
+        check(lib().cmi_plan_create_coo(code, num_rows, num_cols, Aj.numel(), _ptr(Ai), _ptr(Aj), _cfg(cfg), _stream(stream), byref(self._h)))
+        self.format, self.dtype = FORMAT_COO, code
         self.num_rows, self.num_cols, self.num_entries = num_rows, num_cols, Aj.numel()
         return self
 

@@ -297,6 +297,16 @@ CMI_API int cmi_plan_create_csr(int dtype, int64_t num_rows, int64_t num_cols, i
     return plan_create(CMI_FORMAT_CSR, dtype, num_rows, num_cols, num_entries, row_offsets, column_indices, cfg, stream, plan_out);
 }
 
+// COO with both index arrays: cmi_plan_create(CMI_FORMAT_COO, ...) plus, for ROW-SORTED entries, a CSR sub-plan made WITH the columns -- an FEM /
+// KKT matrix held in COO then multiplies from the run-compressed column copy too (the reference's benchmark converts one matrix into every
+// format, performance/spmv/spmv.cu:41-66: its COO line of such a matrix is this path).
+CMI_API int cmi_plan_create_coo(int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *row_indices,
+                                const int32_t *column_indices, const cmi_config *cfg, void *stream, cmi_plan **plan_out)
+{
+    if (num_entries > 0 && !column_indices) return fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create_coo: null column indices");
+    return plan_create(CMI_FORMAT_COO, dtype, num_rows, num_cols, num_entries, row_indices, column_indices, cfg, stream, plan_out);
+}
+
 // CSR with the structure arrays AND the values: cmi_plan_create_csr plus -- asked for by cfg->kernel == CMI_CSR_STREAM_PACKED -- the packed
 // per-tile copy of pieces and values (spmv_csr_runs.hip).  The values of any other plan stay the caller's.
 CMI_API int cmi_plan_create_csr_values(int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *row_offsets,
@@ -585,7 +595,7 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
                 int sorted2 = 0;
                 if (st == CMI_SUCCESS) st = cmi_coo_row_offsets(num_rows, num_entries, index_array, p->coo_offsets, &sorted2, stream);
                 if (st == CMI_SUCCESS && sorted2)
-                    st = plan_create(CMI_FORMAT_CSR, dtype, num_rows, num_cols, num_entries, p->coo_offsets, nullptr, nullptr, stream, &p->coo_csr_plan);
+                    st = plan_create(CMI_FORMAT_CSR, dtype, num_rows, num_cols, num_entries, p->coo_offsets, csr_columns /* cmi_plan_create_coo: the CSR plan may then hold the run-compressed copy */, nullptr, stream, &p->coo_csr_plan);
                 if (st == CMI_SUCCESS && p->coo_csr_plan) p->cfg = p->coo_csr_plan->cfg; // what cmi_plan_config reports: the kernel that runs
             }
             // an explicit CMI_COO_TILE on unsorted entries would add rows up wrongly: refuse it here, where it is known
@@ -599,6 +609,10 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
     if (st == CMI_SUCCESS && (p->runs_packed || p->csr16_packed) && csr_values) {
         st = fingerprint(num_entries * (dtype == CMI_F64 ? 2 : 1), reinterpret_cast<const int *>(csr_values), s, &p->fp_values);
         p->has_fp_values = st == CMI_SUCCESS;
+    }
+    if (st == CMI_SUCCESS && p->coo_csr_plan && p->coo_csr_plan->has_fp_columns) { // (a COO plan made with the columns: its CSR sub-plan's copy is what cmi_plan_validate guards)
+        p->fp_columns = p->coo_csr_plan->fp_columns;
+        p->has_fp_columns = true;
     }
     if (st == CMI_SUCCESS && (p->csr16_cols || p->runs_pieces || p->csr16_packed) && csr_columns) {
         st = fingerprint(num_entries, csr_columns, s, &p->fp_columns);

@@ -61,7 +61,9 @@ struct plan_slot {
                 cmi_config want = {};
                 want.kernel = CMI_CSR_STREAM_C16;
                 check(cmi_plan_create_csr(dtype, (int64_t)r, (int64_t)c, (int64_t)n, index, columns, compress == 1 ? &want : nullptr, stream, &p));
-            } else
+            } else if (format == CMI_FORMAT_COO && columns) // (round 4: the sorted-COO plan's CSR sub-plan made with the columns too)
+                check(cmi_plan_create_coo(dtype, (int64_t)r, (int64_t)c, (int64_t)n, index, columns, nullptr, stream, &p));
+            else
                 check(cmi_plan_create(format, dtype, (int64_t)r, (int64_t)c, (int64_t)n, index, nullptr, stream, &p));
             plan.reset(p, [](cmi_plan *q) { cmi_plan_destroy(q); });
             index_ptr = index; columns_ptr = columns; rows = r; cols = c; entries = n;
@@ -228,7 +230,7 @@ public:
     const cmi_plan *plan(void *stream = nullptr) const
     {
         return plan_.get(CMI_FORMAT_COO, detail::dtype_code<ValueType>::value, this->num_rows, this->num_cols, this->num_entries,
-                         reinterpret_cast<const int *>(row_indices.data()), stream);
+                         reinterpret_cast<const int *>(row_indices.data()), stream, reinterpret_cast<const int *>(column_indices.data()));
     }
     void invalidate_plan() const { plan_.reset(); }
 

@@ -83,7 +83,16 @@ class CooMatrix(_Planned):
     format = "coo"
 
     def plan(self, stream=None, create=True):
-        return self._plan_for(B.FORMAT_COO, self.row_indices, stream, create)
+        # made from BOTH index arrays (cmi_plan_create_coo, round 4): sorted entries get a CSR sub-plan that may hold a copy derived from
+        # the columns (the run-compressed pieces), so the key carries both arrays' in-place versions
+        key = (self.row_indices.data_ptr(), self.row_indices._version, self.column_indices.data_ptr(), self.column_indices._version,
+               self.num_rows, self.num_cols, self.num_entries, self.values.dtype)
+        if self._plan_key != key:
+            if not create:
+                return None
+            self._plan = B.Plan.coo(self.values.dtype, self.num_rows, self.num_cols, self.row_indices, self.column_indices, None, stream)
+            self._plan_key = key
+        return self._plan
 
     # reference cusp/coo_matrix.h:208-224 (device_memory: cmi_coo_sort_by_row_*, stable; the plan is keyed on the row
     # indices' in-place version, which the sort bumps below)

@@ -333,6 +333,11 @@ int cmi_plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols, i
 /* cmi_set_index_compression(1) (initial value: $CMI_COMPRESS_INDICES).  cmi_plan_config tells whether it was granted.      */
 int cmi_plan_create_csr(int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *row_offsets,
                         const int32_t *column_indices, const cmi_config *cfg, void *stream, cmi_plan **plan);
+/* COO with both index arrays (round 4): cmi_plan_create(CMI_FORMAT_COO, ...) whose CSR sub-plan -- row-sorted entries -- is made WITH   */
+/* the columns, so that a matrix whose columns come in runs multiplies from the run-compressed copy (CMI_CSR_STREAM_WAVER) in COO too.  */
+/* cmi_plan_validate then wants both arrays.  Replaces the per-call temporaries of coo_flat_spmv.h:387-463 like cmi_plan_create does.    */
+int cmi_plan_create_coo(int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *row_indices,
+                        const int32_t *column_indices, const cmi_config *cfg, void *stream, cmi_plan **plan);
 /* ... and with the VALUES (device pointer, `dtype` elements): what cmi_plan_create_csr does, plus -- asked for by                    */
 /* cfg->kernel == CMI_CSR_STREAM_PACKED -- the packed per-tile copy of pieces and values.  Any other config: the values are ignored.  */
 int cmi_plan_create_csr_values(int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries, const int32_t *row_offsets,

@@ -128,6 +128,20 @@ def test_csr_every_path_against_the_oracle(cmi, torch_cuda, orc, shape):
             y = fresh()
             cmi.spmv_csr_plan(plan, A.row_offsets, A.column_indices, A.values, dx, y, accumulate=accumulate)
             check(y.cpu().numpy(), want, bound, dtype, bool(plan.info()["storage_order_sums"]), name + ": " + what)
+        # round 4: the run-compressed column copy (pieces of consecutive columns: "fem" has long runs, every other profile runs of ~1 --
+        # more pieces than the unrolled pass holds) and its packed twin, which also copies the values
+        if cols >= 4:
+            for name, make in (("waver4", lambda: cmi.Plan.csr(dx.dtype, rows, cols, A.row_offsets, A.column_indices, cfg=cmi.Config(kernel=cmi.CSR_STREAM_WAVER, items_per_thread=4))),
+                               ("waver1/cap3", lambda: cmi.Plan.csr(dx.dtype, rows, cols, A.row_offsets, A.column_indices, cfg=cmi.Config(kernel=cmi.CSR_STREAM_WAVER, items_per_thread=1, threads_per_row=3))),
+                               ("packed2", lambda: cmi.Plan.csr_values(rows, cols, A.row_offsets, A.column_indices, A.values, cfg=cmi.Config(kernel=cmi.CSR_STREAM_PACKED, items_per_thread=2)))):
+                try:
+                    plan = make()
+                except Exception:  # noqa: BLE001  (a row longer than half a wave tile, or a row of 512+: refused by name)
+                    continue
+                y = fresh()
+                cmi.spmv_csr_plan(plan, A.row_offsets, A.column_indices, A.values, dx, y, accumulate=accumulate)
+                check(y.cpu().numpy(), want, bound, dtype, bool(plan.info()["storage_order_sums"]), name + ": " + what)
+                assert plan.info()["storage_order_sums"] or plan.config().kernel not in (cmi.CSR_STREAM_WAVER,), name
 
 
 @settings(**SETTINGS)

@@ -239,6 +239,26 @@ def test_configs3_full_size_run_compressed(cmi, torch_cuda, orc, name):
     y.fill_(10.0)
     cmi.multiply(A, dx, y)
     assert np.array_equal(y.cpu().numpy(), want)
+    # the same matrix held in COO (row-sorted, what every conversion produces): the container's plan is made from BOTH index arrays
+    # (cmi_plan_create_coo) and its CSR sub-plan takes the run-compressed copy too
+    import ctypes
+    dAi = torch.empty(nnz, dtype=torch.int32, device="cuda")
+    cmi.check(cmi.lib().cmi_csr_row_indices(rows, ctypes.c_void_p(dAp.data_ptr()), ctypes.c_void_p(dAi.data_ptr()), None))
+    C = cmi.CooMatrix(rows, cols, nnz, dAi, dAj, dAx)
+    y.fill_(10.0)
+    cmi.multiply(C, dx, y)
+    assert np.array_equal(y.cpu().numpy(), want), (name, "coo", C.plan().config())
+    if name in ("ldoor", "nlpkkt120") and source.startswith("seeded"):
+        assert C.plan().config().kernel == cmi.CSR_STREAM_WAVER, C.plan().config()
+        assert C.plan().validate(dAi, dAj) is True
+        with pytest.raises(cmi.CmiError):   # the plan owns a copy derived from the columns: validating it needs them
+            C.plan().validate(dAi)
+    plain = cmi.Plan(cmi.FORMAT_COO, torch.float64, rows, cols, nnz, dAi)   # (row indices only: the CSR kernels on row offsets, as in round 3)
+    assert plain.config().kernel != cmi.CSR_STREAM_WAVER
+    y.fill_(10.0)
+    cmi.spmv_coo_plan(plain, dAi, dAj, dAx, dx, y)
+    assert np.array_equal(y.cpu().numpy(), want), (name, "coo without the columns")
+    del C, dAi
     # f32 values of the same matrix: the AUTO plan takes the run-compressed copy too (ldoor, nlpkkt120), the host loop's f32 bits
     Ax32, x32 = Ax.astype(np.float32), x.astype(np.float32)
     want32 = orc.spmv_csr(Ap, Aj, Ax32, x32, omp=True)
