@@ -1022,6 +1022,75 @@ template <typename Space> void TestDevicePlanOptions()
 }
 DECLARE_SPACE_UNITTEST(TestDevicePlanOptions);
 
+// Round 4: a matrix whose columns come in runs of three (three degrees of freedom per node, 11.5 M entries): the device containers make their
+// plan WITH the column indices, and that plan multiplies from the run-compressed column copy (CMI_CSR_STREAM_WAVER) -- the host loop's bits
+// (reference arithmetic: cusp/system/detail/sequential/multiply/csr_spmv.h:42-74), for csr_matrix and for the same matrix held in coo_matrix;
+// values refreshed in place are seen by the next multiply (nothing of them is cached); CG runs its fused SpMV + dot through the same plan.
+template <typename Space> void TestRunCompressedPlanOfFemBlocks()
+{
+    if constexpr (std::is_same<Space, cusp::device_memory>::value) {
+        const size_t nodes = 160000, N = 3 * nodes;
+        cusp::csr_matrix<int, double, cusp::host_memory> Ah(N, N, 0);
+        std::vector<int> cols;
+        std::vector<double> vals;
+        const long nb[8] = {-401, -400, -399, -1, 0, 1, 400, 401}; // a node couples to itself and seven neighbours of a 400-wide mesh
+        for (size_t node = 0; node < nodes; node++)
+            for (int d = 0; d < 3; d++) {
+                Ah.row_offsets[3 * node + d] = (int)cols.size();
+                for (long o : nb) {
+                    const long other = (long)node + o;
+                    if (other < 0 || other >= (long)nodes) continue;
+                    for (int e = 0; e < 3; e++) {
+                        cols.push_back((int)(3 * other + e));
+                        vals.push_back(o == 0 && e == d ? 30.0 + double(node % 7) : -0.25 - double(((3 * node + d) + (size_t)(3 * other + e)) % 5) / 16.0); // symmetric in (row, column)
+                    }
+                }
+            }
+        Ah.row_offsets[N] = (int)cols.size();
+        Ah.resize(N, N, cols.size());
+        for (size_t k = 0; k < cols.size(); k++) { Ah.column_indices[k] = cols[k]; Ah.values[k] = vals[k]; }
+        ASSERT_EQUAL(Ah.num_entries > 10000000, true);
+        cusp::array1d<double, cusp::host_memory> xh(N), want(N, 10.0);
+        for (size_t i = 0; i < N; i++) xh[i] = double((i * 2654435761u) % 1000u) / 997.0 - 0.5;
+        cusp::multiply(Ah, xh, want);
+        cusp::csr_matrix<int, double, Space> A(Ah);
+        cusp::array1d<double, Space> x(xh), y(N, 10.0);
+        cmi_config c;
+        ASSERT_EQUAL(cmi_plan_config(A.plan(), &c), 0);
+        ASSERT_EQUAL(c.kernel, (int)CMI_CSR_STREAM_WAVER);
+        int64_t owned = 0;
+        ASSERT_EQUAL(cmi_plan_device_bytes(A.plan(), &owned), 0);
+        ASSERT_EQUAL(owned > (int64_t)(Ah.num_entries / 3) * 4 && owned < (int64_t)Ah.num_entries * 3, true); // ~ 4 bytes per piece of three
+        cusp::multiply(A, x, y);
+        cusp::array1d<double, cusp::host_memory> got(y);
+        for (size_t i = 0; i < N; i++) ASSERT_EQUAL(got[i], want[i]);
+        int valid = 0;
+        ASSERT_EQUAL(cmi_plan_validate(A.plan(), A.row_offsets.data(), A.column_indices.data(), nullptr, &valid), 0);
+        ASSERT_EQUAL(valid, 1);
+        // values refreshed IN PLACE: the same plan, the new values' result
+        cusp::blas::scal(A.values, 0.5);
+        for (size_t k = 0; k < Ah.num_entries; k++) Ah.values[k] *= 0.5;
+        cusp::multiply(Ah, xh, want);
+        cusp::multiply(A, x, y);
+        got = y;
+        for (size_t i = 0; i < N; i++) ASSERT_EQUAL(got[i], want[i]);
+        // the same matrix in COO: its plan's CSR sub-plan is made with the columns too
+        cusp::coo_matrix<int, double, Space> C(Ah);
+        ASSERT_EQUAL(cmi_plan_config(C.plan(), &c), 0);
+        ASSERT_EQUAL(c.kernel, (int)CMI_CSR_STREAM_WAVER);
+        cusp::array1d<double, Space> yc(N, 10.0);
+        cusp::multiply(C, x, yc);
+        got = yc;
+        for (size_t i = 0; i < N; i++) ASSERT_EQUAL(got[i], want[i]);
+        // the fused CG iteration through the same plan (diagonally dominant: converges)
+        cusp::array1d<double, Space> sol(N, 0.0), b(N, 1.0);
+        cusp::monitor<double> mon(b, 200, 1e-10);
+        cusp::krylov::cg(A, sol, b, mon);
+        ASSERT_EQUAL(mon.converged(), true);
+    }
+}
+DECLARE_SPACE_UNITTEST(TestRunCompressedPlanOfFemBlocks);
+
 // testing/cg.cu:11-44: cg(policy, ...) reaches a user overload by ADL; a policy without one solves
 template <class LinearOperator, class VectorType1, class VectorType2, class Monitor, class Preconditioner>
 void cg(my_system &system, const LinearOperator &, VectorType1 &, const VectorType2 &, Monitor &, Preconditioner &) { system.validate_dispatch(); }
