@@ -19,7 +19,7 @@ from .binding import (  # noqa: F401
     lib, lib_path, build, version, check,
     Plan, spmv_csr_plan, spmv_coo_plan, spmv_hyb_plan, set_index_compression, get_index_compression,
     spmv_csr, spmv_csr_dot, spmv_ell_dot, spmv_dia_dot, spmv_ell, spmv_dia, spmv_coo, spmv_hyb,
-    count_zeros, tuning_hyb_rule, tuning_set_hyb_rule, hyb_entries_per_row, HYB_RULE_REFERENCE, HYB_RULE_COST, HYB_RULE_COST2, tuning_hyb_light_speed, tuning_set_hyb_light_speed,
+    count_zeros, tuning_hyb_rule, tuning_set_hyb_rule, hyb_entries_per_row, HYB_RULE_REFERENCE, HYB_RULE_COST, HYB_RULE_COST2, tuning_hyb_light_speed, tuning_set_hyb_light_speed, tuning_waver_rule, tuning_set_waver_rule, WaverRule,
     tuning_select, tuning_set, tuning_load, tuning_save, tuning_clear,
     poisson5pt_num_entries, poisson5pt_shard_entries, poisson5pt_csr, poisson5pt_dia,
     csr_to_ell, csr_to_hyb_coo, csr_row_indices, coo_row_offsets, coo_sort_by_row, coo_is_sorted, csr_interior_rows, ell_to_csr, dia_to_csr, hyb_to_csr, ell_row_lengths,

@@ -42,6 +42,20 @@ class Config(ctypes.Structure):
         return "Config(" + ", ".join(f"{k}={v}" for k, v in self.as_dict().items()) + ")"
 
 
+class WaverRule(ctypes.Structure):
+    """struct cmi_waver_rule: csr_waver's launch shape and AUTO gates (tuning table "waver_rule")."""
+    _fields_ = [
+        ("items_per_thread", c_int32), ("cap", c_int32), ("xcd_swizzle", c_int32), ("reserved", c_int32),
+        ("min_piece", c_double), ("min_entries", c_int64),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+    def __repr__(self):
+        return "WaverRule(" + ", ".join(f"{k}={v}" for k, v in self.as_dict().items()) + ")"
+
+
 def lib_path():
     return _LIB_PATH
 
@@ -154,6 +168,8 @@ def _declare(L):
     L.cmi_count_zeros_f32.argtypes = [i64, vp, POINTER(c_int64), vp]
     L.cmi_tuning_hyb_rule.argtypes = [c_int, POINTER(c_int), POINTER(c_double), POINTER(c_int64)]
     L.cmi_tuning_set_hyb_rule.argtypes = [c_int, c_int, c_double, i64]
+    L.cmi_tuning_waver_rule.argtypes = [c_int, POINTER(WaverRule)]
+    L.cmi_tuning_set_waver_rule.argtypes = [c_int, POINTER(WaverRule)]
     L.cmi_tuning_hyb_light_speed.argtypes = [c_int, POINTER(c_double)]
     L.cmi_tuning_set_hyb_light_speed.argtypes = [c_int, c_double]
     L.cmi_hyb_entries_per_row.argtypes = [c_int, i64, vp, c_int, c_double, i64, POINTER(c_int64), vp]
@@ -639,6 +655,20 @@ def tuning_hyb_rule(dtype):
     k, rs, th = c_int(), c_double(), c_int64()
     check(lib().cmi_tuning_hyb_rule(dtype, byref(k), byref(rs), byref(th)))
     return k.value, rs.value, th.value
+
+
+def tuning_waver_rule(dtype):
+    """csr_waver's launch shape and AUTO gates for F64 / F32 (cmi_waver_rule): the table's "waver_rule", else the built-in one."""
+    r = WaverRule()
+    check(lib().cmi_tuning_waver_rule(dtype, byref(r)))
+    return r
+
+
+def tuning_set_waver_rule(dtype, items_per_thread=4, cap=0, xcd_swizzle=16, min_piece=2.5, min_entries=None):
+    """layer a csr_waver rule on the table (tools/autotune_waver.py writes it; tuning_save persists it)"""
+    r = WaverRule(int(items_per_thread), int(cap), int(xcd_swizzle), 0, float(min_piece),
+                  int((10_000_000 if dtype == F64 else 5_000_000) if min_entries is None else min_entries))
+    check(lib().cmi_tuning_set_waver_rule(dtype, byref(r)))
 
 
 def tuning_hyb_light_speed(dtype):

@@ -54,6 +54,7 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 void select_config(int format, int dtype, int64_t num_rows, int64_t num_cols, int64_t num_entries,
                    const cmi_config *user, cmi_config *out);
 
+void waver_rule(int dtype, cmi_waver_rule *out); // tuning.hip: csr_waver's shape and AUTO gates (the table's "waver_rule", else the defaults)
 // row-length profile of a CSR matrix (spmv_csr.hip): longest row, entries sitting in rows of kLongRowMin or more
 struct row_profile { int64_t max_len = -1, in_long = 0; }; // max_len < 0: not measured
 int measure_row_lengths(int64_t rows, const int *Ap, hipStream_t s, int64_t *max_len, int64_t *entries_in_long_rows, int64_t *ends = nullptr); // ends: {Ap[0], Ap[rows]}

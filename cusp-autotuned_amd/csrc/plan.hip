@@ -221,7 +221,6 @@ static int wavev_vectors(int64_t rows, int64_t nnz, const row_profile &prof, boo
 // row.  AUTO plans made with the columns ($CMI_CSR_WAVER=0: never, =1: whenever the rows qualify): f64, at least 4096 rows of 8+ entries on
 // average, no row of 512+, 10 M+ entries (below: the partition's scalar hop is not hidden), and pieces of kWaverMinPiece+ entries on
 // average -- measured by building the copy, which is dropped again when they are shorter.
-constexpr double kWaverMinPiece = 2.5;
 static int waver_env()
 {
     static const int env = [] { const char *e = std::getenv("CMI_CSR_WAVER"); return e ? std::atoi(e) : -1; }();
@@ -233,7 +232,9 @@ static bool waver_try(cmi_plan *p, const int *Ap, const int *Aj, bool asked, int
     if (rows <= 0 || nnz <= 0 || p->prof.max_len < 1 || p->prof.in_long > 0 || p->cols < (p->dtype == CMI_F64 ? 2 : 4) || p->cols >= ((int64_t)1 << 30)) return false;
     // (f32, session 10 of round 4: ldoor-like 49.8 us against csr_stream's 70.9, nlpkkt120-like 101.3 against 156.8 -- the index stream is half of
     //  an f32 matrix's bytes, so compressing it pays more than for f64; same rule, profiles/r04_waver_f32_time.txt)
-    int v = asked_v ? asked_v : 4;
+    cmi_waver_rule rule; // the persisted shape / gates (tuning table "waver_rule": tools/autotune_waver.py), else the built-in ones
+    waver_rule(p->dtype, &rule);
+    int v = asked_v ? asked_v : rule.items_per_thread;
     if (v != 1 && v != 2 && v != 4) return false;
     while (v < 4 && !asked_v && 2 * (p->prof.max_len + 3) > 256 * v) v *= 2;
     if (2 * (p->prof.max_len + 3) > 256 * v) return false;
@@ -244,10 +245,10 @@ static bool waver_try(cmi_plan *p, const int *Ap, const int *Aj, bool asked, int
         // (size gate, profiles/r04_size_gates_scale_sweep.txt: at 10.8-10.9 M entries -- 130 MB of streams -- it takes 0.85-0.95 of the table
         //  kernel's time, at 5 M entries 1.13-1.22: smaller matrices keep csr_stream)
         //  f32 (r04_waver_f32_time.txt, f32 scale sweep): still 0.92 of the table kernel's time at 5.2 M entries -- gate at 5 M
-        if (waver_env() != 1 && (mean < 8.0 || nnz < (int64_t)(p->dtype == CMI_F64 ? 10000000 : 5000000))) return false;
+        if (waver_env() != 1 && (mean < 8.0 || nnz < rule.min_entries)) return false;
     }
     double mean_piece = 0.0;
-    *st = csr_runs_build(p, Ap, Aj, v, asked ? 0.0 : kWaverMinPiece, values, s, &mean_piece, asked ? asked_cap : 0);
+    *st = csr_runs_build(p, Ap, Aj, v, asked ? 0.0 : rule.min_piece, values, s, &mean_piece, asked && asked_cap ? asked_cap : rule.cap);
     if (*st != CMI_SUCCESS || !p->runs_start) return false;
     p->cfg.kernel = values ? CMI_CSR_STREAM_PACKED : CMI_CSR_STREAM_WAVER;
     p->cfg.block_size = 256;
@@ -255,7 +256,7 @@ static bool waver_try(cmi_plan *p, const int *Ap, const int *Aj, bool asked, int
     p->cfg.items_per_thread = v;
     p->cfg.threads_per_row = 0;
     p->cfg.nontemporal &= ~kPolStrided;
-    p->cfg.xcd_swizzle = 16; // chunks of 16 workgroups (64 wave tiles) per XCD: 0.99 of launch order's time on both configs[3] matrices, twice (profiles/r04_waver_xcd_dealing.txt)
+    p->cfg.xcd_swizzle = rule.xcd_swizzle; // (16: chunks of 16 workgroups = 64 wave tiles per XCD: 0.99 of launch order's time on both configs[3] matrices, twice, profiles/r04_waver_xcd_dealing.txt)
     if (!keep_policy) { // (a caller's policy bits are kept as given)
         if (nnz * (int64_t)(p->dtype == CMI_F64 ? 12 : 8) > kInfinityCacheBytes + kInfinityCacheBytes / 4) p->cfg.nontemporal |= kPolLoadNT;
         p->cfg.nontemporal |= kPolStoreNT;

@@ -1,4 +1,4 @@
-// spmv_csr_runs.hip -- CSR SpMV on the plan's RUN-COMPRESSED copy of the column indices (CMI_CSR_STREAM_WAVER, round 4; f64).
+// spmv_csr_runs.hip -- CSR SpMV on the plan's RUN-COMPRESSED copy of the column indices (CMI_CSR_STREAM_WAVER, round 4; f64 and f32).
 //
 // FEM and KKT matrices store their columns in short consecutive runs -- three degrees of freedom per node give runs of 3, 6, 9 ...; a
 // 27-point coupling is nine runs of 3 (measured on the configs[3] stand-ins, profiles/r04_column_runs.txt: ldoor-like 5.9 entries per
@@ -9,7 +9,8 @@
 //     piece[q]  = (first column << 2) | (length - 1)                         4 bytes per piece = 1.25-1.4 bytes per entry on those matrices
 //     start[t]  = {first row, first entry, first piece} of wave tile t       16 bytes per tile of ~950 entries
 // and the multiply reads those instead of Aj: the index stream shrinks to a third, and a piece's x values arrive with TWO 16-byte loads
-// per piece (x[c], x[c+1] and x[c+len-2], x[c+len-1]: branch-free for every length) instead of one 8-byte gather per entry.
+// per piece (x[c], x[c+1] and x[c+len-2], x[c+len-1]: branch-free for every length; f32: ONE load of x[c .. c+3]) instead of one gather
+// per entry.
 // The VALUES stay the caller's array (a caller may refresh values in place; nothing of them is cached) and are streamed exactly as
 // csr_wavev streams them: (double2) pairs, every line requested once.  The x values of a piece meet the values of its entries in the
 // wave's LDS region: pieces -> x values written at their entries' slots -> each lane multiplies its own value pairs in place -> the lanes

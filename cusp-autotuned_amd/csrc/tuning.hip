@@ -31,7 +31,22 @@ struct Table {
     double hyb_relative_speed[2];
     long hyb_threshold[2];
     double hyb_light_speed[2]; // CMI_HYB_RULE_COST2: cost of a COO entry while the COO part is light (one-launch kernel)
+    // csr_waver's shape and AUTO gates per value type (cmi_tuning_waver_rule); not set: the built-in defaults below
+    bool waver_valid[2];
+    cmi_waver_rule waver[2];
 };
+// csr_waver without a table: what round 4 measured (tools/autotune_waver.py, profiles/r04_autotune_waver.txt and the files it cites)
+static cmi_waver_rule default_waver_rule(int dtype)
+{
+    cmi_waver_rule r;
+    r.items_per_thread = 4;
+    r.cap = 0;
+    r.xcd_swizzle = 16;
+    r.reserved = 0;
+    r.min_piece = 2.5;
+    r.min_entries = dtype == CMI_F64 ? 10000000 : 5000000;
+    return r;
+}
 constexpr double kRefRelativeSpeed = 3.0; // reference csr_to_other.h:248-254
 constexpr long kRefBreakeven = 4096;
 
@@ -232,6 +247,31 @@ static int load_file(const char *path)
             }
         }
     }
+    // "waver_rule": {"f64": {"items_per_thread": 4, "cap": 0, "xcd_swizzle": 16, "min_piece": 2.5, "min_entries": 10000000}, "f32": {...}}
+    size_t wr = s.find("\"waver_rule\"");
+    if (wr != std::string::npos) {
+        const size_t wend = s.find("\"entries\"", wr);
+        for (int di = 0; di < 2; di++) {
+            size_t k = s.find(std::string("\"") + kDtypeNames[di] + "\"", wr);
+            if (k != std::string::npos && wend != std::string::npos && k > wend) k = std::string::npos;
+            const size_t a = k == std::string::npos ? k : s.find('{', k);
+            const size_t b = a == std::string::npos ? a : s.find('}', a);
+            if (b == std::string::npos) continue;
+            const std::string obj = s.substr(a, b - a + 1);
+            long v = 0, cap = 0, swz = 0, me = 0;
+            double mp = 0.0;
+            if (find_int(obj, "items_per_thread", &v) && (v == 1 || v == 2 || v == 4) && find_double(obj, "min_piece", &mp) && mp >= 1.0 && find_int(obj, "min_entries", &me) && me >= 0) {
+                cmi_waver_rule r = default_waver_rule(di);
+                r.items_per_thread = (int)v;
+                if (find_int(obj, "cap", &cap) && (cap == 0 || cap == 3 || cap == 4)) r.cap = (int)cap;
+                if (find_int(obj, "xcd_swizzle", &swz) && swz >= 0) r.xcd_swizzle = (int)swz;
+                r.min_piece = mp;
+                r.min_entries = me;
+                g_table.waver[di] = r;
+                g_table.waver_valid[di] = true;
+            }
+        }
+    }
     size_t p = s.find("\"entries\"");
     if (p == std::string::npos) { set_error("cmi_tuning_load: %s has no \"entries\"", path); return CMI_ERROR_IO; }
     p = s.find('[', p);
@@ -390,6 +430,18 @@ CMI_API int cmi_tuning_save(const char *path)
             }
         std::fprintf(f, "},\n");
     }
+    if (g_table.waver_valid[0] || g_table.waver_valid[1]) {
+        std::fprintf(f, "  \"waver_rule\": {");
+        bool first_rule = true;
+        for (int di = 0; di < 2; di++)
+            if (g_table.waver_valid[di]) {
+                const cmi_waver_rule &r = g_table.waver[di];
+                std::fprintf(f, "%s\"%s\": {\"items_per_thread\": %d, \"cap\": %d, \"xcd_swizzle\": %d, \"min_piece\": %.3f, \"min_entries\": %lld}", first_rule ? "" : ", ",
+                             kDtypeNames[di], r.items_per_thread, r.cap, r.xcd_swizzle, r.min_piece, (long long)r.min_entries);
+                first_rule = false;
+            }
+        std::fprintf(f, "},\n");
+    }
     std::fprintf(f, "  \"entries\": [\n");
     bool first = true;
     for (int fi = 0; fi < CMI_TABLE_KEYS; fi++)
@@ -465,6 +517,33 @@ CMI_API int cmi_tuning_set_hyb_rule(int dtype, int kind, double relative_speed, 
 
 // the fourth parameter of CMI_HYB_RULE_COST2 (ignored by the other kinds): cost of a COO entry, in ELL slots, while the COO part is
 // light enough for the one-launch kernel
+// csr_waver's launch shape and AUTO gates (plan.hip waver_try): the table's rule, else the built-in defaults
+namespace cmi {
+void waver_rule(int dtype, cmi_waver_rule *out)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ensure_default_loaded();
+    *out = g_table.waver_valid[dtype] ? g_table.waver[dtype] : default_waver_rule(dtype);
+}
+} // namespace cmi
+CMI_API int cmi_tuning_waver_rule(int dtype, cmi_waver_rule *rule)
+{
+    if (dtype < 0 || dtype > 1 || !rule) return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_waver_rule: bad argument");
+    cmi::waver_rule(dtype, rule);
+    return CMI_SUCCESS;
+}
+CMI_API int cmi_tuning_set_waver_rule(int dtype, const cmi_waver_rule *rule)
+{
+    if (dtype < 0 || dtype > 1 || !rule || (rule->items_per_thread != 1 && rule->items_per_thread != 2 && rule->items_per_thread != 4) ||
+        (rule->cap != 0 && rule->cap != 3 && rule->cap != 4) || rule->xcd_swizzle < 0 || !(rule->min_piece >= 1.0) || rule->min_entries < 0)
+        return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_set_waver_rule: items_per_thread 1 / 2 / 4, cap 0 / 3 / 4, xcd_swizzle >= 0, min_piece >= 1, min_entries >= 0");
+    std::lock_guard<std::mutex> lk(g_mu);
+    ensure_default_loaded();
+    g_table.waver[dtype] = *rule;
+    g_table.waver_valid[dtype] = true;
+    return CMI_SUCCESS;
+}
+
 CMI_API int cmi_tuning_hyb_light_speed(int dtype, double *light_speed)
 {
     if (dtype < 0 || dtype > 1 || !light_speed) return fail(CMI_ERROR_INVALID_VALUE, "cmi_tuning_hyb_light_speed: bad argument");

@@ -290,6 +290,23 @@ int cmi_tuning_set_hyb_rule(int dtype, int kind, double relative_speed, int64_t 
 int cmi_hyb_entries_per_row(int dtype, int64_t num_rows, const int32_t *Ap, int kind, double relative_speed,
                             int64_t threshold, int64_t *width_host, void *stream);
 
+/* The run-compressed column copy's launch shape and AUTO gates (CMI_CSR_STREAM_WAVER, round 4), tuned offline (tools/autotune_waver.py:
+ * items_per_thread x cap x xcd_swizzle swept on FEM / KKT matrices, every shape validated before it is timed) and persisted in the same
+ * table file as "waver_rule" -- what the KTT tuner's per-kernel parameter space (cuda/ktt/csr_multiply.h:239-247) becomes for this kernel.
+ * An AUTO plan made with the column indices takes the copy when the matrix has at least min_entries entries and its pieces of consecutive
+ * columns average at least min_piece entries; it then runs 256 x items_per_thread slots per wave tile, pieces cut at `cap` (0: 3 where that
+ * costs at most 3 % more pieces than 4), tiles dealt to the XCDs in chunks of xcd_swizzle workgroups (0: launch order).            */
+typedef struct cmi_waver_rule {
+    int32_t items_per_thread; /* 1, 2, 4 */
+    int32_t cap;              /* 0, 3, 4 */
+    int32_t xcd_swizzle;      /* >= 0 */
+    int32_t reserved;
+    double min_piece;         /* >= 1 */
+    int64_t min_entries;      /* >= 0 */
+} cmi_waver_rule;
+int cmi_tuning_waver_rule(int dtype, cmi_waver_rule *rule);           /* the table's rule, else the built-in one */
+int cmi_tuning_set_waver_rule(int dtype, const cmi_waver_rule *rule); /* layered on top of the shipped table; cmi_tuning_save writes it */
+
 /* ------------------------------------------------------------------------- */
 /* Plans (cmi_plan_create / destroy / select).        */
 /* A plan holds what the library learns about ONE matrix before its first      */

@@ -319,6 +319,33 @@ def test_hyb_rule_and_sorted_coo_key_in_the_table(cmi, tmp_path):
     cmi.tuning_clear()
 
 
+def test_waver_rule_in_the_table(cmi, tmp_path):
+    """csr_waver's shape and AUTO gates live in the table file ("waver_rule": tools/autotune_waver.py) -- the KTT tuner's per-kernel
+    parameter space (reference cuda/ktt/csr_multiply.h:239-247) settled offline; without one, the built-in rule."""
+    cmi.tuning_clear()
+    r = cmi.tuning_waver_rule(cmi.F64)
+    assert r.as_dict() == {"items_per_thread": 4, "cap": 0, "xcd_swizzle": 16, "min_piece": 2.5, "min_entries": 10_000_000}
+    assert cmi.tuning_waver_rule(cmi.F32).min_entries == 5_000_000
+    cmi.tuning_set_waver_rule(cmi.F32, items_per_thread=2, cap=3, xcd_swizzle=0, min_piece=3.0, min_entries=1234)
+    for bad in (dict(items_per_thread=3), dict(cap=2), dict(xcd_swizzle=-1), dict(min_piece=0.5), dict(min_entries=-1)):
+        with pytest.raises(cmi.CmiError):
+            cmi.tuning_set_waver_rule(cmi.F64, **bad)
+    path = str(tmp_path / "t.json")
+    cmi.tuning_save(path)
+    assert json.load(open(path))["waver_rule"] == {"f32": {"items_per_thread": 2, "cap": 3, "xcd_swizzle": 0, "min_piece": 3.0, "min_entries": 1234}}
+    cmi.tuning_clear()
+    assert cmi.tuning_waver_rule(cmi.F32).items_per_thread == 4
+    cmi.tuning_load(path)
+    assert cmi.tuning_waver_rule(cmi.F32).as_dict() == {"items_per_thread": 2, "cap": 3, "xcd_swizzle": 0, "min_piece": 3.0, "min_entries": 1234}
+    assert cmi.tuning_waver_rule(cmi.F64).as_dict()["items_per_thread"] == 4       # f64 not in the file: the built-in rule
+    # the shipped table carries the rule the sweep settled on (profiles/r04_autotune_waver.txt)
+    cmi.tuning_clear()
+    cmi.tuning_load(os.path.join(os.path.dirname(cmi.lib_path()), "..", "tuned", "gfx950.json"))
+    doc = json.load(open(os.path.join(os.path.dirname(cmi.lib_path()), "..", "tuned", "gfx950.json")))
+    for tag, code in (("f64", cmi.F64), ("f32", cmi.F32)):
+        assert cmi.tuning_waver_rule(code).as_dict() == doc["waver_rule"][tag]
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     """No CPU fallback: without the HIP library the binding raises at first use."""
     import cusp_autotuned_amd.binding as b

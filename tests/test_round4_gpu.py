@@ -476,3 +476,34 @@ def test_wave_tiles_that_overflow_take_further_passes(cmi, torch_cuda, orc, tag)
     y = torch.full((rows2,), 9.0, dtype=tdt, device="cuda")
     cmi.spmv_csr(rows2, rows2, dev(Ap2, torch), dev(Aj2, torch), dev(Ax2, torch), dev(x2, torch), y)   # NULL config, no plan
     assert np.array_equal(y.cpu().numpy(), orc.spmv_csr(Ap2, Aj2, Ax2, x2)), tag
+
+
+def test_the_tables_waver_rule_steers_the_auto_plan(cmi, torch_cuda, orc):
+    """The run-compressed copy's shape and size gate come from the tuning table ("waver_rule", tools/autotune_waver.py): a rule layered on
+    top changes what an AUTO plan made with the columns runs -- and never the bits (every shape is the storage-order sum)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import suitesparse_like as ssl
+    torch = torch_cuda
+    Ap, Aj, Ax = ssl.ldoor_like(0.3)       # ~14 M entries in blocks of 3 columns: over the shipped f64 gate
+    rows = len(Ap) - 1
+    x = np.random.default_rng(3).standard_normal(rows)
+    want = orc.spmv_csr(Ap, Aj, Ax, x)
+    dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+    shipped = cmi.tuning_waver_rule(cmi.F64).as_dict()
+    try:
+        seen = []
+        for rule in (shipped, dict(shipped, items_per_thread=2, cap=4, xcd_swizzle=0), dict(shipped, min_entries=int(Ap[-1]) + 1), dict(shipped, min_piece=3.5)):
+            cmi.tuning_set_waver_rule(cmi.F64, **rule)
+            plan = cmi.Plan.csr(torch.float64, rows, rows, dAp, dAj)
+            c = plan.config()
+            seen.append((c.kernel, c.items_per_thread, c.xcd_swizzle))
+            y = torch.full((rows,), 7.0, dtype=torch.float64, device="cuda")
+            cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
+            assert np.array_equal(y.cpu().numpy(), want), rule
+        assert seen[0] == (cmi.CSR_STREAM_WAVER, shipped["items_per_thread"], shipped["xcd_swizzle"])
+        assert seen[1] == (cmi.CSR_STREAM_WAVER, 2, 0)
+        assert seen[2][0] != cmi.CSR_STREAM_WAVER      # under the size gate
+        assert seen[3][0] != cmi.CSR_STREAM_WAVER      # pieces of 3 are shorter than the rule asks for
+    finally:
+        cmi.tuning_set_waver_rule(cmi.F64, **shipped)

@@ -163,3 +163,34 @@ for rep in range(5):
         assert all(torch.equal(a_, b_) for a_, b_ in zip(first, cur)), "device COO sort is not repeatable"
 assert torch.equal(first[0], C.row_indices)
 print("device COO sort: 5 x 50 M shuffled entries, identical results, rows as the sorted original's")
+
+# round 4: the run-compressed copy (f64 and f32) and the packed tiles -- thousands of launches, the result never changes; plans made and
+# destroyed in a loop (device memory owned by plans is returned)
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import suitesparse_like as ssl
+Ap, Aj, Ax = ssl.ldoor_like(0.5)
+rows_ = len(Ap) - 1
+dAp, dAj = torch.from_numpy(Ap).cuda(), torch.from_numpy(Aj).cuda()
+for dt in (torch.float64, torch.float32):
+    dAx = torch.from_numpy(Ax).cuda().to(dt)
+    xx = cmi.fill_x(rows_, dt, "cuda")
+    yy0, yy = torch.empty(rows_, dtype=dt, device="cuda"), torch.empty(rows_, dtype=dt, device="cuda")
+    cmi.spmv_csr(rows_, rows_, dAp, dAj, dAx, xx, yy0, cfg=cmi.Config(kernel=cmi.CSR_SCALAR))
+    for label, make in (("csr_waver (AUTO)", lambda: cmi.Plan.csr(dt, rows_, rows_, dAp, dAj)),
+                        ("packed tiles", lambda: cmi.Plan.csr_values(rows_, rows_, dAp, dAj, dAx, cmi.Config(kernel=cmi.CSR_STREAM_PACKED)))):
+        p = make()
+        bad = 0
+        for it in range(20):
+            for _ in range(200):
+                cmi.spmv_csr_plan(p, dAp, dAj, dAx, xx, yy)
+            bad += 0 if torch.equal(yy, yy0) else 1
+        free0 = torch.cuda.mem_get_info()[0]
+        for _ in range(30):
+            q = make()
+            cmi.spmv_csr_plan(q, dAp, dAj, dAx, xx, yy)
+            del q
+        torch.cuda.synchronize()
+        leaked = free0 - torch.cuda.mem_get_info()[0]
+        print(f"{label} {str(dt)[6:]}: kernel {p.config().kernel}, 4000 multiplies, mismatching checks {bad}; 30 plans made and destroyed: {leaked / 1e6:.1f} MB not returned")
+        del p
