@@ -218,9 +218,10 @@ static int wavev_vectors(int64_t rows, int64_t nnz, const row_profile &prof, boo
 }
 
 // csr_waver (CMI_CSR_STREAM_WAVER): wave tiles on the run-compressed column copy.  Asked for: built whenever the tile can hold the longest
-// row.  AUTO plans made with the columns ($CMI_CSR_WAVER=0: never, =1: whenever the rows qualify): f64, at least 4096 rows of 8+ entries on
-// average, no row of 512+, 10 M+ entries (below: the partition's scalar hop is not hidden), and pieces of kWaverMinPiece+ entries on
-// average -- measured by building the copy, which is dropped again when they are shorter.
+// row.  AUTO plans made with the columns ($CMI_CSR_WAVER=0: never, =1: whenever the rows qualify): at least 4096 rows of 8+ entries on
+// average, no row of 512+, and the tuning table's "waver_rule" (tools/autotune_waver.py; tuning.hip has the built-in copy): at least
+// min_entries entries (below: the partition's scalar hop is not hidden) and pieces of min_piece+ entries on average -- measured by
+// building the copy, which is dropped again when they are shorter.  The rule also holds the launch shape (slots per lane, cap, XCD dealing).
 static int waver_env()
 {
     static const int env = [] { const char *e = std::getenv("CMI_CSR_WAVER"); return e ? std::atoi(e) : -1; }();
