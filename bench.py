@@ -7,7 +7,7 @@
 
 A "step" = one pass of the hot path over one batch of synthetic input = one y = A*x with A, x, y resident in HBM:
 cmi.multiply(A, x, y) -> the matrix's plan (cmi_plan_create, once) -> cmi_spmv_csr_plan_f64 -> the kernel the plan chose
-(5-point rows: csr_wave).
+(5-point rows in f64 beyond the cache: wave tiles with the 16-byte-vector body, csr_wavev V = 1; r2-r4 until session 20: csr_wave).
 
 N = 1: BASELINE.json configs[1], poisson5pt 3162x3162 (9 998 244 rows, 49 978 572 entries), CSR,
        int32/f64, kernel + launch shape from the persisted tuning table.
@@ -139,17 +139,20 @@ def run_peer_probe(world):
     return False, f"probe exit {r.returncode}: {(r.stderr or r.stdout)[-200:]}"
 
 
-def pmc_traffic(kernel_substr):
+def pmc_traffic(kernel_substr, ran=None):
     """(HBM-side bytes per launch of the dominant kernel, source file) from the newest committed rocprofv3 --pmc summary
     that has this kernel (profiles/*pmc*.json, produced by tools/pmc_summary.py from separate --pmc passes over the same
     matrix and tuning-table config), or (None, None).  PMC collection needs the profiler around the process, so the
     figure is a committed measurement of this kernel, not one taken in this run: the line says so (`traffic_source`)."""
     pdir = os.path.join(ROOT, "profiles")
     # the SpMV kernel of each format (not the builders / converters that carry the format's name too)
-    names = {"csr": ("csr_wave_kernel", "csr_stream_kernel", "csr_balanced_kernel", "csr_vector_kernel", "csr_scalar_kernel"), "ell": ("ell_row_kernel",),
-             "dia": ("dia_row_kernel", "dia_row2_kernel"), "coo": ("csr_wave_kernel", "csr_stream_kernel", "csr_balanced_kernel"),  # sorted entries through a plan: the CSR kernels on the plan's row offsets
+    names = {"csr": ("csr_wavev_kernel", "csr_wave_kernel", "csr_stream_kernel", "csr_balanced_kernel", "csr_vector_kernel", "csr_scalar_kernel"), "ell": ("ell_row_kernel",),
+             "dia": ("dia_row_kernel", "dia_row2_kernel"), "coo": ("csr_wavev_kernel", "csr_wave_kernel", "csr_stream_kernel", "csr_balanced_kernel"),  # sorted entries through a plan: the CSR kernels on the plan's row offsets
              "coo_tile": ("coo_tile_kernel",), "hyb": ("hyb_tile_kernel",), "csr16": ("csr_wave16_kernel", "csr_stream16_kernel"),
              "csr16p": ("csr_wave16p_kernel",)}[kernel_substr]
+    if ran is not None:  # the CSR kernel the matrix's plan actually runs (cmi_config.kernel): a summary of ANOTHER csr kernel is not this one's traffic
+        by_enum = {1: "csr_scalar_kernel", 2: "csr_vector_kernel", 3: "csr_stream_kernel", 5: "csr_balanced_kernel", 7: "csr_wave_kernel", 8: "csr_wavev_kernel", 9: "csr_wavex_kernel", 11: "csr_waver_kernel"}
+        names = (by_enum[ran],) if ran in by_enum else names
     best, src = None, None
     if os.path.isdir(pdir):
         for f in sorted(os.listdir(pdir)):
@@ -782,7 +785,6 @@ def main():
     else:  # hyb: the ELL part's bytes (x and y once) + the COO part's three streams; one launch (the matrix's HYB plan)
         alg_bytes, kname = cmi.ell_bytes(local_rows, HYB_WIDTH, Afmt.ell.pitch) + 16 * Afmt.coo.num_entries, "hyb"
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(kname)
     cfg = cmi.tuning_select({"csr": 0, "ell": 1, "dia": 2, "coo": 3, "hyb": 1}[fmt], cmi.F64, local_rows, N_global,
                             local_nnz if fmt in ("csr", "coo") else local_rows * (HYB_WIDTH if fmt == "hyb" else 5))
     if world == 1 and fmt in ("csr", "coo"):  # what actually ran: the matrix's plan may have turned the table entry into another kernel
@@ -790,6 +792,7 @@ def main():
             cfg = Afmt.plan().config()
         except Exception:  # noqa: BLE001
             pass
+    traffic, traffic_src = pmc_traffic(kname, cfg.kernel if world == 1 and fmt in ("csr", "coo") else None)
     coo_tile = None
     if fmt == "coo" and world == 1:
         # what ran above: the matrix's plan found the entries sorted, built the row offsets they imply and multiplies with the CSR

@@ -17,7 +17,7 @@ namespace cmi {
 constexpr int kBlasBlock = 256;
 constexpr int kCgStorePolicy = 1; // x with the nt hint; see cg_store_policy() and the note in cg_update_kernel
 constexpr int kBlasMaxGrid = kCus * 8;   // reductions: 2048 partials
-constexpr int kFusedMaxGrid = kPartialCapacity;  // fused update+reduce kernels store too: near one-shot grids (65536 partials)
+constexpr int kFusedMaxGrid = 1 << 16;           // fused update+reduce kernels store too: near one-shot grids (65536 partials; the workspace holds kPartialCapacity)
 
 // reductions: a fixed, capped grid (one partial per workgroup, deterministic tree)
 static int blas_grid(int64_t n, int per_thread)
@@ -218,7 +218,7 @@ static void reduce_partials(int npartial, double *workspace, T *result, int take
 
 int reduce_partials_f64(int npartial, double *workspace, double *result, hipStream_t s)
 {
-    if (npartial > kFusedMaxGrid) return fail(CMI_ERROR_INVALID_VALUE, "reduce_partials: more partials than the workspace holds");
+    if (npartial > kPartialCapacity) return fail(CMI_ERROR_INVALID_VALUE, "reduce_partials: more partials than the workspace holds");
     reduce_partials<double>(npartial, workspace, result, 0, s);
     return CMI_SUCCESS;
 }

@@ -72,7 +72,7 @@ int ell_lanes_per_row(const cmi_config &c, int64_t rows, int64_t width);
 
 // Deterministic fold of `npartial` (<= kPartialCapacity) doubles at the start of a
 // cmi_blas_workspace_bytes() buffer into *result (blas1.hip; fixed tree, no atomics).
-constexpr int kPartialCapacity = 1 << 16;
+constexpr int kPartialCapacity = 1 << 17; // (r4: 2^16 -> 2^17, so that wave tiles of 1024 entries per workgroup keep the fused dot up to 134 M entries)
 constexpr int kFoldChunk = 1024;
 constexpr int kFoldedMax = kPartialCapacity / kFoldChunk;
 int reduce_partials_f64(int npartial, double *workspace, double *result, hipStream_t s);

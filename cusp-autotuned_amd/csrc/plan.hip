@@ -134,6 +134,21 @@ static bool wave_tiles_fit(int64_t rows, int64_t nnz, int64_t max_len)
     if (!wave_env() || rows <= 0 || max_len < 2 || max_len > kWaveTileMaxK) return false;
     return (double)nnz >= 0.93 * (double)max_len * (double)rows;
 }
+// Round 4 (the regret run, profiles/r04_auto_regret.txt, then the A/B of tools/stencil_tiles_probe.py, r04_stencil_tiles_ab.txt: one
+// process, plans interleaved, five rounds that agree to 0.3 %): on f64 stencil rows of 5-7 entries csr_wavev with V = 1 -- wave tiles of
+// 256 entries on a plan-built partition, the entry streams fetched as 16-byte vectors instead of csr_wave's lane-strided 4 + 8 bytes --
+// takes 0.954 of csr_wave's time replayed (headline matrix 113.8 against 119.4 us = 0.878 against 0.837 of peak; 7-point 215^3 163.4
+// against 171.2), 0.95-0.96 cold (125.9 against 130.9; 170.9 against 180.2) and 0.954 with the fused <y, w> of CG (123.1 against 129.0).
+// Not so: 3 per row (replay 0.99, cold 1.05, fused dot 1.09), f32 (1.01), a cache-resident matrix (1000^2: 13.7 against 13.3 us), and
+// rows of 9 (0.98 replayed, without the columns).  So: f64, the longest row 5..8, the streams beyond 1.25 x the Infinity Cache, and few
+// enough tiles for the fused dot's partial list (one per 1024 entries) -- otherwise csr_wave as before.  $CMI_CSR_WAVE_VEC=0: never.
+static bool stencil_vector_tiles(int64_t nnz, const row_profile &prof, int dtype, size_t vbytes)
+{
+    static const int env = [] { const char *e = std::getenv("CMI_CSR_WAVE_VEC"); return e ? std::atoi(e) : 1; }();
+    if (!env || dtype != CMI_F64 || prof.max_len < 5 || prof.max_len > 8 || prof.in_long > 0) return false;
+    if (nnz * (int64_t)(sizeof(int) + vbytes) <= kInfinityCacheBytes + kInfinityCacheBytes / 4) return false;
+    return nnz <= (int64_t)1024 * kPartialCapacity;
+}
 // ... and csr_wave on a plan-built partition (spmv_csr.hip wave_partition_build) for IRREGULAR short rows: K entries per lane with
 // K = floor(mean + longest / 64), so that a wave tile of Q = 64 K - longest entries holds about Q / mean <= 64 rows; the longest row
 // small enough for the tiles to fill 90 % of the wave's request slots.  OPT-IN: asked for per plan (cfg.kernel = CMI_CSR_STREAM_WAVE
@@ -483,7 +498,27 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
         // tiles (spmv_csr.hip csr_wave_kernel): 64 rows per wave, as many entries per lane as the longest row has, so every
         // tile fits and (mean within 7 % of the longest row) at least 93 % of the request lanes carry an entry.  Cache policy and
         // XCD dealing are the table's csr_stream entry's.  Not for a caller's explicit kernel, not over a granted 16-bit copy.
-        if (st == CMI_SUCCESS && auto_kernel && !want_wavev && !want_waver && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
+        if (st == CMI_SUCCESS && auto_kernel && !want_partition && !want_wavev && !want_waver && csr_columns && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
+            wave_tiles_fit(num_rows, num_entries, p->prof.max_len) && waver_try(p, index_array, csr_columns, false, 0, 0, false, nullptr, s, &st)) {
+            // stencil rows of 8+ entries whose columns come in runs (9-point: three runs of 3) and a plan made with the columns: the
+            // run-compressed copy, tried BEFORE csr_wave (waver_try's own gates: the table's rule; pieces shorter than it asks -> nothing
+            // is kept and csr_wave below runs).  9-point 3000^2: 143.9 us against csr_wave's 187.1 (f64), 89.8 against 134.0 (f32),
+            // profiles/r04_auto_regret.txt -- until then every stencil-like matrix took csr_wave unseen.
+        } else if (st == CMI_SUCCESS && auto_kernel && !want_partition && !want_wavev && !want_waver && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
+                   wave_tiles_fit(num_rows, num_entries, p->prof.max_len) && stencil_vector_tiles(num_entries, p->prof, dtype, vbytes)) {
+            // f64 stencil rows of 5..8 entries beyond the Infinity Cache: wave tiles of 256 entries on a plan-built partition (8 bytes per
+            // tile), entries fetched as 16-byte vectors (csr_wavev, V = 1) -- see stencil_vector_tiles above
+            st = wave_partition_build(p, index_array, 1, s, 256 - (int)p->prof.max_len - 3);
+            if (st == CMI_SUCCESS && p->wave_row_start) {
+                p->cfg.kernel = CMI_CSR_STREAM_WAVEV;
+                p->cfg.block_size = 256;
+                p->cfg.rows_per_block = 0;
+                p->cfg.items_per_thread = 1;
+                p->cfg.threads_per_row = 0;
+                p->cfg.nontemporal &= ~kPolStrided;
+                p->cfg.nontemporal |= kPolLoadNT | kPolStoreNT; // (beyond the cache by the rule: every line of the streams is requested once)
+            }
+        } else if (st == CMI_SUCCESS && auto_kernel && !want_wavev && !want_waver && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
             wave_tiles_fit(num_rows, num_entries, p->prof.max_len)) {
             p->cfg.kernel = CMI_CSR_STREAM_WAVE;
             p->cfg.block_size = 256;
@@ -533,11 +568,16 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
                     keep_stream = true; // columns scattered over the whole vector: 0.08-0.11 of peak whatever runs; wave tiles 0.97-1.06x
                 } else if (dtype == CMI_F32 && mean >= 16.0 && cp.jumps < 0.5) {
                     keep_stream = true; // f32 stencil / FEM-block rows of 16+ entries (or unknown columns): the table's csr_stream is 5-6 % faster
-                } else if (dtype == CMI_F64 && mean < 8.0 && cp.jumps >= 0.0 && cp.jumps < 0.5) {
-                    // V = 1 -- but only while the longest row still takes at most half of the smaller tile: with Q = 256 v - longest - 3
+                } else if (mean < 12.0 && cp.jumps >= 0.0 && cp.jumps < 0.5) {
+                    // short rows whose columns share x lines: smaller tiles.  f64 rows of fewer than 8 entries, none longer than 16: V = 1
+                    // (thermal2-like 20.4 / 63.4 us against 21.5 / 67.3 with V = 2); otherwise V = 2 -- against V = 4 (what every AUTO plan
+                    // ran until the regret run of round 4, profiles/r04_auto_regret.txt): uniform 1..16 per row 74.9 against 78.3 us (f64) and
+                    // 54.2 against 55.5 (f32), 4 / 40 per row 71.5 against 77.5 (V = 1: 78.6) and 44.9 against 46.3, thermal2-like x3 in f32
+                    // 38.5 against 40.0.  Columns anywhere in a band (jumps >= 0.6) without the x window keep V = 4 (217.5 against 234.0).
+                    // Either way only while the longest row still takes at most half of the smaller tile: with Q = 256 v - longest - 3
                     // entries per tile a few rows of 126-252 entries would leave Q = 127..1, i.e. up to one wave tile (8 bytes of plan
                     // memory, one wave) per handful of entries.  Widen back until the bound wavev_vectors() checked holds.
-                    v = 1;
+                    v = (dtype == CMI_F64 && mean < 8.0 && p->prof.max_len <= 16) ? 1 : 2;
                     while (v < 4 && 2 * (p->prof.max_len + 3) > 256 * v) v *= 2;
                 }
             }

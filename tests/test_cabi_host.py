@@ -166,8 +166,8 @@ def test_argument_validation_of_the_newer_entry_points(cmi):
     # an unknown CSR kernel id is an error, not a fallback
     cfg = cmi.Config(kernel=9)
     assert L.cmi_spmv_csr_f64(0, 0, 0, None, None, None, None, None, 0, ctypes.byref(cfg), None) == 0  # empty: nothing launched
-    # two fold areas: 65536 partials + 64 chunk sums + the ticket (padded) + 16 one-line copies of the folded scalar each
-    assert cmi.lib().cmi_blas_workspace_bytes() == 2 * (65536 + 64 + 2 + 16 * 16) * 8
+    # two fold areas: 131072 partials + 128 chunk sums + the ticket (padded) + 16 one-line copies of the folded scalar each
+    assert cmi.lib().cmi_blas_workspace_bytes() == 2 * (131072 + 128 + 2 + 16 * 16) * 8
     L.cmi_cg_update_fold_f64.argtypes = [i64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     cnt = ctypes.c_int(5)
     assert L.cmi_cg_update_fold_f64(-1, None, None, 1, None, None, None, ctypes.byref(cnt), None) == 1 and cnt.value == 0

@@ -507,3 +507,59 @@ def test_the_tables_waver_rule_steers_the_auto_plan(cmi, torch_cuda, orc):
         assert seen[3][0] != cmi.CSR_STREAM_WAVER      # pieces of 3 are shorter than the rule asks for
     finally:
         cmi.tuning_set_waver_rule(cmi.F64, **shipped)
+
+
+def test_stencil_rows_by_the_regret_runs_rules(cmi, torch_cuda, orc):
+    """What tools/auto_regret.py found and tools/stencil_tiles_probe.py confirmed (profiles/r04_auto_regret.txt, r04_stencil_tiles_ab.txt):
+    f64 stencil rows of 5..8 entries beyond the Infinity Cache run wave tiles of 256 entries with the 16-byte-vector body (csr_wavev,
+    V = 1) instead of csr_wave; f32 and small matrices keep csr_wave; stencil rows of 8+ entries whose columns come in runs (9-point) take
+    the run-compressed copy when the plan is made with the columns.  All bit-exact, plain, accumulating and through the fused dot."""
+    torch = torch_cuda
+    rng = np.random.default_rng(21)
+    # the headline matrix
+    m = 3162
+    A = cmi.poisson5pt(m, m, "csr")
+    N = A.num_rows
+    for plan in (cmi.Plan.csr(torch.float64, N, N, A.row_offsets, A.column_indices), cmi.Plan(cmi.FORMAT_CSR, torch.float64, N, N, A.num_entries, A.row_offsets)):
+        c = plan.config()
+        assert (c.kernel, c.items_per_thread, c.nontemporal & 3) == (cmi.CSR_STREAM_WAVEV, 1, 3), c    # (with or without the columns: the partition needs the offsets only)
+        assert plan.info()["storage_order_sums"] is True
+    Ap, Aj, Ax = (t.cpu().numpy() for t in (A.row_offsets, A.column_indices, A.values))
+    Ax = Ax * rng.standard_normal(len(Ax))
+    x, y0 = rng.standard_normal(N), rng.standard_normal(N)
+    want, want_acc = orc.spmv_csr(Ap, Aj, Ax, x), orc.spmv_csr(Ap, Aj, Ax, x, y0)
+    dAx, dx = dev(Ax, torch), dev(x, torch)
+    y = torch.full((N,), 3.0, dtype=torch.float64, device="cuda")
+    cmi.spmv_csr_plan(plan, A.row_offsets, A.column_indices, dAx, dx, y)
+    assert np.array_equal(y.cpu().numpy(), want)
+    y = dev(y0, torch)
+    cmi.spmv_csr_plan(plan, A.row_offsets, A.column_indices, dAx, dx, y, accumulate=True)
+    assert np.array_equal(y.cpu().numpy(), want_acc)
+    res = torch.zeros(1, dtype=torch.float64, device="cuda")
+    y = torch.zeros(N, dtype=torch.float64, device="cuda")
+    cmi.spmv_csr_dot(N, N, A.row_offsets, A.column_indices, dAx, dx, y, dx, res, cmi.blas_workspace(), plan=plan)
+    assert np.array_equal(y.cpu().numpy(), want)
+    assert abs(float(res) - float(np.dot(want, x))) <= 1e-12 * float(np.abs(want * x).sum())
+    # f32, and a matrix inside the cache: csr_wave as before
+    assert cmi.Plan.csr(torch.float32, N, N, A.row_offsets, A.column_indices).config().kernel == cmi.CSR_STREAM_WAVE
+    S = cmi.poisson5pt(1000, 1000, "csr")
+    assert cmi.Plan.csr(torch.float64, S.num_rows, S.num_rows, S.row_offsets, S.column_indices).config().kernel == cmi.CSR_STREAM_WAVE
+    del A, S, dAx, dx, y
+    torch.cuda.empty_cache()
+    # 9-point: three runs of 3 columns per row
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import autotune as at
+    for tag, tdt, ndt in (("f64", torch.float64, np.float64), ("f32", torch.float32, np.float32)):
+        Ap, Aj, Ax = at.stencil_csr(1200, 1200, 1, at.stencil_points(9), np.float64)      # 12.9 M entries: over both size gates
+        Ax = (Ax * rng.standard_normal(len(Ax))).astype(ndt)
+        N = len(Ap) - 1
+        x = rng.standard_normal(N).astype(ndt)
+        want = orc.spmv_csr(Ap, Aj, Ax, x)
+        dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+        plan = cmi.Plan.csr(tdt, N, N, dAp, dAj)
+        assert plan.config().kernel == cmi.CSR_STREAM_WAVER, (tag, plan.config())
+        assert cmi.Plan(cmi.FORMAT_CSR, tdt, N, N, len(Aj), dAp).config().kernel == cmi.CSR_STREAM_WAVE     # without the columns: as before
+        y = torch.full((N,), 3.0, dtype=tdt, device="cuda")
+        cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
+        assert np.array_equal(y.cpu().numpy(), want), tag

@@ -1256,7 +1256,7 @@ def test_spmv_csr_dot_every_variant(cmi, torch_cuda, golden_irregular):
 @pytest.mark.parametrize("case", ["folded", "over_capacity", "w_is_x"])
 def test_spmv_csr_dot_partial_list_lengths(cmi, torch_cuda, case):
     """Long per-tile partial lists take the middle fold stage (> 2048 tiles); more tiles than the
-    workspace holds (> 65536) fall back to SpMV + dot; w == x is the CG call."""
+    workspace holds (> 131072) fall back to SpMV + dot; w == x is the CG call."""
     torch = torch_cuda
     m = 700
     A = cmi.poisson5pt(m, m, "csr")
@@ -1264,7 +1264,7 @@ def test_spmv_csr_dot_partial_list_lengths(cmi, torch_cuda, case):
     x = cmi.fill_x(n).cuda()
     w = x if case == "w_is_x" else torch.from_numpy(np.random.default_rng(3).standard_normal(n)).cuda()
     cfg = {"folded": cmi.Config(kernel=cmi.CSR_STREAM, block_size=256, rows_per_block=64, nontemporal=2),      # 7657 tiles
-           "over_capacity": cmi.Config(kernel=cmi.CSR_STREAM, block_size=64, rows_per_block=4),                # 122500 tiles
+           "over_capacity": cmi.Config(kernel=cmi.CSR_STREAM, block_size=64, rows_per_block=2),                # 245000 tiles
            "w_is_x": None}[case]
     ws = cmi.blas_workspace()
     res = torch.zeros(1, dtype=torch.float64, device="cuda")
