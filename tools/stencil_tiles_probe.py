@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--launches", type=int, default=40)
     ap.add_argument("--cg-iterations", type=int, default=150)
+    ap.add_argument("--sweep", action="store_true")
     args = ap.parse_args()
     for key in args.matrices.split(","):
         name, build, dt = MATS[key]
@@ -80,6 +81,9 @@ def main():
         print(f"# {name}: rows {rows} entries {nnz}; algorithmic bytes {alg / 1e6:.1f} MB", flush=True)
         variants = [("AUTO plan", None), ("wave tiles V=1", cmi.Config(kernel=cmi.CSR_STREAM_WAVEV, items_per_thread=1)),
                     ("wave tiles V=2", cmi.Config(kernel=cmi.CSR_STREAM_WAVEV, items_per_thread=2))]
+        if args.sweep:  # the wave tiles' cache policy (1 = nt loads, 2 = nt stores) x XCD dealing (chunks of that many workgroups; -1: launch order)
+            variants = [("AUTO plan", None)] + [(f"wave tiles V=1 pol {pol} swz {swz}", cmi.Config(kernel=cmi.CSR_STREAM_WAVEV, items_per_thread=1, nontemporal=pol, xcd_swizzle=swz))
+                                                 for pol in (3, 1, 2) for swz in (-1, 8, 16, 32, 64, 128, 256)]
         if key.startswith("9pt"):
             variants += [("run-compressed copy V=2", cmi.Config(kernel=cmi.CSR_STREAM_WAVER, items_per_thread=2)),
                          ("run-compressed copy V=4", cmi.Config(kernel=cmi.CSR_STREAM_WAVER, items_per_thread=4))]
@@ -108,7 +112,8 @@ def main():
         cg_us = {}
         for label, p in plans.items():
             A = cmi.CsrMatrix(rows, rows, nnz, dAp, dAj, dAx)
-            A._plan = p
+            A.plan()      # (sets the container's plan key for these arrays) ...
+            A._plan = p   # ... and this is the plan its multiplies then run
             b = torch.ones(rows, dtype=dt, device="cuda")
             best = None
             for _ in range(3):
