@@ -171,7 +171,11 @@ typedef enum cmi_kernel {
                                length) int4 index vectors + value vectors per lane, parks the products in its own LDS region and adds
                                every row in storage order.  No workgroup barrier (csr_stream's waves sit at theirs for most of their
                                life on such rows: profiles/r03_long_rows_pmc_csr_stream.json), every wave owns rows.  Bit-exact.  Needs
-                               16-byte aligned Aj / Ax, no row of 512+ entries, longest row <= 128 x items_per_thread - 3.           */
+                               16-byte aligned Aj / Ax, no row of 512+ entries, longest row <= 128 x items_per_thread - 3.
+                               Round 4: with items_per_thread = 1 it is also what an AUTO plan runs on f64 STENCIL rows of 5..8 entries in a
+                               matrix beyond the Infinity Cache (the 5-point headline matrix: 0.95-0.96 of CMI_CSR_STREAM_WAVE's time replayed,
+                               cold and with the fused dot; profiles/r04_stencil_tiles_ab.txt; $CMI_CSR_WAVE_VEC=0: never) -- and V = 2 instead
+                               of 4 on irregular rows of fewer than 12 entries whose columns share x lines.                          */
     CMI_CSR_STREAM_WAVEX = 9, /* plans only (round 3): CMI_CSR_STREAM_WAVEV plus an x WINDOW in LDS -- the workgroup (four wave tiles) copies the
                                rows_per_block (0: 4096; the field carries the WINDOW LENGTH here, a multiple of 512 (f64) / 1024 (f32), at most
                                4096 / 8192) consecutive x entries around the diagonal position of its rows into LDS, coalesced, and gathers
@@ -185,7 +189,8 @@ typedef enum cmi_kernel {
                                (f64: 9.3-9.4 instead of 12 bytes per entry; f32: 5.3-5.4 instead of 8) and a piece's x values arrive with two
                                16-byte loads (f32: one) instead of one gather per entry.  The VALUES stay the caller's array (refreshing them in place is fine).  Same products,
                                storage-order sums: bit-exact.  An AUTO plan made with the columns selects it when the pieces average 2.5+
-                               entries on a matrix csr_wavev's size / row-length rule admits ($CMI_CSR_WAVER=0: never, =1: whenever the rows
+                               entries on a matrix the tuning table's "waver_rule" admits (cmi_tuning_waver_rule; also stencil rows of 8+ entries
+                               with column runs -- 9-point -- where it is tried before CMI_CSR_STREAM_WAVE) ($CMI_CSR_WAVER=0: never, =1: whenever the rows
                                qualify); asked for explicitly it is refused only where the tile cannot hold the longest row.  items_per_thread
                                1, 2, 4 (0: 4) = 256 x that many slots per wave tile; threads_per_row = entries per piece at most, 3 or 4
                                (0: 3 where that costs at most 3 % more pieces than 4 -- pieces of three leave no LDS bank conflict between
