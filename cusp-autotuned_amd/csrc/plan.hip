@@ -142,12 +142,16 @@ static bool wave_tiles_fit(int64_t rows, int64_t nnz, int64_t max_len)
 // Not so: 3 per row (replay 0.99, cold 1.05, fused dot 1.09), f32 (1.01), a cache-resident matrix (1000^2: 13.7 against 13.3 us), and
 // rows of 9 (0.98 replayed, without the columns).  So: f64, the longest row 5..8, the streams beyond 1.25 x the Infinity Cache, and few
 // enough tiles for the fused dot's partial list (one per 1024 entries) -- otherwise csr_wave as before.  $CMI_CSR_WAVE_VEC=0: never.
-static bool stencil_vector_tiles(int64_t nnz, const row_profile &prof, int dtype, size_t vbytes)
+// f32 (sessions 22 / 24 / 25, three boxes): V = 1 gains nothing (0.99-1.01, fused dot 1.06), V = 2 -- tiles of 512 entries -- takes
+// 0.971-0.981 of csr_wave's time replayed on the 5- and 7-point matrices, 0.96-1.00 cold, 0.98-1.00 with the fused dot: small, never a
+// loss, taken.  Returns the index vectors per lane (0: csr_wave stays).
+static int stencil_vector_tiles(int64_t nnz, const row_profile &prof, int dtype, size_t vbytes)
 {
     static const int env = [] { const char *e = std::getenv("CMI_CSR_WAVE_VEC"); return e ? std::atoi(e) : 1; }();
-    if (!env || dtype != CMI_F64 || prof.max_len < 5 || prof.max_len > 8 || prof.in_long > 0) return false;
-    if (nnz * (int64_t)(sizeof(int) + vbytes) <= kInfinityCacheBytes + kInfinityCacheBytes / 4) return false;
-    return nnz <= (int64_t)1024 * kPartialCapacity;
+    if (!env || prof.max_len < 5 || prof.max_len > 8 || prof.in_long > 0) return 0;
+    if (nnz * (int64_t)(sizeof(int) + vbytes) <= kInfinityCacheBytes + kInfinityCacheBytes / 4) return 0;
+    const int v = dtype == CMI_F64 ? 1 : 2;
+    return nnz <= (int64_t)1024 * v * kPartialCapacity ? v : 0;
 }
 // ... and csr_wave on a plan-built partition (spmv_csr.hip wave_partition_build) for IRREGULAR short rows: K entries per lane with
 // K = floor(mean + longest / 64), so that a wave tile of Q = 64 K - longest entries holds about Q / mean <= 64 rows; the longest row
@@ -505,15 +509,16 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
             // is kept and csr_wave below runs).  9-point 3000^2: 143.9 us against csr_wave's 187.1 (f64), 89.8 against 134.0 (f32),
             // profiles/r04_auto_regret.txt -- until then every stencil-like matrix took csr_wave unseen.
         } else if (st == CMI_SUCCESS && auto_kernel && !want_partition && !want_wavev && !want_waver && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
-                   wave_tiles_fit(num_rows, num_entries, p->prof.max_len) && stencil_vector_tiles(num_entries, p->prof, dtype, vbytes)) {
-            // f64 stencil rows of 5..8 entries beyond the Infinity Cache: wave tiles of 256 entries on a plan-built partition (8 bytes per
-            // tile), entries fetched as 16-byte vectors (csr_wavev, V = 1) -- see stencil_vector_tiles above
-            st = wave_partition_build(p, index_array, 1, s, 256 - (int)p->prof.max_len - 3);
+                   wave_tiles_fit(num_rows, num_entries, p->prof.max_len) && stencil_vector_tiles(num_entries, p->prof, dtype, vbytes) > 0) {
+            // stencil rows of 5..8 entries beyond the Infinity Cache: wave tiles of 256 (f64) / 512 (f32) entries on a plan-built partition
+            // (8 bytes per tile), entries fetched as 16-byte vectors (csr_wavev, V = 1 / 2) -- see stencil_vector_tiles above
+            const int sv = stencil_vector_tiles(num_entries, p->prof, dtype, vbytes);
+            st = wave_partition_build(p, index_array, sv, s, 256 * sv - (int)p->prof.max_len - 3);
             if (st == CMI_SUCCESS && p->wave_row_start) {
                 p->cfg.kernel = CMI_CSR_STREAM_WAVEV;
                 p->cfg.block_size = 256;
                 p->cfg.rows_per_block = 0;
-                p->cfg.items_per_thread = 1;
+                p->cfg.items_per_thread = sv;
                 p->cfg.threads_per_row = 0;
                 p->cfg.nontemporal &= ~kPolStrided;
                 p->cfg.nontemporal |= kPolLoadNT | kPolStoreNT; // (beyond the cache by the rule: every line of the streams is requested once)

@@ -172,7 +172,7 @@ typedef enum cmi_kernel {
                                every row in storage order.  No workgroup barrier (csr_stream's waves sit at theirs for most of their
                                life on such rows: profiles/r03_long_rows_pmc_csr_stream.json), every wave owns rows.  Bit-exact.  Needs
                                16-byte aligned Aj / Ax, no row of 512+ entries, longest row <= 128 x items_per_thread - 3.
-                               Round 4: with items_per_thread = 1 it is also what an AUTO plan runs on f64 STENCIL rows of 5..8 entries in a
+                               Round 4: with items_per_thread = 1 (f32: 2) it is also what an AUTO plan runs on STENCIL rows of 5..8 entries in a
                                matrix beyond the Infinity Cache (the 5-point headline matrix: 0.95-0.96 of CMI_CSR_STREAM_WAVE's time replayed,
                                cold and with the fused dot; profiles/r04_stencil_tiles_ab.txt; $CMI_CSR_WAVE_VEC=0: never) -- and V = 2 instead
                                of 4 on irregular rows of fewer than 12 entries whose columns share x lines.                          */

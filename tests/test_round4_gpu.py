@@ -512,7 +512,7 @@ def test_the_tables_waver_rule_steers_the_auto_plan(cmi, torch_cuda, orc):
 def test_stencil_rows_by_the_regret_runs_rules(cmi, torch_cuda, orc):
     """What tools/auto_regret.py found and tools/stencil_tiles_probe.py confirmed (profiles/r04_auto_regret.txt, r04_stencil_tiles_ab.txt):
     f64 stencil rows of 5..8 entries beyond the Infinity Cache run wave tiles of 256 entries with the 16-byte-vector body (csr_wavev,
-    V = 1) instead of csr_wave; f32 and small matrices keep csr_wave; stencil rows of 8+ entries whose columns come in runs (9-point) take
+    V = 1; f32: V = 2) instead of csr_wave; small matrices keep csr_wave; stencil rows of 8+ entries whose columns come in runs (9-point) take
     the run-compressed copy when the plan is made with the columns.  All bit-exact, plain, accumulating and through the fused dot."""
     torch = torch_cuda
     rng = np.random.default_rng(21)
@@ -540,8 +540,9 @@ def test_stencil_rows_by_the_regret_runs_rules(cmi, torch_cuda, orc):
     cmi.spmv_csr_dot(N, N, A.row_offsets, A.column_indices, dAx, dx, y, dx, res, cmi.blas_workspace(), plan=plan)
     assert np.array_equal(y.cpu().numpy(), want)
     assert abs(float(res) - float(np.dot(want, x))) <= 1e-12 * float(np.abs(want * x).sum())
-    # f32, and a matrix inside the cache: csr_wave as before
-    assert cmi.Plan.csr(torch.float32, N, N, A.row_offsets, A.column_indices).config().kernel == cmi.CSR_STREAM_WAVE
+    # f32: tiles of 512 entries (V = 2); a matrix inside the cache: csr_wave as before
+    c32 = cmi.Plan.csr(torch.float32, N, N, A.row_offsets, A.column_indices).config()
+    assert (c32.kernel, c32.items_per_thread) == (cmi.CSR_STREAM_WAVEV, 2), c32
     S = cmi.poisson5pt(1000, 1000, "csr")
     assert cmi.Plan.csr(torch.float64, S.num_rows, S.num_rows, S.row_offsets, S.column_indices).config().kernel == cmi.CSR_STREAM_WAVE
     del A, S, dAx, dx, y
