@@ -600,6 +600,9 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
                     if (num_entries * (int64_t)(sizeof(int) + vbytes) > kInfinityCacheBytes + kInfinityCacheBytes / 4) p->cfg.nontemporal |= kPolLoadNT;
                     p->cfg.nontemporal |= kPolStoreNT;
                 }
+                // ... and so is a caller's XCD dealing (< 0: launch order) -- select_config takes only block size and policy from an AUTO-kernel
+                // config, so until session 29 of round 4 an asked-for dealing was silently the table's (the "sweeps" of it measured nothing)
+                if (want_wavev && wavev_shape.xcd_swizzle != 0) p->cfg.xcd_swizzle = wavev_shape.xcd_swizzle < 0 ? 0 : wavev_shape.xcd_swizzle;
             }
         } else if (st == CMI_SUCCESS && want_wavev) {
             st = fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: CMI_CSR_STREAM_WAVEV needs items_per_thread 0, 1, 2 or 4, no row of 512+ entries and the longest row at most half of the 256 x items_per_thread slots of a wave tile");
