@@ -29,16 +29,13 @@ def matrices():
 
     def random_lens(rows, lo, hi, fix_mean=None):
         lens = rng.integers(lo, hi + 1, size=rows)
-        if fix_mean is not None:  # nudge single rows until the mean sits just below the integer
-            want = int(fix_mean * rows)
-            while lens.sum() > want:
-                i = rng.integers(0, rows)
-                if lens[i] > lo:
-                    lens[i] -= 1
-            while lens.sum() < want:
-                i = rng.integers(0, rows)
-                if lens[i] < hi:
-                    lens[i] += 1
+        if fix_mean is not None:  # nudge single rows (a random selection, all at once) until the mean sits just below the integer
+            diff = int(lens.sum()) - int(fix_mean * rows)
+            order = rng.permutation(rows)
+            if diff > 0:
+                lens[order[lens[order] > lo][:diff]] -= 1
+            elif diff < 0:
+                lens[order[lens[order] < hi][:-diff]] += 1
         Ap = np.r_[0, np.cumsum(lens)].astype(np.int32)
         ri = np.repeat(np.arange(rows, dtype=np.int64), lens)
         Aj = np.clip(ri + rng.integers(-40, 41, size=len(ri)), 0, rows - 1).astype(np.int32)
@@ -56,6 +53,12 @@ def matrices():
     yield "random lengths 1..13, mean 6.99", random_lens(2000000, 1, 13, 6.99)
     yield "random lengths 1..9, mean ~5.0 (also looks like one)", random_lens(3000000, 1, 9)
     yield "thermal2-like (rule: no)", ssl.GENERATORS["thermal2"](1.0)
+    # session 30 of round 4: matrices beyond the Infinity Cache too -- stencils, and look-alikes whose tiles need passes
+    g = 215
+    yield "7-point 215^3 (beyond the cache)", stencil([-g * g, -g, -1, 0, 1, g, g * g], g ** 3)
+    yield "random lengths 1..9, mean 4.99, 7 M rows (looks like a stencil, beyond the cache)", random_lens(7000000, 1, 9, 4.99)
+    yield "random lengths 4..6, mean 4.95, 7 M rows", random_lens(7000000, 4, 6, 4.95)
+    yield "random lengths 1..13, mean 6.99, 5 M rows (beyond the cache)", random_lens(5000000, 1, 13, 6.99)
 
 
 def child():
@@ -97,6 +100,7 @@ def child():
             cmi.check(lib.cmi_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
             ts.append(ms.value / 20 * 1e3)
         out[name] = {"us": float(np.median(ts)), "bit_exact": exact, "mean": nnz / rows, "alg_bytes": cmi.csr_bytes(rows, nnz)}
+        print(f"  {name}: {out[name]['us']:.1f} us", file=sys.stderr, flush=True)
         del dAp, dAj, dAx, x, y, want
         torch.cuda.empty_cache()
     print("RESULT " + json.dumps(out))
@@ -106,18 +110,22 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
         return child()
     res = {}
-    for setting in ("0", "1"):
-        env = dict(os.environ, CMI_PLANLESS_WAVE=setting)
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True, timeout=600)
+    # "0": the table's row-tile kernel; "1": + the csr_wave rule (what the library does); "2": was, in session 31 of round 4, a third setting --
+    # 16-byte-vector wave tiles on fixed row ranges for f64 stencil sizes beyond the cache -- tried and dropped
+    # (profiles/r04_planless_vector_tiles_not_kept.txt); the column is kept so that the table reads the same: it repeats setting "1"
+    for setting, extra in (("0", {"CMI_PLANLESS_WAVE": "0"}), ("1", {"CMI_PLANLESS_WAVE": "1"}), ("2", {"CMI_PLANLESS_WAVE": "1"})):
+        env = dict(os.environ, **extra)
+        print(f"# child: {extra}", flush=True)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, stdout=subprocess.PIPE, text=True, timeout=900)  # (stderr: progress, passed through)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
         if not line:
-            print(r.stdout[-2000:], r.stderr[-2000:])
-            raise SystemExit(f"child with CMI_PLANLESS_WAVE={setting} failed")
+            print(r.stdout[-2000:])
+            raise SystemExit(f"child with {extra} failed")
         res[setting] = json.loads(line[0][7:])
-    print(f"{'matrix':58s} {'mean':>6s} {'table (us)':>11s} {'rule (us)':>10s} {'ratio':>6s}  frac of 8 TB/s  bit-exact")
+    print(f"{'matrix':84s} {'mean':>6s} {'table (us)':>11s} {'csr_wave rule':>14s} {'(again)':>15s} {'ratio':>6s}  frac of 8 TB/s  bit-exact")
     for name in res["0"]:
-        a, b = res["0"][name], res["1"][name]
-        print(f"{name:58s} {a['mean']:6.2f} {a['us']:11.1f} {b['us']:10.1f} {b['us'] / a['us']:6.3f}  {a['alg_bytes'] / a['us'] / 8e6:.3f} -> {b['alg_bytes'] / b['us'] / 8e6:.3f}  {a['bit_exact'] and b['bit_exact']}")
+        a, b, c = res["0"][name], res["1"][name], res["2"][name]
+        print(f"{name:84s} {a['mean']:6.2f} {a['us']:11.1f} {b['us']:14.1f} {c['us']:15.1f} {c['us'] / a['us']:6.3f}  {a['alg_bytes'] / a['us'] / 8e6:.3f} -> {c['alg_bytes'] / c['us'] / 8e6:.3f}  {a['bit_exact'] and b['bit_exact'] and c['bit_exact']}")
 
 
 if __name__ == "__main__":
