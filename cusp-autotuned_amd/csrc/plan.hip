@@ -502,13 +502,26 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
         // tiles (spmv_csr.hip csr_wave_kernel): 64 rows per wave, as many entries per lane as the longest row has, so every
         // tile fits and (mean within 7 % of the longest row) at least 93 % of the request lanes carry an entry.  Cache policy and
         // XCD dealing are the table's csr_stream entry's.  Not for a caller's explicit kernel, not over a granted 16-bit copy.
+        // Equal short rows are a stencil's signature -- but only its columns make it one.  A plan made WITH the columns looks: where 75 %+ of
+        // the entries sit 16+ columns from their predecessor in the row (a 5-point stencil: 40 %, 7-point: 57 %, 9-point: 33 %; columns drawn
+        // anywhere inside a band: 97 %) the matrix is gather-bound and none of the stencil kernels below is right for it -- 6 / 9 entries per
+        // row exactly, columns anywhere in +-2000: csr_wave / V = 1 tiles 161-167 us (f64), 94-95 (f32), where the general rule further down
+        // (wave tiles V = 4, with the x window) gets 120-138 and 70-85 (profiles/r04_auto_regret_equal_lengths.txt).  Without the columns
+        // the lengths decide, as before.
+        bool gather_bound = false;
         if (st == CMI_SUCCESS && auto_kernel && !want_partition && !want_wavev && !want_waver && csr_columns && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
+            wave_tiles_fit(num_rows, num_entries, p->prof.max_len)) {
+            int64_t inside = 0, jumps = 0;
+            st = measure_column_locality(num_rows, num_cols, index_array, csr_columns, 1536, s, &inside, &jumps);
+            gather_bound = st == CMI_SUCCESS && (double)jumps >= 0.75 * (double)num_entries;
+        }
+        if (st == CMI_SUCCESS && !gather_bound && auto_kernel && !want_partition && !want_wavev && !want_waver && csr_columns && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
             wave_tiles_fit(num_rows, num_entries, p->prof.max_len) && waver_try(p, index_array, csr_columns, false, 0, 0, false, nullptr, s, &st)) {
             // stencil rows of 8+ entries whose columns come in runs (9-point: three runs of 3) and a plan made with the columns: the
             // run-compressed copy, tried BEFORE csr_wave (waver_try's own gates: the table's rule; pieces shorter than it asks -> nothing
             // is kept and csr_wave below runs).  9-point 3000^2: 143.9 us against csr_wave's 187.1 (f64), 89.8 against 134.0 (f32),
             // profiles/r04_auto_regret.txt -- until then every stencil-like matrix took csr_wave unseen.
-        } else if (st == CMI_SUCCESS && auto_kernel && !want_partition && !want_wavev && !want_waver && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
+        } else if (st == CMI_SUCCESS && !gather_bound && auto_kernel && !want_partition && !want_wavev && !want_waver && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
                    wave_tiles_fit(num_rows, num_entries, p->prof.max_len) && stencil_vector_tiles(num_entries, p->prof, dtype, vbytes) > 0) {
             // stencil rows of 5..8 entries beyond the Infinity Cache: wave tiles of 256 (f64) / 512 (f32) entries on a plan-built partition
             // (8 bytes per tile), entries fetched as 16-byte vectors (csr_wavev, V = 1 / 2) -- see stencil_vector_tiles above
@@ -523,7 +536,7 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
                 p->cfg.nontemporal &= ~kPolStrided;
                 p->cfg.nontemporal |= kPolLoadNT | kPolStoreNT; // (beyond the cache by the rule: every line of the streams is requested once)
             }
-        } else if (st == CMI_SUCCESS && auto_kernel && !want_wavev && !want_waver && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
+        } else if (st == CMI_SUCCESS && !gather_bound && auto_kernel && !want_wavev && !want_waver && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
             wave_tiles_fit(num_rows, num_entries, p->prof.max_len)) {
             p->cfg.kernel = CMI_CSR_STREAM_WAVE;
             p->cfg.block_size = 256;

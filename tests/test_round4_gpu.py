@@ -564,3 +564,29 @@ def test_stencil_rows_by_the_regret_runs_rules(cmi, torch_cuda, orc):
         y = torch.full((N,), 3.0, dtype=tdt, device="cuda")
         cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
         assert np.array_equal(y.cpu().numpy(), want), tag
+
+
+def test_equal_row_lengths_are_a_stencil_only_if_the_columns_say_so(cmi, torch_cuda, orc):
+    """6 entries in every row, columns drawn anywhere inside +-2000 of the diagonal: by its LENGTHS a stencil, by its columns a gather-bound
+    band matrix.  A plan made with the columns sees that (97 % of the entries jump 16+ columns from their predecessor; a 7-point stencil:
+    57 %) and takes the general rule's wave tiles (V = 4, with the x window) instead of a stencil kernel; a plan made from the row offsets
+    alone cannot know and keeps the lengths' verdict.  Same bits either way (profiles/r04_auto_regret_equal_lengths.txt: 1.28-1.35 x faster)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(33)
+    rows, k = 6_000_000, 6
+    Ap = (np.arange(rows + 1, dtype=np.int64) * k).astype(np.int32)
+    base = np.repeat(np.arange(rows, dtype=np.int64), k)
+    Aj = np.sort(np.clip(base + rng.integers(-2000, 2001, size=rows * k), 0, rows - 1).reshape(rows, k), axis=1).reshape(-1).astype(np.int32)
+    Ax = rng.standard_normal(rows * k)
+    x = rng.standard_normal(rows)
+    want = orc.spmv_csr(Ap, Aj, Ax, x)
+    dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+    with_columns = cmi.Plan.csr(torch.float64, rows, rows, dAp, dAj)
+    offsets_only = cmi.Plan(cmi.FORMAT_CSR, torch.float64, rows, rows, rows * k, dAp)
+    cw, co = with_columns.config(), offsets_only.config()
+    assert cw.kernel in (cmi.CSR_STREAM_WAVEX, cmi.CSR_STREAM_WAVEV) and cw.items_per_thread == 4, cw
+    assert (co.kernel, co.items_per_thread) == (cmi.CSR_STREAM_WAVEV, 1), co
+    for plan in (with_columns, offsets_only):
+        y = torch.full((rows,), 4.0, dtype=torch.float64, device="cuda")
+        cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
+        assert np.array_equal(y.cpu().numpy(), want)

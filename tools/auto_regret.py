@@ -82,6 +82,17 @@ def matrices():
     sk[rng.integers(0, 2_000_000, size=8)] = 1_000_000
     out.append(("8 rows of 10^6 in 2 M rows of 6", lambda sk=sk: lens_csr(sk, 4, spread=1)))
     out.append(("poisson(10) lengths, columns anywhere (scattered)", lambda: scattered_csr(3_000_000, 10, 5)))
+    def fixed_len(rows, k, span, seed):
+        r = np.random.default_rng(seed)
+        Ap = (np.arange(rows + 1, dtype=np.int64) * k).astype(np.int32)
+        base = np.repeat(np.arange(rows, dtype=np.int64), k)
+        Aj = (r.integers(0, rows, size=rows * k) if span is None else np.clip(base + r.integers(-span, span + 1, size=rows * k), 0, rows - 1))
+        Aj = np.sort(Aj.reshape(rows, k), axis=1).reshape(-1).astype(np.int32)
+        return Ap, Aj, r.standard_normal(rows * k)
+    # equal row lengths WITHOUT a stencil's columns: the stencil rules see only the lengths
+    out.append(("6 per row exactly, columns anywhere (scattered)", lambda: fixed_len(6_000_000, 6, None, 61)))
+    out.append(("6 per row exactly, columns anywhere in +-2000", lambda: fixed_len(6_000_000, 6, 2000, 62)))
+    out.append(("9 per row exactly, columns anywhere in +-2000", lambda: fixed_len(4_000_000, 9, 2000, 63)))
     out.append(("poisson5pt 1000^2 (cache-resident)", lambda: at.stencil_csr(1000, 1000, 1, [(0, -1, 0, -1.0), (-1, 0, 0, -1.0), (0, 0, 0, 4.0), (1, 0, 0, -1.0), (0, 1, 0, -1.0)], np.float64)))
     return out
 
