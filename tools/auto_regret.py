@@ -97,6 +97,34 @@ def matrices():
     return out
 
 
+def matrices2():
+    """the second set (session 34): sizes INSIDE the Infinity Cache (the rules have size gates), very short rows, rows of 12..44 without runs,
+    long rows, a rectangular matrix"""
+    rng = np.random.default_rng(505)
+    out = []
+    out.append(("7-point 100^3 (84 MB: cache-resident)", lambda: at.stencil_csr(100, 100, 100, at.stencil_points(7), np.float64)))
+    out.append(("27-point 80^3 (166 MB: cache-resident)", lambda: at.stencil_csr(80, 80, 80, at.stencil_points(27), np.float64)))
+    out.append(("ldoor-like x0.3 (cache-resident)", lambda: ssl.load("ldoor", 0.3)[:3]))
+    out.append(("nlpkkt120-like x0.15 (cache-resident)", lambda: ssl.load("nlpkkt120", 0.15)[:3]))
+    out.append(("poisson(16) lengths, columns anywhere in +-2000, 1 M rows (cache-resident)", lambda: at.synthetic_csr(1_000_000, 1_000_000, 16, 23, np.float64)))
+    out.append(("bidiagonal 2 x 10^7", lambda: at.stencil_csr(20_000_000, 1, 1, [(0, 0, 0, 2.0), (1, 0, 0, -1.0)], np.float64)))
+    out.append(("random lengths 1..4, stride-3 columns, 12 M rows", lambda: lens_csr(rng.integers(1, 5, size=12_000_000), 6)))
+    out.append(("uniform 10..40, stride-3 columns, 1.5 M rows", lambda: lens_csr(rng.integers(10, 41, size=1_500_000), 7)))
+    out.append(("uniform 20..60, stride-1 columns (one run per row), 1 M rows", lambda: lens_csr(rng.integers(20, 61, size=1_000_000), 8, spread=1)))
+    out.append(("uniform 100..300, stride-3 columns, 200 k rows", lambda: lens_csr(rng.integers(100, 301, size=200_000), 9)))
+    out.append(("uniform 400..1200, stride-1 columns, 50 k rows", lambda: lens_csr(rng.integers(400, 1201, size=50_000), 10, spread=1)))
+
+    def rectangular():
+        rows, cols, k = 8_000_000, 500_000, 5
+        r = np.random.default_rng(11)
+        Ap = (np.arange(rows + 1, dtype=np.int64) * k).astype(np.int32)
+        centre = np.repeat(np.arange(rows, dtype=np.int64) * cols // rows, k)
+        Aj = np.sort(np.clip(centre + r.integers(-30, 31, size=rows * k), 0, cols - 1).reshape(rows, k), axis=1).reshape(-1).astype(np.int32)
+        return Ap, Aj, r.standard_normal(rows * k)
+    out.append(("rectangular 8 M x 500 k, 5 per row near the scaled diagonal", rectangular))
+    return out
+
+
 def time_us(go, settle_s=0.05, budget_s=0.25):
     """median of 5 groups; group size from a first probe so that slow candidates (csr_scalar on skewed rows: 100 ms+) stay bounded"""
     go()
@@ -147,11 +175,12 @@ def main():
     ap.add_argument("--dtypes", default="f64,f32")
     ap.add_argument("--only", default="")
     ap.add_argument("--log", default="")
+    ap.add_argument("--set", type=int, default=1)
     args = ap.parse_args()
     log = open(args.log, "w") if args.log else None
     only = [s for s in args.only.split(",") if s]
     summary = []
-    for name, build in matrices():
+    for name, build in (matrices() if args.set == 1 else matrices2()):
         if only and not any(o in name for o in only):
             continue
         t0 = time.time()
