@@ -191,7 +191,7 @@ static bool wavev_auto(int64_t rows, int64_t nnz, const row_profile &prof, int v
     (void)prof;
     if (v != 4 || rows < 4096) return false;
     const double mean = (double)nnz / (double)rows;
-    if (mean < 2.5 || mean >= 44.0) return false;
+    if (mean < 2.0 || mean >= 44.0) return false; // (2.0: until session 35 of round 4 2.5 -- rows of 1..4, mean 2.4999: 84.5 against 102.7 us, r04_auto_regret_set2_before.txt)
     return nnz * (int64_t)(sizeof(int) + vbytes) > kInfinityCacheBytes / 4 * 3;
 }
 // What a plan made with the column indices (cmi_plan_create_csr) adds: where the columns of a row lie.  `jumps` = share of entries 16+
@@ -220,6 +220,20 @@ static bool short_f64_rows(int64_t rows, int64_t nnz, const row_profile &prof, i
     if (env == 0) return false;
     const double mean = (double)nnz / (double)rows;
     return mean >= 2.5 && mean < 8.0 && 2 * (prof.max_len + 3) <= 256;
+}
+// Round 4, session 35 (the regret table's sets 2 and 3, profiles/r04_auto_regret_set2_before.txt, r04_auto_regret_set3_size_gate.txt): on
+// GATHER-BOUND band matrices (columns anywhere inside +-2000: every entry its own L1 lookup) the wave tiles win INSIDE the cache too --
+// poisson(16) row lengths, 16 M entries: 47.0 against 53.5-56.3 us (f64), 29.0 against 33.7-40.5 (f32); 8 M: 26.5-28.1 against 29.0-30.6
+// and 16.6-18.2 against 19.3-23.3; f32 at 4 M: 9.3-10.6 against 10.7-14.0; f64 at 4 M a tie -- where the size gate above (streams beyond
+// 0.75 x the cache: made for rows whose columns share x lines, which lose or tie below it) keeps them out.  Such a matrix is admitted
+// from 8 M entries (f64) / 4 M (f32) when its column profile says so (the caller measures it: plans made with the columns only); there
+// the plain tiles do best, f64 with V = 2, f32 with V = 4 -- the x window pays only beyond the cache.
+static bool band_candidate(int64_t rows, int64_t nnz, const row_profile &prof, int dtype, bool have_columns)
+{
+    if (!have_columns || rows < 4096 || nnz <= 0 || prof.max_len < 1 || prof.in_long > 0 || wavev_env() == 0) return false;
+    const double mean = (double)nnz / (double)rows;
+    const int v = dtype == CMI_F64 ? 2 : 4;
+    return mean >= 2.0 && mean < 44.0 && nnz >= (dtype == CMI_F64 ? 8000000 : 4000000) && 2 * (prof.max_len + 3) <= 256 * v;
 }
 static int wavev_vectors(int64_t rows, int64_t nnz, const row_profile &prof, bool asked, int asked_v, size_t vbytes)
 {
@@ -561,12 +575,15 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
             st = fail(CMI_ERROR_INVALID_VALUE, "cmi_plan_create: CMI_CSR_STREAM_WAVER / _PACKED need f64 values, 2 <= columns < 2^30, items_per_thread 0, 1, 2 or 4, no row of 512+ entries and the longest row at most half of the 256 x items_per_thread slots of a wave tile");
         } else if (st == CMI_SUCCESS && auto_kernel && !want_partition && p->cfg.kernel == CMI_CSR_STREAM && p->cfg.threads_per_row <= 1 &&
                    (wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v, vbytes) > 0 ||
-                    short_f64_rows(num_rows, num_entries, p->prof, dtype, csr_columns != nullptr && !want_wavev))) { // (a caller who asked for csr_wave on a partition gets that)
+                    short_f64_rows(num_rows, num_entries, p->prof, dtype, csr_columns != nullptr && !want_wavev) ||
+                    band_candidate(num_rows, num_entries, p->prof, dtype, csr_columns != nullptr && !want_wavev))) { // (a caller who asked for csr_wave on a partition gets that)
             int v = wavev_vectors(num_rows, num_entries, p->prof, want_wavev, wavev_v, vbytes);
-            // v == 0 here: only the short-row rule of round 4 admitted this (cache-resident) matrix -- it runs wave tiles with V = 1 if its
-            // columns share x lines, else nothing changes
-            const bool short_only = v == 0;
-            if (short_only) v = 1;
+            // v == 0 here: only the rules of round 4 for CACHE-RESIDENT matrices admitted this one -- f64 rows of fewer than 8 entries whose
+            // columns share x lines run wave tiles with V = 1, gather-bound band matrices V = 2 (f64) / 4 (f32); else nothing changes
+            const bool small_only = v == 0;
+            const bool short_rule = small_only && short_f64_rows(num_rows, num_entries, p->prof, dtype, csr_columns != nullptr && !want_wavev);
+            const bool band_rule = small_only && band_candidate(num_rows, num_entries, p->prof, dtype, csr_columns != nullptr && !want_wavev);
+            if (small_only) v = 1;
             bool auto_wavex = false, keep_stream = false;
             if (!want_wavev) { // an AUTO plan: refine by the value type and -- made with the columns -- by where the columns lie
                 const double mean = (double)num_entries / (double)num_rows;
@@ -577,8 +594,9 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
                     if (st == CMI_SUCCESS) { cp.inside = (double)inside / (double)num_entries; cp.jumps = (double)jumps / (double)num_entries; }
                 }
                 const char *wx = std::getenv("CMI_CSR_WAVEX");
-                if (short_only) {
-                    if (!(cp.jumps >= 0.0 && cp.jumps < 0.5)) keep_stream = true;
+                if (small_only) {
+                    if (band_rule && cp.jumps >= 0.6 && cp.inside >= 0.25) v = dtype == CMI_F64 ? 2 : 4; // (plain tiles: no window inside the cache)
+                    else if (!(short_rule && cp.jumps >= 0.0 && cp.jumps < 0.5)) keep_stream = true;
                 } else if (cp.jumps >= 0.6 && cp.inside >= 0.25 && !(wx && wx[0] == '0')) {
                     auto_wavex = true;
                     wavex_window = (dtype == CMI_F32 && mean >= 15.0) ? 4096 : 2048;

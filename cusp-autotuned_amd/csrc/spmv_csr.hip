@@ -1345,8 +1345,12 @@ bool prefers_balanced(int64_t rows, int64_t nnz, const row_profile &pr, size_t v
     const double floor_us = 20.0; // launch + latency floor of any multiply
     if ((double)pr.max_len * (strict_order ? kSerialRowUs : kLongRowUs) > (stream_us > floor_us ? stream_us : floor_us)) return true;
     // a heavy tail: when a quarter of the entries sit in long rows, one workgroup per long row is the slower split
-    // (measured: 2000 rows of 2e4 among 2M short ones, power-law lengths; tools/irregular_probe.py)
-    return pr.in_long * 4 > nnz && stream_us > floor_us;
+    // (measured: 2000 rows of 2e4 among 2M short ones, power-law lengths; tools/irregular_probe.py) -- a TAIL, though: rows that are all
+    // long (400..1200 each, 50 000 of them) are what the table's lane-group shapes of the row-tile kernel are for: 95.4 / 76.4 us (f64 / f32)
+    // plan-less against 131.2 / 118.5 through a plan that turned them over to the merge-path kernel (and csr_vector T = 64: 116.4 / 94.2),
+    // profiles/r04_auto_regret_set2_before.txt.  So: only where the longest row is 16+ times the mean.
+    const double mean = rows > 0 ? (double)nnz / (double)rows : 0.0;
+    return pr.in_long * 4 > nnz && stream_us > floor_us && (double)pr.max_len > 16.0 * mean;
 }
 
 // ---------------------------------------------------------------------------------------------

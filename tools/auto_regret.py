@@ -125,6 +125,17 @@ def matrices2():
     return out
 
 
+def matrices3():
+    """the third set (session 35): where is the size gate of the wave tiles on GATHER-BOUND band matrices?  (set 2 had them winning by 12-40 %
+    at 16 M entries, inside the cache, where the rule of round 3 -- streams beyond 0.75 x the cache -- does not admit them)"""
+    out = []
+    for mean in (8, 16, 32):
+        for entries in (2_000_000, 4_000_000, 8_000_000, 12_000_000):
+            rows = entries // mean
+            out.append((f"poisson({mean}) lengths, columns anywhere in +-2000, {entries // 1_000_000} M entries", lambda rows=rows, mean=mean: at.synthetic_csr(rows, rows, mean, 100 + mean, np.float64)))
+    return out
+
+
 def time_us(go, settle_s=0.05, budget_s=0.25):
     """median of 5 groups; group size from a first probe so that slow candidates (csr_scalar on skewed rows: 100 ms+) stay bounded"""
     go()
@@ -180,7 +191,7 @@ def main():
     log = open(args.log, "w") if args.log else None
     only = [s for s in args.only.split(",") if s]
     summary = []
-    for name, build in (matrices() if args.set == 1 else matrices2()):
+    for name, build in (matrices() if args.set == 1 else matrices2() if args.set == 2 else matrices3()):
         if only and not any(o in name for o in only):
             continue
         t0 = time.time()
