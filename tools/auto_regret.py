@@ -136,6 +136,60 @@ def matrices3():
     return out
 
 
+def matrices4():
+    """the fourth set (session 37): column runs of other lengths (2 / 6 dof per node, pairs, dense blocks), 50..90 entries per row with and
+    without runs, an arrow matrix, a stencil with holes, a small FEM mesh"""
+    rng = np.random.default_rng(707)
+    out = []
+    out.append(("9-point 1500^2 x 2 dof (18 per row, runs of 6)", lambda: at.block_expand(*at.stencil_csr(1500, 1500, 1, at.stencil_points(9), np.float64), 2, np.float64)))
+    out.append(("5-point 2200^2 x 2 dof (10 per row, runs of 2 / 6)", lambda: at.block_expand(*at.stencil_csr(2200, 2200, 1, [(0, -1, 0, -1.0), (-1, 0, 0, -1.0), (0, 0, 0, 4.0), (1, 0, 0, -1.0), (0, 1, 0, -1.0)], np.float64), 2, np.float64)))
+    out.append(("27-point 40^3 x 6 dof (162 per row, runs of 18)", lambda: at.block_expand(*at.stencil_csr(40, 40, 40, at.stencil_points(27), np.float64), 6, np.float64)))
+    out.append(("uniform 50..90, stride-3 columns, 600 k rows", lambda: lens_csr(rng.integers(50, 91, size=600_000), 21)))
+    out.append(("uniform 50..90, stride-1 columns (one run per row), 600 k rows", lambda: lens_csr(rng.integers(50, 91, size=600_000), 22, spread=1)))
+
+    def pairs():
+        rows, k = 2_500_000, 16
+        Ap = (np.arange(rows + 1, dtype=np.int64) * k).astype(np.int32)
+        base = np.repeat(np.arange(rows, dtype=np.int64), k) + np.tile((np.arange(k) // 2 - 4) * 50 + np.arange(k) % 2, rows)
+        return Ap, np.clip(base, 0, rows - 1).astype(np.int32), np.random.default_rng(23).standard_normal(rows * k)
+    out.append(("16 per row as 8 pairs of neighbours 50 apart (runs of 2)", pairs))
+
+    def dense_blocks():
+        b, nb = 32, 40_000
+        rows = b * nb
+        Ap = (np.arange(rows + 1, dtype=np.int64) * b).astype(np.int32)
+        Aj = (np.repeat(np.arange(nb, dtype=np.int64) * b, b * b).reshape(nb, b, b) + np.arange(b)[None, None, :]).reshape(-1).astype(np.int32)
+        return Ap, Aj, np.random.default_rng(24).standard_normal(rows * b)
+    out.append(("block-diagonal, dense 32 x 32 blocks (1.28 M rows)", dense_blocks))
+
+    def arrow():
+        n = 4_000_000
+        lens = np.full(n, 5, np.int64)
+        lens[0] = n
+        Ap = np.zeros(n + 1, np.int64)
+        Ap[1:] = np.cumsum(lens)
+        Aj = np.empty(int(Ap[-1]), np.int32)
+        Aj[:n] = np.arange(n)
+        r = np.arange(1, n, dtype=np.int64)
+        body = np.stack([np.zeros(n - 1, np.int64), np.clip(r - 1, 0, n - 1), r, np.clip(r + 1, 0, n - 1), np.clip(r + 2, 0, n - 1)], axis=1)
+        Aj[n:] = body.reshape(-1)
+        return Ap.astype(np.int32), Aj, np.random.default_rng(25).standard_normal(int(Ap[-1]))
+    out.append(("arrow: 4 M rows of 5 under one dense row", arrow))
+
+    def holes():
+        Ap, Aj, Ax = at.stencil_csr(200, 200, 200, at.stencil_points(7), np.float64)
+        keep = np.random.default_rng(26).random(len(Aj)) > 0.12
+        row = np.repeat(np.arange(len(Ap) - 1), np.diff(Ap))
+        keep |= Aj == row                                   # the diagonal stays
+        lens = np.bincount(row[keep], minlength=len(Ap) - 1)
+        Ap2 = np.zeros(len(Ap), np.int64)
+        Ap2[1:] = np.cumsum(lens)
+        return Ap2.astype(np.int32), Aj[keep], Ax[keep]
+    out.append(("7-point 200^3 with 12 % of the off-diagonal entries removed", holes))
+    out.append(("thermal2-like x0.3 (37 MB)", lambda: ssl.load("thermal2", 0.3)[:3]))
+    return out
+
+
 def time_us(go, settle_s=0.05, budget_s=0.25):
     """median of 5 groups; group size from a first probe so that slow candidates (csr_scalar on skewed rows: 100 ms+) stay bounded"""
     go()
@@ -191,7 +245,7 @@ def main():
     log = open(args.log, "w") if args.log else None
     only = [s for s in args.only.split(",") if s]
     summary = []
-    for name, build in (matrices() if args.set == 1 else matrices2() if args.set == 2 else matrices3()):
+    for name, build in (matrices() if args.set == 1 else matrices2() if args.set == 2 else matrices3() if args.set == 3 else matrices4()):
         if only and not any(o in name for o in only):
             continue
         t0 = time.time()
