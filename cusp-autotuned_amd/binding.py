@@ -664,9 +664,9 @@ def tuning_waver_rule(dtype):
     return r
 
 
-def tuning_set_waver_rule(dtype, items_per_thread=4, cap=0, xcd_swizzle=16, min_piece=2.5, min_entries=None):
+def tuning_set_waver_rule(dtype, items_per_thread=4, cap=0, xcd_swizzle=16, min_piece=None, min_entries=None):
     """layer a csr_waver rule on the table (tools/autotune_waver.py writes it; tuning_save persists it)"""
-    r = WaverRule(int(items_per_thread), int(cap), int(xcd_swizzle), 0, float(min_piece),
+    r = WaverRule(int(items_per_thread), int(cap), int(xcd_swizzle), 0, float((2.2 if dtype == F64 else 1.9) if min_piece is None else min_piece),
                   int((4_400_000 if dtype == F64 else 6_400_000) if min_entries is None else min_entries))
     check(lib().cmi_tuning_set_waver_rule(dtype, byref(r)))
 

@@ -269,6 +269,9 @@ static bool waver_try(cmi_plan *p, const int *Ap, const int *Aj, bool asked, int
     cmi_waver_rule rule; // the persisted shape / gates (tuning table "waver_rule": tools/autotune_waver.py), else the built-in ones
     waver_rule(p->dtype, &rule);
     int v = asked_v ? asked_v : rule.items_per_thread;
+    // (f64 rows of fewer than 12 entries: tiles of 512 slots, as for the plain wave tiles -- 5-point x 2 dof, 10 per row: 190.6 against
+    //  211.3 us with V = 4; 9-point 143.7 against 144.4; in f32 V = 4 is ahead there, 125.1 against 133.1: r04_auto_regret_set4_before.txt)
+    if (!asked && !asked_v && p->dtype == CMI_F64 && p->rows > 0 && (double)p->nnz < 12.0 * (double)p->rows && v == 4) v = 2; // (AUTO plans: an asked-for plan keeps the table's V)
     if (v != 1 && v != 2 && v != 4) return false;
     while (v < 4 && !asked_v && 2 * (p->prof.max_len + 3) > 256 * v) v *= 2;
     if (2 * (p->prof.max_len + 3) > 256 * v) return false;
@@ -604,7 +607,9 @@ static int plan_create(int format, int dtype, int64_t num_rows, int64_t num_cols
                     keep_stream = true; // columns scattered over the whole vector: 0.08-0.11 of peak whatever runs; wave tiles 0.97-1.06x
                 } else if (dtype == CMI_F32 && mean >= 16.0 && cp.jumps < 0.5) {
                     keep_stream = true; // f32 stencil / FEM-block rows of 16+ entries (or unknown columns): the table's csr_stream is 5-6 % faster
-                } else if (mean < 12.0 && cp.jumps >= 0.0 && cp.jumps < 0.5) {
+                } else if (mean < 12.0 && cp.jumps >= 0.0 && cp.jumps < (dtype == CMI_F64 ? 0.6 : 0.5)) {
+                    // (f64 up to 0.6 since session 38: a 7-point stencil with 12 % of its entries removed -- rows of 1..7, 57 % jumps -- 118.3 us
+                    //  with V = 1 against 127.0 with V = 4; in f32 V = 4 stays ahead there, 88.5 against 90.2 / 92.5)
                     // short rows whose columns share x lines: smaller tiles.  f64 rows of fewer than 8 entries, none longer than 16: V = 1
                     // (thermal2-like 20.4 / 63.4 us against 21.5 / 67.3 with V = 2); otherwise V = 2 -- against V = 4 (what every AUTO plan
                     // ran until the regret run of round 4, profiles/r04_auto_regret.txt): uniform 1..16 per row 74.9 against 78.3 us (f64) and

@@ -43,7 +43,10 @@ static cmi_waver_rule default_waver_rule(int dtype)
     r.cap = 0;
     r.xcd_swizzle = 16;
     r.reserved = 0;
-    r.min_piece = 2.5;
+    // pieces of consecutive columns, entries on average: 2.5 until session 38 of round 4 -- then the regret table's fourth set had the copy
+    // ahead at exactly 2.5 (5-point x 2 dof: -14 % f64, -22 % f32, missed by boundary rows) and at 2.0 in f32 (pairs of neighbours: -14 %;
+    // f64 there +4 %), behind at 1.4-1.7 (5- / 7-point stencils)
+    r.min_piece = dtype == CMI_F64 ? 2.2 : 1.9;
     r.min_entries = dtype == CMI_F64 ? 4400000 : 6400000; // (r04_autotune_waver.txt: the copy wins by 2 %+ on every measured matrix from here up)
     return r;
 }

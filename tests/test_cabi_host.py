@@ -324,8 +324,8 @@ def test_waver_rule_in_the_table(cmi, tmp_path):
     parameter space (reference cuda/ktt/csr_multiply.h:239-247) settled offline; without one, the built-in rule."""
     cmi.tuning_clear()
     r = cmi.tuning_waver_rule(cmi.F64)
-    assert r.as_dict() == {"items_per_thread": 4, "cap": 0, "xcd_swizzle": 16, "min_piece": 2.5, "min_entries": 4_400_000}
-    assert cmi.tuning_waver_rule(cmi.F32).min_entries == 6_400_000
+    assert r.as_dict() == {"items_per_thread": 4, "cap": 0, "xcd_swizzle": 16, "min_piece": 2.2, "min_entries": 4_400_000}
+    assert cmi.tuning_waver_rule(cmi.F32).min_entries == 6_400_000 and cmi.tuning_waver_rule(cmi.F32).min_piece == 1.9
     cmi.tuning_set_waver_rule(cmi.F32, items_per_thread=2, cap=3, xcd_swizzle=0, min_piece=3.0, min_entries=1234)
     for bad in (dict(items_per_thread=3), dict(cap=2), dict(xcd_swizzle=-1), dict(min_piece=0.5), dict(min_entries=-1)):
         with pytest.raises(cmi.CmiError):
