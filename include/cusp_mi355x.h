@@ -188,7 +188,7 @@ typedef enum cmi_kernel {
                                KKT / 27-point matrices keep their columns in runs of 3 or more, so the index stream shrinks to about a third
                                (f64: 9.3-9.4 instead of 12 bytes per entry; f32: 5.3-5.4 instead of 8) and a piece's x values arrive with two
                                16-byte loads (f32: one) instead of one gather per entry.  The VALUES stay the caller's array (refreshing them in place is fine).  Same products,
-                               storage-order sums: bit-exact.  An AUTO plan made with the columns selects it when the pieces average 2.5+
+                               storage-order sums: bit-exact.  An AUTO plan made with the columns selects it when the pieces average 2.2+ (f64) / 1.9+ (f32)
                                entries on a matrix the tuning table's "waver_rule" admits (cmi_tuning_waver_rule; also stencil rows of 8+ entries
                                with column runs -- 9-point -- where it is tried before CMI_CSR_STREAM_WAVE) ($CMI_CSR_WAVER=0: never, =1: whenever the rows
                                qualify); asked for explicitly it is refused only where the tile cannot hold the longest row.  items_per_thread
