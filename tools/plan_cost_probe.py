@@ -47,6 +47,7 @@ def mult_us(fn, iters=200):
 
 rows = [
     ("CSR (row-length profile)", lambda: cmi.Plan(cmi.FORMAT_CSR, torch.float64, N, N, nnz, A.row_offsets), lambda: cmi.multiply(A, x, y)),
+    ("CSR with the columns (what the containers make: + partition, + a look at the columns)", lambda: cmi.Plan.csr(torch.float64, N, N, A.row_offsets, A.column_indices), lambda: cmi.multiply(A, x, y)),
     ("CSR + 16-bit column copy", lambda: cmi.Plan.csr(torch.float64, N, N, A.row_offsets, A.column_indices, cfg=cmi.Config(kernel=cmi.CSR_STREAM_C16)), None),
     ("COO sorted (row offsets + CSR sub-plan)", lambda: cmi.Plan(cmi.FORMAT_COO, torch.float64, N, N, nnz, C.row_indices), lambda: cmi.multiply(C, x, y)),
     ("HYB K=4 (order check + tile ranges)", lambda: cmi.Plan.hyb(torch.float64, N, N, 4, H.coo.row_indices), lambda: cmi.multiply(H, x, y)),
