@@ -590,3 +590,56 @@ def test_equal_row_lengths_are_a_stencil_only_if_the_columns_say_so(cmi, torch_c
         y = torch.full((rows,), 4.0, dtype=torch.float64, device="cuda")
         cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
         assert np.array_equal(y.cpu().numpy(), want)
+
+
+def test_auto_rules_from_the_later_regret_sets(cmi, torch_cuda, orc):
+    """The rules that the regret table's sets 2-4 led to, pinned by what the AUTO plan selects -- and by the oracle's bits /
+    bounds: rows that are ALL long keep the row-tile kernel (the merge-path kernel is for a TAIL of long rows); rows of 1..4 take wave
+    tiles (mean >= 2); a gather-bound band matrix INSIDE the cache takes the plain wave tiles (f64 V = 2, f32 V = 4); the run-compressed
+    copy from 2.2 / 1.9 entries per piece (5-point x 2 dof: exactly 2.5 but for the boundary rows), with V = 2 on short f64 rows."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import autotune as at
+    torch = torch_cuda
+    rng = np.random.default_rng(41)
+
+    def stride_csr(lens, spread):
+        lens = np.asarray(lens, np.int64)
+        rows = len(lens)
+        Ap = np.zeros(rows + 1, np.int64)
+        Ap[1:] = np.cumsum(lens)
+        row = np.repeat(np.arange(rows, dtype=np.int64), lens)
+        j = np.arange(int(Ap[-1]), dtype=np.int64) - Ap[:-1][row]
+        col = np.clip(row + (j - lens[row] // 2) * spread, 0, rows - 1)
+        return Ap.astype(np.int32), col.astype(np.int32), rng.standard_normal(int(Ap[-1]))
+
+    def run(name, Ap, Aj, Ax, tdt, expect, exact=True):
+        ndt = np.float64 if tdt == torch.float64 else np.float32
+        rows = len(Ap) - 1
+        Ax = Ax.astype(ndt)
+        x = rng.standard_normal(rows).astype(ndt)
+        dAp, dAj, dAx, dx = dev(Ap, torch), dev(Aj, torch), dev(Ax, torch), dev(x, torch)
+        plan = cmi.Plan.csr(tdt, rows, rows, dAp, dAj)
+        c = plan.config()
+        assert expect(c), (name, c)
+        y = torch.full((rows,), 6.0, dtype=tdt, device="cuda")
+        cmi.spmv_csr_plan(plan, dAp, dAj, dAx, dx, y)
+        want = orc.spmv_csr(Ap, Aj, Ax, x)
+        if exact:
+            assert plan.info()["storage_order_sums"] is True and np.array_equal(y.cpu().numpy(), want), name
+        else:   # lane groups add a long row: the 1e-6 class (|dy| <= 1e-6 sum |a_ij x_j|)
+            bound = orc.spmv_csr(Ap, Aj, np.abs(Ax), np.abs(x))
+            assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - want) <= (1e-6 if ndt == np.float64 else 1e-4) * bound + 1e-300), name
+
+    Ap, Aj, Ax = stride_csr(rng.integers(400, 1201, size=20_000), 1)
+    run("all rows 400..1200 long", Ap, Aj, Ax, torch.float64, lambda c: c.kernel == cmi.CSR_STREAM and c.threads_per_row > 1, exact=False)
+    Ap, Aj, Ax = stride_csr(rng.integers(1, 5, size=12_000_000), 3)
+    assert Ap[-1] / 12_000_000 < 2.55
+    run("rows of 1..4", Ap, Aj, Ax, torch.float64, lambda c: (c.kernel, c.items_per_thread) == (cmi.CSR_STREAM_WAVEV, 1))   # (f64 rows of < 8, none longer than 16: V = 1)
+    del Ap, Aj, Ax
+    Ap, Aj, Ax = at.synthetic_csr(1_000_000, 1_000_000, 16, 23, np.float64)        # 16 M entries: inside the cache in both value types
+    run("band matrix inside the cache, f64", Ap, Aj, Ax, torch.float64, lambda c: (c.kernel, c.items_per_thread) == (cmi.CSR_STREAM_WAVEV, 2))
+    run("band matrix inside the cache, f32", Ap, Aj, Ax, torch.float32, lambda c: (c.kernel, c.items_per_thread) == (cmi.CSR_STREAM_WAVEV, 4))
+    Ap, Aj, Ax = at.block_expand(*at.stencil_csr(1200, 1200, 1, [(0, -1, 0, -1.0), (-1, 0, 0, -1.0), (0, 0, 0, 4.0), (1, 0, 0, -1.0), (0, 1, 0, -1.0)], np.float64), 2, np.float64)
+    run("5-point x 2 dof, f64", Ap, Aj, Ax, torch.float64, lambda c: (c.kernel, c.items_per_thread) == (cmi.CSR_STREAM_WAVER, 2))
+    run("5-point x 2 dof, f32", Ap, Aj, Ax, torch.float32, lambda c: (c.kernel, c.items_per_thread) == (cmi.CSR_STREAM_WAVER, 4))
