@@ -32,6 +32,8 @@ MATS = {
     "5pt32": ("poisson5pt 3162^2 f32", lambda: at.stencil_csr(3162, 3162, 1, P5, np.float64), torch.float32),
     "7pt": ("7-point 215^3 f64", lambda: at.stencil_csr(215, 215, 215, at.stencil_points(7), np.float64), torch.float64),
     **{f"5pt_{m}": (f"poisson5pt {m}^2 f64", (lambda m=m: at.stencil_csr(m, m, 1, P5, np.float64)), torch.float64) for m in (1500, 2000, 2400, 2800)},  # the rule's size gate
+    "5pt_10000x1250": ("poisson5pt 10000 x 1250 f64 (configs[4]'s rank block as a square matrix: same rows, same band, x of 1.25e7)", lambda: at.stencil_csr(10000, 1250, 1, P5, np.float64), torch.float64),
+    "5pt_1250x10000": ("poisson5pt 1250 x 10000 f64 (the same rows with a band of 1250)", lambda: at.stencil_csr(1250, 10000, 1, P5, np.float64), torch.float64),
     "7pt32": ("7-point 215^3 f32", lambda: at.stencil_csr(215, 215, 215, at.stencil_points(7), np.float64), torch.float32),
     "9pt": ("9-point 3000^2 f64", lambda: at.stencil_csr(3000, 3000, 1, at.stencil_points(9), np.float64), torch.float64),
     "9pt32": ("9-point 3000^2 f32", lambda: at.stencil_csr(3000, 3000, 1, at.stencil_points(9), np.float64), torch.float32),
